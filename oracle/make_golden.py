@@ -1,0 +1,157 @@
+"""Generate tests/golden/* from the REAL reference (build container only).
+
+Test infrastructure (see oracle/__init__.py).  Run:  ``python -m oracle.make_golden``
+
+The reference holds no golden vectors for this path, so the fixtures are outputs of
+the unmodified reference (``/root/reference/team_code/model.py::LidarCenterNet``, imported through
+oracle/ref_harness.py) on the deterministic weights / inputs / labels of oracle/tfpp_port.py
+(``make_state_dict``, ``make_inputs``, ``make_labels`` -- all oracle/detrand.py streams, so they are
+reproduced bit-for-bit on the GPU box without shipping 481 MB of weights).
+
+Files written
+  state_dict_schema.json   keys + shapes + dtypes of the reference's state_dict (1332 entries)
+  tfpp_eval_bs1.npz        config 2 (eval forward, bs=1, fp32): all outputs (large maps strided) + checksums
+  tfpp_train_bs2.npz       train-mode forward (dropout 0) + compute_loss + backward, bs=2: the 10 losses,
+                           per-parameter gradient norms and sampled gradient values, BN statistics update
+  tfpp_wp_eval_bs1.npz     WP variant (use_wp_gru=1, use_controller_input_prediction=0): pred_wp
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from oracle import ref_harness, tfpp_port as P
+
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+SEM_STRIDE, BEV_STRIDE, DEPTH_STRIDE = 8, 4, 8
+
+
+def _np(t):
+  return t.detach().cpu().numpy()
+
+
+def pack_outputs(out):
+  """Reduce the 10-tuple to a dict of small arrays (shared with tests/parity_util.py through the same strides)."""
+  d = {}
+  if out[0] is not None:
+    d['pred_wp'] = _np(out[0])
+  if out[1] is not None:
+    d['pred_target_speed'] = _np(out[1])
+  if out[2] is not None:
+    d['pred_checkpoint'] = _np(out[2])
+  sem, bev, dep = _np(out[3]), _np(out[4]), _np(out[5])
+  d['pred_semantic_strided'] = sem[:, :, ::SEM_STRIDE, ::SEM_STRIDE].copy()
+  d['pred_bev_semantic_strided'] = bev[:, :, ::BEV_STRIDE, ::BEV_STRIDE].copy()
+  d['pred_depth_strided'] = dep[:, ::DEPTH_STRIDE, ::DEPTH_STRIDE].copy()
+  for name, a in (('pred_semantic', sem), ('pred_bev_semantic', bev), ('pred_depth', dep)):
+    d[name + '_sum'] = np.array([a.astype(np.float64).sum(), np.abs(a.astype(np.float64)).sum()])
+    d[name + '_rowsum'] = a.astype(np.float64).sum(axis=-1).astype(np.float32)  # catches any mis-placed row
+  for i, name in enumerate(('heatmap', 'wh', 'offset', 'yaw_class', 'yaw_res')):
+    d['bb_' + name] = _np(out[6][i])
+  return d
+
+
+def reference_loss_kwargs(out, lab):
+  return dict(pred_wp=out[0], pred_target_speed=out[1], pred_checkpoint=out[2], pred_semantic=out[3],
+              pred_bev_semantic=out[4], pred_depth=out[5], pred_bounding_box=out[6], pred_wp_1=out[8],
+              selected_path=out[9], **lab)
+
+
+def disable_dropout(model):
+  for mod in model.modules():
+    if isinstance(mod, torch.nn.Dropout):
+      mod.p = 0.0
+    if isinstance(mod, torch.nn.MultiheadAttention):
+      mod.dropout = 0.0
+
+
+GRAD_SAMPLES = 16
+
+
+def sample_idx(n):
+  return np.unique(np.linspace(0, n - 1, GRAD_SAMPLES).astype(np.int64))
+
+
+def main():
+  if not ref_harness.available():
+    sys.exit('needs /root/reference (build container)')
+  os.makedirs(GOLDEN, exist_ok=True)
+  torch.set_num_threads(os.cpu_count())
+
+  # ---- default TF++ ---------------------------------------------------------------------------
+  model, _ = ref_harness.build_reference_model()
+  cfg = P.PortConfig()
+  ref_sd = model.state_dict()
+  schema = [[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in ref_sd.items()]
+  with open(os.path.join(GOLDEN, 'state_dict_schema.json'), 'w', encoding='utf-8') as f:
+    json.dump({'n_trainable': sum(p.numel() for p in model.parameters() if p.requires_grad), 'entries': schema}, f)
+  sd = P.make_state_dict(cfg)
+  model.load_state_dict(sd, strict=True)
+
+  model.eval()
+  inp = P.make_inputs(1, cfg)
+  with torch.inference_mode():
+    out = model(*inp)
+  d = pack_outputs(out)
+  d['weights_checksum'] = np.array([float(v.double().sum()) for v in sd.values()])
+  d['inputs_checksum'] = np.array([float(x.double().sum()) for x in inp])
+  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_eval_bs1.npz'), **d)
+  print('eval bs1:', {k: v.shape for k, v in d.items()})
+
+  # ---- training step (dropout disabled so it is deterministic; BN in train mode) ----------------
+  model.train()
+  disable_dropout(model)
+  inp = P.make_inputs(2, cfg)
+  lab = P.make_labels(2, cfg)
+  out = model(*inp)
+  losses = model.compute_loss(**reference_loss_kwargs(out, lab))
+  w = P.loss_weights(cfg)
+  total = sum(w[k] * v for k, v in losses.items())
+  total.backward()
+  t = {'loss_names': np.array(list(losses.keys())), 'losses': np.array([v.item() for v in losses.values()]),
+       'total_loss': np.array(total.item())}
+  names, norms, samples = [], [], []
+  for k, p in model.named_parameters():
+    if p.grad is None:
+      continue
+    g = p.grad.detach().flatten()
+    names.append(k)
+    norms.append([g.double().norm().item(), g.abs().max().item()])
+    s = np.zeros(GRAD_SAMPLES, np.float32)
+    idx = sample_idx(g.numel())
+    s[:len(idx)] = _np(g[idx])
+    samples.append(s)
+  t['grad_names'] = np.array(names)
+  t['grad_norms'] = np.array(norms)
+  t['grad_samples'] = np.stack(samples)
+  new_sd = model.state_dict()
+  rk = [k for k in new_sd if 'running_' in k]
+  t['running_names'] = np.array(rk)
+  t['running_sums'] = np.array([float(new_sd[k].double().sum()) for k in rk])
+  t.update({'fwd_' + k: v for k, v in pack_outputs(out).items() if k.startswith('bb_') or k.startswith('pred_t') or
+            k.startswith('pred_c') or k.endswith('_sum')})
+  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_train_bs2.npz'), **t)
+  print('train bs2: total', total.item(), {k: float(v) for k, v in losses.items()})
+
+  # ---- WP variant -----------------------------------------------------------------------------
+  del model
+  model, _ = ref_harness.build_reference_model(use_wp_gru=True, use_controller_input_prediction=False)
+  import dataclasses
+  cfgw = dataclasses.replace(cfg, use_wp_gru=True, use_controller_input_prediction=False)
+  sdw = P.make_state_dict(cfgw)
+  model.load_state_dict(sdw, strict=True)
+  model.eval()
+  inp = P.make_inputs(1, cfgw)
+  with torch.inference_mode():
+    out = model(*inp)
+  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_wp_eval_bs1.npz'), pred_wp=_np(out[0]),
+                      bb_heatmap=_np(out[6][0]))
+  print('wp variant: pred_wp', _np(out[0]).shape)
+  for fn in sorted(os.listdir(GOLDEN)):
+    print(fn, os.path.getsize(os.path.join(GOLDEN, fn)))
+
+
+if __name__ == '__main__':
+  main()
