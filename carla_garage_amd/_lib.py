@@ -1,0 +1,146 @@
+"""ctypes binding of ``libtfpp_hip.so`` (C ABI declared in include/tfpp.h).
+
+The binding is generated from the header at import time, so the Python side cannot drift from the declared
+ABI; struct mirrors are verified against ``tfpp_struct_sizes``.  There is NO fallback: if the library is missing
+or fails to load, every op raises (the product path never routes through PyTorch ATen kernels or the CPU oracle).
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+HEADER = os.path.join(ROOT, 'include', 'tfpp.h')
+CSRC = os.path.join(PKG_DIR, 'csrc')
+LIB_PATH = os.path.join(PKG_DIR, 'libtfpp_hip.so')
+SOURCES = ['gemm_kernels.hip', 'pointwise_kernels.hip', 'norm_kernels.hip', 'misc_kernels.hip']
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU, ACT_TANH = 0, 1, 2, 3, 4
+EINVAL = -1000
+
+i32, i64, f32, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class ConvParams(ctypes.Structure):
+  _fields_ = [('src', vp), ('w', vp), ('dst', vp), ('scale', vp), ('shift', vp), ('res', vp), ('B', i32), ('Hs', i32),
+              ('Ws', i32), ('Cs', i32), ('Hd', i32), ('Wd', i32), ('Cd', i32), ('R', i32), ('S', i32), ('stride', i32),
+              ('pad', i32), ('G', i32), ('ks_g', i32), ('n_g', i32), ('mode', i32), ('act', i32), ('dst_nchw', i32),
+              ('alpha', f32), ('src_ld', i64), ('dst_ld', i64), ('res_ld', i64), ('dst_f32', i32)]
+
+
+class WgradParams(ctypes.Structure):
+  _fields_ = [('dy', vp), ('x', vp), ('dw', vp), ('row_map', vp), ('col_map', vp), ('B', i32), ('Hs', i32), ('Ws', i32),
+              ('Cs', i32), ('Hd', i32), ('Wd', i32), ('Cd', i32), ('R', i32), ('S', i32), ('stride', i32), ('pad', i32),
+              ('G', i32), ('ks_g', i32), ('n_g', i32), ('c_real', i32), ('splits', i32), ('x_ld', i64), ('dy_ld', i64),
+              ('dw_ld', i64)]
+
+
+class BgemmParams(ctypes.Structure):
+  _fields_ = [('A', vp), ('B', vp), ('C', vp), ('bias', vp), ('M', i32), ('N', i32), ('K', i32), ('lda', i64),
+              ('ldb', i64), ('ldc', i64), ('a_bs0', i64), ('a_bs1', i64), ('b_bs0', i64), ('b_bs1', i64), ('c_bs0', i64),
+              ('c_bs1', i64), ('batch0', i32), ('batch1', i32), ('a_km', i32), ('b_km', i32), ('act', i32), ('c_f32', i32),
+              ('alpha', f32), ('beta', f32)]
+
+
+_CTYPE = {'int': i32, 'int64_t': i64, 'uint64_t': ctypes.c_uint64, 'float': f32, 'double': ctypes.c_double}
+
+
+def declared_functions(header=HEADER):
+  """{name: [ctypes argtypes]} parsed from the ``int tfpp_*(...)`` declarations of include/tfpp.h."""
+  with open(header, encoding='utf-8') as f:
+    text = f.read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  out = {}
+  for m in re.finditer(r'\bint\s+(tfpp_\w+)\s*\(([^)]*)\)\s*;', text):
+    name, args = m.group(1), m.group(2).strip()
+    types = []
+    if args and args != 'void':
+      for a in args.split(','):
+        a = a.strip()
+        if '*' in a:
+          types.append(vp)
+        else:
+          t = a.replace('const', '').split()[0]
+          types.append(_CTYPE[t])
+    out[name] = types
+  return out
+
+
+def build(verbose=False, force=False):
+  """Compile every HIP source for gfx950 into carla_garage_amd/libtfpp_hip.so (hipcc cross-compiles without a GPU)."""
+  srcs = [os.path.join(CSRC, s) for s in SOURCES]
+  deps = srcs + [os.path.join(CSRC, 'common.cuh'), os.path.join(CSRC, 'gemm_core.cuh'), HEADER]
+  if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    return LIB_PATH
+  objs = []
+  procs = []
+  os.makedirs(os.path.join(PKG_DIR, 'build'), exist_ok=True)
+  for s in srcs:
+    o = os.path.join(PKG_DIR, 'build', os.path.basename(s) + '.o')
+    objs.append(o)
+    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o]
+    procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+  for cmd, p in procs:
+    outp = p.communicate()[0].decode()
+    if p.returncode != 0:
+      raise RuntimeError('hipcc failed: ' + ' '.join(cmd) + '\n' + outp)
+    if verbose and outp:
+      print(outp)
+  cmd = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+  r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=False)
+  if r.returncode != 0:
+    raise RuntimeError('link failed: ' + r.stdout.decode())
+  return LIB_PATH
+
+
+class TfppError(RuntimeError):
+  pass
+
+
+class _Lib:
+  """Lazy handle; ``lib.tfpp_xxx(...)`` raises TfppError on a non-zero return code."""
+
+  def __init__(self):
+    self._dll = None
+    self._fns = {}
+
+  def load(self):
+    if self._dll is not None:
+      return self
+    if not os.path.exists(LIB_PATH):
+      raise TfppError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                      '(there is no PyTorch/CPU fallback for the HIP path)')
+    self._dll = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in declared_functions().items():
+      fn = getattr(self._dll, name)  # AttributeError if the library does not export a declared symbol
+      fn.argtypes = argtypes
+      fn.restype = ctypes.c_int
+      self._fns[name] = fn
+    sizes = (ctypes.c_int * 8)()
+    n = self._dll.tfpp_struct_sizes(sizes, 8)
+    mine = [ctypes.sizeof(ConvParams), ctypes.sizeof(WgradParams), ctypes.sizeof(BgemmParams)]
+    if n != 3 or list(sizes[:3]) != mine:
+      raise TfppError(f'struct layout mismatch: library {list(sizes[:3])} vs ctypes {mine}')
+    if self._dll.tfpp_version() != 1:
+      raise TfppError('ABI version mismatch')
+    return self
+
+  def __getattr__(self, name):
+    if name.startswith('_'):
+      raise AttributeError(name)
+    self.load()
+    fn = self._fns[name]
+
+    def call(*args):
+      rc = fn(*args)
+      if rc != 0:
+        raise TfppError(f'{name} failed with code {rc}' + (' (invalid argument)' if rc == EINVAL else ' (hipError)'))
+
+    call.__name__ = name
+    self.__dict__[name] = call
+    return call
+
+
+lib = _Lib()

@@ -1,0 +1,107 @@
+// Common device helpers for the TransFuser++ gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TFPP_WAVE 64
+
+typedef unsigned short bf16_t;  // raw bfloat16 storage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+enum { TFPP_F32 = 0, TFPP_BF16 = 1 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_GELU = 3, ACT_TANH = 4 };
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                          // round-to-nearest-even
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+  static constexpr int VEC = 4;  // elements per 16-byte vector
+  static constexpr int DT = TFPP_F32;
+  __device__ static __forceinline__ float to_f(float v) { return v; }
+  __device__ static __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct ElemTraits<bf16_t> {
+  static constexpr int VEC = 8;
+  static constexpr int DT = TFPP_BF16;
+  __device__ static __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
+  __device__ static __forceinline__ bf16_t from_f(float v) { return f2bf(v); }
+};
+
+// 16-byte vector <-> float[VEC]
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& u, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& u, float* f) {
+  f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* f);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
+  return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
+  return make_uint4((unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16), (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16),
+                    (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16), (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16));
+}
+
+template <typename T> __device__ __forceinline__ void load_vec(const T* p, float* f) {
+  uint4 u = *reinterpret_cast<const uint4*>(p);
+  unpack16<T>(u, f);
+}
+template <typename T> __device__ __forceinline__ void store_vec(T* p, const float* f) {
+  *reinterpret_cast<uint4*>(p) = pack16<T>(f);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    case ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Counter-based RNG for dropout masks (same (seed, index) -> same bit in forward and backward).
+__device__ __forceinline__ unsigned hash_u32(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (unsigned)(x >> 32);
+}
+// returns scale (0 or 1/(1-p)) for element idx
+__device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+  unsigned r = hash_u32(seed * 0x100000001B3ull + idx);
+  return ((float)(r >> 8) * (1.0f / 16777216.0f)) < p ? 0.f : inv_keep;
+}
+
+#define TFPP_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return -(int)e__;                  \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,94 @@
+// MFMA tile core shared by the implicit-GEMM convolution, weight-gradient and batched GEMM kernels.
+//
+// gfx950 MFMA fragments used (wave64):
+//   bf16: v_mfma_f32_16x16x32_bf16   A: lane l holds A[i=l&15][k=(l>>4)*8 .. +7]   B: B[k=(l>>4)*8..+7][j=l&15]
+//   f32 : v_mfma_f32_16x16x4_f32     A: lane l holds A[i=l&15][k=l>>4]             B: B[k=l>>4][j=l&15]
+//   C/D (both): acc[r] = D[i=(l>>4)*4+r][j=l&15]
+// A K-step is 32 for both types.  For f32 a lane still reads 8 consecutive k (two 16-byte LDS reads) and issues
+// 8 MFMAs, the j-th using element j of both operands: MFMA j then reduces k = {8g+j : g=0..3}, the same set for A
+// and B, so the sum over all 8 covers k=0..31 exactly once (order of fp32 accumulation differs from a CPU loop
+// only by this permutation).
+//
+// LDS images: "row-major" [row][k] (pitch LDK, 16-byte aligned rows, fragment = 16-byte reads) for operands whose
+// global layout is k-contiguous, and "k-major" [k][row] (pitch LDR) for operands that are row-contiguous in HBM
+// (weight-gradient GEMMs, P@V): those are stored as loaded (8-byte LDS writes) and gathered element-wise into
+// fragments, which transposes them without a global-memory pass.
+#pragma once
+#include "common.cuh"
+
+template <typename T, int BM_, int BN_, int WM_, int WN_>
+struct TileCfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = 32;
+  static constexpr int VEC = ElemTraits<T>::VEC;
+  static constexpr int KV = BK / VEC;                       // 16-byte vectors per tile row
+  static constexpr int LDK = BK + (sizeof(T) == 2 ? 8 : 4);  // row-major pitch (elements): 80 B / 144 B
+  static constexpr int PADR = (sizeof(T) == 2 ? 4 : 2);      // k-major pitch pad: conflict-free scalar gathers
+  static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
+  static constexpr int NT = WAVES_M * WAVES_N * TFPP_WAVE;
+  static constexpr int FM = WM / 16, FN = WN / 16;
+  static constexpr int LDRA = BM + PADR, LDRB = BN + PADR;
+  static constexpr int A_ELEMS_RM = BM * LDK, B_ELEMS_RM = BN * LDK;
+  static constexpr int A_ELEMS_KM = BK * LDRA, B_ELEMS_KM = BK * LDRB;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { uint4 v; };
+template <> struct Frag<float> { float v[8]; };
+
+// fragment from a row-major LDS image: p points at element [row = frag_row0 + (l&15)][k = (l>>4)*8]
+__device__ __forceinline__ void frag_load_rm(Frag<bf16_t>& f, const bf16_t* p) { f.v = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void frag_load_rm(Frag<float>& f, const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+// fragment from a k-major LDS image: p points at element [k = (l>>4)*8][row = frag_row0 + (l&15)], pitch ldr
+__device__ __forceinline__ void frag_load_km(Frag<bf16_t>& f, const bf16_t* p, int ldr) {
+  unsigned w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w[j] = (unsigned)p[(2 * j) * ldr] | ((unsigned)p[(2 * j + 1) * ldr] << 16);
+  f.v = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ void frag_load_km(Frag<float>& f, const float* p, int ldr) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = p[j * ldr];
+}
+
+__device__ __forceinline__ void frag_mma(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x4_t& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v), acc, 0, 0,
+                                                0);
+}
+__device__ __forceinline__ void frag_mma(const Frag<float>& a, const Frag<float>& b, f32x4_t& acc) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+// One K-step (32) of the block tile held in LDS.
+template <typename C, typename T, bool A_KM, bool B_KM>
+__device__ __forceinline__ void tile_mma_step(const T* As, const T* Bs, int wm, int wn, int lane, f32x4_t (&acc)[C::FM][C::FN]) {
+  Frag<T> fa[C::FM], fb[C::FN];
+  const int r16 = lane & 15, kg = (lane >> 4) * 8;
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i) {
+    const int row = wm * C::WM + i * 16 + r16;
+    if constexpr (A_KM) frag_load_km(fa[i], As + kg * C::LDRA + row, C::LDRA);
+    else frag_load_rm(fa[i], As + row * C::LDK + kg);
+  }
+#pragma unroll
+  for (int j = 0; j < C::FN; ++j) {
+    const int row = wn * C::WN + j * 16 + r16;
+    if constexpr (B_KM) frag_load_km(fb[j], Bs + kg * C::LDRB + row, C::LDRB);
+    else frag_load_rm(fb[j], Bs + row * C::LDK + kg);
+  }
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) frag_mma(fa[i], fb[j], acc[i][j]);
+}
+
+// store a 16-byte vector (VEC elements along rows) into a k-major image at [k][row0..row0+VEC) -- 8-byte aligned
+template <typename T> __device__ __forceinline__ void lds_store_km(T* dst, const uint4& v) {
+  uint2* d = reinterpret_cast<uint2*>(dst);
+  d[0] = make_uint2(v.x, v.y);
+  d[1] = make_uint2(v.z, v.w);
+}

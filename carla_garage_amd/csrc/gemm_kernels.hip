@@ -1,0 +1,433 @@
+// Implicit-GEMM convolution (forward / data-gradient), weight-gradient and strided batched GEMM on MFMA (gfx950).
+// See gemm_core.cuh for the fragment / LDS layouts and include/tfpp.h for the semantics of each entry point.
+#include "gemm_core.cuh"
+#include "../../include/tfpp.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv / linear forward and data gradient
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_kernel(tfpp_conv_params p) {
+  using C = TileCfg<T, BM, BN, WM, WN>;
+  constexpr int VEC = C::VEC, KV = C::KV, NT = C::NT, BK = C::BK;
+  __shared__ __attribute__((aligned(16))) T As[C::A_ELEMS_RM];
+  __shared__ __attribute__((aligned(16))) T Bs[C::B_ELEMS_RM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const int g = blockIdx.z;
+  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const int M = p.B * p.Hd * p.Wd, K = p.R * p.S * p.ks_g;
+  const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
+  const T* __restrict__ wk = reinterpret_cast<const T*>(p.w) + (size_t)g * p.n_g * K;
+
+  constexpr int A_IT = (BM * KV) / NT;
+  static_assert((BM * KV) % NT == 0, "A tile must divide evenly");
+  constexpr int B_IT = (BN * KV + NT - 1) / NT;
+  int a_b[A_IT], a_h0[A_IT], a_w0[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int v = tid + i * NT, row = v / KV, m = bm0 + row;
+    if (m < M) {
+      const int hw = p.Hd * p.Wd, b = m / hw, pix = m - b * hw, hd = pix / p.Wd, wd = pix - hd * p.Wd;
+      a_b[i] = b;
+      if (p.mode == 0) { a_h0[i] = hd * p.stride - p.pad; a_w0[i] = wd * p.stride - p.pad; }
+      else { a_h0[i] = hd + p.pad; a_w0[i] = wd + p.pad; }
+    } else {
+      a_b[i] = -1; a_h0[i] = 0; a_w0[i] = 0;
+    }
+  }
+  f32x4_t acc[C::FM][C::FN];
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (K + BK - 1) / BK;
+  for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int v = tid + i * NT, row = v / KV, kc = v - row * KV, k0 = kt * BK + kc * VEC;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (a_b[i] >= 0 && k0 < K) {
+        const int rs = k0 / p.ks_g, c = k0 - rs * p.ks_g, r = rs / p.S, s = rs - r * p.S;
+        int hs, ws;
+        bool ok;
+        if (p.mode == 0) {
+          hs = a_h0[i] + r; ws = a_w0[i] + s;
+          ok = (hs >= 0) & (hs < p.Hs) & (ws >= 0) & (ws < p.Ws);
+        } else {
+          const int th = a_h0[i] - r, tw = a_w0[i] - s;
+          hs = th / p.stride; ws = tw / p.stride;
+          ok = (th >= 0) & (tw >= 0) & (hs * p.stride == th) & (ws * p.stride == tw) & (hs < p.Hs) & (ws < p.Ws);
+        }
+        if (ok) val = *reinterpret_cast<const uint4*>(src + ((size_t)(a_b[i] * p.Hs + hs) * p.Ws + ws) * p.src_ld + g * p.ks_g + c);
+      }
+      *reinterpret_cast<uint4*>(&As[row * C::LDK + kc * VEC]) = val;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int v = tid + i * NT;
+      if (v < BN * KV) {
+        const int row = v / KV, kc = v - row * KV, k0 = kt * BK + kc * VEC, n = bn0 + row;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (n < p.n_g && k0 < K) val = *reinterpret_cast<const uint4*>(wk + (size_t)n * K + k0);
+        *reinterpret_cast<uint4*>(&Bs[row * C::LDK + kc * VEC]) = val;
+      }
+    }
+    __syncthreads();
+    tile_mma_step<C, T, false, false>(As, Bs, wm, wn, lane, acc);
+    __syncthreads();
+  }
+
+  // epilogue
+  const int hw = p.Hd * p.Wd;
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = bm0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < C::FN; ++j) {
+        const int n = bn0 + wn * WN + j * 16 + (lane & 15);
+        if (n >= p.n_g) continue;
+        const int ch = g * p.n_g + n;
+        float v = acc[i][j][r] * p.alpha;
+        if (p.scale) v *= p.scale[ch];
+        if (p.shift) v += p.shift[ch];
+        if (res) v += ElemTraits<T>::to_f(res[(size_t)m * p.res_ld + ch]);
+        v = apply_act(v, p.act);
+        size_t o;
+        if (p.dst_nchw) { const int b = m / hw, pix = m - b * hw; o = ((size_t)b * p.Cd + ch) * hw + pix; }
+        else o = (size_t)m * p.dst_ld + ch;
+        if (p.dst_f32) reinterpret_cast<float*>(p.dst)[o] = v;
+        else reinterpret_cast<T*>(p.dst)[o] = ElemTraits<T>::from_f(v);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_conv(const tfpp_conv_params& p, hipStream_t st) {
+  using C = TileCfg<T, BM, BN, WM, WN>;
+  const long M = (long)p.B * p.Hd * p.Wd;
+  dim3 grid(cdiv(M, BM), cdiv(p.n_g, BN), p.G);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WM, WN>), grid, dim3(C::NT), 0, st, p);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStream_t st) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  if (p.ks_g % VEC != 0 || p.src_ld % VEC != 0 || p.G < 1 || p.B < 1) return TFPP_EINVAL;
+  if (((uintptr_t)p.src & 15) || ((uintptr_t)p.w & 15)) return TFPP_EINVAL;
+  const long M = (long)p.B * p.Hd * p.Wd;
+  if (M >= (1l << 31) || M * (long)p.dst_ld >= (1l << 40)) return TFPP_EINVAL;
+  const int N = p.n_g;
+  // tile choice: minimise padded N work, prefer wide tiles; small problems get 64x64 tiles for more workgroups
+  if (N <= 32 || (N > 64 && N <= 96) ) {
+    if (N <= 32) return launch_conv<T, 128, 32, 32, 32>(p, st);
+    return launch_conv<T, 128, 32, 32, 32>(p, st);  // 72 -> 3 x 32
+  }
+  if (N <= 64) return launch_conv<T, 128, 64, 64, 32>(p, st);
+  const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128) * p.G;
+  if (tiles128 < 256) return launch_conv<T, 64, 64, 32, 32>(p, st);
+  return launch_conv<T, 128, 128, 64, 64>(p, st);
+}
+
+extern "C" int tfpp_conv_gemm(const tfpp_conv_params* p, int dtype, void* stream) {
+  if (!p || !p->src || !p->w || !p->dst) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) return dispatch_conv<float>(*p, st);
+  if (dtype == TFPP_BF16) return dispatch_conv<bf16_t>(*p, st);
+  return TFPP_EINVAL;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient: dW[n][(c,r,s)] += sum_pixels dY[pix][n] * Xgather[pix][(r,s,c)]   (reduction over pixels)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_kernel(tfpp_wgrad_params p) {
+  using C = TileCfg<T, BM, BN, WM, WN>;
+  constexpr int VEC = C::VEC, NT = C::NT, BK = C::BK;
+  __shared__ __attribute__((aligned(16))) T As[C::A_ELEMS_KM];
+  __shared__ __attribute__((aligned(16))) T Bs[C::B_ELEMS_KM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const int g = blockIdx.z / p.splits, split = blockIdx.z - g * p.splits;
+  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const int KK = p.R * p.S * p.ks_g;
+  const long P = (long)p.B * p.Hd * p.Wd;
+  const long per = ((P + p.splits - 1) / p.splits + BK - 1) / BK * BK;
+  const long p_beg = (long)split * per, p_end = (p_beg + per < P) ? p_beg + per : P;
+  const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+
+  constexpr int AV = BM / VEC, BV = BN / VEC;           // vectors per pixel row of each tile
+  constexpr int A_IT = (BK * AV + NT - 1) / NT, B_IT = (BK * BV + NT - 1) / NT;
+  f32x4_t acc[C::FM][C::FN];
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int hw = p.Hd * p.Wd;
+  for (long pt = p_beg; pt < p_end; pt += BK) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int v = tid + i * NT;
+      if (v < BK * AV) {
+        const int pk = v / AV, nc = v - pk * AV, n = bm0 + nc * VEC;
+        const long pix = pt + pk;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (pix < p_end && n < p.n_g) val = *reinterpret_cast<const uint4*>(dy + (size_t)pix * p.dy_ld + g * p.n_g + n);
+        lds_store_km<T>(&As[pk * C::LDRA + nc * VEC], val);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int v = tid + i * NT;
+      if (v < BK * BV) {
+        const int pk = v / BV, kc = v - pk * BV, kk0 = bn0 + kc * VEC;
+        const long pix = pt + pk;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (pix < p_end && kk0 < KK) {
+          const int rs = kk0 / p.ks_g, c = kk0 - rs * p.ks_g, r = rs / p.S, s = rs - r * p.S;
+          const int b = (int)(pix / hw), rem = (int)(pix - (long)b * hw), hd = rem / p.Wd, wd = rem - hd * p.Wd;
+          const int hs = hd * p.stride - p.pad + r, ws = wd * p.stride - p.pad + s;
+          if (hs >= 0 && hs < p.Hs && ws >= 0 && ws < p.Ws)
+            val = *reinterpret_cast<const uint4*>(x + ((size_t)(b * p.Hs + hs) * p.Ws + ws) * p.x_ld + g * p.ks_g + c);
+        }
+        lds_store_km<T>(&Bs[pk * C::LDRB + kc * VEC], val);
+      }
+    }
+    __syncthreads();
+    tile_mma_step<C, T, true, true>(As, Bs, wm, wn, lane, acc);
+    __syncthreads();
+  }
+
+  const int RS = p.R * p.S;
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = bm0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+      if (n >= p.n_g) continue;
+      int row = g * p.n_g + n;
+      if (p.row_map) row = p.row_map[row];
+      if (row < 0) continue;
+#pragma unroll
+      for (int j = 0; j < C::FN; ++j) {
+        const int kk = bn0 + wn * WN + j * 16 + (lane & 15);
+        if (kk >= KK) continue;
+        long col;
+        if (p.col_map) {
+          col = p.col_map[kk];
+          if (col < 0) continue;
+        } else {
+          const int rs = kk / p.ks_g, c = kk - rs * p.ks_g;
+          if (c >= p.c_real) continue;
+          col = (long)c * RS + rs;
+        }
+        atomicAdd(p.dw + (size_t)row * p.dw_ld + col, acc[i][j][r]);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_wgrad(const tfpp_wgrad_params& p, hipStream_t st) {
+  using C = TileCfg<T, BM, BN, WM, WN>;
+  const int KK = p.R * p.S * p.ks_g;
+  dim3 grid(cdiv(p.n_g, BM), cdiv(KK, BN), p.G * p.splits);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, BM, BN, WM, WN>), grid, dim3(C::NT), 0, st, p);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T> static int dispatch_wgrad(tfpp_wgrad_params p, hipStream_t st) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  if (p.ks_g % VEC != 0 || p.n_g % VEC != 0 || p.x_ld % VEC != 0 || p.dy_ld % VEC != 0) return TFPP_EINVAL;
+  const long P = (long)p.B * p.Hd * p.Wd;
+  const int KK = p.R * p.S * p.ks_g;
+  const bool small = (p.n_g <= 32 || KK <= 32);
+  const int bm = small ? 32 : 64, bn = small ? 32 : 64;
+  if (p.splits <= 0) {
+    // enough workgroups to fill 256 CUs several times over, but at least 256 pixels of reduction each
+    const long tiles = (long)cdiv(p.n_g, bm) * cdiv(KK, bn) * p.G;
+    long want = (2048 + tiles - 1) / tiles;
+    long maxs = (P + 255) / 256;
+    p.splits = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
+    if (p.splits < 1) p.splits = 1;
+  }
+  if (small) return launch_wgrad<T, 32, 32, 16, 16>(p, st);
+  return launch_wgrad<T, 64, 64, 32, 32>(p, st);
+}
+
+extern "C" int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stream) {
+  if (!p || !p->dy || !p->x || !p->dw) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) return dispatch_wgrad<float>(*p, st);
+  if (dtype == TFPP_BF16) return dispatch_wgrad<bf16_t>(*p, st);
+  return TFPP_EINVAL;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// strided batched GEMM (attention products and their gradients); scalar-load fallback for unaligned shapes
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void bgemm_kernel(tfpp_bgemm_params p, int vec_ok) {
+  using C = TileCfg<T, BM, BN, WM, WN>;
+  constexpr int VEC = C::VEC, KV = C::KV, NT = C::NT, BK = C::BK;
+  __shared__ __attribute__((aligned(16))) T As[A_KM ? C::A_ELEMS_KM : C::A_ELEMS_RM];
+  __shared__ __attribute__((aligned(16))) T Bs[B_KM ? C::B_ELEMS_KM : C::B_ELEMS_RM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const int z = blockIdx.z, z0 = z / p.batch1, z1 = z - z0 * p.batch1;
+  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1;
+  const T* __restrict__ Bp = reinterpret_cast<const T*>(p.B) + z0 * p.b_bs0 + z1 * p.b_bs1;
+  const size_t coff = (size_t)z0 * p.c_bs0 + (size_t)z1 * p.c_bs1;
+
+  f32x4_t acc[C::FM][C::FN];
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (p.K + BK - 1) / BK;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int kb = kt * BK;
+    // ---- A tile
+    if constexpr (!A_KM) {
+      constexpr int IT = (BM * KV + NT - 1) / NT;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int v = tid + i * NT;
+        if (v < BM * KV) {
+          const int row = v / KV, kc = v - row * KV, k0 = kb + kc * VEC, m = bm0 + row;
+          T* d = &As[row * C::LDK + kc * VEC];
+          if (vec_ok) {
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (m < p.M && k0 < p.K) val = *reinterpret_cast<const uint4*>(A + (size_t)m * p.lda + k0);
+            *reinterpret_cast<uint4*>(d) = val;
+          } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) d[e] = (m < p.M && k0 + e < p.K) ? A[(size_t)m * p.lda + k0 + e] : (T)0;
+          }
+        }
+      }
+    } else {
+      constexpr int RV = BM / VEC, IT = (BK * RV + NT - 1) / NT;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int v = tid + i * NT;
+        if (v < BK * RV) {
+          const int kk = v / RV, rc = v - kk * RV, k = kb + kk, m0 = bm0 + rc * VEC;
+          T* d = &As[kk * C::LDRA + rc * VEC];
+          if (vec_ok) {
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (k < p.K && m0 < p.M) val = *reinterpret_cast<const uint4*>(A + (size_t)k * p.lda + m0);
+            lds_store_km<T>(d, val);
+          } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) d[e] = (k < p.K && m0 + e < p.M) ? A[(size_t)k * p.lda + m0 + e] : (T)0;
+          }
+        }
+      }
+    }
+    // ---- B tile
+    if constexpr (!B_KM) {
+      constexpr int IT = (BN * KV + NT - 1) / NT;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int v = tid + i * NT;
+        if (v < BN * KV) {
+          const int row = v / KV, kc = v - row * KV, k0 = kb + kc * VEC, n = bn0 + row;
+          T* d = &Bs[row * C::LDK + kc * VEC];
+          if (vec_ok) {
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (n < p.N && k0 < p.K) val = *reinterpret_cast<const uint4*>(Bp + (size_t)n * p.ldb + k0);
+            *reinterpret_cast<uint4*>(d) = val;
+          } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) d[e] = (n < p.N && k0 + e < p.K) ? Bp[(size_t)n * p.ldb + k0 + e] : (T)0;
+          }
+        }
+      }
+    } else {
+      constexpr int RV = BN / VEC, IT = (BK * RV + NT - 1) / NT;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int v = tid + i * NT;
+        if (v < BK * RV) {
+          const int kk = v / RV, rc = v - kk * RV, k = kb + kk, n0 = bn0 + rc * VEC;
+          T* d = &Bs[kk * C::LDRB + rc * VEC];
+          if (vec_ok) {
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (k < p.K && n0 < p.N) val = *reinterpret_cast<const uint4*>(Bp + (size_t)k * p.ldb + n0);
+            lds_store_km<T>(d, val);
+          } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) d[e] = (k < p.K && n0 + e < p.N) ? Bp[(size_t)k * p.ldb + n0 + e] : (T)0;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    tile_mma_step<C, T, A_KM, B_KM>(As, Bs, wm, wn, lane, acc);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = bm0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < C::FN; ++j) {
+        const int n = bn0 + wn * WN + j * 16 + (lane & 15);
+        if (n >= p.N) continue;
+        float v = acc[i][j][r] * p.alpha;
+        if (p.bias) v += p.bias[n];
+        v = apply_act(v, p.act);
+        const size_t o = coff + (size_t)m * p.ldc + n;
+        if (p.c_f32) {
+          float* c = reinterpret_cast<float*>(p.C);
+          c[o] = (p.beta != 0.f) ? v + p.beta * c[o] : v;
+        } else {
+          T* c = reinterpret_cast<T*>(p.C);
+          c[o] = ElemTraits<T>::from_f((p.beta != 0.f) ? v + p.beta * ElemTraits<T>::to_f(c[o]) : v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, bool A_KM, bool B_KM> static int launch_bgemm(const tfpp_bgemm_params& p, hipStream_t st) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  auto al = [&](long v) { return (v % VEC) == 0; };
+  int vec_ok = al(p.lda) && al(p.ldb) && al(p.a_bs0) && al(p.a_bs1) && al(p.b_bs0) && al(p.b_bs1) &&
+               (((uintptr_t)p.A & 15) == 0) && (((uintptr_t)p.B & 15) == 0);
+  vec_ok = vec_ok && (A_KM ? al(p.M) : al(p.K)) && (B_KM ? al(p.N) : al(p.K));
+  using C = TileCfg<T, 64, 64, 32, 32>;
+  dim3 grid(cdiv(p.M, 64), cdiv(p.N, 64), p.batch0 * p.batch1);
+  hipLaunchKernelGGL((bgemm_kernel<T, 64, 64, 32, 32, A_KM, B_KM>), grid, dim3(C::NT), 0, st, p, vec_ok);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T> static int dispatch_bgemm(const tfpp_bgemm_params& p, hipStream_t st) {
+  if (p.a_km) return p.b_km ? launch_bgemm<T, true, true>(p, st) : launch_bgemm<T, true, false>(p, st);
+  return p.b_km ? launch_bgemm<T, false, true>(p, st) : launch_bgemm<T, false, false>(p, st);
+}
+
+extern "C" int tfpp_bgemm(const tfpp_bgemm_params* p, int dtype, void* stream) {
+  if (!p || !p->A || !p->B || !p->C || p->batch0 < 1 || p->batch1 < 1) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) return dispatch_bgemm<float>(*p, st);
+  if (dtype == TFPP_BF16) return dispatch_bgemm<bf16_t>(*p, st);
+  return TFPP_EINVAL;
+}

@@ -1,0 +1,400 @@
+// GRU waypoint decoder, fused loss+gradient kernels and the AdamW(amsgrad) optimizer step.
+#include "common.cuh"
+#include "../../include/tfpp.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// GRU (team_code/model.py:857-867): one block per sample, hidden state in LDS, T sequential steps.
+// torch.nn.GRU gates:  r = s(gi_r + gh_r)  z = s(gi_z + gh_z)  n = tanh(gi_n + r*gh_n)  h' = (1-z)*n + z*h
+// save[b][t] = {r, z, n, h'} (4*H floats); out[b][t][:] = cumsum_t(W_dec h'_t + b_dec)
+// ---------------------------------------------------------------------------------------------------------------
+#define GRU_MAXH 64
+__global__ void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ h0, const float* __restrict__ w_hh,
+                               const float* __restrict__ b_hh, const float* __restrict__ w_dec, const float* __restrict__ b_dec,
+                               float* __restrict__ save, float* __restrict__ out, int T, int H) {
+  __shared__ float h[GRU_MAXH], gh[3 * GRU_MAXH], cum[2];
+  const int b = blockIdx.x, tid = threadIdx.x;  // 3*H threads
+  if (tid < H) h[tid] = h0[(size_t)b * H + tid];
+  if (tid < 2) cum[tid] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    float s = b_hh[tid];
+    for (int k = 0; k < H; ++k) s += w_hh[(size_t)tid * H + k] * h[k];
+    gh[tid] = s;
+    __syncthreads();
+    if (tid < H) {
+      const float* g = gi + ((size_t)b * T + t) * 3 * H;
+      const float r = 1.f / (1.f + __expf(-(g[tid] + gh[tid])));
+      const float z = 1.f / (1.f + __expf(-(g[H + tid] + gh[H + tid])));
+      const float n = tanhf(g[2 * H + tid] + r * gh[2 * H + tid]);
+      const float hn = (1.f - z) * n + z * h[tid];
+      float* sv = save + ((size_t)b * T + t) * 4 * H;
+      sv[tid] = r; sv[H + tid] = z; sv[2 * H + tid] = n; sv[3 * H + tid] = hn;
+      h[tid] = hn;
+    }
+    __syncthreads();
+    if (tid < 2) {
+      float s2 = b_dec[tid];
+      for (int k = 0; k < H; ++k) s2 += w_dec[tid * H + k] * h[k];
+      cum[tid] += s2;
+      out[((size_t)b * T + t) * 2 + tid] = cum[tid];
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int tfpp_gru_fwd(const float* gi, const float* h0, const float* w_hh, const float* b_hh, const float* w_dec, const float* b_dec,
+                            float* save, float* out, int B, int T, int H, void* stream) {
+  if (!gi || !h0 || !w_hh || !b_hh || !w_dec || !b_dec || !save || !out || H > GRU_MAXH) return TFPP_EINVAL;
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(B), dim3(3 * H), 0, (hipStream_t)stream, gi, h0, w_hh, b_hh, w_dec, b_dec, save, out, T, H);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ save, const float* __restrict__ h0,
+                               const float* __restrict__ w_hh, const float* __restrict__ b_hh, const float* __restrict__ w_dec,
+                               float* __restrict__ dgi, float* __restrict__ dh0, float* __restrict__ dw_hh, float* __restrict__ db_hh,
+                               float* __restrict__ dw_dec, float* __restrict__ db_dec, int T, int H) {
+  __shared__ float dh[GRU_MAXH], hp[GRU_MAXH], dgh[3 * GRU_MAXH], ghn[GRU_MAXH], dcum[2], dhn[GRU_MAXH];
+  const int b = blockIdx.x, tid = threadIdx.x;  // 3*H threads
+  if (tid < H) dh[tid] = 0.f;
+  if (tid < 2) dcum[tid] = 0.f;
+  __syncthreads();
+  for (int t = T - 1; t >= 0; --t) {
+    const float* sv = save + ((size_t)b * T + t) * 4 * H;
+    // reverse cumsum: gradient of the per-step decoder output o_t is sum_{tau>=t} dout[tau]
+    if (tid < 2) dcum[tid] += dout[((size_t)b * T + t) * 2 + tid];
+    if (tid < H) hp[tid] = (t > 0) ? save[((size_t)b * T + t - 1) * 4 * H + 3 * H + tid] : h0[(size_t)b * H + tid];
+    __syncthreads();
+    if (tid < H) {
+      const float hn = sv[3 * H + tid];
+      dhn[tid] = dh[tid] + w_dec[tid] * dcum[0] + w_dec[H + tid] * dcum[1];
+      atomicAdd(dw_dec + tid, dcum[0] * hn);
+      atomicAdd(dw_dec + H + tid, dcum[1] * hn);
+      // recompute gh_n = W_hn h_{t-1} + b_hn
+      float s = b_hh[2 * H + tid];
+      for (int k = 0; k < H; ++k) s += w_hh[(size_t)(2 * H + tid) * H + k] * hp[k];
+      ghn[tid] = s;
+    }
+    if (tid < 2) atomicAdd(db_dec + tid, dcum[tid]);
+    __syncthreads();
+    if (tid < H) {
+      const float r = sv[tid], z = sv[H + tid], n = sv[2 * H + tid];
+      const float d = dhn[tid];
+      const float dn = d * (1.f - z);
+      const float dz = d * (hp[tid] - n);
+      const float dpn = dn * (1.f - n * n);
+      const float dr = dpn * ghn[tid];
+      const float dpz = dz * z * (1.f - z);
+      const float dpr = dr * r * (1.f - r);
+      float* g = dgi + ((size_t)b * T + t) * 3 * H;
+      g[tid] = dpr; g[H + tid] = dpz; g[2 * H + tid] = dpn;
+      dgh[tid] = dpr; dgh[H + tid] = dpz; dgh[2 * H + tid] = dpn * r;
+      dh[tid] = d * z;  // direct path h_{t-1} -> h_t
+    }
+    __syncthreads();
+    // parameter gradients of the recurrent projection and the gradient w.r.t. h_{t-1}
+    atomicAdd(db_hh + tid, dgh[tid]);
+    for (int k = 0; k < H; ++k) atomicAdd(dw_hh + (size_t)tid * H + k, dgh[tid] * hp[k]);
+    if (tid < H) {
+      float s = 0.f;
+      for (int j = 0; j < 3 * H; ++j) s += dgh[j] * w_hh[(size_t)j * H + tid];
+      dh[tid] += s;
+    }
+    __syncthreads();
+  }
+  if (tid < H) dh0[(size_t)b * H + tid] = dh[tid];
+}
+
+extern "C" int tfpp_gru_bwd(const float* dout, const float* save, const float* h0, const float* w_hh, const float* b_hh, const float* w_dec,
+                            float* dgi, float* dh0, float* dw_hh, float* db_hh, float* dw_dec, float* db_dec, int B, int T, int H,
+                            void* stream) {
+  if (!dout || !save || !h0 || !w_hh || !b_hh || !w_dec || !dgi || !dh0 || !dw_hh || !db_hh || !dw_dec || !db_dec || H > GRU_MAXH)
+    return TFPP_EINVAL;
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(B), dim3(3 * H), 0, (hipStream_t)stream, dout, save, h0, w_hh, b_hh, w_dec, dgi, dh0, dw_hh, db_hh,
+                     dw_dec, db_dec, T, H);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm1d(1, affine=False) on the ego speed (model.py:216,311): tiny, one block
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void bn1d_scalar_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ rm, float* __restrict__ rv,
+                                   long long* __restrict__ nbt, int B, int training, float momentum, float eps) {
+  __shared__ float stat[2];
+  if (threadIdx.x == 0) {
+    float m, v;
+    if (training) {
+      double s = 0.0, q = 0.0;
+      for (int i = 0; i < B; ++i) s += x[i];
+      m = (float)(s / B);
+      for (int i = 0; i < B; ++i) { const double d = x[i] - m; q += d * d; }
+      v = (float)(q / B);
+      rm[0] = (1.f - momentum) * rm[0] + momentum * m;
+      rv[0] = (1.f - momentum) * rv[0] + momentum * (float)(B > 1 ? q / (B - 1) : q);
+      if (nbt) *nbt += 1;
+    } else {
+      m = rm[0]; v = rv[0];
+    }
+    stat[0] = m; stat[1] = 1.f / sqrtf(v + eps);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < B; i += blockDim.x) y[i] = (x[i] - stat[0]) * stat[1];
+}
+
+extern "C" int tfpp_bn1d_scalar(const float* x, float* y, float* running_mean, float* running_var, int64_t* nbt, int B, int training,
+                                float momentum, float eps, void* stream) {
+  if (!x || !y || !running_mean || !running_var) return TFPP_EINVAL;
+  hipLaunchKernelGGL(bn1d_scalar_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, x, y, running_mean, running_var, (long long*)nbt, B, training,
+                     momentum, eps);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// losses.  pred is [rows, ld] NHWC (C real classes / channels); labels keep the reference's layouts.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  float r = (threadIdx.x < (blockDim.x >> 6)) ? sm[threadIdx.x] : 0.f;
+  if (w == 0) r = wave_sum(r);
+  __syncthreads();
+  return r;  // valid in wave 0
+}
+
+// effective label: -1 (ignored) where the visibility mask is 0 (model.py:427-429), else the label
+__device__ __forceinline__ long long ce_label(const long long* __restrict__ label, const float* __restrict__ vis, long i, long HW) {
+  long long l = label[i];
+  if (vis && vis[i % HW] == 0.f) l = -1;
+  return l;
+}
+
+// pass 1 of cross entropy: ws[0] += sum_i class_weight[label_i] over non-ignored rows
+__global__ void ce_norm_kernel(const long long* __restrict__ label, const float* __restrict__ cw, const float* __restrict__ vis, long HW,
+                               float* __restrict__ ws, long rows) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
+    const long long l = ce_label(label, vis, i, HW);
+    if (l >= 0) s += cw ? cw[l] : 1.f;
+  }
+  s = block_sum_256(s, sm);
+  if (threadIdx.x == 0) atomicAdd(ws, s);
+}
+
+// pass 2: loss and gradient.  denominator: pix_weight mode -> (*denom + eps)   else ws[0] (weighted mean)
+template <typename T>
+__global__ void ce_loss_kernel(const T* __restrict__ pred, const long long* __restrict__ label, const float* __restrict__ cw,
+                               const float* __restrict__ vis, const float* __restrict__ pix_weight, long pw_bstride, long HW,
+                               const float* __restrict__ denom, float denom_eps, const float* __restrict__ ws, float weight,
+                               float* __restrict__ loss_out, T* __restrict__ dpred, long rows, int C, int ld) {
+  __shared__ float sm[4];
+  const float den = pix_weight ? (denom[0] + denom_eps) : ws[0];
+  const float inv = den > 0.f ? 1.f / den : 0.f;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
+    const T* p = pred + (size_t)i * ld;
+    const long long l = ce_label(label, vis, i, HW);
+    float v[16];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { v[c] = (c < C) ? ElemTraits<T>::to_f(p[c < ld ? c : 0]) : -3.0e38f; mx = fmaxf(mx, v[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { v[c] = (c < C) ? __expf(v[c] - mx) : 0.f; s += v[c]; }
+    float w = 0.f;
+    if (l >= 0) {
+      w = cw ? cw[l] : 1.f;
+      if (pix_weight) w *= pix_weight[(i / HW) * pw_bstride + (i % HW)];
+    }
+    const float invs = 1.f / s;
+    if (l >= 0) {
+      float pl = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) pl = (c == (int)l) ? v[c] * invs : pl;
+      acc += -w * __logf(fmaxf(pl, 1e-38f));
+    }
+    if (dpred) {
+      T* d = dpred + (size_t)i * ld;
+      const float gs = weight * w * inv;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        if (c < ld) {
+          float g = 0.f;
+          if (c < C) g = gs * (v[c] * invs - ((c == (int)l) ? 1.f : 0.f));
+          d[c] = ElemTraits<T>::from_f(g);
+        }
+      }
+    }
+  }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) atomicAdd(loss_out, acc * inv);
+}
+
+extern "C" int tfpp_ce_loss(const void* pred, const int64_t* label, const float* class_weight, const float* vis_mask, const float* pix_weight,
+                            int64_t pw_bstride, int64_t HW, const float* denom, float denom_eps, float weight, float* loss_out, void* dpred,
+                            float* ws, int64_t rows, int C, int ld, int dtype, void* stream) {
+  if (!pred || !label || !loss_out || !ws || C > 16 || ld > 16 || ld < C || HW < 1 || (pix_weight && !denom)) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  long blocks = (rows + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (!pix_weight) {
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float), st);
+    if (e != hipSuccess) return -(int)e;
+    hipLaunchKernelGGL(ce_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const long long*)label, class_weight, vis_mask, (long)HW, ws, (long)rows);
+  }
+  if (dtype == TFPP_F32)
+    hipLaunchKernelGGL(ce_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (float*)dpred, (long)rows, C, ld);
+  else
+    hipLaunchKernelGGL(ce_loss_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (bf16_t*)dpred, (long)rows, C, ld);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// regression-type losses over logical elements (b, c, pix): pred at [(b*HW+pix)*ld + c]; target (NCHW) at [(b*C+c)*HW+pix];
+// elem weight (NCHW with wC channels) at [(b*wC + (w_bcast?0:c))*HW + pix].
+// kind 0: L1   1: smooth-L1 (beta 1)   2: gaussian focal loss on sigmoid outputs (transfuser_utils.py:341-364)
+// loss = sum(...)/den, den = denom ? (*denom + denom_eps) * denom_mul : B*C*HW
+template <typename T>
+__global__ void reg_loss_kernel(const T* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ ew, int wC, int w_bcast,
+                                const float* __restrict__ denom, float denom_eps, float denom_mul, float weight, float* __restrict__ loss_out,
+                                T* __restrict__ dpred, int B, int C, long HW, long ld, int kind) {
+  __shared__ float sm[4];
+  const long n = (long)B * HW * ld;
+  const float den = denom ? (denom[0] + denom_eps) * denom_mul : (float)((double)B * C * HW);
+  const float inv = 1.f / den;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ld);
+    float g = 0.f;
+    if (c < C) {
+      const long bp = i / ld;
+      const long b = bp / HW, pix = bp - b * HW;
+      const float p = ElemTraits<T>::to_f(pred[i]);
+      const float t = target[((size_t)b * C + c) * HW + pix];
+      const float w = ew ? ew[((size_t)b * wC + (w_bcast ? 0 : c)) * HW + pix] : 1.f;
+      if (kind == 0) {
+        const float d = p - t;
+        acc += fabsf(d) * w;
+        g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w;
+      } else if (kind == 1) {
+        const float d = p - t, ad = fabsf(d);
+        acc += (ad < 1.f ? 0.5f * d * d : ad - 0.5f) * w;
+        g = (ad < 1.f ? d : (d > 0.f ? 1.f : -1.f)) * w;
+      } else {
+        const float eps = 1e-12f;
+        if (t == 1.f) {
+          const float om = 1.f - p, lg = __logf(p + eps);
+          acc += -lg * om * om;
+          g = -om * om / (p + eps) + 2.f * om * lg;
+        } else {
+          const float omt = 1.f - t, nw = omt * omt * omt * omt, lg = __logf(1.f - p + eps);
+          acc += -lg * p * p * nw;
+          g = (p * p / (1.f - p + eps) - 2.f * p * lg) * nw;
+        }
+      }
+    }
+    if (dpred) dpred[i] = ElemTraits<T>::from_f(g * weight * inv);
+  }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) atomicAdd(loss_out, acc * inv);
+}
+
+extern "C" int tfpp_reg_loss(const void* pred, const float* target, const float* elem_weight, int wC, int w_bcast, const float* denom,
+                             float denom_eps, float denom_mul, float weight, float* loss_out, void* dpred, int B, int C, int64_t HW, int64_t ld,
+                             int kind, int dtype, void* stream) {
+  if (!pred || !target || !loss_out || ld < C) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)B * HW * ld;
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (dtype == TFPP_F32)
+    hipLaunchKernelGGL(reg_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)pred, target, elem_weight, wC, w_bcast, denom, denom_eps, denom_mul, weight, loss_out, (float*)dpred, B, C, (long)HW, (long)ld, kind);
+  else
+    hipLaunchKernelGGL(reg_loss_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)pred, target, elem_weight, wC, w_bcast, denom, denom_eps, denom_mul, weight, loss_out, (bf16_t*)dpred, B, C, (long)HW, (long)ld, kind);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[0] = sum(x[0..n))  (avg_factor.sum(), center_net.py:98)
+__global__ void sum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, long n) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+  s = block_sum_256(s, sm);
+  if (threadIdx.x == 0) out[0] = s;
+}
+extern "C" int tfpp_sum_f32(const float* x, float* out, int64_t n, void* stream) {
+  if (!x || !out) return TFPP_EINVAL;
+  hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// AdamW with amsgrad (torch.optim.AdamW semantics, train.py:529-531) over a flat fp32 arena
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void adamw_amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                     float* __restrict__ vmax, long n, float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                     float bc2_sqrt, float grad_scale) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    if (i + 3 < n) {
+      float4 pp = *reinterpret_cast<float4*>(p + i), gg = *reinterpret_cast<const float4*>(g + i), mm = *reinterpret_cast<float4*>(m + i),
+             vv = *reinterpret_cast<float4*>(v + i), xx = *reinterpret_cast<float4*>(vmax + i);
+      float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x; float* xa = &xx.x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gr = ga[e] * grad_scale;
+        pa[e] *= (1.f - lr * wd);
+        ma[e] = beta1 * ma[e] + (1.f - beta1) * gr;
+        va[e] = beta2 * va[e] + (1.f - beta2) * gr * gr;
+        xa[e] = fmaxf(xa[e], va[e]);
+        pa[e] -= (lr / bc1) * ma[e] / (sqrtf(xa[e]) / bc2_sqrt + eps);
+      }
+      *reinterpret_cast<float4*>(p + i) = pp; *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv;
+      *reinterpret_cast<float4*>(vmax + i) = xx;
+    } else {
+      for (long j = i; j < n; ++j) {
+        const float gr = g[j] * grad_scale;
+        float pj = p[j] * (1.f - lr * wd);
+        const float mj = beta1 * m[j] + (1.f - beta1) * gr;
+        const float vj = beta2 * v[j] + (1.f - beta2) * gr * gr;
+        const float xj = fmaxf(vmax[j], vj);
+        pj -= (lr / bc1) * mj / (sqrtf(xj) / bc2_sqrt + eps);
+        p[j] = pj; m[j] = mj; v[j] = vj; vmax[j] = xj;
+      }
+    }
+  }
+}
+
+extern "C" int tfpp_adamw_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || !vmax || step < 1) return TFPP_EINVAL;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) return TFPP_EINVAL;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_amsgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, (long)n, lr, beta1, beta2,
+                     eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tfpp_version(void) { return TFPP_ABI_VERSION; }
+
+extern "C" int tfpp_struct_sizes(int* out, int n) {
+  if (!out || n < 3) return TFPP_EINVAL;
+  out[0] = (int)sizeof(tfpp_conv_params);
+  out[1] = (int)sizeof(tfpp_wgrad_params);
+  out[2] = (int)sizeof(tfpp_bgemm_params);
+  return 3;
+}

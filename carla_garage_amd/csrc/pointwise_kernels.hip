@@ -1,0 +1,795 @@
+// HBM-bound kernels: weight packing, layout changes, pooling / bilinear resampling, elementwise ops, squeeze-excite.
+// All activations are NHWC; every kernel moves 16-byte vectors per lane along the channel dimension.
+#include "common.cuh"
+#include "../../include/tfpp.h"
+
+#define PW_THREADS 256
+static inline dim3 grid1d(long n, int per = PW_THREADS) {
+  long b = (n + per - 1) / per;
+  return dim3((unsigned)(b < 1 ? 1 : b));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// packing
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int cin_g, int R, int S, int G,
+                                        int ks_pad, int n_pad, int transpose, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int n_g = Cout / G, RS = R * S;
+  float v = 0.f;
+  if (!transpose) {  // [G][n_pad][RS*ks_pad]
+    const int K = RS * ks_pad;
+    const int k = (int)(i % K);
+    const long t = i / K;
+    const int n = (int)(t % n_pad), g = (int)(t / n_pad);
+    const int rs = k / ks_pad, c = k - rs * ks_pad;
+    if (n < n_g && c < cin_g) v = w[((size_t)(g * n_g + n) * cin_g + c) * RS + rs];
+  } else {  // [G][cin_g][RS*n_pad]
+    const int K = RS * n_pad;
+    const int k = (int)(i % K);
+    const long t = i / K;
+    const int c = (int)(t % cin_g), g = (int)(t / cin_g);
+    const int rs = k / n_pad, n = k - rs * n_pad;
+    if (n < n_g) v = w[((size_t)(g * n_g + n) * cin_g + c) * RS + rs];
+  }
+  out[i] = ElemTraits<T>::from_f(v);
+}
+
+extern "C" int tfpp_pack_conv_weight(const float* w, void* out, int Cout, int cin_g, int R, int S, int G, int ks_pad, int n_pad,
+                                     int transpose, int dtype, void* stream) {
+  if (!w || !out || G < 1 || Cout % G) return TFPP_EINVAL;
+  const long total = transpose ? (long)G * cin_g * R * S * n_pad : (long)G * n_pad * R * S * ks_pad;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<float>, grid1d(total), dim3(PW_THREADS), 0, st, w, (float*)out, Cout, cin_g, R, S, G,
+                       ks_pad, n_pad, transpose, total);
+  else
+    hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, grid1d(total), dim3(PW_THREADS), 0, st, w, (bf16_t*)out, Cout, cin_g, R, S, G,
+                       ks_pad, n_pad, transpose, total);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[r][c] = in[rmap(r)][cmap(c)]  (transpose_in: in[cmap(c)][rmap(r)]); -1 in a map -> 0
+template <typename T>
+__global__ void pack2d_kernel(const float* __restrict__ in, T* __restrict__ out, const int* __restrict__ row_map,
+                              const int* __restrict__ col_map, int rows_out, int cols_out, long in_ld, long out_ld, int transpose_in) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows_out * cols_out) return;
+  const int r = (int)(i / cols_out), c = (int)(i - (long)r * cols_out);
+  const int sr = row_map ? row_map[r] : r, sc = col_map ? col_map[c] : c;
+  float v = 0.f;
+  if (sr >= 0 && sc >= 0) v = transpose_in ? in[(size_t)sc * in_ld + sr] : in[(size_t)sr * in_ld + sc];
+  out[(size_t)r * out_ld + c] = ElemTraits<T>::from_f(v);
+}
+
+extern "C" int tfpp_pack2d(const float* in, void* out, const int* row_map, const int* col_map, int rows_out, int cols_out,
+                           int64_t in_ld, int64_t out_ld, int transpose_in, int dtype, void* stream) {
+  if (!in || !out) return TFPP_EINVAL;
+  const long total = (long)rows_out * cols_out;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32)
+    hipLaunchKernelGGL(pack2d_kernel<float>, grid1d(total), dim3(PW_THREADS), 0, st, in, (float*)out, row_map, col_map, rows_out, cols_out,
+                       (long)in_ld, (long)out_ld, transpose_in);
+  else
+    hipLaunchKernelGGL(pack2d_kernel<bf16_t>, grid1d(total), dim3(PW_THREADS), 0, st, in, (bf16_t*)out, row_map, col_map, rows_out,
+                       cols_out, (long)in_ld, (long)out_ld, transpose_in);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename TI, typename TO> __global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = ElemTraits<TO>::from_f(ElemTraits<TI>::to_f(in[i]));
+}
+
+extern "C" int tfpp_cast(const void* in, void* out, int64_t n, int dtype_in, int dtype_out, void* stream) {
+  if (!in || !out) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  long blocks = (n + PW_THREADS - 1) / PW_THREADS;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  dim3 g((unsigned)blocks), b(PW_THREADS);
+  if (dtype_in == TFPP_F32 && dtype_out == TFPP_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, st, (const float*)in, (bf16_t*)out, (long)n);
+  else if (dtype_in == TFPP_BF16 && dtype_out == TFPP_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)in, (float*)out, (long)n);
+  else if (dtype_in == TFPP_F32 && dtype_out == TFPP_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, st, (const float*)in, (float*)out, (long)n);
+  else if (dtype_in == TFPP_BF16 && dtype_out == TFPP_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)in, (bf16_t*)out, (long)n);
+  else return TFPP_EINVAL;
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// layout changes at the boundary
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_affine_kernel(const float* __restrict__ in, T* __restrict__ out, const float* __restrict__ mul,
+                                           const float* __restrict__ add, int B, int C, int HW, int cpad) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one pixel
+  if (i >= (long)B * HW) return;
+  const int b = (int)(i / HW), pix = (int)(i - (long)b * HW);
+  T* o = out + (size_t)i * cpad;
+  for (int c0 = 0; c0 < cpad; c0 += ElemTraits<T>::VEC) {
+    float v[ElemTraits<T>::VEC];
+#pragma unroll
+    for (int e = 0; e < ElemTraits<T>::VEC; ++e) {
+      const int c = c0 + e;
+      float x = 0.f;
+      if (c < C) {
+        x = in[((size_t)b * C + c) * HW + pix];
+        if (mul) x = x * mul[c] + add[c];
+      }
+      v[e] = x;
+    }
+    store_vec<T>(o + c0, v);
+  }
+}
+
+extern "C" int tfpp_nchw_to_nhwc_affine(const float* in, void* out, const float* mul, const float* add, int B, int C, int H, int W,
+                                        int cpad, int dtype, void* stream) {
+  if (!in || !out || cpad < C) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)B * H * W;
+  if (dtype == TFPP_F32) {
+    if (cpad % 4) return TFPP_EINVAL;
+    hipLaunchKernelGGL(nchw_to_nhwc_affine_kernel<float>, grid1d(n), dim3(PW_THREADS), 0, st, in, (float*)out, mul, add, B, C, H * W, cpad);
+  } else {
+    if (cpad % 8) return TFPP_EINVAL;
+    hipLaunchKernelGGL(nchw_to_nhwc_affine_kernel<bf16_t>, grid1d(n), dim3(PW_THREADS), 0, st, in, (bf16_t*)out, mul, add, B, C, H * W, cpad);
+  }
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int B, int C, int HW, long in_ld, int act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C * HW) return;
+  const int pix = (int)(i % HW);
+  const long t = i / HW;
+  const int c = (int)(t % C), b = (int)(t / C);
+  out[i] = apply_act(ElemTraits<T>::to_f(in[((size_t)b * HW + pix) * in_ld + c]), act);
+}
+
+extern "C" int tfpp_nhwc_to_nchw(const void* in, float* out, int B, int C, int H, int W, int64_t in_ld, int act, int dtype,
+                                 void* stream) {
+  if (!in || !out) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)B * C * H * W;
+  if (dtype == TFPP_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid1d(n), dim3(PW_THREADS), 0, st, (const float*)in, out, B, C, H * W, (long)in_ld, act);
+  else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid1d(n), dim3(PW_THREADS), 0, st, (const bf16_t*)in, out, B, C, H * W, (long)in_ld, act);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// gradient counterpart: NCHW fp32 (caller's dL/dpred) -> NHWC dtype with channel stride out_ld, padding channels zero
+template <typename T>
+__global__ void nchw_to_nhwc_grad_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int C, int HW, long out_ld) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * HW * out_ld) return;
+  const int c = (int)(i % out_ld);
+  const long bp = i / out_ld;
+  const int pix = (int)(bp % HW), b = (int)(bp / HW);
+  out[i] = ElemTraits<T>::from_f(c < C ? in[((size_t)b * C + c) * HW + pix] : 0.f);
+}
+
+extern "C" int tfpp_nchw_to_nhwc_pad(const float* in, void* out, int B, int C, int H, int W, int64_t out_ld, int dtype, void* stream) {
+  if (!in || !out || out_ld < C) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)B * H * W * out_ld;
+  if (dtype == TFPP_F32) hipLaunchKernelGGL(nchw_to_nhwc_grad_kernel<float>, grid1d(n), dim3(PW_THREADS), 0, st, in, (float*)out, B, C, H * W, (long)out_ld);
+  else hipLaunchKernelGGL(nchw_to_nhwc_grad_kernel<bf16_t>, grid1d(n), dim3(PW_THREADS), 0, st, in, (bf16_t*)out, B, C, H * W, (long)out_ld);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// elementwise over [rows, C] with 16-byte vectors
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void affine_act_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                  const T* __restrict__ res, const float* __restrict__ gate, T* __restrict__ y, long nvec, int CV,
+                                  long rows_per_batch, int act) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < nvec; i += stride) {
+    const long row = i / CV;
+    const int c0 = (int)(i - row * CV) * VEC;
+    float v[VEC], r[VEC];
+    load_vec<T>(x + i * VEC, v);
+    if (res) load_vec<T>(res + i * VEC, r);
+    const float* gp = gate ? gate + (row / rows_per_batch) * (long)CV * VEC + c0 : nullptr;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float t = v[e];
+      if (gp) t *= gp[e];
+      if (scale) t *= scale[c0 + e];
+      if (shift) t += shift[c0 + e];
+      if (res) t += r[e];
+      v[e] = apply_act(t, act);
+    }
+    store_vec<T>(y + i * VEC, v);
+  }
+}
+
+static inline dim3 grid_stride(long n) {
+  long b = (n + PW_THREADS - 1) / PW_THREADS;
+  if (b > 16384) b = 16384;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+extern "C" int tfpp_affine_act(const void* x, const float* scale, const float* shift, const void* res, const float* gate, void* y,
+                               int64_t rows, int C, int64_t rows_per_batch, int act, int dtype, void* stream) {
+  if (!x || !y) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) {
+    if (C % 4) return TFPP_EINVAL;
+    const long nvec = rows * (C / 4);
+    hipLaunchKernelGGL(affine_act_kernel<float>, grid_stride(nvec), dim3(PW_THREADS), 0, st, (const float*)x, scale, shift, (const float*)res, gate, (float*)y, nvec, C / 4, (long)rows_per_batch, act);
+  } else {
+    if (C % 8) return TFPP_EINVAL;
+    const long nvec = rows * (C / 8);
+    hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid_stride(nvec), dim3(PW_THREADS), 0, st, (const bf16_t*)x, scale, shift, (const bf16_t*)res, gate, (bf16_t*)y, nvec, C / 8, (long)rows_per_batch, act);
+  }
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// y = a + dropout(b)
+template <typename T>
+__global__ void add_dropout_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long n, float p, float inv_keep,
+                                   unsigned long long seed) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float v = ElemTraits<T>::to_f(b[i]);
+    if (p > 0.f) v *= dropout_scale(seed, (unsigned long long)i, p, inv_keep);
+    if (a) v += ElemTraits<T>::to_f(a[i]);
+    y[i] = ElemTraits<T>::from_f(v);
+  }
+}
+
+extern "C" int tfpp_add_dropout(const void* a, const void* b, void* y, int64_t n, float p_drop, uint64_t seed, int dtype, void* stream) {
+  if (!b || !y) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  if (dtype == TFPP_F32) hipLaunchKernelGGL(add_dropout_kernel<float>, grid_stride(n), dim3(PW_THREADS), 0, st, (const float*)a, (const float*)b, (float*)y, (long)n, p_drop, inv_keep, (unsigned long long)seed);
+  else hipLaunchKernelGGL(add_dropout_kernel<bf16_t>, grid_stride(n), dim3(PW_THREADS), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, (long)n, p_drop, inv_keep, (unsigned long long)seed);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// y = x + bcast[i % period]
+template <typename T>
+__global__ void add_bcast_kernel(const T* __restrict__ x, const float* __restrict__ bc, T* __restrict__ y, long n, long period) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = ElemTraits<T>::from_f(ElemTraits<T>::to_f(x[i]) + bc[i % period]);
+}
+
+extern "C" int tfpp_add_bcast(const void* x, const float* bcast, void* y, int64_t n, int64_t period, int dtype, void* stream) {
+  if (!x || !y || !bcast || period < 1) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) hipLaunchKernelGGL(add_bcast_kernel<float>, grid_stride(n), dim3(PW_THREADS), 0, st, (const float*)x, bcast, (float*)y, (long)n, (long)period);
+  else hipLaunchKernelGGL(add_bcast_kernel<bf16_t>, grid_stride(n), dim3(PW_THREADS), 0, st, (const bf16_t*)x, bcast, (bf16_t*)y, (long)n, (long)period);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// dx = dy * act'(.)   (y = activation output for relu/sigmoid/tanh, activation input for gelu)
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long n, int act) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float g = ElemTraits<T>::to_f(dy[i]), v = ElemTraits<T>::to_f(y[i]);
+    float d;
+    switch (act) {
+      case ACT_RELU: d = v > 0.f ? g : 0.f; break;
+      case ACT_SIGMOID: d = g * v * (1.f - v); break;
+      case ACT_TANH: d = g * (1.f - v * v); break;
+      case ACT_GELU: d = g * (0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v)); break;
+      default: d = g;
+    }
+    dx[i] = ElemTraits<T>::from_f(d);
+  }
+}
+
+extern "C" int tfpp_act_bwd(const void* dy, const void* y, void* dx, int64_t n, int act, int dtype, void* stream) {
+  if (!dy || !y || !dx) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, grid_stride(n), dim3(PW_THREADS), 0, st, (const float*)dy, (const float*)y, (float*)dx, (long)n, act);
+  else hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, grid_stride(n), dim3(PW_THREADS), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, (long)n, act);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// y += a * x
+template <typename T> __global__ void axpy_kernel(const T* __restrict__ x, T* __restrict__ y, long n, float a) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = ElemTraits<T>::from_f(ElemTraits<T>::to_f(y[i]) + a * ElemTraits<T>::to_f(x[i]));
+}
+extern "C" int tfpp_axpy(const void* x, void* y, int64_t n, float a, int dtype, void* stream) {
+  if (!x || !y) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) hipLaunchKernelGGL(axpy_kernel<float>, grid_stride(n), dim3(PW_THREADS), 0, st, (const float*)x, (float*)y, (long)n, a);
+  else hipLaunchKernelGGL(axpy_kernel<bf16_t>, grid_stride(n), dim3(PW_THREADS), 0, st, (const bf16_t*)x, (bf16_t*)y, (long)n, a);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// y[b, pix, c] = x[b, pix, c] * m[pix]  (visibility mask, model.py:385); x,y have channel stride ld
+template <typename T>
+__global__ void mul_pixmask_kernel(const T* __restrict__ x, const float* __restrict__ m, T* __restrict__ y, long n, long ld, long HW) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = ElemTraits<T>::from_f(ElemTraits<T>::to_f(x[i]) * m[(i / ld) % HW]);
+}
+extern "C" int tfpp_mul_pixmask(const void* x, const float* m, void* y, int64_t n, int64_t ld, int64_t HW, int dtype, void* stream) {
+  if (!x || !y || !m) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) hipLaunchKernelGGL(mul_pixmask_kernel<float>, grid_stride(n), dim3(PW_THREADS), 0, st, (const float*)x, m, (float*)y, (long)n, (long)ld, (long)HW);
+  else hipLaunchKernelGGL(mul_pixmask_kernel<bf16_t>, grid_stride(n), dim3(PW_THREADS), 0, st, (const bf16_t*)x, m, (bf16_t*)y, (long)n, (long)ld, (long)HW);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// column sums: out[c] += sum_rows x[row*ld + c]   (bias gradients); block = 64 row-slots x 4... generic layout below
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int C, long ld, long rows_per_block) {
+  // threads: 64 columns x 4 row slots
+  const int cl = threadIdx.x & 63, rs = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  float s = 0.f;
+  if (c < C)
+    for (long r = r0 + rs; r < r1; r += 4) s += ElemTraits<T>::to_f(x[(size_t)r * ld + c]);
+  __shared__ float sm[4][64];
+  sm[rs][cl] = s;
+  __syncthreads();
+  if (rs == 0 && c < C) atomicAdd(out + c, sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl]);
+}
+
+extern "C" int tfpp_colsum(const void* x, float* out, int64_t rows, int C, int64_t ld, int dtype, void* stream) {
+  if (!x || !out) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  long rpb = 256;
+  dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((C + 63) / 64));
+  if (grid.x < 1) grid.x = 1;
+  if (dtype == TFPP_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, out, (long)rows, C, (long)ld, rpb);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, out, (long)rows, C, (long)ld, rpb);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pooling / resampling
+// ---------------------------------------------------------------------------------------------------------------
+// adaptive average pooling with uniform windows (H % Ho == 0, W % Wo == 0): thread per (b,ho,wo,channel-vector)
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo, long y_ld) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int CV = C / VEC;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * Ho * Wo * CV) return;
+  const int cv = (int)(i % CV);
+  long t = i / CV;
+  const int wo = (int)(t % Wo); t /= Wo;
+  const int ho = (int)(t % Ho);
+  const int b = (int)(t / Ho);
+  const int kh = H / Ho, kw = W / Wo;
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  for (int dh = 0; dh < kh; ++dh)
+    for (int dw = 0; dw < kw; ++dw) {
+      float v[VEC];
+      load_vec<T>(x + ((size_t)(b * H + ho * kh + dh) * W + wo * kw + dw) * C + cv * VEC, v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+    }
+  const float inv = 1.f / (float)(kh * kw);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] *= inv;
+  store_vec<T>(y + ((size_t)(b * Ho + ho) * Wo + wo) * y_ld + cv * VEC, acc);
+}
+
+extern "C" int tfpp_avgpool_fwd(const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int64_t y_ld, int dtype, void* stream) {
+  if (!x || !y || H % Ho || W % Wo) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) {
+    if (C % 4 || y_ld % 4) return TFPP_EINVAL;
+    hipLaunchKernelGGL(avgpool_fwd_kernel<float>, grid1d((long)B * Ho * Wo * (C / 4)), dim3(PW_THREADS), 0, st, (const float*)x, (float*)y, B, H, W, C, Ho, Wo, (long)y_ld);
+  } else {
+    if (C % 8 || y_ld % 8) return TFPP_EINVAL;
+    hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, grid1d((long)B * Ho * Wo * (C / 8)), dim3(PW_THREADS), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo, (long)y_ld);
+  }
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// dx[b,h,w,:] += dy[b,h/kh,w/kw,:] / (kh*kw)
+template <typename T>
+__global__ void avgpool_bwd_add_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo, long dy_ld) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int CV = C / VEC;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * H * W * CV) return;
+  const int cv = (int)(i % CV);
+  long t = i / CV;
+  const int w = (int)(t % W); t /= W;
+  const int h = (int)(t % H);
+  const int b = (int)(t / H);
+  const int kh = H / Ho, kw = W / Wo;
+  float g[VEC], v[VEC];
+  load_vec<T>(dy + ((size_t)(b * Ho + h / kh) * Wo + w / kw) * dy_ld + cv * VEC, g);
+  T* d = dx + ((size_t)(b * H + h) * W + w) * C + cv * VEC;
+  load_vec<T>(d, v);
+  const float inv = 1.f / (float)(kh * kw);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) v[e] += g[e] * inv;
+  store_vec<T>(d, v);
+}
+
+extern "C" int tfpp_avgpool_bwd_add(const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo, int64_t dy_ld, int dtype, void* stream) {
+  if (!dy || !dx || H % Ho || W % Wo) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) {
+    if (C % 4 || dy_ld % 4) return TFPP_EINVAL;
+    hipLaunchKernelGGL(avgpool_bwd_add_kernel<float>, grid1d((long)B * H * W * (C / 4)), dim3(PW_THREADS), 0, st, (const float*)dy, (float*)dx, B, H, W, C, Ho, Wo, (long)dy_ld);
+  } else {
+    if (C % 8 || dy_ld % 8) return TFPP_EINVAL;
+    hipLaunchKernelGGL(avgpool_bwd_add_kernel<bf16_t>, grid1d((long)B * H * W * (C / 8)), dim3(PW_THREADS), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C, Ho, Wo, (long)dy_ld);
+  }
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// PyTorch bilinear, align_corners=False: src = max(0, (o+0.5)*in/out - 0.5); i0=floor(src); i1=min(i0+1,in-1); l=src-i0
+__device__ __forceinline__ void bilin_coord(int o, int in_sz, int out_sz, int& i0, int& i1, float& l1) {
+  const float scale = (float)in_sz / (float)out_sz;
+  float src = ((float)o + 0.5f) * scale - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > in_sz - 1) i0 = in_sz - 1;
+  i1 = i0 + ((i0 < in_sz - 1) ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+// y = base + bilinear(x) [* mul[pixel]] ; output NHWC dtype (ld y_ld) or NCHW fp32
+template <typename T>
+__global__ void bilinear_fwd_kernel(const T* __restrict__ x, const T* __restrict__ base, const float* __restrict__ mul, void* __restrict__ yv,
+                                    int B, int Hi, int Wi, int Ho, int Wo, int C, long x_ld, long y_ld, int out_nchw_f32, int c_real) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int CV = C / VEC;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * Ho * Wo * CV) return;
+  const int cv = (int)(i % CV);
+  long t = i / CV;
+  const int wo = (int)(t % Wo); t /= Wo;
+  const int ho = (int)(t % Ho);
+  const int b = (int)(t / Ho);
+  int h0, h1, w0, w1;
+  float lh, lw;
+  bilin_coord(ho, Hi, Ho, h0, h1, lh);
+  bilin_coord(wo, Wi, Wo, w0, w1, lw);
+  float v00[VEC], v01[VEC], v10[VEC], v11[VEC], o[VEC];
+  const T* xb = x + (size_t)b * Hi * Wi * x_ld + cv * VEC;
+  load_vec<T>(xb + ((size_t)h0 * Wi + w0) * x_ld, v00);
+  load_vec<T>(xb + ((size_t)h0 * Wi + w1) * x_ld, v01);
+  load_vec<T>(xb + ((size_t)h1 * Wi + w0) * x_ld, v10);
+  load_vec<T>(xb + ((size_t)h1 * Wi + w1) * x_ld, v11);
+  const float m = mul ? mul[(size_t)ho * Wo + wo] : 1.f;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e)
+    o[e] = ((1.f - lh) * ((1.f - lw) * v00[e] + lw * v01[e]) + lh * ((1.f - lw) * v10[e] + lw * v11[e])) * m;
+  const size_t pix = ((size_t)b * Ho + ho) * Wo + wo;
+  if (base) {
+    float bb[VEC];
+    load_vec<T>(base + pix * y_ld + cv * VEC, bb);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] += bb[e];
+  }
+  if (out_nchw_f32) {
+    float* y = reinterpret_cast<float*>(yv);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = cv * VEC + e;
+      if (c < c_real) y[((size_t)b * c_real + c) * Ho * Wo + (size_t)ho * Wo + wo] = o[e];
+    }
+  } else {
+    store_vec<T>(reinterpret_cast<T*>(yv) + pix * y_ld + cv * VEC, o);
+  }
+}
+
+extern "C" int tfpp_bilinear_fwd(const void* x, const void* base, const float* mul, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                 int64_t x_ld, int64_t y_ld, int out_nchw_f32, int c_real, int dtype, void* stream) {
+  if (!x || !y) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) {
+    if (C % 4 || x_ld % 4 || (!out_nchw_f32 && y_ld % 4)) return TFPP_EINVAL;
+    hipLaunchKernelGGL(bilinear_fwd_kernel<float>, grid1d((long)B * Ho * Wo * (C / 4)), dim3(PW_THREADS), 0, st, (const float*)x, (const float*)base, mul, y, B, Hi, Wi, Ho, Wo, C, (long)x_ld, (long)y_ld, out_nchw_f32, c_real);
+  } else {
+    if (C % 8 || x_ld % 8 || (!out_nchw_f32 && y_ld % 8)) return TFPP_EINVAL;
+    hipLaunchKernelGGL(bilinear_fwd_kernel<bf16_t>, grid1d((long)B * Ho * Wo * (C / 8)), dim3(PW_THREADS), 0, st, (const bf16_t*)x, (const bf16_t*)base, mul, y, B, Hi, Wi, Ho, Wo, C, (long)x_ld, (long)y_ld, out_nchw_f32, c_real);
+  }
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// dx[b,hi,wi,:] = sum over output pixels (ho,wo) whose stencil touches (hi,wi) of weight * dy[b,ho,wo,:] * mul[ho,wo]
+template <typename T>
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ mul, T* __restrict__ dx, int B, int Hi, int Wi,
+                                    int Ho, int Wo, int C, long dy_ld, long dx_ld) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int CV = C / VEC;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * Hi * Wi * CV) return;
+  const int cv = (int)(i % CV);
+  long t = i / CV;
+  const int wi = (int)(t % Wi); t /= Wi;
+  const int hi = (int)(t % Hi);
+  const int b = (int)(t / Hi);
+  // candidate output range: src in (hi-1, hi+1)  <=>  o in ((hi-0.5)*s-0.5, (hi+1.5)*s-0.5), s = out/in  (+ clamp effects at borders)
+  const float sh = (float)Ho / (float)Hi, sw = (float)Wo / (float)Wi;
+  int oh0 = (int)floorf(((float)hi - 0.5f) * sh - 0.5f) - 1, oh1 = (int)ceilf(((float)hi + 1.5f) * sh - 0.5f) + 1;
+  int ow0 = (int)floorf(((float)wi - 0.5f) * sw - 0.5f) - 1, ow1 = (int)ceilf(((float)wi + 1.5f) * sw - 0.5f) + 1;
+  if (oh0 < 0) oh0 = 0;
+  if (ow0 < 0) ow0 = 0;
+  if (oh1 > Ho - 1) oh1 = Ho - 1;
+  if (ow1 > Wo - 1) ow1 = Wo - 1;
+  if (hi == 0) oh0 = 0;
+  if (wi == 0) ow0 = 0;
+  if (hi == Hi - 1) oh1 = Ho - 1;
+  if (wi == Wi - 1) ow1 = Wo - 1;
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  for (int oh = oh0; oh <= oh1; ++oh) {
+    int h0, h1; float lh;
+    bilin_coord(oh, Hi, Ho, h0, h1, lh);
+    float wh = 0.f;
+    if (h0 == hi) wh += 1.f - lh;
+    if (h1 == hi) wh += lh;
+    if (wh == 0.f) continue;
+    for (int ow = ow0; ow <= ow1; ++ow) {
+      int w0, w1; float lw;
+      bilin_coord(ow, Wi, Wo, w0, w1, lw);
+      float ww = 0.f;
+      if (w0 == wi) ww += 1.f - lw;
+      if (w1 == wi) ww += lw;
+      if (ww == 0.f) continue;
+      float g[VEC];
+      load_vec<T>(dy + (((size_t)b * Ho + oh) * Wo + ow) * dy_ld + cv * VEC, g);
+      const float wt = wh * ww * (mul ? mul[(size_t)oh * Wo + ow] : 1.f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += wt * g[e];
+    }
+  }
+  store_vec<T>(dx + (((size_t)b * Hi + hi) * Wi + wi) * dx_ld + cv * VEC, acc);
+}
+
+extern "C" int tfpp_bilinear_bwd(const void* dy, const float* mul, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int64_t dy_ld,
+                                 int64_t dx_ld, int dtype, void* stream) {
+  if (!dy || !dx) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) {
+    if (C % 4 || dy_ld % 4 || dx_ld % 4) return TFPP_EINVAL;
+    hipLaunchKernelGGL(bilinear_bwd_kernel<float>, grid1d((long)B * Hi * Wi * (C / 4)), dim3(PW_THREADS), 0, st, (const float*)dy, mul, (float*)dx, B, Hi, Wi, Ho, Wo, C, (long)dy_ld, (long)dx_ld);
+  } else {
+    if (C % 8 || dy_ld % 8 || dx_ld % 8) return TFPP_EINVAL;
+    hipLaunchKernelGGL(bilinear_bwd_kernel<bf16_t>, grid1d((long)B * Hi * Wi * (C / 8)), dim3(PW_THREADS), 0, st, (const bf16_t*)dy, mul, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, (long)dy_ld, (long)dx_ld);
+  }
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// squeeze-excite
+// ---------------------------------------------------------------------------------------------------------------
+// out[b,c] += (1/HW) * sum_{rows in this block's slice} x[b,row,c] * (y ? y[b,row,c] : 1)     (out pre-zeroed)
+template <typename T>
+__global__ void hw_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y, float* __restrict__ out, int HW, int C, float mulv, int rows_per_block) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int CV = C / VEC;
+  const int cvl = threadIdx.x & 63, rs = threadIdx.x >> 6;  // 64 channel vectors x 4 row slots
+  const int cv = blockIdx.y * 64 + cvl;
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = (r0 + rows_per_block < HW) ? r0 + rows_per_block : HW;
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  if (cv < CV) {
+    for (int r = r0 + rs; r < r1; r += 4) {
+      float v[VEC];
+      const size_t off = ((size_t)b * HW + r) * C + cv * VEC;
+      load_vec<T>(x + off, v);
+      if (y) {
+        float w[VEC];
+        load_vec<T>(y + off, w);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += v[e] * w[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+      }
+    }
+  }
+  __shared__ float sm[4][64][VEC + 1];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) sm[rs][cvl][e] = acc[e];
+  __syncthreads();
+  if (rs == 0 && cv < CV) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+      atomicAdd(out + (size_t)b * C + cv * VEC + e, (sm[0][cvl][e] + sm[1][cvl][e] + sm[2][cvl][e] + sm[3][cvl][e]) * mulv);
+  }
+}
+
+template <typename T> static int launch_hw_reduce(const void* x, const void* y, float* out, int B, int HW, int C, float mulv, hipStream_t st) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  if (C % VEC) return TFPP_EINVAL;
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), st);
+  if (e != hipSuccess) return -(int)e;
+  const int CV = C / VEC;
+  int rpb = 256;
+  dim3 grid((unsigned)((HW + rpb - 1) / rpb), (unsigned)((CV + 63) / 64), (unsigned)B);
+  hipLaunchKernelGGL(hw_reduce_kernel<T>, grid, dim3(256), 0, st, (const T*)x, (const T*)y, out, HW, C, mulv, rpb);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tfpp_mean_hw(const void* x, float* out, int B, int HW, int C, int dtype, void* stream) {
+  if (!x || !out) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == TFPP_F32 ? launch_hw_reduce<float>(x, nullptr, out, B, HW, C, 1.f / (float)HW, st)
+                           : launch_hw_reduce<bf16_t>(x, nullptr, out, B, HW, C, 1.f / (float)HW, st);
+}
+
+extern "C" int tfpp_se_dgate(const void* dy, const void* x, float* dgate, int B, int HW, int C, int dtype, void* stream) {
+  if (!dy || !x || !dgate) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == TFPP_F32 ? launch_hw_reduce<float>(dy, x, dgate, B, HW, C, 1.f, st) : launch_hw_reduce<bf16_t>(dy, x, dgate, B, HW, C, 1.f, st);
+}
+
+// one block per sample: hidden = relu(W1 pool + b1) ; gate = sigmoid(W2 hidden + b2)
+__global__ void se_gate_fwd_kernel(const float* __restrict__ pool, const float* __restrict__ w1, const float* __restrict__ b1,
+                                   const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ hidden,
+                                   float* __restrict__ gate, int C, int RD) {
+  extern __shared__ float sm[];  // pool[C] + hidden[RD]
+  float* sp = sm;
+  float* sh = sm + C;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  for (int c = tid; c < C; c += blockDim.x) sp[c] = pool[(size_t)b * C + c];
+  __syncthreads();
+  for (int j = wave; j < RD; j += nw) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += w1[(size_t)j * C + c] * sp[c];
+    s = wave_sum(s);
+    if (lane == 0) {
+      s += b1[j];
+      s = s > 0.f ? s : 0.f;
+      sh[j] = s;
+      hidden[(size_t)b * RD + j] = s;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    float s = b2[c];
+    for (int j = 0; j < RD; ++j) s += w2[(size_t)c * RD + j] * sh[j];
+    gate[(size_t)b * C + c] = 1.f / (1.f + __expf(-s));
+  }
+}
+
+extern "C" int tfpp_se_gate_fwd(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2, float* hidden,
+                                float* gate, int B, int C, int RD, void* stream) {
+  if (!pool || !w1 || !w2 || !hidden || !gate) return TFPP_EINVAL;
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), (size_t)(C + RD) * sizeof(float), (hipStream_t)stream, pool, w1, b1, w2, b2,
+                     hidden, gate, C, RD);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// one block per sample; parameter gradients accumulated with fp32 atomics
+__global__ void se_gate_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate, const float* __restrict__ hidden,
+                                   const float* __restrict__ pool, const float* __restrict__ w1, const float* __restrict__ w2,
+                                   float* __restrict__ dpool, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                   float* __restrict__ db2, int C, int RD) {
+  extern __shared__ float sm[];  // dz2[C] + hid[RD] + dz1[RD] + pool[C]
+  float* dz2 = sm;
+  float* sh = sm + C;
+  float* dz1 = sh + RD;
+  float* sp = dz1 + RD;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  for (int c = tid; c < C; c += blockDim.x) {
+    const float gt = gate[(size_t)b * C + c];
+    const float d = dgate[(size_t)b * C + c] * gt * (1.f - gt);
+    dz2[c] = d;
+    sp[c] = pool[(size_t)b * C + c];
+    atomicAdd(db2 + c, d);
+  }
+  for (int j = tid; j < RD; j += blockDim.x) sh[j] = hidden[(size_t)b * RD + j];
+  __syncthreads();
+  for (int i = tid; i < C * RD; i += blockDim.x) {
+    const int c = i / RD, j = i - c * RD;
+    atomicAdd(dw2 + i, dz2[c] * sh[j]);
+  }
+  for (int j = wave; j < RD; j += nw) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += dz2[c] * w2[(size_t)c * RD + j];
+    s = wave_sum(s);
+    if (lane == 0) {
+      s = sh[j] > 0.f ? s : 0.f;
+      dz1[j] = s;
+      atomicAdd(db1 + j, s);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < C * RD; i += blockDim.x) {
+    const int j = i / C, c = i - j * C;
+    atomicAdd(dw1 + i, dz1[j] * sp[c]);
+  }
+  for (int c = tid; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int j = 0; j < RD; ++j) s += dz1[j] * w1[(size_t)j * C + c];
+    dpool[(size_t)b * C + c] = s;
+  }
+}
+
+extern "C" int tfpp_se_gate_bwd(const float* dgate, const float* gate, const float* hidden, const float* pool, const float* w1,
+                                const float* w2, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int B, int C, int RD,
+                                void* stream) {
+  if (!dgate || !gate || !hidden || !pool || !dpool) return TFPP_EINVAL;
+  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), (size_t)(2 * C + 2 * RD) * sizeof(float), (hipStream_t)stream, dgate, gate,
+                     hidden, pool, w1, w2, dpool, dw1, db1, dw2, db2, C, RD);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// dx = dy * gate[b,c] + dpool[b,c] / HW
+template <typename T>
+__global__ void se_bwd_apply_kernel(const T* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dpool,
+                                    T* __restrict__ dx, long nvec, int CV, long HW) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float inv = 1.f / (float)HW;
+  for (; i < nvec; i += stride) {
+    const long row = i / CV;
+    const int c0 = (int)(i - row * CV) * VEC;
+    const long b = row / HW;
+    float v[VEC];
+    load_vec<T>(dy + i * VEC, v);
+    const float* g = gate + b * (long)CV * VEC + c0;
+    const float* dp = dpool + b * (long)CV * VEC + c0;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = v[e] * g[e] + dp[e] * inv;
+    store_vec<T>(dx + i * VEC, v);
+  }
+}
+
+extern "C" int tfpp_se_bwd_apply(const void* dy, const float* gate, const float* dpool, void* dx, int B, int HW, int C, int dtype, void* stream) {
+  if (!dy || !gate || !dpool || !dx) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) {
+    if (C % 4) return TFPP_EINVAL;
+    const long nvec = (long)B * HW * (C / 4);
+    hipLaunchKernelGGL(se_bwd_apply_kernel<float>, grid_stride(nvec), dim3(PW_THREADS), 0, st, (const float*)dy, gate, dpool, (float*)dx, nvec, C / 4, (long)HW);
+  } else {
+    if (C % 8) return TFPP_EINVAL;
+    const long nvec = (long)B * HW * (C / 8);
+    hipLaunchKernelGGL(se_bwd_apply_kernel<bf16_t>, grid_stride(nvec), dim3(PW_THREADS), 0, st, (const bf16_t*)dy, gate, dpool, (bf16_t*)dx, nvec, C / 8, (long)HW);
+  }
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,382 @@
+"""Tensor-level wrappers over the C ABI (include/tfpp.h).  PyTorch is used for device memory and streams only:
+every function takes CUDA(HIP) tensors, passes raw device pointers + the current stream to ``libtfpp_hip.so``
+and returns/fills tensors allocated with ``torch.empty``.  No ATen compute kernels run here."""
+import ctypes
+
+import torch
+
+from ._lib import (lib, ConvParams, WgradParams, BgemmParams, F32, BF16, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU,
+                   ACT_TANH)
+
+__all__ = ['F32', 'BF16', 'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_GELU', 'ACT_TANH']
+
+
+def dt(t):
+  if t.dtype == torch.float32:
+    return F32
+  if t.dtype == torch.bfloat16:
+    return BF16
+  raise TypeError(f'unsupported dtype {t.dtype}')
+
+
+def vec(dtype):
+  return 4 if dtype == torch.float32 else 8
+
+
+def pad_to(n, m):
+  return (n + m - 1) // m * m
+
+
+def stream():
+  return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+  if t is None:
+    return None
+  assert t.is_cuda, 'HIP ops need device tensors'
+  return t.data_ptr()
+
+
+def _chk(t):
+  assert t.is_contiguous(), 'expected a contiguous tensor'
+  return t
+
+
+# ------------------------------------------------------------------------------------------------ GEMM / conv
+def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=0, G=1, ks_g=None, n_g=None, mode=0,
+              act=ACT_NONE, scale=None, shift=None, res=None, alpha=1.0, dst_nchw=False, src_ld=None, dst_ld=None,
+              res_ld=None):
+  p = ConvParams()
+  p.src, p.w, p.dst = ptr(src), ptr(w), ptr(dst)
+  p.scale, p.shift, p.res = ptr(scale), ptr(shift), ptr(res)
+  p.B, p.Hs, p.Ws, p.Cs, p.Hd, p.Wd, p.Cd = B, Hs, Ws, Cs, Hd, Wd, Cd
+  p.R, p.S, p.stride, p.pad, p.G = R, S, stride, pad, G
+  p.ks_g = ks_g if ks_g is not None else Cs // G
+  p.n_g = n_g if n_g is not None else Cd // G
+  p.mode, p.act, p.dst_nchw, p.alpha = mode, act, int(dst_nchw), alpha
+  p.src_ld = src_ld if src_ld is not None else Cs
+  p.dst_ld = dst_ld if dst_ld is not None else Cd
+  p.res_ld = res_ld if res_ld is not None else p.dst_ld
+  p.dst_f32 = int(dst.dtype == torch.float32 and src.dtype != torch.float32)
+  lib.tfpp_conv_gemm(ctypes.byref(p), dt(src), stream())
+  return dst
+
+
+def conv_wgrad(dy, x, dw, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=0, G=1, ks_g=None, n_g=None, c_real=None,
+               row_map=None, col_map=None, x_ld=None, dy_ld=None, dw_ld=None, splits=0):
+  p = WgradParams()
+  p.dy, p.x, p.dw = ptr(dy), ptr(x), ptr(dw)
+  p.row_map, p.col_map = ptr(row_map), ptr(col_map)
+  p.B, p.Hs, p.Ws, p.Cs, p.Hd, p.Wd, p.Cd = B, Hs, Ws, Cs, Hd, Wd, Cd
+  p.R, p.S, p.stride, p.pad, p.G = R, S, stride, pad, G
+  p.ks_g = ks_g if ks_g is not None else Cs // G
+  p.n_g = n_g if n_g is not None else Cd // G
+  p.c_real = c_real if c_real is not None else p.ks_g
+  p.splits = splits
+  p.x_ld = x_ld if x_ld is not None else Cs
+  p.dy_ld = dy_ld if dy_ld is not None else Cd
+  p.dw_ld = dw_ld if dw_ld is not None else p.c_real * R * S
+  assert dw.dtype == torch.float32
+  lib.tfpp_conv_wgrad(ctypes.byref(p), dt(dy), stream())
+  return dw
+
+
+def bgemm(A, B, C, *, M, N, K, lda, ldb, ldc, batch0=1, batch1=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), a_km=False,
+          b_km=False, alpha=1.0, beta=0.0, bias=None, act=ACT_NONE):
+  p = BgemmParams()
+  p.A, p.B, p.C, p.bias = ptr(A), ptr(B), ptr(C), ptr(bias)
+  p.M, p.N, p.K, p.lda, p.ldb, p.ldc = M, N, K, lda, ldb, ldc
+  p.a_bs0, p.a_bs1, p.b_bs0, p.b_bs1, p.c_bs0, p.c_bs1 = a_bs[0], a_bs[1], b_bs[0], b_bs[1], c_bs[0], c_bs[1]
+  p.batch0, p.batch1, p.a_km, p.b_km, p.act = batch0, batch1, int(a_km), int(b_km), act
+  p.c_f32 = int(C.dtype == torch.float32 and A.dtype != torch.float32)
+  p.alpha, p.beta = alpha, beta
+  lib.tfpp_bgemm(ctypes.byref(p), dt(A), stream())
+  return C
+
+
+# ------------------------------------------------------------------------------------------------ packing
+def pack_conv_weight(w, dtype, G=1, ks_pad=None, n_pad=None, transpose=False):
+  """OIHW fp32 parameter -> kernel image (see tfpp.h)."""
+  cout, cin_g, r, s = w.shape
+  n_g = cout // G
+  ks_pad = ks_pad or cin_g
+  n_pad = n_pad or n_g
+  if transpose:
+    out = torch.empty((G, cin_g, r * s * n_pad), device=w.device, dtype=dtype)
+  else:
+    out = torch.empty((G, n_pad, r * s * ks_pad), device=w.device, dtype=dtype)
+  lib.tfpp_pack_conv_weight(ptr(_chk(w)), ptr(out), cout, cin_g, r, s, G, ks_pad, n_pad, int(transpose), dt(out), stream())
+  return out
+
+
+def pack2d(src, out, rows_out, cols_out, in_ld, out_ld, row_map=None, col_map=None, transpose_in=False, out_offset=0):
+  """out[r][c] = src[rmap(r)][cmap(c)] (or transposed source); ``out_offset`` in elements."""
+  o = out.view(-1)[out_offset:]
+  lib.tfpp_pack2d(ptr(src), ptr(o), ptr(row_map), ptr(col_map), rows_out, cols_out, in_ld, out_ld, int(transpose_in), dt(out),
+                  stream())
+  return out
+
+
+def cast(x, dtype):
+  if x.dtype == dtype:
+    return x
+  out = torch.empty(x.shape, device=x.device, dtype=dtype)
+  lib.tfpp_cast(ptr(_chk(x)), ptr(out), x.numel(), dt(x), dt(out), stream())
+  return out
+
+
+def cast_into(x, out):
+  lib.tfpp_cast(ptr(_chk(x)), ptr(out), x.numel(), dt(x), dt(out), stream())
+  return out
+
+
+# ------------------------------------------------------------------------------------------------ layout
+def nchw_to_nhwc_affine(x, dtype, cpad, mul=None, add=None):
+  b, c, h, w = x.shape
+  out = torch.empty((b, h, w, cpad), device=x.device, dtype=dtype)
+  lib.tfpp_nchw_to_nhwc_affine(ptr(_chk(x)), ptr(out), ptr(mul), ptr(add), b, c, h, w, cpad, dt(out), stream())
+  return out
+
+
+def nhwc_to_nchw(x, c_real, act=ACT_NONE):
+  b, h, w, ld = x.shape
+  out = torch.empty((b, c_real, h, w), device=x.device, dtype=torch.float32)
+  lib.tfpp_nhwc_to_nchw(ptr(_chk(x)), ptr(out), b, c_real, h, w, ld, act, dt(x), stream())
+  return out
+
+
+def nchw_to_nhwc_pad(g, dtype, ld):
+  b, c, h, w = g.shape
+  out = torch.empty((b, h, w, ld), device=g.device, dtype=dtype)
+  lib.tfpp_nchw_to_nhwc_pad(ptr(_chk(g)), ptr(out), b, c, h, w, ld, dt(out), stream())
+  return out
+
+
+# ------------------------------------------------------------------------------------------------ batch norm
+def bn_stats(x, ws):
+  c = x.shape[-1]
+  lib.tfpp_bn_stats(ptr(_chk(x)), ptr(ws), x.numel() // c, c, dt(x), stream())
+
+
+def bn_finalize(ws, gamma, beta, rm, rv, nbt, scale, shift, save_mean, save_invstd, rows, momentum=0.1, eps=1e-5):
+  c = scale.numel()
+  lib.tfpp_bn_finalize(ptr(ws), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nbt), ptr(scale), ptr(shift), ptr(save_mean),
+                       ptr(save_invstd), rows, c, momentum, eps, stream())
+
+
+def bn_fold(gamma, beta, rm, rv, scale, shift, eps=1e-5):
+  lib.tfpp_bn_fold(ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(scale), ptr(shift), scale.numel(), eps, stream())
+
+
+def affine_act(x, y=None, scale=None, shift=None, res=None, gate=None, rows_per_batch=1, act=ACT_NONE):
+  c = x.shape[-1]
+  if y is None:
+    y = torch.empty_like(x)
+  lib.tfpp_affine_act(ptr(_chk(x)), ptr(scale), ptr(shift), ptr(res), ptr(gate), ptr(y), x.numel() // c, c, rows_per_batch, act,
+                      dt(x), stream())
+  return y
+
+
+def bn_bwd(dy, y, x, gamma, save_mean, save_invstd, ws, dgamma, dbeta, relu_mask, want_dres=False):
+  c = x.shape[-1]
+  rows = x.numel() // c
+  lib.tfpp_bn_bwd_reduce(ptr(_chk(dy)), ptr(y), ptr(_chk(x)), ptr(save_mean), ptr(save_invstd), ptr(ws), rows, c, int(relu_mask),
+                         dt(x), stream())
+  dx = torch.empty_like(x)
+  dres = torch.empty_like(x) if want_dres else None
+  lib.tfpp_bn_bwd_apply(ptr(dy), ptr(y), ptr(x), ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(ws), ptr(dx), ptr(dres),
+                        ptr(dgamma), ptr(dbeta), rows, c, int(relu_mask), dt(x), stream())
+  return dx, dres
+
+
+def bn1d_scalar(x, rm, rv, nbt, training, momentum=0.1, eps=1e-5):
+  y = torch.empty_like(x)
+  lib.tfpp_bn1d_scalar(ptr(_chk(x)), ptr(y), ptr(rm), ptr(rv), ptr(nbt), x.numel(), int(training), momentum, eps, stream())
+  return y
+
+
+# ------------------------------------------------------------------------------------------------ squeeze-excite
+def mean_hw(x):
+  b, h, w, c = x.shape
+  out = torch.empty((b, c), device=x.device, dtype=torch.float32)
+  lib.tfpp_mean_hw(ptr(_chk(x)), ptr(out), b, h * w, c, dt(x), stream())
+  return out
+
+
+def se_gate_fwd(pool, w1, b1, w2, b2):
+  b, c = pool.shape
+  rd = w1.shape[0]
+  hidden = torch.empty((b, rd), device=pool.device, dtype=torch.float32)
+  gate = torch.empty((b, c), device=pool.device, dtype=torch.float32)
+  lib.tfpp_se_gate_fwd(ptr(pool), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(hidden), ptr(gate), b, c, rd, stream())
+  return hidden, gate
+
+
+def se_dgate(dy, x):
+  b, h, w, c = x.shape
+  out = torch.empty((b, c), device=x.device, dtype=torch.float32)
+  lib.tfpp_se_dgate(ptr(_chk(dy)), ptr(_chk(x)), ptr(out), b, h * w, c, dt(x), stream())
+  return out
+
+
+def se_gate_bwd(dgate, gate, hidden, pool, w1, w2, dw1, db1, dw2, db2):
+  b, c = gate.shape
+  rd = hidden.shape[1]
+  dpool = torch.empty_like(gate)
+  lib.tfpp_se_gate_bwd(ptr(dgate), ptr(gate), ptr(hidden), ptr(pool), ptr(w1), ptr(w2), ptr(dpool), ptr(dw1), ptr(db1), ptr(dw2),
+                       ptr(db2), b, c, rd, stream())
+  return dpool
+
+
+def se_bwd_apply(dy, gate, dpool):
+  b, h, w, c = dy.shape
+  dx = torch.empty_like(dy)
+  lib.tfpp_se_bwd_apply(ptr(_chk(dy)), ptr(gate), ptr(dpool), ptr(dx), b, h * w, c, dt(dy), stream())
+  return dx
+
+
+# ------------------------------------------------------------------------------------------------ pooling / resampling
+def avgpool_fwd(x, ho, wo, out=None, y_ld=None):
+  b, h, w, c = x.shape
+  if out is None:
+    out = torch.empty((b, ho, wo, c), device=x.device, dtype=x.dtype)
+  lib.tfpp_avgpool_fwd(ptr(_chk(x)), ptr(out), b, h, w, c, ho, wo, y_ld or c, dt(x), stream())
+  return out
+
+
+def avgpool_bwd_add(dy, dx, ho, wo, dy_ld=None):
+  b, h, w, c = dx.shape
+  lib.tfpp_avgpool_bwd_add(ptr(dy), ptr(_chk(dx)), b, h, w, c, ho, wo, dy_ld or c, dt(dx), stream())
+  return dx
+
+
+def bilinear_fwd(x, ho, wo, base=None, mul=None, x_ld=None, nchw_f32=False, c_real=None, shape_in=None):
+  """x: [B,Hi,Wi,C] (or flat with shape_in=(B,Hi,Wi,C) and pixel stride x_ld)."""
+  b, hi, wi, c = shape_in if shape_in is not None else x.shape
+  if nchw_f32:
+    c_real = c_real or c
+    y = torch.empty((b, c_real, ho, wo), device=x.device, dtype=torch.float32)
+  else:
+    y = torch.empty((b, ho, wo, c), device=x.device, dtype=x.dtype)
+  lib.tfpp_bilinear_fwd(ptr(x), ptr(base), ptr(mul), ptr(y), b, hi, wi, ho, wo, c, x_ld or c, c, int(nchw_f32), c_real or c, dt(x),
+                        stream())
+  return y
+
+
+def bilinear_bwd(dy, hi, wi, mul=None, dx=None, dx_ld=None):
+  b, ho, wo, c = dy.shape
+  if dx is None:
+    dx = torch.empty((b, hi, wi, c), device=dy.device, dtype=dy.dtype)
+  lib.tfpp_bilinear_bwd(ptr(_chk(dy)), ptr(mul), ptr(dx), b, hi, wi, ho, wo, c, c, dx_ld or c, dt(dy), stream())
+  return dx
+
+
+# ------------------------------------------------------------------------------------------------ token ops
+def layernorm_fwd(x, gamma, beta, eps=1e-5, save=True):
+  c = x.shape[-1]
+  rows = x.numel() // c
+  y = torch.empty_like(x)
+  mean = torch.empty(rows, device=x.device, dtype=torch.float32) if save else None
+  rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if save else None
+  lib.tfpp_layernorm_fwd(ptr(_chk(x)), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, c, eps, dt(x), stream())
+  return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
+  c = x.shape[-1]
+  dx = torch.empty_like(x)
+  lib.tfpp_layernorm_bwd(ptr(_chk(dy)), ptr(_chk(x)), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
+                         x.numel() // c, c, dt(x), stream())
+  return dx
+
+
+def softmax_fwd(x, rows, cols, ld, alpha=1.0, p_drop=0.0, seed=0):
+  """In place; returns (P, P_dropped) -- the same tensor when p_drop == 0."""
+  pd = torch.empty_like(x) if p_drop > 0.0 else None
+  lib.tfpp_softmax_fwd(ptr(x), ptr(pd), rows, cols, ld, alpha, p_drop, seed, dt(x), stream())
+  return x, (pd if pd is not None else x)
+
+
+def softmax_bwd(p, dp, rows, cols, ld, alpha=1.0, p_drop=0.0, seed=0):
+  lib.tfpp_softmax_bwd(ptr(p), ptr(dp), rows, cols, ld, alpha, p_drop, seed, dt(p), stream())
+  return dp
+
+
+def add_dropout(a, b, p_drop=0.0, seed=0, out=None):
+  if out is None:
+    out = torch.empty_like(b)
+  lib.tfpp_add_dropout(ptr(a), ptr(_chk(b)), ptr(out), b.numel(), p_drop, seed, dt(b), stream())
+  return out
+
+
+def add_bcast(x, bc, out=None):
+  if out is None:
+    out = torch.empty_like(x)
+  lib.tfpp_add_bcast(ptr(_chk(x)), ptr(bc), ptr(out), x.numel(), bc.numel(), dt(x), stream())
+  return out
+
+
+def act_bwd(dy, y, act, out=None):
+  if out is None:
+    out = torch.empty_like(dy)
+  lib.tfpp_act_bwd(ptr(_chk(dy)), ptr(_chk(y)), ptr(out), dy.numel(), act, dt(dy), stream())
+  return out
+
+
+def axpy(x, y, a=1.0):
+  lib.tfpp_axpy(ptr(_chk(x)), ptr(_chk(y)), x.numel(), a, dt(x), stream())
+  return y
+
+
+def mul_pixmask(x, m, hw, out=None):
+  if out is None:
+    out = torch.empty_like(x)
+  lib.tfpp_mul_pixmask(ptr(_chk(x)), ptr(m), ptr(out), x.numel(), x.shape[-1], hw, dt(x), stream())
+  return out
+
+
+def colsum(x, out, rows, c, ld=None):
+  lib.tfpp_colsum(ptr(x), ptr(out), rows, c, ld or c, dt(x), stream())
+  return out
+
+
+def sum_f32(x, out):
+  lib.tfpp_sum_f32(ptr(_chk(x)), ptr(out), x.numel(), stream())
+  return out
+
+
+# ------------------------------------------------------------------------------------------------ GRU / losses / optimizer
+def gru_fwd(gi, h0, w_hh, b_hh, w_dec, b_dec):
+  b, t, h3 = gi.shape
+  h = h3 // 3
+  save = torch.empty((b, t, 4, h), device=gi.device, dtype=torch.float32)
+  out = torch.empty((b, t, 2), device=gi.device, dtype=torch.float32)
+  lib.tfpp_gru_fwd(ptr(_chk(gi)), ptr(_chk(h0)), ptr(w_hh), ptr(b_hh), ptr(w_dec), ptr(b_dec), ptr(save), ptr(out), b, t, h, stream())
+  return out, save
+
+
+def gru_bwd(dout, save, h0, w_hh, b_hh, w_dec, dw_hh, db_hh, dw_dec, db_dec):
+  b, t, _, h = save.shape
+  dgi = torch.empty((b, t, 3 * h), device=save.device, dtype=torch.float32)
+  dh0 = torch.empty((b, h), device=save.device, dtype=torch.float32)
+  lib.tfpp_gru_bwd(ptr(_chk(dout)), ptr(save), ptr(h0), ptr(w_hh), ptr(b_hh), ptr(w_dec), ptr(dgi), ptr(dh0), ptr(dw_hh), ptr(db_hh),
+                   ptr(dw_dec), ptr(db_dec), b, t, h, stream())
+  return dgi, dh0
+
+
+def ce_loss(pred, label, loss_out, ws, *, rows, C, ld, HW, class_weight=None, vis_mask=None, pix_weight=None, pw_bstride=0,
+            denom=None, denom_eps=0.0, weight=1.0, dpred=None):
+  lib.tfpp_ce_loss(ptr(pred), ptr(label), ptr(class_weight), ptr(vis_mask), ptr(pix_weight), pw_bstride, HW, ptr(denom), denom_eps,
+                   weight, ptr(loss_out), ptr(dpred), ptr(ws), rows, C, ld, dt(pred), stream())
+
+
+def reg_loss(pred, target, loss_out, *, B, C, HW, ld, kind, elem_weight=None, wC=1, w_bcast=False, denom=None, denom_eps=0.0,
+             denom_mul=1.0, weight=1.0, dpred=None):
+  lib.tfpp_reg_loss(ptr(pred), ptr(target), ptr(elem_weight), wC, int(w_bcast), ptr(denom), denom_eps, denom_mul, weight,
+                    ptr(loss_out), ptr(dpred), B, C, HW, ld, kind, dt(pred), stream())
+
+
+def adamw_amsgrad(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+  lib.tfpp_adamw_amsgrad(ptr(p), ptr(g), ptr(m), ptr(v), ptr(vmax), p.numel(), lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                         stream())

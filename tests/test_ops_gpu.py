@@ -1,0 +1,515 @@
+"""GPU parity tests of every C-ABI entry point against plain PyTorch fp32 CPU references of the same op
+(-m gpu; runs on the MI355X box).  fp32 kernels are held to 2e-4 relative (exact-f32 MFMA, different summation
+order); bf16 kernels are compared against the fp32 reference evaluated on the bf16-rounded inputs, tolerance 2e-2
+(one bf16 output rounding + fp32 accumulation)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+DTYPES = [torch.float32, torch.bfloat16]
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'ops_report.jsonl')
+
+
+def tol(dtype):
+  return 2e-4 if dtype == torch.float32 else 2e-2
+
+
+def report(name, err, dtype):
+  try:
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, 'a', encoding='utf-8') as f:
+      f.write(json.dumps({'test': name, 'dtype': str(dtype), 'rel_err': err}) + '\n')
+  except OSError:
+    pass
+
+
+def check(name, got, want, dtype, scale=1.0):
+  got = got.detach().float().cpu()
+  want = want.detach().float().cpu()
+  assert got.shape == want.shape, f'{name}: {got.shape} vs {want.shape}'
+  assert torch.isfinite(got).all(), f'{name}: non-finite'
+  err = ((got - want).abs().max() / (want.abs().max() + 1e-20)).item()
+  report(name, err, dtype)
+  assert err <= tol(dtype) * scale, f'{name} [{dtype}]: rel err {err:.3e}'
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, lo=-1.0, hi=1.0):
+  g = torch.Generator().manual_seed(seed + sum(shape))
+  x = torch.rand(*shape, generator=g) * (hi - lo) + lo
+  return x.to(dtype).float()  # value representable in dtype, kept as fp32 on the CPU
+
+
+def dev(x, dtype=None):
+  return x.to(DEV, dtype) if dtype is not None else x.to(DEV)
+
+
+def nhwc(x):  # NCHW -> NHWC
+  return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+  return x.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.fixture(scope='module')
+def ops():
+  from carla_garage_amd import ops as o
+  from carla_garage_amd._lib import lib
+  lib.load()
+  return o
+
+
+CONV_CASES = [
+    # name, B, H, W, Cin, Cout, k, stride, groups
+    ('linear', 300, 1, 1, 72, 72, 1, 1, 1),
+    ('pw_s2', 2, 16, 24, 72, 216, 1, 2, 1),
+    ('grouped3x3_s2', 2, 18, 20, 48, 48, 3, 2, 2),
+    ('grouped3x3_s1', 1, 9, 33, 72, 72, 3, 1, 3),
+    ('dense3x3', 2, 12, 16, 64, 32, 3, 1, 1),
+    ('big_k', 1, 8, 80, 1512, 1512, 1, 1, 1),
+    ('wide_n', 3, 10, 10, 64, 256, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(ops, case, dtype):
+  name, B, H, W, Cin, Cout, k, stride, G = case
+  pad = k // 2
+  x = rnd(B, Cin, H, W, dtype=dtype, seed=1)
+  w = rnd(Cout, Cin // G, k, k, dtype=dtype, seed=2) * (1.0 / math.sqrt(Cin // G * k * k))
+  w = w.to(dtype).float()
+  scale = rnd(Cout, seed=3, lo=0.5, hi=1.5)
+  shift = rnd(Cout, seed=4)
+  Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+  res = rnd(B, Cout, Ho, Wo, dtype=dtype, seed=5)
+  xr = x.clone().requires_grad_(True)
+  wr = w.clone().requires_grad_(True)
+  conv = F.conv2d(xr, wr, None, stride, pad, 1, G)
+  want = F.relu(conv * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+
+  xd = dev(nhwc(x), dtype)
+  wp = ops.pack_conv_weight(dev(w), dtype, G=G)
+  y = torch.empty((B, Ho, Wo, Cout), device=DEV, dtype=dtype)
+  ops.conv_gemm(xd, wp, y, B=B, Hs=H, Ws=W, Cs=Cin, Hd=Ho, Wd=Wo, Cd=Cout, R=k, S=k, stride=stride, pad=pad, G=G,
+                act=ops.ACT_RELU, scale=dev(scale), shift=dev(shift), res=dev(nhwc(res), dtype))
+  check(name + '.fwd', nchw(y.float().cpu()), want, dtype)
+
+  # gradients of the plain convolution
+  dy = rnd(B, Cout, Ho, Wo, dtype=dtype, seed=6)
+  conv.backward(dy)
+  dyd = dev(nhwc(dy), dtype)
+  wt = ops.pack_conv_weight(dev(w), dtype, G=G, transpose=True)
+  dx = torch.empty((B, H, W, Cin), device=DEV, dtype=dtype)
+  ops.conv_gemm(dyd, wt, dx, B=B, Hs=Ho, Ws=Wo, Cs=Cout, Hd=H, Wd=W, Cd=Cin, R=k, S=k, stride=stride, pad=pad, G=G, mode=1)
+  check(name + '.dgrad', nchw(dx.float().cpu()), xr.grad, dtype)
+  dw = torch.zeros((Cout, Cin // G, k, k), device=DEV, dtype=torch.float32)
+  ops.conv_wgrad(dyd, xd, dw, B=B, Hs=H, Ws=W, Cs=Cin, Hd=Ho, Wd=Wo, Cd=Cout, R=k, S=k, stride=stride, pad=pad, G=G)
+  check(name + '.wgrad', dw.cpu(), wr.grad, dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_padded_channels_and_nchw_out(ops, dtype):
+  """Stem-style input padding (3 -> 8 channels), small Cout padded to 8, caller-facing NCHW fp32 output."""
+  B, H, W, Cin, Cout, k = 2, 20, 28, 3, 7, 3
+  v = ops.vec(dtype)
+  x = rnd(B, Cin, H, W, dtype=dtype, seed=11)
+  w = (rnd(Cout, Cin, k, k, seed=12) * 0.3).to(dtype).float()
+  b = rnd(Cout, seed=13)
+  xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+  want = F.conv2d(xr, wr, b, 1, 1)
+  mul = torch.tensor([0.5, 2.0, 1.5])
+  add = torch.tensor([0.1, -0.2, 0.3])
+  xin = ops.nchw_to_nhwc_affine(dev((x - add.view(1, 3, 1, 1)) / mul.view(1, 3, 1, 1)), dtype, 8, dev(mul), dev(add))
+  check('nchw_to_nhwc_affine', xin[..., :3].float().cpu(), nhwc(x), dtype, scale=2.0)
+  assert float(xin[..., 3:].float().abs().max()) == 0.0
+  xin = dev(F.pad(nhwc(x), (0, 8 - Cin)), dtype)
+  npad = ops.pad_to(Cout, v)
+  wp = ops.pack_conv_weight(dev(w), dtype, ks_pad=8, n_pad=npad)
+  bias = dev(F.pad(b, (0, npad - Cout)))
+  y = torch.empty((B, Cout, H, W), device=DEV, dtype=torch.float32)
+  ops.conv_gemm(xin, wp, y, B=B, Hs=H, Ws=W, Cs=8, Hd=H, Wd=W, Cd=Cout, R=k, S=k, pad=1, ks_g=8, n_g=Cout, shift=bias, dst_nchw=True)
+  check('conv_nchw_out', y.cpu(), want, dtype)
+  ypad = torch.empty((B, H, W, npad), device=DEV, dtype=dtype)
+  ops.conv_gemm(xin, wp, ypad, B=B, Hs=H, Ws=W, Cs=8, Hd=H, Wd=W, Cd=npad, R=k, S=k, pad=1, ks_g=8, n_g=npad, shift=bias)
+  check('conv_padded_out', nchw(ypad[..., :Cout].float().cpu()), want, dtype)
+  assert float(ypad[..., Cout:].float().abs().max()) == 0.0
+  check('nhwc_to_nchw', ops.nhwc_to_nchw(ypad, Cout).cpu(), want, dtype)
+  dy = rnd(B, Cout, H, W, dtype=dtype, seed=14)
+  want.backward(dy)
+  dyp = ops.nchw_to_nhwc_pad(dev(dy), dtype, npad)
+  dw = torch.zeros((Cout, Cin, k, k), device=DEV, dtype=torch.float32)
+  rmap = dev(torch.tensor(list(range(Cout)) + [-1] * (npad - Cout), dtype=torch.int32))
+  ops.conv_wgrad(dyp, xin, dw, B=B, Hs=H, Ws=W, Cs=8, Hd=H, Wd=W, Cd=npad, R=k, S=k, pad=1, ks_g=8, n_g=npad, c_real=Cin, row_map=rmap)
+  check('wgrad_padded', dw.cpu(), wr.grad, dtype)
+  db = torch.zeros(npad, device=DEV)
+  ops.colsum(dyp, db, B * H * W, npad)
+  check('colsum', db[:Cout].cpu(), dy.sum((0, 2, 3)), dtype)
+  # data gradient through the padded-output layout
+  wt = ops.pack_conv_weight(dev(w), dtype, n_pad=npad, transpose=True)
+  assert wt.shape == (1, Cin, k * k * npad)
+
+
+BG_CASES = [('nt', False, False, 320, 320, 56, 56), ('nn', False, True, 320, 56, 320, 56), ('tn', True, True, 56, 56, 320, 56),
+            ('nt_unaligned', False, False, 11, 65, 30, 30), ('nn_unaligned', False, True, 11, 30, 65, 30),
+            ('tt_unaligned', True, True, 65, 30, 11, 30), ('tn2', True, False, 64, 40, 96, 40)]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', BG_CASES, ids=[c[0] for c in BG_CASES])
+def test_bgemm(ops, case, dtype):
+  name, a_km, b_km, M, N, K, _ = case
+  nb0, nb1 = 2, 3
+  A = rnd(nb0, nb1, *( (K, M) if a_km else (M, K)), dtype=dtype, seed=21)
+  Bm = rnd(nb0, nb1, *((K, N) if b_km else (N, K)), dtype=dtype, seed=22)
+  bias = rnd(N, seed=23)
+  Am = A.transpose(-1, -2) if a_km else A
+  Bt = Bm if b_km else Bm.transpose(-1, -2)
+  want = 0.5 * (Am @ Bt) + bias
+  Ad, Bd = dev(A, dtype), dev(Bm, dtype)
+  C = torch.empty((nb0, nb1, M, N), device=DEV, dtype=dtype)
+  ops.bgemm(Ad, Bd, C, M=M, N=N, K=K, lda=A.shape[-1], ldb=Bm.shape[-1], ldc=N, batch0=nb0, batch1=nb1,
+            a_bs=(nb1 * A.shape[-2] * A.shape[-1], A.shape[-2] * A.shape[-1]),
+            b_bs=(nb1 * Bm.shape[-2] * Bm.shape[-1], Bm.shape[-2] * Bm.shape[-1]), c_bs=(nb1 * M * N, M * N), a_km=a_km, b_km=b_km,
+            alpha=0.5, bias=dev(bias))
+  check('bgemm.' + name, C, want, dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_pack2d(ops, dtype):
+  w = rnd(12, 10, seed=31)
+  rmap = torch.tensor([0, 1, -1, 3, 4, 5, -1, -1], dtype=torch.int32)
+  cmap = torch.tensor([9, 8, -1, 0], dtype=torch.int32)
+  out = torch.full((8, 6), 7.0, device=DEV, dtype=dtype)
+  ops.pack2d(dev(w), out, 8, 4, 10, 6, row_map=dev(rmap), col_map=dev(cmap), out_offset=1)
+  want = torch.zeros(8, 4)
+  for r in range(8):
+    for c in range(4):
+      if rmap[r] >= 0 and cmap[c] >= 0:
+        want[r, c] = w[rmap[r], cmap[c]]
+  flat = out.view(-1).float().cpu()
+  got = torch.stack([flat[1 + r * 6:1 + r * 6 + 4] for r in range(8)])
+  check('pack2d', got, want.to(dtype).float(), dtype, scale=2.0)
+  assert float(flat[0]) == 7.0 and float(flat[1 + 4]) == 7.0  # untouched outside the written block
+  out2 = torch.empty((10, 12), device=DEV, dtype=dtype)
+  ops.pack2d(dev(w), out2, 10, 12, 10, 12, transpose_in=True)
+  check('pack2d.T', out2, w.t().to(dtype).float(), dtype, scale=2.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('C', [32, 72, 1512])
+def test_batchnorm_train_and_backward(ops, dtype, C):
+  B, H, W = 3, 12, 20
+  x = rnd(B, C, H, W, dtype=dtype, seed=41) * 2.0 + 0.7
+  x = x.to(dtype).float()
+  gamma, beta = rnd(C, seed=42, lo=0.5, hi=1.5), rnd(C, seed=43)
+  rm, rv = rnd(C, seed=44), rnd(C, seed=45, lo=0.5, hi=1.5)
+  res = rnd(B, C, H, W, dtype=dtype, seed=46)
+  xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+  resr = res.clone().requires_grad_(True)
+  rm_ref, rv_ref = rm.clone(), rv.clone()
+  want = F.relu(F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5) + resr)
+  xd = dev(nhwc(x), dtype)
+  ws = torch.empty(2 * C, device=DEV, dtype=torch.float64)
+  ops.bn_stats(xd, ws)
+  scale, shift, sm, si = (torch.empty(C, device=DEV) for _ in range(4))
+  rmd, rvd, nbt = dev(rm), dev(rv), torch.zeros((), device=DEV, dtype=torch.long)
+  ops.bn_finalize(ws, dev(gamma), dev(beta), rmd, rvd, nbt, scale, shift, sm, si, B * H * W)
+  y = ops.affine_act(xd, scale=scale, shift=shift, res=dev(nhwc(res), dtype), act=ops.ACT_RELU)
+  check(f'bn{C}.fwd', nchw(y.float().cpu()), want, dtype)
+  check(f'bn{C}.running_mean', rmd.cpu(), rm_ref, torch.float32, scale=5.0)
+  check(f'bn{C}.running_var', rvd.cpu(), rv_ref, torch.float32, scale=5.0)
+  assert int(nbt.item()) == 1
+  dy = rnd(B, C, H, W, dtype=dtype, seed=47)
+  want.backward(dy)
+  dgamma, dbeta = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+  dx, dres = ops.bn_bwd(dev(nhwc(dy), dtype), y, xd, dev(gamma), sm, si, ws, dgamma, dbeta, relu_mask=True, want_dres=True)
+  # the ReLU mask is taken from the (rounded) output: compare on the reference mask of the same output
+  check(f'bn{C}.dx', nchw(dx.float().cpu()), xr.grad, dtype, scale=5.0)
+  check(f'bn{C}.dres', nchw(dres.float().cpu()), resr.grad, dtype, scale=5.0)
+  check(f'bn{C}.dgamma', dgamma.cpu(), gr.grad, dtype, scale=5.0)
+  check(f'bn{C}.dbeta', dbeta.cpu(), br.grad, dtype, scale=5.0)
+  # eval fold
+  ops.bn_fold(dev(gamma), dev(beta), dev(rm), dev(rv), scale, shift)
+  y2 = ops.affine_act(xd, scale=scale, shift=shift)
+  check(f'bn{C}.eval', nchw(y2.float().cpu()), F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5), dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_squeeze_excite(ops, dtype):
+  B, H, W, C, RD = 3, 10, 14, 72, 18
+  x = rnd(B, C, H, W, dtype=dtype, seed=51)
+  w1, b1, w2, b2 = rnd(RD, C, seed=52) * 0.3, rnd(RD, seed=53), rnd(C, RD, seed=54) * 0.5, rnd(C, seed=55)
+  ps = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+  s = ps[0].mean((2, 3))
+  gate_ref = torch.sigmoid(F.linear(F.relu(F.linear(s, ps[1], ps[2])), ps[3], ps[4]))
+  want = ps[0] * gate_ref.view(B, C, 1, 1)
+  xd = dev(nhwc(x), dtype)
+  pool = ops.mean_hw(xd)
+  check('se.pool', pool.cpu(), s, dtype)
+  hidden, gate = ops.se_gate_fwd(pool, dev(w1), dev(b1), dev(w2), dev(b2))
+  check('se.gate', gate.cpu(), gate_ref, dtype)
+  y = ops.affine_act(xd, gate=gate, rows_per_batch=H * W)
+  check('se.fwd', nchw(y.float().cpu()), want, dtype)
+  dy = rnd(B, C, H, W, dtype=dtype, seed=56)
+  want.backward(dy)
+  dyd = dev(nhwc(dy), dtype)
+  dgate = ops.se_dgate(dyd, xd)
+  grads = [torch.zeros_like(dev(t)) for t in (w1, b1, w2, b2)]
+  dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, dev(w1), dev(w2), *grads)
+  dx = ops.se_bwd_apply(dyd, gate, dpool)
+  check('se.dx', nchw(dx.float().cpu()), ps[0].grad, dtype, scale=3.0)
+  for nme, g, p in zip(('dw1', 'db1', 'dw2', 'db2'), grads, ps[1:]):
+    check('se.' + nme, g.cpu(), p.grad, dtype, scale=3.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_pool_and_bilinear(ops, dtype):
+  B, C = 2, 24
+  x = rnd(B, C, 16, 64, dtype=dtype, seed=61)
+  xr = x.clone().requires_grad_(True)
+  want = F.adaptive_avg_pool2d(xr, (8, 32))
+  y = ops.avgpool_fwd(dev(nhwc(x), dtype), 8, 32)
+  check('avgpool.fwd', nchw(y.float().cpu()), want, dtype)
+  dy = rnd(B, C, 8, 32, dtype=dtype, seed=62)
+  want.backward(dy)
+  base = rnd(B, C, 16, 64, dtype=dtype, seed=63)
+  dx = dev(nhwc(base), dtype)
+  ops.avgpool_bwd_add(dev(nhwc(dy), dtype), dx, 8, 32)
+  check('avgpool.bwd_add', nchw(dx.float().cpu()), base + xr.grad, dtype)
+  for (hi, wi, ho, wo) in [(8, 32, 64, 256), (8, 8, 16, 16), (16, 16, 64, 64), (8, 32, 8, 32), (4, 6, 20, 18)]:
+    t = rnd(B, C, hi, wi, dtype=dtype, seed=64)
+    tr = t.clone().requires_grad_(True)
+    basehi = rnd(B, C, ho, wo, dtype=dtype, seed=65)
+    mul = rnd(ho, wo, seed=66, lo=0.0, hi=1.0).round()
+    want = basehi + F.interpolate(tr, size=(ho, wo), mode='bilinear', align_corners=False) * mul
+    y = ops.bilinear_fwd(dev(nhwc(t), dtype), ho, wo, base=dev(nhwc(basehi), dtype), mul=dev(mul))
+    check(f'bilinear.fwd.{hi}x{wi}->{ho}x{wo}', nchw(y.float().cpu()), want, dtype)
+    g = rnd(B, C, ho, wo, dtype=dtype, seed=67)
+    want.backward(g)
+    dt_ = ops.bilinear_bwd(dev(nhwc(g), dtype), hi, wi, mul=dev(mul))
+    check(f'bilinear.bwd.{hi}x{wi}->{ho}x{wo}', nchw(dt_.float().cpu()), tr.grad, dtype, scale=2.0)
+  t = rnd(B, 8, 8, 8, dtype=dtype, seed=68)
+  yn = ops.bilinear_fwd(dev(nhwc(t), dtype), 32, 32, nchw_f32=True, c_real=5)
+  check('bilinear.nchw_out', yn.cpu(), F.interpolate(t, size=(32, 32), mode='bilinear', align_corners=False)[:, :5], dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('C', [72, 256, 1512])
+def test_layernorm(ops, dtype, C):
+  rows = 2100 if C == 72 else 330
+  x = rnd(rows, C, dtype=dtype, seed=71) * 3.0
+  x = x.to(dtype).float()
+  g, b = rnd(C, seed=72, lo=0.5, hi=1.5), rnd(C, seed=73)
+  xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+  want = F.layer_norm(xr, (C,), gr, br, 1e-5)
+  xd = dev(x, dtype)
+  y, mean, rstd = ops.layernorm_fwd(xd, dev(g), dev(b))
+  check(f'ln{C}.fwd', y, want, dtype)
+  dy = rnd(rows, C, dtype=dtype, seed=74)
+  want.backward(dy)
+  dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+  dx = ops.layernorm_bwd(dev(dy, dtype), xd, dev(g), mean, rstd, dg, db)
+  check(f'ln{C}.dx', dx, xr.grad, dtype, scale=3.0)
+  check(f'ln{C}.dgamma', dg.cpu(), gr.grad, dtype, scale=3.0)
+  check(f'ln{C}.dbeta', db.cpu(), br.grad, dtype, scale=3.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cols', [320, 65, 11])
+def test_softmax_and_dropout(ops, dtype, cols):
+  rows, alpha = 150, 0.37
+  x = rnd(rows, cols, dtype=dtype, seed=81) * 4.0
+  x = x.to(dtype).float()
+  xr = x.clone().requires_grad_(True)
+  want = F.softmax(xr * alpha, -1)
+  xd = dev(x, dtype)
+  p, pd = ops.softmax_fwd(xd, rows, cols, cols, alpha=alpha)
+  assert pd is p
+  check(f'softmax{cols}.fwd', p, want, dtype)
+  dp = rnd(rows, cols, dtype=dtype, seed=82)
+  want.backward(dp)
+  ds = ops.softmax_bwd(p, dev(dp, dtype), rows, cols, cols, alpha=alpha)
+  check(f'softmax{cols}.bwd', ds, xr.grad, dtype, scale=3.0)
+  # dropout: the forward mask and the mask regenerated in backward must agree; keep ratio ~ 1-p
+  xd = dev(x, dtype)
+  p, pd = ops.softmax_fwd(xd, rows, cols, cols, alpha=alpha, p_drop=0.1, seed=1234)
+  mask = (pd.float() != 0).float()
+  keep = mask.mean().item()
+  assert abs(keep - 0.9) < 0.03, keep
+  ones = torch.ones((rows, cols), device=DEV, dtype=dtype)
+  # with P uniform-ish the backward formula applied to dPd = 1 gives alpha*P*(mask/0.9 - sum(mask/0.9 * P))
+  ds = ops.softmax_bwd(p, ones.clone(), rows, cols, cols, alpha=alpha, p_drop=0.1, seed=1234)
+  m = mask / 0.9
+  want_ds = alpha * p.float() * (m - (m * p.float()).sum(-1, keepdim=True))
+  check(f'softmax{cols}.dropout_bwd', ds, want_ds.cpu(), dtype, scale=3.0)
+  a, b = rnd(4000, dtype=dtype, seed=83), rnd(4000, dtype=dtype, seed=84)
+  y0 = ops.add_dropout(dev(a, dtype), dev(b, dtype))
+  check('add', y0, a + b, dtype)
+  y1 = ops.add_dropout(None, dev(b, dtype), p_drop=0.1, seed=7)
+  y2 = ops.add_dropout(None, dev(b, dtype), p_drop=0.1, seed=7)
+  assert torch.equal(y1, y2)
+  kept = (y1.float() != 0).float().mean().item()
+  assert abs(kept - 0.9) < 0.03
+  nz = y1.float() != 0
+  check('dropout.scale', y1.float()[nz], (b / 0.9).to(DEV)[nz], dtype, scale=2.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_elementwise_misc(ops, dtype):
+  x = rnd(6, 40, 16, dtype=dtype, seed=91)
+  pe = rnd(40 * 16, seed=92)
+  check('add_bcast', ops.add_bcast(dev(x, dtype), dev(pe)), x + pe.view(1, 40, 16), dtype)
+  for act, fn in ((ops.ACT_RELU, F.relu), (ops.ACT_SIGMOID, torch.sigmoid), (ops.ACT_TANH, torch.tanh)):
+    xr = x.clone().requires_grad_(True)
+    y = fn(xr)
+    dy = rnd(6, 40, 16, dtype=dtype, seed=93)
+    y.backward(dy)
+    yq = y.detach().to(dtype).float()
+    got = ops.act_bwd(dev(dy, dtype), dev(yq, dtype), act)
+    check(f'act_bwd{act}', got, xr.grad, dtype, scale=3.0)
+  xr = x.clone().requires_grad_(True)
+  F.gelu(xr).backward(dy)
+  check('act_bwd_gelu', ops.act_bwd(dev(dy, dtype), dev(x, dtype), ops.ACT_GELU), xr.grad, dtype, scale=3.0)
+  m = rnd(40, seed=94, lo=0, hi=1).round()
+  check('mul_pixmask', ops.mul_pixmask(dev(x, dtype), dev(m), 40), x * m.view(1, 40, 1), dtype)
+  y = dev(x, dtype)
+  ops.axpy(dev(x, dtype), y, 0.5)
+  check('axpy', y, 1.5 * x, dtype)
+  check('cast', ops.cast(dev(x), dtype), x, dtype)
+
+
+def test_gru(ops):
+  B, T, I, H = 5, 10, 256, 64
+  gru = torch.nn.GRU(I, H, batch_first=True)
+  enc, dec = torch.nn.Linear(2, H), torch.nn.Linear(H, 2)
+  x, tp = rnd(B, T, I, seed=101), rnd(B, 2, seed=102) * 10
+  xr = x.clone().requires_grad_(True)
+  h0 = enc(tp)
+  h0.retain_grad()
+  out, _ = gru(xr, h0.unsqueeze(0))
+  want = torch.cumsum(dec(out.reshape(B * T, H)).reshape(B, T, 2), 1)
+  gi = F.linear(x, gru.weight_ih_l0, gru.bias_ih_l0).detach()
+  d = lambda t: dev(t.detach().contiguous())
+  pred, save = ops.gru_fwd(d(gi), d(h0), d(gru.weight_hh_l0), d(gru.bias_hh_l0), d(dec.weight), d(dec.bias))
+  check('gru.fwd', pred, want, torch.float32, scale=5.0)
+  dout = rnd(B, T, 2, seed=103)
+  want.backward(dout)
+  gr = [torch.zeros_like(d(t)) for t in (gru.weight_hh_l0, gru.bias_hh_l0, dec.weight, dec.bias)]
+  dgi, dh0 = ops.gru_bwd(d(dout), save, d(h0), d(gru.weight_hh_l0), d(gru.bias_hh_l0), d(dec.weight), *gr)
+  check('gru.dh0', dh0, h0.grad, torch.float32, scale=10.0)
+  check('gru.dw_hh', gr[0], gru.weight_hh_l0.grad, torch.float32, scale=10.0)
+  check('gru.db_hh', gr[1], gru.bias_hh_l0.grad, torch.float32, scale=10.0)
+  check('gru.dw_dec', gr[2], dec.weight.grad, torch.float32, scale=10.0)
+  check('gru.db_dec', gr[3], dec.bias.grad, torch.float32, scale=10.0)
+  check('gru.dgi->dx', dgi.cpu() @ gru.weight_ih_l0.detach(), xr.grad, torch.float32, scale=10.0)
+  check('gru.dgi->db_ih', dgi.cpu().sum((0, 1)), gru.bias_ih_l0.grad, torch.float32, scale=10.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_losses(ops, dtype):
+  B, H, W = 2, 16, 24
+  HW = H * W
+  # weighted CE with ignore via visibility mask (BEV semantic)
+  C, ld = 11, 16
+  pred = rnd(B, C, H, W, dtype=dtype, seed=111) * 3
+  pred = pred.to(dtype).float()
+  lab = torch.randint(0, C, (B, H, W), generator=torch.Generator().manual_seed(1))
+  vis = (rnd(H, W, seed=112, lo=0, hi=1) > 0.4).float()
+  cw = rnd(C, seed=113, lo=0.5, hi=2.0)
+  pr = pred.clone().requires_grad_(True)
+  lab_eff = ((vis.long() - 1) + vis.long() * lab)
+  want = F.cross_entropy(pr, lab_eff, weight=cw, ignore_index=-1)
+  (0.3 * want).backward()
+  pd = dev(F.pad(nhwc(pred), (0, ld - C)), dtype)
+  loss, ws = torch.zeros(1, device=DEV), torch.zeros(2, device=DEV)
+  dp = torch.full((B, H, W, ld), 9.0, device=DEV, dtype=dtype)
+  ops.ce_loss(pd, dev(lab), loss, ws, rows=B * HW, C=C, ld=ld, HW=HW, class_weight=dev(cw), vis_mask=dev(vis), weight=0.3, dpred=dp)
+  check('ce.vis.loss', loss.cpu(), want.detach().view(1), dtype)
+  check('ce.vis.grad', nchw(dp[..., :C].float().cpu()), pr.grad, dtype, scale=3.0)
+  assert float(dp[..., C:].float().abs().max()) == 0.0
+  # pixel-weighted CE / avg_factor (yaw class)
+  C, ld = 12, 16
+  pred = (rnd(B, C, H, W, dtype=dtype, seed=114) * 3).to(dtype).float()
+  lab = torch.randint(0, C, (B, H, W), generator=torch.Generator().manual_seed(2))
+  pw = (rnd(B, 2, H, W, seed=115, lo=0, hi=1) > 0.8).float()
+  af = torch.tensor([3.0, 2.0])
+  pr = pred.clone().requires_grad_(True)
+  den = af.sum() + torch.finfo(torch.float32).eps
+  want = (F.cross_entropy(pr, lab, reduction='none') * pw[:, 0]).sum() / den
+  want.backward()
+  afs = torch.zeros(1, device=DEV)
+  ops.sum_f32(dev(af), afs)
+  loss.zero_()
+  dp = torch.empty((B, H, W, ld), device=DEV, dtype=dtype)
+  ops.ce_loss(dev(F.pad(nhwc(pred), (0, ld - C)), dtype), dev(lab), loss, ws, rows=B * HW, C=C, ld=ld, HW=HW, pix_weight=dev(pw),
+              pw_bstride=2 * HW, denom=afs, denom_eps=float(torch.finfo(torch.float32).eps), dpred=dp)
+  check('ce.pw.loss', loss.cpu(), want.detach().view(1), dtype)
+  check('ce.pw.grad', nchw(dp[..., :C].float().cpu()), pr.grad, dtype, scale=3.0)
+  # L1 mean (depth), masked L1 / (avg_factor*2) (wh), smooth-L1 with broadcast weight (yaw_res), gaussian focal
+  for nme, C, ld, kind in (('l1', 1, 8, 0), ('wh', 2, 8, 0), ('yawres', 1, 8, 1), ('focal', 4, 8, 2)):
+    if kind == 2:
+      pred = torch.sigmoid(rnd(B, C, H, W, dtype=dtype, seed=116) * 3).to(dtype).float()
+      tgt = rnd(B, C, H, W, seed=117, lo=0, hi=1)
+      tgt[0, 1, 3, 4] = 1.0
+      tgt[1, 2, 7, 9] = 1.0
+    else:
+      pred = (rnd(B, C, H, W, dtype=dtype, seed=118) * 2).to(dtype).float()
+      tgt = rnd(B, C, H, W, seed=119)
+    pr = pred.clone().requires_grad_(True)
+    kw = dict(B=B, C=C, HW=HW, ld=ld, kind=kind, weight=0.7)
+    if nme == 'l1':
+      want = F.l1_loss(pr, tgt)
+    elif nme == 'wh':
+      want = (torch.abs(pr - tgt) * pw).sum() / (den * 2)
+      kw.update(elem_weight=dev(pw), wC=2, denom=afs, denom_eps=float(torch.finfo(torch.float32).eps), denom_mul=2.0)
+    elif nme == 'yawres':
+      want = (F.smooth_l1_loss(pr, tgt, reduction='none') * pw[:, 0:1]).sum() / den
+      kw.update(elem_weight=dev(pw), wC=2, w_bcast=True, denom=afs, denom_eps=float(torch.finfo(torch.float32).eps))
+    else:
+      eps = 1e-12
+      pos = tgt.eq(1)
+      want = (-(pr + eps).log() * (1 - pr).pow(2) * pos - (1 - pr + eps).log() * pr.pow(2) * (1 - tgt).pow(4)).sum() / den
+      kw.update(denom=afs, denom_eps=float(torch.finfo(torch.float32).eps))
+    (0.7 * want).backward()
+    loss.zero_()
+    dp = torch.full((B, H, W, ld), 5.0, device=DEV, dtype=dtype)
+    ops.reg_loss(dev(F.pad(nhwc(pred), (0, ld - C)), dtype), dev(tgt), loss, dpred=dp, **kw)
+    check(f'reg.{nme}.loss', loss.cpu(), want.detach().view(1), dtype)
+    check(f'reg.{nme}.grad', nchw(dp[..., :C].float().cpu()), pr.grad, dtype, scale=3.0)
+    assert float(dp[..., C:].float().abs().max()) == 0.0
+
+
+def test_adamw_amsgrad(ops):
+  n = 10007
+  p0, g = rnd(n, seed=121), rnd(n, seed=122)
+  pt = torch.nn.Parameter(p0.clone())
+  opt = torch.optim.AdamW([pt], lr=3e-4, amsgrad=True, weight_decay=0.01)
+  p, m, v, vm = dev(p0.clone()), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+  for step in range(1, 4):
+    gs = g * step
+    pt.grad = gs.clone()
+    opt.step()
+    ops.adamw_amsgrad(p, dev(gs * 2.0), m, v, vm, 3e-4, 0.9, 0.999, 1e-8, 0.01, step, grad_scale=0.5)
+  check('adamw', p.cpu() - p0, pt.detach() - p0, torch.float32, scale=5.0)
+
+
+def test_bn1d_scalar(ops):
+  x = rnd(12, 1, seed=131) * 4 + 3
+  rm, rv = torch.tensor([2.5]), torch.tensor([6.0])
+  want_eval = F.batch_norm(x, rm, rv, None, None, False, 0.1, 1e-5)
+  rmd, rvd, nbt = dev(rm), dev(rv), torch.zeros((), device=DEV, dtype=torch.long)
+  check('bn1d.eval', ops.bn1d_scalar(dev(x), rmd, rvd, nbt, False), want_eval, torch.float32)
+  rm2, rv2 = rm.clone(), rv.clone()
+  want_tr = F.batch_norm(x, rm2, rv2, None, None, True, 0.1, 1e-5)
+  check('bn1d.train', ops.bn1d_scalar(dev(x), rmd, rvd, nbt, True), want_tr, torch.float32)
+  check('bn1d.rm', rmd.cpu(), rm2, torch.float32)
+  check('bn1d.rv', rvd.cpu(), rv2, torch.float32)
