@@ -1,0 +1,110 @@
+"""Configuration for the MI355X TransFuser++ path.
+
+``LidarCenterNet(config)`` accepts the reference's own ``GlobalConfig`` object (team_code/config.py) unchanged -- it
+only reads attributes -- or this stand-alone ``GlobalConfig`` which carries the same attribute names with the
+reference defaults for the attributes the hot path reads.  Two additive attributes select the backend precision
+(old ``config.pickle`` files that lack them keep working, see sensor_agent.py:65-71):
+  ``tfpp_dtype``        'fp32' (default; parity / inference) or 'bf16' (training throughput)
+"""
+
+
+class GlobalConfig:
+  """Attribute bag with the reference defaults (team_code/config.py line numbers in comments)."""
+
+  def __init__(self, **overrides):
+    # sensors (config.py:100-121)
+    self.camera_pos = [-1.5, 0.0, 2.0]
+    self.camera_rot_0 = [0.0, 0.0, 0.0]
+    self.camera_width = 1024
+    self.camera_height = 256
+    self.camera_fov = 110
+    self.seq_len = 1
+    self.img_seq_len = 1
+    self.lidar_seq_len = 1
+    self.lidar_resolution_width = 256
+    self.lidar_resolution_height = 256
+    self.pixels_per_meter = 4.0
+    self.use_ground_plane = False
+    self.min_x, self.max_x, self.min_y, self.max_y = -32, 32, -32, 32  # config.py:135-138
+    self.min_z_projection, self.max_z_projection = -10, 14  # config.py:141-142
+    self.bev_grid_height_downsample_factor = 1.0
+    # training / model selection (config.py:185-256)
+    self.detect_boxes = 1
+    self.backbone = 'transFuser'
+    self.use_velocity = 1
+    self.image_architecture = 'regnety_032'
+    self.lidar_architecture = 'regnety_032'
+    self.use_controller_input_prediction = True
+    self.use_focal_loss = False
+    self.use_speed_weights = True
+    self.use_label_smoothing = False
+    self.label_smoothing_alpha = 0.1
+    self.use_bev_semantic = True
+    self.use_depth = True
+    self.use_semantic = True
+    self.use_wp_gru = False
+    self.use_discrete_command = True
+    self.use_tp = True
+    self.tp_attention = False
+    self.multi_wp_output = False
+    self.transformer_decoder_join = True
+    self.normalize_imagenet = True
+    self.target_speeds = [0.0, 2.0, 5.0, 8.0]  # config.py:148 (values only matter for the host-side controller)
+    self.target_speed_weights = [0.866605263873406, 7.4527377240841775, 1.2281629310898465, 0.5269622904065803]
+    self.semantic_weights = [1.0] * 7
+    self.bev_semantic_weights = [1.0] * 11
+    self.pred_len = 8
+    self.wp_dilation = 1
+    self.predict_checkpoint_len = 10
+    # architecture sizes (config.py:329-363, 468-469)
+    self.gru_hidden_size = 64
+    self.gru_input_size = 256
+    self.extra_sensor_channels = 128
+    self.img_vert_anchors = self.camera_height // 32
+    self.img_horz_anchors = self.camera_width // 32
+    self.lidar_vert_anchors = self.lidar_resolution_height // 32
+    self.lidar_horz_anchors = self.lidar_resolution_width // 32
+    self.perspective_downsample_factor = 1
+    self.bev_features_chanels = 64
+    self.bev_down_sample_factor = 4
+    self.bev_upsample_factor = 2
+    self.block_exp = 4
+    self.n_layer = 2
+    self.n_head = 4
+    self.embd_pdrop = 0.1
+    self.resid_pdrop = 0.1
+    self.attn_pdrop = 0.1
+    self.gpt_linear_layer_init_mean = 0.0
+    self.gpt_linear_layer_init_std = 0.02
+    self.gpt_layer_norm_init_weight = 1.0
+    self.num_transformer_decoder_layers = 6
+    self.num_decoder_heads = 8
+    self.num_semantic_classes = 7
+    self.num_bev_semantic_classes = 11
+    self.deconv_channel_num_0 = 128
+    self.deconv_channel_num_1 = 64
+    self.deconv_channel_num_2 = 32
+    self.deconv_scale_factor_0 = 4
+    self.deconv_scale_factor_1 = 8
+    self.bb_input_channel = 64
+    self.num_bb_classes = 4
+    self.num_dir_bins = 12
+    # optimisation (config.py:171-209)
+    self.lr = 0.0003
+    self.batch_size = 32
+    # PID controller constants used by the host-side control_pid* helpers (config.py:395-421)
+    self.turn_kp, self.turn_ki, self.turn_kd, self.turn_n = 1.25, 0.75, 0.3, 20
+    self.speed_kp, self.speed_ki, self.speed_kd, self.speed_n = 5.0, 0.5, 1.0, 20
+    self.brake_speed, self.brake_ratio = 0.4, 1.1
+    self.clip_delta, self.clip_throttle = 0.25, 0.75
+    self.aim_distance_fast, self.aim_distance_slow, self.aim_distance_threshold = 3.0, 2.25, 5.5
+    self.carla_fps, self.data_save_freq = 20, 5
+    # MI355X backend selection (additive)
+    self.tfpp_dtype = 'fp32'
+    for k, v in overrides.items():
+      setattr(self, k, v)
+
+
+def cfg_get(config, name, default):
+  """Attribute lookup that tolerates old pickled configs without the additive ``tfpp_*`` attributes."""
+  return getattr(config, name, default)

@@ -793,3 +793,43 @@ extern "C" int tfpp_se_bwd_apply(const void* dy, const float* gate, const float*
   TFPP_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// small token plumbing: dst[b*dst_bs + dst_off + i] (+)= src[b*src_bs + src_off + i], i in [0, n)  (concat / split /
+// broadcast of token blocks; src_bs = 0 broadcasts a learned query over the batch)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void copy_rows_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int B, long n, long src_bs, long src_off, long dst_bs,
+                                 long dst_off, int accumulate) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * n, stride = (long)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const long b = i / n, k = i - b * n;
+    float v = ElemTraits<TI>::to_f(src[b * src_bs + src_off + k]);
+    TO* d = dst + b * dst_bs + dst_off + k;
+    if (accumulate) v += ElemTraits<TO>::to_f(*d);
+    *d = ElemTraits<TO>::from_f(v);
+  }
+}
+
+extern "C" int tfpp_copy_rows(const void* src, void* dst, int B, int64_t n, int64_t src_bs, int64_t src_off, int64_t dst_bs,
+                              int64_t dst_off, int accumulate, int dtype_in, int dtype_out, void* stream) {
+  if (!src || !dst) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g = grid_stride((long)B * n), b(PW_THREADS);
+#define CR(TI, TO) hipLaunchKernelGGL((copy_rows_kernel<TI, TO>), g, b, 0, st, (const TI*)src, (TO*)dst, B, (long)n, (long)src_bs, (long)src_off, (long)dst_bs, (long)dst_off, accumulate)
+  if (dtype_in == TFPP_F32 && dtype_out == TFPP_F32) CR(float, float);
+  else if (dtype_in == TFPP_F32 && dtype_out == TFPP_BF16) CR(float, bf16_t);
+  else if (dtype_in == TFPP_BF16 && dtype_out == TFPP_F32) CR(bf16_t, float);
+  else if (dtype_in == TFPP_BF16 && dtype_out == TFPP_BF16) CR(bf16_t, bf16_t);
+  else return TFPP_EINVAL;
+#undef CR
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tfpp_zero(void* p, int64_t bytes, void* stream) {
+  if (!p) return TFPP_EINVAL;
+  hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : -(int)e;
+}

@@ -1,0 +1,864 @@
+"""Execution engine of the MI355X TransFuser++ path: forward and hand-written backward over HIP kernels.
+
+The reference expresses the model as ~1100 ATen calls recorded by torch.autograd
+(team_code/model.py:279-392 and team_code/transfuser.py:139-257).  Here the same arithmetic is a static sequence of
+launches of ``libtfpp_hip.so`` kernels (carla_garage_amd/ops.py) on NHWC activations; every forward primitive pushes
+its own backward closure on a small tape, so the backward pass is again a static launch sequence with no ATen
+kernels and can be captured into one hipGraph together with the optimizer step (carla_garage_amd/trainer.py).
+
+Precision: the RegNet branches, fusion transformers and dense decoders run in ``dtype`` (fp32 or bf16 storage,
+fp32 MFMA accumulation); the planning head (65-token decoder, GRU, MLPs: M <= 780 rows, launch-bound) always runs
+in fp32.
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
+
+F32 = torch.float32
+EPS_F32 = float(torch.finfo(torch.float32).eps)
+
+
+def _key(t):
+  return (t.data_ptr(), t.numel())
+
+
+class Tape:
+  """Reverse-mode tape: nodes are (outputs, inputs, backward_fn(*grad_outputs) -> grad_inputs).
+
+  Tensors are identified by (data_ptr, numel) so reshaped views of one buffer are the same node; the tape keeps every
+  recorded tensor alive, so a key cannot be reused while it is pending."""
+
+  def __init__(self):
+    self.nodes = []
+
+  def record(self, outs, ins, fn):
+    self.nodes.append((outs, ins, fn))
+
+  def backward(self, seeds):
+    """seeds: list of (tensor, grad)."""
+    grads, refs = {}, {}
+
+    def acc(t, g):
+      if t is None or g is None:
+        return
+      k = _key(t)
+      cur = grads.get(k)
+      if cur is None:
+        grads[k] = g
+        refs[id(g)] = refs.get(id(g), 0) + 1
+      elif refs.get(id(cur), 0) > 1:  # the stored gradient object is also pending under another key: do not mutate it
+        refs[id(cur)] -= 1
+        new = ops.add_dropout(cur, g if g.dtype == cur.dtype else ops.cast(g, cur.dtype))
+        grads[k] = new
+        refs[id(new)] = 1
+      else:
+        ops.axpy(g if g.dtype == cur.dtype else ops.cast(g, cur.dtype), cur, 1.0)
+
+    for t, g in seeds:
+      acc(t, g)
+    for outs, ins, fn in reversed(self.nodes):
+      gouts = []
+      for o in outs:
+        g = grads.pop(_key(o), None)
+        if g is not None:
+          refs[id(g)] = refs.get(id(g), 1) - 1
+        gouts.append(g)
+      if all(g is None for g in gouts):
+        continue
+      gins = fn(*gouts)
+      if gins is None:
+        gins = ()
+      if not isinstance(gins, (tuple, list)):
+        gins = (gins,)
+      for t, g in zip(ins, gins):
+        acc(t, g)
+    self.nodes = []
+
+
+class ConvSpec:
+  """One convolution / linear layer: geometry, parameters, packed kernel images."""
+
+  def __init__(self, name, weight, bias=None, bn=None, stride=1, pad=0, groups=1, cin_store=None, head=False):
+    self.name = name
+    self.weight, self.bias, self.bn = weight, bias, bn
+    w4 = weight if weight.dim() == 4 else weight.view(weight.shape[0], weight.shape[1], 1, 1)
+    self.cout, self.cin_g, self.k = w4.shape[0], w4.shape[1], w4.shape[2]
+    self.stride, self.pad, self.groups = stride, pad, groups
+    self.head = head  # fp32 planning-head layer
+    # storage channel counts: inputs may be zero-padded (stem: 3 -> 8); outputs padded to a multiple of 8
+    self.cin_store = cin_store if cin_store is not None else self.cin_g * groups
+    self.n_store = self.cout if groups > 1 else ops.pad_to(self.cout, 8)
+    self.wp = self.wt = self.bias_pad = None
+    self.scale = self.shift = None  # folded BN (eval)
+    self.row_map = None
+    self.packed_for = None
+
+
+class Engine:
+
+  def __init__(self, model):
+    self.m = model
+    self.cfg = model.config
+    self.dtype = F32
+    self.tape = None
+    self.training = False
+    self.seed = 0x5EED
+    self._seed_ctr = 0
+    self.specs = {}
+    self.grads = {}  # param name -> fp32 grad tensor (views of self.flat_grad)
+    self.flat_grad = None
+    self._consts = {}
+    self._packed_key = None
+    self._build_specs()
+
+  # ------------------------------------------------------------------------------------------------ set-up
+  def _spec(self, key, *a, **k):
+    self.specs[key] = ConvSpec(key, *a, **k)
+    return self.specs[key]
+
+  def _build_specs(self):
+    m = self.m
+    bb = m.backbone
+    for br, enc in (('image_encoder', bb.image_encoder), ('lidar_encoder', bb.lidar_encoder)):
+      p = f'backbone.{br}'
+      self._spec(f'{p}.stem', enc['stem'].conv.weight, bn=enc['stem'].bn, stride=2, pad=1, cin_store=8)
+      for si in range(1, 5):
+        for bname, blk in enc[f's{si}'].named_children():
+          q = f'{p}.s{si}.{bname}'
+          self._spec(q + '.conv1', blk.conv1.conv.weight, bn=blk.conv1.bn)
+          self._spec(q + '.conv2', blk.conv2.conv.weight, bn=blk.conv2.bn, stride=blk.stride, pad=1,
+                     groups=blk.conv2.conv.groups)
+          self._spec(q + '.conv3', blk.conv3.conv.weight, bn=blk.conv3.bn)
+          if blk.downsample is not None:
+            self._spec(q + '.downsample', blk.downsample.conv.weight, bn=blk.downsample.bn, stride=blk.stride)
+    for i in range(4):
+      for nme in ('lidar_channel_to_img', 'img_channel_to_lidar'):
+        conv = getattr(bb, nme)[i]
+        self._spec(f'backbone.{nme}.{i}', conv.weight, conv.bias)
+      g = bb.transformers[i]
+      for l, blk in enumerate(g.blocks):
+        q = f'backbone.transformers.{i}.blocks.{l}'
+        self._spec(q + '.attn.proj', blk.attn.proj.weight, blk.attn.proj.bias)
+        self._spec(q + '.mlp.0', blk.mlp[0].weight, blk.mlp[0].bias)
+        self._spec(q + '.mlp.2', blk.mlp[2].weight, blk.mlp[2].bias)
+    if hasattr(bb, 'c5_conv'):
+      self._spec('backbone.c5_conv', bb.c5_conv.weight, bb.c5_conv.bias)
+      self._spec('backbone.up_conv5', bb.up_conv5.weight, bb.up_conv5.bias, pad=1)
+      self._spec('backbone.up_conv4', bb.up_conv4.weight, bb.up_conv4.bias, pad=1)
+    if self.cfg.detect_boxes:
+      for n in m.head.BRANCHES:
+        seq = getattr(m.head, n + '_head')
+        self._spec(f'head.{n}_head.0', seq[0].weight, seq[0].bias, pad=1)
+        self._spec(f'head.{n}_head.2', seq[2].weight, seq[2].bias)
+    for dec_name in ('semantic_decoder', 'depth_decoder'):
+      if hasattr(m, dec_name):
+        dec = getattr(m, dec_name)
+        for blk in ('deconv1', 'deconv2', 'deconv3'):
+          for j in (0, 2):
+            conv = getattr(dec, blk)[j]
+            self._spec(f'{dec_name}.{blk}.{j}', conv.weight, conv.bias, pad=1)
+    if self.cfg.use_bev_semantic:
+      self._spec('bev_semantic_decoder.0', m.bev_semantic_decoder[0].weight, m.bev_semantic_decoder[0].bias, pad=1)
+      self._spec('bev_semantic_decoder.2', m.bev_semantic_decoder[2].weight, m.bev_semantic_decoder[2].bias)
+    self._spec('change_channel', m.change_channel.weight, m.change_channel.bias)
+    # planning head (fp32): weights are used in place ([out,in] fp32 is already the kernel layout)
+    h = dict(head=True)
+    self._spec('extra_sensor_encoder.0', m.extra_sensor_encoder[0].weight, m.extra_sensor_encoder[0].bias, cin_store=8, **h)
+    self._spec('extra_sensor_encoder.2', m.extra_sensor_encoder[2].weight, m.extra_sensor_encoder[2].bias, **h)
+    for l, layer in enumerate(m.join.layers):
+      q = f'join.layers.{l}'
+      self._spec(q + '.self_attn.out_proj', layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias, **h)
+      self._spec(q + '.multihead_attn.out_proj', layer.multihead_attn.out_proj.weight, layer.multihead_attn.out_proj.bias, **h)
+      self._spec(q + '.linear1', layer.linear1.weight, layer.linear1.bias, **h)
+      self._spec(q + '.linear2', layer.linear2.weight, layer.linear2.bias, **h)
+    for dn in ('checkpoint_decoder', 'wp_decoder'):
+      if hasattr(m, dn):
+        d = getattr(m, dn)
+        self._spec(dn + '.gru.ih', d.gru.weight_ih_l0, d.gru.bias_ih_l0, **h)
+        self._spec(dn + '.encoder', d.encoder.weight, d.encoder.bias, cin_store=4, **h)
+    if hasattr(m, 'target_speed_network'):
+      self._spec('target_speed_network.0', m.target_speed_network[0].weight, m.target_speed_network[0].bias, **h)
+      self._spec('target_speed_network.2', m.target_speed_network[2].weight, m.target_speed_network[2].bias, **h)
+
+  def _const(self, key, fn):
+    dev = self.device
+    k = (key, str(dev))
+    if k not in self._consts:
+      self._consts[k] = fn().to(dev)
+    return self._consts[k]
+
+  @property
+  def device(self):
+    return self.m.change_channel.weight.device
+
+  def next_seed(self):
+    self._seed_ctr += 1
+    return (self.seed * 1000003 + self._seed_ctr) & 0xFFFFFFFFFFFF
+
+  # ------------------------------------------------------------------------------------------------ weights
+  def _weights_key(self, dtype, need_t):
+    return (dtype, need_t, tuple((p.data_ptr(), p._version) for p in self.m.parameters()),
+            tuple((b.data_ptr(), b._version) for b in self.m.buffers()) if not self.training else None)
+
+  def prepare(self, dtype, training, need_grad):
+    """(Re)pack weights for ``dtype`` when parameters changed; fold BN for eval."""
+    self.dtype, self.training = dtype, training
+    key = self._weights_key(dtype, need_grad)
+    if key == self._packed_key:
+      return
+    self.repack(dtype, need_grad)
+    self._packed_key = self._weights_key(dtype, need_grad)
+
+  def repack(self, dtype, need_t):
+    dev = self.device
+    for s in self.specs.values():
+      dt_ = F32 if s.head else dtype
+      w = s.weight.detach()
+      w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
+      ks_pad = s.cin_store // s.groups
+      plain = (dt_ == F32 and s.k == 1 and ks_pad == s.cin_g and s.n_store == s.cout and s.groups == 1)
+      if plain:
+        s.wp = w4.view(1, s.cout, s.cin_g)  # fp32 [out,in] is the kernel layout already
+      else:
+        s.wp = ops.pack_conv_weight(w4, dt_, G=s.groups, ks_pad=ks_pad, n_pad=s.n_store // s.groups)
+      s.wt = ops.pack_conv_weight(w4, dt_, G=s.groups, n_pad=s.n_store // s.groups, transpose=True) if need_t else None
+      if s.bias is not None:
+        if s.n_store == s.cout:
+          s.bias_pad = s.bias.detach()
+        else:
+          if s.bias_pad is None or s.bias_pad.numel() != s.n_store or s.bias_pad.device != dev:
+            s.bias_pad = ops.zeros(s.n_store, F32, dev)
+          ops.copy_rows(s.bias.detach(), s.bias_pad, 1, s.cout, 0, 0, 0, 0)
+      if s.n_store != s.cout and s.row_map is None:
+        s.row_map = torch.tensor(list(range(s.cout)) + [-1] * (s.n_store - s.cout), dtype=torch.int32).to(dev)
+      if s.bn is not None:
+        if s.scale is None or s.scale.device != dev:
+          s.scale = torch.empty(s.cout, device=dev, dtype=F32)
+          s.shift = torch.empty(s.cout, device=dev, dtype=F32)
+          s.save_mean = torch.empty(s.cout, device=dev, dtype=F32)
+          s.save_invstd = torch.empty(s.cout, device=dev, dtype=F32)
+          s.ws = torch.empty(2 * s.cout, device=dev, dtype=torch.float64)
+        if not (self.training and s.bn.training):
+          ops.bn_fold(s.bn.weight.detach(), s.bn.bias.detach(), s.bn.running_mean, s.bn.running_var, s.scale, s.shift, s.bn.eps)
+    # fusion-transformer QKV: fused, head-padded images
+    for i, g in enumerate(self.m.backbone.transformers):
+      c, nh = g.n_embd, self.cfg.n_head
+      d = c // nh
+      dp = ops.pad_to(d, 8)
+      rmap = torch.full((nh * dp,), -1, dtype=torch.int32)
+      for hh in range(nh):
+        rmap[hh * dp:hh * dp + d] = torch.arange(hh * d, (hh + 1) * d, dtype=torch.int32)
+      rmap = self._const(f'qkv_rmap{i}', lambda rmap=rmap: rmap)
+      inv = torch.full((c,), -1, dtype=torch.int32)  # parameter column -> packed column
+      inv[rmap.cpu()[rmap.cpu() >= 0].long()] = torch.nonzero(rmap.cpu() >= 0).flatten().to(torch.int32)
+      inv = self._const(f'qkv_inv{i}', lambda inv=inv: inv)
+      for l, blk in enumerate(g.blocks):
+        st = self._attn_state(i, l)
+        st.update(c=c, nh=nh, d=d, dp=dp, rmap=rmap, inv=inv)
+        npk = 3 * nh * dp
+        st['wqkv'] = torch.empty((npk, c), device=dev, dtype=dtype)
+        st['bqkv'] = ops.zeros(npk, F32, dev)
+        for j, lin in enumerate((blk.attn.query, blk.attn.key, blk.attn.value)):
+          ops.pack2d(lin.weight.detach(), st['wqkv'], nh * dp, c, c, c, row_map=rmap, out_offset=j * nh * dp * c)
+          ops.pack2d(lin.bias.detach(), st['bqkv'], 1, nh * dp, c, nh * dp, col_map=rmap, out_offset=j * nh * dp)
+        st['wproj'] = torch.empty((c, nh * dp), device=dev, dtype=dtype)
+        ops.pack2d(blk.attn.proj.weight.detach(), st['wproj'], c, nh * dp, c, nh * dp, col_map=rmap)
+        if need_t:
+          st['wqkv_t'] = torch.empty((c, npk), device=dev, dtype=dtype)
+          for j, lin in enumerate((blk.attn.query, blk.attn.key, blk.attn.value)):
+            ops.pack2d(lin.weight.detach(), st['wqkv_t'], c, nh * dp, c, npk, col_map=rmap, transpose_in=True,
+                       out_offset=j * nh * dp)
+          st['wproj_t'] = torch.empty((nh * dp, c), device=dev, dtype=dtype)
+          ops.pack2d(blk.attn.proj.weight.detach(), st['wproj_t'], nh * dp, c, c, c, row_map=rmap, transpose_in=True)
+
+  def _attn_state(self, i, l):
+    if not hasattr(self, '_attn'):
+      self._attn = {}
+    return self._attn.setdefault((i, l), {})
+
+  # ------------------------------------------------------------------------------------------------ gradients
+  def alloc_grads(self):
+    params = [(n, p) for n, p in self.m.named_parameters() if p.requires_grad]
+    total = sum(ops.pad_to(p.numel(), 4) for _, p in params)
+    if self.flat_grad is None or self.flat_grad.numel() != total or self.flat_grad.device != self.device:
+      self.flat_grad = torch.empty(total, device=self.device, dtype=F32)
+      self.grads = {}
+      off = 0
+      for n, p in params:
+        self.grads[n] = self.flat_grad[off:off + p.numel()].view(p.shape)
+        off += ops.pad_to(p.numel(), 4)
+      self._gid = {id(p): n for n, p in params}
+    ops.zero_(self.flat_grad)
+
+  def g(self, param):
+    n = self._gid.get(id(param))
+    return None if n is None else self.grads[n]
+
+  # ------------------------------------------------------------------------------------------------ primitives
+  def rec(self, outs, ins, fn):
+    if self.tape is not None:
+      self.tape.record(outs, ins, fn)
+
+  def conv(self, x, key, act=ACT_NONE, res=None, x_grad=True, out_f32=False):
+    """x: [B,H,W,Cstore] NHWC.  Returns [B,Ho,Wo,n_store]."""
+    s = self.specs[key]
+    B, H, W, Cs = x.shape
+    k, st, pd, G = s.k, s.stride, s.pad, s.groups
+    Ho, Wo = (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
+    odt = F32 if (out_f32 or s.head) else x.dtype
+    geo = dict(B=B, Hs=H, Ws=W, Cs=Cs, Hd=Ho, Wd=Wo, Cd=s.n_store, R=k, S=k, stride=st, pad=pd, G=G, ks_g=Cs // G,
+               n_g=s.n_store // G)
+    bn_train = s.bn is not None and self.training and s.bn.training
+    if s.bn is None:
+      y = torch.empty((B, Ho, Wo, s.n_store), device=x.device, dtype=odt)
+      ops.conv_gemm(x, s.wp, y, act=act, shift=s.bias_pad, res=res, **geo)
+      raw = None
+    elif not bn_train:
+      if self.tape is not None:
+        raise NotImplementedError('gradients through eval-mode BatchNorm are not implemented on the HIP path (round 1); '
+                                  'call model.train() or run under torch.no_grad()')
+      y = torch.empty((B, Ho, Wo, s.n_store), device=x.device, dtype=odt)
+      ops.conv_gemm(x, s.wp, y, act=act, scale=s.scale, shift=s.shift, res=res, **geo)
+      raw = None
+    else:
+      raw = torch.empty((B, Ho, Wo, s.n_store), device=x.device, dtype=odt)
+      ops.conv_gemm(x, s.wp, raw, **geo)
+      if bn_train:
+        ops.bn_stats(raw, s.ws)
+        ops.bn_finalize(s.ws, s.bn.weight.detach(), s.bn.bias.detach(), s.bn.running_mean, s.bn.running_var,
+                        s.bn.num_batches_tracked, s.scale, s.shift, s.save_mean, s.save_invstd, B * Ho * Wo, s.bn.momentum,
+                        s.bn.eps)
+      y = ops.affine_act(raw, scale=s.scale, shift=s.shift, res=res, act=act)
+    if self.tape is not None:
+
+      def bwd(dy):
+        if s.bn is None:
+          dz = ops.act_bwd(dy, y, act) if act != ACT_NONE else dy
+          dres = dz if res is not None else None
+          if s.bias is not None and s.bias.requires_grad:
+            if s.n_store == s.cout:
+              ops.colsum(dz, self.g(s.bias), B * Ho * Wo, s.cout, s.n_store)
+            else:
+              tmp = ops.zeros(s.n_store, F32, x.device)
+              ops.colsum(dz, tmp, B * Ho * Wo, s.n_store, s.n_store)
+              ops.copy_rows(tmp, self.g(s.bias), 1, s.cout, 0, 0, 0, 0, accumulate=True)
+          dconv = dz
+        elif bn_train:
+          dconv, dres = ops.bn_bwd(dy, y, raw, s.bn.weight.detach(), s.save_mean, s.save_invstd, s.ws, self.g(s.bn.weight),
+                                   self.g(s.bn.bias), relu_mask=(act == ACT_RELU), want_dres=res is not None)
+        gsrc = dconv if dconv.dtype == x.dtype else ops.cast(dconv, x.dtype)
+        if s.weight.requires_grad:
+          ops.conv_wgrad(gsrc, x, self.g(s.weight), B=B, Hs=H, Ws=W, Cs=Cs, Hd=Ho, Wd=Wo, Cd=s.n_store, R=k, S=k, stride=st,
+                         pad=pd, G=G, ks_g=Cs // G, n_g=s.n_store // G, c_real=s.cin_g, row_map=s.row_map)
+        dx = None
+        if x_grad:
+          dx = torch.empty((B, H, W, Cs), device=x.device, dtype=x.dtype)
+          ops.conv_gemm(gsrc, s.wt, dx, B=B, Hs=Ho, Ws=Wo, Cs=s.n_store, Hd=H, Wd=W, Cd=Cs, R=k, S=k, stride=st, pad=pd, G=G,
+                        ks_g=s.n_store // G, n_g=Cs // G, mode=1)
+        return dx, dres
+
+      self.rec([y], [x, res], bwd)
+    return y
+
+  def linear(self, x, key, act=ACT_NONE, res=None, x_grad=True, out_f32=False):
+    """x: [..., K] tokens -> [..., n_store]."""
+    shp = x.shape
+    rows = x.numel() // shp[-1]
+    y = self.conv(x.view(rows, 1, 1, shp[-1]), key, act=act, res=None if res is None else res.view(rows, 1, 1, -1),
+                  x_grad=x_grad, out_f32=out_f32)
+    return y.view(*shp[:-1], y.shape[-1])
+
+  def raw_linear(self, x, w, bias, wt, gw, gb, n, k, act=ACT_NONE, row_map=None, col_map=None, n_real=None):
+    """Linear with explicitly supplied packed images (fusion QKV / proj, decoder in_proj slices).
+    x: [rows, k];  w: [n, k];  wt: [k, n] (for the data gradient);  gw/gb: gradient destinations (callables)."""
+    rows = x.numel() // k
+    y = torch.empty((rows, n), device=x.device, dtype=x.dtype)
+    geo = dict(B=rows, Hs=1, Ws=1, Cs=k, Hd=1, Wd=1, Cd=n)
+    ops.conv_gemm(x, w, y, act=act, shift=bias, **geo)
+    if self.tape is not None:
+
+      def bwd(dy):
+        dz = ops.act_bwd(dy, y, act) if act != ACT_NONE else dy
+        gw(dz, x)
+        if gb is not None:
+          gb(dz)
+        dx = torch.empty((rows, k), device=x.device, dtype=x.dtype)
+        ops.conv_gemm(dz, wt, dx, B=rows, Hs=1, Ws=1, Cs=n, Hd=1, Wd=1, Cd=k, mode=1)
+        return dx
+
+      self.rec([y], [x], bwd)
+    return y
+
+  def layernorm(self, x, ln):
+    y, mean, rstd = ops.layernorm_fwd(x, ln.weight.detach(), ln.bias.detach(), ln.eps, save=self.tape is not None)
+    if self.tape is not None:
+      self.rec([y], [x], lambda dy: ops.layernorm_bwd(dy, x, ln.weight.detach(), mean, rstd, self.g(ln.weight), self.g(ln.bias)))
+    return y
+
+  def add(self, a, b, p_drop=0.0):
+    """a + dropout(b)."""
+    p = p_drop if self.training else 0.0
+    seed = self.next_seed() if p > 0 else 0
+    y = ops.add_dropout(a, b, p, seed)
+    if self.tape is not None:
+      self.rec([y], [a, b], lambda dy: (dy, ops.add_dropout(None, dy, p, seed) if p > 0 else dy))
+    return y
+
+  def dropout(self, b, p_drop):
+    p = p_drop if self.training else 0.0
+    if p <= 0:
+      return b
+    seed = self.next_seed()
+    y = ops.add_dropout(None, b, p, seed)
+    if self.tape is not None:
+      self.rec([y], [b], lambda dy: ops.add_dropout(None, dy, p, seed))
+    return y
+
+  def activation(self, x, act):
+    y = ops.affine_act(x, act=act)
+    if self.tape is not None:
+      self.rec([y], [x], lambda dy: ops.act_bwd(dy, y, act))
+    return y
+
+  def add_table(self, x, table, param=None):
+    """x + table broadcast over the batch (positional embeddings); ``param``: the nn.Parameter behind table."""
+    y = ops.add_bcast(x, table)
+    if self.tape is not None:
+
+      def bwd(dy):
+        if param is not None and param.requires_grad:
+          n = table.numel()
+          ops.colsum(dy, self.g(param).view(-1), dy.numel() // n, n, n)
+        return dy
+
+      self.rec([y], [x], bwd)
+    return y
+
+  def attention(self, q, k, v, B, nh, tq, tk, d, ld_q, ld_kv, scale, p_drop, out_ld):
+    """Batched multi-head attention core on head-major slices.  q/k/v are views (with data_ptr offsets) into token
+    matrices with row strides ld_q / ld_kv; output [B, tq, nh*d(out_ld)]."""
+    dev, dt_ = q.device, q.dtype
+    S = torch.empty((B, nh, tq, tk), device=dev, dtype=dt_)
+    ops.bgemm(q, k, S, M=tq, N=tk, K=d, lda=ld_q, ldb=ld_kv, ldc=tk, batch0=B, batch1=nh, a_bs=(tq * ld_q, d), b_bs=(tk * ld_kv, d),
+              c_bs=(nh * tq * tk, tq * tk))
+    p = p_drop if self.training else 0.0
+    seed = self.next_seed() if p > 0 else 0
+    P, Pd = ops.softmax_fwd(S, B * nh * tq, tk, tk, alpha=scale, p_drop=p, seed=seed)
+    O = torch.empty((B, tq, out_ld), device=dev, dtype=dt_)
+    ops.bgemm(Pd, v, O, M=tq, N=d, K=tk, lda=tk, ldb=ld_kv, ldc=out_ld, batch0=B, batch1=nh, a_bs=(nh * tq * tk, tq * tk),
+              b_bs=(tk * ld_kv, d), c_bs=(tq * out_ld, d), b_km=True)
+    return O, P, Pd, (p, seed)
+
+  def attention_bwd(self, dO, q, k, v, dq, dk, dv, P, Pd, drop, B, nh, tq, tk, d, ld_q, ld_kv, scale, out_ld):
+    """Writes dq/dk/dv (views with the same strides as q/k/v)."""
+    p, seed = drop
+    dev, dt_ = dO.device, dO.dtype
+    # dV = Pd^T dO
+    ops.bgemm(Pd, dO, dv, M=tk, N=d, K=tq, lda=tk, ldb=out_ld, ldc=ld_kv, batch0=B, batch1=nh, a_bs=(nh * tq * tk, tq * tk),
+              b_bs=(tq * out_ld, d), c_bs=(tk * ld_kv, d), a_km=True, b_km=True)
+    dP = torch.empty((B, nh, tq, tk), device=dev, dtype=dt_)
+    ops.bgemm(dO, v, dP, M=tq, N=tk, K=d, lda=out_ld, ldb=ld_kv, ldc=tk, batch0=B, batch1=nh, a_bs=(tq * out_ld, d),
+              b_bs=(tk * ld_kv, d), c_bs=(nh * tq * tk, tq * tk))
+    ops.softmax_bwd(P, dP, B * nh * tq, tk, tk, alpha=scale, p_drop=p, seed=seed)
+    ops.bgemm(dP, k, dq, M=tq, N=d, K=tk, lda=tk, ldb=ld_kv, ldc=ld_q, batch0=B, batch1=nh, a_bs=(nh * tq * tk, tq * tk),
+              b_bs=(tk * ld_kv, d), c_bs=(tq * ld_q, d), b_km=True)
+    ops.bgemm(dP, q, dk, M=tk, N=d, K=tq, lda=tk, ldb=ld_q, ldc=ld_kv, batch0=B, batch1=nh, a_bs=(nh * tq * tk, tq * tk),
+              b_bs=(tq * ld_q, d), c_bs=(tk * ld_kv, d), a_km=True, b_km=True)
+
+  # ------------------------------------------------------------------------------------------------ RegNet
+  def bottleneck(self, x, key, blk):
+    """RegNet-Y block (timm Bottleneck)."""
+    sc = self.conv(x, key + '.downsample') if blk.downsample is not None else x
+    y = self.conv(x, key + '.conv1', act=ACT_RELU)
+    y = self.conv(y, key + '.conv2', act=ACT_RELU)
+    y = self.squeeze_excite(y, blk.se)
+    return self.conv(y, key + '.conv3', act=ACT_RELU, res=sc)
+
+  def squeeze_excite(self, x, se):
+    B, H, W, C = x.shape
+    pool = ops.mean_hw(x)
+    w1, b1 = se.fc1.weight.detach().view(se.fc1.weight.shape[0], C), se.fc1.bias.detach()
+    w2, b2 = se.fc2.weight.detach().view(C, -1), se.fc2.bias.detach()
+    hidden, gate = ops.se_gate_fwd(pool, w1, b1, w2, b2)
+    y = ops.affine_act(x, gate=gate, rows_per_batch=H * W)
+    if self.tape is not None:
+
+      def bwd(dy):
+        dgate = ops.se_dgate(dy, x)
+        dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
+                                self.g(se.fc2.weight), self.g(se.fc2.bias))
+        return ops.se_bwd_apply(dy, gate, dpool)
+
+      self.rec([y], [x], bwd)
+    return y
+
+  def stage(self, x, key, stage_mod):
+    for bname, blk in stage_mod.named_children():
+      x = self.bottleneck(x, f'{key}.{bname}', blk)
+    return x
+
+  # ------------------------------------------------------------------------------------------------ fusion GPT
+  def pool_tokens(self, x, ho, wo):
+    B, H, W, C = x.shape
+    y = ops.avgpool_fwd(x, ho, wo)
+    if self.tape is not None:
+
+      def bwd(dy):
+        dx = ops.zeros((B, H, W, C), x.dtype, x.device)
+        ops.avgpool_bwd_add(dy, dx, ho, wo)
+        return dx
+
+      self.rec([y], [x], bwd)
+    return y
+
+  def upsample_add(self, tok, base, mul=None):
+    """base + bilinear(tok) (F.interpolate align_corners=False, transfuser.py:239-255)."""
+    B, hi, wi, C = tok.shape
+    _, ho, wo, _ = base.shape
+    y = ops.bilinear_fwd(tok, ho, wo, base=base)
+    if self.tape is not None:
+      self.rec([y], [tok, base], lambda dy: (ops.bilinear_bwd(dy, hi, wi), dy))
+    return y
+
+  def upsample(self, x, ho, wo, mul=None):
+    B, hi, wi, C = x.shape
+    y = ops.bilinear_fwd(x, ho, wo, mul=mul)
+    if self.tape is not None:
+      self.rec([y], [x], lambda dy: ops.bilinear_bwd(dy, hi, wi, mul=mul))
+    return y
+
+  def gpt(self, i, img_tok, lid_tok):
+    """team_code/transfuser.py:301-339: tokens [B,256,C] + [B,64,C] -> same shapes."""
+    g = self.m.backbone.transformers[i]
+    cfg = self.cfg
+    B, ni, C = img_tok.shape[0], img_tok.shape[1] * img_tok.shape[2], img_tok.shape[3]
+    nl = lid_tok.shape[1] * lid_tok.shape[2]
+    T = ni + nl
+    dt_ = img_tok.dtype
+    x0 = torch.empty((B, T, C), device=img_tok.device, dtype=dt_)
+    ops.copy_rows(img_tok, x0, B, ni * C, ni * C, 0, T * C, 0)
+    ops.copy_rows(lid_tok, x0, B, nl * C, nl * C, 0, T * C, ni * C)
+    if self.tape is not None:
+
+      def bwd_cat(d):
+        di = torch.empty_like(img_tok)
+        dl = torch.empty_like(lid_tok)
+        ops.copy_rows(d, di, B, ni * C, T * C, 0, ni * C, 0)
+        ops.copy_rows(d, dl, B, nl * C, T * C, ni * C, nl * C, 0)
+        return di, dl
+
+      self.rec([x0], [img_tok, lid_tok], bwd_cat)
+    x = self.add_table(x0, g.pos_emb.detach().view(-1), g.pos_emb)
+    x = self.dropout(x, cfg.embd_pdrop)
+    for l, blk in enumerate(g.blocks):
+      x = self.gpt_block(i, l, blk, x, B, T, C)
+    x = self.layernorm(x, g.ln_f)
+    io = torch.empty((B, img_tok.shape[1], img_tok.shape[2], C), device=x.device, dtype=dt_)
+    lo = torch.empty((B, lid_tok.shape[1], lid_tok.shape[2], C), device=x.device, dtype=dt_)
+    ops.copy_rows(x, io, B, ni * C, T * C, 0, ni * C, 0)
+    ops.copy_rows(x, lo, B, nl * C, T * C, ni * C, nl * C, 0)
+    if self.tape is not None:
+
+      def bwd_split(di, dl):
+        d = ops.zeros((B, T, C), dt_, x.device)
+        if di is not None:
+          ops.copy_rows(di, d, B, ni * C, ni * C, 0, T * C, 0)
+        if dl is not None:
+          ops.copy_rows(dl, d, B, nl * C, nl * C, 0, T * C, ni * C)
+        return d
+
+      self.rec([io, lo], [x], bwd_split)
+    return io, lo
+
+  def gpt_block(self, i, l, blk, x, B, T, C):
+    cfg = self.cfg
+    st = self._attn_state(i, l)
+    nh, d, dp = st['nh'], st['d'], st['dp']
+    npk = 3 * nh * dp
+    key = f'backbone.transformers.{i}.blocks.{l}'
+    h = self.layernorm(x, blk.ln1)
+
+    def gw_qkv(dz, xin):
+      for j, lin in enumerate((blk.attn.query, blk.attn.key, blk.attn.value)):
+        dslice = dz.view(-1, npk)[:, j * nh * dp:]
+        ops.conv_wgrad(dslice, xin, self.g(lin.weight), B=B * T, Hs=1, Ws=1, Cs=C, Hd=1, Wd=1, Cd=nh * dp, c_real=C,
+                       row_map=st['rmap'], dy_ld=npk, dw_ld=C)
+
+    def gb_qkv(dz):
+      tmp = ops.zeros(npk, F32, dz.device)
+      ops.colsum(dz, tmp, B * T, npk, npk)
+      for j, lin in enumerate((blk.attn.query, blk.attn.key, blk.attn.value)):
+        ops.pack2d(tmp[j * nh * dp:], self.g(lin.bias), 1, C, nh * dp, C, col_map=st['inv'])
+
+    qkv = self.raw_linear(h.view(B * T, C), st['wqkv'], st['bqkv'], st.get('wqkv_t'), gw_qkv, gb_qkv, npk, C)
+    q, k, v = qkv.view(-1)[0:], qkv.view(-1)[nh * dp:], qkv.view(-1)[2 * nh * dp:]
+    O, P, Pd, drop = self.attention(q, k, v, B, nh, T, T, dp, npk, npk, 1.0 / math.sqrt(d), cfg.attn_pdrop, nh * dp)
+    if self.tape is not None:
+
+      def bwd_attn(dO):
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = dqkv.view(-1)[0:], dqkv.view(-1)[nh * dp:], dqkv.view(-1)[2 * nh * dp:]
+        self.attention_bwd(dO, q, k, v, dq, dk, dv, P, Pd, drop, B, nh, T, T, dp, npk, npk, 1.0 / math.sqrt(d), nh * dp)
+        return dqkv
+
+      self.rec([O], [qkv], bwd_attn)
+
+    def gw_proj(dz, xin):
+      ops.conv_wgrad(dz, xin, self.g(blk.attn.proj.weight), B=B * T, Hs=1, Ws=1, Cs=nh * dp, Hd=1, Wd=1, Cd=C, c_real=nh * dp,
+                     col_map=st['rmap'], dw_ld=C)
+
+    def gb_proj(dz):
+      ops.colsum(dz, self.g(blk.attn.proj.bias), B * T, C, C)
+
+    y = self.raw_linear(O.view(B * T, nh * dp), st['wproj'], blk.attn.proj.bias.detach(), st.get('wproj_t'), gw_proj, gb_proj, C,
+                        nh * dp)
+    x = self.add(x, y.view(B, T, C), cfg.resid_pdrop)
+    h = self.layernorm(x, blk.ln2)
+    h = self.linear(h, key + '.mlp.0', act=ACT_RELU)
+    h = self.linear(h, key + '.mlp.2')
+    return self.add(x, h, cfg.resid_pdrop)
+
+  # ------------------------------------------------------------------------------------------------ planning head (fp32)
+  def mha(self, x, mem, prefix, layer_attn, B, tq, tk, self_attn):
+    """nn.MultiheadAttention (batch_first) as nn.TransformerDecoderLayer uses it (model.py:137-143)."""
+    cfg = self.cfg
+    dm, nh = x.shape[-1], cfg.num_decoder_heads
+    d = dm // nh
+    pd = self._decoder_dropout()
+    w, b = layer_attn.in_proj_weight, layer_attn.in_proj_bias
+    wd, bd = w.detach(), b.detach()
+
+    def proj(inp, r0, r1, rows):
+      n = r1 - r0
+
+      def gw(dz, xin):
+        ops.conv_wgrad(dz, xin, self.g(w)[r0:r1], B=rows, Hs=1, Ws=1, Cs=dm, Hd=1, Wd=1, Cd=n, c_real=dm, dw_ld=dm)
+
+      def gb(dz):
+        ops.colsum(dz, self.g(b)[r0:r1], rows, n, n)
+
+      y = torch.empty((rows, n), device=inp.device, dtype=F32)
+      ops.conv_gemm(inp, wd[r0:r1], y, B=rows, Hs=1, Ws=1, Cs=dm, Hd=1, Wd=1, Cd=n, shift=bd[r0:r1])
+      if self.tape is not None:
+
+        def bwd(dy):
+          gw(dy, inp)
+          gb(dy)
+          dx = torch.empty((rows, dm), device=inp.device, dtype=F32)
+          # dx = dy @ W[r0:r1]  : W slice [n, dm] is k-major for this product -> batched GEMM with b_km
+          ops.bgemm(dy, wd[r0:r1], dx, M=rows, N=dm, K=n, lda=n, ldb=dm, ldc=dm, b_km=True)
+          return dx
+
+        self.rec([y], [inp], bwd)
+      return y
+
+    if self_attn:
+      qkv = proj(x.view(B * tq, dm), 0, 3 * dm, B * tq)
+      q, k, v = qkv.view(-1)[0:], qkv.view(-1)[dm:], qkv.view(-1)[2 * dm:]
+      ld_q = ld_kv = 3 * dm
+      srcs = [qkv]
+    else:
+      qq = proj(x.view(B * tq, dm), 0, dm, B * tq)
+      kv = proj(mem.view(B * tk, dm), dm, 3 * dm, B * tk)
+      q, k, v = qq.view(-1), kv.view(-1)[0:], kv.view(-1)[dm:]
+      ld_q, ld_kv = dm, 2 * dm
+      srcs = [qq, kv]
+    O, P, Pd, drop = self.attention(q, k, v, B, nh, tq, tk, d, ld_q, ld_kv, 1.0 / math.sqrt(d), pd, dm)
+    if self.tape is not None:
+
+      def bwd_attn(dO):
+        if self_attn:
+          dqkv = torch.empty_like(srcs[0])
+          dq, dk, dv = dqkv.view(-1)[0:], dqkv.view(-1)[dm:], dqkv.view(-1)[2 * dm:]
+          self.attention_bwd(dO, q, k, v, dq, dk, dv, P, Pd, drop, B, nh, tq, tk, d, ld_q, ld_kv, 1.0 / math.sqrt(d), dm)
+          return dqkv
+        dqq, dkv = torch.empty_like(srcs[0]), torch.empty_like(srcs[1])
+        self.attention_bwd(dO, q, k, v, dqq.view(-1), dkv.view(-1)[0:], dkv.view(-1)[dm:], P, Pd, drop, B, nh, tq, tk, d, ld_q, ld_kv,
+                           1.0 / math.sqrt(d), dm)
+        return dqq, dkv
+
+      self.rec([O], srcs, bwd_attn)
+    return self.linear(O, prefix + '.out_proj')
+
+  def _decoder_dropout(self):
+    return float(self.m.join.layers[0].dropout.p)
+
+  def decoder(self, query, mem, B, tq, tk):
+    """nn.TransformerDecoder: post-norm layers, ReLU FFN as actually run (see DESIGN.md 'decoder activation')."""
+    pd = self._decoder_dropout()
+    x = query
+    for l, layer in enumerate(self.m.join.layers):
+      q = f'join.layers.{l}'
+      x = self.layernorm(self.add(x, self.mha(x, None, q + '.self_attn', layer.self_attn, B, tq, tq, True), pd), layer.norm1)
+      x = self.layernorm(self.add(x, self.mha(x, mem, q + '.multihead_attn', layer.multihead_attn, B, tq, tk, False), pd),
+                         layer.norm2)
+      h = self.linear(x, q + '.linear1', act=ACT_RELU)
+      h = self.dropout(h, pd)
+      h = self.linear(h, q + '.linear2')
+      x = self.layernorm(self.add(x, h, pd), layer.norm3)
+    return self.layernorm(x, self.m.join.norm)
+
+  def gru_decoder(self, feats, target_point, dec, name, B, T):
+    """team_code/model.py:857-867."""
+    dm = feats.shape[-1]
+    tp4 = ops.zeros((B, 4), F32, feats.device)
+    ops.copy_rows(target_point, tp4, B, 2, 2, 0, 4, 0)
+    h0 = self.linear(tp4, name + '.encoder', x_grad=False)
+    gi = self.linear(feats, name + '.gru.ih')
+    whh, bhh = dec.gru.weight_hh_l0, dec.gru.bias_hh_l0
+    wdec, bdec = dec.decoder.weight, dec.decoder.bias
+    out, save = ops.gru_fwd(gi, h0, whh.detach(), bhh.detach(), wdec.detach(), bdec.detach())
+    if self.tape is not None:
+
+      def bwd(dout):
+        return ops.gru_bwd(dout, save, h0, whh.detach(), bhh.detach(), wdec.detach(), self.g(whh), self.g(bhh), self.g(wdec),
+                           self.g(bdec))
+
+      self.rec([out], [gi, h0], bwd)
+    return out
+
+  # ------------------------------------------------------------------------------------------------ full forward
+  def forward(self, rgb, lidar_bev, target_point, ego_vel, command):
+    """Returns a dict of internal tensors (NHWC, channel-padded) -- see model.py for the caller-facing tuple."""
+    m, cfg, dt_ = self.m, self.cfg, self.dtype
+    dev = rgb.device
+    B = rgb.shape[0]
+    bb = m.backbone
+    out = {}
+    if cfg.normalize_imagenet:
+      mul = self._const('img_mul', lambda: torch.tensor([1.0 / (255.0 * s) for s in (0.229, 0.224, 0.225)]))
+      add = self._const('img_add', lambda: torch.tensor([-mu / s for mu, s in ((0.485, 0.229), (0.456, 0.224), (0.406, 0.225))]))
+      xi = ops.nchw_to_nhwc_affine(rgb.float().contiguous(), dt_, 8, mul, add)
+    else:
+      xi = ops.nchw_to_nhwc_affine(rgb.float().contiguous(), dt_, 8)
+    xl = ops.nchw_to_nhwc_affine(lidar_bev.float().contiguous(), dt_, 8)
+    xi = self.conv(xi, 'backbone.image_encoder.stem', act=ACT_RELU, x_grad=False)
+    xl = self.conv(xl, 'backbone.lidar_encoder.stem', act=ACT_RELU, x_grad=False)
+    for i in range(4):
+      xi = self.stage(xi, f'backbone.image_encoder.s{i + 1}', bb.image_encoder[f's{i + 1}'])
+      xl = self.stage(xl, f'backbone.lidar_encoder.s{i + 1}', bb.lidar_encoder[f's{i + 1}'])
+      it = self.pool_tokens(xi, cfg.img_vert_anchors, cfg.img_horz_anchors)
+      lt = self.pool_tokens(xl, cfg.lidar_vert_anchors, cfg.lidar_horz_anchors)
+      lt = self.conv(lt, f'backbone.lidar_channel_to_img.{i}')
+      io, lo = self.gpt(i, it, lt)
+      lo = self.conv(lo, f'backbone.img_channel_to_lidar.{i}')
+      xi = self.upsample_add(io, xi)
+      xl = self.upsample_add(lo, xl)
+    out['image_feature_grid'], out['fused_features'] = xi, xl
+
+    # BEV feature pyramid (transfuser.py:131-137)
+    bev = None
+    if cfg.detect_boxes or cfg.use_bev_semantic:
+      p5 = self.conv(xl, 'backbone.c5_conv', act=ACT_RELU)
+      p4 = self.upsample(p5, p5.shape[1] * cfg.bev_upsample_factor, p5.shape[2] * cfg.bev_upsample_factor)
+      p4 = self.conv(p4, 'backbone.up_conv5', act=ACT_RELU)
+      p3 = self.upsample(p4, cfg.lidar_resolution_height // cfg.bev_down_sample_factor,
+                         cfg.lidar_resolution_width // cfg.bev_down_sample_factor)
+      bev = self.conv(p3, 'backbone.up_conv4', act=ACT_RELU)
+    out['bev'] = bev
+
+    # planning head, fp32 (model.py:299-358)
+    dm = cfg.gru_input_size
+    x = self.conv(xl, 'change_channel', out_f32=True)  # [B,8,8,256] fp32
+    hh, ww = x.shape[1], x.shape[2]
+    pos = self._const(f'sine{hh}x{ww}', lambda: m.sine_table(hh, ww))
+    x = self.add_table(x, pos.view(-1))
+    vel = ops.bn1d_scalar(ego_vel.float().contiguous(), m.velocity_normalization.running_mean, m.velocity_normalization.running_var,
+                          m.velocity_normalization.num_batches_tracked, self.training and m.velocity_normalization.training,
+                          m.velocity_normalization.momentum, m.velocity_normalization.eps)
+    es_in = ops.zeros((B, 8), F32, dev)
+    ops.copy_rows(vel, es_in, B, 1, 1, 0, 8, 0)
+    ops.copy_rows(command.float().contiguous(), es_in, B, 6, 6, 0, 8, 1)
+    es = self.linear(es_in, 'extra_sensor_encoder.0', act=ACT_RELU, x_grad=False)
+    es = self.linear(es, 'extra_sensor_encoder.2', act=ACT_RELU)
+    es = self.add_table(es, m.extra_sensor_pos_embed.detach().view(-1), m.extra_sensor_pos_embed)
+    ntok = hh * ww
+    mem = torch.empty((B, ntok + 1, dm), device=dev, dtype=F32)
+    ops.copy_rows(x, mem, B, ntok * dm, ntok * dm, 0, (ntok + 1) * dm, 0)
+    ops.copy_rows(es, mem, B, dm, dm, 0, (ntok + 1) * dm, ntok * dm)
+    if self.tape is not None:
+
+      def bwd_mem(d):
+        dx_ = torch.empty_like(x)
+        des = torch.empty_like(es)
+        ops.copy_rows(d, dx_, B, ntok * dm, (ntok + 1) * dm, 0, ntok * dm, 0)
+        ops.copy_rows(d, des, B, dm, (ntok + 1) * dm, ntok * dm, dm, 0)
+        return dx_, des
+
+      self.rec([mem], [x, es], bwd_mem)
+    out['memory'] = mem
+
+    def run_queries(qparam, nq):
+      q0 = torch.empty((B, nq, dm), device=dev, dtype=F32)
+      ops.copy_rows(qparam.detach(), q0, B, nq * dm, 0, 0, nq * dm, 0)
+      if self.tape is not None:
+
+        def bwd_q(d):
+          if qparam.requires_grad:
+            ops.colsum(d, self.g(qparam).view(-1), B, nq * dm, nq * dm)
+          return ()
+
+        self.rec([q0], [], bwd_q)
+      return self.decoder(q0, mem, B, nq, ntok + 1)
+
+    out['pred_wp'] = out['pred_target_speed'] = out['pred_checkpoint'] = None
+    if cfg.use_wp_gru:
+      nq = cfg.pred_len // cfg.wp_dilation
+      j = run_queries(m.wp_query, nq)
+      out['pred_wp'] = self.gru_decoder(j, target_point.float().contiguous(), m.wp_decoder, 'wp_decoder', B, nq)
+    if cfg.use_controller_input_prediction:
+      n = cfg.predict_checkpoint_len
+      j = run_queries(m.checkpoint_query, n + 1)
+      out['joined'] = j
+      gf = torch.empty((B, n, dm), device=dev, dtype=F32)
+      tsf = torch.empty((B, dm), device=dev, dtype=F32)
+      ops.copy_rows(j, gf, B, n * dm, (n + 1) * dm, 0, n * dm, 0)
+      ops.copy_rows(j, tsf, B, dm, (n + 1) * dm, n * dm, dm, 0)
+      if self.tape is not None:
+
+        def bwd_j(dg, dt2):
+          d = ops.zeros((B, n + 1, dm), F32, dev)
+          if dg is not None:
+            ops.copy_rows(dg, d, B, n * dm, n * dm, 0, (n + 1) * dm, 0)
+          if dt2 is not None:
+            ops.copy_rows(dt2, d, B, dm, dm, 0, (n + 1) * dm, n * dm)
+          return d
+
+        self.rec([gf, tsf], [j], bwd_j)
+      out['pred_checkpoint'] = self.gru_decoder(gf, target_point.float().contiguous(), m.checkpoint_decoder, 'checkpoint_decoder',
+                                                B, n)
+      ts = self.linear(tsf, 'target_speed_network.0', act=ACT_RELU)
+      out['pred_target_speed'] = self.linear(ts, 'target_speed_network.2')  # [B, 8] (4 real)
+
+    # auxiliary dense heads
+    out['pred_semantic'] = self.perspective_decoder(xi, 'semantic_decoder') if cfg.use_semantic else None
+    out['pred_depth'] = self.activation(self.perspective_decoder(xi, 'depth_decoder'), ACT_SIGMOID) if cfg.use_depth else None
+    out['pred_bev_semantic'] = None
+    if cfg.use_bev_semantic:
+      y = self.conv(bev, 'bev_semantic_decoder.0', act=ACT_RELU)
+      y = self.conv(y, 'bev_semantic_decoder.2')
+      mask = m.valid_bev_pixels.detach().view(-1)
+      out['pred_bev_semantic'] = self.upsample(y, cfg.lidar_resolution_height, cfg.lidar_resolution_width, mul=mask)
+    out['bb'] = None
+    if cfg.detect_boxes:
+      bbs = []
+      for br in m.head.BRANCHES:
+        h = self.conv(bev, f'head.{br}_head.0', act=ACT_RELU)
+        bbs.append(self.conv(h, f'head.{br}_head.2', act=ACT_SIGMOID if br == 'heatmap' else ACT_NONE))
+      out['bb'] = bbs
+    return out
+
+  def perspective_decoder(self, x, name):
+    """team_code/transfuser_utils.py:697-704."""
+    m = getattr(self.m, name)
+    x = self.conv(x, name + '.deconv1.0', act=ACT_RELU)
+    x = self.conv(x, name + '.deconv1.2', act=ACT_RELU)
+    x = self.upsample(x, x.shape[1] * m.scale_factor_0, x.shape[2] * m.scale_factor_0)
+    x = self.conv(x, name + '.deconv2.0', act=ACT_RELU)
+    x = self.conv(x, name + '.deconv2.2', act=ACT_RELU)
+    x = self.upsample(x, x.shape[1] * m.scale_factor_1, x.shape[2] * m.scale_factor_1)
+    x = self.conv(x, name + '.deconv3.0', act=ACT_RELU)
+    return self.conv(x, name + '.deconv3.2')

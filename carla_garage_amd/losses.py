@@ -1,0 +1,186 @@
+"""Fused loss + gradient evaluation (team_code/model.py:394-445, team_code/center_net.py:77-123,
+team_code/transfuser_utils.py:341-364) on the engine's internal NHWC tensors.
+
+``fused_losses`` is the trainer path: one HIP kernel per loss writes the scalar and d(weight*loss)/d(pred) in a single
+pass.  ``reference_form_losses`` backs ``LidarCenterNet.compute_loss`` for drop-in use under team_code/train.py: the
+same kernels, wrapped so that each returned 0-d tensor is connected to the autograd graph of the forward outputs.
+"""
+import torch
+
+from . import ops
+from .engine import F32, EPS_F32
+
+LOSS_ORDER = ('loss_wp', 'loss_target_speed', 'loss_checkpoint', 'loss_semantic', 'loss_bev_semantic', 'loss_depth',
+              'loss_center_heatmap', 'loss_wh', 'loss_offset', 'loss_yaw_class', 'loss_yaw_res')
+
+
+def active_losses(cfg):
+  names = []
+  if cfg.use_wp_gru:
+    names.append('loss_wp')
+  if cfg.use_controller_input_prediction:
+    names += ['loss_target_speed', 'loss_checkpoint']
+  if cfg.use_semantic:
+    names.append('loss_semantic')
+  if cfg.use_bev_semantic:
+    names.append('loss_bev_semantic')
+  if cfg.use_depth:
+    names.append('loss_depth')
+  if cfg.detect_boxes:
+    names += ['loss_center_heatmap', 'loss_wh', 'loss_offset', 'loss_yaw_class', 'loss_yaw_res']
+  return names
+
+
+def normalized_loss_weights(cfg):
+  """team_code/train.py:383-456: unused losses are zeroed, the remaining detailed_loss_weights (all 1.0 by default,
+  team_code/config.py:223-239) are divided by their sum."""
+  base = getattr(cfg, 'detailed_loss_weights', None)
+  names = active_losses(cfg)
+  w = {n: float(base[n]) if base is not None and n in base else 1.0 for n in names}
+  s = sum(w.values())
+  return {n: v / s for n, v in w.items()}
+
+
+def _one_loss(model, name, t, labels, slot, weight, want_grad, af_sum):
+  """Launch the kernel for one loss on internal tensors ``t``; returns (pred_tensor, dpred or None)."""
+  cfg = model.config
+  dev = slot.device
+
+  def grad_like(x):
+    return torch.empty_like(x) if want_grad else None
+
+  if name == 'loss_target_speed':
+    p = t['pred_target_speed']  # [B, 8] fp32 (4 real)
+    d = grad_like(p)
+    ws = torch.empty(2, device=dev, dtype=F32)
+    ops.ce_loss(p, labels['target_speed_label'], slot, ws, rows=p.shape[0], C=len(cfg.target_speeds), ld=p.shape[1],
+                HW=p.shape[0], class_weight=model.loss_speed.weight, weight=weight, dpred=d)
+    return p, d
+  if name in ('loss_checkpoint', 'loss_wp'):
+    p = t['pred_checkpoint'] if name == 'loss_checkpoint' else t['pred_wp']
+    lab = labels['checkpoint_label'] if name == 'loss_checkpoint' else labels['waypoint_label']
+    d = grad_like(p)
+    ops.reg_loss(p, lab.contiguous(), slot, B=p.shape[0], C=1, HW=p.shape[1] * p.shape[2], ld=1, kind=0, weight=weight, dpred=d)
+    return p, d
+  if name == 'loss_semantic':
+    p = t['pred_semantic']  # [B,H,W,8]
+    d = grad_like(p)
+    B, H, W, ld = p.shape
+    ws = torch.empty(2, device=dev, dtype=F32)
+    ops.ce_loss(p, labels['semantic_label'], slot, ws, rows=B * H * W, C=cfg.num_semantic_classes, ld=ld, HW=H * W,
+                class_weight=model.loss_semantic.weight, weight=weight, dpred=d)
+    return p, d
+  if name == 'loss_bev_semantic':
+    p = t['pred_bev_semantic']
+    d = grad_like(p)
+    B, H, W, ld = p.shape
+    ws = torch.empty(2, device=dev, dtype=F32)
+    ops.ce_loss(p, labels['bev_semantic_label'], slot, ws, rows=B * H * W, C=cfg.num_bev_semantic_classes, ld=ld, HW=H * W,
+                class_weight=model.loss_bev_semantic.weight, vis_mask=model.valid_bev_pixels.detach().view(-1), weight=weight, dpred=d)
+    return p, d
+  if name == 'loss_depth':
+    p = t['pred_depth']  # sigmoid output [B,H,W,8]
+    d = grad_like(p)
+    B, H, W, ld = p.shape
+    ops.reg_loss(p, labels['depth_label'].contiguous(), slot, B=B, C=1, HW=H * W, ld=ld, kind=0, weight=weight, dpred=d)
+    return p, d
+  # CenterNet head
+  idx = {'loss_center_heatmap': 0, 'loss_wh': 1, 'loss_offset': 2, 'loss_yaw_class': 3, 'loss_yaw_res': 4}[name]
+  p = t['bb'][idx]
+  d = grad_like(p)
+  B, H, W, ld = p.shape
+  pw = labels['pixel_weight_label'].contiguous()
+  common = dict(B=B, HW=H * W, ld=ld, denom=af_sum, denom_eps=EPS_F32, weight=weight, dpred=d)
+  if name == 'loss_center_heatmap':
+    ops.reg_loss(p, labels['center_heatmap_label'].contiguous(), slot, C=cfg.num_bb_classes, kind=2, **common)
+  elif name == 'loss_wh':
+    ops.reg_loss(p, labels['wh_label'].contiguous(), slot, C=2, kind=0, elem_weight=pw, wC=2, denom_mul=2.0, **common)
+  elif name == 'loss_offset':
+    ops.reg_loss(p, labels['offset_label'].contiguous(), slot, C=2, kind=0, elem_weight=pw, wC=2, denom_mul=2.0, **common)
+  elif name == 'loss_yaw_res':
+    ops.reg_loss(p, labels['yaw_res_label'].contiguous(), slot, C=1, kind=1, elem_weight=pw, wC=2, w_bcast=True, **common)
+  else:
+    ws = torch.empty(2, device=dev, dtype=F32)
+    ops.ce_loss(p, labels['yaw_class_label'], slot, ws, rows=B * H * W, C=cfg.num_dir_bins, ld=ld, HW=H * W, pix_weight=pw,
+                pw_bstride=2 * H * W, denom=af_sum, denom_eps=EPS_F32, weight=weight, dpred=d)
+  return p, d
+
+
+def fused_losses(model, t, labels, weights=None, want_grad=True):
+  """Returns (names, loss_vector [n] fp32 of the UNWEIGHTED losses, seeds [(pred, dpred)] with the weights folded in)."""
+  names = active_losses(model.config)
+  dev = t['fused_features'].device
+  vals = ops.zeros(len(names), F32, dev)
+  af_sum = None
+  if model.config.detect_boxes:
+    af_sum = torch.empty(1, device=dev, dtype=F32)
+    ops.sum_f32(labels['avg_factor_label'].float().contiguous(), af_sum)
+  seeds = []
+  for i, n in enumerate(names):
+    w = 1.0 if weights is None else weights[n]
+    p, d = _one_loss(model, n, t, labels, vals[i:i + 1], w, want_grad, af_sum)
+    if want_grad:
+      seeds.append((p, d))
+  return names, vals, seeds
+
+
+class _LossNode(torch.autograd.Function):
+  """0-d loss connected to the caller-facing prediction tensor; backward returns dLoss/dpred in the caller layout."""
+
+  @staticmethod
+  def forward(ctx, pred_caller, value, to_caller_grad):
+    ctx.to_caller_grad = to_caller_grad
+    return value.clone()
+
+  @staticmethod
+  def backward(ctx, g):
+    return ctx.to_caller_grad(g), None, None
+
+
+def _scale_by_device_scalar(x, g):
+  """x * g for a 0-d device tensor g without a host sync (broadcast g into a per-channel scale vector)."""
+  ld = x.shape[-1] if x.dim() > 1 and x.shape[-1] % 4 == 0 else 4
+  v = torch.empty(ld, device=x.device, dtype=F32)
+  ops.copy_rows(g.float().reshape(1), v, ld, 1, 0, 0, 1, 0)
+  return ops.affine_act(x.reshape(-1, ld), scale=v).view(x.shape)
+
+
+def reference_form_losses(model, args):
+  """Drop-in ``compute_loss``: the predictions must be the tensors returned by the last ``forward`` (as in
+  team_code/train.py:776-820); the losses are evaluated by the fused HIP kernels on the internal tensors."""
+  t = model.__dict__.get('_last_internal')
+  if t is None:
+    raise RuntimeError('compute_loss must follow forward() of the same model (no stand-alone PyTorch loss path)')
+  cfg = model.config
+  label_keys = ('waypoint_label', 'target_speed_label', 'checkpoint_label', 'semantic_label', 'bev_semantic_label', 'depth_label',
+                'center_heatmap_label', 'wh_label', 'yaw_class_label', 'yaw_res_label', 'offset_label', 'pixel_weight_label',
+                'avg_factor_label')
+  labels = {k: args[k] for k in label_keys if args.get(k) is not None}
+  callers = {'loss_wp': args['pred_wp'], 'loss_target_speed': args['pred_target_speed'], 'loss_checkpoint': args['pred_checkpoint'],
+             'loss_semantic': args['pred_semantic'], 'loss_bev_semantic': args['pred_bev_semantic'], 'loss_depth': args['pred_depth']}
+  if cfg.detect_boxes:
+    for i, n in enumerate(('loss_center_heatmap', 'loss_wh', 'loss_offset', 'loss_yaw_class', 'loss_yaw_res')):
+      callers[n] = args['pred_bounding_box'][i]
+  want_grad = torch.is_grad_enabled()
+  names, vals, seeds = fused_losses(model, t, labels, None, want_grad)
+  out = {}
+  for i, n in enumerate(names):
+    caller = callers[n]
+    if want_grad and caller.requires_grad:
+      pred, dpred = seeds[i]
+
+      def to_caller(g, pred=pred, dpred=dpred, caller=caller, n=n):
+        d = _scale_by_device_scalar(dpred, g)
+        if n == 'loss_target_speed':
+          o = torch.empty(caller.shape, device=d.device, dtype=F32)
+          ops.copy_rows(d, o, caller.shape[0], caller.shape[1], d.shape[1], 0, caller.shape[1], 0)
+          return o
+        if d.dim() == 4:
+          c_real = caller.shape[1] if caller.dim() == 4 else 1
+          return ops.nhwc_to_nchw(d, c_real).view(caller.shape)
+        return d.view(caller.shape)
+
+      out[n] = _LossNode.apply(caller, vals[i], to_caller)
+    else:
+      out[n] = vals[i].clone()
+  return out

@@ -1,0 +1,233 @@
+"""Parameter containers with the reference's ``state_dict`` schema.
+
+These ``nn.Module`` trees only HOLD parameters / buffers under the reference's names (so released checkpoints,
+``create_optimizer_groups``' isinstance checks, DDP, ``requires_grad_`` on sub-modules and ``SyncBatchNorm``
+conversion keep working, team_code/train.py:479-531) and initialise them the way the reference does.  Their
+``forward`` methods are never the compute path: all arithmetic goes through carla_garage_amd/engine.py -> HIP.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+REGNETY_032 = dict(widths=(72, 216, 576, 1512), depths=(2, 5, 13, 1), group_w=24, stem_w=32, se_ratio=0.25)
+
+
+def _no_forward(self, *a, **k):
+  raise RuntimeError('parameter container: compute runs through carla_garage_amd.engine (HIP), not nn.Module.forward')
+
+
+class ConvBn(nn.Module):
+  """timm ConvNormAct naming: ``conv`` (no bias) + ``bn`` (team_code/model.py:586-589 relies on 'conv.' / '.bn')."""
+  forward = _no_forward
+
+  def __init__(self, cin, cout, k, stride=1, groups=1):
+    super().__init__()
+    self.conv = nn.Conv2d(cin, cout, k, stride, k // 2, groups=groups, bias=False)
+    self.bn = nn.BatchNorm2d(cout)
+    fan_out = k * k * cout // groups
+    nn.init.normal_(self.conv.weight, 0.0, math.sqrt(2.0 / fan_out))
+
+
+class SqueezeExcite(nn.Module):
+  forward = _no_forward
+
+  def __init__(self, chs, rd):
+    super().__init__()
+    self.fc1 = nn.Conv2d(chs, rd, 1)
+    self.fc2 = nn.Conv2d(rd, chs, 1)
+
+
+class Bottleneck(nn.Module):
+  """RegNet-Y block: conv1 1x1, conv2 grouped 3x3 (stride), se, conv3 1x1, optional downsample 1x1 (stride)."""
+  forward = _no_forward
+
+  def __init__(self, cin, cout, stride, group_w, se_ratio):
+    super().__init__()
+    self.conv1 = ConvBn(cin, cout, 1)
+    self.conv2 = ConvBn(cout, cout, 3, stride, cout // group_w)
+    self.se = SqueezeExcite(cout, int(round(cin * se_ratio)))
+    self.conv3 = ConvBn(cout, cout, 1)
+    if cin != cout or stride != 1:
+      self.downsample = ConvBn(cin, cout, 1, stride)
+    else:
+      self.downsample = None
+    nn.init.zeros_(self.conv3.bn.weight)  # zero_init_last
+    self.stride = stride
+
+
+class FeatureInfo:
+
+  def __init__(self, info):
+    self.info = info
+
+
+class RegNetY(nn.ModuleDict):
+  """``timm.create_model('regnety_032', features_only=True)``-shaped container: children stem, s1..s4."""
+  forward = _no_forward
+
+  def __init__(self, in_chans=3, arch=None):
+    super().__init__()
+    a = arch or REGNETY_032
+    self['stem'] = ConvBn(in_chans, a['stem_w'], 3, 2)
+    cin = a['stem_w']
+    for i, (w, d) in enumerate(zip(a['widths'], a['depths'])):
+      stage = nn.Sequential()
+      for k in range(d):
+        stage.add_module(f'b{k + 1}', Bottleneck(cin, w, 2 if k == 0 else 1, a['group_w'], a['se_ratio']))
+        cin = w
+      self[f's{i + 1}'] = stage
+    self.in_chans = in_chans
+    self.return_layers = {n: str(i) for i, n in enumerate(['stem', 's1', 's2', 's3', 's4'])}
+    self.feature_info = FeatureInfo([dict(num_chs=a['stem_w'], reduction=2, module='stem')] + [
+        dict(num_chs=w, reduction=4 * 2**i, module=f's{i + 1}') for i, w in enumerate(a['widths'])
+    ])
+
+
+class SelfAttention(nn.Module):
+  forward = _no_forward
+
+  def __init__(self, c):
+    super().__init__()
+    self.key = nn.Linear(c, c)
+    self.query = nn.Linear(c, c)
+    self.value = nn.Linear(c, c)
+    self.proj = nn.Linear(c, c)
+
+
+class Block(nn.Module):
+  forward = _no_forward
+
+  def __init__(self, c, block_exp):
+    super().__init__()
+    self.ln1 = nn.LayerNorm(c)
+    self.ln2 = nn.LayerNorm(c)
+    self.attn = SelfAttention(c)
+    self.mlp = nn.Sequential(nn.Linear(c, block_exp * c), nn.ReLU(True), nn.Linear(block_exp * c, c), nn.Dropout(0.0))
+
+
+class GPT(nn.Module):
+  """Fusion transformer container (team_code/transfuser.py:260-299): pos_emb, blocks.{l}, ln_f."""
+  forward = _no_forward
+
+  def __init__(self, c, config, n_tokens):
+    super().__init__()
+    self.n_embd = c
+    self.pos_emb = nn.Parameter(torch.zeros(1, n_tokens, c))
+    self.blocks = nn.Sequential(*[Block(c, config.block_exp) for _ in range(config.n_layer)])
+    self.ln_f = nn.LayerNorm(c)
+    std, mean = getattr(config, 'gpt_linear_layer_init_std', 0.02), getattr(config, 'gpt_linear_layer_init_mean', 0.0)
+    for m in self.modules():
+      if isinstance(m, nn.Linear):
+        m.weight.data.normal_(mean=mean, std=std)
+        m.bias.data.zero_()
+      elif isinstance(m, nn.LayerNorm):
+        m.bias.data.zero_()
+        m.weight.data.fill_(getattr(config, 'gpt_layer_norm_init_weight', 1.0))
+
+
+class TransfuserBackbone(nn.Module):
+  """Container for team_code/transfuser.py:16-129 (default 2-D RegNet LiDAR branch)."""
+  forward = _no_forward
+
+  def __init__(self, config):
+    super().__init__()
+    if config.image_architecture != 'regnety_032' or config.lidar_architecture != 'regnety_032':
+      raise ValueError('the MI355X path implements the regnety_032 image / LiDAR branches '
+                       f'(got {config.image_architecture} / {config.lidar_architecture})')
+    self.config = config
+    in_ch = config.lidar_seq_len * (2 if config.use_ground_plane else 1)
+    self.image_encoder = RegNetY(3)
+    self.lidar_encoder = RegNetY(in_ch)
+    widths = REGNETY_032['widths']
+    n_tok = config.img_vert_anchors * config.img_horz_anchors + config.lidar_vert_anchors * config.lidar_horz_anchors
+    self.transformers = nn.ModuleList([GPT(c, config, n_tok) for c in widths])
+    self.lidar_channel_to_img = nn.ModuleList([nn.Conv2d(c, c, 1) for c in widths])
+    self.img_channel_to_lidar = nn.ModuleList([nn.Conv2d(c, c, 1) for c in widths])
+    self.num_image_features = widths[-1]
+    self.num_features = widths[-1]
+    self.perspective_upsample_factor = 32 // config.perspective_downsample_factor
+    ch = config.bev_features_chanels
+    if config.detect_boxes or config.use_bev_semantic:
+      self.up_conv5 = nn.Conv2d(ch, ch, 3, padding=1)
+      self.up_conv4 = nn.Conv2d(ch, ch, 3, padding=1)
+      self.c5_conv = nn.Conv2d(widths[-1], ch, 1)
+
+
+class LidarCenterNetHead(nn.Module):
+  """Container for team_code/center_net.py:23-47 (single-frame: 5 branches)."""
+  forward = _no_forward
+  BRANCHES = ('heatmap', 'wh', 'offset', 'yaw_class', 'yaw_res')
+
+  def __init__(self, config):
+    super().__init__()
+    self.config = config
+    c = config.bb_input_channel
+    outs = dict(heatmap=config.num_bb_classes, wh=2, offset=2, yaw_class=config.num_dir_bins, yaw_res=1)
+    for n in self.BRANCHES:
+      setattr(self, n + '_head', nn.Sequential(nn.Conv2d(c, c, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(c, outs[n], 1)))
+    self.out_channels = outs
+
+
+class PerspectiveDecoder(nn.Module):
+  """Container for team_code/transfuser_utils.py:668-695."""
+  forward = _no_forward
+
+  def __init__(self, cin, cout, c0, c1, c2, scale_factor_0, scale_factor_1):
+    super().__init__()
+    self.scale_factor_0, self.scale_factor_1 = scale_factor_0, scale_factor_1
+    self.deconv1 = nn.Sequential(nn.Conv2d(cin, c0, 3, 1, 1), nn.ReLU(True), nn.Conv2d(c0, c1, 3, 1, 1), nn.ReLU(True))
+    self.deconv2 = nn.Sequential(nn.Conv2d(c1, c2, 3, 1, 1), nn.ReLU(True), nn.Conv2d(c2, c2, 3, 1, 1), nn.ReLU(True))
+    self.deconv3 = nn.Sequential(nn.Conv2d(c2, c2, 3, 1, 1), nn.ReLU(True), nn.Conv2d(c2, cout, 3, 1, 1))
+
+
+class GRUWaypointsPredictorInterFuser(nn.Module):
+  """Container for team_code/model.py:839-855."""
+  forward = _no_forward
+
+  def __init__(self, input_dim, waypoints, hidden_size, target_point_size):
+    super().__init__()
+    self.gru = nn.GRU(input_size=input_dim, hidden_size=hidden_size, batch_first=True)
+    if target_point_size > 0:
+      self.encoder = nn.Linear(target_point_size, hidden_size)
+    self.target_point_size, self.hidden_size, self.waypoints = target_point_size, hidden_size, waypoints
+    self.decoder = nn.Linear(hidden_size, 2)
+
+
+def visibility_mask(config):
+  """``valid_bev_pixels`` (1,1,H,W): BEV pixels with at least one voxel centre that a pinhole projection puts
+  inside the camera image -- team_code/transfuser_utils.py:596-665 + team_code/model.py:93-98.  Init-time, host."""
+  mpp = 1.0 / config.pixels_per_meter
+  xs = torch.arange(config.min_x, config.max_x, mpp) + 0.5 * mpp  # lateral
+  ys = torch.arange(config.min_y, config.max_y, mpp) + 0.5 * mpp  # forward (depth)
+  mz = mpp * config.bev_grid_height_downsample_factor
+  zs = torch.arange(config.min_z_projection, config.max_z_projection, mz) + 0.5 * mz
+  fwd, lat, up = torch.meshgrid(ys, xs, zs, indexing='ij')
+  cam = torch.tensor(config.camera_pos, dtype=torch.float32)
+  pts = torch.stack((fwd, lat, up), 0).reshape(3, -1) - cam.unsqueeze(1)
+  f = config.camera_width / (2.0 * np.tan(config.camera_fov * np.pi / 360.0))
+  intr = torch.from_numpy(np.array([[f, 0.0, config.camera_width / 2.0], [0.0, f, config.camera_height / 2.0],
+                                    [0.0, 0.0, 1.0]])).to(torch.float32)
+  proj = intr @ torch.stack((pts[1], pts[2], pts[0]))
+  depth = proj[2:3]
+  uv = proj[:2] / depth
+  inside = (uv[0:1] >= 0.0) & (uv[0:1] < config.camera_width) & (uv[1:2] >= 0.0) & (uv[1:2] < config.camera_height) & (depth > 0.0)
+  vol = inside.to(torch.float32).reshape(1, len(ys), len(xs), len(zs))
+  return vol.max(dim=3)[0].unsqueeze(1).transpose(2, 3).contiguous()
+
+
+def sine_position_table(h, w, num_pos_feats, temperature=10000.0):
+  """Constant of ``PositionEmbeddingSine(num_pos_feats, normalize=True)`` (team_code/model.py:916-953) for an
+  h x w grid, returned token-major [h*w, 2*num_pos_feats] (y half then x half).  Init-time, host."""
+  two_pi = 2.0 * math.pi
+  yy = (torch.arange(1, h + 1, dtype=torch.float32) / (float(h) + 1e-6) * two_pi).view(h, 1, 1).expand(h, w, 1)
+  xx = (torch.arange(1, w + 1, dtype=torch.float32) / (float(w) + 1e-6) * two_pi).view(1, w, 1).expand(h, w, 1)
+  i = torch.arange(num_pos_feats, dtype=torch.float32)
+  freq = temperature**(2 * torch.div(i, 2, rounding_mode='floor') / num_pos_feats)
+
+  def enc(v):
+    a = v / freq
+    return torch.stack((a[..., 0::2].sin(), a[..., 1::2].cos()), -1).flatten(-2)
+
+  return torch.cat((enc(yy), enc(xx)), -1).reshape(h * w, 2 * num_pos_feats).contiguous()

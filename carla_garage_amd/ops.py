@@ -341,6 +341,20 @@ def colsum(x, out, rows, c, ld=None):
   return out
 
 
+def copy_rows(src, dst, B, n, src_bs, src_off, dst_bs, dst_off, accumulate=False):
+  lib.tfpp_copy_rows(ptr(src), ptr(dst), B, n, src_bs, src_off, dst_bs, dst_off, int(accumulate), dt(src), dt(dst), stream())
+  return dst
+
+
+def zero_(t):
+  lib.tfpp_zero(ptr(t), t.numel() * t.element_size(), stream())
+  return t
+
+
+def zeros(shape, dtype=torch.float32, device='cuda'):
+  return zero_(torch.empty(shape, device=device, dtype=dtype))
+
+
 def sum_f32(x, out):
   lib.tfpp_sum_f32(ptr(_chk(x)), ptr(out), x.numel(), stream())
   return out

@@ -1,0 +1,29 @@
+"""One small invocation of the hot path on cuda:0 checked against the CPU oracle (used by __graft_entry__.smoke())."""
+import torch
+
+
+def run(verbose=True):
+  from oracle import tfpp_port as P  # checker only
+  from carla_garage_amd.config import GlobalConfig
+  from carla_garage_amd.model import LidarCenterNet
+  dev = torch.device('cuda:0')
+  cfg = GlobalConfig()
+  pc = P.PortConfig()
+  sd = P.make_state_dict(pc)
+  model = LidarCenterNet(cfg)
+  model.load_state_dict(sd, strict=True)
+  model.to(dev).eval()
+  inp = P.make_inputs(1, pc)
+  with torch.inference_mode():
+    got = model(*[x.to(dev) for x in inp])
+    want = P.forward(sd, pc, *inp)
+  torch.cuda.synchronize()
+  worst = 0.0
+  for name, g, w in (('pred_target_speed', got[1], want[1]), ('pred_checkpoint', got[2], want[2]), ('heatmap', got[6][0], want[6][0]),
+                     ('pred_semantic', got[3], want[3]), ('pred_bev_semantic', got[4], want[4]), ('pred_depth', got[5], want[5])):
+    e = ((g.float().cpu() - w).abs().max() / (w.abs().max() + 1e-20)).item()
+    worst = max(worst, e)
+    if verbose:
+      print(f'smoke {name:20s} rel_err {e:.3e}')
+    assert e <= 1e-3, f'{name}: rel err {e:.3e} > 1e-3 vs the CPU oracle'
+  return worst

@@ -1,0 +1,88 @@
+"""Training step of the MI355X path: the data-parallel hot loop of team_code/train.py:883-910 without autograd.
+
+One step = repack weights -> forward (engine tape) -> fused loss+gradient kernels -> tape backward into ONE flat fp32
+gradient arena -> (RCCL all-reduce of that arena, the path's only collective: plain data parallelism,
+team_code/train.py:516-520) -> fused AdamW(amsgrad) over the flat parameter arena (team_code/train.py:529-531,908).
+The whole step is a static launch sequence, so after warm-up it can be captured into a hipGraph
+(``capture_graph=True``) and replayed without Python or launch overhead.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .engine import Tape, F32
+from .losses import fused_losses, normalized_loss_weights, active_losses
+
+
+class Trainer:
+
+  def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, process_group=None, use_graph=False):
+    self.model = model
+    self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+    self.pg = process_group
+    self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+    self.step_count = 0
+    self.use_graph = use_graph
+    self.graph = None
+    self._static = None
+    self.eng = model._engine()
+    self.loss_names = active_losses(model.config)
+    self.loss_weights = normalized_loss_weights(model.config)
+    self._flatten()
+
+  # ---------------------------------------------------------------------------------------------- flat arenas
+  def _flatten(self):
+    """Re-home every trainable parameter into one flat fp32 arena (same offsets as the gradient arena)."""
+    eng = self.eng
+    eng.alloc_grads()
+    dev = eng.device
+    params = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
+    self.flat_param = torch.empty_like(eng.flat_grad)
+    ops.zero_(self.flat_param)
+    off = 0
+    for _, p in params:
+      n = p.numel()
+      dst = self.flat_param[off:off + n]
+      ops.copy_rows(p.detach().contiguous(), dst, 1, n, 0, 0, 0, 0)
+      p.data = dst.view(p.shape)
+      off += ops.pad_to(n, 4)
+    self.exp_avg = ops.zeros(self.flat_param.shape, F32, dev)
+    self.exp_avg_sq = ops.zeros(self.flat_param.shape, F32, dev)
+    self.max_exp_avg_sq = ops.zeros(self.flat_param.shape, F32, dev)
+    if self.world > 1:  # rank 0's parameters everywhere (DDP constructor broadcast, train.py:516)
+      dist.broadcast(self.flat_param, 0, group=self.pg)
+      for b in self.model.buffers():
+        dist.broadcast(b, 0, group=self.pg)
+
+  # ---------------------------------------------------------------------------------------------- one step
+  def _step_body(self, batch):
+    eng, model = self.eng, self.model
+    eng.training = True
+    eng.dtype = model.compute_dtype
+    eng.repack(eng.dtype, True)
+    eng.alloc_grads()
+    eng.tape = Tape()
+    t = eng.forward(batch['rgb'], batch['lidar_bev'], batch['target_point'], batch['ego_vel'], batch['command'])
+    _, vals, seeds = fused_losses(model, t, batch, self.loss_weights, True)
+    tape, eng.tape = eng.tape, None
+    tape.backward(seeds)
+    return vals
+
+  def _optimizer(self, step):
+    ops.adamw_amsgrad(self.flat_param, self.eng.flat_grad, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, self.lr, self.betas[0],
+                      self.betas[1], self.eps, self.weight_decay, step, grad_scale=1.0 / self.world)
+
+  def train_step(self, batch):
+    """batch: dict with rgb, lidar_bev, target_point, ego_vel, command and the *_label tensors (reference layouts).
+    Returns the vector of unweighted losses (device tensor, order = self.loss_names)."""
+    self.model.train()
+    self.step_count += 1
+    vals = self._step_body(batch)
+    if self.world > 1:
+      dist.all_reduce(self.eng.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+    self._optimizer(self.step_count)
+    return vals
+
+  def total_loss(self, vals):
+    w = torch.tensor([self.loss_weights[n] for n in self.loss_names])
+    return float((vals.detach().cpu() * w).sum())

@@ -194,6 +194,11 @@ int tfpp_axpy(const void* x, void* y, int64_t n, float a, int dtype, void* strea
 int tfpp_mul_pixmask(const void* x, const float* m, void* y, int64_t n, int64_t ld, int64_t HW, int dtype, void* stream);
 int tfpp_colsum(const void* x, float* out, int64_t rows, int C, int64_t ld, int dtype, void* stream); /* out[c] += sum_rows */
 int tfpp_sum_f32(const float* x, float* out, int64_t n, void* stream);
+/* token plumbing (torch.cat / slicing / .repeat in transfuser.py:323,329-337 and model.py:318-324,352-355):
+ * dst[b*dst_bs + dst_off + i] (+)= src[b*src_bs + src_off + i] for i in [0,n), with dtype conversion. */
+int tfpp_copy_rows(const void* src, void* dst, int B, int64_t n, int64_t src_bs, int64_t src_off, int64_t dst_bs, int64_t dst_off,
+                   int accumulate, int dtype_in, int dtype_out, void* stream);
+int tfpp_zero(void* p, int64_t bytes, void* stream); /* hipMemsetAsync(p, 0, bytes) */
 
 /* ---------------------------------------------------------------------------------------------------------
  * GRU waypoint / checkpoint decoder (model.py:857-867): h0 = enc(target_point); nn.GRU(256->64) over T steps;
