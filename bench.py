@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""bench.py -- TransFuser++ training throughput on MI355X (BASELINE.json metric: training samples/s at bs=12/GPU).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one synthetic batch: forward (train-mode BN, dropout), the 10 losses, the
+hand-written backward, the gradient all-reduce (N>1, RCCL) and AdamW(amsgrad) -- carla_garage_amd/trainer.py.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; it carries
+  roofline      the dominant kernel family's achieved TFLOP/s (algorithmic FLOPs / HIP-event time on the launch stream)
+  cpu_baseline  the CPU oracle (oracle/tfpp_port.py, "port") doing the same train step on the host cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+GFLOP_PER_SAMPLE_TRAIN = 306.0  # 51.06 GMAC fwd x 2 FLOP x 3 (fwd + bwd)
+
+
+def synthetic_batch(bs, cfg, device, seed):
+  """Synthetic camera + LiDAR batch and labels of SURVEY.md section 8(d) (seeded torch.Generator, seed 1234 + rank)."""
+  g = torch.Generator().manual_seed(seed)
+  H, W, LH, LW = cfg.camera_height, cfg.camera_width, cfg.lidar_resolution_height, cfg.lidar_resolution_width
+  hb, wb = LH // cfg.bev_down_sample_factor, LW // cfg.bev_down_sample_factor
+  b = {}
+  b['rgb'] = torch.randint(0, 256, (bs, 3, H, W), generator=g).float()
+  occ = (torch.rand(bs, 1, LH, LW, generator=g) < 0.1).float()
+  b['lidar_bev'] = occ * torch.randint(1, 6, (bs, 1, LH, LW), generator=g).float() / 5.0
+  b['target_point'] = torch.randn(bs, 2, generator=g) * torch.tensor([20.0, 5.0])
+  b['ego_vel'] = torch.rand(bs, 1, generator=g) * 8.0
+  b['command'] = torch.eye(6)[torch.randint(0, 6, (bs,), generator=g)]
+  b['target_speed_label'] = torch.randint(0, 4, (bs,), generator=g)
+  b['checkpoint_label'] = torch.randn(bs, cfg.predict_checkpoint_len, 2, generator=g) * 5
+  b['waypoint_label'] = torch.randn(bs, cfg.pred_len, 2, generator=g) * 5
+  b['semantic_label'] = torch.randint(0, cfg.num_semantic_classes, (bs, H, W), generator=g)
+  b['bev_semantic_label'] = torch.randint(0, cfg.num_bev_semantic_classes, (bs, LH, LW), generator=g)
+  b['depth_label'] = torch.rand(bs, H, W, generator=g)
+  heat = torch.zeros(bs, cfg.num_bb_classes, hb, wb)
+  pw = torch.zeros(bs, 2, hb, wb)
+  ys, xs = torch.meshgrid(torch.arange(hb).float(), torch.arange(wb).float(), indexing='ij')
+  nbox = torch.randint(1, 6, (bs,), generator=g)
+  for i in range(bs):
+    for _ in range(int(nbox[i])):
+      y, x, c = [int(torch.randint(lo, hi, (1,), generator=g)) for lo, hi in ((4, hb - 4), (4, wb - 4), (0, cfg.num_bb_classes))]
+      blob = torch.exp(-((ys - y)**2 + (xs - x)**2) / (2 * 1.5**2))
+      blob[y, x] = 1.0
+      heat[i, c] = torch.maximum(heat[i, c], blob)
+      pw[i, :, y, x] = 1.0
+  b['center_heatmap_label'] = heat
+  b['wh_label'] = torch.rand(bs, 2, hb, wb, generator=g) * 8
+  b['yaw_class_label'] = torch.randint(0, cfg.num_dir_bins, (bs, hb, wb), generator=g)
+  b['yaw_res_label'] = (torch.rand(bs, 1, hb, wb, generator=g) - 0.5) * 0.6
+  b['offset_label'] = torch.rand(bs, 2, hb, wb, generator=g)
+  b['pixel_weight_label'] = pw
+  b['avg_factor_label'] = nbox.float()
+  return {k: (v.to(device) if device is not None else v) for k, v in b.items()}
+
+
+def cpu_baseline_worker(cfg_bs, budget_s):
+  """Child process: the oracle ("port": plain-PyTorch fp32 restatement of the reference) doing the same train step on the
+  host cores: forward + 10 losses + backward + AdamW(amsgrad).  Prints one JSON line per timed step (cumulative median)."""
+  from oracle import tfpp_port as P
+  # 256-thread hosts thrash on these layer sizes (intra-op parallelism saturates far earlier): cap at 32 threads
+  torch.set_num_threads(min(os.cpu_count() or 1, 32))
+  pc = P.PortConfig()
+  sd = P.make_state_dict(pc)
+  frozen = lambda k: ('valid_bev' in k or 'running' in k or k.startswith('loss_'))
+  sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not frozen(k) else v.clone()) for k, v in sd.items()}
+  opt = torch.optim.AdamW([v for v in sd.values() if v.requires_grad], lr=3e-4, amsgrad=True)
+  inp = P.make_inputs(cfg_bs, pc)
+  lab = P.make_labels(cfg_bs, pc)
+  times = []
+  t_start = time.perf_counter()
+  it = 0
+  while True:
+    t0 = time.perf_counter()
+    out = P.forward(sd, pc, *inp, training=True)
+    total, _ = P.total_loss(sd, pc, out, lab)
+    opt.zero_grad(set_to_none=True)
+    total.backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    if it > 0 or dt > budget_s / 2:  # the first step is warm-up unless it alone eats the budget
+      times.append(dt)
+      med = sorted(times)[len(times) // 2]
+      print(json.dumps({'value': round(cfg_bs / med, 4), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                        'sample': f'bs={cfg_bs} x {len(times)} train steps (fwd + 10 losses + bwd + AdamW-amsgrad), fp32, '
+                                  f'median step {med:.2f} s'}), flush=True)
+    it += 1
+    if time.perf_counter() - t_start > budget_s or len(times) >= 5:
+      break
+
+
+def cpu_baseline(cfg_bs=2, budget_s=25.0, hard_timeout_s=90.0):
+  """Runs cpu_baseline_worker in a subprocess with a hard timeout so a slow host can never stall the bench."""
+  import subprocess
+  cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--batch-size', str(cfg_bs), '--cpu-budget', str(budget_s)]
+  env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+  last = None
+  try:
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=hard_timeout_s, env=env, check=False)
+    out = p.stdout.decode()
+  except subprocess.TimeoutExpired as e:
+    out = (e.stdout or b'').decode()
+  for ln in out.splitlines():
+    try:
+      last = json.loads(ln)
+    except ValueError:
+      pass
+  if last is None:
+    last = {'value': None, 'unit': 'samples/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': f'no CPU train step finished within {hard_timeout_s:.0f} s on this host'}
+  return last
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=10)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--batch-size', type=int, default=12)
+  ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-roofline', action='store_true')
+  ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel-family time table to stderr')
+  ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
+  ap.add_argument('--cpu-budget', type=float, default=25.0, help=argparse.SUPPRESS)
+  args = ap.parse_args()
+  if args.cpu_baseline_only:
+    cpu_baseline_worker(args.batch_size, args.cpu_budget)
+    return
+
+  rank = int(os.environ.get('RANK', 0))
+  local_rank = int(os.environ.get('LOCAL_RANK', 0))
+  world = int(os.environ.get('WORLD_SIZE', 1))
+  if args.gpus != world and world > 1:
+    raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', init_method='env://')  # RCCL over xGMI
+
+  from carla_garage_amd.config import GlobalConfig
+  from carla_garage_amd.model import LidarCenterNet
+  from carla_garage_amd.trainer import Trainer
+  from carla_garage_amd._lib import lib, KernelProfiler
+
+  torch.manual_seed(0)  # identical random-init weights on every rank
+  cfg = GlobalConfig(tfpp_dtype=args.dtype)
+  model = LidarCenterNet(cfg)
+  for m in model.modules():  # zero_init_last leaves residual branches inert; give BN gains non-trivial values
+    if isinstance(m, torch.nn.BatchNorm2d):
+      torch.nn.init.uniform_(m.weight, 0.5, 1.0)
+  model.to(device).train()
+  t_wall = time.perf_counter()
+
+  def log(msg):
+    if rank == 0:
+      print(f'[bench +{time.perf_counter() - t_wall:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+  trainer = Trainer(model, lr=cfg.lr)
+  batch = synthetic_batch(args.batch_size, cfg, device, 1234 + rank)
+  log('model, trainer and synthetic batch ready')
+
+  def sync():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    vals = trainer.train_step(batch)
+  sync()
+  log(f'{args.warmup} warm-up steps done')
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    vals = trainer.train_step(batch)
+  sync()
+  elapsed = time.perf_counter() - t0
+  log(f'{args.steps} timed steps: {1e3 * elapsed / args.steps:.1f} ms/step')
+  tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+  if world > 1:
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+  elapsed = float(tmax.item())
+  loss_total = trainer.total_loss(vals)
+  assert loss_total == loss_total and abs(loss_total) < 1e9, f'training diverged: {loss_total}'
+
+  roof = None
+  if rank == 0 and not args.no_roofline:
+    prof = KernelProfiler()
+    lib.profiler = prof
+    nprof = 2
+    for _ in range(nprof):
+      trainer.train_step(batch)
+    lib.profiler = None
+    agg = prof.summary()
+    total_ms = sum(a['ms'] for a in agg.values())
+    fam, a = max(((f, a) for f, a in agg.items() if a['flops'] > 0), key=lambda fa: fa[1]['ms'])
+    ach = a['flops'] / (a['ms'] * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.dtype]
+    roof = {'bound': 'mfma', 'kernel': fam, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'traffic': None, 'launches_per_step': a['calls'] // nprof, 'avg_launch_us': round(1e3 * a['ms'] / a['calls'], 2),
+            'share_of_step_kernel_time': round(a['ms'] / total_ms, 3)}
+    if args.kernel_table:
+      for f, x in sorted(agg.items(), key=lambda fa: -fa[1]['ms']):
+        tf = x['flops'] / (x['ms'] * 1e-3) / 1e12 if x['flops'] else 0.0
+        print(f'{f:42s} calls/step {x["calls"] // nprof:5d}  ms/step {x["ms"] / nprof:9.3f}  {100 * x["ms"] / total_ms:5.1f}%  {tf:8.1f} TFLOP/s',
+              file=sys.stderr)
+  if world > 1:
+    dist.barrier()
+
+  if rank == 0:
+    ms = 1e3 * elapsed / args.steps
+    value = args.batch_size * world * args.steps / elapsed
+    line = {
+        'metric': 'training samples/sec (TransFuser++ bs=12/GPU)', 'value': round(value, 3), 'unit': 'samples/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': 'TransFuser++ training step (fwd + 10 losses + bwd + AdamW-amsgrad), RegNetY-3.2GF x2, 256x1024 RGB + '
+                               '256x256 LiDAR BEV, train-mode BN + dropout, random-init weights',
+                   'global_batch': args.batch_size * world, 'per_gpu_batch': args.batch_size, 'parallelism': f'dp{world}',
+                   'algorithmic_tflop_per_step_per_gpu': round(GFLOP_PER_SAMPLE_TRAIN * args.batch_size / 1e3, 3),
+                   'model_tflops_per_gpu': round(GFLOP_PER_SAMPLE_TRAIN * args.batch_size / 1e3 / (ms * 1e-3), 2),
+                   'final_weighted_loss': round(loss_total, 5)},
+    }
+    if roof is not None:
+      line['roofline'] = roof
+    if world == 1 and not args.no_cpu_baseline:
+      line['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(line), flush=True)
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

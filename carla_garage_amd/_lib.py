@@ -99,12 +99,54 @@ class TfppError(RuntimeError):
   pass
 
 
+class KernelProfiler:
+  """Brackets every library call with HIP events on the launch stream (torch's current stream) and aggregates the
+  elapsed time per kernel family; ``tag()`` lets ops.py attach a family name and algorithmic FLOPs to the next call."""
+
+  def __init__(self):
+    import torch
+    self._torch = torch
+    self.records = []
+    self._pending = None
+
+  def tag(self, family, flops=0.0, nbytes=0.0):
+    self._pending = (family, float(flops), float(nbytes))
+
+  def run(self, name, fn, args):
+    fam, flops, nbytes = self._pending if self._pending is not None else (name, 0.0, 0.0)
+    self._pending = None
+    e0 = self._torch.cuda.Event(enable_timing=True)
+    e1 = self._torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    self.records.append((fam, flops, nbytes, e0, e1))
+    return rc
+
+  def summary(self):
+    self._torch.cuda.synchronize()
+    agg = {}
+    for fam, flops, nbytes, e0, e1 in self.records:
+      a = agg.setdefault(fam, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+      a['calls'] += 1
+      a['ms'] += e0.elapsed_time(e1)
+      a['flops'] += flops
+      a['bytes'] += nbytes
+    return agg
+
+
 class _Lib:
   """Lazy handle; ``lib.tfpp_xxx(...)`` raises TfppError on a non-zero return code."""
 
   def __init__(self):
     self._dll = None
     self._fns = {}
+    self.profiler = None
+
+  def raw(self, name):
+    """The bare ctypes function (for entry points whose return value is data, not an error code)."""
+    self.load()
+    return self._fns[name]
 
   def load(self):
     if self._dll is not None:
@@ -134,7 +176,8 @@ class _Lib:
     fn = self._fns[name]
 
     def call(*args):
-      rc = fn(*args)
+      prof = self.__dict__.get('profiler')
+      rc = fn(*args) if prof is None else prof.run(name, fn, args)
       if rc != 0:
         raise TfppError(f'{name} failed with code {rc}' + (' (invalid argument)' if rc == EINVAL else ' (hipError)'))
 

@@ -118,22 +118,31 @@ static int launch_conv(const tfpp_conv_params& p, hipStream_t st) {
   return 0;
 }
 
+// tile choice: minimise padded N work, prefer wide tiles; small problems get 64x64 tiles for more workgroups.
+// 0: 128x32   1: 128x64   2: 64x64   3: 128x128
+static int conv_variant(const tfpp_conv_params& p) {
+  const long M = (long)p.B * p.Hd * p.Wd;
+  const int N = p.n_g;
+  if (N <= 32 || (N > 64 && N <= 96)) return 0;  // 24/32 -> one tile, 72 -> 3 x 32
+  if (N <= 64) return 1;
+  const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128) * p.G;
+  return tiles128 < 256 ? 2 : 3;
+}
+
+extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p) { return p ? conv_variant(*p) : TFPP_EINVAL; }
+
 template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStream_t st) {
   constexpr int VEC = ElemTraits<T>::VEC;
   if (p.ks_g % VEC != 0 || p.src_ld % VEC != 0 || p.G < 1 || p.B < 1) return TFPP_EINVAL;
   if (((uintptr_t)p.src & 15) || ((uintptr_t)p.w & 15)) return TFPP_EINVAL;
   const long M = (long)p.B * p.Hd * p.Wd;
   if (M >= (1l << 31) || M * (long)p.dst_ld >= (1l << 40)) return TFPP_EINVAL;
-  const int N = p.n_g;
-  // tile choice: minimise padded N work, prefer wide tiles; small problems get 64x64 tiles for more workgroups
-  if (N <= 32 || (N > 64 && N <= 96) ) {
-    if (N <= 32) return launch_conv<T, 128, 32, 32, 32>(p, st);
-    return launch_conv<T, 128, 32, 32, 32>(p, st);  // 72 -> 3 x 32
+  switch (conv_variant(p)) {
+    case 0: return launch_conv<T, 128, 32, 32, 32>(p, st);
+    case 1: return launch_conv<T, 128, 64, 64, 32>(p, st);
+    case 2: return launch_conv<T, 64, 64, 32, 32>(p, st);
+    default: return launch_conv<T, 128, 128, 64, 64>(p, st);
   }
-  if (N <= 64) return launch_conv<T, 128, 64, 64, 32>(p, st);
-  const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128) * p.G;
-  if (tiles128 < 256) return launch_conv<T, 64, 64, 32, 32>(p, st);
-  return launch_conv<T, 128, 128, 64, 64>(p, st);
 }
 
 extern "C" int tfpp_conv_gemm(const tfpp_conv_params* p, int dtype, void* stream) {

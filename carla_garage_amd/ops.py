@@ -59,6 +59,10 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
   p.dst_ld = dst_ld if dst_ld is not None else Cd
   p.res_ld = res_ld if res_ld is not None else p.dst_ld
   p.dst_f32 = int(dst.dtype == torch.float32 and src.dtype != torch.float32)
+  if lib.profiler is not None:
+    var = lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p))
+    lib.profiler.tag(f'conv_gemm<{"f32" if src.dtype == torch.float32 else "bf16"},{("128x32", "128x64", "64x64", "128x128")[var]}>',
+                     2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g))
   lib.tfpp_conv_gemm(ctypes.byref(p), dt(src), stream())
   return dst
 
@@ -78,6 +82,8 @@ def conv_wgrad(dy, x, dw, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=
   p.dy_ld = dy_ld if dy_ld is not None else Cd
   p.dw_ld = dw_ld if dw_ld is not None else p.c_real * R * S
   assert dw.dtype == torch.float32
+  if lib.profiler is not None:
+    lib.profiler.tag(f'conv_wgrad<{"f32" if dy.dtype == torch.float32 else "bf16"}>', 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g))
   lib.tfpp_conv_wgrad(ctypes.byref(p), dt(dy), stream())
   return dw
 
@@ -91,6 +97,8 @@ def bgemm(A, B, C, *, M, N, K, lda, ldb, ldc, batch0=1, batch1=1, a_bs=(0, 0), b
   p.batch0, p.batch1, p.a_km, p.b_km, p.act = batch0, batch1, int(a_km), int(b_km), act
   p.c_f32 = int(C.dtype == torch.float32 and A.dtype != torch.float32)
   p.alpha, p.beta = alpha, beta
+  if lib.profiler is not None:
+    lib.profiler.tag(f'bgemm<{"f32" if A.dtype == torch.float32 else "bf16"}>', 2.0 * batch0 * batch1 * M * N * K)
   lib.tfpp_bgemm(ctypes.byref(p), dt(A), stream())
   return C
 
