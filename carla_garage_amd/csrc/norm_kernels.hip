@@ -6,19 +6,21 @@
 #include "../../include/tfpp.h"
 
 // ---------------------------------------------------------------------------------------------------------------
-// BatchNorm statistics.  Block = 256 threads = CVB channel-vectors x RS row-slots (CVB = pow2 >= min(CV,64)).
+// BatchNorm reductions, two stages, no atomics.
+// Stage 1: block = 256 threads = CVB channel-vectors x NRS row-slots (CVB = pow2 >= min(CV,64)); a block walks its rows
+// with a grid stride (4 independent 16-byte loads in flight per lane) and writes one partial per channel to
+// partial[blockIdx.x][2*C].  Stage 2 sums the <=512 partials per value in double.
 // MODE 0: sum x, sum x^2.   MODE 1 (backward): g = dy*(y>0?), sum g, sum g*xhat.
 // ---------------------------------------------------------------------------------------------------------------
+#define BN_MAX_PARTIALS 512
 template <typename T, int MODE>
 __global__ void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
-                                 const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ ws, long rows,
-                                 int C, int cvb_log2, int relu_mask, int rows_per_block) {
+                                 const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial, long rows,
+                                 int C, int cvb_log2, int relu_mask) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const int CV = C / VEC, cvb = 1 << cvb_log2, nrs = 256 >> cvb_log2;
   const int cvl = threadIdx.x & (cvb - 1), rs = threadIdx.x >> cvb_log2;
   const int cv = blockIdx.y * cvb + cvl;
-  const long r0 = (long)blockIdx.x * rows_per_block;
-  const long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
   float s0[VEC], s1[VEC], mu[VEC], is[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { s0[e] = 0.f; s1[e] = 0.f; mu[e] = 0.f; is[e] = 1.f; }
@@ -27,7 +29,42 @@ __global__ void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ 
 #pragma unroll
       for (int e = 0; e < VEC; ++e) { mu[e] = mean[cv * VEC + e]; is[e] = invstd[cv * VEC + e]; }
     }
-    for (long r = r0 + rs; r < r1; r += nrs) {
+    const long stride = (long)gridDim.x * nrs;
+    constexpr int U = 4;
+    long r = (long)blockIdx.x * nrs + rs;
+    for (; r + (U - 1) * stride < rows; r += U * stride) {
+      uint4 xv[U], gv[U], ov[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t off = (size_t)(r + u * stride) * C + cv * VEC;
+        xv[u] = *reinterpret_cast<const uint4*>(x + off);
+        if (MODE == 1) {
+          gv[u] = *reinterpret_cast<const uint4*>(dy + off);
+          if (relu_mask) ov[u] = *reinterpret_cast<const uint4*>(y + off);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float v[VEC];
+        unpack16<T>(xv[u], v);
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { s0[e] += v[e]; s1[e] += v[e] * v[e]; }
+        } else {
+          float g[VEC];
+          unpack16<T>(gv[u], g);
+          if (relu_mask) {
+            float o[VEC];
+            unpack16<T>(ov[u], o);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { s0[e] += g[e]; s1[e] += g[e] * (v[e] - mu[e]) * is[e]; }
+        }
+      }
+    }
+    for (; r < rows; r += stride) {
       const size_t off = (size_t)r * C + cv * VEC;
       float v[VEC];
       load_vec<T>(x + off, v);
@@ -53,48 +90,68 @@ __global__ void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ 
   for (int e = 0; e < VEC; ++e) { sm[threadIdx.x][e] = s0[e]; sm[threadIdx.x][VEC + e] = s1[e]; }
   __syncthreads();
   if (rs == 0 && cv < CV) {
+    float* out = partial + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      double a = 0.0, b = 0.0;
-      for (int k = 0; k < nrs; ++k) { a += (double)sm[k * cvb + cvl][e]; b += (double)sm[k * cvb + cvl][VEC + e]; }
-      atomicAdd(ws + cv * VEC + e, a);
-      atomicAdd(ws + C + cv * VEC + e, b);
+      float a = 0.f, b = 0.f;
+      for (int k = 0; k < nrs; ++k) { a += sm[k * cvb + cvl][e]; b += sm[k * cvb + cvl][VEC + e]; }
+      out[cv * VEC + e] = a;
+      out[C + cv * VEC + e] = b;
     }
   }
 }
 
+// ws[v] = sum_k partial[k][v] in double; block = 64 values x 4 slots
+__global__ void bn_reduce_final_kernel(const float* __restrict__ partial, double* __restrict__ ws, int nblk, int n2c) {
+  const int vl = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const int v = blockIdx.x * 64 + vl;
+  double s = 0.0;
+  if (v < n2c)
+    for (int k = slot; k < nblk; k += 4) s += (double)partial[(size_t)k * n2c + v];
+  __shared__ double sm[4][64];
+  sm[slot][vl] = s;
+  __syncthreads();
+  if (slot == 0 && v < n2c) ws[v] = sm[0][vl] + sm[1][vl] + sm[2][vl] + sm[3][vl];
+}
+
 template <typename T, int MODE>
-static int launch_bn_reduce(const void* x, const void* dy, const void* y, const float* mean, const float* invstd, double* ws, long rows, int C,
-                            int relu_mask, hipStream_t st) {
+static int launch_bn_reduce(const void* x, const void* dy, const void* y, const float* mean, const float* invstd, float* partial, double* ws,
+                            long rows, int C, int relu_mask, hipStream_t st) {
   constexpr int VEC = ElemTraits<T>::VEC;
   if (C % VEC) return TFPP_EINVAL;
-  hipError_t e = hipMemsetAsync(ws, 0, (size_t)2 * C * sizeof(double), st);
-  if (e != hipSuccess) return -(int)e;
   const int CV = C / VEC;
   int lg = 0;
   while ((1 << lg) < CV && lg < 6) ++lg;
   const int cvb = 1 << lg, nrs = 256 >> lg;
-  const int rpb = nrs * 16;  // 16 rows per thread
-  dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((CV + cvb - 1) / cvb));
-  hipLaunchKernelGGL((bn_reduce_kernel<T, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)y, mean, invstd, ws, rows, C, lg,
-                     relu_mask, rpb);
+  long nblk = (rows + (long)nrs * 8 - 1) / ((long)nrs * 8);  // >= 8 rows per thread
+  const int ny = (CV + cvb - 1) / cvb;
+  const long cap = BN_MAX_PARTIALS;
+  if (nblk > cap) nblk = cap;
+  if (nblk * ny > 4096) nblk = 4096 / ny > 1 ? 4096 / ny : 1;
+  if (nblk < 1) nblk = 1;
+  dim3 grid((unsigned)nblk, (unsigned)ny);
+  hipLaunchKernelGGL((bn_reduce_kernel<T, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)y, mean, invstd, partial, rows, C,
+                     lg, relu_mask);
+  hipLaunchKernelGGL(bn_reduce_final_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, partial, ws, (int)nblk, 2 * C);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int tfpp_bn_stats(const void* x, double* ws, int64_t rows, int C, int dtype, void* stream) {
-  if (!x || !ws) return TFPP_EINVAL;
+extern "C" int tfpp_bn_scratch_floats(int C) { return BN_MAX_PARTIALS * 2 * C + 4 * C; }
+
+extern "C" int tfpp_bn_stats(const void* x, float* scratch, double* ws, int64_t rows, int C, int dtype, void* stream) {
+  if (!x || !ws || !scratch) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  return dtype == TFPP_F32 ? launch_bn_reduce<float, 0>(x, nullptr, nullptr, nullptr, nullptr, ws, (long)rows, C, 0, st)
-                           : launch_bn_reduce<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, ws, (long)rows, C, 0, st);
+  return dtype == TFPP_F32 ? launch_bn_reduce<float, 0>(x, nullptr, nullptr, nullptr, nullptr, scratch, ws, (long)rows, C, 0, st)
+                           : launch_bn_reduce<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, scratch, ws, (long)rows, C, 0, st);
 }
 
-extern "C" int tfpp_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* save_mean, const float* save_invstd, double* ws,
-                                  int64_t rows, int C, int relu_mask, int dtype, void* stream) {
-  if (!dy || !x || !ws || !save_mean || !save_invstd || (relu_mask && !y)) return TFPP_EINVAL;
+extern "C" int tfpp_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* save_mean, const float* save_invstd,
+                                  float* scratch, double* ws, int64_t rows, int C, int relu_mask, int dtype, void* stream) {
+  if (!dy || !x || !ws || !scratch || !save_mean || !save_invstd || (relu_mask && !y)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  return dtype == TFPP_F32 ? launch_bn_reduce<float, 1>(x, dy, y, save_mean, save_invstd, ws, (long)rows, C, relu_mask, st)
-                           : launch_bn_reduce<bf16_t, 1>(x, dy, y, save_mean, save_invstd, ws, (long)rows, C, relu_mask, st);
+  return dtype == TFPP_F32 ? launch_bn_reduce<float, 1>(x, dy, y, save_mean, save_invstd, scratch, ws, (long)rows, C, relu_mask, st)
+                           : launch_bn_reduce<bf16_t, 1>(x, dy, y, save_mean, save_invstd, scratch, ws, (long)rows, C, relu_mask, st);
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ ws, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -150,21 +207,29 @@ extern "C" int tfpp_bn_fold(const float* gamma, const float* beta, const float* 
   return 0;
 }
 
-// dx = gamma*invstd*(g - ws0/rows - xhat*ws1/rows) ; dres = g ; block (0,*) also accumulates dgamma/dbeta
+// dx = gamma*invstd*(g - ws0/rows - xhat*ws1/rows) = A[c]*g + Bc[c]*x + D[c] ; dres = g.
+// coefficient kernel (per channel) also accumulates dgamma += ws1, dbeta += ws0.
+__global__ void bn_bwd_coef_kernel(const double* __restrict__ ws, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                   const float* __restrict__ invstd, float* __restrict__ coef, float* __restrict__ dgamma,
+                                   float* __restrict__ dbeta, long rows, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double n = (double)rows, s0 = ws[c], s1 = ws[C + c];
+  const double gm = gamma ? (double)gamma[c] : 1.0, is = (double)invstd[c], mu = (double)mean[c];
+  const double A = gm * is, Bc = -gm * is * is * s1 / n, D = -gm * is * s0 / n - Bc * mu;
+  coef[c] = (float)A;
+  coef[C + c] = (float)Bc;
+  coef[2 * C + c] = (float)D;
+  if (dgamma) dgamma[c] += (float)s1;
+  if (dbeta) dbeta[c] += (float)s0;
+}
+
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x, const float* __restrict__ gamma,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd, const double* __restrict__ ws,
-                                    T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta, long rows,
-                                    int C, int relu_mask) {
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x, const float* __restrict__ coef,
+                                    T* __restrict__ dx, T* __restrict__ dres, long nvec, int C, int relu_mask) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const int CV = C / VEC;
-  const long nvec = rows * CV;
-  const float invn = 1.f / (float)rows;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < C) {
-    if (dgamma) dgamma[i] += (float)ws[C + i];
-    if (dbeta) dbeta[i] += (float)ws[i];
-  }
   const long stride = (long)gridDim.x * blockDim.x;
   for (; i < nvec; i += stride) {
     const int c0 = (int)(i % CV) * VEC;
@@ -179,32 +244,29 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
     }
     if (dres) store_vec<T>(dres + i * VEC, g);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const int c = c0 + e;
-      const float is = invstd[c], xh = (v[e] - mean[c]) * is;
-      const float gm = gamma ? gamma[c] : 1.f;
-      v[e] = gm * is * (g[e] - (float)ws[c] * invn - xh * (float)ws[C + c] * invn);
-    }
+    for (int e = 0; e < VEC; ++e) v[e] = coef[c0 + e] * g[e] + coef[C + c0 + e] * v[e] + coef[2 * C + c0 + e];
     store_vec<T>(dx + i * VEC, v);
   }
 }
 
 extern "C" int tfpp_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
-                                 const float* save_invstd, const double* ws, void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows,
-                                 int C, int relu_mask, int dtype, void* stream) {
-  if (!dy || !x || !ws || !dx || !save_mean || !save_invstd || (relu_mask && !y)) return TFPP_EINVAL;
+                                 const float* save_invstd, const double* ws, float* scratch, void* dx, void* dres, float* dgamma,
+                                 float* dbeta, int64_t rows, int C, int relu_mask, int dtype, void* stream) {
+  if (!dy || !x || !ws || !dx || !scratch || !save_mean || !save_invstd || (relu_mask && !y)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int VEC = dtype == TFPP_F32 ? 4 : 8;
   if (C % VEC) return TFPP_EINVAL;
+  float* coef = scratch + (size_t)BN_MAX_PARTIALS * 2 * C;  // after the stage-1 partials
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, gamma, save_mean, save_invstd, coef, dgamma, dbeta,
+                     (long)rows, C);
   long nvec = rows * (C / VEC);
   long blocks = (nvec + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  if (blocks * 256 < C) blocks = (C + 255) / 256;
-  // NOTE: the dgamma/dbeta accumulation uses the first C global threads; grid-stride keeps them valid.
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
   if (dtype == TFPP_F32)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)dy, (const float*)y, (const float*)x, gamma, save_mean, save_invstd, ws, (float*)dx, (float*)dres, dgamma, dbeta, (long)rows, C, relu_mask);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)dy, (const float*)y, (const float*)x, coef, (float*)dx, (float*)dres, nvec, C, relu_mask);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, gamma, save_mean, save_invstd, ws, (bf16_t*)dx, (bf16_t*)dres, dgamma, dbeta, (long)rows, C, relu_mask);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, coef, (bf16_t*)dx, (bf16_t*)dres, nvec, C, relu_mask);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

@@ -662,96 +662,108 @@ extern "C" int tfpp_se_dgate(const void* dy, const void* x, float* dgate, int B,
   return dtype == TFPP_F32 ? launch_hw_reduce<float>(dy, x, dgate, B, HW, C, 1.f, st) : launch_hw_reduce<bf16_t>(dy, x, dgate, B, HW, C, 1.f, st);
 }
 
-// one block per sample: hidden = relu(W1 pool + b1) ; gate = sigmoid(W2 hidden + b2)
-__global__ void se_gate_fwd_kernel(const float* __restrict__ pool, const float* __restrict__ w1, const float* __restrict__ b1,
-                                   const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ hidden,
-                                   float* __restrict__ gate, int C, int RD) {
-  extern __shared__ float sm[];  // pool[C] + hidden[RD]
-  float* sp = sm;
-  float* sh = sm + C;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  for (int c = tid; c < C; c += blockDim.x) sp[c] = pool[(size_t)b * C + c];
-  __syncthreads();
-  for (int j = wave; j < RD; j += nw) {
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += w1[(size_t)j * C + c] * sp[c];
-    s = wave_sum(s);
-    if (lane == 0) {
-      s += b1[j];
-      s = s > 0.f ? s : 0.f;
-      sh[j] = s;
-      hidden[(size_t)b * RD + j] = s;
-    }
+// squeeze-excite gate: hidden = relu(W1 pool + b1) [one wave per (b,j)] ; gate = sigmoid(W2 hidden + b2) [thread per (b,c)]
+__global__ void se_hidden_kernel(const float* __restrict__ pool, const float* __restrict__ w1, const float* __restrict__ b1,
+                                 float* __restrict__ hidden, int B, int C, int RD) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= B * RD) return;
+  const int b = w / RD, j = w - b * RD;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += w1[(size_t)j * C + c] * pool[(size_t)b * C + c];
+  s = wave_sum(s);
+  if (lane == 0) {
+    s += b1[j];
+    hidden[w] = s > 0.f ? s : 0.f;
   }
+}
+
+__global__ void se_gate_kernel(const float* __restrict__ hidden, const float* __restrict__ w2, const float* __restrict__ b2,
+                               float* __restrict__ gate, int C, int RD) {
+  extern __shared__ float sh[];  // hidden[b, :RD]
+  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int j = threadIdx.x; j < RD; j += blockDim.x) sh[j] = hidden[(size_t)b * RD + j];
   __syncthreads();
-  for (int c = tid; c < C; c += blockDim.x) {
-    float s = b2[c];
-    for (int j = 0; j < RD; ++j) s += w2[(size_t)c * RD + j] * sh[j];
-    gate[(size_t)b * C + c] = 1.f / (1.f + __expf(-s));
-  }
+  if (c >= C) return;
+  float s = b2[c];
+  const float* wr = w2 + (size_t)c * RD;
+  for (int j = 0; j < RD; ++j) s += wr[j] * sh[j];
+  gate[(size_t)b * C + c] = 1.f / (1.f + __expf(-s));
 }
 
 extern "C" int tfpp_se_gate_fwd(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2, float* hidden,
                                 float* gate, int B, int C, int RD, void* stream) {
   if (!pool || !w1 || !w2 || !hidden || !gate) return TFPP_EINVAL;
-  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), (size_t)(C + RD) * sizeof(float), (hipStream_t)stream, pool, w1, b1, w2, b2,
-                     hidden, gate, C, RD);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(se_hidden_kernel, dim3((B * RD + 3) / 4), dim3(256), 0, st, pool, w1, b1, hidden, B, C, RD);
+  hipLaunchKernelGGL(se_gate_kernel, dim3((C + 255) / 256, B), dim3(256), (size_t)RD * sizeof(float), st, hidden, w2, b2, gate, C, RD);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
 
-// one block per sample; parameter gradients accumulated with fp32 atomics
-__global__ void se_gate_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate, const float* __restrict__ hidden,
-                                   const float* __restrict__ pool, const float* __restrict__ w1, const float* __restrict__ w2,
-                                   float* __restrict__ dpool, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
-                                   float* __restrict__ db2, int C, int RD) {
-  extern __shared__ float sm[];  // dz2[C] + hid[RD] + dz1[RD] + pool[C]
-  float* dz2 = sm;
-  float* sh = sm + C;
-  float* dz1 = sh + RD;
-  float* sp = dz1 + RD;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  for (int c = tid; c < C; c += blockDim.x) {
-    const float gt = gate[(size_t)b * C + c];
-    const float d = dgate[(size_t)b * C + c] * gt * (1.f - gt);
-    dz2[c] = d;
-    sp[c] = pool[(size_t)b * C + c];
-    atomicAdd(db2 + c, d);
+// backward of the gate MLP.  gd[b,c] = dgate*g*(1-g).  dz1[b,j] = (hidden>0) * sum_c gd[b,c] w2[c,j]  (one wave per (b,j))
+__global__ void se_dz1_kernel(const float* __restrict__ dgate, const float* __restrict__ gate, const float* __restrict__ hidden,
+                              const float* __restrict__ w2, float* __restrict__ dz1, int B, int C, int RD) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= B * RD) return;
+  const int b = w / RD, j = w - b * RD;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float g = gate[(size_t)b * C + c];
+    s += dgate[(size_t)b * C + c] * g * (1.f - g) * w2[(size_t)c * RD + j];
   }
-  for (int j = tid; j < RD; j += blockDim.x) sh[j] = hidden[(size_t)b * RD + j];
-  __syncthreads();
-  for (int i = tid; i < C * RD; i += blockDim.x) {
-    const int c = i / RD, j = i - c * RD;
-    atomicAdd(dw2 + i, dz2[c] * sh[j]);
-  }
-  for (int j = wave; j < RD; j += nw) {
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += dz2[c] * w2[(size_t)c * RD + j];
-    s = wave_sum(s);
-    if (lane == 0) {
-      s = sh[j] > 0.f ? s : 0.f;
-      dz1[j] = s;
-      atomicAdd(db1 + j, s);
+  s = wave_sum(s);
+  if (lane == 0) dz1[w] = hidden[w] > 0.f ? s : 0.f;
+}
+
+// one thread per output element, single writer (no atomics): [0,C*RD) dw2 (+db2), [C*RD,2*C*RD) dw1 (+db1), then dpool
+__global__ void se_param_grads_kernel(const float* __restrict__ dgate, const float* __restrict__ gate, const float* __restrict__ hidden,
+                                      const float* __restrict__ pool, const float* __restrict__ w1, const float* __restrict__ dz1,
+                                      float* __restrict__ dpool, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                      float* __restrict__ db2, int B, int C, int RD) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n1 = (long)C * RD;
+  if (i < n1) {  // dw2[c][j]
+    const int c = (int)(i / RD), j = (int)(i - (long)c * RD);
+    float s = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float g = gate[(size_t)b * C + c];
+      const float gd = dgate[(size_t)b * C + c] * g * (1.f - g);
+      s += gd * hidden[(size_t)b * RD + j];
+      sb += gd;
     }
-  }
-  __syncthreads();
-  for (int i = tid; i < C * RD; i += blockDim.x) {
-    const int j = i / C, c = i - j * C;
-    atomicAdd(dw1 + i, dz1[j] * sp[c]);
-  }
-  for (int c = tid; c < C; c += blockDim.x) {
+    dw2[i] += s;
+    if (j == 0) db2[c] += sb;
+  } else if (i < 2 * n1) {  // dw1[j][c]
+    const long k = i - n1;
+    const int j = (int)(k / C), c = (int)(k - (long)j * C);
+    float s = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float d = dz1[(size_t)b * RD + j];
+      s += d * pool[(size_t)b * C + c];
+      sb += d;
+    }
+    dw1[k] += s;
+    if (c == 0) db1[j] += sb;
+  } else if (i < 2 * n1 + (long)B * C) {  // dpool[b][c]
+    const long k = i - 2 * n1;
+    const int b = (int)(k / C), c = (int)(k - (long)b * C);
     float s = 0.f;
-    for (int j = 0; j < RD; ++j) s += dz1[j] * w1[(size_t)j * C + c];
-    dpool[(size_t)b * C + c] = s;
+    for (int j = 0; j < RD; ++j) s += dz1[(size_t)b * RD + j] * w1[(size_t)j * C + c];
+    dpool[k] = s;
   }
 }
 
 extern "C" int tfpp_se_gate_bwd(const float* dgate, const float* gate, const float* hidden, const float* pool, const float* w1,
-                                const float* w2, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int B, int C, int RD,
-                                void* stream) {
-  if (!dgate || !gate || !hidden || !pool || !dpool) return TFPP_EINVAL;
-  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), (size_t)(2 * C + 2 * RD) * sizeof(float), (hipStream_t)stream, dgate, gate,
-                     hidden, pool, w1, w2, dpool, dw1, db1, dw2, db2, C, RD);
+                                const float* w2, float* dz1_scratch, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int B,
+                                int C, int RD, void* stream) {
+  if (!dgate || !gate || !hidden || !pool || !dpool || !dz1_scratch) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(se_dz1_kernel, dim3((B * RD + 3) / 4), dim3(256), 0, st, dgate, gate, hidden, w2, dz1_scratch, B, C, RD);
+  const long n = 2l * C * RD + (long)B * C;
+  hipLaunchKernelGGL(se_param_grads_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dgate, gate, hidden, pool, w1, dz1_scratch,
+                     dpool, dw1, db1, dw2, db2, B, C, RD);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

@@ -141,7 +141,6 @@ class Engine:
       g = bb.transformers[i]
       for l, blk in enumerate(g.blocks):
         q = f'backbone.transformers.{i}.blocks.{l}'
-        self._spec(q + '.attn.proj', blk.attn.proj.weight, blk.attn.proj.bias)
         self._spec(q + '.mlp.0', blk.mlp[0].weight, blk.mlp[0].bias)
         self._spec(q + '.mlp.2', blk.mlp[2].weight, blk.mlp[2].bias)
     if hasattr(bb, 'c5_conv'):
@@ -248,13 +247,17 @@ class Engine:
       c, nh = g.n_embd, self.cfg.n_head
       d = c // nh
       dp = ops.pad_to(d, 8)
-      rmap = torch.full((nh * dp,), -1, dtype=torch.int32)
-      for hh in range(nh):
-        rmap[hh * dp:hh * dp + d] = torch.arange(hh * d, (hh + 1) * d, dtype=torch.int32)
-      rmap = self._const(f'qkv_rmap{i}', lambda rmap=rmap: rmap)
-      inv = torch.full((c,), -1, dtype=torch.int32)  # parameter column -> packed column
-      inv[rmap.cpu()[rmap.cpu() >= 0].long()] = torch.nonzero(rmap.cpu() >= 0).flatten().to(torch.int32)
-      inv = self._const(f'qkv_inv{i}', lambda inv=inv: inv)
+
+      def host_maps(nh=nh, d=d, dp=dp, c=c):
+        r = torch.full((nh * dp,), -1, dtype=torch.int32)
+        for hh in range(nh):
+          r[hh * dp:hh * dp + d] = torch.arange(hh * d, (hh + 1) * d, dtype=torch.int32)
+        iv = torch.full((c,), -1, dtype=torch.int32)  # parameter column -> packed column
+        iv[r[r >= 0].long()] = torch.nonzero(r >= 0).flatten().to(torch.int32)
+        return r, iv
+
+      rmap = self._const(f'qkv_rmap{i}', lambda: host_maps()[0])
+      inv = self._const(f'qkv_inv{i}', lambda: host_maps()[1])
       for l, blk in enumerate(g.blocks):
         st = self._attn_state(i, l)
         st.update(c=c, nh=nh, d=d, dp=dp, rmap=rmap, inv=inv)

@@ -162,9 +162,23 @@ def nchw_to_nhwc_pad(g, dtype, ld):
 
 
 # ------------------------------------------------------------------------------------------------ batch norm
+_BN_SCRATCH = {}
+
+
+def bn_scratch(c, device):
+  """Shared scratch for the BatchNorm reductions (kernels on one stream run in order, so one buffer serves every layer)."""
+  need = lib.raw('tfpp_bn_scratch_floats')(c)
+  key = str(device)
+  buf = _BN_SCRATCH.get(key)
+  if buf is None or buf.numel() < need:
+    buf = torch.empty(max(need, lib.raw('tfpp_bn_scratch_floats')(1512)), device=device, dtype=torch.float32)
+    _BN_SCRATCH[key] = buf
+  return buf
+
+
 def bn_stats(x, ws):
   c = x.shape[-1]
-  lib.tfpp_bn_stats(ptr(_chk(x)), ptr(ws), x.numel() // c, c, dt(x), stream())
+  lib.tfpp_bn_stats(ptr(_chk(x)), ptr(bn_scratch(c, x.device)), ptr(ws), x.numel() // c, c, dt(x), stream())
 
 
 def bn_finalize(ws, gamma, beta, rm, rv, nbt, scale, shift, save_mean, save_invstd, rows, momentum=0.1, eps=1e-5):
@@ -189,12 +203,13 @@ def affine_act(x, y=None, scale=None, shift=None, res=None, gate=None, rows_per_
 def bn_bwd(dy, y, x, gamma, save_mean, save_invstd, ws, dgamma, dbeta, relu_mask, want_dres=False):
   c = x.shape[-1]
   rows = x.numel() // c
-  lib.tfpp_bn_bwd_reduce(ptr(_chk(dy)), ptr(y), ptr(_chk(x)), ptr(save_mean), ptr(save_invstd), ptr(ws), rows, c, int(relu_mask),
-                         dt(x), stream())
+  scratch = bn_scratch(c, x.device)
+  lib.tfpp_bn_bwd_reduce(ptr(_chk(dy)), ptr(y), ptr(_chk(x)), ptr(save_mean), ptr(save_invstd), ptr(scratch), ptr(ws), rows, c,
+                         int(relu_mask), dt(x), stream())
   dx = torch.empty_like(x)
   dres = torch.empty_like(x) if want_dres else None
-  lib.tfpp_bn_bwd_apply(ptr(dy), ptr(y), ptr(x), ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(ws), ptr(dx), ptr(dres),
-                        ptr(dgamma), ptr(dbeta), rows, c, int(relu_mask), dt(x), stream())
+  lib.tfpp_bn_bwd_apply(ptr(dy), ptr(y), ptr(x), ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(ws), ptr(scratch), ptr(dx),
+                        ptr(dres), ptr(dgamma), ptr(dbeta), rows, c, int(relu_mask), dt(x), stream())
   return dx, dres
 
 
@@ -232,8 +247,9 @@ def se_gate_bwd(dgate, gate, hidden, pool, w1, w2, dw1, db1, dw2, db2):
   b, c = gate.shape
   rd = hidden.shape[1]
   dpool = torch.empty_like(gate)
-  lib.tfpp_se_gate_bwd(ptr(dgate), ptr(gate), ptr(hidden), ptr(pool), ptr(w1), ptr(w2), ptr(dpool), ptr(dw1), ptr(db1), ptr(dw2),
-                       ptr(db2), b, c, rd, stream())
+  scratch = torch.empty_like(hidden)
+  lib.tfpp_se_gate_bwd(ptr(dgate), ptr(gate), ptr(hidden), ptr(pool), ptr(w1), ptr(w2), ptr(scratch), ptr(dpool), ptr(dw1), ptr(db1),
+                       ptr(dw2), ptr(db2), b, c, rd, stream())
   return dpool
 
 

@@ -125,7 +125,7 @@ int tfpp_nchw_to_nhwc_pad(const float* in, void* out, int B, int C, int H, int W
 
 /* ---------------------------------------------------------------------------------------------------------
  * BatchNorm2d (timm ConvNormAct in every RegNet block; F.batch_norm).  x is [rows, C] (NHWC flattened).
- * bn_stats: ws[0:C] = sum x, ws[C:2C] = sum x^2 in double (ws zeroed by the call).
+ * bn_stats: ws[0:C] = sum x, ws[C:2C] = sum x^2 in double (two-stage reduction through `scratch`, no atomics).
  * bn_finalize (train): batch mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale; saves
  *   mean/invstd; running stats update with `momentum` and the unbiased variance; num_batches_tracked += 1.
  * bn_fold (eval): scale/shift from the running statistics (then applied in the conv epilogue).
@@ -133,7 +133,9 @@ int tfpp_nchw_to_nhwc_pad(const float* in, void* out, int B, int C, int H, int W
  *   squeeze-excite scale, [B,C] fp32, rows_per_batch rows per sample).
  * bn_bwd_reduce: g = dy*(y>0 if relu_mask); ws[0:C] = sum g, ws[C:2C] = sum g*xhat (double).
  * bn_bwd_apply: dx = gamma*invstd*(g - ws0/rows - xhat*ws1/rows); dgamma += ws1; dbeta += ws0; dres = g (nullable). */
-int tfpp_bn_stats(const void* x, double* ws, int64_t rows, int C, int dtype, void* stream);
+/* scratch: tfpp_bn_scratch_floats(C) floats shared by the three reduction entry points (stage-1 partials + coefficients) */
+int tfpp_bn_scratch_floats(int C);
+int tfpp_bn_stats(const void* x, float* scratch, double* ws, int64_t rows, int C, int dtype, void* stream);
 int tfpp_bn_finalize(const double* ws, const float* gamma, const float* beta, float* running_mean, float* running_var,
                      int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean, float* save_invstd, int64_t rows,
                      int C, float momentum, float eps, void* stream);
@@ -141,11 +143,11 @@ int tfpp_bn_fold(const float* gamma, const float* beta, const float* running_mea
                  float* shift, int C, float eps, void* stream);
 int tfpp_affine_act(const void* x, const float* scale, const float* shift, const void* res, const float* gate, void* y, int64_t rows,
                     int C, int64_t rows_per_batch, int act, int dtype, void* stream);
-int tfpp_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* save_mean, const float* save_invstd, double* ws,
-                       int64_t rows, int C, int relu_mask, int dtype, void* stream);
+int tfpp_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* save_mean, const float* save_invstd, float* scratch,
+                       double* ws, int64_t rows, int C, int relu_mask, int dtype, void* stream);
 int tfpp_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
-                      const float* save_invstd, const double* ws, void* dx, void* dres, float* dgamma, float* dbeta, int64_t rows,
-                      int C, int relu_mask, int dtype, void* stream);
+                      const float* save_invstd, const double* ws, float* scratch, void* dx, void* dres, float* dgamma, float* dbeta,
+                      int64_t rows, int C, int relu_mask, int dtype, void* stream);
 /* BatchNorm1d(1, affine=False) on the ego speed (model.py:216,311), fp32 [B]. */
 int tfpp_bn1d_scalar(const float* x, float* y, float* running_mean, float* running_var, int64_t* nbt, int B, int training,
                      float momentum, float eps, void* stream);
@@ -160,7 +162,8 @@ int tfpp_se_gate_fwd(const float* pool, const float* w1, const float* b1, const 
                      float* gate, int B, int C, int RD, void* stream);
 int tfpp_se_dgate(const void* dy, const void* x, float* dgate, int B, int HW, int C, int dtype, void* stream);
 int tfpp_se_gate_bwd(const float* dgate, const float* gate, const float* hidden, const float* pool, const float* w1,
-                     const float* w2, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int B, int C, int RD, void* stream);
+                     const float* w2, float* dz1_scratch /* [B*RD] */, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
+                     int B, int C, int RD, void* stream);
 int tfpp_se_bwd_apply(const void* dy, const float* gate, const float* dpool, void* dx, int B, int HW, int C, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
