@@ -22,7 +22,7 @@ struct TileCfg {
   static constexpr int VEC = ElemTraits<T>::VEC;
   static constexpr int KV = BK / VEC;                       // 16-byte vectors per tile row
   static constexpr int LDK = BK + (sizeof(T) == 2 ? 8 : 4);  // row-major pitch (elements): 80 B / 144 B
-  static constexpr int PADR = (sizeof(T) == 2 ? 4 : 2);      // k-major pitch pad: conflict-free scalar gathers
+  static constexpr int PADR = (sizeof(T) == 2 ? 16 : 2);     // k-major pitch pad (bf16: 32-byte row skew for ds_read_tr16_b64)
   static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
   static constexpr int NT = WAVES_M * WAVES_N * TFPP_WAVE;
   static constexpr int FM = WM / 16, FN = WN / 16;
@@ -42,16 +42,23 @@ __device__ __forceinline__ void frag_load_rm(Frag<float>& f, const float* p) {
   const float4 b = *reinterpret_cast<const float4*>(p + 4);
   f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
 }
-// fragment from a k-major LDS image: p points at element [k = (l>>4)*8][row = frag_row0 + (l&15)], pitch ldr
-__device__ __forceinline__ void frag_load_km(Frag<bf16_t>& f, const bf16_t* p, int ldr) {
-  unsigned w[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) w[j] = (unsigned)p[(2 * j) * ldr] | ((unsigned)p[(2 * j + 1) * ldr] << 16);
-  f.v = make_uint4(w[0], w[1], w[2], w[3]);
+// fragment from a k-major LDS image [k][row] (pitch ldr): p points at element [k = (l>>4)*8][row = frag_row0], r16 = l&15.
+// bf16: two hardware transpose reads (ds_read_b64_tr_b16).  Within each 16-lane group, lane m supplies the address of 4
+// consecutive rows at k-row (m>>2), row chunk (m&3)*4; the instruction returns to lane i the 4 k-values of row i
+// (out[i][j] = in[4j + (i>>2)][i&3] -- measured on gfx950).  Two reads give k = 0..3 and 4..7.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ void frag_load_km(Frag<bf16_t>& f, const bf16_t* p, int ldr, int r16) {
+  const bf16_t* a0 = p + (r16 >> 2) * ldr + (r16 & 3) * 4;
+  const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+  const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * ldr));
+  f.v = make_uint4((unsigned)(unsigned short)v0[0] | ((unsigned)(unsigned short)v0[1] << 16),
+                   (unsigned)(unsigned short)v0[2] | ((unsigned)(unsigned short)v0[3] << 16),
+                   (unsigned)(unsigned short)v1[0] | ((unsigned)(unsigned short)v1[1] << 16),
+                   (unsigned)(unsigned short)v1[2] | ((unsigned)(unsigned short)v1[3] << 16));
 }
-__device__ __forceinline__ void frag_load_km(Frag<float>& f, const float* p, int ldr) {
+__device__ __forceinline__ void frag_load_km(Frag<float>& f, const float* p, int ldr, int r16) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) f.v[j] = p[j * ldr];
+  for (int j = 0; j < 8; ++j) f.v[j] = p[j * ldr + r16];
 }
 
 __device__ __forceinline__ void frag_mma(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x4_t& acc) {
@@ -70,15 +77,15 @@ __device__ __forceinline__ void tile_mma_step(const T* As, const T* Bs, int wm, 
   const int r16 = lane & 15, kg = (lane >> 4) * 8;
 #pragma unroll
   for (int i = 0; i < C::FM; ++i) {
-    const int row = wm * C::WM + i * 16 + r16;
-    if constexpr (A_KM) frag_load_km(fa[i], As + kg * C::LDRA + row, C::LDRA);
-    else frag_load_rm(fa[i], As + row * C::LDK + kg);
+    const int row0 = wm * C::WM + i * 16;
+    if constexpr (A_KM) frag_load_km(fa[i], As + kg * C::LDRA + row0, C::LDRA, r16);
+    else frag_load_rm(fa[i], As + (row0 + r16) * C::LDK + kg);
   }
 #pragma unroll
   for (int j = 0; j < C::FN; ++j) {
-    const int row = wn * C::WN + j * 16 + r16;
-    if constexpr (B_KM) frag_load_km(fb[j], Bs + kg * C::LDRB + row, C::LDRB);
-    else frag_load_rm(fb[j], Bs + row * C::LDK + kg);
+    const int row0 = wn * C::WN + j * 16;
+    if constexpr (B_KM) frag_load_km(fb[j], Bs + kg * C::LDRB + row0, C::LDRB, r16);
+    else frag_load_rm(fb[j], Bs + (row0 + r16) * C::LDK + kg);
   }
 #pragma unroll
   for (int i = 0; i < C::FM; ++i)

@@ -126,7 +126,7 @@ static int conv_variant(const tfpp_conv_params& p) {
   if (N <= 32 || (N > 64 && N <= 96)) return 0;  // 24/32 -> one tile, 72 -> 3 x 32
   if (N <= 64) return 1;
   const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128) * p.G;
-  return tiles128 < 256 ? 2 : 3;
+  return tiles128 < 1024 ? 2 : 3;  // latency-bound regime: keep >= 4 workgroups per CU in flight
 }
 
 extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p) { return p ? conv_variant(*p) : TFPP_EINVAL; }
@@ -261,7 +261,8 @@ template <typename T> static int dispatch_wgrad(tfpp_wgrad_params p, hipStream_t
   const long P = (long)p.B * p.Hd * p.Wd;
   const int KK = p.R * p.S * p.ks_g;
   const bool small = (p.n_g <= 32 || KK <= 32);
-  const int bm = small ? 32 : 64, bn = small ? 32 : 64;
+  const bool big = false;  // 128x128 weight-gradient tiles measured slower (atomic traffic, fewer workgroups)
+  const int bm = small ? 32 : (big ? 128 : 64), bn = bm;
   if (p.splits <= 0) {
     // enough workgroups to fill 256 CUs several times over, but at least 256 pixels of reduction each
     const long tiles = (long)cdiv(p.n_g, bm) * cdiv(KK, bn) * p.G;

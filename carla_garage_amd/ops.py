@@ -8,6 +8,10 @@ import torch
 from ._lib import (lib, ConvParams, WgradParams, BgemmParams, F32, BF16, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU,
                    ACT_TANH)
 
+import os as _os
+
+PROFILE_SHAPES = bool(int(_os.environ.get('TFPP_PROFILE_SHAPES', '0')))
+
 __all__ = ['F32', 'BF16', 'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_GELU', 'ACT_TANH']
 
 
@@ -61,8 +65,10 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
   p.dst_f32 = int(dst.dtype == torch.float32 and src.dtype != torch.float32)
   if lib.profiler is not None:
     var = lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p))
-    lib.profiler.tag(f'conv_gemm<{"f32" if src.dtype == torch.float32 else "bf16"},{("128x32", "128x64", "64x64", "128x128")[var]}>',
-                     2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g))
+    fam = f'conv_gemm<{"f32" if src.dtype == torch.float32 else "bf16"},{("128x32", "128x64", "64x64", "128x128")[var]}>'
+    if PROFILE_SHAPES:
+      fam += f' m{mode} M={B * Hd * Wd} N={p.n_g} K={R * S * p.ks_g} G={G} k{R}s{stride}'
+    lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g))
   lib.tfpp_conv_gemm(ctypes.byref(p), dt(src), stream())
   return dst
 
@@ -83,7 +89,10 @@ def conv_wgrad(dy, x, dw, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=
   p.dw_ld = dw_ld if dw_ld is not None else p.c_real * R * S
   assert dw.dtype == torch.float32
   if lib.profiler is not None:
-    lib.profiler.tag(f'conv_wgrad<{"f32" if dy.dtype == torch.float32 else "bf16"}>', 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g))
+    fam = f'conv_wgrad<{"f32" if dy.dtype == torch.float32 else "bf16"}>'
+    if PROFILE_SHAPES:
+      fam += f' P={B * Hd * Wd} N={p.n_g} K={R * S * p.ks_g} G={G} k{R}s{stride}'
+    lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g))
   lib.tfpp_conv_wgrad(ctypes.byref(p), dt(dy), stream())
   return dw
 
