@@ -1,0 +1,60 @@
+"""Data-parallel exchange of the MI355X path (team_code/train.py:361-365,516-520): one process per GPU, one flat fp32
+gradient arena, one all-reduce per step.  Backend 'nccl' is RCCL over xGMI on ROCm; the same code runs on 'gloo' CPU
+tensors, which is how tests/test_dist.py covers it without GPUs."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+  """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); returns (rank, local_rank, world)."""
+  rank = int(os.environ.get('RANK', 0))
+  local_rank = int(os.environ.get('LOCAL_RANK', 0))
+  world = int(os.environ.get('WORLD_SIZE', 1))
+  if world > 1 and not dist.is_initialized():
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    dist.init_process_group(backend or ('nccl' if torch.cuda.is_available() else 'gloo'), init_method='env://')
+  return rank, local_rank, world
+
+
+def world_size(group=None):
+  return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def broadcast_state(flat_param, buffers, group=None, src=0):
+  """Rank ``src``'s parameters and buffers everywhere (what the DDP constructor does, train.py:516)."""
+  if world_size(group) == 1:
+    return
+  dist.broadcast(flat_param, src, group=group)
+  for b in buffers:
+    dist.broadcast(b, src, group=group)
+
+
+def all_reduce_gradients(flat_grad, group=None, chunk_elems=None):
+  """SUM all-reduce of the flat gradient arena (the average is folded into the optimizer's grad_scale = 1/world).
+  ``chunk_elems`` splits the arena into fewer, larger collectives than DDP's 25 MB buckets (default: one)."""
+  w = world_size(group)
+  if w == 1:
+    return 1.0
+  if chunk_elems is None or chunk_elems >= flat_grad.numel():
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+  else:
+    works = [dist.all_reduce(flat_grad[o:o + chunk_elems], op=dist.ReduceOp.SUM, group=group, async_op=True)
+             for o in range(0, flat_grad.numel(), chunk_elems)]
+    for wk in works:
+      wk.wait()
+  return 1.0 / w
+
+
+def max_over_ranks(value, device, group=None):
+  t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+  if world_size(group) > 1:
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+  return float(t.item())
+
+
+def rank_seed(base, rank):
+  """Each rank draws a disjoint synthetic shard (DistributedSampler's role, train.py:544-553)."""
+  return int(base) + int(rank)

@@ -325,8 +325,8 @@ class LidarCenterNet(nn.Module):
             {'params': [params[n] for n in sorted(no_decay)], 'weight_decay': 0.0}]
 
   def convert_features_to_bb_metric(self, bb_predictions):
-    from .postprocess import decode_boxes
-    return decode_boxes(self.config, bb_predictions)
+    raise NotImplementedError('heat-map decode + NMS (center_net.py:172-237) is host-side post-processing outside this '
+                              "path's round-1 scope (SURVEY.md section 8f, row 2)")
 
   def init_visualization(self):
     if cfg_get(self.config, 'debug', False):

@@ -10,6 +10,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from . import dist as tdist
 from .engine import Tape, F32
 from .losses import fused_losses, normalized_loss_weights, active_losses
 
@@ -49,10 +50,7 @@ class Trainer:
     self.exp_avg = ops.zeros(self.flat_param.shape, F32, dev)
     self.exp_avg_sq = ops.zeros(self.flat_param.shape, F32, dev)
     self.max_exp_avg_sq = ops.zeros(self.flat_param.shape, F32, dev)
-    if self.world > 1:  # rank 0's parameters everywhere (DDP constructor broadcast, train.py:516)
-      dist.broadcast(self.flat_param, 0, group=self.pg)
-      for b in self.model.buffers():
-        dist.broadcast(b, 0, group=self.pg)
+    tdist.broadcast_state(self.flat_param, list(self.model.buffers()), self.pg)  # DDP constructor broadcast, train.py:516
 
   # ---------------------------------------------------------------------------------------------- one step
   def _step_body(self, batch):
@@ -78,8 +76,7 @@ class Trainer:
     self.model.train()
     self.step_count += 1
     vals = self._step_body(batch)
-    if self.world > 1:
-      dist.all_reduce(self.eng.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+    tdist.all_reduce_gradients(self.eng.flat_grad, self.pg)
     self._optimizer(self.step_count)
     return vals
 

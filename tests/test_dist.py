@@ -1,0 +1,77 @@
+"""world_size-2 test of the data-parallel exchange on CPU (gloo): parameter broadcast, flat-gradient all-reduce with the
+1/world average folded into the update, identical replicas afterwards, disjoint per-rank data seeds."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from carla_garage_amd import dist as tdist
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
+
+
+def _adamw_amsgrad_ref(p, g, m, v, vmax, lr, b1, b2, eps, wd, step, grad_scale):
+  """Same arithmetic as csrc/misc_kernels.hip::adamw_amsgrad_kernel (torch.optim.AdamW(amsgrad=True) semantics)."""
+  g = g * grad_scale
+  p = p * (1 - lr * wd)
+  m = b1 * m + (1 - b1) * g
+  v = b2 * v + (1 - b2) * g * g
+  vmax = torch.maximum(vmax, v)
+  p = p - (lr / (1 - b1**step)) * m / (vmax.sqrt() / (1 - b2**step)**0.5 + eps)
+  return p, m, v, vmax
+
+
+def _worker(rank, world, port, out):
+  os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  r, lr_, w = tdist.init_from_env('gloo')
+  assert (r, w) == (rank, world) and tdist.world_size() == world
+  n = 10007
+  torch.manual_seed(100 + rank)  # different initial replicas on purpose
+  flat_param = torch.randn(n)
+  buf = torch.randn(5)
+  tdist.broadcast_state(flat_param, [buf])
+  m, v, vmax = torch.zeros(n), torch.zeros(n), torch.zeros(n)
+  grads = []
+  for step in range(1, 4):
+    g = torch.Generator().manual_seed(tdist.rank_seed(1234, rank) * 10 + step)
+    flat_grad = torch.randn(n, generator=g)
+    grads.append(flat_grad.clone())
+    scale = tdist.all_reduce_gradients(flat_grad, chunk_elems=4096 if step == 2 else None)
+    assert scale == 1.0 / world
+    flat_param, m, v, vmax = _adamw_amsgrad_ref(flat_param, flat_grad, m, v, vmax, 3e-4, 0.9, 0.999, 1e-8, 0.01, step, scale)
+  tmax = tdist.max_over_ranks(1.0 + rank, torch.device('cpu'))
+  torch.save({'param': flat_param, 'buf': buf, 'grads': grads, 'tmax': tmax}, os.path.join(out, f'rank{rank}.pt'))
+  dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_exchange(tmp_path):
+  world, port = 2, _free_port()
+  mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+  r0 = torch.load(tmp_path / 'rank0.pt')
+  r1 = torch.load(tmp_path / 'rank1.pt')
+  assert torch.equal(r0['param'], r1['param'])  # replicas stay bit-identical
+  assert torch.equal(r0['buf'], r1['buf'])
+  assert r0['tmax'] == r1['tmax'] == 2.0
+  assert not torch.equal(r0['grads'][0], r1['grads'][0])  # disjoint shards
+  # single-process reference: average of the two ranks' gradients
+  torch.manual_seed(100)
+  p = torch.randn(10007)
+  m, v, vmax = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+  for step in range(1, 4):
+    g = r0['grads'][step - 1] + r1['grads'][step - 1]
+    p, m, v, vmax = _adamw_amsgrad_ref(p, g, m, v, vmax, 3e-4, 0.9, 0.999, 1e-8, 0.01, step, 0.5)
+  np.testing.assert_allclose(r0['param'].numpy(), p.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_single_process_is_a_no_op():
+  t = torch.ones(8)
+  assert tdist.all_reduce_gradients(t) == 1.0 and tdist.world_size() == 1
+  tdist.broadcast_state(t, [])
+  assert tdist.max_over_ranks(3.5, torch.device('cpu')) == 3.5
