@@ -14,7 +14,7 @@ ROOT = os.path.dirname(PKG_DIR)
 HEADER = os.path.join(ROOT, 'include', 'tfpp.h')
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libtfpp_hip.so')
-SOURCES = ['gemm_kernels.hip', 'pointwise_kernels.hip', 'norm_kernels.hip', 'misc_kernels.hip']
+SOURCES = ['gemm_kernels.hip', 'gemm_direct.hip', 'pointwise_kernels.hip', 'norm_kernels.hip', 'misc_kernels.hip']
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU, ACT_TANH = 0, 1, 2, 3, 4
@@ -71,7 +71,7 @@ def declared_functions(header=HEADER):
 def build(verbose=False, force=False):
   """Compile every HIP source for gfx950 into carla_garage_amd/libtfpp_hip.so (hipcc cross-compiles without a GPU)."""
   srcs = [os.path.join(CSRC, s) for s in SOURCES]
-  deps = srcs + [os.path.join(CSRC, 'common.cuh'), os.path.join(CSRC, 'gemm_core.cuh'), HEADER]
+  deps = srcs + [os.path.join(CSRC, 'common.cuh'), os.path.join(CSRC, 'gemm_core.cuh'), os.path.join(CSRC, 'gemm_internal.h'), HEADER]
   if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
     return LIB_PATH
   objs = []

@@ -16,9 +16,9 @@
 #pragma once
 #include "common.cuh"
 
-template <typename T, int BM_, int BN_, int WM_, int WN_>
+template <typename T, int BM_, int BN_, int WM_, int WN_, int BK_ = 32>
 struct TileCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = 32;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_;  // BK: K elements per LDS stage (multiple of 32)
   static constexpr int VEC = ElemTraits<T>::VEC;
   static constexpr int KV = BK / VEC;                       // 16-byte vectors per tile row
   static constexpr int LDK = BK + (sizeof(T) == 2 ? 8 : 4);  // row-major pitch (elements): 80 B / 144 B
@@ -70,11 +70,14 @@ __device__ __forceinline__ void frag_mma(const Frag<float>& a, const Frag<float>
   for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
 }
 
-// One K-step (32) of the block tile held in LDS.
+// All K-steps (BK/32 of them) of the block tile held in LDS.
 template <typename C, typename T, bool A_KM, bool B_KM>
 __device__ __forceinline__ void tile_mma_step(const T* As, const T* Bs, int wm, int wn, int lane, f32x4_t (&acc)[C::FM][C::FN]) {
+  const int r16 = lane & 15;
+#pragma unroll
+ for (int ks = 0; ks < C::BK / 32; ++ks) {
   Frag<T> fa[C::FM], fb[C::FN];
-  const int r16 = lane & 15, kg = (lane >> 4) * 8;
+  const int kg = ks * 32 + (lane >> 4) * 8;
 #pragma unroll
   for (int i = 0; i < C::FM; ++i) {
     const int row0 = wm * C::WM + i * 16;
@@ -91,6 +94,7 @@ __device__ __forceinline__ void tile_mma_step(const T* As, const T* Bs, int wm, 
   for (int i = 0; i < C::FM; ++i)
 #pragma unroll
     for (int j = 0; j < C::FN; ++j) frag_mma(fa[i], fb[j], acc[i][j]);
+ }
 }
 
 // store a 16-byte vector (VEC elements along rows) into a k-major image at [k][row0..row0+VEC) -- 8-byte aligned

@@ -1,14 +1,16 @@
 // Implicit-GEMM convolution (forward / data-gradient), weight-gradient and strided batched GEMM on MFMA (gfx950).
 // See gemm_core.cuh for the fragment / LDS layouts and include/tfpp.h for the semantics of each entry point.
 #include "gemm_core.cuh"
-#include "../../include/tfpp.h"
+#include "gemm_internal.h"
+#include <cstdlib>
+#include <cstring>
 
 // ---------------------------------------------------------------------------------------------------------------
 // conv / linear forward and data gradient
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int BKT>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_kernel(tfpp_conv_params p) {
-  using C = TileCfg<T, BM, BN, WM, WN>;
+  using C = TileCfg<T, BM, BN, WM, WN, BKT>;
   constexpr int VEC = C::VEC, KV = C::KV, NT = C::NT, BK = C::BK;
   __shared__ __attribute__((aligned(16))) T As[C::A_ELEMS_RM];
   __shared__ __attribute__((aligned(16))) T Bs[C::B_ELEMS_RM];
@@ -110,10 +112,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
 
 template <typename T, int BM, int BN, int WM, int WN>
 static int launch_conv(const tfpp_conv_params& p, hipStream_t st) {
-  using C = TileCfg<T, BM, BN, WM, WN>;
+  // bf16: 64-deep K stages (half the barriers per FLOP; the kernels are latency-bound); fp32 keeps 32 (LDS budget)
+  constexpr int BKT = sizeof(T) == 2 ? 64 : 32;
+  using C = TileCfg<T, BM, BN, WM, WN, BKT>;
   const long M = (long)p.B * p.Hd * p.Wd;
   dim3 grid(cdiv(M, BM), cdiv(p.n_g, BN), p.G);
-  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WM, WN>), grid, dim3(C::NT), 0, st, p);
+  const int K = p.R * p.S * p.ks_g;
+  if (BKT == 64 && K <= 32) {  // tiny-K layers (stem): one 32-deep stage is enough
+    hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WM, WN, 32>), grid, dim3(C::NT), 0, st, p);
+    TFPP_CHECK_LAUNCH();
+    return 0;
+  }
+  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WM, WN, BKT>), grid, dim3(C::NT), 0, st, p);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -129,7 +139,20 @@ static int conv_variant(const tfpp_conv_params& p) {
   return tiles128 < 1024 ? 2 : 3;  // latency-bound regime: keep >= 4 workgroups per CU in flight
 }
 
-extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p) { return p ? conv_variant(*p) : TFPP_EINVAL; }
+// TFPP_CONV_IMPL=direct selects the barrier-free direct-to-register kernel (gemm_direct.hip) for A/B measurements; the
+// LDS-staged kernels below are the default (measured faster on every shape of this model, profiles/r01_gemm_micro.txt)
+static bool use_direct_impl() {
+  static const int v = [] {
+    const char* e = std::getenv("TFPP_CONV_IMPL");
+    return (e && std::strcmp(e, "direct") == 0) ? 1 : 0;
+  }();
+  return v != 0;
+}
+
+extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype) {
+  if (!p) return TFPP_EINVAL;
+  return use_direct_impl() ? conv_direct_variant(*p, dtype) : conv_variant(*p);
+}
 
 template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStream_t st) {
   constexpr int VEC = ElemTraits<T>::VEC;
@@ -137,6 +160,7 @@ template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStr
   if (((uintptr_t)p.src & 15) || ((uintptr_t)p.w & 15)) return TFPP_EINVAL;
   const long M = (long)p.B * p.Hd * p.Wd;
   if (M >= (1l << 31) || M * (long)p.dst_ld >= (1l << 40)) return TFPP_EINVAL;
+  if (use_direct_impl()) return conv_gemm_direct(p, ElemTraits<T>::DT, st);
   switch (conv_variant(p)) {
     case 0: return launch_conv<T, 128, 32, 32, 32>(p, st);
     case 1: return launch_conv<T, 128, 64, 64, 32>(p, st);
@@ -156,9 +180,9 @@ extern "C" int tfpp_conv_gemm(const tfpp_conv_params* p, int dtype, void* stream
 // ---------------------------------------------------------------------------------------------------------------
 // weight gradient: dW[n][(c,r,s)] += sum_pixels dY[pix][n] * Xgather[pix][(r,s,c)]   (reduction over pixels)
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int BKT>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_kernel(tfpp_wgrad_params p) {
-  using C = TileCfg<T, BM, BN, WM, WN>;
+  using C = TileCfg<T, BM, BN, WM, WN, BKT>;
   constexpr int VEC = C::VEC, NT = C::NT, BK = C::BK;
   __shared__ __attribute__((aligned(16))) T As[C::A_ELEMS_KM];
   __shared__ __attribute__((aligned(16))) T Bs[C::B_ELEMS_KM];
@@ -247,10 +271,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_
 
 template <typename T, int BM, int BN, int WM, int WN>
 static int launch_wgrad(const tfpp_wgrad_params& p, hipStream_t st) {
-  using C = TileCfg<T, BM, BN, WM, WN>;
+  constexpr int BKT = sizeof(T) == 2 ? 64 : 32;
+  using C = TileCfg<T, BM, BN, WM, WN, BKT>;
   const int KK = p.R * p.S * p.ks_g;
   dim3 grid(cdiv(p.n_g, BM), cdiv(KK, BN), p.G * p.splits);
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, BM, BN, WM, WN>), grid, dim3(C::NT), 0, st, p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, BM, BN, WM, WN, BKT>), grid, dim3(C::NT), 0, st, p);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -266,8 +291,8 @@ template <typename T> static int dispatch_wgrad(tfpp_wgrad_params p, hipStream_t
   if (p.splits <= 0) {
     // enough workgroups to fill 256 CUs several times over, but at least 256 pixels of reduction each
     const long tiles = (long)cdiv(p.n_g, bm) * cdiv(KK, bn) * p.G;
-    long want = (2048 + tiles - 1) / tiles;
-    long maxs = (P + 255) / 256;
+    long want = (1536 + tiles - 1) / tiles;
+    long maxs = (P + 511) / 512;  // >= 512 pixels of reduction per workgroup amortises its atomic epilogue
     p.splits = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
     if (p.splits < 1) p.splits = 1;
   }

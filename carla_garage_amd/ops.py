@@ -64,8 +64,9 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
   p.res_ld = res_ld if res_ld is not None else p.dst_ld
   p.dst_f32 = int(dst.dtype == torch.float32 and src.dtype != torch.float32)
   if lib.profiler is not None:
-    var = lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p))
-    fam = f'conv_gemm<{"f32" if src.dtype == torch.float32 else "bf16"},{("128x32", "128x64", "64x64", "128x128")[var]}>'
+    var = lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p), dt(src))
+    tile = f'direct{(var - 100) // 10 * 32}x{(var - 100) % 10 * 32}' if var >= 100 else ('128x32', '128x64', '64x64', '128x128')[var]
+    fam = f'conv_gemm<{"f32" if src.dtype == torch.float32 else "bf16"},{tile}>'
     if PROFILE_SHAPES:
       fam += f' m{mode} M={B * Hd * Wd} N={p.n_g} K={R * S * p.ks_g} G={G} k{R}s{stride}'
     lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g))

@@ -63,8 +63,10 @@ typedef struct {
   int dst_f32;          /* 1: dst is float regardless of dtype */
 } tfpp_conv_params;
 int tfpp_conv_gemm(const tfpp_conv_params* p, int dtype, void* stream);
-/* tile variant the dispatcher picks for p (0: 128x32, 1: 128x64, 2: 64x64, 3: 128x128) -- used by the bench's per-kernel roofline. */
-int tfpp_conv_gemm_variant(const tfpp_conv_params* p);
+/* kernel variant the dispatcher picks for p -- used by the bench's per-kernel roofline.  100 + FM*10 + FN: barrier-free
+ * direct-to-register kernel with wave tile (16 FM) x (16 FN); 0..3: LDS-staged 128x32 / 128x64 / 64x64 / 128x128
+ * (only with TFPP_CONV_IMPL=lds). */
+int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype);
 
 /* Weight gradient of the same convolution (autograd of F.conv2d / F.linear, train.py:898):
  *   dw[(g*n_g+n), c, r, s] += sum_{b,hd,wd} dy[b,hd,wd,g*n_g+n] * x[b,hd*stride-pad+r,wd*stride-pad+s,g*ks_g+c]
