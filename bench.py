@@ -122,6 +122,41 @@ def cpu_baseline(cfg_bs=2, budget_s=25.0, hard_timeout_s=90.0):
   return last
 
 
+def inference_latency(model, cfg, device, log, iters=20):
+  """Second half of the BASELINE metric: TransFuser++ forward ms/frame at bs=1 (the 20 Hz closed-loop tick,
+  sensor_agent.py:456-461), eval mode, caller-facing fp32 NCHW outputs included; eager launches and hipGraph replay."""
+  from carla_garage_amd.graph import GraphedForward
+  b = synthetic_batch(1, cfg, device, 99)
+  inp = [b[k] for k in ('rgb', 'lidar_bev', 'target_point', 'ego_vel', 'command')]
+  out = {}
+  model.eval()
+  for dtype in ('bf16', 'fp32'):
+    cfg.tfpp_dtype = dtype
+    with torch.inference_mode():
+      for _ in range(3):
+        model(*inp)
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for _ in range(iters):
+        model(*inp)
+      torch.cuda.synchronize()
+      out[f'{dtype}_eager'] = round(1e3 * (time.perf_counter() - t0) / iters, 3)
+    try:
+      g = GraphedForward(model, *inp)
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for _ in range(iters):
+        g(*inp)
+      torch.cuda.synchronize()
+      out[f'{dtype}_hipgraph'] = round(1e3 * (time.perf_counter() - t0) / iters, 3)
+    except Exception as e:  # pylint: disable=broad-except
+      out[f'{dtype}_hipgraph'] = None
+      log(f'inference hipGraph capture failed: {type(e).__name__}: {e}')
+    log(f'forward bs=1 {dtype}: {out}')
+  model.train()
+  return out
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -131,6 +166,8 @@ def main():
   ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-roofline', action='store_true')
+  ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay of the step body')
+  ap.add_argument('--no-inference', action='store_true', help='skip the bs=1 forward latency measurement')
   ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel-family time table to stderr')
   ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
   ap.add_argument('--cpu-budget', type=float, default=25.0, help=argparse.SUPPRESS)
@@ -179,13 +216,24 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
+  step_fn = lambda: trainer.train_step(batch)
+  graphed = False
+  if not args.no_graph:
+    try:  # capture the step body (repack + fwd + losses + bwd) into one hipGraph; all-reduce + optimizer stay eager
+      from carla_garage_amd.graph import GraphedTrainStep
+      gstep = GraphedTrainStep(trainer, batch, warmup=1)
+      step_fn = lambda: gstep()
+      graphed = True
+      log('training step captured into a hipGraph')
+    except Exception as e:  # pylint: disable=broad-except
+      log(f'hipGraph capture unavailable ({type(e).__name__}: {e}); running the eager launch sequence')
   for _ in range(args.warmup):
-    vals = trainer.train_step(batch)
+    vals = step_fn()
   sync()
   log(f'{args.warmup} warm-up steps done')
   t0 = time.perf_counter()
   for _ in range(args.steps):
-    vals = trainer.train_step(batch)
+    vals = step_fn()
   sync()
   elapsed = time.perf_counter() - t0
   log(f'{args.steps} timed steps: {1e3 * elapsed / args.steps:.1f} ms/step')
@@ -217,6 +265,9 @@ def main():
         tf = x['flops'] / (x['ms'] * 1e-3) / 1e12 if x['flops'] else 0.0
         print(f'{f:42s} calls/step {x["calls"] // nprof:5d}  ms/step {x["ms"] / nprof:9.3f}  {100 * x["ms"] / total_ms:5.1f}%  {tf:8.1f} TFLOP/s',
               file=sys.stderr)
+  fwd = None
+  if rank == 0 and not args.no_inference:
+    fwd = inference_latency(model, cfg, device, log)
   if world > 1:
     dist.barrier()
 
@@ -232,8 +283,10 @@ def main():
                    'global_batch': args.batch_size * world, 'per_gpu_batch': args.batch_size, 'parallelism': f'dp{world}',
                    'algorithmic_tflop_per_step_per_gpu': round(GFLOP_PER_SAMPLE_TRAIN * args.batch_size / 1e3, 3),
                    'model_tflops_per_gpu': round(GFLOP_PER_SAMPLE_TRAIN * args.batch_size / 1e3 / (ms * 1e-3), 2),
-                   'final_weighted_loss': round(loss_total, 5)},
+                   'final_weighted_loss': round(loss_total, 5), 'hipgraph_step': graphed},
     }
+    if fwd is not None:
+      line['fwd_ms_per_frame'] = fwd
     if roof is not None:
       line['roofline'] = roof
     if world == 1 and not args.no_cpu_baseline:

@@ -398,3 +398,12 @@ extern "C" int tfpp_struct_sizes(int* out, int n) {
   out[2] = (int)sizeof(tfpp_bgemm_params);
   return 3;
 }
+
+// *p += 1 : per-step counter added to every dropout seed (captured in the training-step hipGraph)
+__global__ void inc_u64_kernel(unsigned long long* p) { *p += 1ull; }
+extern "C" int tfpp_inc_u64(uint64_t* p, void* stream) {
+  if (!p) return TFPP_EINVAL;
+  hipLaunchKernelGGL(inc_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)p);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}

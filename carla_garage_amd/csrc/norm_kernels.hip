@@ -426,7 +426,8 @@ extern "C" int tfpp_layernorm_bwd(const void* dy, const void* x, const float* ga
 // P = softmax(alpha * x) written in place; if pd != NULL also pd = dropout(P) (mask keyed by seed and element index)
 template <typename T>
 __global__ void softmax_fwd_kernel(T* __restrict__ x, T* __restrict__ pd, long rows, int cols, long ld, float alpha, float p_drop, float inv_keep,
-                                   unsigned long long seed) {
+                                   unsigned long long seed, const unsigned long long* __restrict__ seed_off) {
+  if (seed_off) seed += *seed_off * 0x9E3779B97F4A7C15ull;  // per-step device counter: hipGraph replays draw fresh masks
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -459,14 +460,14 @@ __global__ void softmax_fwd_kernel(T* __restrict__ x, T* __restrict__ pd, long r
   }
 }
 
-extern "C" int tfpp_softmax_fwd(void* x, void* pd, int64_t rows, int cols, int64_t ld, float alpha, float p_drop, uint64_t seed, int dtype,
+extern "C" int tfpp_softmax_fwd(void* x, void* pd, int64_t rows, int cols, int64_t ld, float alpha, float p_drop, uint64_t seed, const uint64_t* seed_offset, int dtype,
                                 void* stream) {
   if (!x || cols > 64 * SM_MAXE) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   dim3 grid((unsigned)((rows + 3) / 4));
-  if (dtype == TFPP_F32) hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, dim3(256), 0, st, (float*)x, (float*)pd, (long)rows, cols, (long)ld, alpha, p_drop, inv_keep, (unsigned long long)seed);
-  else hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (bf16_t*)x, (bf16_t*)pd, (long)rows, cols, (long)ld, alpha, p_drop, inv_keep, (unsigned long long)seed);
+  if (dtype == TFPP_F32) hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, dim3(256), 0, st, (float*)x, (float*)pd, (long)rows, cols, (long)ld, alpha, p_drop, inv_keep, (unsigned long long)seed, (const unsigned long long*)seed_offset);
+  else hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (bf16_t*)x, (bf16_t*)pd, (long)rows, cols, (long)ld, alpha, p_drop, inv_keep, (unsigned long long)seed, (const unsigned long long*)seed_offset);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -474,7 +475,8 @@ extern "C" int tfpp_softmax_fwd(void* x, void* pd, int64_t rows, int cols, int64
 // in place on dp: dP = dPd * mask ; dS = alpha * P .* (dP - sum_j dP_j P_j)
 template <typename T>
 __global__ void softmax_bwd_kernel(const T* __restrict__ p, T* __restrict__ dp, long rows, int cols, long ld, float alpha, float p_drop,
-                                   float inv_keep, unsigned long long seed) {
+                                   float inv_keep, unsigned long long seed, const unsigned long long* __restrict__ seed_off) {
+  if (seed_off) seed += *seed_off * 0x9E3779B97F4A7C15ull;  // per-step device counter: hipGraph replays draw fresh masks
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -501,14 +503,14 @@ __global__ void softmax_bwd_kernel(const T* __restrict__ p, T* __restrict__ dp, 
   }
 }
 
-extern "C" int tfpp_softmax_bwd(const void* p, void* dp_inout, int64_t rows, int cols, int64_t ld, float alpha, float p_drop, uint64_t seed,
+extern "C" int tfpp_softmax_bwd(const void* p, void* dp_inout, int64_t rows, int cols, int64_t ld, float alpha, float p_drop, uint64_t seed, const uint64_t* seed_offset,
                                 int dtype, void* stream) {
   if (!p || !dp_inout || cols > 64 * SM_MAXE) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   dim3 grid((unsigned)((rows + 3) / 4));
-  if (dtype == TFPP_F32) hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)p, (float*)dp_inout, (long)rows, cols, (long)ld, alpha, p_drop, inv_keep, (unsigned long long)seed);
-  else hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)p, (bf16_t*)dp_inout, (long)rows, cols, (long)ld, alpha, p_drop, inv_keep, (unsigned long long)seed);
+  if (dtype == TFPP_F32) hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)p, (float*)dp_inout, (long)rows, cols, (long)ld, alpha, p_drop, inv_keep, (unsigned long long)seed, (const unsigned long long*)seed_offset);
+  else hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)p, (bf16_t*)dp_inout, (long)rows, cols, (long)ld, alpha, p_drop, inv_keep, (unsigned long long)seed, (const unsigned long long*)seed_offset);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

@@ -243,7 +243,8 @@ extern "C" int tfpp_affine_act(const void* x, const float* scale, const float* s
 // y = a + dropout(b)
 template <typename T>
 __global__ void add_dropout_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long n, float p, float inv_keep,
-                                   unsigned long long seed) {
+                                   unsigned long long seed, const unsigned long long* __restrict__ seed_off) {
+  if (seed_off) seed += *seed_off * 0x9E3779B97F4A7C15ull;  // per-step device counter: hipGraph replays draw fresh masks
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
@@ -254,12 +255,12 @@ __global__ void add_dropout_kernel(const T* __restrict__ a, const T* __restrict_
   }
 }
 
-extern "C" int tfpp_add_dropout(const void* a, const void* b, void* y, int64_t n, float p_drop, uint64_t seed, int dtype, void* stream) {
+extern "C" int tfpp_add_dropout(const void* a, const void* b, void* y, int64_t n, float p_drop, uint64_t seed, const uint64_t* seed_offset, int dtype, void* stream) {
   if (!b || !y) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-  if (dtype == TFPP_F32) hipLaunchKernelGGL(add_dropout_kernel<float>, grid_stride(n), dim3(PW_THREADS), 0, st, (const float*)a, (const float*)b, (float*)y, (long)n, p_drop, inv_keep, (unsigned long long)seed);
-  else hipLaunchKernelGGL(add_dropout_kernel<bf16_t>, grid_stride(n), dim3(PW_THREADS), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, (long)n, p_drop, inv_keep, (unsigned long long)seed);
+  if (dtype == TFPP_F32) hipLaunchKernelGGL(add_dropout_kernel<float>, grid_stride(n), dim3(PW_THREADS), 0, st, (const float*)a, (const float*)b, (float*)y, (long)n, p_drop, inv_keep, (unsigned long long)seed, (const unsigned long long*)seed_offset);
+  else hipLaunchKernelGGL(add_dropout_kernel<bf16_t>, grid_stride(n), dim3(PW_THREADS), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, (long)n, p_drop, inv_keep, (unsigned long long)seed, (const unsigned long long*)seed_offset);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

@@ -1,0 +1,59 @@
+"""hipGraph capture of the static launch sequences (inference forward; training step body).
+
+Shapes are static and the engine issues only ``libtfpp_hip.so`` launches + hipMemsetAsync on the current stream, so
+one forward (~900 launches at bs=1, the 20 Hz closed-loop tick of sensor_agent.py:456-461) or one training step
+(~3500 launches) replays as a single hipGraphLaunch.  torch.cuda.CUDAGraph is used for the capture plumbing
+(stream + private memory pool); no ATen kernels are captured.
+"""
+import torch
+
+
+class GraphedForward:
+  """``y = GraphedForward(model, rgb, lidar_bev, target_point, ego_vel, command)(...)`` -- eval-mode, no-grad forward."""
+
+  def __init__(self, model, *example_inputs, warmup=2):
+    self.model = model
+    self.static_in = [x.clone() for x in example_inputs]
+    with torch.inference_mode():
+      for _ in range(warmup):  # populate weight images / constants outside the capture
+        model(*self.static_in)
+    torch.cuda.synchronize()
+    self.graph = torch.cuda.CUDAGraph()
+    with torch.inference_mode(), torch.cuda.graph(self.graph):
+      self.static_out = model(*self.static_in)
+    torch.cuda.synchronize()
+
+  def __call__(self, *inputs):
+    for dst, src in zip(self.static_in, inputs):
+      if dst.data_ptr() != src.data_ptr():
+        dst.copy_(src, non_blocking=True)
+    self.graph.replay()
+    return self.static_out
+
+
+class GraphedTrainStep:
+  """Captures Trainer._step_body (repack + forward + losses + backward) for a fixed batch layout; the gradient
+  all-reduce and the optimizer launch stay outside the graph so RCCL is never captured."""
+
+  def __init__(self, trainer, batch, warmup=2):
+    self.trainer = trainer
+    self.static_batch = {k: v.clone() for k, v in batch.items()}
+    for _ in range(warmup):
+      trainer.train_step(self.static_batch)
+    torch.cuda.synchronize()
+    self.graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(self.graph):
+      self.vals = trainer._step_body(self.static_batch)
+    torch.cuda.synchronize()
+
+  def __call__(self, batch=None):
+    tr = self.trainer
+    if batch is not None:
+      for k, dst in self.static_batch.items():
+        src = batch[k]
+        if dst.data_ptr() != src.data_ptr():
+          dst.copy_(src, non_blocking=True)
+    tr.step_count += 1
+    self.graph.replay()
+    tr.finish_step()
+    return self.vals

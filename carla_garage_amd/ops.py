@@ -307,6 +307,18 @@ def bilinear_bwd(dy, hi, wi, mul=None, dx=None, dx_ld=None):
 
 
 # ------------------------------------------------------------------------------------------------ token ops
+SEED_OFFSET = None  # device uint64 counter added to every dropout seed (set by the trainer)
+
+
+def set_seed_offset(t):
+  global SEED_OFFSET
+  SEED_OFFSET = t
+
+
+def inc_u64(t):
+  lib.tfpp_inc_u64(ptr(t), stream())
+
+
 def layernorm_fwd(x, gamma, beta, eps=1e-5, save=True):
   c = x.shape[-1]
   rows = x.numel() // c
@@ -328,19 +340,19 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
 def softmax_fwd(x, rows, cols, ld, alpha=1.0, p_drop=0.0, seed=0):
   """In place; returns (P, P_dropped) -- the same tensor when p_drop == 0."""
   pd = torch.empty_like(x) if p_drop > 0.0 else None
-  lib.tfpp_softmax_fwd(ptr(x), ptr(pd), rows, cols, ld, alpha, p_drop, seed, dt(x), stream())
+  lib.tfpp_softmax_fwd(ptr(x), ptr(pd), rows, cols, ld, alpha, p_drop, seed, ptr(SEED_OFFSET), dt(x), stream())
   return x, (pd if pd is not None else x)
 
 
 def softmax_bwd(p, dp, rows, cols, ld, alpha=1.0, p_drop=0.0, seed=0):
-  lib.tfpp_softmax_bwd(ptr(p), ptr(dp), rows, cols, ld, alpha, p_drop, seed, dt(p), stream())
+  lib.tfpp_softmax_bwd(ptr(p), ptr(dp), rows, cols, ld, alpha, p_drop, seed, ptr(SEED_OFFSET), dt(p), stream())
   return dp
 
 
 def add_dropout(a, b, p_drop=0.0, seed=0, out=None):
   if out is None:
     out = torch.empty_like(b)
-  lib.tfpp_add_dropout(ptr(a), ptr(_chk(b)), ptr(out), b.numel(), p_drop, seed, dt(b), stream())
+  lib.tfpp_add_dropout(ptr(a), ptr(_chk(b)), ptr(out), b.numel(), p_drop, seed, ptr(SEED_OFFSET), dt(b), stream())
   return out
 
 

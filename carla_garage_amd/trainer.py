@@ -30,6 +30,8 @@ class Trainer:
     self.loss_names = active_losses(model.config)
     self.loss_weights = normalized_loss_weights(model.config)
     self._flatten()
+    self.seed_offset = ops.zeros(1, torch.int64, self.eng.device)  # advanced once per step (fresh dropout masks under replay)
+    ops.set_seed_offset(self.seed_offset)
 
   # ---------------------------------------------------------------------------------------------- flat arenas
   def _flatten(self):
@@ -59,6 +61,8 @@ class Trainer:
     eng.dtype = model.compute_dtype
     eng.repack(eng.dtype, True)
     eng.alloc_grads()
+    ops.inc_u64(self.seed_offset)
+    eng._seed_ctr = 0  # the per-call part of the seeds is a function of the call site only
     eng.tape = Tape()
     t = eng.forward(batch['rgb'], batch['lidar_bev'], batch['target_point'], batch['ego_vel'], batch['command'])
     _, vals, seeds = fused_losses(model, t, batch, self.loss_weights, True)
@@ -76,9 +80,13 @@ class Trainer:
     self.model.train()
     self.step_count += 1
     vals = self._step_body(batch)
+    self.finish_step()
+    return vals
+
+  def finish_step(self):
+    """gradient exchange + optimizer (kept outside any captured graph)."""
     tdist.all_reduce_gradients(self.eng.flat_grad, self.pg)
     self._optimizer(self.step_count)
-    return vals
 
   def total_loss(self, vals):
     w = torch.tensor([self.loss_weights[n] for n in self.loss_names])

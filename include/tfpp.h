@@ -190,11 +190,14 @@ int tfpp_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
                        float eps, int dtype, void* stream);
 int tfpp_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                        float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
-int tfpp_softmax_fwd(void* x, void* pd, int64_t rows, int cols, int64_t ld, float alpha, float p_drop, uint64_t seed, int dtype,
+int tfpp_softmax_fwd(void* x, void* pd, int64_t rows, int cols, int64_t ld, float alpha, float p_drop, uint64_t seed, const uint64_t* seed_offset, int dtype,
                      void* stream);
-int tfpp_softmax_bwd(const void* p, void* dp_inout, int64_t rows, int cols, int64_t ld, float alpha, float p_drop, uint64_t seed,
+int tfpp_softmax_bwd(const void* p, void* dp_inout, int64_t rows, int cols, int64_t ld, float alpha, float p_drop, uint64_t seed, const uint64_t* seed_offset,
                      int dtype, void* stream);
-int tfpp_add_dropout(const void* a, const void* b, void* y, int64_t n, float p_drop, uint64_t seed, int dtype, void* stream);
+int tfpp_add_dropout(const void* a, const void* b, void* y, int64_t n, float p_drop, uint64_t seed, const uint64_t* seed_offset, int dtype, void* stream);
+/* dropout masks are a pure function of (seed + *seed_offset, element index); seed_offset (nullable) is a device counter that
+ * tfpp_inc_u64 advances once per training step so that a replayed hipGraph draws fresh masks. */
+int tfpp_inc_u64(uint64_t* p, void* stream);
 int tfpp_add_bcast(const void* x, const float* bcast, void* y, int64_t n, int64_t period, int dtype, void* stream);
 int tfpp_act_bwd(const void* dy, const void* y, void* dx, int64_t n, int act, int dtype, void* stream);
 int tfpp_axpy(const void* x, void* y, int64_t n, float a, int dtype, void* stream);
