@@ -44,6 +44,11 @@ class BgemmParams(ctypes.Structure):
               ('alpha', f32), ('beta', f32)]
 
 
+class PackDesc(ctypes.Structure):
+  _fields_ = [('src', vp), ('dst', vp), ('row_map', vp), ('col_map', vp), ('total', i64), ('in_ld', i64), ('out_ld', i64),
+              ('blk_start', i64), ('kind', i32), ('dtype', i32), ('a', i32 * 8)]
+
+
 _CTYPE = {'int': i32, 'int64_t': i64, 'uint64_t': ctypes.c_uint64, 'float': f32, 'double': ctypes.c_double}
 
 
@@ -162,9 +167,9 @@ class _Lib:
       self._fns[name] = fn
     sizes = (ctypes.c_int * 8)()
     n = self._dll.tfpp_struct_sizes(sizes, 8)
-    mine = [ctypes.sizeof(ConvParams), ctypes.sizeof(WgradParams), ctypes.sizeof(BgemmParams)]
-    if n != 3 or list(sizes[:3]) != mine:
-      raise TfppError(f'struct layout mismatch: library {list(sizes[:3])} vs ctypes {mine}')
+    mine = [ctypes.sizeof(ConvParams), ctypes.sizeof(WgradParams), ctypes.sizeof(BgemmParams), ctypes.sizeof(PackDesc)]
+    if n != 4 or list(sizes[:4]) != mine:
+      raise TfppError(f'struct layout mismatch: library {list(sizes[:4])} vs ctypes {mine}')
     if self._dll.tfpp_version() != 1:
       raise TfppError('ABI version mismatch')
     return self

@@ -392,11 +392,12 @@ extern "C" int tfpp_adamw_amsgrad(float* p, const float* g, float* m, float* v, 
 extern "C" int tfpp_version(void) { return TFPP_ABI_VERSION; }
 
 extern "C" int tfpp_struct_sizes(int* out, int n) {
-  if (!out || n < 3) return TFPP_EINVAL;
+  if (!out || n < 4) return TFPP_EINVAL;
   out[0] = (int)sizeof(tfpp_conv_params);
   out[1] = (int)sizeof(tfpp_wgrad_params);
   out[2] = (int)sizeof(tfpp_bgemm_params);
-  return 3;
+  out[3] = (int)sizeof(tfpp_pack_desc);
+  return 4;
 }
 
 // *p += 1 : per-step counter added to every dropout seed (captured in the training-step hipGraph)

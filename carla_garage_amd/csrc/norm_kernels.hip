@@ -402,6 +402,35 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
   }
 }
 
+// parameter gradients of LayerNorm as a column reduction: dgamma[c] += sum_r dy*xhat, dbeta[c] += sum_r dy.
+// grid (ceil(C/64), S); block = 64 channels x 4 row slots; <= S atomics per address.
+template <typename T>
+__global__ void layernorm_param_grad_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
+                                            const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                            long rows, int C, long rows_per_block) {
+  const int cl = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  float sg = 0.f, sb = 0.f;
+  if (c < C) {
+    for (long r = r0 + slot; r < r1; r += 4) {
+      const float g = ElemTraits<T>::to_f(dy[(size_t)r * C + c]);
+      const float xh = (ElemTraits<T>::to_f(x[(size_t)r * C + c]) - mean[r]) * rstd[r];
+      sg += g * xh;
+      sb += g;
+    }
+  }
+  __shared__ float sm[2][4][64];
+  sm[0][slot][cl] = sg;
+  sm[1][slot][cl] = sb;
+  __syncthreads();
+  if (slot == 0 && c < C) {
+    if (dgamma) atomicAdd(dgamma + c, sm[0][0][cl] + sm[0][1][cl] + sm[0][2][cl] + sm[0][3][cl]);
+    if (dbeta) atomicAdd(dbeta + c, sm[1][0][cl] + sm[1][1][cl] + sm[1][2][cl] + sm[1][3][cl]);
+  }
+}
+
 extern "C" int tfpp_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                                   float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx) return TFPP_EINVAL;
@@ -409,12 +438,22 @@ extern "C" int tfpp_layernorm_bwd(const void* dy, const void* x, const float* ga
   const int VEC = dtype == TFPP_F32 ? 4 : 8;
   if (C % VEC || C / VEC > 64 * 6) return TFPP_EINVAL;
   const int nv = (C / VEC + 63) / 64;
-  const int rpw = rows >= 2048 ? 8 : 1;
+  const int rpw = 1;  // dx: one wave per row, no atomics (parameter gradients come from the column-reduction kernel below)
   const long waves = (rows + rpw - 1) / rpw;
   dim3 grid((unsigned)((waves + 3) / 4));
-#define LN_BWD(TT, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, MV>), grid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, gamma, mean, rstd, (TT*)dx, dgamma, dbeta, (long)rows, C, rpw)
+  float* nullf = nullptr;
+#define LN_BWD(TT, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, MV>), grid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, gamma, mean, rstd, (TT*)dx, nullf, nullf, (long)rows, C, rpw)
 #define LN_BWD_T(TT) do { if (nv <= 1) LN_BWD(TT, 1); else if (nv <= 2) LN_BWD(TT, 2); else if (nv <= 3) LN_BWD(TT, 3); else if (nv <= 4) LN_BWD(TT, 4); else LN_BWD(TT, 6); } while (0)
   if (dtype == TFPP_F32) LN_BWD_T(float); else LN_BWD_T(bf16_t);
+  if (dgamma || dbeta) {
+    long S = rows / 16;
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    const long rpb = (rows + S - 1) / S;
+    dim3 g2((unsigned)((C + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
+    if (dtype == TFPP_F32) hipLaunchKernelGGL(layernorm_param_grad_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, (const float*)x, mean, rstd, dgamma, dbeta, (long)rows, C, rpb);
+    else hipLaunchKernelGGL(layernorm_param_grad_kernel<bf16_t>, g2, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, dgamma, dbeta, (long)rows, C, rpb);
+  }
   TFPP_CHECK_LAUNCH();
   return 0;
 }

@@ -363,7 +363,10 @@ __global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, 
 extern "C" int tfpp_colsum(const void* x, float* out, int64_t rows, int C, int64_t ld, int dtype, void* stream) {
   if (!x || !out) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  // rows per workgroup: keep <= ~128 atomics per output address while still filling the chip for narrow tensors
   long rpb = 256;
+  const long col_blocks = (C + 63) / 64;
+  while ((rows + rpb - 1) / rpb > 128 && (rows + rpb - 1) / rpb * col_blocks > 2048) rpb *= 2;
   dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((C + 63) / 64));
   if (grid.x < 1) grid.x = 1;
   if (dtype == TFPP_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, out, (long)rows, C, (long)ld, rpb);
@@ -845,4 +848,68 @@ extern "C" int tfpp_zero(void* p, int64_t bytes, void* stream) {
   if (!p) return TFPP_EINVAL;
   hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
   return e == hipSuccess ? 0 : -(int)e;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// multi-tensor weight packing: every per-step weight image (conv forward / data-gradient layouts, head-padded QKV,
+// transposes, fp32 -> bf16 casts) in ONE launch, driven by a device-resident descriptor table.
+// ---------------------------------------------------------------------------------------------------------------
+#define PACK_ELEMS_PER_BLOCK 2048
+template <typename T>
+__device__ __forceinline__ void pack_one(const tfpp_pack_desc& d, long i) {
+  float v = 0.f;
+  if (d.kind == 0 || d.kind == 1) {  // conv weight, a = {Cout, cin_g, R, S, G, ks_pad, n_pad}
+    const int Cout = d.a[0], cin_g = d.a[1], RS = d.a[2] * d.a[3], G = d.a[4], ks_pad = d.a[5], n_pad = d.a[6];
+    const int n_g = Cout / G;
+    if (d.kind == 0) {
+      const int K = RS * ks_pad;
+      const int k = (int)(i % K);
+      const long t = i / K;
+      const int n = (int)(t % n_pad), g = (int)(t / n_pad);
+      const int rs = k / ks_pad, c = k - rs * ks_pad;
+      if (n < n_g && c < cin_g) v = d.src[((size_t)(g * n_g + n) * cin_g + c) * RS + rs];
+    } else {
+      const int K = RS * n_pad;
+      const int k = (int)(i % K);
+      const long t = i / K;
+      const int c = (int)(t % cin_g), g = (int)(t / cin_g);
+      const int rs = k / n_pad, n = k - rs * n_pad;
+      if (n < n_g) v = d.src[((size_t)(g * n_g + n) * cin_g + c) * RS + rs];
+    }
+    reinterpret_cast<T*>(d.dst)[i] = ElemTraits<T>::from_f(v);
+  } else {  // pack2d, a = {rows_out, cols_out, transpose_in}
+    const int cols_out = d.a[1];
+    const int r = (int)(i / cols_out), c = (int)(i - (long)r * cols_out);
+    const int sr = d.row_map ? d.row_map[r] : r, sc = d.col_map ? d.col_map[c] : c;
+    if (sr >= 0 && sc >= 0) v = d.a[2] ? d.src[(size_t)sc * d.in_ld + sr] : d.src[(size_t)sr * d.in_ld + sc];
+    reinterpret_cast<T*>(d.dst)[(size_t)r * d.out_ld + c] = ElemTraits<T>::from_f(v);
+  }
+}
+
+__global__ void pack_multi_kernel(const tfpp_pack_desc* __restrict__ descs, int n) {
+  // binary search: last descriptor with blk_start <= blockIdx.x
+  int lo = 0, hi = n - 1;
+  const long b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].blk_start <= b) lo = mid;
+    else hi = mid - 1;
+  }
+  const tfpp_pack_desc d = descs[lo];
+  const long base = (b - d.blk_start) * PACK_ELEMS_PER_BLOCK;
+  for (int e = threadIdx.x; e < PACK_ELEMS_PER_BLOCK; e += blockDim.x) {
+    const long i = base + e;
+    if (i >= d.total) break;
+    if (d.dtype == TFPP_F32) pack_one<float>(d, i);
+    else pack_one<bf16_t>(d, i);
+  }
+}
+
+extern "C" int tfpp_pack_elems_per_block(void) { return PACK_ELEMS_PER_BLOCK; }
+
+extern "C" int tfpp_pack_multi(const tfpp_pack_desc* descs_dev, int n, int64_t total_blocks, void* stream) {
+  if (!descs_dev || n < 1 || total_blocks < 1) return TFPP_EINVAL;
+  hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+  TFPP_CHECK_LAUNCH();
+  return 0;
 }

@@ -212,6 +212,35 @@ class Engine:
     self._packed_key = self._weights_key(dtype, need_grad)
 
   def repack(self, dtype, need_t):
+    """Refresh every kernel-layout weight image.  The first call records all packing requests into a PackPlan
+    (persistent destinations); later calls replay the whole plan as one launch."""
+    key = (dtype, need_t, str(self.device), tuple(p.data_ptr() for p in self.m.parameters()))
+    if getattr(self, '_plan', None) is not None and self._plan_key == key:
+      self._plan.launch()
+      self._refresh_small()
+      return
+    plan = ops.PackPlan()
+    ops.PACK_PLAN = plan
+    try:
+      self._repack_build(dtype, need_t)
+    finally:
+      ops.PACK_PLAN = None
+    plan.finalize(self.device)
+    plan.launch()
+    self._plan, self._plan_key = plan, key
+    self._refresh_small()
+
+  def _refresh_small(self):
+    """Padded biases and (eval) folded BatchNorm scale/shift: tiny per-layer launches."""
+    for s in self.specs.values():
+      if s.bias is not None and s.n_store != s.cout:
+        ops.copy_rows(s.bias.detach(), s.bias_pad, 1, s.cout, 0, 0, 0, 0)
+      elif s.bias is not None:
+        s.bias_pad = s.bias.detach()
+      if s.bn is not None and not (self.training and s.bn.training):
+        ops.bn_fold(s.bn.weight.detach(), s.bn.bias.detach(), s.bn.running_mean, s.bn.running_var, s.scale, s.shift, s.bn.eps)
+
+  def _repack_build(self, dtype, need_t):
     dev = self.device
     for s in self.specs.values():
       dt_ = F32 if s.head else dtype
@@ -224,13 +253,9 @@ class Engine:
       else:
         s.wp = ops.pack_conv_weight(w4, dt_, G=s.groups, ks_pad=ks_pad, n_pad=s.n_store // s.groups)
       s.wt = ops.pack_conv_weight(w4, dt_, G=s.groups, n_pad=s.n_store // s.groups, transpose=True) if need_t else None
-      if s.bias is not None:
-        if s.n_store == s.cout:
-          s.bias_pad = s.bias.detach()
-        else:
-          if s.bias_pad is None or s.bias_pad.numel() != s.n_store or s.bias_pad.device != dev:
-            s.bias_pad = ops.zeros(s.n_store, F32, dev)
-          ops.copy_rows(s.bias.detach(), s.bias_pad, 1, s.cout, 0, 0, 0, 0)
+      if s.bias is not None and s.n_store != s.cout:
+        if s.bias_pad is None or s.bias_pad.numel() != s.n_store or s.bias_pad.device != dev:
+          s.bias_pad = ops.zeros(s.n_store, F32, dev)
       if s.n_store != s.cout and s.row_map is None:
         s.row_map = torch.tensor(list(range(s.cout)) + [-1] * (s.n_store - s.cout), dtype=torch.int32).to(dev)
       if s.bn is not None:
@@ -240,8 +265,6 @@ class Engine:
           s.save_mean = torch.empty(s.cout, device=dev, dtype=F32)
           s.save_invstd = torch.empty(s.cout, device=dev, dtype=F32)
           s.ws = torch.empty(2 * s.cout, device=dev, dtype=torch.float64)
-        if not (self.training and s.bn.training):
-          ops.bn_fold(s.bn.weight.detach(), s.bn.bias.detach(), s.bn.running_mean, s.bn.running_var, s.scale, s.shift, s.bn.eps)
     # fusion-transformer QKV: fused, head-padded images
     for i, g in enumerate(self.m.backbone.transformers):
       c, nh = g.n_embd, self.cfg.n_head

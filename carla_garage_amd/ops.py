@@ -5,7 +5,7 @@ import ctypes
 
 import torch
 
-from ._lib import (lib, ConvParams, WgradParams, BgemmParams, F32, BF16, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU,
+from ._lib import (lib, ConvParams, WgradParams, BgemmParams, PackDesc, F32, BF16, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU,
                    ACT_TANH)
 
 import os as _os
@@ -114,6 +114,39 @@ def bgemm(A, B, C, *, M, N, K, lda, ldb, ldc, batch0=1, batch1=1, a_bs=(0, 0), b
 
 
 # ------------------------------------------------------------------------------------------------ packing
+class PackPlan:
+  """Records every weight-packing request once (persistent destinations) and replays them all as ONE launch."""
+
+  def __init__(self):
+    self.descs, self.keep, self.table, self.total_blocks = [], [], None, 0
+
+  def add(self, kind, src, dst, total, a, row_map=None, col_map=None, in_ld=0, out_ld=0):
+    d = PackDesc()
+    d.src, d.dst, d.row_map, d.col_map = ptr(src), ptr(dst), ptr(row_map), ptr(col_map)
+    d.total, d.in_ld, d.out_ld, d.kind, d.dtype = total, in_ld, out_ld, kind, dt(dst)
+    for i, v in enumerate(a):
+      d.a[i] = int(v)
+    self.descs.append(d)
+    self.keep += [src, dst, row_map, col_map]
+
+  def finalize(self, device):
+    per = lib.raw('tfpp_pack_elems_per_block')()
+    blk = 0
+    for d in self.descs:
+      d.blk_start = blk
+      blk += (d.total + per - 1) // per
+    self.total_blocks = blk
+    raw = b''.join(bytes(d) for d in self.descs)
+    self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+  def launch(self):
+    if self.descs:
+      lib.tfpp_pack_multi(ptr(self.table), len(self.descs), self.total_blocks, stream())
+
+
+PACK_PLAN = None  # when set, pack_conv_weight / pack2d record into it instead of launching
+
+
 def pack_conv_weight(w, dtype, G=1, ks_pad=None, n_pad=None, transpose=False):
   """OIHW fp32 parameter -> kernel image (see tfpp.h)."""
   cout, cin_g, r, s = w.shape
@@ -124,6 +157,9 @@ def pack_conv_weight(w, dtype, G=1, ks_pad=None, n_pad=None, transpose=False):
     out = torch.empty((G, cin_g, r * s * n_pad), device=w.device, dtype=dtype)
   else:
     out = torch.empty((G, n_pad, r * s * ks_pad), device=w.device, dtype=dtype)
+  if PACK_PLAN is not None:
+    PACK_PLAN.add(1 if transpose else 0, _chk(w), out, out.numel(), (cout, cin_g, r, s, G, ks_pad, n_pad))
+    return out
   lib.tfpp_pack_conv_weight(ptr(_chk(w)), ptr(out), cout, cin_g, r, s, G, ks_pad, n_pad, int(transpose), dt(out), stream())
   return out
 
@@ -131,6 +167,9 @@ def pack_conv_weight(w, dtype, G=1, ks_pad=None, n_pad=None, transpose=False):
 def pack2d(src, out, rows_out, cols_out, in_ld, out_ld, row_map=None, col_map=None, transpose_in=False, out_offset=0):
   """out[r][c] = src[rmap(r)][cmap(c)] (or transposed source); ``out_offset`` in elements."""
   o = out.view(-1)[out_offset:]
+  if PACK_PLAN is not None:
+    PACK_PLAN.add(2, src, o, rows_out * cols_out, (rows_out, cols_out, int(transpose_in)), row_map, col_map, in_ld, out_ld)
+    return out
   lib.tfpp_pack2d(ptr(src), ptr(o), ptr(row_map), ptr(col_map), rows_out, cols_out, in_ld, out_ld, int(transpose_in), dt(out),
                   stream())
   return out

@@ -114,6 +114,17 @@ int tfpp_pack_conv_weight(const float* w, void* out, int Cout, int cin_g, int R,
 int tfpp_pack2d(const float* in, void* out, const int* row_map, const int* col_map, int rows_out, int cols_out, int64_t in_ld,
                 int64_t out_ld, int transpose_in, int dtype, void* stream);
 int tfpp_cast(const void* in, void* out, int64_t n, int dtype_in, int dtype_out, void* stream);
+/* All per-step weight images in ONE launch: a device-resident table of descriptors (kind 0/1 = tfpp_pack_conv_weight
+ * forward / transposed with a = {Cout, cin_g, R, S, G, ks_pad, n_pad}; kind 2 = tfpp_pack2d with a = {rows_out, cols_out,
+ * transpose_in}).  Descriptor i owns workgroups [blk_start, blk_start + ceil(total / tfpp_pack_elems_per_block())). */
+typedef struct {
+  const float* src; void* dst; const int* row_map; const int* col_map;
+  int64_t total, in_ld, out_ld, blk_start;
+  int kind, dtype;
+  int a[8];
+} tfpp_pack_desc;
+int tfpp_pack_elems_per_block(void);
+int tfpp_pack_multi(const tfpp_pack_desc* descs_dev, int n, int64_t total_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Boundary layout changes.  nchw_to_nhwc_affine = normalize_imagenet (transfuser_utils.py:542-551) fused with
