@@ -81,6 +81,42 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
     __syncthreads();
   }
 
+  // optional fused BatchNorm statistics: per-channel sum / sum of squares of this tile's fp32 results, accumulated into
+  // stats_rows partial rows (tfpp_bn_reduce_final adds the rows in double).  Saves the separate read pass of tfpp_bn_stats.
+  if (p.stats_partial) {
+    __shared__ float st[2][C::WAVES_M][C::WAVES_N][C::FN][16];
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = bm0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+          if (m < M) { const float v = acc[i][j][r] * p.alpha; s += v; q += v * v; }
+        }
+      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      if (lane < 16) { st[0][wm][wn][j][lane] = s; st[1][wm][wn][j][lane] = q; }
+    }
+    __syncthreads();
+    if (wm == 0 && lane < 16) {
+      const int ctot = p.G * p.n_g;
+#pragma unroll
+      for (int j = 0; j < C::FN; ++j) {
+        const int n = bn0 + wn * WN + j * 16 + lane;
+        if (n < p.n_g) {
+          float s = 0.f, q = 0.f;
+          for (int w2 = 0; w2 < C::WAVES_M; ++w2) { s += st[0][w2][wn][j][lane]; q += st[1][w2][wn][j][lane]; }
+          // M-tiles are folded onto stats_rows accumulation rows (<= ~100 fp32 atomics per address, pre-zeroed by the caller)
+          float* row = p.stats_partial + (size_t)(blockIdx.x % p.stats_rows) * 2 * ctot;
+          atomicAdd(row + g * p.n_g + n, s);
+          atomicAdd(row + ctot + g * p.n_g + n, q);
+        }
+      }
+    }
+  }
+
   // epilogue
   const int hw = p.Hd * p.Wd;
   const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
@@ -149,6 +185,13 @@ static bool use_direct_impl() {
   return v != 0;
 }
 
+// number of M-tiles (= rows of stats_partial the LDS kernel writes) for p
+extern "C" int tfpp_conv_gemm_mtiles(const tfpp_conv_params* p) {
+  if (!p) return TFPP_EINVAL;
+  static const int bm[4] = {128, 128, 64, 128};
+  return cdiv((long)p->B * p->Hd * p->Wd, bm[conv_variant(*p)]);
+}
+
 extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
   return use_direct_impl() ? conv_direct_variant(*p, dtype) : conv_variant(*p);
@@ -160,7 +203,7 @@ template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStr
   if (((uintptr_t)p.src & 15) || ((uintptr_t)p.w & 15)) return TFPP_EINVAL;
   const long M = (long)p.B * p.Hd * p.Wd;
   if (M >= (1l << 31) || M * (long)p.dst_ld >= (1l << 40)) return TFPP_EINVAL;
-  if (use_direct_impl()) return conv_gemm_direct(p, ElemTraits<T>::DT, st);
+  if (use_direct_impl() && !p.stats_partial) return conv_gemm_direct(p, ElemTraits<T>::DT, st);
   switch (conv_variant(p)) {
     case 0: return launch_conv<T, 128, 32, 32, 32>(p, st);
     case 1: return launch_conv<T, 128, 64, 64, 32>(p, st);

@@ -137,6 +137,13 @@ static int launch_bn_reduce(const void* x, const void* dy, const void* y, const 
   return 0;
 }
 
+extern "C" int tfpp_bn_reduce_final(const float* partial, double* ws, int nblk, int n2c, void* stream) {
+  if (!partial || !ws || nblk < 1) return TFPP_EINVAL;
+  hipLaunchKernelGGL(bn_reduce_final_kernel, dim3((n2c + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, ws, nblk, n2c);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int tfpp_bn_scratch_floats(int C) { return BN_MAX_PARTIALS * 2 * C + 4 * C; }
 
 extern "C" int tfpp_bn_stats(const void* x, float* scratch, double* ws, int64_t rows, int C, int dtype, void* stream) {

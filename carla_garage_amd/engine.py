@@ -351,9 +351,8 @@ class Engine:
       raw = None
     else:
       raw = torch.empty((B, Ho, Wo, s.n_store), device=x.device, dtype=odt)
-      ops.conv_gemm(x, s.wp, raw, **geo)
+      ops.conv_gemm(x, s.wp, raw, stats_ws=s.ws if bn_train else None, **geo)  # BN statistics fused into the epilogue
       if bn_train:
-        ops.bn_stats(raw, s.ws)
         ops.bn_finalize(s.ws, s.bn.weight.detach(), s.bn.bias.detach(), s.bn.running_mean, s.bn.running_var,
                         s.bn.num_batches_tracked, s.scale, s.shift, s.save_mean, s.save_invstd, B * Ho * Wo, s.bn.momentum,
                         s.bn.eps)

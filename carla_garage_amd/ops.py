@@ -50,7 +50,8 @@ def _chk(t):
 # ------------------------------------------------------------------------------------------------ GEMM / conv
 def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=0, G=1, ks_g=None, n_g=None, mode=0,
               act=ACT_NONE, scale=None, shift=None, res=None, alpha=1.0, dst_nchw=False, src_ld=None, dst_ld=None,
-              res_ld=None):
+              res_ld=None, stats_ws=None):
+  """stats_ws (double[2*Cd]): also produce per-channel sum / sum of squares of the result (fused BatchNorm statistics)."""
   p = ConvParams()
   p.src, p.w, p.dst = ptr(src), ptr(w), ptr(dst)
   p.scale, p.shift, p.res = ptr(scale), ptr(shift), ptr(res)
@@ -63,6 +64,12 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
   p.dst_ld = dst_ld if dst_ld is not None else Cd
   p.res_ld = res_ld if res_ld is not None else p.dst_ld
   p.dst_f32 = int(dst.dtype == torch.float32 and src.dtype != torch.float32)
+  scratch = None
+  if stats_ws is not None:
+    nblk = min(64, lib.raw('tfpp_conv_gemm_mtiles')(ctypes.byref(p)))
+    scratch = bn_scratch(Cd, src.device)
+    lib.tfpp_zero(ptr(scratch), nblk * 2 * Cd * 4, stream())
+    p.stats_partial, p.stats_rows = ptr(scratch), nblk
   if lib.profiler is not None:
     var = lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p), dt(src))
     tile = f'direct{(var - 100) // 10 * 32}x{(var - 100) % 10 * 32}' if var >= 100 else ('128x32', '128x64', '64x64', '128x128')[var]
@@ -71,6 +78,8 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
       fam += f' m{mode} M={B * Hd * Wd} N={p.n_g} K={R * S * p.ks_g} G={G} k{R}s{stride}'
     lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g))
   lib.tfpp_conv_gemm(ctypes.byref(p), dt(src), stream())
+  if stats_ws is not None:
+    lib.tfpp_bn_reduce_final(ptr(scratch), ptr(stats_ws), nblk, 2 * Cd, stream())
   return dst
 
 
@@ -214,9 +223,9 @@ def nchw_to_nhwc_pad(g, dtype, ld):
 _BN_SCRATCH = {}
 
 
-def bn_scratch(c, device):
+def bn_scratch(c, device, min_floats=0):
   """Shared scratch for the BatchNorm reductions (kernels on one stream run in order, so one buffer serves every layer)."""
-  need = lib.raw('tfpp_bn_scratch_floats')(c)
+  need = max(lib.raw('tfpp_bn_scratch_floats')(c), min_floats)
   key = str(device)
   buf = _BN_SCRATCH.get(key)
   if buf is None or buf.numel() < need:

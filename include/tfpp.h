@@ -61,12 +61,15 @@ typedef struct {
   float alpha;
   int64_t src_ld, dst_ld, res_ld; /* pixel strides in elements (allow channel-slice views) */
   int dst_f32;          /* 1: dst is float regardless of dtype */
+  float* stats_partial; /* nullable: fused BatchNorm statistics, [stats_rows][2*Cd] fp32 partial sums / sums of squares, zeroed by the caller */
+  int stats_rows;       /* M-tile t accumulates into row t % stats_rows */
 } tfpp_conv_params;
 int tfpp_conv_gemm(const tfpp_conv_params* p, int dtype, void* stream);
 /* kernel variant the dispatcher picks for p -- used by the bench's per-kernel roofline.  100 + FM*10 + FN: barrier-free
  * direct-to-register kernel with wave tile (16 FM) x (16 FN); 0..3: LDS-staged 128x32 / 128x64 / 64x64 / 128x128
  * (only with TFPP_CONV_IMPL=lds). */
 int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype);
+int tfpp_conv_gemm_mtiles(const tfpp_conv_params* p);
 
 /* Weight gradient of the same convolution (autograd of F.conv2d / F.linear, train.py:898):
  *   dw[(g*n_g+n), c, r, s] += sum_{b,hd,wd} dy[b,hd,wd,g*n_g+n] * x[b,hd*stride-pad+r,wd*stride-pad+s,g*ks_g+c]
@@ -149,6 +152,8 @@ int tfpp_nchw_to_nhwc_pad(const float* in, void* out, int B, int C, int H, int W
 /* scratch: tfpp_bn_scratch_floats(C) floats shared by the three reduction entry points (stage-1 partials + coefficients) */
 int tfpp_bn_scratch_floats(int C);
 int tfpp_bn_stats(const void* x, float* scratch, double* ws, int64_t rows, int C, int dtype, void* stream);
+/* second stage on its own: ws[v] = sum_k partial[k][v], v < n2c (used with tfpp_conv_params.stats_partial) */
+int tfpp_bn_reduce_final(const float* partial, double* ws, int nblk, int n2c, void* stream);
 int tfpp_bn_finalize(const double* ws, const float* gamma, const float* beta, float* running_mean, float* running_var,
                      int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean, float* save_invstd, int64_t rows,
                      int C, float momentum, float eps, void* stream);

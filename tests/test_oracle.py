@@ -143,3 +143,15 @@ def test_regnet_restatement_vs_hf_transformers():
     assert len(a) == len(b) == 5
     for u, v in zip(a, b):
       assert torch.equal(u, v)
+
+
+@pytest.mark.skipif(not ref_harness.available(), reason='needs /root/reference (build container only)')
+def test_reference_aim_config_runs_through_the_harness():
+  """BASELINE config 1 (AIM image-only backbone, bs=2, CPU): the reference's own model code builds and steps on the
+  harness' timm restatement -- plumbing check of the oracle, no GPU."""
+  model, _ = ref_harness.build_reference_model(backbone='aim', use_semantic=0, use_depth=0, detect_boxes=0, use_bev_semantic=0)
+  rgb = P.make_inputs(2)[0]
+  out = model(rgb, torch.zeros(2, 1, 256, 256), torch.zeros(2, 2), torch.ones(2, 1), torch.eye(6)[:2])
+  assert out[1].shape == (2, 4) and out[2].shape == (2, 10, 2) and out[3] is None and out[6] is None
+  (out[1].sum() + out[2].sum()).backward()
+  assert all(p.grad is not None for n, p in model.named_parameters() if 'image_encoder' in n and p.requires_grad)
