@@ -257,8 +257,18 @@ def main():
     fam, a = max(((f, a) for f, a in agg.items() if a['flops'] > 0), key=lambda fa: fa[1]['ms'])
     ach = a['flops'] / (a['ms'] * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.dtype]
+    traffic, traffic_note = None, 'no PMC measurement committed for this kernel'
+    try:  # HBM-side bytes per launch from the committed rocprofv3 --pmc pass (bench.py cannot collect PMC counters itself)
+      with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json'), encoding='utf-8') as f:
+        pmc = json.load(f)
+      if fam in pmc:
+        traffic = pmc[fam]['fetch_bytes_per_launch']
+        traffic_note = 'FETCH_SIZE x2 (gfx950 correction), read side only, from profiles/r01_pmc_traffic.json'
+    except (OSError, ValueError):
+      pass
     roof = {'bound': 'mfma', 'kernel': fam, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'traffic': None, 'launches_per_step': a['calls'] // nprof, 'avg_launch_us': round(1e3 * a['ms'] / a['calls'], 2),
+            'traffic': traffic, 'traffic_note': traffic_note, 'algorithmic_flop_per_launch': round(a['flops'] / a['calls']),
+            'launches_per_step': a['calls'] // nprof, 'avg_launch_us': round(1e3 * a['ms'] / a['calls'], 2),
             'share_of_step_kernel_time': round(a['ms'] / total_ms, 3)}
     if args.kernel_table:
       for f, x in sorted(agg.items(), key=lambda fa: -fa[1]['ms']):

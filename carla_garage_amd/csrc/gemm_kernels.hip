@@ -16,8 +16,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
   __shared__ __attribute__((aligned(16))) T Bs[C::B_ELEMS_RM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  // grid: x = N-tile (fastest), y = M-tile, z = group.  Consecutive workgroups share the same activation rows (A) and
+  // workgroup b lands on XCD b % 8, so each XCD's L2 keeps a fixed subset of weight panels (B) resident.
   const int g = blockIdx.z;
-  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const int mtile = blockIdx.y;
+  const int bm0 = mtile * BM, bn0 = blockIdx.x * BN;
   const int M = p.B * p.Hd * p.Wd, K = p.R * p.S * p.ks_g;
   const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
   const T* __restrict__ wk = reinterpret_cast<const T*>(p.w) + (size_t)g * p.n_g * K;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
           float s = 0.f, q = 0.f;
           for (int w2 = 0; w2 < C::WAVES_M; ++w2) { s += st[0][w2][wn][j][lane]; q += st[1][w2][wn][j][lane]; }
           // M-tiles are folded onto stats_rows accumulation rows (<= ~100 fp32 atomics per address, pre-zeroed by the caller)
-          float* row = p.stats_partial + (size_t)(blockIdx.x % p.stats_rows) * 2 * ctot;
+          float* row = p.stats_partial + (size_t)(mtile % p.stats_rows) * 2 * ctot;
           atomicAdd(row + g * p.n_g + n, s);
           atomicAdd(row + ctot + g * p.n_g + n, q);
         }
@@ -152,7 +155,7 @@ static int launch_conv(const tfpp_conv_params& p, hipStream_t st) {
   constexpr int BKT = sizeof(T) == 2 ? 64 : 32;
   using C = TileCfg<T, BM, BN, WM, WN, BKT>;
   const long M = (long)p.B * p.Hd * p.Wd;
-  dim3 grid(cdiv(M, BM), cdiv(p.n_g, BN), p.G);
+  dim3 grid(cdiv(p.n_g, BN), cdiv(M, BM), p.G);
   const int K = p.R * p.S * p.ks_g;
   if (BKT == 64 && K <= 32) {  // tiny-K layers (stem): one 32-deep stage is enough
     hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WM, WN, 32>), grid, dim3(C::NT), 0, st, p);
@@ -231,8 +234,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_
   __shared__ __attribute__((aligned(16))) T Bs[C::B_ELEMS_KM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
-  const int g = blockIdx.z / p.splits, split = blockIdx.z - g * p.splits;
-  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  // grid: x = (group, pixel split) with the split fastest, y = output-row tile, z = column tile.  All tiles of one pixel slab
+  // then run on XCD (split % 8): the slab of dY / X is fetched into that L2 once and shared by every (n, kk) tile.
+  const int g = blockIdx.x / p.splits, split = blockIdx.x - g * p.splits;
+  const int bm0 = blockIdx.y * BM, bn0 = blockIdx.z * BN;
   const int KK = p.R * p.S * p.ks_g;
   const long P = (long)p.B * p.Hd * p.Wd;
   const long per = ((P + p.splits - 1) / p.splits + BK - 1) / BK * BK;
@@ -317,7 +322,7 @@ static int launch_wgrad(const tfpp_wgrad_params& p, hipStream_t st) {
   constexpr int BKT = sizeof(T) == 2 ? 64 : 32;
   using C = TileCfg<T, BM, BN, WM, WN, BKT>;
   const int KK = p.R * p.S * p.ks_g;
-  dim3 grid(cdiv(p.n_g, BM), cdiv(KK, BN), p.G * p.splits);
+  dim3 grid(p.G * p.splits, cdiv(p.n_g, BM), cdiv(KK, BN));
   hipLaunchKernelGGL((conv_wgrad_kernel<T, BM, BN, WM, WN, BKT>), grid, dim3(C::NT), 0, st, p);
   TFPP_CHECK_LAUNCH();
   return 0;
@@ -337,6 +342,7 @@ template <typename T> static int dispatch_wgrad(tfpp_wgrad_params p, hipStream_t
     long want = (1536 + tiles - 1) / tiles;
     long maxs = (P + 511) / 512;  // >= 512 pixels of reduction per workgroup amortises its atomic epilogue
     p.splits = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
+    if (p.splits >= 8) p.splits = p.splits / 8 * 8;  // whole XCD rounds
     if (p.splits < 1) p.splits = 1;
   }
   if (small) return launch_wgrad<T, 32, 32, 16, 16>(p, st);
