@@ -1,0 +1,288 @@
+// Multi-stage LDS-DMA implicit GEMM (forward / data gradient), bf16, for the N >= 128 shapes of the model.
+//
+// Structure (cdna_hip_programming.md section 5, "glds" rows): every K-tile (BK = 32) of A (BM rows) and B (BN rows) is copied
+// HBM/L2 -> LDS by `global_load_lds_dwordx4` (no VGPR round trip, no ds_write pass), NSTAGE tiles deep, so NSTAGE-1 tiles are
+// in flight behind the MFMAs of the current one; one raw s_barrier per tile, counted `s_waitcnt vmcnt(N)` (never 0 in the
+// steady state).  LDS-DMA writes lane-linear (wave-uniform base + lane*16 B), so the tile image is linear [row][4 x 16 B] and the
+// bank-conflict swizzle is applied on the SOURCE chunk index and again on the fragment read (rule 21):
+//     physical 16-byte slot of (row, kc) = kc ^ F[(row >> 2) & 3],  F = {0, 2, 3, 1}
+// which makes every ds_read_b128 lane group hit 16 distinct slots.  LDS-DMA cannot zero-fill, so out-of-range rows / taps /
+// K-tails read a 16-byte zero page in global memory.  Fragment reads are inline-asm ds_read_b128 (the compiler would otherwise
+// drain the DMA queue with vmcnt(0) before any LDS read it can see).
+#include "gemm_core.cuh"
+#include "gemm_internal.h"
+#include <cstdlib>
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __attribute__((aligned(16))) unsigned int tfpp_zero_page[4] = {0u, 0u, 0u, 0u};
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 lds_read_b128_asm(unsigned addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+template <int BM, int BN, int NSTAGE, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_conv_params p) {
+  typedef bf16_t T;
+  constexpr int NT = WGM * WGN * 64, NWAVES = WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INST = BM * 4 / NT, B_INST = BN * 4 / NT;  // 16-byte chunks per thread per tile
+  static_assert((BM * 4) % NT == 0 && (BN * 4) % NT == 0, "tile must divide over the threads");
+  constexpr int LOADS = A_INST + B_INST;              // LDS-DMA instructions per wave per tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int g = blockIdx.z;
+  const int mtile = blockIdx.y;
+  const int bm0 = mtile * BM, bn0 = blockIdx.x * BN;
+  const int M = p.B * p.Hd * p.Wd, K = p.R * p.S * p.ks_g;
+  const T* __restrict__ src = reinterpret_cast<const T*>(p.src) + g * p.ks_g;
+  const T* __restrict__ wk = reinterpret_cast<const T*>(p.w) + (size_t)g * p.n_g * K;
+  const T* zero = reinterpret_cast<const T*>(tfpp_zero_page);
+  const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)smem;  // LDS byte address of the ring
+
+  // ---- per-thread chunk bookkeeping (fixed over the K loop)
+  int a_kc[A_INST], a_b[A_INST], a_h0[A_INST], a_w0[A_INST];
+  const T* a_ptr[A_INST];  // pointwise fast path
+  const bool pointwise = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
+#pragma unroll
+  for (int i = 0; i < A_INST; ++i) {
+    const int q = i * NT + tid, row = q >> 2, slot = q & 3;
+    const int f = (0x1320 >> (((row >> 2) & 3) * 4)) & 3;  // F = {0,2,3,1}
+    a_kc[i] = slot ^ f;
+    const int m = bm0 + row;
+    a_ptr[i] = nullptr;
+    if (m < M) {
+      const int hw = p.Hd * p.Wd, b = m / hw, pix = m - b * hw, hd = pix / p.Wd, wd = pix - hd * p.Wd;
+      a_b[i] = b;
+      if (p.mode == 0) { a_h0[i] = hd * p.stride - p.pad; a_w0[i] = wd * p.stride - p.pad; }
+      else { a_h0[i] = hd + p.pad; a_w0[i] = wd + p.pad; }
+      if (pointwise) a_ptr[i] = src + ((size_t)(b * p.Hs + a_h0[i]) * p.Ws + a_w0[i]) * p.src_ld;
+    } else {
+      a_b[i] = -1; a_h0[i] = 0; a_w0[i] = 0;
+    }
+  }
+  int b_kc[B_INST];
+  const T* b_ptr[B_INST];
+#pragma unroll
+  for (int j = 0; j < B_INST; ++j) {
+    const int q = j * NT + tid, row = q >> 2, slot = q & 3;
+    const int f = (0x1320 >> (((row >> 2) & 3) * 4)) & 3;
+    b_kc[j] = slot ^ f;
+    const int n = bn0 + row;
+    b_ptr[j] = (n < p.n_g) ? wk + (size_t)n * K : nullptr;
+  }
+
+  auto issue = [&](int kt) {  // LDS-DMA of K-tile kt into ring slot kt % NSTAGE
+    const unsigned stage = lds_base + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+      const int k0 = kt * 32 + a_kc[i] * 8;
+      const T* gp = zero;
+      if (k0 < K && a_b[i] >= 0) {
+        if (pointwise) gp = a_ptr[i] + k0;
+        else {
+          const int rs = k0 / p.ks_g, c = k0 - rs * p.ks_g, r = rs / p.S, s = rs - r * p.S;
+          int hs, ws;
+          bool ok;
+          if (p.mode == 0) {
+            hs = a_h0[i] + r; ws = a_w0[i] + s;
+            ok = (hs >= 0) & (hs < p.Hs) & (ws >= 0) & (ws < p.Ws);
+          } else {
+            const int th = a_h0[i] - r, tw = a_w0[i] - s;
+            hs = th / p.stride; ws = tw / p.stride;
+            ok = (th >= 0) & (tw >= 0) & (hs * p.stride == th) & (ws * p.stride == tw) & (hs < p.Hs) & (ws < p.Ws);
+          }
+          if (ok) gp = src + ((size_t)(a_b[i] * p.Hs + hs) * p.Ws + ws) * p.src_ld + c;
+        }
+      }
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)gp, (lds_void_t*)(stage + (unsigned)((i * NWAVES + wave) * 1024)), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_INST; ++j) {
+      const int k0 = kt * 32 + b_kc[j] * 8;
+      const T* gp = (k0 < K && b_ptr[j]) ? b_ptr[j] + k0 : zero;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)gp, (lds_void_t*)(stage + (unsigned)(A_BYTES + (j * NWAVES + wave) * 1024)), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets inside a stage (fixed): row*64 + ((l>>4) ^ F[(row>>2)&3]) * 16
+  const int r16 = lane & 15, kgrp = lane >> 4;
+  unsigned a_off[FM], b_off[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int row = wm * WM + i * 16 + r16;
+    a_off[i] = (unsigned)(row * 64 + ((kgrp ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3)) * 16));
+  }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int row = wn * WN + j * 16 + r16;
+    b_off[j] = (unsigned)(A_BYTES + row * 64 + ((kgrp ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3)) * 16));
+  }
+
+  const int nkt = (K + 31) / 32;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nkt) issue(s);
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    // tiles issued after kt and still allowed in flight: min(NSTAGE-2, nkt-1-kt)
+    const int ahead = (nkt - 1 - kt) < (NSTAGE - 2) ? (nkt - 1 - kt) : (NSTAGE - 2);
+    switch (ahead) {  // wave-uniform
+#define TFPP_WAIT_CASE(A) case A: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A) * LOADS < 63 ? (A) * LOADS : 63) : "memory"); break
+      TFPP_WAIT_CASE(0); TFPP_WAIT_CASE(1); TFPP_WAIT_CASE(2); TFPP_WAIT_CASE(3); TFPP_WAIT_CASE(4); TFPP_WAIT_CASE(5);
+      TFPP_WAIT_CASE(6); TFPP_WAIT_CASE(7); TFPP_WAIT_CASE(8); TFPP_WAIT_CASE(9); TFPP_WAIT_CASE(10);
+#undef TFPP_WAIT_CASE
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; every wave is done with tile kt-1
+    if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1);
+    const unsigned stage = lds_base + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
+    Frag<T> fa[FM], fb[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) fa[i].v = lds_read_b128_asm(stage + a_off[i]);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) fb[j].v = lds_read_b128_asm(stage + b_off[j]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) frag_mma(fa[i], fb[j], acc[i][j]);
+  }
+
+  // ---- fused BatchNorm statistics (same contract as the LDS-staged kernel; the ring is free after the last barrier + MMA)
+  if (p.stats_partial) {
+    __syncthreads();
+    float* st = reinterpret_cast<float*>(smem);  // [2][WGM][WGN][FN][16]
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = bm0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+          if (m < M) { const float v = acc[i][j][r] * p.alpha; s += v; q += v * v; }
+        }
+      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      if (lane < 16) {
+        st[(((0 * WGM + wm) * WGN + wn) * FN + j) * 16 + lane] = s;
+        st[(((1 * WGM + wm) * WGN + wn) * FN + j) * 16 + lane] = q;
+      }
+    }
+    __syncthreads();
+    if (wm == 0 && lane < 16) {
+      const int ctot = p.G * p.n_g;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n = bn0 + wn * WN + j * 16 + lane;
+        if (n < p.n_g) {
+          float s = 0.f, q = 0.f;
+#pragma unroll
+          for (int w2 = 0; w2 < WGM; ++w2) {
+            s += st[(((0 * WGM + w2) * WGN + wn) * FN + j) * 16 + lane];
+            q += st[(((1 * WGM + w2) * WGN + wn) * FN + j) * 16 + lane];
+          }
+          float* row = p.stats_partial + (size_t)(mtile % p.stats_rows) * 2 * ctot;
+          atomicAdd(row + g * p.n_g + n, s);
+          atomicAdd(row + ctot + g * p.n_g + n, q);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue
+  const int hw = p.Hd * p.Wd;
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = bm0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n = bn0 + wn * WN + j * 16 + r16;
+        if (n >= p.n_g) continue;
+        const int ch = g * p.n_g + n;
+        float v = acc[i][j][r] * p.alpha;
+        if (p.scale) v *= p.scale[ch];
+        if (p.shift) v += p.shift[ch];
+        if (res) v += bf2f(res[(size_t)m * p.res_ld + ch]);
+        v = apply_act(v, p.act);
+        size_t o;
+        if (p.dst_nchw) { const int b = m / hw, pix = m - b * hw; o = ((size_t)b * p.Cd + ch) * hw + pix; }
+        else o = (size_t)m * p.dst_ld + ch;
+        if (p.dst_f32) reinterpret_cast<float*>(p.dst)[o] = v;
+        else reinterpret_cast<T*>(p.dst)[o] = f2bf(v);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int NSTAGE, int WGM, int WGN> static int launch_glds(const tfpp_conv_params& p, hipStream_t st) {
+  const long M = (long)p.B * p.Hd * p.Wd;
+  dim3 grid(cdiv(p.n_g, BN), cdiv(M, BM), p.G);
+  const size_t lds = (size_t)NSTAGE * (BM + BN) * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN>), grid, dim3(WGM * WGN * 64), lds, st, p);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// variant codes 200 + : 0 = 128x128, 1 = 64x128
+int conv_glds_variant(const tfpp_conv_params& p) {
+  const long M = (long)p.B * p.Hd * p.Wd;
+  const long tiles = (long)cdiv(M, 128) * cdiv(p.n_g, 128) * p.G;
+  return tiles >= 512 ? 200 : 201;
+}
+
+bool conv_glds_supported(const tfpp_conv_params& p, int dtype) {
+  static const int min_k = [] { const char* e = std::getenv("TFPP_GLDS_MIN_K"); return e ? std::atoi(e) : 512; }();
+  return dtype == TFPP_BF16 && p.n_g >= 128 && p.ks_g % 8 == 0 && p.src_ld % 8 == 0 && p.R * p.S * p.ks_g >= min_k;
+}
+
+static int glds_cfg() {  // TFPP_GLDS_CFG: tuning switch (stages x wave grid)
+  static const int v = [] {
+    const char* e = std::getenv("TFPP_GLDS_CFG");
+    return e ? std::atoi(e) : 0;
+  }();
+  return v;
+}
+
+int conv_gemm_glds(const tfpp_conv_params& p, hipStream_t st) {
+  const int c = glds_cfg();
+  if (conv_glds_variant(p) == 200) {
+    switch (c) {
+      case 1: return launch_glds<128, 128, 3, 2, 2>(p, st);
+      case 2: return launch_glds<128, 128, 2, 2, 2>(p, st);
+      case 4: return launch_glds<128, 128, 3, 2, 4>(p, st);
+      case 5: return launch_glds<128, 128, 2, 2, 4>(p, st);
+      case 6: return launch_glds<128, 128, 4, 2, 2>(p, st);
+      default: return launch_glds<128, 128, 4, 2, 4>(p, st);  // 8 waves: 516 vs 317-390 TFLOP/s on 3840x6048x1512
+    }
+  }
+  switch (c) {
+    case 2: return launch_glds<64, 128, 2, 2, 2>(p, st);
+    case 6: return launch_glds<64, 128, 4, 2, 2>(p, st);
+    default: return launch_glds<64, 128, 3, 2, 2>(p, st);
+  }
+}

@@ -192,12 +192,23 @@ static bool use_direct_impl() {
 extern "C" int tfpp_conv_gemm_mtiles(const tfpp_conv_params* p) {
   if (!p) return TFPP_EINVAL;
   static const int bm[4] = {128, 128, 64, 128};
-  return cdiv((long)p->B * p->Hd * p->Wd, bm[conv_variant(*p)]);
+  return cdiv((long)p->B * p->Hd * p->Wd, bm[conv_variant(*p)]);  // only an upper bound for the row count is needed
+}
+
+// TFPP_CONV_GLDS=0 disables the multi-stage LDS-DMA kernel (gemm_glds.hip) for A/B measurements
+static bool use_glds_impl() {
+  static const int v = [] {
+    const char* e = std::getenv("TFPP_CONV_GLDS");
+    return (e && std::strcmp(e, "0") == 0) ? 0 : 1;
+  }();
+  return v != 0;
 }
 
 extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
-  return use_direct_impl() ? conv_direct_variant(*p, dtype) : conv_variant(*p);
+  if (use_direct_impl() && !p->stats_partial) return conv_direct_variant(*p, dtype);
+  if (use_glds_impl() && conv_glds_supported(*p, dtype)) return conv_glds_variant(*p);
+  return conv_variant(*p);
 }
 
 template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStream_t st) {
@@ -207,6 +218,7 @@ template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStr
   const long M = (long)p.B * p.Hd * p.Wd;
   if (M >= (1l << 31) || M * (long)p.dst_ld >= (1l << 40)) return TFPP_EINVAL;
   if (use_direct_impl() && !p.stats_partial) return conv_gemm_direct(p, ElemTraits<T>::DT, st);
+  if (use_glds_impl() && conv_glds_supported(p, ElemTraits<T>::DT)) return conv_gemm_glds(p, st);
   switch (conv_variant(p)) {
     case 0: return launch_conv<T, 128, 32, 32, 32>(p, st);
     case 1: return launch_conv<T, 128, 64, 64, 32>(p, st);

@@ -72,7 +72,12 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
     p.stats_partial, p.stats_rows = ptr(scratch), nblk
   if lib.profiler is not None:
     var = lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p), dt(src))
-    tile = f'direct{(var - 100) // 10 * 32}x{(var - 100) % 10 * 32}' if var >= 100 else ('128x32', '128x64', '64x64', '128x128')[var]
+    if var >= 200:
+      tile = ('glds128x128', 'glds64x128')[var - 200]
+    elif var >= 100:
+      tile = f'direct{(var - 100) // 10 * 32}x{(var - 100) % 10 * 32}'
+    else:
+      tile = ('128x32', '128x64', '64x64', '128x128')[var]
     fam = f'conv_gemm<{"f32" if src.dtype == torch.float32 else "bf16"},{tile}>'
     if PROFILE_SHAPES:
       fam += f' m{mode} M={B * Hd * Wd} N={p.n_g} K={R * S * p.ks_g} G={G} k{R}s{stride}'
