@@ -105,3 +105,53 @@ __device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned
   } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Column-fixed thread layout for channels-last [rows, C] tensors walked in 16-byte chunks (CV = C / VEC chunks a row).
+// A 256-thread workgroup is RP row-slots x SW chunk-columns with SW = CV when CV <= 256, so one pass of a workgroup
+// reads RP whole rows = one contiguous span, every lane that exists is active (216/256 .. 256/256 for the RegNet
+// widths), and a thread keeps its channel chunk for its whole life: per-channel parameters and accumulators sit in
+// registers instead of being re-fetched per element.
+// ---------------------------------------------------------------------------------------------------------------
+struct ColLayout { int sw, rp, ny; };
+static inline ColLayout col_layout(int CV) {
+  ColLayout l;
+  l.sw = CV <= 256 ? CV : 256;
+  l.rp = 256 / l.sw;
+  l.ny = (CV + l.sw - 1) / l.sw;
+  return l;
+}
+// number of workgroups along rows: ~rows_per_thread rows per thread, at most max_blocks workgroups in total
+static inline int col_blocks_x(long rows, const ColLayout& l, int rows_per_thread, long max_blocks, long batch = 1) {
+  long nb = (rows + (long)l.rp * rows_per_thread - 1) / ((long)l.rp * rows_per_thread);
+  long cap = max_blocks / ((long)l.ny * batch);
+  if (cap < 1) cap = 1;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+__device__ __forceinline__ bool col_thread(int sw, int rp, int CV, int& rr, int& cv) {
+  rr = (int)threadIdx.x / sw;
+  cv = (int)blockIdx.y * sw + ((int)threadIdx.x - rr * sw);
+  return rr < rp && cv < CV;
+}
+// Sum NV per-thread accumulators over the RP row-slots of a workgroup; on return the rr == 0 threads hold the totals.
+// sm: NV * 256 floats of LDS.  Inactive threads must pass zeros.
+template <int NV> __device__ __forceinline__ void col_block_reduce(float (&acc)[NV], int sw, int rp, int rr, float* sm) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < NV; ++e) sm[e * 256 + tid] = acc[e];
+  __syncthreads();
+  for (int n = rp; n > 1;) {
+    const int h = (n + 1) >> 1;
+    if (rr + h < n) {
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        acc[e] += sm[e * 256 + tid + h * sw];
+        sm[e * 256 + tid] = acc[e];
+      }
+    }
+    __syncthreads();
+    n = h;
+  }
+}

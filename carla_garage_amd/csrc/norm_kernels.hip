@@ -7,8 +7,8 @@
 
 // ---------------------------------------------------------------------------------------------------------------
 // BatchNorm reductions, two stages, no atomics.
-// Stage 1: block = 256 threads = CVB channel-vectors x NRS row-slots (CVB = pow2 >= min(CV,64)); a block walks its rows
-// with a grid stride (4 independent 16-byte loads in flight per lane) and writes one partial per channel to
+// Stage 1: column-fixed layout (common.cuh): a workgroup is RP row-slots x SW channel-chunks and walks its rows with a
+// grid stride (U independent 16-byte loads per operand in flight per lane), then writes one partial per channel to
 // partial[blockIdx.x][2*C].  Stage 2 sums the <=512 partials per value in double.
 // MODE 0: sum x, sum x^2.   MODE 1 (backward): g = dy*(y>0?), sum g, sum g*xhat.
 // ---------------------------------------------------------------------------------------------------------------
@@ -16,22 +16,40 @@
 template <typename T, int MODE>
 __global__ void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                  const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial, long rows,
-                                 int C, int cvb_log2, int relu_mask) {
+                                 int C, int sw, int rp, int relu_mask) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  const int CV = C / VEC, cvb = 1 << cvb_log2, nrs = 256 >> cvb_log2;
-  const int cvl = threadIdx.x & (cvb - 1), rs = threadIdx.x >> cvb_log2;
-  const int cv = blockIdx.y * cvb + cvl;
-  float s0[VEC], s1[VEC], mu[VEC], is[VEC];
+  const int CV = C / VEC;
+  int rr, cv;
+  const bool active = col_thread(sw, rp, CV, rr, cv);
+  float acc[2 * VEC];  // [0,VEC): s0   [VEC,2VEC): s1
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) { s0[e] = 0.f; s1[e] = 0.f; mu[e] = 0.f; is[e] = 1.f; }
-  if (cv < CV) {
-    if (MODE == 1) {
+  for (int e = 0; e < 2 * VEC; ++e) acc[e] = 0.f;
+  if (active) {
+    float mu[VEC], is[VEC];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) { mu[e] = mean[cv * VEC + e]; is[e] = invstd[cv * VEC + e]; }
-    }
-    const long stride = (long)gridDim.x * nrs;
-    constexpr int U = 4;
-    long r = (long)blockIdx.x * nrs + rs;
+    for (int e = 0; e < VEC; ++e) { mu[e] = MODE == 1 ? mean[cv * VEC + e] : 0.f; is[e] = MODE == 1 ? invstd[cv * VEC + e] : 1.f; }
+    auto accumulate = [&](const uint4& xv, const uint4& gv, const uint4& ov) {
+      float v[VEC];
+      unpack16<T>(xv, v);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { acc[e] += v[e]; acc[VEC + e] += v[e] * v[e]; }
+      } else {
+        float g[VEC];
+        unpack16<T>(gv, g);
+        if (relu_mask) {
+          float o[VEC];
+          unpack16<T>(ov, o);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { acc[e] += g[e]; acc[VEC + e] += g[e] * (v[e] - mu[e]) * is[e]; }
+      }
+    };
+    const long stride = (long)gridDim.x * rp;
+    constexpr int U = MODE == 0 ? 4 : 2;
+    long r = (long)blockIdx.x * rp + rr;
     for (; r + (U - 1) * stride < rows; r += U * stride) {
       uint4 xv[U], gv[U], ov[U];
 #pragma unroll
@@ -44,74 +62,64 @@ __global__ void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ 
         }
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        float v[VEC];
-        unpack16<T>(xv[u], v);
-        if (MODE == 0) {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) { s0[e] += v[e]; s1[e] += v[e] * v[e]; }
-        } else {
-          float g[VEC];
-          unpack16<T>(gv[u], g);
-          if (relu_mask) {
-            float o[VEC];
-            unpack16<T>(ov[u], o);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
-          }
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) { s0[e] += g[e]; s1[e] += g[e] * (v[e] - mu[e]) * is[e]; }
-        }
-      }
+      for (int u = 0; u < U; ++u) accumulate(xv[u], gv[u], ov[u]);
     }
     for (; r < rows; r += stride) {
       const size_t off = (size_t)r * C + cv * VEC;
-      float v[VEC];
-      load_vec<T>(x + off, v);
-      if (MODE == 0) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) { s0[e] += v[e]; s1[e] += v[e] * v[e]; }
-      } else {
-        float g[VEC];
-        load_vec<T>(dy + off, g);
-        if (relu_mask) {
-          float o[VEC];
-          load_vec<T>(y + off, o);
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) { s0[e] += g[e]; s1[e] += g[e] * (v[e] - mu[e]) * is[e]; }
+      uint4 xv = *reinterpret_cast<const uint4*>(x + off), gv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+      if (MODE == 1) {
+        gv = *reinterpret_cast<const uint4*>(dy + off);
+        if (relu_mask) ov = *reinterpret_cast<const uint4*>(y + off);
       }
+      accumulate(xv, gv, ov);
     }
   }
-  __shared__ float sm[256][2 * VEC + 1];
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) { sm[threadIdx.x][e] = s0[e]; sm[threadIdx.x][VEC + e] = s1[e]; }
-  __syncthreads();
-  if (rs == 0 && cv < CV) {
+  __shared__ float sm[2 * VEC * 256];
+  col_block_reduce<2 * VEC>(acc, sw, rp, rr, sm);
+  if (active && rr == 0) {
     float* out = partial + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      float a = 0.f, b = 0.f;
-      for (int k = 0; k < nrs; ++k) { a += sm[k * cvb + cvl][e]; b += sm[k * cvb + cvl][VEC + e]; }
-      out[cv * VEC + e] = a;
-      out[C + cv * VEC + e] = b;
+      out[cv * VEC + e] = acc[e];
+      out[C + cv * VEC + e] = acc[VEC + e];
     }
   }
 }
 
-// ws[v] = sum_k partial[k][v] in double; block = 64 values x 4 slots
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// Sum of the partial rows of one channel pair (sum, sum-of-products) in double, one wave64 per channel: lanes take the
+// rows (independent loads, one or a few per lane), then a shuffle reduction.  clear: re-zero what was read (the conv
+// epilogue accumulates into rows that are zero between uses, so no memset launch is needed).
+__device__ __forceinline__ void partial_pair_sum(float* partial, int nrows, int C, int c, int lane, bool clear, double& s0, double& s1) {
+  double a = 0.0, b = 0.0;
+  for (int k = lane; k < nrows; k += 64) {
+    float* row = partial + (size_t)k * 2 * C;
+    a += (double)row[c];
+    b += (double)row[C + c];
+    if (clear) { row[c] = 0.f; row[C + c] = 0.f; }
+  }
+  s0 = wave_sum_f64(a);
+  s1 = wave_sum_f64(b);
+}
+
+// ws[v] = sum_k partial[k][v] in double; one wave per value
 __global__ void bn_reduce_final_kernel(const float* __restrict__ partial, double* __restrict__ ws, int nblk, int n2c) {
-  const int vl = threadIdx.x & 63, slot = threadIdx.x >> 6;
-  const int v = blockIdx.x * 64 + vl;
+  const int lane = threadIdx.x & 63, v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= n2c) return;
   double s = 0.0;
-  if (v < n2c)
-    for (int k = slot; k < nblk; k += 4) s += (double)partial[(size_t)k * n2c + v];
-  __shared__ double sm[4][64];
-  sm[slot][vl] = s;
-  __syncthreads();
-  if (slot == 0 && v < n2c) ws[v] = sm[0][vl] + sm[1][vl] + sm[2][vl] + sm[3][vl];
+  for (int k = lane; k < nblk; k += 64) s += (double)partial[(size_t)k * n2c + v];
+  s = wave_sum_f64(s);
+  if (lane == 0) ws[v] = s;
+}
+
+static inline int bn_reduce_blocks(long rows, int CV, int mode) {
+  const ColLayout l = col_layout(CV);
+  int nblk = col_blocks_x(rows, l, mode == 0 ? 8 : 4, 4096);
+  return nblk > BN_MAX_PARTIALS ? BN_MAX_PARTIALS : nblk;
 }
 
 template <typename T, int MODE>
@@ -119,27 +127,19 @@ static int launch_bn_reduce(const void* x, const void* dy, const void* y, const 
                             long rows, int C, int relu_mask, hipStream_t st) {
   constexpr int VEC = ElemTraits<T>::VEC;
   if (C % VEC) return TFPP_EINVAL;
-  const int CV = C / VEC;
-  int lg = 0;
-  while ((1 << lg) < CV && lg < 6) ++lg;
-  const int cvb = 1 << lg, nrs = 256 >> lg;
-  long nblk = (rows + (long)nrs * 8 - 1) / ((long)nrs * 8);  // >= 8 rows per thread
-  const int ny = (CV + cvb - 1) / cvb;
-  const long cap = BN_MAX_PARTIALS;
-  if (nblk > cap) nblk = cap;
-  if (nblk * ny > 4096) nblk = 4096 / ny > 1 ? 4096 / ny : 1;
-  if (nblk < 1) nblk = 1;
-  dim3 grid((unsigned)nblk, (unsigned)ny);
+  const ColLayout l = col_layout(C / VEC);
+  const int nblk = bn_reduce_blocks(rows, C / VEC, MODE);
+  dim3 grid((unsigned)nblk, (unsigned)l.ny);
   hipLaunchKernelGGL((bn_reduce_kernel<T, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)y, mean, invstd, partial, rows, C,
-                     lg, relu_mask);
-  hipLaunchKernelGGL(bn_reduce_final_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, partial, ws, (int)nblk, 2 * C);
+                     l.sw, l.rp, relu_mask);
+  if (ws) hipLaunchKernelGGL(bn_reduce_final_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, st, partial, ws, nblk, 2 * C);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int tfpp_bn_reduce_final(const float* partial, double* ws, int nblk, int n2c, void* stream) {
   if (!partial || !ws || nblk < 1) return TFPP_EINVAL;
-  hipLaunchKernelGGL(bn_reduce_final_kernel, dim3((n2c + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, ws, nblk, n2c);
+  hipLaunchKernelGGL(bn_reduce_final_kernel, dim3((n2c + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, ws, nblk, n2c);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -155,7 +155,7 @@ extern "C" int tfpp_bn_stats(const void* x, float* scratch, double* ws, int64_t 
 
 extern "C" int tfpp_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* save_mean, const float* save_invstd,
                                   float* scratch, double* ws, int64_t rows, int C, int relu_mask, int dtype, void* stream) {
-  if (!dy || !x || !ws || !scratch || !save_mean || !save_invstd || (relu_mask && !y)) return TFPP_EINVAL;
+  if (!dy || !x || !scratch || !save_mean || !save_invstd || (relu_mask && !y)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   return dtype == TFPP_F32 ? launch_bn_reduce<float, 1>(x, dy, y, save_mean, save_invstd, scratch, ws, (long)rows, C, relu_mask, st)
                            : launch_bn_reduce<bf16_t, 1>(x, dy, y, save_mean, save_invstd, scratch, ws, (long)rows, C, relu_mask, st);
@@ -195,6 +195,46 @@ extern "C" int tfpp_bn_finalize(const double* ws, const float* gamma, const floa
   return 0;
 }
 
+// The same from accumulation rows (tfpp_conv_params.stats_partial), one wave per channel; re-zeroes the rows it consumed.
+__global__ void bn_finalize_partials_kernel(float* __restrict__ partial, int nrows, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv,
+                                            long long* __restrict__ nbt, float* __restrict__ scale, float* __restrict__ shift,
+                                            float* __restrict__ save_mean, float* __restrict__ save_invstd, long rows, int C, float momentum,
+                                            float eps, int clear) {
+  const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c == 0 && lane == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double s0, s1;
+  partial_pair_sum(partial, nrows, C, c, lane, clear != 0, s0, s1);
+  if (lane != 0) return;
+  const double n = (double)rows;
+  const double m = s0 / n;
+  double var = s1 / n - m * m;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * invstd;
+  shift[c] = b - (float)m * g * invstd;
+  if (save_mean) save_mean[c] = (float)m;
+  if (save_invstd) save_invstd[c] = invstd;
+  if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * (float)m;
+  if (rv) {
+    const double unb = rows > 1 ? var * n / (n - 1.0) : var;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unb;
+  }
+}
+
+extern "C" int tfpp_bn_finalize_partials(float* partial, int nrows, int clear, const float* gamma, const float* beta, float* running_mean,
+                                         float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
+                                         float* save_invstd, int64_t rows, int C, float momentum, float eps, void* stream) {
+  if (!partial || nrows < 1 || !scale || !shift) return TFPP_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nrows, gamma, beta,
+                     running_mean, running_var, (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd, (long)rows, C, momentum,
+                     eps, clear);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
 __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
                                const float* __restrict__ rv, float* __restrict__ scale, float* __restrict__ shift, int C, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -216,64 +256,97 @@ extern "C" int tfpp_bn_fold(const float* gamma, const float* beta, const float* 
 
 // dx = gamma*invstd*(g - ws0/rows - xhat*ws1/rows) = A[c]*g + Bc[c]*x + D[c] ; dres = g.
 // coefficient kernel (per channel) also accumulates dgamma += ws1, dbeta += ws0.
-__global__ void bn_bwd_coef_kernel(const double* __restrict__ ws, const float* __restrict__ gamma, const float* __restrict__ mean,
-                                   const float* __restrict__ invstd, float* __restrict__ coef, float* __restrict__ dgamma,
-                                   float* __restrict__ dbeta, long rows, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void bn_bwd_coef_kernel(float* __restrict__ partial, int nrows, double* __restrict__ ws, const float* __restrict__ gamma,
+                                   const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ coef,
+                                   float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int C) {
+  const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
-  const double n = (double)rows, s0 = ws[c], s1 = ws[C + c];
+  double s0, s1;
+  partial_pair_sum(partial, nrows, C, c, lane, false, s0, s1);
+  if (lane != 0) return;
+  const double n = (double)rows;
   const double gm = gamma ? (double)gamma[c] : 1.0, is = (double)invstd[c], mu = (double)mean[c];
   const double A = gm * is, Bc = -gm * is * is * s1 / n, D = -gm * is * s0 / n - Bc * mu;
   coef[c] = (float)A;
   coef[C + c] = (float)Bc;
   coef[2 * C + c] = (float)D;
+  if (ws) { ws[c] = s0; ws[C + c] = s1; }
   if (dgamma) dgamma[c] += (float)s1;
   if (dbeta) dbeta[c] += (float)s0;
 }
 
-template <typename T>
+template <typename T, bool RELU, bool DRES>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x, const float* __restrict__ coef,
-                                    T* __restrict__ dx, T* __restrict__ dres, long nvec, int C, int relu_mask) {
+                                    T* __restrict__ dx, T* __restrict__ dres, long rows, int C, int sw, int rp) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const int CV = C / VEC;
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (; i < nvec; i += stride) {
-    const int c0 = (int)(i % CV) * VEC;
+  int rr, cv;
+  if (!col_thread(sw, rp, CV, rr, cv)) return;
+  const int c0 = cv * VEC;
+  float ka[VEC], kb[VEC], kd[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { ka[e] = coef[c0 + e]; kb[e] = coef[C + c0 + e]; kd[e] = coef[2 * C + c0 + e]; }
+  auto body = [&](size_t off, const uint4& gv, const uint4& xv, const uint4& ov) {
     float g[VEC], v[VEC];
-    load_vec<T>(dy + i * VEC, g);
-    load_vec<T>(x + i * VEC, v);
-    if (relu_mask) {
+    unpack16<T>(gv, g);
+    unpack16<T>(xv, v);
+    if (RELU) {
       float o[VEC];
-      load_vec<T>(y + i * VEC, o);
+      unpack16<T>(ov, o);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
     }
-    if (dres) store_vec<T>(dres + i * VEC, g);
+    if (DRES) store_vec<T>(dres + off, g);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) v[e] = coef[c0 + e] * g[e] + coef[C + c0 + e] * v[e] + coef[2 * C + c0 + e];
-    store_vec<T>(dx + i * VEC, v);
+    for (int e = 0; e < VEC; ++e) v[e] = ka[e] * g[e] + kb[e] * v[e] + kd[e];
+    store_vec<T>(dx + off, v);
+  };
+  const long stride = (long)gridDim.x * rp;
+  constexpr int U = 2;
+  long r = (long)blockIdx.x * rp + rr;
+  for (; r + (U - 1) * stride < rows; r += U * stride) {
+    uint4 gv[U], xv[U], ov[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t off = (size_t)(r + u * stride) * C + c0;
+      gv[u] = *reinterpret_cast<const uint4*>(dy + off);
+      xv[u] = *reinterpret_cast<const uint4*>(x + off);
+      if (RELU) ov[u] = *reinterpret_cast<const uint4*>(y + off);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) body((size_t)(r + u * stride) * C + c0, gv[u], xv[u], ov[u]);
+  }
+  for (; r < rows; r += stride) {
+    const size_t off = (size_t)r * C + c0;
+    uint4 gv = *reinterpret_cast<const uint4*>(dy + off), xv = *reinterpret_cast<const uint4*>(x + off), ov = make_uint4(0, 0, 0, 0);
+    if (RELU) ov = *reinterpret_cast<const uint4*>(y + off);
+    body(off, gv, xv, ov);
   }
 }
 
+template <typename T>
+static void launch_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* coef, void* dx, void* dres, long rows, int C,
+                                int relu_mask, hipStream_t st) {
+  const ColLayout l = col_layout(C / ElemTraits<T>::VEC);
+  dim3 grid((unsigned)col_blocks_x(rows, l, 4, 1 << 20), (unsigned)l.ny);
+#define BA(R_, D_) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R_, D_>), grid, dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, coef, (T*)dx, (T*)dres, rows, C, l.sw, l.rp)
+  if (relu_mask) { if (dres) BA(true, true); else BA(true, false); }
+  else { if (dres) BA(false, true); else BA(false, false); }
+#undef BA
+}
+
 extern "C" int tfpp_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
-                                 const float* save_invstd, const double* ws, float* scratch, void* dx, void* dres, float* dgamma,
+                                 const float* save_invstd, double* ws, float* scratch, void* dx, void* dres, float* dgamma,
                                  float* dbeta, int64_t rows, int C, int relu_mask, int dtype, void* stream) {
-  if (!dy || !x || !ws || !dx || !scratch || !save_mean || !save_invstd || (relu_mask && !y)) return TFPP_EINVAL;
+  if (!dy || !x || !dx || !scratch || !save_mean || !save_invstd || (relu_mask && !y)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int VEC = dtype == TFPP_F32 ? 4 : 8;
   if (C % VEC) return TFPP_EINVAL;
   float* coef = scratch + (size_t)BN_MAX_PARTIALS * 2 * C;  // after the stage-1 partials
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, gamma, save_mean, save_invstd, coef, dgamma, dbeta,
-                     (long)rows, C);
-  long nvec = rows * (C / VEC);
-  long blocks = (nvec + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  if (blocks < 1) blocks = 1;
-  if (dtype == TFPP_F32)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)dy, (const float*)y, (const float*)x, coef, (float*)dx, (float*)dres, nvec, C, relu_mask);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, coef, (bf16_t*)dx, (bf16_t*)dres, nvec, C, relu_mask);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 3) / 4), dim3(256), 0, st, scratch, bn_reduce_blocks((long)rows, C / VEC, 1), ws, gamma,
+                     save_mean, save_invstd, coef, dgamma, dbeta, (long)rows, C);
+  if (dtype == TFPP_F32) launch_bn_bwd_apply<float>(dy, y, x, coef, dx, dres, (long)rows, C, relu_mask, st);
+  else launch_bn_bwd_apply<bf16_t>(dy, y, x, coef, dx, dres, (long)rows, C, relu_mask, st);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

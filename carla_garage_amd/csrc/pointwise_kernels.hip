@@ -189,31 +189,77 @@ extern "C" int tfpp_nchw_to_nhwc_pad(const float* in, void* out, int B, int C, i
 // ---------------------------------------------------------------------------------------------------------------
 // elementwise over [rows, C] with 16-byte vectors
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T>
+// y = act(x * gate[b,c] * scale[c] + shift[c] + res); column-fixed layout, scale/shift live in registers.
+// ACT < 0: activation chosen at run time (uniform switch); otherwise compiled in.
+template <typename T, bool RES, bool GATE, int ACT>
 __global__ void affine_act_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                  const T* __restrict__ res, const float* __restrict__ gate, T* __restrict__ y, long nvec, int CV,
-                                  long rows_per_batch, int act) {
+                                  const T* __restrict__ res, const float* __restrict__ gate, T* __restrict__ y, long rows, int CV,
+                                  int sw, int rp, long rows_per_batch, int act_rt) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (; i < nvec; i += stride) {
-    const long row = i / CV;
-    const int c0 = (int)(i - row * CV) * VEC;
-    float v[VEC], r[VEC];
-    load_vec<T>(x + i * VEC, v);
-    if (res) load_vec<T>(res + i * VEC, r);
-    const float* gp = gate ? gate + (row / rows_per_batch) * (long)CV * VEC + c0 : nullptr;
+  int rr, cv;
+  if (!col_thread(sw, rp, CV, rr, cv)) return;
+  const int c0 = cv * VEC, C = CV * VEC;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { sc[e] = scale ? scale[c0 + e] : 1.f; sh[e] = shift ? shift[c0 + e] : 0.f; }
+  const long stride = (long)gridDim.x * rp;
+  constexpr int U = 2;
+  auto body = [&](long r, const uint4& xv, const uint4& rv) {
+    float v[VEC], q[VEC];
+    unpack16<T>(xv, v);
+    if (RES) unpack16<T>(rv, q);
+    if (GATE) {
+      const float4* gp = reinterpret_cast<const float4*>(gate + (size_t)((unsigned)r / (unsigned)rows_per_batch) * C + c0);
+#pragma unroll
+      for (int h = 0; h < VEC / 4; ++h) {
+        const float4 g4 = gp[h];
+        v[4 * h + 0] *= g4.x; v[4 * h + 1] *= g4.y; v[4 * h + 2] *= g4.z; v[4 * h + 3] *= g4.w;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      float t = v[e];
-      if (gp) t *= gp[e];
-      if (scale) t *= scale[c0 + e];
-      if (shift) t += shift[c0 + e];
-      if (res) t += r[e];
-      v[e] = apply_act(t, act);
+      float t = v[e] * sc[e] + sh[e];
+      if (RES) t += q[e];
+      v[e] = ACT < 0 ? apply_act(t, act_rt) : apply_act(t, ACT);
     }
-    store_vec<T>(y + i * VEC, v);
+    store_vec<T>(y + (size_t)r * C + c0, v);
+  };
+  long r = (long)blockIdx.x * rp + rr;
+  for (; r + (U - 1) * stride < rows; r += U * stride) {
+    uint4 xv[U], rv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t off = (size_t)(r + u * stride) * C + c0;
+      xv[u] = *reinterpret_cast<const uint4*>(x + off);
+      if (RES) rv[u] = *reinterpret_cast<const uint4*>(res + off);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) body(r + u * stride, xv[u], rv[u]);
   }
+  for (; r < rows; r += stride) {
+    const size_t off = (size_t)r * C + c0;
+    uint4 xv = *reinterpret_cast<const uint4*>(x + off), rv = make_uint4(0, 0, 0, 0);
+    if (RES) rv = *reinterpret_cast<const uint4*>(res + off);
+    body(r, xv, rv);
+  }
+}
+
+template <typename T>
+static int launch_affine_act(const void* x, const float* scale, const float* shift, const void* res, const float* gate, void* y, long rows,
+                             int C, long rows_per_batch, int act, hipStream_t st) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  if (C % VEC) return TFPP_EINVAL;
+  const int CV = C / VEC;
+  const ColLayout l = col_layout(CV);
+  dim3 grid((unsigned)col_blocks_x(rows, l, 4, 1 << 20), (unsigned)l.ny);
+#define AA(R_, G_, A_) hipLaunchKernelGGL((affine_act_kernel<T, R_, G_, A_>), grid, dim3(256), 0, st, (const T*)x, scale, shift, (const T*)res, gate, (T*)y, rows, CV, l.sw, l.rp, rows_per_batch, act)
+#define AA_ACT(R_, G_) do { if (act == ACT_RELU) AA(R_, G_, ACT_RELU); else if (act == ACT_NONE) AA(R_, G_, ACT_NONE); else AA(R_, G_, -1); } while (0)
+  if (res) { if (gate) AA_ACT(true, true); else AA_ACT(true, false); }
+  else { if (gate) AA_ACT(false, true); else AA_ACT(false, false); }
+#undef AA_ACT
+#undef AA
+  TFPP_CHECK_LAUNCH();
+  return 0;
 }
 
 static inline dim3 grid_stride(long n) {
@@ -225,19 +271,10 @@ static inline dim3 grid_stride(long n) {
 
 extern "C" int tfpp_affine_act(const void* x, const float* scale, const float* shift, const void* res, const float* gate, void* y,
                                int64_t rows, int C, int64_t rows_per_batch, int act, int dtype, void* stream) {
-  if (!x || !y) return TFPP_EINVAL;
+  if (!x || !y || (gate && rows_per_batch < 1)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TFPP_F32) {
-    if (C % 4) return TFPP_EINVAL;
-    const long nvec = rows * (C / 4);
-    hipLaunchKernelGGL(affine_act_kernel<float>, grid_stride(nvec), dim3(PW_THREADS), 0, st, (const float*)x, scale, shift, (const float*)res, gate, (float*)y, nvec, C / 4, (long)rows_per_batch, act);
-  } else {
-    if (C % 8) return TFPP_EINVAL;
-    const long nvec = rows * (C / 8);
-    hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid_stride(nvec), dim3(PW_THREADS), 0, st, (const bf16_t*)x, scale, shift, (const bf16_t*)res, gate, (bf16_t*)y, nvec, C / 8, (long)rows_per_batch, act);
-  }
-  TFPP_CHECK_LAUNCH();
-  return 0;
+  return dtype == TFPP_F32 ? launch_affine_act<float>(x, scale, shift, res, gate, y, (long)rows, C, (long)rows_per_batch, act, st)
+                           : launch_affine_act<bf16_t>(x, scale, shift, res, gate, y, (long)rows, C, (long)rows_per_batch, act, st);
 }
 
 // y = a + dropout(b)
@@ -344,9 +381,32 @@ extern "C" int tfpp_mul_pixmask(const void* x, const float* m, void* y, int64_t 
 // ---------------------------------------------------------------------------------------------------------------
 // column sums: out[c] += sum_rows x[row*ld + c]   (bias gradients); block = 64 row-slots x 4... generic layout below
 // ---------------------------------------------------------------------------------------------------------------
+// Second stage of the two-stage column reductions: out[b][c] (+)= mul * sum_{k<P} partial[(b*P + k)*Cw + c].
+// block = 64 columns x 4 partial slots (coalesced 256-byte row segments, <= P/4 independent loads per thread).
+__global__ void col_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, int Cw, float mul, int accumulate) {
+  const int cl = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+  float s = 0.f;
+  if (c < Cw) {
+    const float* base = partial + (size_t)b * P * Cw + c;
+#pragma unroll 8
+    for (int k = ks; k < P; k += 4) s += base[(size_t)k * Cw];
+  }
+  __shared__ float sm[4][64];
+  sm[ks][cl] = s;
+  __syncthreads();
+  if (ks == 0 && c < Cw) {
+    const float t = (sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl]) * mul;
+    float* o = out + (size_t)b * Cw + c;
+    *o = accumulate ? *o + t : t;
+  }
+}
+#define COLSUM_MAX_PARTIALS 128
+#define HW_MAX_PARTIALS 64
+
+// Generic path (any C / ld): 64 columns x 4 row slots, scalar loads.
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int C, long ld, long rows_per_block) {
-  // threads: 64 columns x 4 row slots
   const int cl = threadIdx.x & 63, rs = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + cl;
   const long r0 = (long)blockIdx.x * rows_per_block;
@@ -360,19 +420,78 @@ __global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, 
   if (rs == 0 && c < C) atomicAdd(out + c, sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl]);
 }
 
-extern "C" int tfpp_colsum(const void* x, float* out, int64_t rows, int C, int64_t ld, int dtype, void* stream) {
-  if (!x || !out) return TFPP_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  // rows per workgroup: keep <= ~128 atomics per output address while still filling the chip for narrow tensors
-  long rpb = 256;
-  const long col_blocks = (C + 63) / 64;
-  while ((rows + rpb - 1) / rpb > 128 && (rows + rpb - 1) / rpb * col_blocks > 2048) rpb *= 2;
-  dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((C + 63) / 64));
-  if (grid.x < 1) grid.x = 1;
-  if (dtype == TFPP_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, out, (long)rows, C, (long)ld, rpb);
-  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, out, (long)rows, C, (long)ld, rpb);
+// Vector path (C % VEC == 0, ld % VEC == 0): column-fixed layout, 16-byte loads, 4 in flight per lane.
+template <typename T>
+__global__ void colsum_vec_kernel(const T* __restrict__ x, float* __restrict__ partial, long rows, int CV, long ld, int sw, int rp) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  int rr, cv;
+  const bool active = col_thread(sw, rp, CV, rr, cv);
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  if (active) {
+    const long stride = (long)gridDim.x * rp;
+    constexpr int U = 4;
+    long r = (long)blockIdx.x * rp + rr;
+    for (; r + (U - 1) * stride < rows; r += U * stride) {
+      uint4 xv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const uint4*>(x + (size_t)(r + u * stride) * ld + cv * VEC);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float v[VEC];
+        unpack16<T>(xv[u], v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+      }
+    }
+    for (; r < rows; r += stride) {
+      float v[VEC];
+      load_vec<T>(x + (size_t)r * ld + cv * VEC, v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+    }
+  }
+  __shared__ float sm[VEC * 256];
+  col_block_reduce<VEC>(acc, sw, rp, rr, sm);
+  if (active && rr == 0) {
+    float* o = partial + (size_t)blockIdx.x * CV * VEC + cv * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = acc[e];
+  }
+}
+
+template <typename T> static int launch_colsum(const void* x, float* out, float* scratch, long rows, int C, long ld, hipStream_t st) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  if (scratch && C % VEC == 0 && ld % VEC == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const ColLayout l = col_layout(C / VEC);
+    int nb = col_blocks_x(rows, l, 8, 2048);
+    if (nb > COLSUM_MAX_PARTIALS) nb = COLSUM_MAX_PARTIALS;
+    hipLaunchKernelGGL(colsum_vec_kernel<T>, dim3((unsigned)nb, (unsigned)l.ny), dim3(256), 0, st, (const T*)x, scratch, rows, C / VEC, ld, l.sw, l.rp);
+    hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)((C + 63) / 64), 1), dim3(256), 0, st, scratch, out, nb, C, 1.f, 1);
+  } else {
+    // rows per workgroup: keep <= ~128 atomics per output address while still filling the chip for narrow tensors
+    long rpb = 256;
+    const long col_blocks = (C + 63) / 64;
+    while ((rows + rpb - 1) / rpb > 128 && (rows + rpb - 1) / rpb * col_blocks > 2048) rpb *= 2;
+    dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((C + 63) / 64));
+    if (grid.x < 1) grid.x = 1;
+    hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, (const T*)x, out, rows, C, ld, rpb);
+  }
   TFPP_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int tfpp_colsum(const void* x, float* out, float* scratch, int64_t rows, int C, int64_t ld, int dtype, void* stream) {
+  if (!x || !out) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == TFPP_F32 ? launch_colsum<float>(x, out, scratch, (long)rows, C, (long)ld, st)
+                           : launch_colsum<bf16_t>(x, out, scratch, (long)rows, C, (long)ld, st);
+}
+
+extern "C" int tfpp_reduce_scratch_floats(int B, int C) {
+  const long hw = (long)B * HW_MAX_PARTIALS * C, cs = (long)COLSUM_MAX_PARTIALS * C;
+  return (int)(hw > cs ? hw : cs);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -600,26 +719,48 @@ extern "C" int tfpp_bilinear_bwd(const void* dy, const float* mul, void* dx, int
 // ---------------------------------------------------------------------------------------------------------------
 // squeeze-excite
 // ---------------------------------------------------------------------------------------------------------------
-// out[b,c] += (1/HW) * sum_{rows in this block's slice} x[b,row,c] * (y ? y[b,row,c] : 1)     (out pre-zeroed)
-template <typename T>
-__global__ void hw_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y, float* __restrict__ out, int HW, int C, float mulv, int rows_per_block) {
+// partial[b][blockIdx.x][c] = sum_{this workgroup's rows of image b} x[b,row,c] * (y ? y[b,row,c] : 1); column-fixed layout
+template <typename T, bool DOT>
+__global__ void hw_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y, float* __restrict__ partial, int HW, int CV, int sw, int rp) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  const int CV = C / VEC;
-  const int cvl = threadIdx.x & 63, rs = threadIdx.x >> 6;  // 64 channel vectors x 4 row slots
-  const int cv = blockIdx.y * 64 + cvl;
-  const int b = blockIdx.z;
-  const int r0 = blockIdx.x * rows_per_block;
-  const int r1 = (r0 + rows_per_block < HW) ? r0 + rows_per_block : HW;
+  int rr, cv;
+  const bool active = col_thread(sw, rp, CV, rr, cv);
+  const int b = blockIdx.z, C = CV * VEC;
   float acc[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-  if (cv < CV) {
-    for (int r = r0 + rs; r < r1; r += 4) {
-      float v[VEC];
-      const size_t off = ((size_t)b * HW + r) * C + cv * VEC;
+  if (active) {
+    const size_t base = (size_t)b * HW * C + cv * VEC;
+    const int stride = (int)gridDim.x * rp;
+    constexpr int U = DOT ? 2 : 4;
+    int r = (int)blockIdx.x * rp + rr;
+    for (; r + (U - 1) * stride < HW; r += U * stride) {
+      uint4 xv[U], yv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t off = base + (size_t)(r + u * stride) * C;
+        xv[u] = *reinterpret_cast<const uint4*>(x + off);
+        if (DOT) yv[u] = *reinterpret_cast<const uint4*>(y + off);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float v[VEC], w[VEC];
+        unpack16<T>(xv[u], v);
+        if (DOT) {
+          unpack16<T>(yv[u], w);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[e] += v[e] * w[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+        }
+      }
+    }
+    for (; r < HW; r += stride) {
+      const size_t off = base + (size_t)r * C;
+      float v[VEC], w[VEC];
       load_vec<T>(x + off, v);
-      if (y) {
-        float w[VEC];
+      if (DOT) {
         load_vec<T>(y + off, w);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] += v[e] * w[e];
@@ -629,41 +770,42 @@ __global__ void hw_reduce_kernel(const T* __restrict__ x, const T* __restrict__ 
       }
     }
   }
-  __shared__ float sm[4][64][VEC + 1];
+  __shared__ float sm[VEC * 256];
+  col_block_reduce<VEC>(acc, sw, rp, rr, sm);
+  if (active && rr == 0) {
+    float* o = partial + ((size_t)b * gridDim.x + blockIdx.x) * C + cv * VEC;
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) sm[rs][cvl][e] = acc[e];
-  __syncthreads();
-  if (rs == 0 && cv < CV) {
-#pragma unroll
-    for (int e = 0; e < VEC; ++e)
-      atomicAdd(out + (size_t)b * C + cv * VEC + e, (sm[0][cvl][e] + sm[1][cvl][e] + sm[2][cvl][e] + sm[3][cvl][e]) * mulv);
+    for (int e = 0; e < VEC; ++e) o[e] = acc[e];
   }
 }
 
-template <typename T> static int launch_hw_reduce(const void* x, const void* y, float* out, int B, int HW, int C, float mulv, hipStream_t st) {
+template <typename T>
+static int launch_hw_reduce(const void* x, const void* y, float* out, float* scratch, int B, int HW, int C, float mulv, hipStream_t st) {
   constexpr int VEC = ElemTraits<T>::VEC;
   if (C % VEC) return TFPP_EINVAL;
-  hipError_t e = hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), st);
-  if (e != hipSuccess) return -(int)e;
-  const int CV = C / VEC;
-  int rpb = 256;
-  dim3 grid((unsigned)((HW + rpb - 1) / rpb), (unsigned)((CV + 63) / 64), (unsigned)B);
-  hipLaunchKernelGGL(hw_reduce_kernel<T>, grid, dim3(256), 0, st, (const T*)x, (const T*)y, out, HW, C, mulv, rpb);
+  const ColLayout l = col_layout(C / VEC);
+  int nb = col_blocks_x(HW, l, y ? 4 : 8, 4096, B);
+  if (nb > HW_MAX_PARTIALS) nb = HW_MAX_PARTIALS;
+  dim3 grid((unsigned)nb, (unsigned)l.ny, (unsigned)B);
+  if (y) hipLaunchKernelGGL((hw_reduce_kernel<T, true>), grid, dim3(256), 0, st, (const T*)x, (const T*)y, scratch, HW, C / VEC, l.sw, l.rp);
+  else hipLaunchKernelGGL((hw_reduce_kernel<T, false>), grid, dim3(256), 0, st, (const T*)x, (const T*)y, scratch, HW, C / VEC, l.sw, l.rp);
+  hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0, st, scratch, out, nb, C, mulv, 0);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int tfpp_mean_hw(const void* x, float* out, int B, int HW, int C, int dtype, void* stream) {
-  if (!x || !out) return TFPP_EINVAL;
+extern "C" int tfpp_mean_hw(const void* x, float* out, float* scratch, int B, int HW, int C, int dtype, void* stream) {
+  if (!x || !out || !scratch) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  return dtype == TFPP_F32 ? launch_hw_reduce<float>(x, nullptr, out, B, HW, C, 1.f / (float)HW, st)
-                           : launch_hw_reduce<bf16_t>(x, nullptr, out, B, HW, C, 1.f / (float)HW, st);
+  return dtype == TFPP_F32 ? launch_hw_reduce<float>(x, nullptr, out, scratch, B, HW, C, 1.f / (float)HW, st)
+                           : launch_hw_reduce<bf16_t>(x, nullptr, out, scratch, B, HW, C, 1.f / (float)HW, st);
 }
 
-extern "C" int tfpp_se_dgate(const void* dy, const void* x, float* dgate, int B, int HW, int C, int dtype, void* stream) {
-  if (!dy || !x || !dgate) return TFPP_EINVAL;
+extern "C" int tfpp_se_dgate(const void* dy, const void* x, float* dgate, float* scratch, int B, int HW, int C, int dtype, void* stream) {
+  if (!dy || !x || !dgate || !scratch) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  return dtype == TFPP_F32 ? launch_hw_reduce<float>(dy, x, dgate, B, HW, C, 1.f, st) : launch_hw_reduce<bf16_t>(dy, x, dgate, B, HW, C, 1.f, st);
+  return dtype == TFPP_F32 ? launch_hw_reduce<float>(dy, x, dgate, scratch, B, HW, C, 1.f, st)
+                           : launch_hw_reduce<bf16_t>(dy, x, dgate, scratch, B, HW, C, 1.f, st);
 }
 
 // squeeze-excite gate: hidden = relu(W1 pool + b1) [one wave per (b,j)] ; gate = sigmoid(W2 hidden + b2) [thread per (b,c)]

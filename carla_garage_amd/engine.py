@@ -351,11 +351,11 @@ class Engine:
       raw = None
     else:
       raw = torch.empty((B, Ho, Wo, s.n_store), device=x.device, dtype=odt)
-      ops.conv_gemm(x, s.wp, raw, stats_ws=s.ws if bn_train else None, **geo)  # BN statistics fused into the epilogue
-      if bn_train:
-        ops.bn_finalize(s.ws, s.bn.weight.detach(), s.bn.bias.detach(), s.bn.running_mean, s.bn.running_var,
-                        s.bn.num_batches_tracked, s.scale, s.shift, s.save_mean, s.save_invstd, B * Ho * Wo, s.bn.momentum,
-                        s.bn.eps)
+      acc = ops.stats_rows_buffer(s.n_store, x.device)
+      nrows = ops.conv_gemm(x, s.wp, raw, stats_acc=acc, **geo)  # BN statistics fused into the epilogue
+      ops.bn_finalize_partials(acc, nrows, s.bn.weight.detach(), s.bn.bias.detach(), s.bn.running_mean, s.bn.running_var,
+                               s.bn.num_batches_tracked, s.scale, s.shift, s.save_mean, s.save_invstd, B * Ho * Wo,
+                               s.bn.momentum, s.bn.eps)
       y = ops.affine_act(raw, scale=s.scale, shift=s.shift, res=res, act=act)
     if self.tape is not None:
 
@@ -372,7 +372,7 @@ class Engine:
               ops.copy_rows(tmp, self.g(s.bias), 1, s.cout, 0, 0, 0, 0, accumulate=True)
           dconv = dz
         elif bn_train:
-          dconv, dres = ops.bn_bwd(dy, y, raw, s.bn.weight.detach(), s.save_mean, s.save_invstd, s.ws, self.g(s.bn.weight),
+          dconv, dres = ops.bn_bwd(dy, y, raw, s.bn.weight.detach(), s.save_mean, s.save_invstd, None, self.g(s.bn.weight),
                                    self.g(s.bn.bias), relu_mask=(act == ACT_RELU), want_dres=res is not None)
         gsrc = dconv if dconv.dtype == x.dtype else ops.cast(dconv, x.dtype)
         if s.weight.requires_grad:

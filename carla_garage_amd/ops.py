@@ -50,8 +50,10 @@ def _chk(t):
 # ------------------------------------------------------------------------------------------------ GEMM / conv
 def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=0, G=1, ks_g=None, n_g=None, mode=0,
               act=ACT_NONE, scale=None, shift=None, res=None, alpha=1.0, dst_nchw=False, src_ld=None, dst_ld=None,
-              res_ld=None, stats_ws=None):
-  """stats_ws (double[2*Cd]): also produce per-channel sum / sum of squares of the result (fused BatchNorm statistics)."""
+              res_ld=None, stats_ws=None, stats_acc=None):
+  """stats_ws (double[2*Cd]): also produce per-channel sum / sum of squares of the result (fused BatchNorm statistics).
+  stats_acc (zeroed fp32 accumulation rows from stats_rows_buffer()): leave the statistics in the rows for
+  bn_finalize_partials and return the number of rows used."""
   p = ConvParams()
   p.src, p.w, p.dst = ptr(src), ptr(w), ptr(dst)
   p.scale, p.shift, p.res = ptr(scale), ptr(shift), ptr(res)
@@ -65,7 +67,10 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
   p.res_ld = res_ld if res_ld is not None else p.dst_ld
   p.dst_f32 = int(dst.dtype == torch.float32 and src.dtype != torch.float32)
   scratch = None
-  if stats_ws is not None:
+  if stats_acc is not None:
+    nblk = min(64, lib.raw('tfpp_conv_gemm_mtiles')(ctypes.byref(p)))
+    p.stats_partial, p.stats_rows = ptr(stats_acc), nblk
+  elif stats_ws is not None:
     nblk = min(64, lib.raw('tfpp_conv_gemm_mtiles')(ctypes.byref(p)))
     scratch = bn_scratch(Cd, src.device)
     lib.tfpp_zero(ptr(scratch), nblk * 2 * Cd * 4, stream())
@@ -83,6 +88,8 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
       fam += f' m{mode} M={B * Hd * Wd} N={p.n_g} K={R * S * p.ks_g} G={G} k{R}s{stride}'
     lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g))
   lib.tfpp_conv_gemm(ctypes.byref(p), dt(src), stream())
+  if stats_acc is not None:
+    return nblk
   if stats_ws is not None:
     lib.tfpp_bn_reduce_final(ptr(scratch), ptr(stats_ws), nblk, 2 * Cd, stream())
   return dst
@@ -239,6 +246,39 @@ def bn_scratch(c, device, min_floats=0):
   return buf
 
 
+_STATS_ROWS = {}
+_REDUCE_SCRATCH = {}
+
+
+def stats_rows_buffer(c, device):
+  """64 fp32 accumulation rows [64][2*c] for the BatchNorm statistics fused into the conv epilogue.  Zero when handed out
+  and zero again after bn_finalize_partials(clear=True) consumed it, so no memset launch sits between layers."""
+  key = str(device)
+  buf = _STATS_ROWS.get(key)
+  if buf is None or buf.numel() < 64 * 2 * c:
+    buf = torch.zeros(64 * 2 * max(c, 1512), device=device, dtype=torch.float32)
+    _STATS_ROWS[key] = buf
+  return buf
+
+
+def reduce_scratch(b, c, device):
+  """Stage-1 partials of the two-stage column reductions (mean_hw / se_dgate / colsum)."""
+  need = lib.raw('tfpp_reduce_scratch_floats')(b, c)
+  key = str(device)
+  buf = _REDUCE_SCRATCH.get(key)
+  if buf is None or buf.numel() < need:
+    buf = torch.empty(max(need, lib.raw('tfpp_reduce_scratch_floats')(12, 1512)), device=device, dtype=torch.float32)
+    _REDUCE_SCRATCH[key] = buf
+  return buf
+
+
+def bn_finalize_partials(acc, nrows, gamma, beta, rm, rv, nbt, scale, shift, save_mean, save_invstd, rows, momentum=0.1, eps=1e-5,
+                         clear=True):
+  c = scale.numel()
+  lib.tfpp_bn_finalize_partials(ptr(acc), nrows, int(clear), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nbt), ptr(scale), ptr(shift),
+                                ptr(save_mean), ptr(save_invstd), rows, c, momentum, eps, stream())
+
+
 def bn_stats(x, ws):
   c = x.shape[-1]
   lib.tfpp_bn_stats(ptr(_chk(x)), ptr(bn_scratch(c, x.device)), ptr(ws), x.numel() // c, c, dt(x), stream())
@@ -267,7 +307,7 @@ def bn_bwd(dy, y, x, gamma, save_mean, save_invstd, ws, dgamma, dbeta, relu_mask
   c = x.shape[-1]
   rows = x.numel() // c
   scratch = bn_scratch(c, x.device)
-  lib.tfpp_bn_bwd_reduce(ptr(_chk(dy)), ptr(y), ptr(_chk(x)), ptr(save_mean), ptr(save_invstd), ptr(scratch), ptr(ws), rows, c,
+  lib.tfpp_bn_bwd_reduce(ptr(_chk(dy)), ptr(y), ptr(_chk(x)), ptr(save_mean), ptr(save_invstd), ptr(scratch), None, rows, c,
                          int(relu_mask), dt(x), stream())
   dx = torch.empty_like(x)
   dres = torch.empty_like(x) if want_dres else None
@@ -286,7 +326,7 @@ def bn1d_scalar(x, rm, rv, nbt, training, momentum=0.1, eps=1e-5):
 def mean_hw(x):
   b, h, w, c = x.shape
   out = torch.empty((b, c), device=x.device, dtype=torch.float32)
-  lib.tfpp_mean_hw(ptr(_chk(x)), ptr(out), b, h * w, c, dt(x), stream())
+  lib.tfpp_mean_hw(ptr(_chk(x)), ptr(out), ptr(reduce_scratch(b, c, x.device)), b, h * w, c, dt(x), stream())
   return out
 
 
@@ -302,7 +342,7 @@ def se_gate_fwd(pool, w1, b1, w2, b2):
 def se_dgate(dy, x):
   b, h, w, c = x.shape
   out = torch.empty((b, c), device=x.device, dtype=torch.float32)
-  lib.tfpp_se_dgate(ptr(_chk(dy)), ptr(_chk(x)), ptr(out), b, h * w, c, dt(x), stream())
+  lib.tfpp_se_dgate(ptr(_chk(dy)), ptr(_chk(x)), ptr(out), ptr(reduce_scratch(b, c, x.device)), b, h * w, c, dt(x), stream())
   return out
 
 
@@ -436,7 +476,7 @@ def mul_pixmask(x, m, hw, out=None):
 
 
 def colsum(x, out, rows, c, ld=None):
-  lib.tfpp_colsum(ptr(x), ptr(out), rows, c, ld or c, dt(x), stream())
+  lib.tfpp_colsum(ptr(x), ptr(out), ptr(reduce_scratch(1, c, x.device)), rows, c, ld or c, dt(x), stream())
   return out
 
 

@@ -147,8 +147,12 @@ int tfpp_nchw_to_nhwc_pad(const float* in, void* out, int B, int C, int H, int W
  * bn_fold (eval): scale/shift from the running statistics (then applied in the conv epilogue).
  * affine_act: y = act(x*gate[b,c]*scale[c] + shift[c] + res)   (each of gate/scale/shift/res nullable; gate is the
  *   squeeze-excite scale, [B,C] fp32, rows_per_batch rows per sample).
- * bn_bwd_reduce: g = dy*(y>0 if relu_mask); ws[0:C] = sum g, ws[C:2C] = sum g*xhat (double).
- * bn_bwd_apply: dx = gamma*invstd*(g - ws0/rows - xhat*ws1/rows); dgamma += ws1; dbeta += ws0; dres = g (nullable). */
+ * bn_bwd_reduce: g = dy*(y>0 if relu_mask); stage-1 partials of sum g, sum g*xhat into scratch (ws nullable: if given it
+ *   also receives the two sums in double).
+ * bn_bwd_apply: reads the partials left in scratch by bn_bwd_reduce for the same (rows, C, dtype):
+ *   dx = gamma*invstd*(g - s0/rows - xhat*s1/rows); dgamma += s1; dbeta += s0; dres = g (nullable); ws (nullable) <- s0,s1.
+ * bn_finalize_partials: bn_finalize straight from `nrows` accumulation rows [nrows][2C] (tfpp_conv_params.stats_partial);
+ *   clear != 0 re-zeroes the rows, so a buffer that starts zeroed needs no memset between layers. */
 /* scratch: tfpp_bn_scratch_floats(C) floats shared by the three reduction entry points (stage-1 partials + coefficients) */
 int tfpp_bn_scratch_floats(int C);
 int tfpp_bn_stats(const void* x, float* scratch, double* ws, int64_t rows, int C, int dtype, void* stream);
@@ -157,6 +161,9 @@ int tfpp_bn_reduce_final(const float* partial, double* ws, int nblk, int n2c, vo
 int tfpp_bn_finalize(const double* ws, const float* gamma, const float* beta, float* running_mean, float* running_var,
                      int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean, float* save_invstd, int64_t rows,
                      int C, float momentum, float eps, void* stream);
+int tfpp_bn_finalize_partials(float* partial, int nrows, int clear, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
+                              float* save_invstd, int64_t rows, int C, float momentum, float eps, void* stream);
 int tfpp_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float* scale,
                  float* shift, int C, float eps, void* stream);
 int tfpp_affine_act(const void* x, const float* scale, const float* shift, const void* res, const float* gate, void* y, int64_t rows,
@@ -164,7 +171,7 @@ int tfpp_affine_act(const void* x, const float* scale, const float* shift, const
 int tfpp_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* save_mean, const float* save_invstd, float* scratch,
                        double* ws, int64_t rows, int C, int relu_mask, int dtype, void* stream);
 int tfpp_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
-                      const float* save_invstd, const double* ws, float* scratch, void* dx, void* dres, float* dgamma, float* dbeta,
+                      const float* save_invstd, double* ws, float* scratch, void* dx, void* dres, float* dgamma, float* dbeta,
                       int64_t rows, int C, int relu_mask, int dtype, void* stream);
 /* BatchNorm1d(1, affine=False) on the ego speed (model.py:216,311), fp32 [B]. */
 int tfpp_bn1d_scalar(const float* x, float* y, float* running_mean, float* running_var, int64_t* nbt, int B, int training,
@@ -175,10 +182,13 @@ int tfpp_bn1d_scalar(const float* x, float* y, float* running_mean, float* runni
  * mean_hw: [B,HW,C] -> [B,C] fp32.  se_gate_fwd: hidden [B,RD], gate [B,C].  The gate multiply is fused into
  * tfpp_affine_act.  Backward: se_dgate[b,c] = sum_hw dy*x; se_gate_bwd -> dpool + parameter gradients (atomics);
  * se_bwd_apply: dx = dy*gate[b,c] + dpool[b,c]/HW. */
-int tfpp_mean_hw(const void* x, float* out, int B, int HW, int C, int dtype, void* stream);
+/* scratch (mean_hw, se_dgate, colsum): tfpp_reduce_scratch_floats(B, C) floats of stage-1 partials; the column reductions are
+ * two-stage (plain stores + a small second kernel), deterministic, no atomics or memsets. */
+int tfpp_reduce_scratch_floats(int B, int C);
+int tfpp_mean_hw(const void* x, float* out, float* scratch, int B, int HW, int C, int dtype, void* stream);
 int tfpp_se_gate_fwd(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2, float* hidden,
                      float* gate, int B, int C, int RD, void* stream);
-int tfpp_se_dgate(const void* dy, const void* x, float* dgate, int B, int HW, int C, int dtype, void* stream);
+int tfpp_se_dgate(const void* dy, const void* x, float* dgate, float* scratch, int B, int HW, int C, int dtype, void* stream);
 int tfpp_se_gate_bwd(const float* dgate, const float* gate, const float* hidden, const float* pool, const float* w1,
                      const float* w2, float* dz1_scratch /* [B*RD] */, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
                      int B, int C, int RD, void* stream);
@@ -218,7 +228,8 @@ int tfpp_add_bcast(const void* x, const float* bcast, void* y, int64_t n, int64_
 int tfpp_act_bwd(const void* dy, const void* y, void* dx, int64_t n, int act, int dtype, void* stream);
 int tfpp_axpy(const void* x, void* y, int64_t n, float a, int dtype, void* stream);
 int tfpp_mul_pixmask(const void* x, const float* m, void* y, int64_t n, int64_t ld, int64_t HW, int dtype, void* stream);
-int tfpp_colsum(const void* x, float* out, int64_t rows, int C, int64_t ld, int dtype, void* stream); /* out[c] += sum_rows */
+/* out[c] += sum_rows x[row*ld + c]; scratch: tfpp_reduce_scratch_floats(1, C) floats (NULL -> slower atomic path) */
+int tfpp_colsum(const void* x, float* out, float* scratch, int64_t rows, int C, int64_t ld, int dtype, void* stream);
 int tfpp_sum_f32(const float* x, float* out, int64_t n, void* stream);
 /* token plumbing (torch.cat / slicing / .repeat in transfuser.py:323,329-337 and model.py:318-324,352-355):
  * dst[b*dst_bs + dst_off + i] (+)= src[b*src_bs + src_off + i] for i in [0,n), with dtype conversion. */

@@ -244,6 +244,62 @@ def test_batchnorm_train_and_backward(ops, dtype, C):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(3, 12, 20, 40, 72, 1, 1), (2, 9, 11, 48, 48, 3, 2), (1, 8, 80, 576, 1512, 1, 1)],
+                         ids=['pw72', 'g3x3', 'wide1512'])
+def test_conv_fused_batchnorm_statistics(ops, dtype, case):
+  """conv -> BN(train) with the statistics accumulated in the conv epilogue and finalised straight from the
+  accumulation rows (which the finalise kernel hands back zeroed)."""
+  B, H, W, Cin, Cout, k, G = case
+  pad = k // 2
+  x = rnd(B, Cin, H, W, dtype=dtype, seed=61)
+  w = (rnd(Cout, Cin // G, k, k, seed=62) * (1.0 / math.sqrt(Cin // G * k * k))).to(dtype).float()
+  gamma, beta = rnd(Cout, seed=63, lo=0.5, hi=1.5), rnd(Cout, seed=64)
+  rm, rv = rnd(Cout, seed=65), rnd(Cout, seed=66, lo=0.5, hi=1.5)
+  rm_ref, rv_ref = rm.clone(), rv.clone()
+  conv = F.conv2d(x, w, None, 1, pad, 1, G)
+  if dtype == torch.bfloat16:
+    conv = conv.to(dtype).float()  # the HIP path stores the raw conv output in bf16 before normalising it
+  want = F.relu(F.batch_norm(conv, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
+  xd = dev(nhwc(x), dtype)
+  wp = ops.pack_conv_weight(dev(w), dtype, G=G)
+  raw = torch.empty((B, H, W, Cout), device=DEV, dtype=dtype)
+  acc = ops.stats_rows_buffer(Cout, DEV)
+  assert float(acc.abs().max()) == 0.0
+  nrows = ops.conv_gemm(xd, wp, raw, B=B, Hs=H, Ws=W, Cs=Cin, Hd=H, Wd=W, Cd=Cout, R=k, S=k, stride=1, pad=pad, G=G, stats_acc=acc)
+  assert 1 <= nrows <= 64
+  scale, shift, sm, si = (torch.empty(Cout, device=DEV) for _ in range(4))
+  rmd, rvd, nbt = dev(rm), dev(rv), torch.zeros((), device=DEV, dtype=torch.long)
+  ops.bn_finalize_partials(acc, nrows, dev(gamma), dev(beta), rmd, rvd, nbt, scale, shift, sm, si, B * H * W)
+  y = ops.affine_act(raw, scale=scale, shift=shift, act=ops.ACT_RELU)
+  # the statistics come from the fp32 accumulators, the normalised tensor from the rounded output: allow 2 roundings
+  check('convbn.fwd', nchw(y.float().cpu()), want, dtype, scale=3.0)
+  check('convbn.running_mean', rmd.cpu(), rm_ref, dtype, scale=1.0 if dtype == torch.bfloat16 else 5.0)
+  check('convbn.running_var', rvd.cpu(), rv_ref, dtype, scale=1.0 if dtype == torch.bfloat16 else 5.0)
+  assert int(nbt.item()) == 1
+  assert float(acc.abs().max()) == 0.0, 'accumulation rows must come back zeroed'
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(3, 140, 72), (2, 1030, 32), (1, 77, 1512), (2, 64, 6048)], ids=['c72', 'c32', 'c1512', 'c6048'])
+def test_column_reductions(ops, dtype, shape):
+  """mean_hw / se_dgate / colsum (two-stage, column-fixed layout) over awkward row counts and widths."""
+  B, HW, C = shape
+  x, y = rnd(B, HW, 1, C, dtype=dtype, seed=71), rnd(B, HW, 1, C, dtype=dtype, seed=72)
+  xd, yd = dev(x, dtype), dev(y, dtype)
+  check('colred.mean_hw', ops.mean_hw(xd).cpu(), x.mean((1, 2)), dtype)
+  check('colred.se_dgate', ops.se_dgate(yd, xd).cpu(), (x * y).sum((1, 2)), dtype)
+  out = torch.full((C,), 0.5, device=DEV)
+  ops.colsum(xd, out, B * HW, C)
+  check('colred.colsum', out.cpu(), x.sum((0, 1, 2)) + 0.5, dtype)
+  ld = C + 8  # strided rows (a slice of a wider buffer)
+  wide = torch.zeros(B * HW, ld, device=DEV, dtype=dtype)
+  wide[:, :C] = xd.view(-1, C)
+  out2 = torch.zeros(C, device=DEV)
+  ops.colsum(wide, out2, B * HW, C, ld)
+  check('colred.colsum_ld', out2.cpu(), x.sum((0, 1, 2)), dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_squeeze_excite(ops, dtype):
   B, H, W, C, RD = 3, 10, 14, 72, 18
   x = rnd(B, C, H, W, dtype=dtype, seed=51)
