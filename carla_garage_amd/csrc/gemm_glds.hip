@@ -37,7 +37,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int g = blockIdx.z;
+  int g = blockIdx.z, split = 0;
+  if (p.splitk > 1) { g = blockIdx.z / p.splitk; split = blockIdx.z - g * p.splitk; }  // z = (group, K slice)
   const int mtile = blockIdx.y;
   const int bm0 = mtile * BM, bn0 = blockIdx.x * BN;
   const int M = p.B * p.Hd * p.Wd, K = p.R * p.S * p.ks_g;
@@ -78,11 +79,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
     b_ptr[j] = (n < p.n_g) ? wk + (size_t)n * K : nullptr;
   }
 
-  auto issue = [&](int kt) {  // LDS-DMA of K-tile kt into ring slot kt % NSTAGE
+  // K tiles of this workgroup: all of them, or one slice of a split-K launch
+  int kt_beg = 0, nkt = (K + 31) / 32;
+  if (p.splitk > 1) {
+    const int per = (nkt + p.splitk - 1) / p.splitk;
+    kt_beg = split * per;
+    nkt = (kt_beg + per < nkt ? kt_beg + per : nkt) - kt_beg;
+    if (nkt < 0) nkt = 0;
+  }
+  auto issue = [&](int kt) {  // LDS-DMA of this workgroup's K-tile kt into ring slot kt % NSTAGE
     const unsigned stage = lds_base + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
-      const int k0 = kt * 32 + a_kc[i] * 8;
+      const int k0 = (kt_beg + kt) * 32 + a_kc[i] * 8;
       const T* gp = zero;
       if (k0 < K && a_b[i] >= 0) {
         if (pointwise) gp = a_ptr[i] + k0;
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
     }
 #pragma unroll
     for (int j = 0; j < B_INST; ++j) {
-      const int k0 = kt * 32 + b_kc[j] * 8;
+      const int k0 = (kt_beg + kt) * 32 + b_kc[j] * 8;
       const T* gp = (k0 < K && b_ptr[j]) ? b_ptr[j] + k0 : zero;
       __builtin_amdgcn_global_load_lds((gbl_void_t*)gp, (lds_void_t*)(stage + (unsigned)(A_BYTES + (j * NWAVES + wave) * 1024)), 16, 0, 0);
     }
@@ -131,7 +140,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
     b_off[j] = (unsigned)(A_BYTES + row * 64 + ((kgrp ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3)) * 16));
   }
 
-  const int nkt = (K + 31) / 32;
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nkt) issue(s);
@@ -160,6 +168,24 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) frag_mma(fa[i], fb[j], acc[i][j]);
+  }
+
+  if (p.splitk > 1) {  // raw fp32 slice -> workspace [split][M][G*n_g]; splitk_epilogue_kernel finishes the job
+    const int ntot = p.G * p.n_g;
+    float* __restrict__ wsp = p.splitk_ws + (size_t)split * M * ntot;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = bm0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int n = bn0 + wn * WN + j * 16 + (lane & 15);
+          if (n < p.n_g) wsp[(size_t)m * ntot + g * p.n_g + n] = acc[i][j][r];
+        }
+      }
+    return;
   }
 
   // ---- fused BatchNorm statistics (same contract as the LDS-staged kernel; the ring is free after the last barrier + MMA)
@@ -235,7 +261,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
 
 template <int BM, int BN, int NSTAGE, int WGM, int WGN> static int launch_glds(const tfpp_conv_params& p, hipStream_t st) {
   const long M = (long)p.B * p.Hd * p.Wd;
-  dim3 grid(cdiv(p.n_g, BN), cdiv(M, BM), p.G);
+  dim3 grid(cdiv(p.n_g, BN), cdiv(M, BM), p.G * (p.splitk > 1 ? p.splitk : 1));
   const size_t lds = (size_t)NSTAGE * (BM + BN) * 64;
   static bool attr_set = false;
   if (!attr_set) {

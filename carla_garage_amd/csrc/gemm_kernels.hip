@@ -18,7 +18,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
   const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
   // grid: x = N-tile (fastest), y = M-tile, z = group.  Consecutive workgroups share the same activation rows (A) and
   // workgroup b lands on XCD b % 8, so each XCD's L2 keeps a fixed subset of weight panels (B) resident.
-  const int g = blockIdx.z;
+  int g = blockIdx.z, split = 0;
+  if (p.splitk > 1) { g = blockIdx.z / p.splitk; split = blockIdx.z - g * p.splitk; }  // z = (group, K slice)
   const int mtile = blockIdx.y;
   const int bm0 = mtile * BM, bn0 = blockIdx.x * BN;
   const int M = p.B * p.Hd * p.Wd, K = p.R * p.S * p.ks_g;
@@ -48,7 +49,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
     for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (K + BK - 1) / BK;
-  for (int kt = 0; kt < nkt; ++kt) {
+  int kt_beg = 0, kt_end = nkt;
+  if (p.splitk > 1) {
+    const int per = (nkt + p.splitk - 1) / p.splitk;
+    kt_beg = split * per;
+    kt_end = kt_beg + per < nkt ? kt_beg + per : nkt;
+  }
+  for (int kt = kt_beg; kt < kt_end; ++kt) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int v = tid + i * NT, row = v / KV, kc = v - row * KV, k0 = kt * BK + kc * VEC;
@@ -82,6 +89,24 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
     __syncthreads();
     tile_mma_step<C, T, false, false>(As, Bs, wm, wn, lane, acc);
     __syncthreads();
+  }
+
+  if (p.splitk > 1) {  // raw fp32 slice -> workspace [split][M][G*n_g]; splitk_epilogue_kernel finishes the job
+    const int ntot = p.G * p.n_g;
+    float* __restrict__ wsp = p.splitk_ws + (size_t)split * M * ntot;
+#pragma unroll
+    for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = bm0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < C::FN; ++j) {
+          const int n = bn0 + wn * WN + j * 16 + (lane & 15);
+          if (n < p.n_g) wsp[(size_t)m * ntot + g * p.n_g + n] = acc[i][j][r];
+        }
+      }
+    return;
   }
 
   // optional fused BatchNorm statistics: per-channel sum / sum of squares of this tile's fp32 results, accumulated into
@@ -155,7 +180,7 @@ static int launch_conv(const tfpp_conv_params& p, hipStream_t st) {
   constexpr int BKT = sizeof(T) == 2 ? 64 : 32;
   using C = TileCfg<T, BM, BN, WM, WN, BKT>;
   const long M = (long)p.B * p.Hd * p.Wd;
-  dim3 grid(cdiv(p.n_g, BN), cdiv(M, BM), p.G);
+  dim3 grid(cdiv(p.n_g, BN), cdiv(M, BM), p.G * (p.splitk > 1 ? p.splitk : 1));
   const int K = p.R * p.S * p.ks_g;
   if (BKT == 64 && K <= 32) {  // tiny-K layers (stem): one 32-deep stage is enough
     hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WM, WN, 32>), grid, dim3(C::NT), 0, st, p);
@@ -176,6 +201,58 @@ static int conv_variant(const tfpp_conv_params& p) {
   if (N <= 64) return 1;
   const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128) * p.G;
   return tiles128 < 1024 ? 2 : 3;  // latency-bound regime: keep >= 4 workgroups per CU in flight
+}
+
+// Second stage of split-K: dst = epilogue(sum_s ws[s][m][ch]); 4 channels per thread.
+template <typename T> __global__ void splitk_epilogue_kernel(tfpp_conv_params p) {
+  const int M = p.B * p.Hd * p.Wd, ntot = p.G * p.n_g, nq = ntot >> 2;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)M * nq) return;
+  const int m = (int)(i / nq), ch0 = (int)(i - (long)m * nq) * 4;
+  const float* __restrict__ wsp = p.splitk_ws + (size_t)m * ntot + ch0;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sidx = 0; sidx < p.splitk; ++sidx) {
+    const float4 v = *reinterpret_cast<const float4*>(wsp + (size_t)sidx * M * ntot);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  const float acc[4] = {a.x, a.y, a.z, a.w};
+  const int hw = p.Hd * p.Wd;
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ch = ch0 + e;
+    float v = acc[e] * p.alpha;
+    if (p.scale) v *= p.scale[ch];
+    if (p.shift) v += p.shift[ch];
+    if (res) v += ElemTraits<T>::to_f(res[(size_t)m * p.res_ld + ch]);
+    v = apply_act(v, p.act);
+    size_t o;
+    if (p.dst_nchw) { const int b = m / hw, pix = m - b * hw; o = ((size_t)b * p.Cd + ch) * hw + pix; }
+    else o = (size_t)m * p.dst_ld + ch;
+    if (p.dst_f32) reinterpret_cast<float*>(p.dst)[o] = v;
+    else reinterpret_cast<T*>(p.dst)[o] = ElemTraits<T>::from_f(v);
+  }
+}
+
+template <typename T> static int launch_splitk_epilogue(const tfpp_conv_params& p, hipStream_t st) {
+  const long n = (long)p.B * p.Hd * p.Wd * ((p.G * p.n_g) >> 2);
+  hipLaunchKernelGGL(splitk_epilogue_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// K slices for a problem that yields `tiles` output tiles with K stages of depth bk: only when the grid would leave most
+// of the chip idle (<= 192 workgroups) and every slice keeps >= 2 K stages.
+static int conv_splits(const tfpp_conv_params& p, long tiles, int bk) {
+  if (!p.splitk_ws || p.stats_partial || tiles > 192) return 1;
+  const int K = p.R * p.S * p.ks_g, ntot = p.G * p.n_g;
+  if (ntot % 4) return 1;
+  long sp = (512 + tiles - 1) / tiles;
+  if (sp > K / (2 * bk)) sp = K / (2 * bk);
+  if (sp > 32) sp = 32;
+  const long per_slice = (long)p.B * p.Hd * p.Wd * ntot;
+  while (sp > 1 && sp * per_slice > p.splitk_ws_floats) --sp;
+  return sp < 2 ? 1 : (int)sp;
 }
 
 // TFPP_CONV_IMPL=direct selects the barrier-free direct-to-register kernel (gemm_direct.hip) for A/B measurements; the
@@ -211,6 +288,23 @@ extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype) {
   return conv_variant(*p);
 }
 
+static int conv_splits_for(const tfpp_conv_params& p, int dtype) {
+  const long M = (long)p.B * p.Hd * p.Wd;
+  if (use_glds_impl() && conv_glds_supported(p, dtype)) {
+    const int bm = conv_glds_variant(p) == 200 ? 128 : 64;
+    return conv_splits(p, (long)cdiv(M, bm) * cdiv(p.n_g, 128) * p.G, 64);
+  }
+  static const int bm[4] = {128, 128, 64, 128}, bn[4] = {32, 64, 64, 128};
+  const int v = conv_variant(p);
+  return conv_splits(p, (long)cdiv(M, bm[v]) * cdiv(p.n_g, bn[v]) * p.G, dtype == TFPP_BF16 ? 64 : 32);
+}
+
+extern "C" int tfpp_conv_gemm_splits(const tfpp_conv_params* p, int dtype) {
+  if (!p) return TFPP_EINVAL;
+  if (use_direct_impl() && !p->stats_partial) return 1;
+  return conv_splits_for(*p, dtype);
+}
+
 template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStream_t st) {
   constexpr int VEC = ElemTraits<T>::VEC;
   if (p.ks_g % VEC != 0 || p.src_ld % VEC != 0 || p.G < 1 || p.B < 1) return TFPP_EINVAL;
@@ -218,13 +312,20 @@ template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStr
   const long M = (long)p.B * p.Hd * p.Wd;
   if (M >= (1l << 31) || M * (long)p.dst_ld >= (1l << 40)) return TFPP_EINVAL;
   if (use_direct_impl() && !p.stats_partial) return conv_gemm_direct(p, ElemTraits<T>::DT, st);
-  if (use_glds_impl() && conv_glds_supported(p, ElemTraits<T>::DT)) return conv_gemm_glds(p, st);
-  switch (conv_variant(p)) {
-    case 0: return launch_conv<T, 128, 32, 32, 32>(p, st);
-    case 1: return launch_conv<T, 128, 64, 64, 32>(p, st);
-    case 2: return launch_conv<T, 64, 64, 32, 32>(p, st);
-    default: return launch_conv<T, 128, 128, 64, 64>(p, st);
+  tfpp_conv_params q = p;
+  q.splitk = conv_splits_for(p, ElemTraits<T>::DT);
+  int rc;
+  if (use_glds_impl() && conv_glds_supported(p, ElemTraits<T>::DT)) rc = conv_gemm_glds(q, st);
+  else {
+    switch (conv_variant(p)) {
+      case 0: rc = launch_conv<T, 128, 32, 32, 32>(q, st); break;
+      case 1: rc = launch_conv<T, 128, 64, 64, 32>(q, st); break;
+      case 2: rc = launch_conv<T, 64, 64, 32, 32>(q, st); break;
+      default: rc = launch_conv<T, 128, 128, 64, 64>(q, st); break;
+    }
   }
+  if (rc != 0 || q.splitk <= 1) return rc;
+  return launch_splitk_epilogue<T>(q, st);
 }
 
 extern "C" int tfpp_conv_gemm(const tfpp_conv_params* p, int dtype, void* stream) {

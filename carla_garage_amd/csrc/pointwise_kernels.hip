@@ -863,15 +863,36 @@ __global__ void se_dz1_kernel(const float* __restrict__ dgate, const float* __re
   if (lane == 0) dz1[w] = hidden[w] > 0.f ? s : 0.f;
 }
 
-// one thread per output element, single writer (no atomics): [0,C*RD) dw2 (+db2), [C*RD,2*C*RD) dw1 (+db1), then dpool
+// Single writer per output (no atomics).  Workgroups [0, nblk_dw): one thread per dw2[c][j] (+db2) / dw1[j][c] (+db1) element.
+// Workgroups after that: dpool[b][c] = sum_j dz1[b,j] w1[j,c], 16 channels x 16 j-slots per workgroup (the RD-long
+// reduction is the long pole of this kernel when a single thread walks it).
 __global__ void se_param_grads_kernel(const float* __restrict__ dgate, const float* __restrict__ gate, const float* __restrict__ hidden,
                                       const float* __restrict__ pool, const float* __restrict__ w1, const float* __restrict__ dz1,
                                       float* __restrict__ dpool, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
-                                      float* __restrict__ db2, int B, int C, int RD) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long n1 = (long)C * RD;
+                                      float* __restrict__ db2, int B, int C, int RD, int nblk_dw) {
+  if ((int)blockIdx.x >= nblk_dw) {
+    const int ctiles = (C + 15) / 16;
+    const int t = blockIdx.x - nblk_dw, b = t / ctiles, c = (t - b * ctiles) * 16 + (threadIdx.x & 15), js = threadIdx.x >> 4;
+    float s = 0.f;
+    if (c < C) {
+#pragma unroll 4
+      for (int j = js; j < RD; j += 16) s += dz1[b * RD + j] * w1[(size_t)j * C + c];
+    }
+    __shared__ float sm[16][17];
+    sm[js][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (js == 0 && c < C) {
+      float tot = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot += sm[k][threadIdx.x];
+      dpool[(size_t)b * C + c] = tot;
+    }
+    return;
+  }
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned n1 = (unsigned)C * RD;
   if (i < n1) {  // dw2[c][j]
-    const int c = (int)(i / RD), j = (int)(i - (long)c * RD);
+    const unsigned c = i / RD, j = i - c * RD;
     float s = 0.f, sb = 0.f;
     for (int b = 0; b < B; ++b) {
       const float g = gate[(size_t)b * C + c];
@@ -882,8 +903,8 @@ __global__ void se_param_grads_kernel(const float* __restrict__ dgate, const flo
     dw2[i] += s;
     if (j == 0) db2[c] += sb;
   } else if (i < 2 * n1) {  // dw1[j][c]
-    const long k = i - n1;
-    const int j = (int)(k / C), c = (int)(k - (long)j * C);
+    const unsigned k = i - n1;
+    const unsigned j = k / C, c = k - j * C;
     float s = 0.f, sb = 0.f;
     for (int b = 0; b < B; ++b) {
       const float d = dz1[(size_t)b * RD + j];
@@ -892,12 +913,6 @@ __global__ void se_param_grads_kernel(const float* __restrict__ dgate, const flo
     }
     dw1[k] += s;
     if (c == 0) db1[j] += sb;
-  } else if (i < 2 * n1 + (long)B * C) {  // dpool[b][c]
-    const long k = i - 2 * n1;
-    const int b = (int)(k / C), c = (int)(k - (long)b * C);
-    float s = 0.f;
-    for (int j = 0; j < RD; ++j) s += dz1[(size_t)b * RD + j] * w1[(size_t)j * C + c];
-    dpool[k] = s;
   }
 }
 
@@ -905,11 +920,12 @@ extern "C" int tfpp_se_gate_bwd(const float* dgate, const float* gate, const flo
                                 const float* w2, float* dz1_scratch, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int B,
                                 int C, int RD, void* stream) {
   if (!dgate || !gate || !hidden || !pool || !dpool || !dz1_scratch) return TFPP_EINVAL;
+  if (2l * C * RD >= (1l << 31)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(se_dz1_kernel, dim3((B * RD + 3) / 4), dim3(256), 0, st, dgate, gate, hidden, w2, dz1_scratch, B, C, RD);
-  const long n = 2l * C * RD + (long)B * C;
-  hipLaunchKernelGGL(se_param_grads_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dgate, gate, hidden, pool, w1, dz1_scratch,
-                     dpool, dw1, db1, dw2, db2, B, C, RD);
+  const int nblk_dw = (int)((2l * C * RD + 255) / 256);
+  hipLaunchKernelGGL(se_param_grads_kernel, dim3((unsigned)(nblk_dw + B * ((C + 15) / 16))), dim3(256), 0, st, dgate, gate, hidden, pool, w1,
+                     dz1_scratch, dpool, dw1, db1, dw2, db2, B, C, RD, nblk_dw);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

@@ -48,9 +48,25 @@ def _chk(t):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM / conv
+_SPLITK_WS = {}
+SPLITK_WS_FLOATS = 16 << 20
+
+
+def splitk_workspace(device):
+  """fp32 slices of split-K launches (few output tiles x long reduction); one buffer per device, kernels on a stream run
+  in order.  TFPP_SPLITK=0 disables split-K."""
+  key = str(device)
+  buf = _SPLITK_WS.get(key)
+  if buf is None:
+    n = SPLITK_WS_FLOATS if _os.environ.get('TFPP_SPLITK', '1') != '0' else 4
+    buf = torch.empty(n, device=device, dtype=torch.float32)
+    _SPLITK_WS[key] = buf
+  return buf
+
+
 def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=0, G=1, ks_g=None, n_g=None, mode=0,
               act=ACT_NONE, scale=None, shift=None, res=None, alpha=1.0, dst_nchw=False, src_ld=None, dst_ld=None,
-              res_ld=None, stats_ws=None, stats_acc=None):
+              res_ld=None, stats_ws=None, stats_acc=None, plan_only=False):
   """stats_ws (double[2*Cd]): also produce per-channel sum / sum of squares of the result (fused BatchNorm statistics).
   stats_acc (zeroed fp32 accumulation rows from stats_rows_buffer()): leave the statistics in the rows for
   bn_finalize_partials and return the number of rows used."""
@@ -66,6 +82,10 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
   p.dst_ld = dst_ld if dst_ld is not None else Cd
   p.res_ld = res_ld if res_ld is not None else p.dst_ld
   p.dst_f32 = int(dst.dtype == torch.float32 and src.dtype != torch.float32)
+  ws = splitk_workspace(src.device)
+  p.splitk_ws, p.splitk_ws_floats, p.splitk = ptr(ws), ws.numel(), 0
+  if plan_only:  # (kernel variant, K slices) the dispatcher would use -- tests / bench bookkeeping
+    return lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p), dt(src)), lib.raw('tfpp_conv_gemm_splits')(ctypes.byref(p), dt(src))
   scratch = None
   if stats_acc is not None:
     nblk = min(64, lib.raw('tfpp_conv_gemm_mtiles')(ctypes.byref(p)))

@@ -63,7 +63,14 @@ typedef struct {
   int dst_f32;          /* 1: dst is float regardless of dtype */
   float* stats_partial; /* nullable: fused BatchNorm statistics, [stats_rows][2*Cd] fp32 partial sums / sums of squares, zeroed by the caller */
   int stats_rows;       /* M-tile t accumulates into row t % stats_rows */
+  float* splitk_ws;     /* nullable: fp32 workspace for split-K (few output tiles x long reduction: the fp32 planning head,
+                           K = 9*1512 FPN convs); the dispatcher splits K over up to splitk_ws_floats / (M*Cd) workgroups per
+                           tile and a second kernel sums the slices and applies the epilogue */
+  int64_t splitk_ws_floats;
+  int splitk;           /* must be 0 (set by the dispatcher on its own copy) */
 } tfpp_conv_params;
+/* number of K slices the dispatcher would use for p (1 = no split) */
+int tfpp_conv_gemm_splits(const tfpp_conv_params* p, int dtype);
 int tfpp_conv_gemm(const tfpp_conv_params* p, int dtype, void* stream);
 /* kernel variant the dispatcher picks for p -- used by the bench's per-kernel roofline.  100 + FM*10 + FN: barrier-free
  * direct-to-register kernel with wave tile (16 FM) x (16 FN); 0..3: LDS-staged 128x32 / 128x64 / 64x64 / 128x128

@@ -76,6 +76,8 @@ CONV_CASES = [
     ('dense3x3', 2, 12, 16, 64, 32, 3, 1, 1),
     ('big_k', 1, 8, 80, 1512, 1512, 1, 1, 1),
     ('wide_n', 3, 10, 10, 64, 256, 1, 1, 1),
+    ('splitk_linear', 132, 1, 1, 2048, 256, 1, 1, 1),  # fp32 planning head FFN: 12 output tiles, K = 2048
+    ('splitk_3x3', 1, 16, 16, 256, 128, 3, 1, 1),      # few tiles, K = 2304 (LDS-DMA kernel in bf16)
 ]
 
 
@@ -102,6 +104,10 @@ def test_conv_fwd_dgrad_wgrad(ops, case, dtype):
   ops.conv_gemm(xd, wp, y, B=B, Hs=H, Ws=W, Cs=Cin, Hd=Ho, Wd=Wo, Cd=Cout, R=k, S=k, stride=stride, pad=pad, G=G,
                 act=ops.ACT_RELU, scale=dev(scale), shift=dev(shift), res=dev(nhwc(res), dtype))
   check(name + '.fwd', nchw(y.float().cpu()), want, dtype)
+  if name.startswith('splitk'):
+    _, splits = ops.conv_gemm(xd, wp, y, B=B, Hs=H, Ws=W, Cs=Cin, Hd=Ho, Wd=Wo, Cd=Cout, R=k, S=k, stride=stride, pad=pad, G=G,
+                              plan_only=True)
+    assert splits > 1, 'expected the split-K path for this shape'
 
   # gradients of the plain convolution
   dy = rnd(B, Cout, Ho, Wo, dtype=dtype, seed=6)
