@@ -35,7 +35,7 @@ class WgradParams(ctypes.Structure):
   _fields_ = [('dy', vp), ('x', vp), ('dw', vp), ('row_map', vp), ('col_map', vp), ('B', i32), ('Hs', i32), ('Ws', i32),
               ('Cs', i32), ('Hd', i32), ('Wd', i32), ('Cd', i32), ('R', i32), ('S', i32), ('stride', i32), ('pad', i32),
               ('G', i32), ('ks_g', i32), ('n_g', i32), ('c_real', i32), ('splits', i32), ('x_ld', i64), ('dy_ld', i64),
-              ('dw_ld', i64)]
+              ('dw_ld', i64), ('ws', vp), ('ws_floats', i64)]
 
 
 class BgemmParams(ctypes.Structure):

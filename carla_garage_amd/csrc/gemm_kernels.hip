@@ -340,7 +340,7 @@ extern "C" int tfpp_conv_gemm(const tfpp_conv_params* p, int dtype, void* stream
 // weight gradient: dW[n][(c,r,s)] += sum_pixels dY[pix][n] * Xgather[pix][(r,s,c)]   (reduction over pixels)
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WM, int WN, int BKT>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_kernel(tfpp_wgrad_params p) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_kernel(tfpp_wgrad_params p, int dbg_skip_epilogue) {
   using C = TileCfg<T, BM, BN, WM, WN, BKT>;
   constexpr int VEC = C::VEC, NT = C::NT, BK = C::BK;
   __shared__ __attribute__((aligned(16))) T As[C::A_ELEMS_KM];
@@ -402,6 +402,31 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_
   }
 
   const int RS = p.R * p.S;
+  if (dbg_skip_epilogue) {  // TFPP_WGRAD_EPI=0: timing experiment only (keeps the MFMA chain alive, stores nothing useful)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::FN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 12345.678f) p.dw[0] = t;
+    return;
+  }
+  if (p.ws && p.splits > 1) {  // slice -> workspace [split][G*n_g][KK]; wgrad_reduce_kernel sums the slices into dw
+    float* __restrict__ wsp = p.ws + ((size_t)split * p.G * p.n_g + (size_t)g * p.n_g) * KK;
+#pragma unroll
+    for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = bm0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+        if (n >= p.n_g) continue;
+#pragma unroll
+        for (int j = 0; j < C::FN; ++j) {
+          const int kk = bn0 + wn * WN + j * 16 + (lane & 15);
+          if (kk < KK) wsp[(size_t)n * KK + kk] = acc[i][j][r];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < C::FM; ++i) {
 #pragma unroll
@@ -424,10 +449,49 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_
           if (c >= p.c_real) continue;
           col = (long)c * RS + rs;
         }
-        atomicAdd(p.dw + (size_t)row * p.dw_ld + col, acc[i][j][r]);
+        float* o = p.dw + (size_t)row * p.dw_ld + col;
+        if (p.splits > 1) atomicAdd(o, acc[i][j][r]);
+        else *o += acc[i][j][r];  // single writer
       }
     }
   }
+}
+
+// dw[row][col] += sum_s ws[s][row][kk]  (second stage of the pixel-split weight gradient).  A workgroup is SLOTS slice
+// slots x (256 / SLOTS) consecutive (row, kk) elements: many slices of a small gradient (stage-1 layers: 384 slices of
+// 72 x 72) are summed by 16 slots in parallel, few slices of a large one by 4.
+template <int SLOTS> __global__ void wgrad_reduce_kernel(tfpp_wgrad_params p) {
+  constexpr int EL = 256 / SLOTS;
+  const int KK = p.R * p.S * p.ks_g, rows = p.G * p.n_g;
+  const int el = threadIdx.x % EL, slot = threadIdx.x / EL;
+  const long i = (long)blockIdx.x * EL + el;
+  const size_t slice = (size_t)rows * KK;
+  float s = 0.f;
+  if (i < (long)slice) {
+    const float* __restrict__ wsp = p.ws + i;
+#pragma unroll 4
+    for (int k = slot; k < p.splits; k += SLOTS) s += wsp[(size_t)k * slice];
+  }
+  __shared__ float sm[SLOTS][EL + 1];
+  sm[slot][el] = s;
+  __syncthreads();
+  if (slot != 0 || i >= (long)slice) return;
+#pragma unroll
+  for (int k = 1; k < SLOTS; ++k) s += sm[k][el];
+  const int r = (int)(i / KK), kk = (int)(i - (long)r * KK);
+  int row = r;
+  if (p.row_map) row = p.row_map[r];
+  if (row < 0) return;
+  long col;
+  if (p.col_map) {
+    col = p.col_map[kk];
+    if (col < 0) return;
+  } else {
+    const int rs = kk / p.ks_g, c = kk - rs * p.ks_g;
+    if (c >= p.c_real) return;
+    col = (long)c * (p.R * p.S) + rs;
+  }
+  p.dw[(size_t)row * p.dw_ld + col] += s;
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -436,7 +500,8 @@ static int launch_wgrad(const tfpp_wgrad_params& p, hipStream_t st) {
   using C = TileCfg<T, BM, BN, WM, WN, BKT>;
   const int KK = p.R * p.S * p.ks_g;
   dim3 grid(p.G * p.splits, cdiv(p.n_g, BM), cdiv(KK, BN));
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, BM, BN, WM, WN, BKT>), grid, dim3(C::NT), 0, st, p);
+  static const int dbg_skip = [] { const char* e = std::getenv("TFPP_WGRAD_EPI"); return (e && e[0] == '0') ? 1 : 0; }();
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, BM, BN, WM, WN, BKT>), grid, dim3(C::NT), 0, st, p, dbg_skip);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -458,8 +523,18 @@ template <typename T> static int dispatch_wgrad(tfpp_wgrad_params p, hipStream_t
     if (p.splits >= 8) p.splits = p.splits / 8 * 8;  // whole XCD rounds
     if (p.splits < 1) p.splits = 1;
   }
-  if (small) return launch_wgrad<T, 32, 32, 16, 16>(p, st);
-  return launch_wgrad<T, 64, 64, 32, 32>(p, st);
+  const long slice = (long)p.G * p.n_g * KK;
+  if (p.ws && p.splits > 1 && (long)p.splits * slice > p.ws_floats) {  // shrink to what the workspace holds
+    const long fit = p.ws_floats / slice;
+    if (fit >= 2) p.splits = (int)fit;
+    else p.ws = nullptr;  // atomics
+  }
+  const int rc = small ? launch_wgrad<T, 32, 32, 16, 16>(p, st) : launch_wgrad<T, 64, 64, 32, 32>(p, st);
+  if (rc != 0 || !p.ws || p.splits <= 1) return rc;
+  if (p.splits >= 32) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((slice + 15) / 16)), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((slice + 63) / 64)), dim3(256), 0, st, p);
+  TFPP_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stream) {

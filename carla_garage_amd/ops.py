@@ -130,6 +130,8 @@ def conv_wgrad(dy, x, dw, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=
   p.dy_ld = dy_ld if dy_ld is not None else Cd
   p.dw_ld = dw_ld if dw_ld is not None else p.c_real * R * S
   assert dw.dtype == torch.float32
+  ws = splitk_workspace(dy.device)
+  p.ws, p.ws_floats = ptr(ws), ws.numel()
   if lib.profiler is not None:
     fam = f'conv_wgrad<{"f32" if dy.dtype == torch.float32 else "bf16"}>'
     if PROFILE_SHAPES:

@@ -80,7 +80,10 @@ int tfpp_conv_gemm_mtiles(const tfpp_conv_params* p);
 
 /* Weight gradient of the same convolution (autograd of F.conv2d / F.linear, train.py:898):
  *   dw[(g*n_g+n), c, r, s] += sum_{b,hd,wd} dy[b,hd,wd,g*n_g+n] * x[b,hd*stride-pad+r,wd*stride-pad+s,g*ks_g+c]
- * accumulated with fp32 atomics into `dw` (reference layout OIHW, [Cout][c_real][R][S]); channels c >= c_real
+ * accumulated into `dw` (reference layout OIHW, [Cout][c_real][R][S]).  The pixel reduction is split over `splits`
+ * workgroups per output tile; with a workspace the slices are stored as fp32 tiles and summed by a second kernel
+ * (deterministic; device-scope fp32 atomics measured 2-7x slower on gfx950), without one they are added with atomics.
+ * Channels c >= c_real
  * (zero padding of the stem input) are dropped; row_map (nullable) maps packed output rows to parameter rows
  * (-1 = padding row) for the head-padded fused QKV weight. */
 typedef struct {
@@ -93,6 +96,8 @@ typedef struct {
   int splits;           /* <=0: chosen by the library */
   int64_t x_ld, dy_ld;
   int64_t dw_ld;        /* elements per output row of dw (c_real*R*S unless rows are wider) */
+  float* ws;            /* nullable: workspace for the pixel-split slices, [splits][G*n_g][R*S*ks_g] fp32 */
+  int64_t ws_floats;
 } tfpp_wgrad_params;
 int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stream);
 
