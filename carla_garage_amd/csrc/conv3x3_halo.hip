@@ -1,0 +1,197 @@
+// 3x3 / stride 1 / pad 1 convolution (forward and data gradient) with the input tile staged ONCE in LDS, bf16.
+//
+// The implicit-GEMM kernels gather the A operand per K-tile, so a 3x3 layer pulls every input pixel through L2 -> CU nine
+// times; on the narrow 3x3 layers of this model (full-resolution perspective decoders: 3.1 M pixels x 32 channels;
+// RegNet grouped convs: 24 channels per group) that L2 traffic, not MFMA, is what bounds them.  Here a workgroup
+// owns an 8 x 32 pixel output tile of one group: it loads the (8+2) x (32+2) x Cin_g halo once (contiguous image
+// [halo pixel][Cin_g]) and the group's weights [n][K] once, and then every tap is just an LDS address offset:
+//   MFMA K index kk = tap * Cin_g + c  ->  lane (pixel p = l & 15, k-group g = l >> 4) reads the 16-byte chunk
+//   halo[(row + 1 + dr(tap)) * 34 + col + 1 + dc(tap)][c0 .. c0+7],   tap = (32 j + 8 g) / Cin_g,  c0 = (32 j + 8 g) % Cin_g.
+// With Cin_g = 32 the 64 lanes of a fragment read 1 KB of contiguous LDS (conflict-free); weight rows are skewed by 16 B.
+// One barrier per workgroup (after staging); 4 waves x (2 rows x 32 pixels) x FN 16-channel fragments.
+// Data gradient (mode 1) at stride 1 is the same gather with the tap offsets negated (the caller passes the transposed pack).
+#include "gemm_core.cuh"
+#include "gemm_internal.h"
+#include <cstdlib>
+
+namespace {
+constexpr int TH = 8, TW = 32, HH = TH + 2, HWID = TW + 2;
+
+template <int FN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, int tiles_w, int tiles_h, int ksteps) {
+  typedef bf16_t T;
+  constexpr int FM = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cin = p.ks_g, cv = cin >> 3, K = 9 * cin;
+  const int g = blockIdx.y;
+  int t = blockIdx.x;
+  const int tw = t % tiles_w; t /= tiles_w;
+  const int th = t % tiles_h;
+  const int b = t / tiles_h;
+  const int h0 = th * TH, w0 = tw * TW;
+  const int H = p.Hd, W = p.Wd;
+  const int kpitch = ksteps * 32 + 8;  // weight row pitch in elements (16-byte skew: conflict-free fragment reads)
+  T* halo = reinterpret_cast<T*>(smem);
+  T* wl = halo + HH * HWID * cin;
+
+  // ---- stage the halo tile (zero outside the image) and the group's weights (zero rows / K tail)
+  const T* __restrict__ src = reinterpret_cast<const T*>(p.src) + g * cin;
+  for (int q = tid; q < HH * HWID * cv; q += 256) {
+    const int pix = q / cv, c = q - pix * cv;
+    const int hr = pix / HWID, hc = pix - hr * HWID;
+    const int h = h0 + hr - 1, w = w0 + hc - 1;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (h >= 0 && h < H && w >= 0 && w < W) v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * H + h) * W + w) * p.src_ld + c * 8);
+    *reinterpret_cast<uint4*>(halo + (size_t)q * 8) = v;
+  }
+  const T* __restrict__ wk = reinterpret_cast<const T*>(p.w) + (size_t)g * p.n_g * K;
+  const int kc_row = kpitch >> 3;  // 16-byte chunks per LDS weight row
+  for (int q = tid; q < FN * 16 * kc_row; q += 256) {
+    const int n = q / kc_row, kc = q - n * kc_row;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (n < p.n_g && kc * 8 < K) v = *reinterpret_cast<const uint4*>(wk + (size_t)n * K + kc * 8);
+    *reinterpret_cast<uint4*>(wl + (size_t)n * kpitch + kc * 8) = v;
+  }
+  __syncthreads();
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // this wave: tile rows 2*wave, 2*wave+1; fragment i covers row 2*wave + (i >> 1), columns (i & 1) * 16 + (lane & 15)
+  const int p16 = lane & 15, kg = lane >> 4;
+  int a_pix[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) a_pix[i] = (2 * wave + (i >> 1) + 1) * HWID + (i & 1) * 16 + p16 + 1;
+  const int sgn = p.mode == 0 ? 1 : -1;
+  for (int j = 0; j < ksteps; ++j) {
+    const int kk0 = j * 32 + kg * 8;
+    const int tap = kk0 / cin, c0 = kk0 - tap * cin;
+    const int r = tap / 3, s = tap - r * 3;
+    const int off = sgn * ((r - 1) * HWID + (s - 1));
+    Frag<T> fa[FM], fb[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      fa[i].v = make_uint4(0, 0, 0, 0);
+      if (tap < 9) fa[i].v = *reinterpret_cast<const uint4*>(halo + (size_t)(a_pix[i] + off) * cin + c0);
+    }
+#pragma unroll
+    for (int n = 0; n < FN; ++n) fb[n].v = *reinterpret_cast<const uint4*>(wl + (size_t)(n * 16 + p16) * kpitch + kk0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int n = 0; n < FN; ++n) frag_mma(fa[i], fb[n], acc[i][n]);
+  }
+
+  // ---- fused BatchNorm statistics (same contract as conv_gemm_kernel: rows pre-zeroed, fp32 atomics per workgroup)
+  if (p.stats_partial) {
+    __syncthreads();  // staging buffers are dead
+    float* st = reinterpret_cast<float*>(smem);  // [2][4 waves][FN][16]
+#pragma unroll
+    for (int n = 0; n < FN; ++n) {
+      float sum = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int h = h0 + 2 * wave + (i >> 1), w = w0 + (i & 1) * 16 + kg * 4 + r;
+          if (h < H && w < W) { const float v = acc[i][n][r] * p.alpha; sum += v; sq += v * v; }
+        }
+      sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+      sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
+      if (lane < 16) { st[((0 * 4 + wave) * FN + n) * 16 + lane] = sum; st[((1 * 4 + wave) * FN + n) * 16 + lane] = sq; }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+      const int ctot = p.G * p.n_g;
+#pragma unroll
+      for (int n = 0; n < FN; ++n) {
+        const int ch = n * 16 + lane;
+        if (ch < p.n_g) {
+          float sum = 0.f, sq = 0.f;
+#pragma unroll
+          for (int w2 = 0; w2 < 4; ++w2) { sum += st[((0 * 4 + w2) * FN + n) * 16 + lane]; sq += st[((1 * 4 + w2) * FN + n) * 16 + lane]; }
+          float* row = p.stats_partial + (size_t)(blockIdx.x % p.stats_rows) * 2 * ctot;
+          atomicAdd(row + g * p.n_g + ch, sum);
+          atomicAdd(row + ctot + g * p.n_g + ch, sq);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: C fragment row (kg * 4 + r) is the pixel, column p16 the channel
+  const int hw = H * W;
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int h = h0 + 2 * wave + (i >> 1);
+    if (h >= H) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = w0 + (i & 1) * 16 + kg * 4 + r;
+      if (w >= W) continue;
+      const size_t m = (size_t)(b * H + h) * W + w;
+#pragma unroll
+      for (int n = 0; n < FN; ++n) {
+        const int nn = n * 16 + p16;
+        if (nn >= p.n_g) continue;
+        const int ch = g * p.n_g + nn;
+        float v = acc[i][n][r] * p.alpha;
+        if (p.scale) v *= p.scale[ch];
+        if (p.shift) v += p.shift[ch];
+        if (res) v += bf2f(res[m * p.res_ld + ch]);
+        v = apply_act(v, p.act);
+        size_t o;
+        if (p.dst_nchw) o = ((size_t)b * p.Cd + ch) * hw + (size_t)h * W + w;
+        else o = m * p.dst_ld + ch;
+        if (p.dst_f32) reinterpret_cast<float*>(p.dst)[o] = v;
+        else reinterpret_cast<T*>(p.dst)[o] = f2bf(v);
+      }
+    }
+  }
+}
+
+size_t halo_lds_bytes(const tfpp_conv_params& p, int fn) {
+  const int ksteps = (9 * p.ks_g + 31) / 32;
+  return (size_t)HH * HWID * p.ks_g * 2 + (size_t)fn * 16 * (ksteps * 32 + 8) * 2;
+}
+
+template <int FN> int launch_halo(const tfpp_conv_params& p, hipStream_t st) {
+  const int tiles_w = cdiv(p.Wd, TW), tiles_h = cdiv(p.Hd, TH), ksteps = (9 * p.ks_g + 31) / 32;
+  const size_t lds = halo_lds_bytes(p, FN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<FN>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(tiles_w * tiles_h * p.B), (unsigned)p.G);
+  hipLaunchKernelGGL(conv3x3_halo_kernel<FN>, grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+}  // namespace
+
+// variant code 300 + FN
+bool conv_halo_supported(const tfpp_conv_params& p, int dtype) {
+  static const int on = [] { const char* e = std::getenv("TFPP_CONV_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (!on || dtype != TFPP_BF16) return false;
+  if (p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || p.Hs != p.Hd || p.Ws != p.Wd) return false;
+  if (p.ks_g % 8 || p.src_ld % 8 || p.n_g > 64 || p.Wd < 32 || p.Hd < 4) return false;
+  const int fn = p.n_g <= 16 ? 1 : (p.n_g <= 32 ? 2 : 4);
+  return halo_lds_bytes(p, fn) <= 65536;
+}
+
+int conv_halo_variant(const tfpp_conv_params& p) { return 300 + (p.n_g <= 16 ? 1 : (p.n_g <= 32 ? 2 : 4)); }
+
+int conv_halo_mtiles(const tfpp_conv_params& p) { return cdiv(p.Wd, TW) * cdiv(p.Hd, TH) * p.B; }
+
+int conv_gemm_halo(const tfpp_conv_params& p, hipStream_t st) {
+  switch (conv_halo_variant(p) - 300) {
+    case 1: return launch_halo<1>(p, st);
+    case 2: return launch_halo<2>(p, st);
+    default: return launch_halo<4>(p, st);
+  }
+}

@@ -11,3 +11,9 @@ int conv_gemm_direct(const tfpp_conv_params& p, int dtype, hipStream_t st);
 bool conv_glds_supported(const tfpp_conv_params& p, int dtype);
 int conv_glds_variant(const tfpp_conv_params& p);
 int conv_gemm_glds(const tfpp_conv_params& p, hipStream_t st);
+
+// 3x3 / stride 1 / pad 1 with the input tile staged once in LDS (conv3x3_halo.hip), bf16, n_g <= 64; variant codes 300 + FN
+bool conv_halo_supported(const tfpp_conv_params& p, int dtype);
+int conv_halo_variant(const tfpp_conv_params& p);
+int conv_halo_mtiles(const tfpp_conv_params& p);
+int conv_gemm_halo(const tfpp_conv_params& p, hipStream_t st);

@@ -268,6 +268,10 @@ static bool use_direct_impl() {
 // number of M-tiles (= rows of stats_partial the LDS kernel writes) for p
 extern "C" int tfpp_conv_gemm_mtiles(const tfpp_conv_params* p) {
   if (!p) return TFPP_EINVAL;
+  if (conv_halo_supported(*p, TFPP_BF16)) {  // dtype unknown here: an upper bound over both kernels is enough
+    const int a = conv_halo_mtiles(*p), b = cdiv((long)p->B * p->Hd * p->Wd, 64);
+    return a > b ? a : b;
+  }
   static const int bm[4] = {128, 128, 64, 128};
   return cdiv((long)p->B * p->Hd * p->Wd, bm[conv_variant(*p)]);  // only an upper bound for the row count is needed
 }
@@ -284,12 +288,14 @@ static bool use_glds_impl() {
 extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
   if (use_direct_impl() && !p->stats_partial) return conv_direct_variant(*p, dtype);
+  if (conv_halo_supported(*p, dtype)) return conv_halo_variant(*p);
   if (use_glds_impl() && conv_glds_supported(*p, dtype)) return conv_glds_variant(*p);
   return conv_variant(*p);
 }
 
 static int conv_splits_for(const tfpp_conv_params& p, int dtype) {
   const long M = (long)p.B * p.Hd * p.Wd;
+  if (conv_halo_supported(p, dtype)) return 1;
   if (use_glds_impl() && conv_glds_supported(p, dtype)) {
     const int bm = conv_glds_variant(p) == 200 ? 128 : 64;
     return conv_splits(p, (long)cdiv(M, bm) * cdiv(p.n_g, 128) * p.G, 64);
@@ -312,6 +318,7 @@ template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStr
   const long M = (long)p.B * p.Hd * p.Wd;
   if (M >= (1l << 31) || M * (long)p.dst_ld >= (1l << 40)) return TFPP_EINVAL;
   if (use_direct_impl() && !p.stats_partial) return conv_gemm_direct(p, ElemTraits<T>::DT, st);
+  if (conv_halo_supported(p, ElemTraits<T>::DT)) return conv_gemm_halo(p, st);
   tfpp_conv_params q = p;
   q.splitk = conv_splits_for(p, ElemTraits<T>::DT);
   int rc;

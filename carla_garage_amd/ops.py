@@ -97,7 +97,9 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
     p.stats_partial, p.stats_rows = ptr(scratch), nblk
   if lib.profiler is not None:
     var = lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p), dt(src))
-    if var >= 200:
+    if var >= 300:
+      tile = f'halo8x32x{(var - 300) * 16}'
+    elif var >= 200:
       tile = ('glds128x128', 'glds64x128')[var - 200]
     elif var >= 100:
       tile = f'direct{(var - 100) // 10 * 32}x{(var - 100) % 10 * 32}'

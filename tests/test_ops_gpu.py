@@ -76,6 +76,9 @@ CONV_CASES = [
     ('dense3x3', 2, 12, 16, 64, 32, 3, 1, 1),
     ('big_k', 1, 8, 80, 1512, 1512, 1, 1, 1),
     ('wide_n', 3, 10, 10, 64, 256, 1, 1, 1),
+    ('halo_dense', 2, 12, 40, 32, 32, 3, 1, 1),   # LDS-halo 3x3 kernel (bf16): decoder-style 32 -> 32
+    ('halo_n8', 1, 10, 64, 32, 8, 3, 1, 1),       # 32 -> 8 (and 8 -> 32 as its data gradient)
+    ('halo_wide', 1, 7, 35, 16, 64, 3, 1, 1),     # ragged tile edges, 4 channel fragments
     ('splitk_linear', 132, 1, 1, 2048, 256, 1, 1, 1),  # fp32 planning head FFN: 12 output tiles, K = 2048
     ('splitk_3x3', 1, 16, 16, 256, 128, 3, 1, 1),      # few tiles, K = 2304 (LDS-DMA kernel in bf16)
 ]
@@ -250,8 +253,8 @@ def test_batchnorm_train_and_backward(ops, dtype, C):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('case', [(3, 12, 20, 40, 72, 1, 1), (2, 9, 11, 48, 48, 3, 2), (1, 8, 80, 576, 1512, 1, 1)],
-                         ids=['pw72', 'g3x3', 'wide1512'])
+@pytest.mark.parametrize('case', [(3, 12, 20, 40, 72, 1, 1), (2, 9, 11, 48, 48, 3, 2), (1, 8, 80, 576, 1512, 1, 1), (2, 10, 40, 48, 48, 3, 2)],
+                         ids=['pw72', 'g3x3', 'wide1512', 'g3x3_halo'])
 def test_conv_fused_batchnorm_statistics(ops, dtype, case):
   """conv -> BN(train) with the statistics accumulated in the conv epilogue and finalised straight from the
   accumulation rows (which the finalise kernel hands back zeroed)."""
