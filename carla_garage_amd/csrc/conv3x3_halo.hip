@@ -123,6 +123,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
   }
 
   // ---- epilogue: C fragment row (kg * 4 + r) is the pixel, column p16 the channel
+  if (epi_vec_ok(p)) {  // coalesced 16-pixel passes through a per-wave LDS strip (staging buffers are dead)
+    __syncthreads();
+    float* strip = reinterpret_cast<float*>(smem) + wave * EpiStrip<FN>::FLOATS;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int h = h0 + 2 * wave + (i >> 1), wc = w0 + (i & 1) * 16;
+      epi_pass_bf16<FN>(p, acc[i], strip, lane, (long)(b * H + h) * W + wc, h < H ? W - wc : 0, 0, g);
+    }
+    return;
+  }
   const int hw = H * W;
   const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
 #pragma unroll

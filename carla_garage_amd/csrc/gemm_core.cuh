@@ -15,6 +15,7 @@
 // fragments, which transposes them without a global-memory pass.
 #pragma once
 #include "common.cuh"
+#include "../../include/tfpp.h"
 
 template <typename T, int BM_, int BN_, int WM_, int WN_, int BK_ = 32>
 struct TileCfg {
@@ -102,4 +103,66 @@ template <typename T> __device__ __forceinline__ void lds_store_km(T* dst, const
   uint2* d = reinterpret_cast<uint2*>(dst);
   d[0] = make_uint2(v.x, v.y);
   d[1] = make_uint2(v.z, v.w);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Coalesced bf16 epilogue.  The MFMA C layout gives a lane 4 rows x 1 column per fragment, so storing straight from the
+// accumulators issues 2-byte stores that touch 4 cache lines per instruction with 32 valid bytes each; the phase trace
+// of the LDS-DMA kernel (tools/glds_trace.py) showed that costing 6-7 us per workgroup -- as much as an 18-tile K loop.
+// Instead each wave passes 16 rows x (16 FN) columns of fp32 results through a private LDS strip and every lane then
+// finishes 8 consecutive channels of one row: scale / shift / residual are 16-byte loads, the store is 16 bytes, and a
+// wave writes 64..128-byte row segments.  Preconditions (epi_vec_ok): NHWC bf16 destination, n_g, dst_ld (res_ld)
+// multiples of 8, 16-byte aligned bases.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool epi_vec_ok(const tfpp_conv_params& p) {
+  return !p.dst_nchw && !p.dst_f32 && ((p.n_g | (int)p.dst_ld) & 7) == 0 && ((uintptr_t)p.dst & 15) == 0 &&
+         (!p.res || (((int)p.res_ld & 7) == 0 && ((uintptr_t)p.res & 15) == 0));
+}
+template <int FN> struct EpiStrip { static constexpr int PITCH = FN * 16 + 4, FLOATS = 16 * PITCH; };
+
+// one pass: rows m_pass .. m_pass + rows_valid - 1 (<= 16), columns n_base .. n_base + 16 FN - 1 of group g
+template <int FN>
+__device__ __forceinline__ void epi_pass_bf16(const tfpp_conv_params& p, const f32x4_t (&acc)[FN], float* strip, int lane, long m_pass,
+                                              int rows_valid, int n_base, int g) {
+  constexpr int PITCH = EpiStrip<FN>::PITCH, CH = FN * 2, NCHUNK = 16 * CH;
+  const int p16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) strip[(kg * 4 + r) * PITCH + j * 16 + p16] = acc[j][r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private strip: DS ops retire in order, this also pins the compiler
+#pragma unroll
+  for (int c = 0; c < (NCHUNK + 63) / 64; ++c) {
+    const int q = lane + c * 64;
+    const int row = q / CH, c8 = q - row * CH, n = n_base + c8 * 8;
+    if (q < NCHUNK && row < rows_valid && n < p.n_g) {
+      const float4 lo = *reinterpret_cast<const float4*>(strip + row * PITCH + c8 * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(strip + row * PITCH + c8 * 8 + 4);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const int ch = g * p.n_g + n;
+      const long m = m_pass + row;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+      if (p.scale) {
+        const float4 s0 = *reinterpret_cast<const float4*>(p.scale + ch), s1 = *reinterpret_cast<const float4*>(p.scale + ch + 4);
+        v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w; v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
+      }
+      if (p.shift) {
+        const float4 s0 = *reinterpret_cast<const float4*>(p.shift + ch), s1 = *reinterpret_cast<const float4*>(p.shift + ch + 4);
+        v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w; v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
+      }
+      if (p.res) {
+        float rv[8];
+        load_vec<bf16_t>(reinterpret_cast<const bf16_t*>(p.res) + (size_t)m * p.res_ld + ch, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+      if (p.act != ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
+      }
+      store_vec<bf16_t>(reinterpret_cast<bf16_t*>(p.dst) + (size_t)m * p.dst_ld + ch, v);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip is rewritten by the next pass
 }

@@ -18,6 +18,11 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 __device__ __attribute__((aligned(16))) unsigned int tfpp_zero_page[4] = {0u, 0u, 0u, 0u};
 
+// TFPP_GLDS_TRACE=1: phase timestamps (100 MHz wall clock) of up to 4096 workgroups, read back with tfpp_debug_glds_trace
+#define TRACE_SLOTS 6
+__device__ unsigned long long tfpp_glds_trace[4096 * TRACE_SLOTS];
+#define TRACE(k) do { if (trace && tid == 0) { const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); if (bid < 4096) tfpp_glds_trace[bid * TRACE_SLOTS + (k)] = wall_clock64(); } } while (0)
+
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 lds_read_b128_asm(unsigned addr) {
   u32x4_t v;
@@ -26,7 +31,7 @@ __device__ __forceinline__ uint4 lds_read_b128_asm(unsigned addr) {
 }
 
 template <int BM, int BN, int NSTAGE, int WGM, int WGN>
-__global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_conv_params p) {
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_conv_params p, int trace) {
   typedef bf16_t T;
   constexpr int NT = WGM * WGN * 64, NWAVES = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
@@ -36,6 +41,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
   constexpr int LOADS = A_INST + B_INST;              // LDS-DMA instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TRACE(0);
   const int wm = wave / WGN, wn = wave % WGN;
   int g = blockIdx.z, split = 0;
   if (p.splitk > 1) { g = blockIdx.z / p.splitk; split = blockIdx.z - g * p.splitk; }  // z = (group, K slice)
@@ -140,9 +146,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
     b_off[j] = (unsigned)(A_BYTES + row * 64 + ((kgrp ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3)) * 16));
   }
 
+  TRACE(1);
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nkt) issue(s);
+  TRACE(2);
 
   for (int kt = 0; kt < nkt; ++kt) {
     // tiles issued after kt and still allowed in flight: min(NSTAGE-2, nkt-1-kt)
@@ -155,6 +163,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; every wave is done with tile kt-1
+    if (kt == 0) TRACE(3);
     if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1);
     const unsigned stage = lds_base + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
     Frag<T> fa[FM], fb[FN];
@@ -170,6 +179,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
       for (int j = 0; j < FN; ++j) frag_mma(fa[i], fb[j], acc[i][j]);
   }
 
+  TRACE(4);
   if (p.splitk > 1) {  // raw fp32 slice -> workspace [split][M][G*n_g]; splitk_epilogue_kernel finishes the job
     const int ntot = p.G * p.n_g;
     float* __restrict__ wsp = p.splitk_ws + (size_t)split * M * ntot;
@@ -231,6 +241,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
   }
 
   // ---- epilogue
+  if (epi_vec_ok(p)) {  // coalesced: 16-row passes through a per-wave LDS strip (the ring is free)
+    __syncthreads();
+    float* strip = reinterpret_cast<float*>(smem) + wave * EpiStrip<FN>::FLOATS;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m_pass = bm0 + wm * WM + i * 16;
+      epi_pass_bf16<FN>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g);
+    }
+    TRACE(5);
+    return;
+  }
   const int hw = p.Hd * p.Wd;
   const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
 #pragma unroll
@@ -257,6 +278,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
       }
     }
   }
+  TRACE(5);
 }
 
 template <int BM, int BN, int NSTAGE, int WGM, int WGN> static int launch_glds(const tfpp_conv_params& p, hipStream_t st) {
@@ -269,7 +291,8 @@ template <int BM, int BN, int NSTAGE, int WGM, int WGN> static int launch_glds(c
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN>), grid, dim3(WGM * WGN * 64), lds, st, p);
+  static const int trace = [] { const char* e = std::getenv("TFPP_GLDS_TRACE"); return (e && e[0] == '1') ? 1 : 0; }();
+  hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN>), grid, dim3(WGM * WGN * 64), lds, st, p, trace);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -278,7 +301,8 @@ template <int BM, int BN, int NSTAGE, int WGM, int WGN> static int launch_glds(c
 int conv_glds_variant(const tfpp_conv_params& p) {
   const long M = (long)p.B * p.Hd * p.Wd;
   const long tiles = (long)cdiv(M, 128) * cdiv(p.n_g, 128) * p.G;
-  return tiles >= 512 ? 200 : 201;
+  static const int min_tiles = [] { const char* e = std::getenv("TFPP_GLDS_128_MIN_TILES"); return e ? std::atoi(e) : 512; }();
+  return tiles >= min_tiles ? 200 : 201;
 }
 
 bool conv_glds_supported(const tfpp_conv_params& p, int dtype) {
@@ -309,6 +333,15 @@ int conv_gemm_glds(const tfpp_conv_params& p, hipStream_t st) {
   switch (c) {
     case 2: return launch_glds<64, 128, 2, 2, 2>(p, st);
     case 6: return launch_glds<64, 128, 4, 2, 2>(p, st);
+    case 7: return launch_glds<64, 128, 8, 2, 2>(p, st);
+    case 8: return launch_glds<64, 128, 6, 2, 2>(p, st);
     default: return launch_glds<64, 128, 3, 2, 2>(p, st);
   }
+}
+
+// debugging aid: copy the phase timestamps of the last traced launch (TFPP_GLDS_TRACE=1) to host memory
+extern "C" int tfpp_debug_glds_trace(uint64_t* out, int n_blocks) {
+  if (!out || n_blocks < 1 || n_blocks > 4096) return TFPP_EINVAL;
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(tfpp_glds_trace), (size_t)n_blocks * TRACE_SLOTS * sizeof(unsigned long long));
+  return e == hipSuccess ? TRACE_SLOTS : -(int)e;
 }

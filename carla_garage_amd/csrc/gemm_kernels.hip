@@ -12,8 +12,12 @@ template <typename T, int BM, int BN, int WM, int WN, int BKT>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_kernel(tfpp_conv_params p) {
   using C = TileCfg<T, BM, BN, WM, WN, BKT>;
   constexpr int VEC = C::VEC, KV = C::KV, NT = C::NT, BK = C::BK;
-  __shared__ __attribute__((aligned(16))) T As[C::A_ELEMS_RM];
-  __shared__ __attribute__((aligned(16))) T Bs[C::B_ELEMS_RM];
+  // one raw buffer: the A / B stages during the K loop, the per-wave epilogue strips afterwards
+  constexpr size_t STAGE_BYTES = (size_t)(C::A_ELEMS_RM + C::B_ELEMS_RM) * sizeof(T);
+  constexpr size_t STRIP_BYTES = (size_t)(NT / 64) * EpiStrip<C::FN>::FLOATS * sizeof(float);
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[STAGE_BYTES > STRIP_BYTES ? STAGE_BYTES : STRIP_BYTES];
+  T* As = reinterpret_cast<T*>(smem_raw);
+  T* Bs = As + C::A_ELEMS_RM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
   // grid: x = N-tile (fastest), y = M-tile, z = group.  Consecutive workgroups share the same activation rows (A) and
@@ -146,6 +150,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
   }
 
   // epilogue
+  if constexpr (sizeof(T) == 2) {
+    if (epi_vec_ok(p)) {  // coalesced: 16-row passes through a per-wave LDS strip (see gemm_core.cuh)
+      __syncthreads();
+      float* strip = reinterpret_cast<float*>(smem_raw) + wave * EpiStrip<C::FN>::FLOATS;
+#pragma unroll
+      for (int i = 0; i < C::FM; ++i) {
+        const int m_pass = bm0 + wm * WM + i * 16;
+        epi_pass_bf16<C::FN>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g);
+      }
+      return;
+    }
+  }
   const int hw = p.Hd * p.Wd;
   const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
 #pragma unroll

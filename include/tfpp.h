@@ -77,6 +77,8 @@ int tfpp_conv_gemm(const tfpp_conv_params* p, int dtype, void* stream);
  * (only with TFPP_CONV_IMPL=lds). */
 int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype);
 int tfpp_conv_gemm_mtiles(const tfpp_conv_params* p);
+/* debugging aid (TFPP_GLDS_TRACE=1): per-workgroup phase timestamps of the last LDS-DMA GEMM launch; returns slots per workgroup */
+int tfpp_debug_glds_trace(uint64_t* out, int n_blocks);
 
 /* Weight gradient of the same convolution (autograd of F.conv2d / F.linear, train.py:898):
  *   dw[(g*n_g+n), c, r, s] += sum_{b,hd,wd} dy[b,hd,wd,g*n_g+n] * x[b,hd*stride-pad+r,wd*stride-pad+s,g*ks_g+c]

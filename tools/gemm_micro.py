@@ -14,6 +14,8 @@ SHAPES = [
     ('fusion_mlp0 3840x6048x1512', 3840, 1, 1, 1512, 6048, 1, 1, 1),
     ('fusion_proj 3840x1512x1512', 3840, 1, 1, 1512, 1512, 1, 1, 1),
     ('s3_1x1 12288x576x576', 12, 16, 64, 576, 576, 1, 1, 1),
+    ('lid_s3_1x1 3072x576x576', 12, 16, 16, 576, 576, 1, 1, 1),
+    ('lid_s4_1x1 768x1512x1512', 12, 8, 8, 1512, 1512, 1, 1, 1),
     ('s2_1x1 49152x216x216', 12, 32, 128, 216, 216, 1, 1, 1),
     ('s1_1x1 196608x72x72', 12, 64, 256, 72, 72, 1, 1, 1),
     ('s3_g3x3 12288 g24', 12, 16, 64, 576, 576, 3, 1, 24),
@@ -27,10 +29,14 @@ def main():
   ap.add_argument('--iters', type=int, default=10)
   ap.add_argument('--only', default='')
   ap.add_argument('--wgrad', action='store_true')
+  ap.add_argument('--shape', action='append', default=[], help='B,H,W,Cin,Cout,k,stride,G (repeatable; replaces the built-in list)')
   args = ap.parse_args()
   dev = 'cuda'
   dt = torch.bfloat16
-  for name, B, H, W, Cin, Cout, k, st, G in SHAPES:
+  shapes = SHAPES
+  if args.shape:
+    shapes = [(f'custom {t}',) + tuple(int(v) for v in t.split(',')) for t in args.shape]
+  for name, B, H, W, Cin, Cout, k, st, G in shapes:
     if args.only and args.only not in name:
       continue
     pad = k // 2
@@ -50,10 +56,16 @@ def main():
 
     run()
     torch.cuda.synchronize()
+    # replay `iters` launches from a hipGraph: measures GPU time, not the Python launch rate
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+      for _ in range(args.iters):
+        run()
+    graph.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(args.iters):
-      run()
+    graph.replay()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.iters
