@@ -11,6 +11,7 @@ fp32 MFMA accumulation); the planning head (65-token decoder, GRU, MLPs: M <= 78
 in fp32.
 """
 import math
+import os
 
 import torch
 
@@ -31,11 +32,18 @@ class Tape:
   Tensors are identified by (data_ptr, numel) so reshaped views of one buffer are the same node; the tape keeps every
   recorded tensor alive, so a key cannot be reused while it is pending."""
 
+  current = None  # the tape whose backward() is running (closures use it to freeze tensors / register finalizers)
+
   def __init__(self):
     self.nodes = []
+    self.frozen = {}      # id(tensor) -> tensor: handed to another stream, must not be accumulated into in place
+    self.finalizers = []  # run once at the end of backward (joins side streams)
 
   def record(self, outs, ins, fn):
     self.nodes.append((outs, ins, fn))
+
+  def freeze(self, t):
+    self.frozen[id(t)] = t
 
   def backward(self, seeds):
     """seeds: list of (tensor, grad)."""
@@ -49,7 +57,8 @@ class Tape:
       if cur is None:
         grads[k] = g
         refs[id(g)] = refs.get(id(g), 0) + 1
-      elif refs.get(id(cur), 0) > 1:  # the stored gradient object is also pending under another key: do not mutate it
+      elif refs.get(id(cur), 0) > 1 or id(cur) in self.frozen:
+        # the stored gradient object is also pending under another key, or is being read on the side stream: do not mutate it
         refs[id(cur)] -= 1
         new = ops.add_dropout(cur, g if g.dtype == cur.dtype else ops.cast(g, cur.dtype))
         grads[k] = new
@@ -57,6 +66,7 @@ class Tape:
       else:
         ops.axpy(g if g.dtype == cur.dtype else ops.cast(g, cur.dtype), cur, 1.0)
 
+    Tape.current = self
     for t, g in seeds:
       acc(t, g)
     for outs, ins, fn in reversed(self.nodes):
@@ -76,6 +86,56 @@ class Tape:
       for t, g in zip(ins, gins):
         acc(t, g)
     self.nodes = []
+    for fin in self.finalizers:
+      fin()
+    self.finalizers = []
+    self.frozen = {}
+    Tape.current = None
+
+
+class SideLane:
+  """A second HIP stream for backward work that is off the critical path: weight gradients only feed the optimizer, so
+  they trail the dY chain on their own stream and fill the CUs the small latency-bound kernels of the main chain leave
+  idle.  Captured into the step's hipGraph as a parallel branch (fork = event wait, join at the end of backward).
+  Tensors a side kernel reads are frozen on the tape (never accumulated into in place) and kept alive until the join, so
+  the caching allocator cannot hand their memory to a main-stream kernel that might overtake the side stream.
+  TFPP_SIDE_STREAM=0 runs everything on one stream."""
+
+  def __init__(self):
+    self.enabled = os.environ.get('TFPP_SIDE_STREAM', '1') != '0'
+    self.batch = int(os.environ.get('TFPP_SIDE_BATCH', '16'))  # launches per fork (one event wait per batch)
+    self.stream = None
+    self.keep = []
+    self.pending = []
+
+  def run(self, tape, fn, *tensors):
+    if not self.enabled or tape is None or not tensors[0].is_cuda:
+      fn()
+      return
+    if self.stream is None:
+      self.stream = torch.cuda.Stream(tensors[0].device)
+    if not self.keep:
+      tape.finalizers.append(self.join)
+    for t in tensors:
+      tape.freeze(t)
+      self.keep.append(t)
+    self.pending.append(fn)
+    if len(self.pending) >= self.batch:
+      self.flush()
+
+  def flush(self):
+    if self.pending:
+      self.stream.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(self.stream):
+        for fn in self.pending:
+          fn()
+      self.pending = []
+
+  def join(self):
+    if self.keep:
+      self.flush()
+      torch.cuda.current_stream().wait_stream(self.stream)
+      self.keep = []
 
 
 class ConvSpec:
@@ -112,6 +172,7 @@ class Engine:
     self.flat_grad = None
     self._consts = {}
     self._packed_key = None
+    self.side = SideLane()
     self._build_specs()
 
   # ------------------------------------------------------------------------------------------------ set-up
@@ -376,8 +437,9 @@ class Engine:
                                    self.g(s.bn.bias), relu_mask=(act == ACT_RELU), want_dres=res is not None)
         gsrc = dconv if dconv.dtype == x.dtype else ops.cast(dconv, x.dtype)
         if s.weight.requires_grad:
-          ops.conv_wgrad(gsrc, x, self.g(s.weight), B=B, Hs=H, Ws=W, Cs=Cs, Hd=Ho, Wd=Wo, Cd=s.n_store, R=k, S=k, stride=st,
-                         pad=pd, G=G, ks_g=Cs // G, n_g=s.n_store // G, c_real=s.cin_g, row_map=s.row_map)
+          self.side.run(Tape.current, lambda: ops.conv_wgrad(
+              gsrc, x, self.g(s.weight), B=B, Hs=H, Ws=W, Cs=Cs, Hd=Ho, Wd=Wo, Cd=s.n_store, R=k, S=k, stride=st, pad=pd, G=G,
+              ks_g=Cs // G, n_g=s.n_store // G, c_real=s.cin_g, row_map=s.row_map), gsrc, x)
         dx = None
         if x_grad:
           dx = torch.empty((B, H, W, Cs), device=x.device, dtype=x.dtype)
@@ -407,7 +469,7 @@ class Engine:
 
       def bwd(dy):
         dz = ops.act_bwd(dy, y, act) if act != ACT_NONE else dy
-        gw(dz, x)
+        self.side.run(Tape.current, lambda: gw(dz, x), dz, x)
         if gb is not None:
           gb(dz)
         dx = torch.empty((rows, k), device=x.device, dtype=x.dtype)
@@ -670,7 +732,7 @@ class Engine:
       if self.tape is not None:
 
         def bwd(dy):
-          gw(dy, inp)
+          self.side.run(Tape.current, lambda: gw(dy, inp), dy, inp)
           gb(dy)
           dx = torch.empty((rows, dm), device=inp.device, dtype=F32)
           # dx = dy @ W[r0:r1]  : W slice [n, dm] is k-major for this product -> batched GEMM with b_km

@@ -55,7 +55,7 @@ SPLITK_WS_FLOATS = 16 << 20
 def splitk_workspace(device):
   """fp32 slices of split-K launches (few output tiles x long reduction); one buffer per device, kernels on a stream run
   in order.  TFPP_SPLITK=0 disables split-K."""
-  key = str(device)
+  key = (str(device), torch.cuda.current_stream(device).cuda_stream)  # one per stream: the side lane runs concurrently
   buf = _SPLITK_WS.get(key)
   if buf is None:
     n = SPLITK_WS_FLOATS if _os.environ.get('TFPP_SPLITK', '1') != '0' else 4
