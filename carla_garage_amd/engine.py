@@ -10,6 +10,7 @@ Precision: the RegNet branches, fusion transformers and dense decoders run in ``
 fp32 MFMA accumulation); the planning head (65-token decoder, GRU, MLPs: M <= 780 rows, launch-bound) always runs
 in fp32.
 """
+import contextlib
 import math
 import os
 
@@ -26,30 +27,97 @@ def _key(t):
   return (t.data_ptr(), t.numel())
 
 
+class Lanes:
+  """HIP streams of the two encoder branches.  Lane 0 is the caller's stream (image branch, fusion transformers, heads), lane 1
+  a second stream for the LiDAR branch: its kernels (a quarter of the pixels: small, latency-bound launches) overlap with the
+  image branch between fusion points, in forward and -- through the lane tag on every tape node -- in backward.  Captured into
+  the hipGraphs as parallel branches.  TFPP_BRANCH_STREAMS=0 keeps everything on one stream."""
+
+  def __init__(self):
+    self.enabled = os.environ.get('TFPP_BRANCH_STREAMS', '1') != '0'
+    self.main = self.branch = None
+    self.cur = 0
+    self.held = []
+
+  def hold(self, *tensors):
+    """Keep tensors that cross lanes alive until the next pass begins: the caching allocator only orders reuse within
+    the stream a block was allocated on, and the consumer runs on the other one."""
+    if self.on():
+      self.held.extend(tensors)
+
+  def begin(self, device):
+    """Call at the start of a forward / backward pass: lane 0 = the stream current right now."""
+    self.cur = 0
+    self.held = []
+    if not self.enabled or torch.device(device).type != 'cuda':
+      self.main = None
+      return
+    self.main = torch.cuda.current_stream(device)
+    if self.branch is None:
+      self.branch = torch.cuda.Stream(device)
+
+  def on(self):
+    return self.main is not None
+
+  def stream(self, k):
+    return self.main if k == 0 else self.branch
+
+  def streams(self):
+    return [self.main, self.branch] if self.on() else []
+
+  @contextlib.contextmanager
+  def fork(self, k=1):
+    """Run the body on lane k, ordered after everything issued so far on lane 0."""
+    if not self.on():
+      yield
+      return
+    self.branch.wait_stream(self.main)
+    prev, self.cur = self.cur, k
+    try:
+      with torch.cuda.stream(self.branch):
+        yield
+    finally:
+      self.cur = prev
+
+  def join(self):
+    if self.on():
+      self.main.wait_stream(self.branch)
+
+
 class Tape:
-  """Reverse-mode tape: nodes are (outputs, inputs, backward_fn(*grad_outputs) -> grad_inputs).
+  """Reverse-mode tape: nodes are (outputs, inputs, backward_fn(*grad_outputs) -> grad_inputs, lane).
 
   Tensors are identified by (data_ptr, numel) so reshaped views of one buffer are the same node; the tape keeps every
-  recorded tensor alive, so a key cannot be reused while it is pending."""
+  recorded tensor alive, so a key cannot be reused while it is pending.  With ``lanes`` a node's backward runs on the
+  stream of the lane it was recorded on; a gradient that crosses lanes makes the consuming stream wait for the producing one."""
 
   current = None  # the tape whose backward() is running (closures use it to freeze tensors / register finalizers)
 
-  def __init__(self):
+  def __init__(self, lanes=None):
     self.nodes = []
+    self.lanes = lanes
     self.frozen = {}      # id(tensor) -> tensor: handed to another stream, must not be accumulated into in place
     self.finalizers = []  # run once at the end of backward (joins side streams)
 
-  def record(self, outs, ins, fn):
-    self.nodes.append((outs, ins, fn))
+  def record(self, outs, ins, fn, lane=0):
+    self.nodes.append((outs, ins, fn, lane))
 
   def freeze(self, t):
     self.frozen[id(t)] = t
 
   def backward(self, seeds):
     """seeds: list of (tensor, grad)."""
-    grads, refs = {}, {}
+    grads, refs, glane = {}, {}, {}
+    lanes = self.lanes
+    if lanes is not None and seeds:
+      lanes.begin(seeds[0][1].device)
+    multi = lanes is not None and lanes.on()
 
-    def acc(t, g):
+    def sync(to_lane, from_lane):
+      if multi and to_lane != from_lane:
+        lanes.stream(to_lane).wait_stream(lanes.stream(from_lane))
+
+    def acc(t, g, lane):
       if t is None or g is None:
         return
       k = _key(t)
@@ -57,7 +125,13 @@ class Tape:
       if cur is None:
         grads[k] = g
         refs[id(g)] = refs.get(id(g), 0) + 1
-      elif refs.get(id(cur), 0) > 1 or id(cur) in self.frozen:
+        glane[k] = lane
+        return
+      if multi and glane[k] != lane:  # the pending gradient was last written on another lane
+        sync(lane, glane[k])
+        lanes.hold(cur, g)
+      glane[k] = lane
+      if refs.get(id(cur), 0) > 1 or id(cur) in self.frozen:
         # the stored gradient object is also pending under another key, or is being read on the side stream: do not mutate it
         refs[id(cur)] -= 1
         new = ops.add_dropout(cur, g if g.dtype == cur.dtype else ops.cast(g, cur.dtype))
@@ -68,26 +142,43 @@ class Tape:
 
     Tape.current = self
     for t, g in seeds:
-      acc(t, g)
-    for outs, ins, fn in reversed(self.nodes):
-      gouts = []
+      acc(t, g, 0)
+    for outs, ins, fn, lane in reversed(self.nodes):
+      if not multi:
+        lane = 0
+      gouts, src_lanes = [], set()
       for o in outs:
-        g = grads.pop(_key(o), None)
+        k = _key(o)
+        g = grads.pop(k, None)
         if g is not None:
           refs[id(g)] = refs.get(id(g), 1) - 1
+          src_lanes.add(glane.pop(k, 0))
         gouts.append(g)
       if all(g is None for g in gouts):
         continue
-      gins = fn(*gouts)
-      if gins is None:
-        gins = ()
-      if not isinstance(gins, (tuple, list)):
-        gins = (gins,)
-      for t, g in zip(ins, gins):
-        acc(t, g)
+      ctx = torch.cuda.stream(lanes.stream(lane)) if multi and lane != 0 else contextlib.nullcontext()
+      with ctx:
+        if multi:
+          lanes.cur = lane
+        for sl in src_lanes:
+          sync(lane, sl)
+        if multi and src_lanes - {lane}:
+          lanes.hold(*[g for g in gouts if g is not None])
+        gins = fn(*gouts)
+        if gins is None:
+          gins = ()
+        if not isinstance(gins, (tuple, list)):
+          gins = (gins,)
+        for t, g in zip(ins, gins):
+          acc(t, g, lane)
     self.nodes = []
+    if multi:
+      lanes.cur = 0
     for fin in self.finalizers:
       fin()
+    if multi:
+      lanes.join()
+      lanes.held = []
     self.finalizers = []
     self.frozen = {}
     Tape.current = None
@@ -105,6 +196,7 @@ class SideLane:
     self.enabled = os.environ.get('TFPP_SIDE_STREAM', '1') != '0'
     self.batch = int(os.environ.get('TFPP_SIDE_BATCH', '16'))  # launches per fork (one event wait per batch)
     self.stream = None
+    self.lanes = None  # Lanes of the engine: a batch may hold closures from both encoder-branch streams
     self.keep = []
     self.pending = []
 
@@ -126,6 +218,9 @@ class SideLane:
   def flush(self):
     if self.pending:
       self.stream.wait_stream(torch.cuda.current_stream())
+      if self.lanes is not None:
+        for st in self.lanes.streams():
+          self.stream.wait_stream(st)
       with torch.cuda.stream(self.stream):
         for fn in self.pending:
           fn()
@@ -172,7 +267,9 @@ class Engine:
     self.flat_grad = None
     self._consts = {}
     self._packed_key = None
+    self.lanes = Lanes()
     self.side = SideLane()
+    self.side.lanes = self.lanes
     self._build_specs()
 
   # ------------------------------------------------------------------------------------------------ set-up
@@ -387,7 +484,7 @@ class Engine:
   # ------------------------------------------------------------------------------------------------ primitives
   def rec(self, outs, ins, fn):
     if self.tape is not None:
-      self.tape.record(outs, ins, fn)
+      self.tape.record(outs, ins, fn, self.lanes.cur)
 
   def conv(self, x, key, act=ACT_NONE, res=None, x_grad=True, out_f32=False):
     """x: [B,H,W,Cstore] NHWC.  Returns [B,Ho,Wo,n_store]."""
@@ -815,25 +912,35 @@ class Engine:
     B = rgb.shape[0]
     bb = m.backbone
     out = {}
+    self.lanes.begin(dev)
     if cfg.normalize_imagenet:
       mul = self._const('img_mul', lambda: torch.tensor([1.0 / (255.0 * s) for s in (0.229, 0.224, 0.225)]))
       add = self._const('img_add', lambda: torch.tensor([-mu / s for mu, s in ((0.485, 0.229), (0.456, 0.224), (0.406, 0.225))]))
       xi = ops.nchw_to_nhwc_affine(rgb.float().contiguous(), dt_, 8, mul, add)
     else:
       xi = ops.nchw_to_nhwc_affine(rgb.float().contiguous(), dt_, 8)
-    xl = ops.nchw_to_nhwc_affine(lidar_bev.float().contiguous(), dt_, 8)
+    lidar_in = lidar_bev.float().contiguous()
+    lanes = self.lanes
+    lanes.hold(lidar_in)
+    with lanes.fork():  # the LiDAR branch runs on its own stream between the fusion points
+      xl = ops.nchw_to_nhwc_affine(lidar_in, dt_, 8)
+      xl = self.conv(xl, 'backbone.lidar_encoder.stem', act=ACT_RELU, x_grad=False)
     xi = self.conv(xi, 'backbone.image_encoder.stem', act=ACT_RELU, x_grad=False)
-    xl = self.conv(xl, 'backbone.lidar_encoder.stem', act=ACT_RELU, x_grad=False)
     for i in range(4):
+      with lanes.fork():
+        xl = self.stage(xl, f'backbone.lidar_encoder.s{i + 1}', bb.lidar_encoder[f's{i + 1}'])
+        lt = self.pool_tokens(xl, cfg.lidar_vert_anchors, cfg.lidar_horz_anchors)
+        lt = self.conv(lt, f'backbone.lidar_channel_to_img.{i}')
       xi = self.stage(xi, f'backbone.image_encoder.s{i + 1}', bb.image_encoder[f's{i + 1}'])
-      xl = self.stage(xl, f'backbone.lidar_encoder.s{i + 1}', bb.lidar_encoder[f's{i + 1}'])
       it = self.pool_tokens(xi, cfg.img_vert_anchors, cfg.img_horz_anchors)
-      lt = self.pool_tokens(xl, cfg.lidar_vert_anchors, cfg.lidar_horz_anchors)
-      lt = self.conv(lt, f'backbone.lidar_channel_to_img.{i}')
+      lanes.join()
       io, lo = self.gpt(i, it, lt)
-      lo = self.conv(lo, f'backbone.img_channel_to_lidar.{i}')
+      lanes.hold(lt, lo)
+      with lanes.fork():
+        lo = self.conv(lo, f'backbone.img_channel_to_lidar.{i}')
+        xl = self.upsample_add(lo, xl)
       xi = self.upsample_add(io, xi)
-      xl = self.upsample_add(lo, xl)
+    lanes.join()
     out['image_feature_grid'], out['fused_features'] = xi, xl
 
     # BEV feature pyramid (transfuser.py:131-137)

@@ -45,7 +45,7 @@ class _WholeModel(torch.autograd.Function):
   @staticmethod
   def forward(ctx, model, n_out, rgb, lidar_bev, target_point, ego_vel, command, *params):
     eng = model.engine
-    eng.tape = Tape()
+    eng.tape = Tape(eng.lanes)
     internal = eng.forward(rgb, lidar_bev, target_point, ego_vel, command)
     model.__dict__['_last_internal'] = internal
     outs, seeds = model._export(internal)

@@ -48,6 +48,12 @@ def _chk(t):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM / conv
+def _scratch_key(device):
+  """Scratch buffers are per (device, stream): the encoder branches and the weight-gradient lane run concurrently."""
+  device = torch.device(device)
+  return (str(device), torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
+
+
 _SPLITK_WS = {}
 SPLITK_WS_FLOATS = 16 << 20
 
@@ -55,7 +61,7 @@ SPLITK_WS_FLOATS = 16 << 20
 def splitk_workspace(device):
   """fp32 slices of split-K launches (few output tiles x long reduction); one buffer per device, kernels on a stream run
   in order.  TFPP_SPLITK=0 disables split-K."""
-  key = (str(device), torch.cuda.current_stream(device).cuda_stream)  # one per stream: the side lane runs concurrently
+  key = _scratch_key(device)
   buf = _SPLITK_WS.get(key)
   if buf is None:
     n = SPLITK_WS_FLOATS if _os.environ.get('TFPP_SPLITK', '1') != '0' else 4
@@ -262,7 +268,7 @@ _BN_SCRATCH = {}
 def bn_scratch(c, device, min_floats=0):
   """Shared scratch for the BatchNorm reductions (kernels on one stream run in order, so one buffer serves every layer)."""
   need = max(lib.raw('tfpp_bn_scratch_floats')(c), min_floats)
-  key = str(device)
+  key = _scratch_key(device)
   buf = _BN_SCRATCH.get(key)
   if buf is None or buf.numel() < need:
     buf = torch.empty(max(need, lib.raw('tfpp_bn_scratch_floats')(1512)), device=device, dtype=torch.float32)
@@ -277,7 +283,7 @@ _REDUCE_SCRATCH = {}
 def stats_rows_buffer(c, device):
   """64 fp32 accumulation rows [64][2*c] for the BatchNorm statistics fused into the conv epilogue.  Zero when handed out
   and zero again after bn_finalize_partials(clear=True) consumed it, so no memset launch sits between layers."""
-  key = str(device)
+  key = _scratch_key(device)
   buf = _STATS_ROWS.get(key)
   if buf is None or buf.numel() < 64 * 2 * c:
     buf = torch.zeros(64 * 2 * max(c, 1512), device=device, dtype=torch.float32)
@@ -288,7 +294,7 @@ def stats_rows_buffer(c, device):
 def reduce_scratch(b, c, device):
   """Stage-1 partials of the two-stage column reductions (mean_hw / se_dgate / colsum)."""
   need = lib.raw('tfpp_reduce_scratch_floats')(b, c)
-  key = str(device)
+  key = _scratch_key(device)
   buf = _REDUCE_SCRATCH.get(key)
   if buf is None or buf.numel() < need:
     buf = torch.empty(max(need, lib.raw('tfpp_reduce_scratch_floats')(12, 1512)), device=device, dtype=torch.float32)

@@ -63,7 +63,7 @@ class Trainer:
     eng.alloc_grads()
     ops.inc_u64(self.seed_offset)
     eng._seed_ctr = 0  # the per-call part of the seeds is a function of the call site only
-    eng.tape = Tape()
+    eng.tape = Tape(eng.lanes)
     t = eng.forward(batch['rgb'], batch['lidar_bev'], batch['target_point'], batch['ego_vel'], batch['command'])
     _, vals, seeds = fused_losses(model, t, batch, self.loss_weights, True)
     tape, eng.tape = eng.tape, None
