@@ -955,77 +955,79 @@ class Engine:
     out['bev'] = bev
 
     # planning head, fp32 (model.py:299-358)
-    dm = cfg.gru_input_size
-    x = self.conv(xl, 'change_channel', out_f32=True)  # [B,8,8,256] fp32
-    hh, ww = x.shape[1], x.shape[2]
-    pos = self._const(f'sine{hh}x{ww}', lambda: m.sine_table(hh, ww))
-    x = self.add_table(x, pos.view(-1))
-    vel = ops.bn1d_scalar(ego_vel.float().contiguous(), m.velocity_normalization.running_mean, m.velocity_normalization.running_var,
-                          m.velocity_normalization.num_batches_tracked, self.training and m.velocity_normalization.training,
-                          m.velocity_normalization.momentum, m.velocity_normalization.eps)
-    es_in = ops.zeros((B, 8), F32, dev)
-    ops.copy_rows(vel, es_in, B, 1, 1, 0, 8, 0)
-    ops.copy_rows(command.float().contiguous(), es_in, B, 6, 6, 0, 8, 1)
-    es = self.linear(es_in, 'extra_sensor_encoder.0', act=ACT_RELU, x_grad=False)
-    es = self.linear(es, 'extra_sensor_encoder.2', act=ACT_RELU)
-    es = self.add_table(es, m.extra_sensor_pos_embed.detach().view(-1), m.extra_sensor_pos_embed)
-    ntok = hh * ww
-    mem = torch.empty((B, ntok + 1, dm), device=dev, dtype=F32)
-    ops.copy_rows(x, mem, B, ntok * dm, ntok * dm, 0, (ntok + 1) * dm, 0)
-    ops.copy_rows(es, mem, B, dm, dm, 0, (ntok + 1) * dm, ntok * dm)
-    if self.tape is not None:
-
-      def bwd_mem(d):
-        dx_ = torch.empty_like(x)
-        des = torch.empty_like(es)
-        ops.copy_rows(d, dx_, B, ntok * dm, (ntok + 1) * dm, 0, ntok * dm, 0)
-        ops.copy_rows(d, des, B, dm, (ntok + 1) * dm, ntok * dm, dm, 0)
-        return dx_, des
-
-      self.rec([mem], [x, es], bwd_mem)
-    out['memory'] = mem
-
-    def run_queries(qparam, nq):
-      q0 = torch.empty((B, nq, dm), device=dev, dtype=F32)
-      ops.copy_rows(qparam.detach(), q0, B, nq * dm, 0, 0, nq * dm, 0)
+    # on the LiDAR lane (idle after the backbone): ~250 tiny latency-bound launches that overlap with the dense heads below
+    with self.lanes.fork():
+      dm = cfg.gru_input_size
+      x = self.conv(xl, 'change_channel', out_f32=True)  # [B,8,8,256] fp32
+      hh, ww = x.shape[1], x.shape[2]
+      pos = self._const(f'sine{hh}x{ww}', lambda: m.sine_table(hh, ww))
+      x = self.add_table(x, pos.view(-1))
+      vel = ops.bn1d_scalar(ego_vel.float().contiguous(), m.velocity_normalization.running_mean, m.velocity_normalization.running_var,
+                            m.velocity_normalization.num_batches_tracked, self.training and m.velocity_normalization.training,
+                            m.velocity_normalization.momentum, m.velocity_normalization.eps)
+      es_in = ops.zeros((B, 8), F32, dev)
+      ops.copy_rows(vel, es_in, B, 1, 1, 0, 8, 0)
+      ops.copy_rows(command.float().contiguous(), es_in, B, 6, 6, 0, 8, 1)
+      es = self.linear(es_in, 'extra_sensor_encoder.0', act=ACT_RELU, x_grad=False)
+      es = self.linear(es, 'extra_sensor_encoder.2', act=ACT_RELU)
+      es = self.add_table(es, m.extra_sensor_pos_embed.detach().view(-1), m.extra_sensor_pos_embed)
+      ntok = hh * ww
+      mem = torch.empty((B, ntok + 1, dm), device=dev, dtype=F32)
+      ops.copy_rows(x, mem, B, ntok * dm, ntok * dm, 0, (ntok + 1) * dm, 0)
+      ops.copy_rows(es, mem, B, dm, dm, 0, (ntok + 1) * dm, ntok * dm)
       if self.tape is not None:
 
-        def bwd_q(d):
-          if qparam.requires_grad:
-            ops.colsum(d, self.g(qparam).view(-1), B, nq * dm, nq * dm)
-          return ()
+        def bwd_mem(d):
+          dx_ = torch.empty_like(x)
+          des = torch.empty_like(es)
+          ops.copy_rows(d, dx_, B, ntok * dm, (ntok + 1) * dm, 0, ntok * dm, 0)
+          ops.copy_rows(d, des, B, dm, (ntok + 1) * dm, ntok * dm, dm, 0)
+          return dx_, des
 
-        self.rec([q0], [], bwd_q)
-      return self.decoder(q0, mem, B, nq, ntok + 1)
+        self.rec([mem], [x, es], bwd_mem)
+      out['memory'] = mem
 
-    out['pred_wp'] = out['pred_target_speed'] = out['pred_checkpoint'] = None
-    if cfg.use_wp_gru:
-      nq = cfg.pred_len // cfg.wp_dilation
-      j = run_queries(m.wp_query, nq)
-      out['pred_wp'] = self.gru_decoder(j, target_point.float().contiguous(), m.wp_decoder, 'wp_decoder', B, nq)
-    if cfg.use_controller_input_prediction:
-      n = cfg.predict_checkpoint_len
-      j = run_queries(m.checkpoint_query, n + 1)
-      out['joined'] = j
-      gf = torch.empty((B, n, dm), device=dev, dtype=F32)
-      tsf = torch.empty((B, dm), device=dev, dtype=F32)
-      ops.copy_rows(j, gf, B, n * dm, (n + 1) * dm, 0, n * dm, 0)
-      ops.copy_rows(j, tsf, B, dm, (n + 1) * dm, n * dm, dm, 0)
-      if self.tape is not None:
+      def run_queries(qparam, nq):
+        q0 = torch.empty((B, nq, dm), device=dev, dtype=F32)
+        ops.copy_rows(qparam.detach(), q0, B, nq * dm, 0, 0, nq * dm, 0)
+        if self.tape is not None:
 
-        def bwd_j(dg, dt2):
-          d = ops.zeros((B, n + 1, dm), F32, dev)
-          if dg is not None:
-            ops.copy_rows(dg, d, B, n * dm, n * dm, 0, (n + 1) * dm, 0)
-          if dt2 is not None:
-            ops.copy_rows(dt2, d, B, dm, dm, 0, (n + 1) * dm, n * dm)
-          return d
+          def bwd_q(d):
+            if qparam.requires_grad:
+              ops.colsum(d, self.g(qparam).view(-1), B, nq * dm, nq * dm)
+            return ()
 
-        self.rec([gf, tsf], [j], bwd_j)
-      out['pred_checkpoint'] = self.gru_decoder(gf, target_point.float().contiguous(), m.checkpoint_decoder, 'checkpoint_decoder',
-                                                B, n)
-      ts = self.linear(tsf, 'target_speed_network.0', act=ACT_RELU)
-      out['pred_target_speed'] = self.linear(ts, 'target_speed_network.2')  # [B, 8] (4 real)
+          self.rec([q0], [], bwd_q)
+        return self.decoder(q0, mem, B, nq, ntok + 1)
+
+      out['pred_wp'] = out['pred_target_speed'] = out['pred_checkpoint'] = None
+      if cfg.use_wp_gru:
+        nq = cfg.pred_len // cfg.wp_dilation
+        j = run_queries(m.wp_query, nq)
+        out['pred_wp'] = self.gru_decoder(j, target_point.float().contiguous(), m.wp_decoder, 'wp_decoder', B, nq)
+      if cfg.use_controller_input_prediction:
+        n = cfg.predict_checkpoint_len
+        j = run_queries(m.checkpoint_query, n + 1)
+        out['joined'] = j
+        gf = torch.empty((B, n, dm), device=dev, dtype=F32)
+        tsf = torch.empty((B, dm), device=dev, dtype=F32)
+        ops.copy_rows(j, gf, B, n * dm, (n + 1) * dm, 0, n * dm, 0)
+        ops.copy_rows(j, tsf, B, dm, (n + 1) * dm, n * dm, dm, 0)
+        if self.tape is not None:
+
+          def bwd_j(dg, dt2):
+            d = ops.zeros((B, n + 1, dm), F32, dev)
+            if dg is not None:
+              ops.copy_rows(dg, d, B, n * dm, n * dm, 0, (n + 1) * dm, 0)
+            if dt2 is not None:
+              ops.copy_rows(dt2, d, B, dm, dm, 0, (n + 1) * dm, n * dm)
+            return d
+
+          self.rec([gf, tsf], [j], bwd_j)
+        out['pred_checkpoint'] = self.gru_decoder(gf, target_point.float().contiguous(), m.checkpoint_decoder, 'checkpoint_decoder',
+                                                  B, n)
+        ts = self.linear(tsf, 'target_speed_network.0', act=ACT_RELU)
+        out['pred_target_speed'] = self.linear(ts, 'target_speed_network.2')  # [B, 8] (4 real)
 
     # auxiliary dense heads
     out['pred_semantic'] = self.perspective_decoder(xi, 'semantic_decoder') if cfg.use_semantic else None
@@ -1043,6 +1045,7 @@ class Engine:
         h = self.conv(bev, f'head.{br}_head.0', act=ACT_RELU)
         bbs.append(self.conv(h, f'head.{br}_head.2', act=ACT_SIGMOID if br == 'heatmap' else ACT_NONE))
       out['bb'] = bbs
+    self.lanes.join()
     return out
 
   def perspective_decoder(self, x, name):
