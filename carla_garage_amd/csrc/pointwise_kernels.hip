@@ -1044,6 +1044,79 @@ __device__ __forceinline__ void pack_one(const tfpp_pack_desc& d, long i) {
   }
 }
 
+// Fast paths (mode in a[7], set by tfpp_pack_desc_plan):
+//   1  contiguous cast copy (1x1 forward image without padding): 8 elements per thread, 16-byte stores
+//   2  tiled transpose (1x1 data-gradient image, transposed pack2d incl. head-padding maps): a workgroup owns a
+//      64 (destination rows = source-contiguous index) x 32 (destination columns) tile, reads the source coalesced, turns the
+//      tile in LDS and writes 16-byte row segments.  The element-wise path read such sources with a stride of a whole row.
+#define PACK_TILE_R 64
+#define PACK_TILE_C 32
+struct PackTileGeom { int rows, cols, groups; };  // destination matrix per group
+__host__ __device__ static inline PackTileGeom pack_tile_geom(const tfpp_pack_desc& d) {
+  PackTileGeom g;
+  if (d.kind == 1) { g.rows = d.a[1]; g.cols = d.a[6]; g.groups = d.a[4]; }   // [cin_g][n_pad] per group
+  else { g.rows = d.a[0]; g.cols = d.a[1]; g.groups = 1; }                    // pack2d [rows_out][cols_out]
+  return g;
+}
+
+template <typename T> __device__ __forceinline__ void pack_store8(T* dst, const float* v, int nvalid);
+template <> __device__ __forceinline__ void pack_store8<bf16_t>(bf16_t* dst, const float* v, int nvalid) {
+  if (nvalid >= 8 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) store_vec<bf16_t>(dst, v);
+  else for (int e = 0; e < nvalid && e < 8; ++e) dst[e] = f2bf(v[e]);
+}
+template <> __device__ __forceinline__ void pack_store8<float>(float* dst, const float* v, int nvalid) {
+  if (nvalid >= 8 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) { store_vec<float>(dst, v); store_vec<float>(dst + 4, v + 4); }
+  else for (int e = 0; e < nvalid && e < 8; ++e) dst[e] = v[e];
+}
+
+template <typename T> __device__ __forceinline__ void pack_tile_transpose(const tfpp_pack_desc& d, long rel_block, float* lds) {
+  const PackTileGeom gm = pack_tile_geom(d);
+  const int tiles_c = (gm.cols + PACK_TILE_C - 1) / PACK_TILE_C, tiles_r = (gm.rows + PACK_TILE_R - 1) / PACK_TILE_R;
+  const int tc = (int)(rel_block % tiles_c);
+  const long t2 = rel_block / tiles_c;
+  const int tr = (int)(t2 % tiles_r), g = (int)(t2 / tiles_r);
+  const int r0 = tr * PACK_TILE_R, c0 = tc * PACK_TILE_C, tid = threadIdx.x;
+  {  // load: thread = (destination column, 8 consecutive destination rows = 8 consecutive source elements)
+    const int col = tid >> 3, rch = tid & 7, c = c0 + col;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (c < gm.cols) {
+      if (d.kind == 1) {
+        const int n_g = d.a[0] / d.a[4], cin_g = d.a[1];
+        if (c < n_g) {
+          const float* sp = d.src + ((size_t)g * n_g + c) * cin_g;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const int r = r0 + rch * 8 + e; if (r < gm.rows) v[e] = sp[r]; }
+        }
+      } else {
+        const int sc = d.col_map ? d.col_map[c] : c;
+        if (sc >= 0) {
+          const float* sp = d.src + (size_t)sc * d.in_ld;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int r = r0 + rch * 8 + e;
+            if (r < gm.rows) { const int sr = d.row_map ? d.row_map[r] : r; if (sr >= 0) v[e] = sp[sr]; }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds[(rch * 8 + e) * (PACK_TILE_C + 1) + col] = v[e];
+  }
+  __syncthreads();
+  {  // store: thread = (destination row, 8 consecutive destination columns)
+    const int row = tid >> 2, cch = tid & 3, r = r0 + row, c = c0 + cch * 8;
+    if (r < gm.rows && c < gm.cols) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = lds[row * (PACK_TILE_C + 1) + cch * 8 + e];
+      const size_t off = d.kind == 1 ? ((size_t)g * gm.rows + r) * gm.cols + c : (size_t)r * d.out_ld + c;
+      pack_store8<T>(reinterpret_cast<T*>(d.dst) + off, v, gm.cols - c);
+    }
+  }
+}
+
 __global__ void pack_multi_kernel(const tfpp_pack_desc* __restrict__ descs, int n) {
   // binary search: last descriptor with blk_start <= blockIdx.x
   int lo = 0, hi = n - 1;
@@ -1054,13 +1127,46 @@ __global__ void pack_multi_kernel(const tfpp_pack_desc* __restrict__ descs, int 
     else hi = mid - 1;
   }
   const tfpp_pack_desc d = descs[lo];
+  const int mode = d.a[7];
+  if (mode == 2) {
+    __shared__ float lds[PACK_TILE_R * (PACK_TILE_C + 1)];
+    if (d.dtype == TFPP_F32) pack_tile_transpose<float>(d, b - d.blk_start, lds);
+    else pack_tile_transpose<bf16_t>(d, b - d.blk_start, lds);
+    return;
+  }
   const long base = (b - d.blk_start) * PACK_ELEMS_PER_BLOCK;
+  if (mode == 1) {
+    const long i = base + (long)threadIdx.x * 8;
+    if (i < d.total) {
+      float v[8];
+      const int nv = d.total - i < 8 ? (int)(d.total - i) : 8;
+      for (int e = 0; e < 8; ++e) v[e] = e < nv ? d.src[i + e] : 0.f;
+      if (d.dtype == TFPP_F32) pack_store8<float>(reinterpret_cast<float*>(d.dst) + i, v, nv);
+      else pack_store8<bf16_t>(reinterpret_cast<bf16_t*>(d.dst) + i, v, nv);
+    }
+    return;
+  }
   for (int e = threadIdx.x; e < PACK_ELEMS_PER_BLOCK; e += blockDim.x) {
     const long i = base + e;
     if (i >= d.total) break;
     if (d.dtype == TFPP_F32) pack_one<float>(d, i);
     else pack_one<bf16_t>(d, i);
   }
+}
+
+// Host side of the table: choose the path for a descriptor (written to a[7]) and return the workgroups it needs.
+extern "C" int tfpp_pack_desc_plan(tfpp_pack_desc* d) {
+  if (!d) return TFPP_EINVAL;
+  int mode = 0;
+  if (d->kind == 0 && d->a[2] * d->a[3] == 1 && d->a[5] == d->a[1] && d->a[6] * d->a[4] == d->a[0]) mode = 1;
+  else if (d->kind == 1 && d->a[2] * d->a[3] == 1) mode = 2;
+  else if (d->kind == 2 && d->a[2] != 0) mode = 2;
+  d->a[7] = mode;
+  if (mode == 2) {
+    const PackTileGeom g = pack_tile_geom(*d);
+    return g.groups * ((g.rows + PACK_TILE_R - 1) / PACK_TILE_R) * ((g.cols + PACK_TILE_C - 1) / PACK_TILE_C);
+  }
+  return (int)((d->total + PACK_ELEMS_PER_BLOCK - 1) / PACK_ELEMS_PER_BLOCK);
 }
 
 extern "C" int tfpp_pack_elems_per_block(void) { return PACK_ELEMS_PER_BLOCK; }

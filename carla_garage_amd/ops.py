@@ -181,11 +181,11 @@ class PackPlan:
     self.keep += [src, dst, row_map, col_map]
 
   def finalize(self, device):
-    per = lib.raw('tfpp_pack_elems_per_block')()
+    plan = lib.raw('tfpp_pack_desc_plan')
     blk = 0
     for d in self.descs:
       d.blk_start = blk
-      blk += (d.total + per - 1) // per
+      blk += plan(ctypes.byref(d))
     self.total_blocks = blk
     raw = b''.join(bytes(d) for d in self.descs)
     self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)

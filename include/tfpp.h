@@ -133,7 +133,7 @@ int tfpp_pack2d(const float* in, void* out, const int* row_map, const int* col_m
 int tfpp_cast(const void* in, void* out, int64_t n, int dtype_in, int dtype_out, void* stream);
 /* All per-step weight images in ONE launch: a device-resident table of descriptors (kind 0/1 = tfpp_pack_conv_weight
  * forward / transposed with a = {Cout, cin_g, R, S, G, ks_pad, n_pad}; kind 2 = tfpp_pack2d with a = {rows_out, cols_out,
- * transpose_in}).  Descriptor i owns workgroups [blk_start, blk_start + ceil(total / tfpp_pack_elems_per_block())). */
+ * transpose_in}).  Descriptor i owns workgroups [blk_start, blk_start + tfpp_pack_desc_plan(&desc_i)). */
 typedef struct {
   const float* src; void* dst; const int* row_map; const int* col_map;
   int64_t total, in_ld, out_ld, blk_start;
@@ -141,6 +141,9 @@ typedef struct {
   int a[8];
 } tfpp_pack_desc;
 int tfpp_pack_elems_per_block(void);
+/* host side of the table: picks the packing path for *d (stored in d->a[7]: 0 element-wise, 1 contiguous cast, 2 LDS-tiled
+ * transpose) and returns the number of workgroups the descriptor owns (blk_start of the next one = blk_start + that). */
+int tfpp_pack_desc_plan(tfpp_pack_desc* d);
 int tfpp_pack_multi(const tfpp_pack_desc* descs_dev, int n, int64_t total_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------

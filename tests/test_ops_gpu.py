@@ -214,6 +214,55 @@ def test_pack2d(ops, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_pack_multi_matches_single_tensor_packing(ops, dtype):
+  """The one-launch multi-tensor pack (vector copy / LDS-tiled transpose / element-wise paths) against the per-tensor kernels."""
+  g = torch.Generator().manual_seed(5)
+  ws = {'pw': torch.rand(200, 72, 1, 1, generator=g), 'pw_big': torch.rand(1512, 576, 1, 1, generator=g),
+        'k3': torch.rand(48, 24, 3, 3, generator=g), 'odd': torch.rand(7, 30, 1, 1, generator=g)}
+  ws = {k: dev(v) for k, v in ws.items()}
+  lin = dev(torch.rand(90, 70, generator=g))
+  rmap = dev(torch.tensor([i if i % 5 else -1 for i in range(96)], dtype=torch.int32).clamp(max=69))
+  cmap = dev(torch.tensor([89 - i if i % 7 else -1 for i in range(88)], dtype=torch.int32))
+
+  def run_all():
+    out = []
+    out.append(ops.pack_conv_weight(ws['pw'], dtype))
+    out.append(ops.pack_conv_weight(ws['pw'], dtype, transpose=True))
+    out.append(ops.pack_conv_weight(ws['pw_big'], dtype))
+    out.append(ops.pack_conv_weight(ws['pw_big'], dtype, transpose=True))
+    out.append(ops.pack_conv_weight(ws['pw'], dtype, G=2, transpose=True))
+    out.append(ops.pack_conv_weight(ws['k3'], dtype, G=2))
+    out.append(ops.pack_conv_weight(ws['k3'], dtype, G=2, transpose=True))
+    out.append(ops.pack_conv_weight(ws['odd'], dtype, ks_pad=32, n_pad=8))
+    out.append(ops.pack_conv_weight(ws['odd'], dtype, n_pad=8, transpose=True))
+    a = torch.zeros((96, 72), device=DEV, dtype=dtype)
+    out.append(ops.pack2d(lin, a, 90, 70, 70, 72))
+    b = torch.zeros((70, 96), device=DEV, dtype=dtype)
+    out.append(ops.pack2d(lin, b, 70, 90, 70, 96, transpose_in=True))
+    c = torch.zeros((96, 88), device=DEV, dtype=dtype)
+    out.append(ops.pack2d(lin, c, 96, 88, 70, 88, row_map=cmap[:1].new_tensor([min(i, 89) if i % 5 else -1 for i in range(96)]), col_map=rmap[:88]))
+    d = torch.zeros((96, 88), device=DEV, dtype=dtype)
+    out.append(ops.pack2d(lin, d, 96, 88, 70, 88, row_map=rmap, col_map=cmap, transpose_in=True))
+    return out
+
+  want = run_all()
+  torch.cuda.synchronize()
+  plan = ops.PackPlan()
+  ops.PACK_PLAN = plan
+  try:
+    got = run_all()
+  finally:
+    ops.PACK_PLAN = None
+  plan.finalize(DEV)
+  plan.launch()
+  torch.cuda.synchronize()
+  modes = sorted({int(d.a[7]) for d in plan.descs})
+  assert modes == [0, 1, 2], modes
+  for i, (gt, wt) in enumerate(zip(got, want)):
+    assert torch.equal(gt.float().cpu(), wt.float().cpu()), f'pack #{i} differs'
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('C', [32, 72, 1512])
 def test_batchnorm_train_and_backward(ops, dtype, C):
   B, H, W = 3, 12, 20
