@@ -17,3 +17,7 @@ bool conv_halo_supported(const tfpp_conv_params& p, int dtype);
 int conv_halo_variant(const tfpp_conv_params& p);
 int conv_halo_mtiles(const tfpp_conv_params& p);
 int conv_gemm_halo(const tfpp_conv_params& p, hipStream_t st);
+
+// weight gradient with the LDS-DMA ring + hardware transpose reads (gemm_wgrad_glds.hip), bf16, 64 x 64 tiles
+bool wgrad_glds_supported(const tfpp_wgrad_params& p, int dtype);
+int conv_wgrad_glds(const tfpp_wgrad_params& p, hipStream_t st);

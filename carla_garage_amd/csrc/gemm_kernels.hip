@@ -552,7 +552,8 @@ template <typename T> static int dispatch_wgrad(tfpp_wgrad_params p, hipStream_t
     if (fit >= 2) p.splits = (int)fit;
     else p.ws = nullptr;  // atomics
   }
-  const int rc = small ? launch_wgrad<T, 32, 32, 16, 16>(p, st) : launch_wgrad<T, 64, 64, 32, 32>(p, st);
+  const int rc = small ? launch_wgrad<T, 32, 32, 16, 16>(p, st)
+                       : (wgrad_glds_supported(p, ElemTraits<T>::DT) ? conv_wgrad_glds(p, st) : launch_wgrad<T, 64, 64, 32, 32>(p, st));
   if (rc != 0 || !p.ws || p.splits <= 1) return rc;
   if (p.splits >= 32) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((slice + 15) / 16)), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((slice + 63) / 64)), dim3(256), 0, st, p);

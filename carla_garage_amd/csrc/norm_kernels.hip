@@ -416,22 +416,17 @@ extern "C" int tfpp_layernorm_fwd(const void* x, const float* gamma, const float
 }
 
 // each wave walks rows_per_wave rows, accumulating dgamma/dbeta partials in registers, one atomic per channel at the end
+// dx only: the parameter gradients are a separate column reduction (layernorm_param_grad_kernel), which keeps this kernel's
+// live state to the row itself (g, xhat, gamma) instead of two more per-channel accumulators.
 template <typename T, int LN_MAXV>
 __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
-                                     const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int C, int rows_per_wave) {
+                                     const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx, long rows, int C,
+                                     int rows_per_wave) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const int CV = C / VEC;
   const int lane = threadIdx.x & 63;
   const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long r0 = w * rows_per_wave;
-  float ag[LN_MAXV][VEC], ab[LN_MAXV][VEC], gm[LN_MAXV][VEC];
-#pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
-    const int cv = lane + k * 64;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; gm[k][e] = (cv < CV) ? gamma[cv * VEC + e] : 0.f; }
-  }
   for (long row = r0; row < r0 + rows_per_wave && row < rows; ++row) {
     const float mu = mean[row], rs = rstd[row];
     float g[LN_MAXV][VEC], xh[LN_MAXV][VEC];
@@ -440,15 +435,15 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
     for (int k = 0; k < LN_MAXV; ++k) {
       const int cv = lane + k * 64;
       if (cv < CV) {
-        float v[VEC];
+        float v[VEC], gm[VEC];
         load_vec<T>(dy + (size_t)row * C + cv * VEC, g[k]);
         load_vec<T>(x + (size_t)row * C + cv * VEC, v);
+        load_vec<float>(gamma + cv * VEC, gm);
+        if (VEC == 8) load_vec<float>(gamma + cv * VEC + 4, gm + 4);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           xh[k][e] = (v[e] - mu) * rs;
-          ag[k][e] += g[k][e] * xh[k][e];
-          ab[k][e] += g[k][e];
-          g[k][e] *= gm[k][e];
+          g[k][e] *= gm[e];
           c1 += g[k][e];
           c2 += g[k][e] * xh[k][e];
         }
@@ -464,19 +459,6 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = rs * (g[k][e] - c1 - xh[k][e] * c2);
         store_vec<T>(dx + (size_t)row * C + cv * VEC, o);
-      }
-    }
-  }
-  if (r0 < rows) {
-#pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
-      const int cv = lane + k * 64;
-      if (cv < CV) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          if (dgamma) atomicAdd(dgamma + cv * VEC + e, ag[k][e]);
-          if (dbeta) atomicAdd(dbeta + cv * VEC + e, ab[k][e]);
-        }
       }
     }
   }
@@ -521,8 +503,7 @@ extern "C" int tfpp_layernorm_bwd(const void* dy, const void* x, const float* ga
   const int rpw = 1;  // dx: one wave per row, no atomics (parameter gradients come from the column-reduction kernel below)
   const long waves = (rows + rpw - 1) / rpw;
   dim3 grid((unsigned)((waves + 3) / 4));
-  float* nullf = nullptr;
-#define LN_BWD(TT, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, MV>), grid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, gamma, mean, rstd, (TT*)dx, nullf, nullf, (long)rows, C, rpw)
+#define LN_BWD(TT, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, MV>), grid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, gamma, mean, rstd, (TT*)dx, (long)rows, C, rpw)
 #define LN_BWD_T(TT) do { if (nv <= 1) LN_BWD(TT, 1); else if (nv <= 2) LN_BWD(TT, 2); else if (nv <= 3) LN_BWD(TT, 3); else if (nv <= 4) LN_BWD(TT, 4); else LN_BWD(TT, 6); } while (0)
   if (dtype == TFPP_F32) LN_BWD_T(float); else LN_BWD_T(bf16_t);
   if (dgamma || dbeta) {

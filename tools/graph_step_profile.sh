@@ -1,0 +1,34 @@
+#!/bin/bash
+# rocprofv3 kernel trace of hipGraph-replayed training steps; prints span / busy time of the last step and writes the
+# per-kernel table of that step to gpurun_out/graph_step_kernels.txt.  Run on the GPU box from the repo root.
+set -e
+REPO=$(pwd)
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-inference --no-roofline > $REPO/gpurun_out/prof_bench.log 2>&1
+t=$(find /tmp/prof -name "*kernel_trace.csv" | head -1)
+python - "$t" "$REPO/gpurun_out/graph_step_kernels.txt" <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
+a, b = idx[-2] + 1, idx[-1] + 1
+step = rows[a:b]
+t0 = min(int(r["Start_Timestamp"]) for r in step); t1 = max(int(r["End_Timestamp"]) for r in step)
+busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step)
+# union of busy intervals (streams overlap)
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in step)
+cov, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+for s, e in iv[1:]:
+    if s > cur_e: cov += cur_e - cur_s; cur_s, cur_e = s, e
+    else: cur_e = max(cur_e, e)
+cov += cur_e - cur_s
+print("last step: %d kernels, span %.2f ms, sum of kernel durations %.2f ms, time with >=1 kernel running %.2f ms" % (len(step), (t1 - t0) / 1e6, busy / 1e6, cov / 1e6))
+agg = collections.defaultdict(lambda: [0, 0])
+for r in step:
+    k = r["Kernel_Name"][:100]; agg[k][0] += 1; agg[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+with open(sys.argv[2], "w") as out:
+    out.write("# kernel | calls | total_ms | avg_us   (one hipGraph-replayed training step, bs=12 bf16)\n")
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        out.write("%-102s %5d %9.3f ms %8.2f us\n" % (k, v[0], v[1] / 1e6, v[1] / v[0] / 1e3))
+PY
