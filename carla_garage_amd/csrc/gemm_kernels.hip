@@ -534,6 +534,16 @@ template <typename T> static int dispatch_wgrad(tfpp_wgrad_params p, hipStream_t
   if (p.ks_g % VEC != 0 || p.n_g % VEC != 0 || p.x_ld % VEC != 0 || p.dy_ld % VEC != 0) return TFPP_EINVAL;
   const long P = (long)p.B * p.Hd * p.Wd;
   const int KK = p.R * p.S * p.ks_g;
+  if (const int hs = wgrad_halo_slices(p, ElemTraits<T>::DT)) {  // 3x3 stride 1, few channels: halo tiles staged once in LDS
+    p.splits = hs;
+    const int rc = conv_wgrad_halo(p, hs, st);
+    if (rc != 0) return rc;
+    const long sl = (long)p.G * p.n_g * KK;
+    if (hs >= 32) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((sl + 15) / 16)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((sl + 63) / 64)), dim3(256), 0, st, p);
+    TFPP_CHECK_LAUNCH();
+    return 0;
+  }
   const bool small = (p.n_g <= 32 || KK <= 32);
   const bool big = false;  // 128x128 weight-gradient tiles measured slower (atomic traffic, fewer workgroups)
   const int bm = small ? 32 : (big ? 128 : 64), bn = bm;

@@ -24,6 +24,15 @@ for s, e in iv[1:]:
     else: cur_e = max(cur_e, e)
 cov += cur_e - cur_s
 print("last step: %d kernels, span %.2f ms, sum of kernel durations %.2f ms, time with >=1 kernel running %.2f ms" % (len(step), (t1 - t0) / 1e6, busy / 1e6, cov / 1e6))
+qkey = "Queue_Id" if "Queue_Id" in step[0] else None
+if qkey:
+    perq = collections.defaultdict(lambda: [0, 0, collections.defaultdict(float)])
+    for r in step:
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        q = perq[r[qkey]]; q[0] += 1; q[1] += d; q[2][r["Kernel_Name"][:60]] += d
+    for qid, (n, busy_q, ks) in sorted(perq.items(), key=lambda kv: -kv[1][1]):
+        top = ", ".join("%s %.2f" % (k[:40], v / 1e6) for k, v in sorted(ks.items(), key=lambda kv: -kv[1])[:6])
+        print("queue %s: %d kernels, busy %.2f ms; top: %s" % (qid, n, busy_q / 1e6, top))
 agg = collections.defaultdict(lambda: [0, 0])
 for r in step:
     k = r["Kernel_Name"][:100]; agg[k][0] += 1; agg[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
