@@ -301,7 +301,7 @@ template <int BM, int BN, int NSTAGE, int WGM, int WGN> static int launch_glds(c
 int conv_glds_variant(const tfpp_conv_params& p) {
   const long M = (long)p.B * p.Hd * p.Wd;
   const long tiles = (long)cdiv(M, 128) * cdiv(p.n_g, 128) * p.G;
-  static const int min_tiles = [] { const char* e = std::getenv("TFPP_GLDS_128_MIN_TILES"); return e ? std::atoi(e) : 512; }();
+  static const int min_tiles = [] { const char* e = std::getenv("TFPP_GLDS_128_MIN_TILES"); return e ? std::atoi(e) : 256; }();
   return tiles >= min_tiles ? 200 : 201;
 }
 

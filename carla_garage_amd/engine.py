@@ -97,6 +97,7 @@ class Tape:
     self.nodes = []
     self.lanes = lanes
     self.frozen = {}      # id(tensor) -> tensor: handed to another stream, must not be accumulated into in place
+    self._grads = None    # pending gradients while backward() runs (take_pending)
     self.finalizers = []  # run once at the end of backward (joins side streams)
 
   def record(self, outs, ins, fn, lane=0):
@@ -105,13 +106,36 @@ class Tape:
   def freeze(self, t):
     self.frozen[id(t)] = t
 
+  def take_pending(self, t, like=None):
+    """Remove and return the gradient already accumulated for tensor ``t`` (None if there is none, or if it must not be
+    consumed: shared with another key, frozen for the weight-gradient lane, or of another dtype/size than ``like``).  The
+    caller adds it inside its own kernel -- the residual operand of the data-gradient GEMM epilogue -- and returns the sum
+    as the gradient of ``t``, which saves the separate accumulation pass over the tensor."""
+    if self._grads is None:
+      return None
+    k = _key(t)
+    cur = self._grads.get(k)
+    if cur is None or self._refs.get(id(cur), 0) > 1 or id(cur) in self.frozen:
+      return None
+    if like is not None and (cur.dtype != like.dtype or cur.numel() != like.numel()):
+      return None
+    if self._multi and self._glane[k] != self._lane:
+      self.lanes.stream(self._lane).wait_stream(self.lanes.stream(self._glane[k]))
+      self.lanes.hold(cur)
+    del self._grads[k]
+    self._glane.pop(k, None)
+    self._refs[id(cur)] = self._refs.get(id(cur), 1) - 1
+    return cur
+
   def backward(self, seeds):
     """seeds: list of (tensor, grad)."""
     grads, refs, glane = {}, {}, {}
+    self._grads, self._refs, self._glane, self._lane = grads, refs, glane, 0
     lanes = self.lanes
     if lanes is not None and seeds:
       lanes.begin(seeds[0][1].device)
     multi = lanes is not None and lanes.on()
+    self._multi = multi
 
     def sync(to_lane, from_lane):
       if multi and to_lane != from_lane:
@@ -158,6 +182,7 @@ class Tape:
         continue
       ctx = torch.cuda.stream(lanes.stream(lane)) if multi and lane != 0 else contextlib.nullcontext()
       with ctx:
+        self._lane = lane
         if multi:
           lanes.cur = lane
         for sl in src_lanes:
@@ -172,6 +197,7 @@ class Tape:
         for t, g in zip(ins, gins):
           acc(t, g, lane)
     self.nodes = []
+    self._grads = None
     if multi:
       lanes.cur = 0
     for fin in self.finalizers:
@@ -522,12 +548,16 @@ class Engine:
           dz = ops.act_bwd(dy, y, act) if act != ACT_NONE else dy
           dres = dz if res is not None else None
           if s.bias is not None and s.bias.requires_grad:
-            if s.n_store == s.cout:
-              ops.colsum(dz, self.g(s.bias), B * Ho * Wo, s.cout, s.n_store)
-            else:
-              tmp = ops.zeros(s.n_store, F32, x.device)
-              ops.colsum(dz, tmp, B * Ho * Wo, s.n_store, s.n_store)
-              ops.copy_rows(tmp, self.g(s.bias), 1, s.cout, 0, 0, 0, 0, accumulate=True)
+
+            def bias_grad():  # parameter gradient only: weight-gradient lane
+              if s.n_store == s.cout:
+                ops.colsum(dz, self.g(s.bias), B * Ho * Wo, s.cout, s.n_store)
+              else:
+                tmp = ops.zeros(s.n_store, F32, x.device)
+                ops.colsum(dz, tmp, B * Ho * Wo, s.n_store, s.n_store)
+                ops.copy_rows(tmp, self.g(s.bias), 1, s.cout, 0, 0, 0, 0, accumulate=True)
+
+            self.side.run(Tape.current, bias_grad, dz)
           dconv = dz
         elif bn_train:
           dconv, dres = ops.bn_bwd(dy, y, raw, s.bn.weight.detach(), s.save_mean, s.save_invstd, None, self.g(s.bn.weight),
@@ -540,8 +570,10 @@ class Engine:
         dx = None
         if x_grad:
           dx = torch.empty((B, H, W, Cs), device=x.device, dtype=x.dtype)
+          # a gradient already pending for x (the other path of a residual / FPN fan-out) is added in the GEMM epilogue
+          pend = Tape.current.take_pending(x, dx) if os.environ.get('TFPP_FUSE_GRAD_ACC', '1') != '0' else None
           ops.conv_gemm(gsrc, s.wt, dx, B=B, Hs=Ho, Ws=Wo, Cs=s.n_store, Hd=H, Wd=W, Cd=Cs, R=k, S=k, stride=st, pad=pd, G=G,
-                        ks_g=s.n_store // G, n_g=Cs // G, mode=1)
+                        ks_g=s.n_store // G, n_g=Cs // G, mode=1, res=pend)
         return dx, dres
 
       self.rec([y], [x, res], bwd)
@@ -566,9 +598,7 @@ class Engine:
 
       def bwd(dy):
         dz = ops.act_bwd(dy, y, act) if act != ACT_NONE else dy
-        self.side.run(Tape.current, lambda: gw(dz, x), dz, x)
-        if gb is not None:
-          gb(dz)
+        self.side.run(Tape.current, lambda: (gw(dz, x), gb(dz) if gb is not None else None), dz, x)
         dx = torch.empty((rows, k), device=x.device, dtype=x.dtype)
         ops.conv_gemm(dz, wt, dx, B=rows, Hs=1, Ws=1, Cs=n, Hd=1, Wd=1, Cd=k, mode=1)
         return dx
@@ -829,8 +859,7 @@ class Engine:
       if self.tape is not None:
 
         def bwd(dy):
-          self.side.run(Tape.current, lambda: gw(dy, inp), dy, inp)
-          gb(dy)
+          self.side.run(Tape.current, lambda: (gw(dy, inp), gb(dy)), dy, inp)
           dx = torch.empty((rows, dm), device=inp.device, dtype=F32)
           # dx = dy @ W[r0:r1]  : W slice [n, dm] is k-major for this product -> batched GEMM with b_km
           ops.bgemm(dy, wd[r0:r1], dx, M=rows, N=dm, K=n, lda=n, ldb=dm, ldc=dm, b_km=True)
