@@ -206,3 +206,52 @@ def test_dropin_autograd_path_matches_engine_path():
     worst = max(worst, abs(params[str(name)].grad.double().norm().item() - norm) / norm)
   _report('dropin', {'worst_grad_norm': worst})
   assert worst <= 3e-2
+
+
+@pytest.mark.gpu
+def test_streams_and_hipgraph_do_not_change_the_training_step():
+  """Identical fp32 trainers run two steps on one stream / on the three concurrent lanes / lanes + hipGraph replay: losses
+  and the gradient arena must agree to the run-to-run noise of the single-stream path itself (order of the fp32 atomics
+  of the fused BatchNorm statistics: ~1e-6 on the losses, ~2e-3 relative L2 on the gradients of step 1; a race between
+  streams shows up orders of magnitude above that).  bf16 is not used here: with train-mode BN at batch 2 its
+  run-to-run gradient noise is 0.2 relative L2 on one stream already (tools/streams_probe.py)."""
+  from carla_garage_amd.graph import GraphedTrainStep
+  from carla_garage_amd.trainer import Trainer
+  batch = {k: v.cuda() for k, v in P.make_labels(2).items()}
+  for k, v in zip(('rgb', 'lidar_bev', 'target_point', 'ego_vel', 'command'), P.make_inputs(2)):
+    batch[k] = v.cuda()
+  saved = {k: os.environ.get(k) for k in ('TFPP_BRANCH_STREAMS', 'TFPP_SIDE_STREAM')}
+
+  def run(single, graph):
+    for k in saved:
+      if single:
+        os.environ[k] = '0'
+      else:
+        os.environ.pop(k, None)
+    m = _model('fp32').train()
+    _zero_dropout(m)
+    tr = Trainer(m, lr=1e-5)
+    assert tr.eng.lanes.enabled == (not single) and tr.eng.side.enabled == (not single)
+    v1 = tr.train_step(batch).detach().float().cpu().numpy().copy()
+    g1 = tr.eng.flat_grad.detach().double().cpu().numpy().copy()
+    v2 = (GraphedTrainStep(tr, batch, warmup=0)(batch) if graph else tr.train_step(batch)).detach().float().cpu().numpy().copy()
+    torch.cuda.synchronize()
+    return v1, g1, v2, tr.eng.flat_grad.detach().double().cpu().numpy().copy()
+
+  try:
+    ref = run(True, False)
+    assert all(np.isfinite(a).all() for a in ref)
+    errs = {}
+    for name, args in (('lanes', (False, False)), ('lanes+graph', (False, True))):
+      r = run(*args)
+      errs[name] = {'loss1': float(np.max(np.abs(r[0] - ref[0]) / np.abs(ref[0]))), 'grad1': float(np.linalg.norm(r[1] - ref[1]) / np.linalg.norm(ref[1])),
+                    'loss2': float(np.max(np.abs(r[2] - ref[2]) / np.abs(ref[2]))), 'grad2': float(np.linalg.norm(r[3] - ref[3]) / np.linalg.norm(ref[3]))}
+  finally:
+    for k, v in saved.items():
+      if v is None:
+        os.environ.pop(k, None)
+      else:
+        os.environ[k] = v
+  _report('streams', errs)
+  for name, e in errs.items():
+    assert e['loss1'] < 1e-4 and e['grad1'] < 2e-2 and e['loss2'] < 5e-3 and e['grad2'] < 8e-2, (name, e)
