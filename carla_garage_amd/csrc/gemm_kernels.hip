@@ -327,6 +327,16 @@ extern "C" int tfpp_conv_gemm_splits(const tfpp_conv_params* p, int dtype) {
   return conv_splits_for(*p, dtype);
 }
 
+// exact number of M-tiles (= distinct stats_partial rows) of the kernel the dispatcher runs for (p, dtype)
+extern "C" int tfpp_conv_gemm_stats_rows(const tfpp_conv_params* p, int dtype) {
+  if (!p) return TFPP_EINVAL;
+  const long M = (long)p->B * p->Hd * p->Wd;
+  if (conv_halo_supported(*p, dtype)) return conv_halo_mtiles(*p);
+  if (use_glds_impl() && conv_glds_supported(*p, dtype)) return cdiv(M, conv_glds_variant(*p) == 200 ? 128 : 64);
+  static const int bm[4] = {128, 128, 64, 128};
+  return cdiv(M, bm[conv_variant(*p)]);
+}
+
 template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStream_t st) {
   constexpr int VEC = ElemTraits<T>::VEC;
   if (p.ks_g % VEC != 0 || p.src_ld % VEC != 0 || p.G < 1 || p.B < 1) return TFPP_EINVAL;

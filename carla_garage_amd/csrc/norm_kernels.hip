@@ -195,18 +195,40 @@ extern "C" int tfpp_bn_finalize(const double* ws, const float* gamma, const floa
   return 0;
 }
 
-// The same from accumulation rows (tfpp_conv_params.stats_partial), one wave per channel; re-zeroes the rows it consumed.
+// The same from accumulation rows (tfpp_conv_params.stats_partial); re-zeroes the rows it consumed.  WIDE = false: one wave
+// per channel (<= 256 rows); WIDE = true: one 256-thread workgroup per channel (one row per M-tile on the large feature
+// maps: up to 1536 rows), combined through LDS in a fixed order -- the sum is independent of scheduling either way.
+template <bool WIDE>
 __global__ void bn_finalize_partials_kernel(float* __restrict__ partial, int nrows, const float* __restrict__ gamma,
                                             const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv,
                                             long long* __restrict__ nbt, float* __restrict__ scale, float* __restrict__ shift,
                                             float* __restrict__ save_mean, float* __restrict__ save_invstd, long rows, int C, float momentum,
                                             float eps, int clear) {
-  const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c == 0 && lane == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
-  double s0, s1;
-  partial_pair_sum(partial, nrows, C, c, lane, clear != 0, s0, s1);
-  if (lane != 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = WIDE ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+  if (c == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  double s0 = 0.0, s1 = 0.0;
+  if (WIDE) {
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < nrows; k += 256) {
+      float* row = partial + (size_t)k * 2 * C;
+      a += (double)row[c];
+      b += (double)row[C + c];
+      if (clear) { row[c] = 0.f; row[C + c] = 0.f; }
+    }
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
+    __shared__ double sm[2][4];
+    if (lane == 0) { sm[0][wave] = a; sm[1][wave] = b; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s0 = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
+    s1 = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+  } else {
+    if (c >= C) return;
+    partial_pair_sum(partial, nrows, C, c, lane, clear != 0, s0, s1);
+    if (lane != 0) return;
+  }
   const double n = (double)rows;
   const double m = s0 / n;
   double var = s1 / n - m * m;
@@ -228,9 +250,13 @@ extern "C" int tfpp_bn_finalize_partials(float* partial, int nrows, int clear, c
                                          float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
                                          float* save_invstd, int64_t rows, int C, float momentum, float eps, void* stream) {
   if (!partial || nrows < 1 || !scale || !shift) return TFPP_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nrows, gamma, beta,
-                     running_mean, running_var, (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd, (long)rows, C, momentum,
-                     eps, clear);
+  if (nrows > 256)
+    hipLaunchKernelGGL(bn_finalize_partials_kernel<true>, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nrows, gamma, beta, running_mean,
+                       running_var, (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd, (long)rows, C, momentum, eps, clear);
+  else
+    hipLaunchKernelGGL(bn_finalize_partials_kernel<false>, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nrows, gamma, beta,
+                       running_mean, running_var, (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd, (long)rows, C,
+                       momentum, eps, clear);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

@@ -535,8 +535,7 @@ class Engine:
       raw = None
     else:
       raw = torch.empty((B, Ho, Wo, s.n_store), device=x.device, dtype=odt)
-      acc = ops.stats_rows_buffer(s.n_store, x.device)
-      nrows = ops.conv_gemm(x, s.wp, raw, stats_acc=acc, **geo)  # BN statistics fused into the epilogue
+      nrows, acc = ops.conv_gemm(x, s.wp, raw, stats_acc=True, **geo)  # BN statistics fused into the epilogue
       ops.bn_finalize_partials(acc, nrows, s.bn.weight.detach(), s.bn.bias.detach(), s.bn.running_mean, s.bn.running_var,
                                s.bn.num_batches_tracked, s.scale, s.shift, s.save_mean, s.save_invstd, B * Ho * Wo,
                                s.bn.momentum, s.bn.eps)

@@ -74,8 +74,8 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
               act=ACT_NONE, scale=None, shift=None, res=None, alpha=1.0, dst_nchw=False, src_ld=None, dst_ld=None,
               res_ld=None, stats_ws=None, stats_acc=None, plan_only=False):
   """stats_ws (double[2*Cd]): also produce per-channel sum / sum of squares of the result (fused BatchNorm statistics).
-  stats_acc (zeroed fp32 accumulation rows from stats_rows_buffer()): leave the statistics in the rows for
-  bn_finalize_partials and return the number of rows used."""
+  stats_acc (True, or zeroed fp32 accumulation rows from stats_rows_buffer()): leave the statistics in the rows for
+  bn_finalize_partials and return (number of rows used, rows buffer)."""
   p = ConvParams()
   p.src, p.w, p.dst = ptr(src), ptr(w), ptr(dst)
   p.scale, p.shift, p.res = ptr(scale), ptr(shift), ptr(res)
@@ -94,7 +94,12 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
     return lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p), dt(src)), lib.raw('tfpp_conv_gemm_splits')(ctypes.byref(p), dt(src))
   scratch = None
   if stats_acc is not None:
-    nblk = min(64, lib.raw('tfpp_conv_gemm_mtiles')(ctypes.byref(p)))
+    nblk = lib.raw('tfpp_conv_gemm_stats_rows')(ctypes.byref(p), dt(src))
+    if STATS_ROWS_CAP > 0:
+      nblk = min(STATS_ROWS_CAP, nblk)
+    if stats_acc is True:
+      stats_acc = stats_rows_buffer(Cd, src.device, nblk)
+    assert stats_acc.numel() >= nblk * 2 * Cd
     p.stats_partial, p.stats_rows = ptr(stats_acc), nblk
   elif stats_ws is not None:
     nblk = min(64, lib.raw('tfpp_conv_gemm_mtiles')(ctypes.byref(p)))
@@ -117,7 +122,7 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
     lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g))
   lib.tfpp_conv_gemm(ctypes.byref(p), dt(src), stream())
   if stats_acc is not None:
-    return nblk
+    return nblk, stats_acc
   if stats_ws is not None:
     lib.tfpp_bn_reduce_final(ptr(scratch), ptr(stats_ws), nblk, 2 * Cd, stream())
   return dst
@@ -280,13 +285,19 @@ _STATS_ROWS = {}
 _REDUCE_SCRATCH = {}
 
 
-def stats_rows_buffer(c, device):
-  """64 fp32 accumulation rows [64][2*c] for the BatchNorm statistics fused into the conv epilogue.  Zero when handed out
-  and zero again after bn_finalize_partials(clear=True) consumed it, so no memset launch sits between layers."""
+STATS_ROWS_CAP = int(_os.environ.get('TFPP_BN_STATS_ROWS', '0'))  # 0: one row per M-tile (deterministic); n > 0: fold onto n rows
+
+
+def stats_rows_buffer(c, device, rows=64):
+  """fp32 accumulation rows [rows][2*c] for the BatchNorm statistics fused into the conv epilogue.  Zero when handed out
+  and zero again after bn_finalize_partials(clear=True) consumed it, so no memset launch sits between layers.  With one
+  row per M-tile (the default) every (row, channel) cell receives exactly one addend: the statistics -- and with them the
+  whole bf16 training step -- are bit-reproducible run to run; folding M-tiles onto fewer rows adds them in atomic order."""
   key = _scratch_key(device)
   buf = _STATS_ROWS.get(key)
-  if buf is None or buf.numel() < 64 * 2 * c:
-    buf = torch.zeros(64 * 2 * max(c, 1512), device=device, dtype=torch.float32)
+  need = rows * 2 * c
+  if buf is None or buf.numel() < need:
+    buf = torch.zeros(max(need, 64 * 2 * 1512), device=device, dtype=torch.float32)
     _STATS_ROWS[key] = buf
   return buf
 
