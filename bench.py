@@ -263,11 +263,16 @@ def main():
         pmc = json.load(f)
       if fam in pmc:
         traffic = pmc[fam]['fetch_bytes_per_launch']
-        traffic_note = 'FETCH_SIZE x2 (gfx950 correction), read side only, from profiles/r01_pmc_traffic.json'
+        traffic_note = 'FETCH_SIZE x2 (gfx950 correction)'
+        if pmc[fam].get('write_bytes_per_launch'):
+          traffic += pmc[fam]['write_bytes_per_launch']
+          traffic_note += ' + WRITE_SIZE (raw, uncalibrated on gfx950)'
+        traffic_note += ', separate counter-only rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json'
     except (OSError, ValueError):
       pass
     roof = {'bound': 'mfma', 'kernel': fam, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'traffic': traffic, 'traffic_note': traffic_note, 'algorithmic_flop_per_launch': round(a['flops'] / a['calls']),
+            'algorithmic_bytes_per_launch': round(a['bytes'] / a['calls']) if a.get('bytes') else None,
             'launches_per_step': a['calls'] // nprof, 'avg_launch_us': round(1e3 * a['ms'] / a['calls'], 2),
             'share_of_step_kernel_time': round(a['ms'] / total_ms, 3)}
     if args.kernel_table:

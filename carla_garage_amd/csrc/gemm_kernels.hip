@@ -539,29 +539,26 @@ static int launch_wgrad(const tfpp_wgrad_params& p, hipStream_t st) {
   return 0;
 }
 
-template <typename T> static int dispatch_wgrad(tfpp_wgrad_params p, hipStream_t st) {
+// The plan of one weight-gradient call: which kernel, how many pixel slices, whether a second-stage sum follows.
+// variant: 0 = LDS-staged 32x32, 1 = LDS-staged 64x64, 2 = LDS-DMA ring 64x64 (gemm_wgrad_glds.hip), 3 = 3x3 halo (wgrad3x3_halo.hip)
+struct WgradPlan { int variant, splits, reduce; };
+template <typename T> static int plan_wgrad(tfpp_wgrad_params& p, WgradPlan& pl) {
   constexpr int VEC = ElemTraits<T>::VEC;
   if (p.ks_g % VEC != 0 || p.n_g % VEC != 0 || p.x_ld % VEC != 0 || p.dy_ld % VEC != 0) return TFPP_EINVAL;
   const long P = (long)p.B * p.Hd * p.Wd;
   const int KK = p.R * p.S * p.ks_g;
   if (const int hs = wgrad_halo_slices(p, ElemTraits<T>::DT)) {  // 3x3 stride 1, few channels: halo tiles staged once in LDS
     p.splits = hs;
-    const int rc = conv_wgrad_halo(p, hs, st);
-    if (rc != 0) return rc;
-    const long sl = (long)p.G * p.n_g * KK;
-    if (hs >= 32) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((sl + 15) / 16)), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((sl + 63) / 64)), dim3(256), 0, st, p);
-    TFPP_CHECK_LAUNCH();
+    pl = WgradPlan{3, hs, 1};
     return 0;
   }
   const bool small = (p.n_g <= 32 || KK <= 32);
-  const bool big = false;  // 128x128 weight-gradient tiles measured slower (atomic traffic, fewer workgroups)
-  const int bm = small ? 32 : (big ? 128 : 64), bn = bm;
+  const int bm = small ? 32 : 64, bn = bm;  // 128x128 weight-gradient tiles measured slower (fewer workgroups)
   if (p.splits <= 0) {
-    // enough workgroups to fill 256 CUs several times over, but at least 256 pixels of reduction each
+    // enough workgroups to fill 256 CUs several times over, but at least 512 pixels of reduction each
     const long tiles = (long)cdiv(p.n_g, bm) * cdiv(KK, bn) * p.G;
     long want = (1536 + tiles - 1) / tiles;
-    long maxs = (P + 511) / 512;  // >= 512 pixels of reduction per workgroup amortises its atomic epilogue
+    long maxs = (P + 511) / 512;
     p.splits = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
     if (p.splits >= 8) p.splits = p.splits / 8 * 8;  // whole XCD rounds
     if (p.splits < 1) p.splits = 1;
@@ -572,20 +569,56 @@ template <typename T> static int dispatch_wgrad(tfpp_wgrad_params p, hipStream_t
     if (fit >= 2) p.splits = (int)fit;
     else p.ws = nullptr;  // atomics
   }
-  const int rc = small ? launch_wgrad<T, 32, 32, 16, 16>(p, st)
-                       : (wgrad_glds_supported(p, ElemTraits<T>::DT) ? conv_wgrad_glds(p, st) : launch_wgrad<T, 64, 64, 32, 32>(p, st));
-  if (rc != 0 || !p.ws || p.splits <= 1) return rc;
+  pl.variant = small ? 0 : (wgrad_glds_supported(p, ElemTraits<T>::DT) ? 2 : 1);
+  pl.splits = p.splits;
+  pl.reduce = (p.ws && p.splits > 1) ? 1 : 0;
+  return 0;
+}
+
+template <typename T> static int run_wgrad_stage1(const tfpp_wgrad_params& p, const WgradPlan& pl, hipStream_t st) {
+  switch (pl.variant) {
+    case 3: return conv_wgrad_halo(p, pl.splits, st);
+    case 2: return conv_wgrad_glds(p, st);
+    case 1: return launch_wgrad<T, 64, 64, 32, 32>(p, st);
+    default: return launch_wgrad<T, 32, 32, 16, 16>(p, st);
+  }
+}
+
+static int run_wgrad_reduce(const tfpp_wgrad_params& p, hipStream_t st) {
+  const long slice = (long)p.G * p.n_g * p.R * p.S * p.ks_g;
   if (p.splits >= 32) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((slice + 15) / 16)), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((slice + 63) / 64)), dim3(256), 0, st, p);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
 
+// stage: 0 = both kernels, 1 = first stage only, 2 = slice sum only.  plan_out (nullable): {variant, splits, reduce}.
+template <typename T> static int dispatch_wgrad(tfpp_wgrad_params p, int stage, int* plan_out, hipStream_t st) {
+  WgradPlan pl;
+  int rc = plan_wgrad<T>(p, pl);
+  if (rc != 0) return rc;
+  if (plan_out) { plan_out[0] = pl.variant; plan_out[1] = pl.splits; plan_out[2] = pl.reduce; }
+  if (stage < 0) return 0;  // plan only
+  if (stage != 2) rc = run_wgrad_stage1<T>(p, pl, st);
+  if (rc != 0 || stage == 1 || !pl.reduce) return rc;
+  return run_wgrad_reduce(p, st);
+}
+
 extern "C" int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stream) {
   if (!p || !p->dy || !p->x || !p->dw) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TFPP_F32) return dispatch_wgrad<float>(*p, st);
-  if (dtype == TFPP_BF16) return dispatch_wgrad<bf16_t>(*p, st);
+  if (dtype == TFPP_F32) return dispatch_wgrad<float>(*p, 0, nullptr, st);
+  if (dtype == TFPP_BF16) return dispatch_wgrad<bf16_t>(*p, 0, nullptr, st);
+  return TFPP_EINVAL;
+}
+
+// The same in separately launchable pieces (per-kernel timing in bench.py): stage 1 = first-stage kernel, 2 = slice sum,
+// -1 = plan only.  plan_out[3] = {variant (0 LDS 32x32, 1 LDS 64x64, 2 LDS-DMA ring 64x64, 3 3x3 halo), slices, has second stage}.
+extern "C" int tfpp_conv_wgrad_stage(const tfpp_wgrad_params* p, int dtype, int stage, int* plan_out, void* stream) {
+  if (!p || !p->dy || !p->x || !p->dw || stage == 0 || stage > 2) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TFPP_F32) return dispatch_wgrad<float>(*p, stage, plan_out, st);
+  if (dtype == TFPP_BF16) return dispatch_wgrad<bf16_t>(*p, stage, plan_out, st);
   return TFPP_EINVAL;
 }
 

@@ -119,7 +119,10 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
     fam = f'conv_gemm<{"f32" if src.dtype == torch.float32 else "bf16"},{tile}>'
     if PROFILE_SHAPES:
       fam += f' m{mode} M={B * Hd * Wd} N={p.n_g} K={R * S * p.ks_g} G={G} k{R}s{stride}'
-    lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g))
+    esz = src.element_size()
+    nbytes = (B * Hs * Ws * G * p.ks_g + G * p.n_g * R * S * p.ks_g + (B * Hd * Wd * G * p.n_g if res is not None else 0)) * esz + \
+        B * Hd * Wd * G * p.n_g * dst.element_size()  # source, weights (, residual) read once; destination written once
+    lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g), nbytes)
   lib.tfpp_conv_gemm(ctypes.byref(p), dt(src), stream())
   if stats_acc is not None:
     return nblk, stats_acc
@@ -145,11 +148,23 @@ def conv_wgrad(dy, x, dw, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=
   assert dw.dtype == torch.float32
   ws = splitk_workspace(dy.device)
   p.ws, p.ws_floats = ptr(ws), ws.numel()
-  if lib.profiler is not None:
-    fam = f'conv_wgrad<{"f32" if dy.dtype == torch.float32 else "bf16"}>'
+  if lib.profiler is not None:  # one profiled call per kernel: first stage and slice sum are timed separately
+    plan = (ctypes.c_int * 3)()
+    lib.raw('tfpp_conv_wgrad_stage')(ctypes.byref(p), dt(dy), -1, plan, stream())  # plan only: no launch, not timed
+    kind = ('lds32x32', 'lds64x64', 'glds64x64', 'halo3x3')[plan[0]]
+    fam = f'conv_wgrad<{"f32" if dy.dtype == torch.float32 else "bf16"},{kind}>'
     if PROFILE_SHAPES:
       fam += f' P={B * Hd * Wd} N={p.n_g} K={R * S * p.ks_g} G={G} k{R}s{stride}'
-    lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g))
+    esz = dy.element_size()
+    kk = R * S * p.ks_g
+    # algorithmic bytes: dY and X read once, the fp32 slices (or the gradient itself, read-modify-write) written once
+    nbytes = (B * Hd * Wd * G * p.n_g + B * Hs * Ws * G * p.ks_g) * esz + (plan[1] if plan[2] else 2) * G * p.n_g * kk * 4
+    lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * kk, nbytes)
+    lib.tfpp_conv_wgrad_stage(ctypes.byref(p), dt(dy), 1, None, stream())
+    if plan[2]:
+      lib.profiler.tag('wgrad_slice_sum', 0.0)
+      lib.tfpp_conv_wgrad_stage(ctypes.byref(p), dt(dy), 2, None, stream())
+    return dw
   lib.tfpp_conv_wgrad(ctypes.byref(p), dt(dy), stream())
   return dw
 
