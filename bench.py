@@ -154,7 +154,35 @@ def inference_latency(model, cfg, device, log, iters=20):
       log(f'inference hipGraph capture failed: {type(e).__name__}: {e}')
     log(f'forward bs=1 {dtype}: {out}')
   model.train()
+  out['lidar_histogram_60k_points_us'] = lidar_histogram_latency(cfg, device, log)
   return out
+
+
+def lidar_histogram_latency(cfg, device, log, n=60000, iters=50):
+  """the LiDAR -> BEV histogram that feeds forward() on every tick (data.py:873-906).  HIP path with
+  the points already on the device, and the CPU oracle (numpy, 1 core) beside it as the reported baseline."""
+  import numpy as np
+  from carla_garage_amd.lidar import LidarHistogram
+  from oracle import lidar_port
+  cloud = lidar_port.make_cloud(n, 11)
+  pts = torch.from_numpy(cloud).to(device)
+  hist = LidarHistogram(cfg, device)
+  res = hist(pts, False)
+  assert np.array_equal(res.cpu().numpy(), lidar_port.lidar_to_histogram_features(cloud, False)), 'LiDAR histogram differs from the oracle'
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(iters):
+    hist(pts, False, out=res)
+  e1.record()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(5):
+    lidar_port.lidar_to_histogram_features(cloud, False)
+  cpu = (time.perf_counter() - t0) / 5
+  r = {'hip': round(1e3 * e0.elapsed_time(e1) / iters, 2), 'cpu_numpy_1core': round(1e6 * cpu, 1), 'bit_exact': True}
+  log(f'LiDAR histogram ({n} points): {r}')
+  return r
 
 
 def main():

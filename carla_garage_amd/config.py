@@ -24,6 +24,9 @@ class GlobalConfig:
     self.lidar_resolution_width = 256
     self.lidar_resolution_height = 256
     self.pixels_per_meter = 4.0
+    self.hist_max_per_pixel = 5  # config.py:128
+    self.lidar_split_height = 0.2  # config.py:131
+    self.max_height_lidar = 100.0  # config.py:481
     self.use_ground_plane = False
     self.min_x, self.max_x, self.min_y, self.max_y = -32, 32, -32, 32  # config.py:135-138
     self.min_z_projection, self.max_z_projection = -10, 14  # config.py:141-142

@@ -1,0 +1,60 @@
+"""LiDAR point cloud -> BEV histogram on the GPU: the producer of ``lidar_bev``.
+
+Mirror of ``CARLA_Data.lidar_to_histogram_features`` (team_code/data.py:873-906), which the agent calls on every tick
+(team_code/sensor_agent.py:421-425: numpy ``histogramdd`` on ~60 k points, then a host-to-device copy of the image).  Here
+the raw points go to the device once (720 KB) and the (C, 256, 256) image is produced there, bit-exactly
+(tests/test_lidar.py), ready to be fed to ``LidarCenterNet.forward``.  No CPU fallback: without the HIP library this raises.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import lib
+
+
+class LidarHistogram:
+  """``hist = LidarHistogram(config); lidar_bev = hist(points, use_ground_plane)`` -> float32 CUDA tensor (C, H, W)."""
+
+  def __init__(self, config, device='cuda'):
+    c = config
+    self.device = torch.device(device)
+    if self.device.type != 'cuda':
+      raise RuntimeError('carla_garage_amd.lidar runs on the MI355X HIP path only')
+    # exactly the edges the reference builds (team_code/data.py:883-886); float64 on the device
+    xe = np.linspace(c.min_x, c.max_x, (c.max_x - c.min_x) * int(c.pixels_per_meter) + 1)
+    ye = np.linspace(c.min_y, c.max_y, (c.max_y - c.min_y) * int(c.pixels_per_meter) + 1)
+    self.nx, self.ny = len(xe) - 1, len(ye) - 1
+    self.xe = torch.from_numpy(xe).to(self.device)
+    self.ye = torch.from_numpy(ye).to(self.device)
+    self.hist_max = int(c.hist_max_per_pixel)
+    # the reference compares the float32 heights with Python floats, i.e. in float32 (NumPy weak-scalar rule)
+    self.max_height = float(np.float32(c.max_height_lidar))
+    self.split = float(np.float32(c.lidar_split_height))
+    self.counts = torch.empty(2 * self.nx * self.ny, device=self.device, dtype=torch.int32)
+
+  def __call__(self, lidar, use_ground_plane=False, out=None):
+    if isinstance(lidar, np.ndarray):
+      lidar = torch.from_numpy(np.ascontiguousarray(lidar, dtype=np.float32))
+    pts = lidar.to(self.device, torch.float32, non_blocking=True).contiguous()
+    if pts.dim() != 2 or pts.shape[1] < 3:
+      raise ValueError(f'expected an (N, >=3) point cloud, got {tuple(pts.shape)}')
+    ch = 2 if use_ground_plane else 1
+    if out is None:
+      out = torch.empty((ch, self.ny, self.nx), device=self.device, dtype=torch.float32)
+    lib.load()
+    lib.tfpp_lidar_histogram(ops.ptr(pts) if pts.numel() else None, pts.shape[0], pts.shape[1], ops.ptr(self.xe), self.nx, ops.ptr(self.ye),
+                             self.ny, ops.ptr(self.counts), ops.ptr(out), self.max_height, self.split, int(use_ground_plane), self.hist_max,
+                             ops.stream())
+    return out
+
+
+_CACHE = {}
+
+
+def lidar_to_histogram_features(config, lidar, use_ground_plane, device='cuda'):
+  """Function form with the reference's argument meaning (``self.config`` made explicit); returns a CUDA tensor (C, H, W)."""
+  key = (id(config), str(device))
+  h = _CACHE.get(key)
+  if h is None:
+    h = _CACHE[key] = LidarHistogram(config, device)
+  return h(lidar, use_ground_plane)

@@ -153,6 +153,17 @@ int tfpp_pack_desc_plan(tfpp_pack_desc* d);
 int tfpp_pack_multi(const tfpp_pack_desc* descs_dev, int n, int64_t total_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * LiDAR point cloud -> BEV histogram, the producer of `lidar_bev`: replaces
+ * CARLA_Data.lidar_to_histogram_features (team_code/data.py:873-906, called per tick at team_code/sensor_agent.py:421-425).
+ * points: [n][point_stride >= 3] fp32 (x, y, z, ...); xedges/yedges: the nx+1 / ny+1 float64 bin edges of
+ * np.linspace(min, max, (max-min)*int(pixels_per_meter)+1); counts: int32 scratch [C*ny*nx]; out: [C][ny][nx] fp32 with
+ * C = 2 (below, above lidar_split_height) if use_ground_plane else 1 (above).  numpy.histogramdd bin semantics, counts
+ * clipped at hist_max and divided by it (float64 divide, then float32).  Bit-exact with the reference. */
+int tfpp_lidar_histogram(const float* points, int64_t n, int point_stride, const double* xedges, int nx, const double* yedges, int ny,
+                         int32_t* counts, float* out, float max_height, float split_height, int use_ground_plane, int hist_max,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Boundary layout changes.  nchw_to_nhwc_affine = normalize_imagenet (transfuser_utils.py:542-551) fused with
  * NCHW->NHWC and zero channel padding to `cpad`: out[b,h,w,c] = c<C ? in[b,c,h,w]*mul[c]+add[c] : 0 (mul/add nullable).
  * nhwc_to_nchw writes the caller-facing fp32 NCHW outputs (optionally through an activation, e.g. the depth sigmoid
