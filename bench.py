@@ -154,7 +154,6 @@ def inference_latency(model, cfg, device, log, iters=20):
       log(f'inference hipGraph capture failed: {type(e).__name__}: {e}')
     log(f'forward bs=1 {dtype}: {out}')
   model.train()
-  out['lidar_histogram_60k_points_us'] = lidar_histogram_latency(cfg, device, log)
   return out
 
 
@@ -308,9 +307,10 @@ def main():
         tf = x['flops'] / (x['ms'] * 1e-3) / 1e12 if x['flops'] else 0.0
         print(f'{f:42s} calls/step {x["calls"] // nprof:5d}  ms/step {x["ms"] / nprof:9.3f}  {100 * x["ms"] / total_ms:5.1f}%  {tf:8.1f} TFLOP/s',
               file=sys.stderr)
-  fwd = None
+  fwd = lidar_hist = None
   if rank == 0 and not args.no_inference:
     fwd = inference_latency(model, cfg, device, log)
+    lidar_hist = lidar_histogram_latency(cfg, device, log)
   if world > 1:
     dist.barrier()
 
@@ -330,6 +330,8 @@ def main():
     }
     if fwd is not None:
       line['fwd_ms_per_frame'] = fwd
+    if lidar_hist is not None:
+      line['lidar_histogram_60k_points_us'] = lidar_hist
     if roof is not None:
       line['roofline'] = roof
     if world == 1 and not args.no_cpu_baseline:

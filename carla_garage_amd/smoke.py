@@ -26,4 +26,13 @@ def run(verbose=True):
     if verbose:
       print(f'smoke {name:20s} rel_err {e:.3e}')
     assert e <= 1e-3, f'{name}: rel err {e:.3e} > 1e-3 vs the CPU oracle'
+  # producer of lidar_bev: bit-exact integer/byte work
+  import numpy as np
+  from oracle import lidar_port as L  # checker only
+  from carla_garage_amd.lidar import LidarHistogram
+  cloud = L.make_cloud(20000, 5)
+  hist = LidarHistogram(cfg, dev)(cloud, True).cpu().numpy()
+  assert np.array_equal(hist, L.lidar_to_histogram_features(cloud, True)), 'LiDAR histogram differs from the CPU oracle'
+  if verbose:
+    print('smoke lidar_histogram      bit-exact')
   return worst
