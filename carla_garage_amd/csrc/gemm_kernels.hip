@@ -271,16 +271,6 @@ static int conv_splits(const tfpp_conv_params& p, long tiles, int bk) {
   return sp < 2 ? 1 : (int)sp;
 }
 
-// TFPP_CONV_IMPL=direct selects the barrier-free direct-to-register kernel (gemm_direct.hip) for A/B measurements; the
-// LDS-staged kernels below are the default (measured faster on every shape of this model, profiles/r01_gemm_micro.txt)
-static bool use_direct_impl() {
-  static const int v = [] {
-    const char* e = std::getenv("TFPP_CONV_IMPL");
-    return (e && std::strcmp(e, "direct") == 0) ? 1 : 0;
-  }();
-  return v != 0;
-}
-
 // number of M-tiles (= rows of stats_partial the LDS kernel writes) for p
 extern "C" int tfpp_conv_gemm_mtiles(const tfpp_conv_params* p) {
   if (!p) return TFPP_EINVAL;
@@ -303,7 +293,6 @@ static bool use_glds_impl() {
 
 extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
-  if (use_direct_impl() && !p->stats_partial) return conv_direct_variant(*p, dtype);
   if (conv_halo_supported(*p, dtype)) return conv_halo_variant(*p);
   if (use_glds_impl() && conv_glds_supported(*p, dtype)) return conv_glds_variant(*p);
   return conv_variant(*p);
@@ -323,7 +312,6 @@ static int conv_splits_for(const tfpp_conv_params& p, int dtype) {
 
 extern "C" int tfpp_conv_gemm_splits(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
-  if (use_direct_impl() && !p->stats_partial) return 1;
   return conv_splits_for(*p, dtype);
 }
 
@@ -343,7 +331,6 @@ template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStr
   if (((uintptr_t)p.src & 15) || ((uintptr_t)p.w & 15)) return TFPP_EINVAL;
   const long M = (long)p.B * p.Hd * p.Wd;
   if (M >= (1l << 31) || M * (long)p.dst_ld >= (1l << 40)) return TFPP_EINVAL;
-  if (use_direct_impl() && !p.stats_partial) return conv_gemm_direct(p, ElemTraits<T>::DT, st);
   if (conv_halo_supported(p, ElemTraits<T>::DT)) return conv_gemm_halo(p, st);
   tfpp_conv_params q = p;
   q.splitk = conv_splits_for(p, ElemTraits<T>::DT);
@@ -373,7 +360,7 @@ extern "C" int tfpp_conv_gemm(const tfpp_conv_params* p, int dtype, void* stream
 // weight gradient: dW[n][(c,r,s)] += sum_pixels dY[pix][n] * Xgather[pix][(r,s,c)]   (reduction over pixels)
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WM, int WN, int BKT>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_kernel(tfpp_wgrad_params p, int dbg_skip_epilogue) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_kernel(tfpp_wgrad_params p) {
   using C = TileCfg<T, BM, BN, WM, WN, BKT>;
   constexpr int VEC = C::VEC, NT = C::NT, BK = C::BK;
   __shared__ __attribute__((aligned(16))) T As[C::A_ELEMS_KM];
@@ -435,15 +422,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_
   }
 
   const int RS = p.R * p.S;
-  if (dbg_skip_epilogue) {  // TFPP_WGRAD_EPI=0: timing experiment only (keeps the MFMA chain alive, stores nothing useful)
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < C::FM; ++i)
-#pragma unroll
-      for (int j = 0; j < C::FN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (t == 12345.678f) p.dw[0] = t;
-    return;
-  }
   if (p.ws && p.splits > 1) {  // slice -> workspace [split][G*n_g][KK]; wgrad_reduce_kernel sums the slices into dw
     float* __restrict__ wsp = p.ws + ((size_t)split * p.G * p.n_g + (size_t)g * p.n_g) * KK;
 #pragma unroll
@@ -533,8 +511,7 @@ static int launch_wgrad(const tfpp_wgrad_params& p, hipStream_t st) {
   using C = TileCfg<T, BM, BN, WM, WN, BKT>;
   const int KK = p.R * p.S * p.ks_g;
   dim3 grid(p.G * p.splits, cdiv(p.n_g, BM), cdiv(KK, BN));
-  static const int dbg_skip = [] { const char* e = std::getenv("TFPP_WGRAD_EPI"); return (e && e[0] == '0') ? 1 : 0; }();
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, BM, BN, WM, WN, BKT>), grid, dim3(C::NT), 0, st, p, dbg_skip);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, BM, BN, WM, WN, BKT>), grid, dim3(C::NT), 0, st, p);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

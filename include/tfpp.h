@@ -72,9 +72,9 @@ typedef struct {
 /* number of K slices the dispatcher would use for p (1 = no split) */
 int tfpp_conv_gemm_splits(const tfpp_conv_params* p, int dtype);
 int tfpp_conv_gemm(const tfpp_conv_params* p, int dtype, void* stream);
-/* kernel variant the dispatcher picks for p -- used by the bench's per-kernel roofline.  100 + FM*10 + FN: barrier-free
- * direct-to-register kernel with wave tile (16 FM) x (16 FN); 0..3: LDS-staged 128x32 / 128x64 / 64x64 / 128x128
- * (only with TFPP_CONV_IMPL=lds). */
+/* kernel variant the dispatcher picks for (p, dtype) -- used by the bench's per-kernel bookkeeping.  0..3: LDS-staged
+ * 128x32 / 128x64 / 64x64 / 128x128 tiles; 200 / 201: LDS-DMA ring 128x128 / 64x128 (bf16, N >= 128, K >= 512); 300 + FN: 3x3 stride-1
+ * LDS-halo kernel with FN 16-channel output fragments. */
 int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype);
 int tfpp_conv_gemm_mtiles(const tfpp_conv_params* p);
 /* exact number of M-tiles of the kernel that runs for (p, dtype): with stats_rows = that, every (row, channel) cell of

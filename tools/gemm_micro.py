@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of the implicit-GEMM kernels on the model's dominant shapes (bs=12).  Used with rocprofv3 --pmc to
-attribute time (profiles/).  TFPP_CONV_IMPL=lds|direct selects the forward/data-gradient kernel."""
+attribute time (profiles/).  Launches are replayed from a hipGraph, so the numbers are GPU time, not the Python launch rate."""
 import argparse
 import os
 import sys
