@@ -17,13 +17,16 @@
 namespace {
 constexpr int TH = 8, TW = 32, HH = TH + 2, HWID = TW + 2;
 
-template <int FN>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, int tiles_w, int tiles_h, int ksteps) {
+// CV = Cin_g / 8 at compile time (0: run-time loop): with CV known the staging loops are fully unrolled, so a thread issues all of
+// its ~11 global loads before the first LDS store instead of paying one memory latency per 16-byte chunk.
+template <int FN, int CV>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, int tiles_w, int tiles_h, int ksteps_rt) {
   typedef bf16_t T;
   constexpr int FM = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cin = p.ks_g, cv = cin >> 3, K = 9 * cin;
+  const int cin = CV ? CV * 8 : p.ks_g, cv = cin >> 3, K = 9 * cin;
+  const int ksteps = CV ? (9 * CV * 8 + 31) / 32 : ksteps_rt;
   const int g = blockIdx.y;
   int t = blockIdx.x;
   const int tw = t % tiles_w; t /= tiles_w;
@@ -37,21 +40,43 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
 
   // ---- stage the halo tile (zero outside the image) and the group's weights (zero rows / K tail)
   const T* __restrict__ src = reinterpret_cast<const T*>(p.src) + g * cin;
-  for (int q = tid; q < HH * HWID * cv; q += 256) {
+  const T* __restrict__ wk = reinterpret_cast<const T*>(p.w) + (size_t)g * p.n_g * K;
+  const int kc_row = kpitch >> 3;  // 16-byte chunks per LDS weight row
+  auto halo_chunk = [&](int q) {
     const int pix = q / cv, c = q - pix * cv;
     const int hr = pix / HWID, hc = pix - hr * HWID;
     const int h = h0 + hr - 1, w = w0 + hc - 1;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (h >= 0 && h < H && w >= 0 && w < W) v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * H + h) * W + w) * p.src_ld + c * 8);
-    *reinterpret_cast<uint4*>(halo + (size_t)q * 8) = v;
-  }
-  const T* __restrict__ wk = reinterpret_cast<const T*>(p.w) + (size_t)g * p.n_g * K;
-  const int kc_row = kpitch >> 3;  // 16-byte chunks per LDS weight row
-  for (int q = tid; q < FN * 16 * kc_row; q += 256) {
+    return v;
+  };
+  auto weight_chunk = [&](int q) {
     const int n = q / kc_row, kc = q - n * kc_row;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (n < p.n_g && kc * 8 < K) v = *reinterpret_cast<const uint4*>(wk + (size_t)n * K + kc * 8);
-    *reinterpret_cast<uint4*>(wl + (size_t)n * kpitch + kc * 8) = v;
+    return v;
+  };
+  if constexpr (CV > 0) {
+    constexpr int HCH = HH * HWID * CV, HIT = (HCH + 255) / 256;
+    constexpr int WCH = FN * 16 * (((9 * CV * 8 + 31) / 32) * 4 + 1), WIT = (WCH + 255) / 256;
+    uint4 hv[HIT], wv[WIT];
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) { const int q = tid + it * 256; hv[it] = q < HCH ? halo_chunk(q) : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) { const int q = tid + it * 256; wv[it] = q < WCH ? weight_chunk(q) : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) { const int q = tid + it * 256; if (q < HCH) *reinterpret_cast<uint4*>(halo + (size_t)q * 8) = hv[it]; }
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+      const int q = tid + it * 256;
+      if (q < WCH) { const int n = q / kc_row, kc = q - n * kc_row; *reinterpret_cast<uint4*>(wl + (size_t)n * kpitch + kc * 8) = wv[it]; }
+    }
+  } else {
+    for (int q = tid; q < HH * HWID * cv; q += 256) *reinterpret_cast<uint4*>(halo + (size_t)q * 8) = halo_chunk(q);
+    for (int q = tid; q < FN * 16 * kc_row; q += 256) {
+      const int n = q / kc_row, kc = q - n * kc_row;
+      *reinterpret_cast<uint4*>(wl + (size_t)n * kpitch + kc * 8) = weight_chunk(q);
+    }
   }
   __syncthreads();
 
@@ -169,18 +194,24 @@ size_t halo_lds_bytes(const tfpp_conv_params& p, int fn) {
   return (size_t)HH * HWID * p.ks_g * 2 + (size_t)fn * 16 * (ksteps * 32 + 8) * 2;
 }
 
-template <int FN> int launch_halo(const tfpp_conv_params& p, hipStream_t st) {
+template <int FN, int CV> int launch_halo(const tfpp_conv_params& p, hipStream_t st) {
   const int tiles_w = cdiv(p.Wd, TW), tiles_h = cdiv(p.Hd, TH), ksteps = (9 * p.ks_g + 31) / 32;
   const size_t lds = halo_lds_bytes(p, FN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<FN>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    attr_set = true;
-  }
   dim3 grid((unsigned)(tiles_w * tiles_h * p.B), (unsigned)p.G);
-  hipLaunchKernelGGL(conv3x3_halo_kernel<FN>, grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
   TFPP_CHECK_LAUNCH();
   return 0;
+}
+
+template <int FN> int launch_halo_cv(const tfpp_conv_params& p, hipStream_t st) {
+  switch (p.ks_g >> 3) {  // the channel counts of this model get the unrolled staging; anything else the run-time loop
+    case 1: return launch_halo<FN, 1>(p, st);
+    case 2: return launch_halo<FN, 2>(p, st);
+    case 3: return launch_halo<FN, 3>(p, st);
+    case 4: return launch_halo<FN, 4>(p, st);
+    case 8: return launch_halo<FN, 8>(p, st);
+    default: return launch_halo<FN, 0>(p, st);
+  }
 }
 }  // namespace
 
@@ -200,8 +231,8 @@ int conv_halo_mtiles(const tfpp_conv_params& p) { return cdiv(p.Wd, TW) * cdiv(p
 
 int conv_gemm_halo(const tfpp_conv_params& p, hipStream_t st) {
   switch (conv_halo_variant(p) - 300) {
-    case 1: return launch_halo<1>(p, st);
-    case 2: return launch_halo<2>(p, st);
-    default: return launch_halo<4>(p, st);
+    case 1: return launch_halo_cv<1>(p, st);
+    case 2: return launch_halo_cv<2>(p, st);
+    default: return launch_halo_cv<4>(p, st);
   }
 }

@@ -21,14 +21,17 @@ __device__ __forceinline__ uint2 lds_tr16(const bf16_t* p) {
                     (unsigned)(unsigned short)v[2] | ((unsigned)(unsigned short)v[3] << 16));
 }
 
-// FNN: 16-channel fragments of dY (n_g <= 16 FNN); CB: 16-channel blocks of X per tap (Cin_g <= 16 CB)
-template <int FNN, int CB>
+// FNN: 16-channel fragments of dY (n_g <= 16 FNN); CV = Cin_g / 8 (compile time: the staging loops are fully unrolled, all of a
+// thread's global loads are in flight before its first LDS store); CB = 16-channel blocks of X per tap
+template <int FNN, int CV>
 __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(tfpp_wgrad_params p, int tiles_w, int tiles_h, int nblk) {
   typedef bf16_t T;
+  constexpr int CB = CV <= 2 ? 1 : (CV <= 4 ? 2 : 4);
   constexpr int NCOL = 9 * CB, NCW = (NCOL + 3) / 4;  // column blocks in total / per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cin = p.ks_g, cv = cin >> 3, ng = p.n_g, nv = ng >> 3;
+  constexpr int cin = CV * 8, cv = CV;
+  const int ng = p.n_g, nv = ng >> 3;
   const int npitch = FNN * 16 + 8;  // dY row pitch in elements (16-byte skew)
   const int g = blockIdx.y;
   const int H = p.Hd, W = p.Wd;
@@ -49,20 +52,29 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(tfpp_wgrad_params p,
     const int tw = t % tiles_w, t2 = t / tiles_w, th = t2 % tiles_h, b = t2 / tiles_h;
     const int h0 = th * TH, w0 = tw * TW;
     // ---- stage X halo and dY tile (zero outside the image)
-    for (int q = tid; q < HH * HWID * cv; q += 256) {
-      const int pix = q / cv, c = q - pix * cv;
+    constexpr int HCH = HH * HWID * CV, HIT = (HCH + 255) / 256, DCH = TH * TW * FNN * 2, DIT = DCH / 256;
+    uint4 hv[HIT], dv[DIT];
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+      const int q = tid + it * 256, pix = q / cv, c = q - pix * cv;
       const int hr = pix / HWID, hc = pix - hr * HWID;
       const int h = h0 + hr - 1, w = w0 + hc - 1;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (h >= 0 && h < H && w >= 0 && w < W) v = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + h) * W + w) * p.x_ld + c * 8);
-      *reinterpret_cast<uint4*>(halo + (size_t)q * 8) = v;
+      hv[it] = make_uint4(0, 0, 0, 0);
+      if (q < HCH && h >= 0 && h < H && w >= 0 && w < W) hv[it] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + h) * W + w) * p.x_ld + c * 8);
     }
-    for (int q = tid; q < TH * TW * (FNN * 2); q += 256) {
-      const int pix = q / (FNN * 2), c = q - pix * (FNN * 2);
+#pragma unroll
+    for (int it = 0; it < DIT; ++it) {
+      const int q = tid + it * 256, pix = q / (FNN * 2), c = q - pix * (FNN * 2);
       const int h = h0 + pix / TW, w = w0 + pix % TW;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (c < nv && h < H && w < W) v = *reinterpret_cast<const uint4*>(dy + ((size_t)(b * H + h) * W + w) * p.dy_ld + c * 8);
-      *reinterpret_cast<uint4*>(dyl + (size_t)pix * npitch + c * 8) = v;
+      dv[it] = make_uint4(0, 0, 0, 0);
+      if (c < nv && h < H && w < W) dv[it] = *reinterpret_cast<const uint4*>(dy + ((size_t)(b * H + h) * W + w) * p.dy_ld + c * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) { const int q = tid + it * 256; if (q < HCH) *reinterpret_cast<uint4*>(halo + (size_t)q * 8) = hv[it]; }
+#pragma unroll
+    for (int it = 0; it < DIT; ++it) {
+      const int q = tid + it * 256, pix = q / (FNN * 2), c = q - pix * (FNN * 2);
+      *reinterpret_cast<uint4*>(dyl + (size_t)pix * npitch + c * 8) = dv[it];
     }
     __syncthreads();
     // ---- 8 K-steps: step ks = tile row ks (32 pixels); lane (m16, kg) feeds pixel columns kg*8 + (m16>>2) [+4], channel quad m16&3
@@ -117,15 +129,15 @@ size_t halo_lds_bytes(const tfpp_wgrad_params& p, int fnn) {
   return (size_t)(HH * HWID + 4) * p.ks_g * 2 + (size_t)TH * TW * (fnn * 16 + 8) * 2;
 }
 
-template <int FNN, int CB> int launch(const tfpp_wgrad_params& p, int nblk, hipStream_t st) {
+template <int FNN, int CV> int launch(const tfpp_wgrad_params& p, int nblk, hipStream_t st) {
   const int tiles_w = cdiv(p.Wd, TW), tiles_h = cdiv(p.Hd, TH);
   const size_t lds = halo_lds_bytes(p, FNN);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_halo_kernel<FNN, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_halo_kernel<FNN, CV>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad3x3_halo_kernel<FNN, CB>), dim3((unsigned)nblk, (unsigned)p.G), dim3(256), lds, st, p, tiles_w, tiles_h, nblk);
+  hipLaunchKernelGGL((wgrad3x3_halo_kernel<FNN, CV>), dim3((unsigned)nblk, (unsigned)p.G), dim3(256), lds, st, p, tiles_w, tiles_h, nblk);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -138,6 +150,8 @@ int wgrad_halo_slices(const tfpp_wgrad_params& p, int dtype) {
   if (p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || p.Hs != p.Hd || p.Ws != p.Wd) return 0;
   if (p.ks_g % 8 || p.n_g % 8 || p.x_ld % 8 || p.dy_ld % 8 || p.n_g > 64 || p.ks_g > 64 || p.Wd < 32 || p.Hd < 4) return 0;
   if (((uintptr_t)p.dy & 15) || ((uintptr_t)p.x & 15)) return 0;
+  const int cv8 = p.ks_g >> 3;
+  if (!(cv8 == 1 || cv8 == 2 || cv8 == 3 || cv8 == 4 || cv8 == 8)) return 0;  // instantiated channel counts
   const int fnn = p.n_g <= 16 ? 1 : (p.n_g <= 32 ? 2 : 4);
   if (halo_lds_bytes(p, fnn) > 98304) return 0;
   const long tiles = (long)cdiv(p.Wd, TW) * cdiv(p.Hd, TH) * p.B;
@@ -151,11 +165,11 @@ int wgrad_halo_slices(const tfpp_wgrad_params& p, int dtype) {
 }
 
 int conv_wgrad_halo(const tfpp_wgrad_params& p, int nblk, hipStream_t st) {
-  const int fnn = p.n_g <= 16 ? 1 : (p.n_g <= 32 ? 2 : 4), cb = p.ks_g <= 16 ? 1 : (p.ks_g <= 32 ? 2 : 4);
-#define HALO_CASE(F, C) if (fnn == F && cb == C) return launch<F, C>(p, nblk, st)
-  HALO_CASE(1, 1); HALO_CASE(1, 2); HALO_CASE(1, 4);
-  HALO_CASE(2, 1); HALO_CASE(2, 2); HALO_CASE(2, 4);
-  HALO_CASE(4, 1); HALO_CASE(4, 2); HALO_CASE(4, 4);
+  const int fnn = p.n_g <= 16 ? 1 : (p.n_g <= 32 ? 2 : 4), cv = p.ks_g >> 3;
+#define HALO_CASE(F, C) if (fnn == F && cv == C) return launch<F, C>(p, nblk, st)
+  HALO_CASE(1, 1); HALO_CASE(1, 2); HALO_CASE(1, 3); HALO_CASE(1, 4); HALO_CASE(1, 8);
+  HALO_CASE(2, 1); HALO_CASE(2, 2); HALO_CASE(2, 3); HALO_CASE(2, 4); HALO_CASE(2, 8);
+  HALO_CASE(4, 1); HALO_CASE(4, 2); HALO_CASE(4, 3); HALO_CASE(4, 4); HALO_CASE(4, 8);
 #undef HALO_CASE
   return TFPP_EINVAL;
 }
