@@ -31,7 +31,7 @@ __device__ __forceinline__ uint4 lds_read_b128_asm(unsigned addr) {
 }
 
 template <int BM, int BN, int NSTAGE, int WGM, int WGN>
-__global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_conv_params p, int trace) {
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_conv_params p, int trace, int m_major) {
   typedef bf16_t T;
   constexpr int NT = WGM * WGN * 64, NWAVES = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
@@ -45,9 +45,26 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
   const int wm = wave / WGN, wn = wave % WGN;
   int g = blockIdx.z, split = 0;
   if (p.splitk > 1) { g = blockIdx.z / p.splitk; split = blockIdx.z - g * p.splitk; }  // z = (group, K slice)
-  const int mtile = blockIdx.y;
-  const int bm0 = mtile * BM, bn0 = blockIdx.x * BN;
   const int M = p.B * p.Hd * p.Wd, K = p.R * p.S * p.ks_g;
+  // Workgroup id -> XCD id % 8.  Default order (x = N-tile fastest): every XCD sees all M-tiles but only every 8th weight panel, so
+  // its share of the weights stays in its L2 ("weights stationary") and the activation rows are fetched by up to 8 XCDs.  When the
+  // weights are small (RegNet 1x1 convs: 0.7 MB against 14 MB of activations) that is the wrong way round: m_major gives XCD x the
+  // M-tiles x, x+8, ... and walks all N-tiles of one M-tile back to back, so an activation tile enters one L2 once.
+  int mtile = blockIdx.y, ntile = blockIdx.x;
+  if (m_major) {
+    const int gx = gridDim.x, gy = gridDim.y, id = blockIdx.x + gx * blockIdx.y;
+    const int full = (gy >> 3) << 3;  // M-tiles covered by whole rounds of 8
+    if (id < full * gx) {
+      const int xcd = id & 7, j = id >> 3;
+      ntile = j % gx;
+      mtile = (j / gx) * 8 + xcd;
+    } else {  // the last (< 8) M-tiles keep the default order
+      const int r = id - full * gx;
+      ntile = r % gx;
+      mtile = full + r / gx;
+    }
+  }
+  const int bm0 = mtile * BM, bn0 = ntile * BN;
   const T* __restrict__ src = reinterpret_cast<const T*>(p.src) + g * p.ks_g;
   const T* __restrict__ wk = reinterpret_cast<const T*>(p.w) + (size_t)g * p.n_g * K;
   const T* zero = reinterpret_cast<const T*>(tfpp_zero_page);
@@ -292,7 +309,11 @@ template <int BM, int BN, int NSTAGE, int WGM, int WGN> static int launch_glds(c
     attr_set = true;
   }
   static const int trace = [] { const char* e = std::getenv("TFPP_GLDS_TRACE"); return (e && e[0] == '1') ? 1 : 0; }();
-  hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN>), grid, dim3(WGM * WGN * 64), lds, st, p, trace);
+  // small weight panels (<= 6 MB per group, measured: 1512x1512 gains, 6048x1512 loses): M-major order (see the kernel)
+  static const int mm_env = [] { const char* e = std::getenv("TFPP_GLDS_M_MAJOR"); return e ? std::atoi(e) : -1; }();
+  const long w_bytes = (long)p.n_g * p.R * p.S * p.ks_g * 2;
+  const int m_major = mm_env >= 0 ? mm_env : (w_bytes <= (6l << 20) ? 1 : 0);
+  hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN>), grid, dim3(WGM * WGN * 64), lds, st, p, trace, m_major);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
