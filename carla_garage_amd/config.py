@@ -25,6 +25,9 @@ class GlobalConfig:
     self.lidar_resolution_height = 256
     self.pixels_per_meter = 4.0
     self.hist_max_per_pixel = 5  # config.py:128
+    self.bb_confidence_threshold = 0.3  # config.py:312
+    self.top_k_center_keypoints = 100  # config.py:319
+    self.center_net_max_pooling_kernel = 3  # config.py:320
     self.lidar_split_height = 0.2  # config.py:131
     self.max_height_lidar = 100.0  # config.py:481
     self.use_ground_plane = False

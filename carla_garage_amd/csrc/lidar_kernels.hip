@@ -61,3 +61,107 @@ extern "C" int tfpp_lidar_histogram(const float* points, int64_t n, int point_st
   TFPP_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// CenterNet heat-map decode: LidarCenterNetHead.decode_heatmap (team_code/center_net.py:172-237) with
+// get_local_maximum / get_topk_from_heatmap / transpose_and_gather_feat (team_code/gaussian_target.py:186-264) in one launch.
+// One 1024-thread workgroup per sample: every thread keeps its share of the ncls*H*W candidates (3x3 local maxima keep their score,
+// everything else scores 0) in registers as 64-bit keys (order-preserving score bits << 32 | ~index, so equal scores resolve to the
+// lower index); k rounds of thread-max -> wave shuffle max -> LDS max pick the top-k in descending order, and the thread that owns a
+// pick gathers its box (argmax over the yaw bins, class2angle, offsets, scaling) and writes row i.  fp32 operations are the
+// reference's, one rounding each (no FMA contraction), so the result is bit-exact whenever the scores are distinct.
+// ---------------------------------------------------------------------------------------------------------------
+#define DEC_THREADS 1024
+#define DEC_MAX_PER_THREAD 32
+__device__ __forceinline__ unsigned long long dec_key(float v, unsigned idx) {
+  unsigned b = __float_as_uint(v);
+  b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // order-preserving map of IEEE floats onto unsigned
+  return ((unsigned long long)b << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+__device__ __forceinline__ unsigned long long dec_max(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+
+__global__ __launch_bounds__(DEC_THREADS) void centernet_decode_kernel(const float* __restrict__ heat, const float* __restrict__ wh,
+                                                                       const float* __restrict__ offset, const float* __restrict__ yaw_class,
+                                                                       const float* __restrict__ yaw_res, float* __restrict__ out, int ncls,
+                                                                       int H, int W, int k, int nbins, float width_ratio, float height_ratio) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hw = H * W, n = ncls * hw;
+  const float* hb = heat + (size_t)b * n;
+  unsigned long long keys[DEC_MAX_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < DEC_MAX_PER_THREAD; ++j) {
+    const int idx = tid + j * DEC_THREADS;
+    keys[j] = 0ull;  // below every real candidate
+    if (idx < n) {
+      const int c = idx / hw, p = idx - c * hw, y = p / W, x = p - y * W;
+      const float v = hb[idx];
+      float m = v;  // 3x3 max pooling, padding never wins (gaussian_target.py:197-198)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = y + dy, xx = x + dx;
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W) m = fmaxf(m, hb[c * hw + yy * W + xx]);
+        }
+      keys[j] = dec_key(m == v ? v : v * 0.f, (unsigned)idx);  // heat * keep
+    }
+  }
+  __shared__ unsigned long long sm[DEC_THREADS / 64];
+  __shared__ unsigned long long winner;
+  for (int i = 0; i < k; ++i) {
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int j = 0; j < DEC_MAX_PER_THREAD; ++j) best = dec_max(best, keys[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = dec_max(best, (unsigned long long)__shfl_xor((long long)best, o, 64));
+    if (lane == 0) sm[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long w = sm[0];
+      for (int q = 1; q < DEC_THREADS / 64; ++q) w = dec_max(w, sm[q]);
+      winner = w;
+    }
+    __syncthreads();
+    const unsigned long long w = winner;
+    const unsigned idx = 0xFFFFFFFFu - (unsigned)(w & 0xFFFFFFFFull);
+    if (w != 0ull && (int)(idx % DEC_THREADS) == tid) {  // this thread owns the pick: retire it and write the box
+#pragma unroll
+      for (int j = 0; j < DEC_MAX_PER_THREAD; ++j)
+        if (keys[j] == w) keys[j] = 0ull;
+      unsigned sb = (unsigned)(w >> 32);
+      sb = (sb & 0x80000000u) ? (sb & 0x7FFFFFFFu) : ~sb;
+      const float score = __uint_as_float(sb);
+      const int cls = (int)idx / hw, p = (int)idx - cls * hw, y = p / W, x = p - y * W;
+      auto at = [&](const float* f, int C, int c) { return f[((size_t)b * C + c) * hw + p]; };
+      int ycls = 0;
+      float ymax = at(yaw_class, nbins, 0);
+      for (int c = 1; c < nbins; ++c) { const float v = at(yaw_class, nbins, c); if (v > ymax) { ymax = v; ycls = c; } }  // first maximum
+      float center = (float)ycls * (float)(2.0 * 3.141592653589793 / (double)nbins);  // class2angle, center_net.py:135-137
+      asm volatile("" : "+v"(center));  // keep the product rounded on its own: the reference adds the residual in a second operation
+      float angle = center + at(yaw_res, 1, 0);
+      if (angle > (float)3.141592653589793) angle = angle - (float)(2.0 * 3.141592653589793);
+      float* o = out + ((size_t)b * k + i) * 9;
+      o[0] = ((float)x + at(offset, 2, 0)) * width_ratio;  // add then multiply: two roundings with or without contraction
+      o[1] = ((float)y + at(offset, 2, 1)) * height_ratio;
+      o[2] = at(wh, 2, 0) * width_ratio;
+      o[3] = at(wh, 2, 1) * height_ratio;
+      o[4] = angle;
+      o[5] = 0.f;  // velocity / brake heads only exist for multi-frame inputs (center_net.py:214-220)
+      o[6] = 0.f;
+      o[7] = (float)cls;
+      o[8] = score;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int tfpp_centernet_decode(const float* heat, const float* wh, const float* offset, const float* yaw_class, const float* yaw_res,
+                                     float* out, int B, int ncls, int H, int W, int k, int num_dir_bins, float width_ratio,
+                                     float height_ratio, void* stream) {
+  if (!heat || !wh || !offset || !yaw_class || !yaw_res || !out || B < 1 || ncls < 1 || H < 1 || W < 1 || k < 1 || num_dir_bins < 1)
+    return TFPP_EINVAL;
+  const long n = (long)ncls * H * W;
+  if (n > (long)DEC_THREADS * DEC_MAX_PER_THREAD || k > n) return TFPP_EINVAL;
+  hipLaunchKernelGGL(centernet_decode_kernel, dim3((unsigned)B), dim3(DEC_THREADS), 0, (hipStream_t)stream, heat, wh, offset, yaw_class, yaw_res,
+                     out, ncls, H, W, k, num_dir_bins, width_ratio, height_ratio);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}

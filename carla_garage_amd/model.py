@@ -325,8 +325,24 @@ class LidarCenterNet(nn.Module):
             {'params': [params[n] for n in sorted(no_decay)], 'weight_decay': 0.0}]
 
   def convert_features_to_bb_metric(self, bb_predictions):
-    raise NotImplementedError('heat-map decode + NMS (center_net.py:172-237) is host-side post-processing outside this '
-                              "path's round-1 scope (SURVEY.md section 8f, row 2)")
+    """team_code/model.py:447-459: decode the first sample's boxes on the GPU (``head.get_bboxes``), keep those above
+    ``bb_confidence_threshold`` and convert them to the vehicle coordinate system (team_code/transfuser_utils.py:388-406).
+    Returns the reference's list of (9,) float32 arrays; one device-to-host copy of 100 x 9 floats."""
+    bboxes = self.head.get_bboxes(bb_predictions[0], bb_predictions[1], bb_predictions[2], bb_predictions[3], bb_predictions[4],
+                                  bb_predictions[5], bb_predictions[6])[0]
+    bboxes = bboxes.detach().cpu().numpy()
+    bboxes = bboxes[bboxes[:, -1] > cfg_get(self.config, 'bb_confidence_threshold', 0.3)]
+    ppm, min_x, min_y = self.config.pixels_per_meter, self.config.min_x, self.config.min_y
+    carla_bboxes = []
+    for box in bboxes:
+      box = box.copy()
+      box[4] = -box[4]
+      box[:2] = box[:2] - np.array([-(min_x * ppm), -(min_y * ppm)])  # pixel that represents 0/0
+      box[0], box[1] = box[1], box[0]  # image is y front, x right; CARLA x front, y right
+      box[2], box[3] = box[3], box[2]
+      box[:4] = box[:4] / ppm
+      carla_bboxes.append(box)
+    return carla_bboxes
 
   def init_visualization(self):
     if cfg_get(self.config, 'debug', False):

@@ -169,6 +169,27 @@ class LidarCenterNetHead(nn.Module):
       setattr(self, n + '_head', nn.Sequential(nn.Conv2d(c, c, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(c, outs[n], 1)))
     self.out_channels = outs
 
+  def get_bboxes(self, center_heatmap_preds, wh_preds, offset_preds, yaw_class_preds, yaw_res_preds, velocity_preds=None, brake_preds=None):
+    """team_code/center_net.py:142-170 -> decode_heatmap (172-237) as one HIP launch: (B, k, 9) boxes in image coordinates
+    (x, y, w, h, yaw, velocity, brake, class, score), top-k by score.  Single-frame configuration (velocity = brake = 0)."""
+    import torch
+    from . import ops
+    from ._lib import lib
+    cfg = self.config
+    heat = center_heatmap_preds
+    if not heat.is_cuda:
+      raise RuntimeError('carla_garage_amd runs on the MI355X HIP path only: CenterNet decode needs CUDA tensors')
+    maps = [t.detach().float().contiguous() for t in (heat, wh_preds, offset_preds, yaw_class_preds, yaw_res_preds)]
+    B, ncls, H, W = maps[0].shape
+    k = int(getattr(cfg, 'top_k_center_keypoints', 100))
+    if int(getattr(cfg, 'center_net_max_pooling_kernel', 3)) != 3:
+      raise NotImplementedError('the decode kernel implements the reference default 3x3 local-maximum window')
+    out = torch.empty((B, k, 9), device=heat.device, dtype=torch.float32)
+    lib.load()
+    lib.tfpp_centernet_decode(*[ops.ptr(m) for m in maps], ops.ptr(out), B, ncls, H, W, k, int(cfg.num_dir_bins),
+                              float(cfg.lidar_resolution_width / W), float(cfg.lidar_resolution_height / H), ops.stream())
+    return out
+
 
 class PerspectiveDecoder(nn.Module):
   """Container for team_code/transfuser_utils.py:668-695."""

@@ -163,6 +163,14 @@ int tfpp_lidar_histogram(const float* points, int64_t n, int point_stride, const
                          int32_t* counts, float* out, float max_height, float split_height, int use_ground_plane, int hist_max,
                          void* stream);
 
+/* CenterNet heat-map decode, the step right after forward() when boxes are requested (replaces
+ * LidarCenterNetHead.decode_heatmap, team_code/center_net.py:172-237, incl. gaussian_target.py:186-264): 3x3 local maxima of
+ * heat (B, ncls, H, W), top-k in descending score order (equal scores: lower flat index first), gathered wh / offset /
+ * argmax(yaw_class) + yaw_res -> out (B, k, 9) = x, y, w, h in image pixels, yaw, velocity = 0, brake = 0, class, score.
+ * All maps are the caller-facing fp32 NCHW tensors.  ncls*H*W <= 32768. */
+int tfpp_centernet_decode(const float* heat, const float* wh, const float* offset, const float* yaw_class, const float* yaw_res, float* out,
+                          int B, int ncls, int H, int W, int k, int num_dir_bins, float width_ratio, float height_ratio, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Boundary layout changes.  nchw_to_nhwc_affine = normalize_imagenet (transfuser_utils.py:542-551) fused with
  * NCHW->NHWC and zero channel padding to `cpad`: out[b,h,w,c] = c<C ? in[b,c,h,w]*mul[c]+add[c] : 0 (mul/add nullable).
