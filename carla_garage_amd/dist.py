@@ -48,6 +48,14 @@ def all_reduce_gradients(flat_grad, group=None, chunk_elems=None):
   return 1.0 / w
 
 
+def all_reduce_async(tensor, group=None):
+  """SUM all-reduce of a slice of the gradient arena, returned as a work handle (``.wait()`` orders the current stream after
+  it).  Used to send the part of the gradients that is finished early while the rest of backward still runs."""
+  if world_size(group) == 1 or tensor.numel() == 0:
+    return None
+  return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
 def max_over_ranks(value, device, group=None):
   t = torch.tensor([float(value)], device=device, dtype=torch.float64)
   if world_size(group) > 1:

@@ -98,6 +98,8 @@ class Tape:
     self.lanes = lanes
     self.frozen = {}      # id(tensor) -> tensor: handed to another stream, must not be accumulated into in place
     self._grads = None    # pending gradients while backward() runs (take_pending)
+    self._rest = []
+    self.split_index = None
     self.finalizers = []  # run once at the end of backward (joins side streams)
 
   def record(self, outs, ins, fn, lane=0):
@@ -127,47 +129,79 @@ class Tape:
     self._refs[id(cur)] = self._refs.get(id(cur), 1) - 1
     return cur
 
-  def backward(self, seeds):
-    """seeds: list of (tensor, grad)."""
-    grads, refs, glane = {}, {}, {}
-    self._grads, self._refs, self._glane, self._lane = grads, refs, glane, 0
+  def mark(self):
+    """Split point for a two-segment backward: nodes recorded after this call form the first segment."""
+    self.split_index = len(self.nodes)
+
+  def backward(self, seeds, stop_at_mark=False):
+    """seeds: list of (tensor, grad).  With ``stop_at_mark`` only the nodes recorded after ``mark()`` are processed (the lanes are
+    joined, so every gradient those nodes produce is complete) and ``backward_resume()`` runs the rest -- the trainer all-reduces
+    the finished part of the gradient arena while the second segment computes."""
+    self._grads, self._refs, self._glane, self._lane = {}, {}, {}, 0
     lanes = self.lanes
     if lanes is not None and seeds:
       lanes.begin(seeds[0][1].device)
-    multi = lanes is not None and lanes.on()
-    self._multi = multi
-
-    def sync(to_lane, from_lane):
-      if multi and to_lane != from_lane:
-        lanes.stream(to_lane).wait_stream(lanes.stream(from_lane))
-
-    def acc(t, g, lane):
-      if t is None or g is None:
-        return
-      k = _key(t)
-      cur = grads.get(k)
-      if cur is None:
-        grads[k] = g
-        refs[id(g)] = refs.get(id(g), 0) + 1
-        glane[k] = lane
-        return
-      if multi and glane[k] != lane:  # the pending gradient was last written on another lane
-        sync(lane, glane[k])
-        lanes.hold(cur, g)
-      glane[k] = lane
-      if refs.get(id(cur), 0) > 1 or id(cur) in self.frozen:
-        # the stored gradient object is also pending under another key, or is being read on the side stream: do not mutate it
-        refs[id(cur)] -= 1
-        new = ops.add_dropout(cur, g if g.dtype == cur.dtype else ops.cast(g, cur.dtype))
-        grads[k] = new
-        refs[id(new)] = 1
-      else:
-        ops.axpy(g if g.dtype == cur.dtype else ops.cast(g, cur.dtype), cur, 1.0)
-
+    self._multi = lanes is not None and lanes.on()
     Tape.current = self
     for t, g in seeds:
-      acc(t, g, 0)
-    for outs, ins, fn, lane in reversed(self.nodes):
+      self._acc(t, g, 0)
+    split = self.split_index if (stop_at_mark and self.split_index is not None) else 0
+    todo, self.nodes = self.nodes, []
+    self._rest = todo[:split]
+    self._run(todo[split:])
+    self._join()
+    if not self._rest:
+      self._finish()
+
+  def backward_resume(self):
+    """Second segment after ``backward(..., stop_at_mark=True)``."""
+    if self._grads is None:
+      return
+    if self.lanes is not None and self._multi:
+      held = self.lanes.held
+      self.lanes.begin(self.lanes.main.device)  # lane 0 = the stream current now (the same capture stream in a hipGraph)
+      self.lanes.held = held
+      # fork lane 1 from lane 0 before anything runs on it: this segment may be the start of a new hipGraph capture, and a stream
+      # that has not yet waited on the capturing stream is not part of the capture (its kernels would run eagerly and be missing
+      # from the replay); the first lane-1 node of the segment can consume a gradient that was produced on lane 1 itself
+      self.lanes.branch.wait_stream(self.lanes.main)
+    Tape.current = self
+    rest, self._rest = self._rest, []
+    self._run(rest)
+    self._join()
+    self._finish()
+
+  def _sync(self, to_lane, from_lane):
+    if self._multi and to_lane != from_lane:
+      self.lanes.stream(to_lane).wait_stream(self.lanes.stream(from_lane))
+
+  def _acc(self, t, g, lane):
+    if t is None or g is None:
+      return
+    grads, refs, glane = self._grads, self._refs, self._glane
+    k = _key(t)
+    cur = grads.get(k)
+    if cur is None:
+      grads[k] = g
+      refs[id(g)] = refs.get(id(g), 0) + 1
+      glane[k] = lane
+      return
+    if self._multi and glane[k] != lane:  # the pending gradient was last written on another lane
+      self._sync(lane, glane[k])
+      self.lanes.hold(cur, g)
+    glane[k] = lane
+    if refs.get(id(cur), 0) > 1 or id(cur) in self.frozen:
+      # the stored gradient object is also pending under another key, or is being read on the side stream: do not mutate it
+      refs[id(cur)] -= 1
+      new = ops.add_dropout(cur, g if g.dtype == cur.dtype else ops.cast(g, cur.dtype))
+      grads[k] = new
+      refs[id(new)] = 1
+    else:
+      ops.axpy(g if g.dtype == cur.dtype else ops.cast(g, cur.dtype), cur, 1.0)
+
+  def _run(self, nodes):
+    grads, refs, glane, lanes, multi = self._grads, self._refs, self._glane, self.lanes, self._multi
+    for outs, ins, fn, lane in reversed(nodes):
       if not multi:
         lane = 0
       gouts, src_lanes = [], set()
@@ -186,7 +220,7 @@ class Tape:
         if multi:
           lanes.cur = lane
         for sl in src_lanes:
-          sync(lane, sl)
+          self._sync(lane, sl)
         if multi and src_lanes - {lane}:
           lanes.hold(*[g for g in gouts if g is not None])
         gins = fn(*gouts)
@@ -195,17 +229,23 @@ class Tape:
         if not isinstance(gins, (tuple, list)):
           gins = (gins,)
         for t, g in zip(ins, gins):
-          acc(t, g, lane)
-    self.nodes = []
-    self._grads = None
+          self._acc(t, g, lane)
+    self._lane = 0
     if multi:
       lanes.cur = 0
+
+  def _join(self):
+    """End of a segment: flush + join the weight-gradient lane, join the encoder lanes."""
     for fin in self.finalizers:
       fin()
-    if multi:
-      lanes.join()
-      lanes.held = []
     self.finalizers = []
+    if self._multi:
+      self.lanes.join()
+
+  def _finish(self):
+    if self._multi:
+      self.lanes.held = []
+    self._grads = None
     self.frozen = {}
     Tape.current = None
 
@@ -257,6 +297,26 @@ class SideLane:
       self.flush()
       torch.cuda.current_stream().wait_stream(self.stream)
       self.keep = []
+
+
+EARLY_GRAD_PREFIXES = ('backbone.image_encoder.s4', 'backbone.lidar_encoder.s4', 'backbone.transformers.3', 'backbone.lidar_channel_to_img.3',
+                       'backbone.img_channel_to_lidar.3', 'backbone.c5_conv', 'backbone.up_conv')
+
+
+def finishes_early(name):
+  """Parameters whose gradient is complete once backward has walked back to the end of fusion stage 3 (Tape.mark() in
+  Engine.forward): everything outside the backbone (heads, decoders, planning head) and the stage-4 part of the backbone --
+  about two thirds of the 481 MB.  They sit at the tail of the flat arenas so that slice can be all-reduced early."""
+  return (not name.startswith('backbone.')) or name.startswith(EARLY_GRAD_PREFIXES)
+
+
+def arena_order(model):
+  """[(name, param)] of the trainable parameters in flat-arena order (late-finishing gradients first) and the element offset at
+  which the early-finishing group starts.  Engine.alloc_grads and Trainer._flatten both use it."""
+  params = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+  late = [(n, p) for n, p in params if not finishes_early(n)]
+  early = [(n, p) for n, p in params if finishes_early(n)]
+  return late + early, sum(ops.pad_to(p.numel(), 4) for _, p in late)
 
 
 class ConvSpec:
@@ -491,7 +551,7 @@ class Engine:
 
   # ------------------------------------------------------------------------------------------------ gradients
   def alloc_grads(self):
-    params = [(n, p) for n, p in self.m.named_parameters() if p.requires_grad]
+    params, self.early_offset = arena_order(self.m)
     total = sum(ops.pad_to(p.numel(), 4) for _, p in params)
     if self.flat_grad is None or self.flat_grad.numel() != total or self.flat_grad.device != self.device:
       self.flat_grad = torch.empty(total, device=self.device, dtype=F32)
@@ -968,6 +1028,8 @@ class Engine:
         lo = self.conv(lo, f'backbone.img_channel_to_lidar.{i}')
         xl = self.upsample_add(lo, xl)
       xi = self.upsample_add(io, xi)
+      if i == 2 and self.tape is not None:
+        self.tape.mark()  # everything recorded from here on only touches the "early" parameters (finishes_early)
     lanes.join()
     out['image_feature_grid'], out['fused_features'] = xi, xl
 

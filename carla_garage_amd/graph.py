@@ -32,8 +32,10 @@ class GraphedForward:
 
 
 class GraphedTrainStep:
-  """Captures Trainer._step_body (repack + forward + losses + backward) for a fixed batch layout; the gradient
-  all-reduce and the optimizer launch stay outside the graph so RCCL is never captured."""
+  """Captures the training step body (repack + forward + losses + backward) for a fixed batch layout; the gradient
+  all-reduce and the optimizer launch stay outside the graphs so RCCL is never captured.  With more than one rank the body is
+  captured as TWO graphs sharing one memory pool, split where the gradients of the heads and of fusion stage 4 are final
+  (Tape.mark): their slice of the arena is all-reduced while the second graph replays."""
 
   def __init__(self, trainer, batch, warmup=2):
     self.trainer = trainer
@@ -41,9 +43,18 @@ class GraphedTrainStep:
     for _ in range(warmup):
       trainer.train_step(self.static_batch)
     torch.cuda.synchronize()
+    self.split = trainer.overlap_enabled()
     self.graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(self.graph):
-      self.vals = trainer._step_body(self.static_batch)
+    self.graph2 = None
+    if self.split:
+      with torch.cuda.graph(self.graph):
+        self.vals = trainer._step_part1(self.static_batch)
+      self.graph2 = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+        trainer._step_part2()
+    else:
+      with torch.cuda.graph(self.graph):
+        self.vals = trainer._step_body(self.static_batch)
     torch.cuda.synchronize()
 
   def __call__(self, batch=None):
@@ -55,5 +66,9 @@ class GraphedTrainStep:
           dst.copy_(src, non_blocking=True)
     tr.step_count += 1
     self.graph.replay()
-    tr.finish_step()
+    early = None
+    if self.graph2 is not None:
+      early = tr.reduce_early()
+      self.graph2.replay()
+    tr.finish_step(early)
     return self.vals

@@ -6,12 +6,14 @@ team_code/train.py:516-520) -> fused AdamW(amsgrad) over the flat parameter aren
 The whole step is a static launch sequence, so after warm-up it can be captured into a hipGraph
 (``capture_graph=True``) and replayed without Python or launch overhead.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from . import ops
 from . import dist as tdist
-from .engine import Tape, F32
+from .engine import Tape, F32, arena_order
 from .losses import fused_losses, normalized_loss_weights, active_losses
 
 
@@ -39,7 +41,7 @@ class Trainer:
     eng = self.eng
     eng.alloc_grads()
     dev = eng.device
-    params = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
+    params, _ = arena_order(self.model)  # same order as the gradient arena: late-finishing gradients first
     self.flat_param = torch.empty_like(eng.flat_grad)
     ops.zero_(self.flat_param)
     off = 0
@@ -55,7 +57,9 @@ class Trainer:
     tdist.broadcast_state(self.flat_param, list(self.model.buffers()), self.pg)  # DDP constructor broadcast, train.py:516
 
   # ---------------------------------------------------------------------------------------------- one step
-  def _step_body(self, batch):
+  def _step_part1(self, batch):
+    """repack + forward + losses + the first backward segment (back to the end of fusion stage 3): on return the tail of the
+    gradient arena, flat_grad[eng.early_offset:], is final."""
     eng, model = self.eng, self.model
     eng.training = True
     eng.dtype = model.compute_dtype
@@ -66,8 +70,18 @@ class Trainer:
     eng.tape = Tape(eng.lanes)
     t = eng.forward(batch['rgb'], batch['lidar_bev'], batch['target_point'], batch['ego_vel'], batch['command'])
     _, vals, seeds = fused_losses(model, t, batch, self.loss_weights, True)
-    tape, eng.tape = eng.tape, None
-    tape.backward(seeds)
+    self._tape, eng.tape = eng.tape, None
+    self._tape.backward(seeds, stop_at_mark=True)
+    return vals
+
+  def _step_part2(self):
+    """the rest of backward (stems .. fusion stage 3)"""
+    self._tape.backward_resume()
+    self._tape = None
+
+  def _step_body(self, batch):
+    vals = self._step_part1(batch)
+    self._step_part2()
     return vals
 
   def _optimizer(self, step):
@@ -79,13 +93,29 @@ class Trainer:
     Returns the vector of unweighted losses (device tensor, order = self.loss_names)."""
     self.model.train()
     self.step_count += 1
-    vals = self._step_body(batch)
-    self.finish_step()
+    vals = self._step_part1(batch)
+    early = self.reduce_early()  # N > 1: the finished two thirds of the gradients travel while the rest is computed
+    self._step_part2()
+    self.finish_step(early)
     return vals
 
-  def finish_step(self):
-    """gradient exchange + optimizer (kept outside any captured graph)."""
-    tdist.all_reduce_gradients(self.eng.flat_grad, self.pg)
+  def overlap_enabled(self):
+    return self.world > 1 or os.environ.get('TFPP_SPLIT_STEP', '0') == '1'
+
+  def reduce_early(self):
+    """Asynchronous all-reduce of flat_grad[early_offset:] (RCCL runs it on its own stream, ordered after what this stream has
+    issued so far).  Returns the handle finish_step() waits on, or None when there is nothing to overlap."""
+    if self.world == 1:
+      return None
+    return tdist.all_reduce_async(self.eng.flat_grad[self.eng.early_offset:], self.pg)
+
+  def finish_step(self, early=None):
+    """rest of the gradient exchange + optimizer (kept outside any captured graph)."""
+    if early is None:
+      tdist.all_reduce_gradients(self.eng.flat_grad, self.pg)
+    else:
+      tdist.all_reduce_gradients(self.eng.flat_grad[:self.eng.early_offset], self.pg)
+      early.wait()
     self._optimizer(self.step_count)
 
   def total_loss(self, vals):

@@ -43,7 +43,13 @@ def _worker(rank, world, port, out):
     g = torch.Generator().manual_seed(tdist.rank_seed(1234, rank) * 10 + step)
     flat_grad = torch.randn(n, generator=g)
     grads.append(flat_grad.clone())
-    scale = tdist.all_reduce_gradients(flat_grad, chunk_elems=4096 if step == 2 else None)
+    if step == 3:  # the trainer's overlapped exchange: tail of the arena early (async), head afterwards, then wait
+      early = tdist.all_reduce_async(flat_grad[6000:])
+      assert early is not None
+      scale = tdist.all_reduce_gradients(flat_grad[:6000])
+      early.wait()
+    else:
+      scale = tdist.all_reduce_gradients(flat_grad, chunk_elems=4096 if step == 2 else None)
     assert scale == 1.0 / world
     flat_param, m, v, vmax = _adamw_amsgrad_ref(flat_param, flat_grad, m, v, vmax, 3e-4, 0.9, 0.999, 1e-8, 0.01, step, scale)
   tmax = tdist.max_over_ranks(1.0 + rank, torch.device('cpu'))
@@ -75,3 +81,4 @@ def test_single_process_is_a_no_op():
   assert tdist.all_reduce_gradients(t) == 1.0 and tdist.world_size() == 1
   tdist.broadcast_state(t, [])
   assert tdist.max_over_ranks(3.5, torch.device('cpu')) == 3.5
+  assert tdist.all_reduce_async(t) is None

@@ -86,6 +86,30 @@ def _report(name, errs):
     pass
 
 
+def test_arena_order_puts_early_finishing_gradients_at_the_tail(model_cpu):
+  """Flat-arena layout used for the overlapped gradient exchange: every trainable parameter exactly once, the parameters whose
+  gradients are complete after the first backward segment (heads, decoders, planning head, stage 4 of the backbone) contiguous
+  at the tail, and that tail is the larger part of the 481 MB."""
+  from carla_garage_amd.engine import arena_order, finishes_early
+  order, early_off = arena_order(model_cpu)
+  names = [n for n, _ in order]
+  want = [n for n, p in model_cpu.named_parameters() if p.requires_grad]
+  assert sorted(names) == sorted(want) and len(set(names)) == len(names)
+  flags = [finishes_early(n) for n in names]
+  first_early = flags.index(True)
+  assert all(flags[first_early:]) and not any(flags[:first_early])
+  pad4 = lambda k: (k + 3) // 4 * 4
+  assert early_off == sum(pad4(p.numel()) for _, p in order[:first_early])
+  total = sum(pad4(p.numel()) for _, p in order)
+  assert 0.5 < (total - early_off) / total < 0.9
+  for n in ('backbone.transformers.3.blocks.0.attn.query.weight', 'backbone.image_encoder.s4.b1.conv1.conv.weight', 'head.heatmap_head.0.weight',
+            'join.layers.0.linear1.weight', 'backbone.c5_conv.weight'):
+    assert finishes_early(n), n
+  for n in ('backbone.transformers.2.blocks.1.mlp.0.weight', 'backbone.image_encoder.s3.b1.conv1.conv.weight', 'backbone.lidar_encoder.stem.conv.weight',
+            'backbone.lidar_channel_to_img.2.weight'):
+    assert not finishes_early(n), n
+
+
 @pytest.mark.gpu
 def test_eval_forward_fp32_vs_reference_golden_and_oracle():
   """BASELINE config 2: TransFuser++ inference forward, bs=1, fp32, parity within 1e-3 relative."""
@@ -220,14 +244,15 @@ def test_streams_and_hipgraph_do_not_change_the_training_step():
   batch = {k: v.cuda() for k, v in P.make_labels(2).items()}
   for k, v in zip(('rgb', 'lidar_bev', 'target_point', 'ego_vel', 'command'), P.make_inputs(2)):
     batch[k] = v.cuda()
-  saved = {k: os.environ.get(k) for k in ('TFPP_BRANCH_STREAMS', 'TFPP_SIDE_STREAM')}
+  saved = {k: os.environ.get(k) for k in ('TFPP_BRANCH_STREAMS', 'TFPP_SIDE_STREAM', 'TFPP_SPLIT_STEP')}
 
-  def run(single, graph):
-    for k in saved:
+  def run(single, graph, split=False):
+    for k in ('TFPP_BRANCH_STREAMS', 'TFPP_SIDE_STREAM'):
       if single:
         os.environ[k] = '0'
       else:
         os.environ.pop(k, None)
+    os.environ['TFPP_SPLIT_STEP'] = '1' if split else '0'  # two graphs split at Tape.mark(), as the multi-GPU step is captured
     m = _model('fp32').train()
     _zero_dropout(m)
     tr = Trainer(m, lr=1e-5)
@@ -242,7 +267,7 @@ def test_streams_and_hipgraph_do_not_change_the_training_step():
     ref = run(True, False)
     assert all(np.isfinite(a).all() for a in ref)
     errs = {}
-    for name, args in (('lanes', (False, False)), ('lanes+graph', (False, True))):
+    for name, args in (('lanes', (False, False)), ('lanes+graph', (False, True)), ('lanes+split-graphs', (False, True, True))):
       r = run(*args)
       errs[name] = {'loss1': float(np.max(np.abs(r[0] - ref[0]) / np.abs(ref[0]))), 'grad1': float(np.linalg.norm(r[1] - ref[1]) / np.linalg.norm(ref[1])),
                     'loss2': float(np.max(np.abs(r[2] - ref[2]) / np.abs(ref[2]))), 'grad2': float(np.linalg.norm(r[3] - ref[3]) / np.linalg.norm(ref[3]))}
@@ -255,3 +280,30 @@ def test_streams_and_hipgraph_do_not_change_the_training_step():
   _report('streams', errs)
   for name, e in errs.items():
     assert e['loss1'] < 1e-4 and e['grad1'] < 2e-2 and e['loss2'] < 5e-3 and e['grad2'] < 8e-2, (name, e)
+
+
+@pytest.mark.gpu
+def test_first_backward_segment_completes_the_early_gradients():
+  """The overlapped gradient exchange all-reduces flat_grad[early_offset:] after the first backward segment: that slice must be
+  final there (bit-identical after the second segment), the head of the arena must still be incomplete."""
+  from carla_garage_amd.trainer import Trainer
+  batch = {k: v.cuda() for k, v in P.make_labels(2).items()}
+  for k, v in zip(('rgb', 'lidar_bev', 'target_point', 'ego_vel', 'command'), P.make_inputs(2)):
+    batch[k] = v.cuda()
+  m = _model('bf16').train()
+  tr = Trainer(m, lr=1e-5)
+  tr._step_part1(batch)
+  torch.cuda.synchronize()
+  g, off = tr.eng.flat_grad, tr.eng.early_offset
+  assert 0 < off < g.numel()
+  early, late = g[off:].clone(), g[:off].clone()
+  assert float(early.abs().sum()) > 0
+  tr._step_part2()
+  torch.cuda.synchronize()
+  assert torch.equal(g[off:], early)
+  assert not torch.equal(g[:off], late)
+  # every early parameter received a gradient in segment 1, every late one in segment 2 (spot checks on both sides)
+  for name in ('head.heatmap_head.0.weight', 'backbone.transformers.3.blocks.0.mlp.0.weight', 'backbone.image_encoder.s4.b1.conv1.conv.weight'):
+    assert float(tr.eng.grads[name].abs().sum()) > 0, name
+  for name in ('backbone.transformers.2.blocks.0.mlp.0.weight', 'backbone.lidar_encoder.stem.conv.weight'):
+    assert float(tr.eng.grads[name].abs().sum()) > 0, name
