@@ -57,9 +57,10 @@ class Trainer:
     tdist.broadcast_state(self.flat_param, list(self.model.buffers()), self.pg)  # DDP constructor broadcast, train.py:516
 
   # ---------------------------------------------------------------------------------------------- one step
-  def _step_part1(self, batch):
+  def _step_part1(self, batch, split=True):
     """repack + forward + losses + the first backward segment (back to the end of fusion stage 3): on return the tail of the
-    gradient arena, flat_grad[eng.early_offset:], is final."""
+    gradient arena, flat_grad[eng.early_offset:], is final.  split=False runs the whole backward in one segment (no join of the
+    lanes in the middle: the single-GPU step)."""
     eng, model = self.eng, self.model
     eng.training = True
     eng.dtype = model.compute_dtype
@@ -71,7 +72,7 @@ class Trainer:
     t = eng.forward(batch['rgb'], batch['lidar_bev'], batch['target_point'], batch['ego_vel'], batch['command'])
     _, vals, seeds = fused_losses(model, t, batch, self.loss_weights, True)
     self._tape, eng.tape = eng.tape, None
-    self._tape.backward(seeds, stop_at_mark=True)
+    self._tape.backward(seeds, stop_at_mark=split)
     return vals
 
   def _step_part2(self):
@@ -80,8 +81,8 @@ class Trainer:
     self._tape = None
 
   def _step_body(self, batch):
-    vals = self._step_part1(batch)
-    self._step_part2()
+    vals = self._step_part1(batch, split=False)
+    self._tape = None
     return vals
 
   def _optimizer(self, step):
@@ -93,6 +94,10 @@ class Trainer:
     Returns the vector of unweighted losses (device tensor, order = self.loss_names)."""
     self.model.train()
     self.step_count += 1
+    if not self.overlap_enabled():
+      vals = self._step_body(batch)
+      self.finish_step()
+      return vals
     vals = self._step_part1(batch)
     early = self.reduce_early()  # N > 1: the finished two thirds of the gradients travel while the rest is computed
     self._step_part2()
