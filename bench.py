@@ -272,12 +272,14 @@ def main():
   assert loss_total == loss_total and abs(loss_total) < 1e9, f'training diverged: {loss_total}'
 
   roof = None
-  if rank == 0 and not args.no_roofline:
+  if rank == 0 and world == 1 and not args.no_roofline:  # per-kernel timing runs extra local steps: single-process runs only
     prof = KernelProfiler()
     lib.profiler = prof
     nprof = 2
-    for _ in range(nprof):
-      trainer.train_step(batch)
+    for _ in range(nprof):  # local steps (no gradient exchange): only this rank profiles, so it must not enter a collective
+      trainer.step_count += 1
+      trainer._step_body(batch)
+      trainer._optimizer(trainer.step_count)
     lib.profiler = None
     agg = prof.summary()
     total_ms = sum(a['ms'] for a in agg.values())
@@ -337,6 +339,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline()
     print(json.dumps(line), flush=True)
+  torch.cuda.synchronize()  # nothing in flight when the graphs and the arenas are torn down
   if world > 1:
     dist.destroy_process_group()
 
