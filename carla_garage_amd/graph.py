@@ -7,6 +7,11 @@ one forward (~900 launches at bs=1, the 20 Hz closed-loop tick of sensor_agent.p
 """
 import torch
 
+# Other threads of the process may issue HIP calls while a capture is open (the RCCL watchdog thread of an initialised process
+# group polls its events): with the default "global" mode any such call invalidates the capture.  "thread_local" still rejects
+# unsafe calls made by the capturing thread itself.
+CAPTURE_MODE = 'thread_local'
+
 
 class GraphedForward:
   """``y = GraphedForward(model, rgb, lidar_bev, target_point, ego_vel, command)(...)`` -- eval-mode, no-grad forward."""
@@ -19,7 +24,7 @@ class GraphedForward:
         model(*self.static_in)
     torch.cuda.synchronize()
     self.graph = torch.cuda.CUDAGraph()
-    with torch.inference_mode(), torch.cuda.graph(self.graph):
+    with torch.inference_mode(), torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
       self.static_out = model(*self.static_in)
     torch.cuda.synchronize()
 
@@ -47,13 +52,13 @@ class GraphedTrainStep:
     self.graph = torch.cuda.CUDAGraph()
     self.graph2 = None
     if self.split:
-      with torch.cuda.graph(self.graph):
+      with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
         self.vals = trainer._step_part1(self.static_batch)
       self.graph2 = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+      with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode=CAPTURE_MODE):
         trainer._step_part2()
     else:
-      with torch.cuda.graph(self.graph):
+      with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
         self.vals = trainer._step_body(self.static_batch)
     torch.cuda.synchronize()
 
