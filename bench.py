@@ -94,7 +94,9 @@ def cpu_baseline_worker(cfg_bs, budget_s):
       med = sorted(times)[len(times) // 2]
       print(json.dumps({'value': round(cfg_bs / med, 4), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
                         'sample': f'bs={cfg_bs} x {len(times)} train steps (fwd + 10 losses + bwd + AdamW-amsgrad), fp32, '
-                                  f'median step {med:.2f} s'}), flush=True)
+                                  f'median step {med:.2f} s; bs=2 not 12 so that >= 3 steps fit the 25 s CPU budget of the default run '
+                                  f'(a bs=12 step takes ~23 s on 8 cores, samples/s is the same within 10%), threads capped at 32 '
+                                  f'of {os.cpu_count()} (intra-op scaling of these layer sizes saturates earlier)'}), flush=True)
     it += 1
     if time.perf_counter() - t_start > budget_s or len(times) >= 5:
       break
@@ -184,6 +186,31 @@ def lidar_histogram_latency(cfg, device, log, n=60000, iters=50):
   return r
 
 
+def pmc_traffic(family):
+  """HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written
+  by tools/pmc_traffic.sh; bench.py cannot collect PMC counters itself).  An entry records the sha of the kernel source it was
+  measured on: after the kernel changes the entry is refused (traffic = null) instead of silently going stale."""
+  import hashlib
+  try:
+    with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), encoding='utf-8') as f:
+      ent = json.load(f).get(family)
+  except (OSError, ValueError):
+    ent = None
+  if not ent:
+    return None, 'no PMC measurement committed for this kernel family'
+  try:
+    with open(os.path.join(ROOT, 'carla_garage_amd', 'csrc', ent['source_file']), 'rb') as f:
+      sha = hashlib.sha256(f.read()).hexdigest()[:16]
+  except OSError:
+    sha = None
+  if sha != ent.get('source_sha16'):
+    return None, f"stale: {ent['source_file']} changed since the PMC pass of {ent.get('measured', '?')} (re-run tools/pmc_traffic.sh)"
+  traffic = ent['fetch_bytes_per_launch'] + (ent.get('write_bytes_per_launch') or 0)
+  note = ('FETCH_SIZE x2 (gfx950 correction)' + (' + WRITE_SIZE (raw, uncalibrated on gfx950)' if ent.get('write_bytes_per_launch') else '') +
+          f", separate counter-only rocprofv3 --pmc passes, {ent.get('measured', '')}, profiles/pmc_traffic.json")
+  return traffic, note
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -196,6 +223,8 @@ def main():
   ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay of the step body')
   ap.add_argument('--no-inference', action='store_true', help='skip the bs=1 forward latency measurement')
   ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel-family time table to stderr')
+  ap.add_argument('--force-collectives', action='store_true',
+                  help='initialise a process group and issue the gradient all-reduces even with one rank (exercises the RCCL path on one GPU)')
   ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
   ap.add_argument('--cpu-budget', type=float, default=25.0, help=argparse.SUPPRESS)
   args = ap.parse_args()
@@ -203,18 +232,46 @@ def main():
     cpu_baseline_worker(args.batch_size, args.cpu_budget)
     return
 
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    # started by hand as `python bench.py --gpus N`: become the launcher the driver uses (team_code/shell_train.sh:12 is the
+    # reference's torchrun line) -- one rank per GPU, RCCL rendezvous on 127.0.0.1 -- instead of quietly measuring one GPU
+    if torch.cuda.device_count() < args.gpus:
+      raise SystemExit(f'bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node; refusing to report a '
+                       f'{args.gpus}-GPU number from fewer devices')
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+      sk.bind(('127.0.0.1', 0))
+      port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
   rank = int(os.environ.get('RANK', 0))
   local_rank = int(os.environ.get('LOCAL_RANK', 0))
   world = int(os.environ.get('WORLD_SIZE', 1))
-  if args.gpus != world and world > 1:
-    raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-  if not torch.cuda.is_available():
-    raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+  if args.gpus != world:
+    raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python -m torch.distributed.run '
+                     f'--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)')
+  if local_rank >= torch.cuda.device_count():
+    raise SystemExit(f'rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) visible')
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
-  if world > 1:
+  rccl_ranks = None
+  if world > 1 or args.force_collectives:
+    # one process per GPU, RCCL over xGMI (backend 'nccl' is RCCL on ROCm).  --force-collectives builds the group even for one
+    # rank, so a 1-GPU box executes the whole exchange path (two-graph step + all-reduce between the replays)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', init_method='env://')  # RCCL over xGMI
+    os.environ.setdefault('MASTER_PORT', '29511')
+    if args.force_collectives:
+      os.environ['TFPP_FORCE_COLLECTIVES'] = '1'
+    dist.init_process_group('nccl', init_method='env://', rank=rank, world_size=world)
+    probe = torch.ones(1, device=device)
+    dist.all_reduce(probe)  # a real collective: the reported rank count is what RCCL summed, not what the environment claims
+    torch.cuda.synchronize()
+    rccl_ranks = int(probe.item())
+    assert rccl_ranks == world, f'RCCL all-reduce over {rccl_ranks} ranks, expected {world}'
 
   from carla_garage_amd.config import GlobalConfig
   from carla_garage_amd.model import LidarCenterNet
@@ -239,7 +296,7 @@ def main():
   log('model, trainer and synthetic batch ready')
 
   def sync():
-    if world > 1:
+    if rccl_ranks is not None:
       dist.barrier()
     torch.cuda.synchronize()
 
@@ -265,14 +322,44 @@ def main():
   elapsed = time.perf_counter() - t0
   log(f'{args.steps} timed steps: {1e3 * elapsed / args.steps:.1f} ms/step')
   tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-  if world > 1:
+  if rccl_ranks is not None:
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
   elapsed = float(tmax.item())
   loss_total = trainer.total_loss(vals)
   assert loss_total == loss_total and abs(loss_total) < 1e9, f'training diverged: {loss_total}'
 
+  comm = None
+  if rccl_ranks is not None:
+    # exposed communication = step time with the gradient exchange - time of the identical local step (no collective; every rank
+    # runs it, so nobody waits in one).  The local step is captured the same way as the real one (single-segment hipGraph).
+    trainer.exchange = False
+    try:
+      local_fn = lambda: trainer.train_step(batch)
+      if graphed:
+        from carla_garage_amd.graph import GraphedTrainStep
+        glocal = GraphedTrainStep(trainer, batch, warmup=1)
+        local_fn = lambda: glocal()
+      for _ in range(max(1, args.warmup // 2)):
+        local_fn()
+      sync()
+      t1 = time.perf_counter()
+      for _ in range(args.steps):
+        local_fn()
+      sync()
+      tl = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
+      if world > 1:
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+      local_ms = 1e3 * float(tl.item()) / args.steps
+      comm = {'rccl_ranks': rccl_ranks, 'ms_per_step_without_exchange': round(local_ms, 3),
+              'exposed_comm_ms_per_step': round(1e3 * elapsed / args.steps - local_ms, 3),
+              'allreduce_bytes_per_step': int(trainer.eng.flat_grad.numel()) * 4,
+              'overlap': 'two hipGraph segments, all-reduce of the early-finishing 2/3 of the arena between the replays'}
+      log(f'gradient exchange: {comm}')
+    finally:
+      trainer.exchange = True
+
   roof = None
-  if rank == 0 and world == 1 and not args.no_roofline:  # per-kernel timing runs extra local steps: single-process runs only
+  if rank == 0 and rccl_ranks is None and not args.no_roofline:  # per-kernel timing runs extra local steps: single-process runs only
     prof = KernelProfiler()
     lib.profiler = prof
     nprof = 2
@@ -286,19 +373,7 @@ def main():
     fam, a = max(((f, a) for f, a in agg.items() if a['flops'] > 0), key=lambda fa: fa[1]['ms'])
     ach = a['flops'] / (a['ms'] * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.dtype]
-    traffic, traffic_note = None, 'no PMC measurement committed for this kernel'
-    try:  # HBM-side bytes per launch from the committed rocprofv3 --pmc pass (bench.py cannot collect PMC counters itself)
-      with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json'), encoding='utf-8') as f:
-        pmc = json.load(f)
-      if fam in pmc:
-        traffic = pmc[fam]['fetch_bytes_per_launch']
-        traffic_note = 'FETCH_SIZE x2 (gfx950 correction)'
-        if pmc[fam].get('write_bytes_per_launch'):
-          traffic += pmc[fam]['write_bytes_per_launch']
-          traffic_note += ' + WRITE_SIZE (raw, uncalibrated on gfx950)'
-        traffic_note += ', separate counter-only rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json'
-    except (OSError, ValueError):
-      pass
+    traffic, traffic_note = pmc_traffic(fam)
     roof = {'bound': 'mfma', 'kernel': fam, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'traffic': traffic, 'traffic_note': traffic_note, 'algorithmic_flop_per_launch': round(a['flops'] / a['calls']),
             'algorithmic_bytes_per_launch': round(a['bytes'] / a['calls']) if a.get('bytes') else None,
@@ -313,7 +388,7 @@ def main():
   if rank == 0 and not args.no_inference:
     fwd = inference_latency(model, cfg, device, log)
     lidar_hist = lidar_histogram_latency(cfg, device, log)
-  if world > 1:
+  if rccl_ranks is not None:
     dist.barrier()
 
   if rank == 0:
@@ -334,13 +409,15 @@ def main():
       line['fwd_ms_per_frame'] = fwd
     if lidar_hist is not None:
       line['lidar_histogram_60k_points_us'] = lidar_hist
+    if comm is not None:
+      line['gradient_exchange'] = comm
     if roof is not None:
       line['roofline'] = roof
     if world == 1 and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline()
     print(json.dumps(line), flush=True)
   torch.cuda.synchronize()  # nothing in flight when the graphs and the arenas are torn down
-  if world > 1:
+  if rccl_ranks is not None:
     dist.destroy_process_group()
 
 

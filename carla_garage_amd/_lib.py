@@ -74,11 +74,40 @@ def declared_functions(header=HEADER):
   return out
 
 
+def source_hash():
+  """64-bit hash over the kernel sources and the ABI header (file names + contents): compiled into the library by build() and
+  compared by load(), so the binary under test is always the one these sources produce."""
+  import hashlib
+  h = hashlib.sha256()
+  files = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cuh', '.h')))
+  for path in [os.path.join(CSRC, f) for f in files] + [HEADER]:
+    h.update(os.path.basename(path).encode() + b'\0')
+    with open(path, 'rb') as f:
+      h.update(f.read())
+    h.update(b'\0')
+  return int(h.hexdigest()[:16], 16)
+
+
+HASH_PATH = LIB_PATH + '.srchash'  # written by build() next to the library (reading the embedded hash would dlopen the old binary)
+
+
+def built_hash():
+  """Source hash of the library on disk according to build()'s sidecar file (None: no library / no sidecar).  The authoritative
+  check is load(), which reads the hash compiled into the binary."""
+  if not (os.path.exists(LIB_PATH) and os.path.exists(HASH_PATH)):
+    return None
+  try:
+    with open(HASH_PATH, encoding='utf-8') as f:
+      return int(f.read().strip(), 16)
+  except (OSError, ValueError):
+    return None
+
+
 def build(verbose=False, force=False):
   """Compile every HIP source for gfx950 into carla_garage_amd/libtfpp_hip.so (hipcc cross-compiles without a GPU)."""
   srcs = [os.path.join(CSRC, s) for s in SOURCES]
-  deps = srcs + [os.path.join(CSRC, 'common.cuh'), os.path.join(CSRC, 'gemm_core.cuh'), os.path.join(CSRC, 'gemm_internal.h'), HEADER]
-  if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+  want = source_hash()
+  if not force and built_hash() == want:
     return LIB_PATH
   objs = []
   procs = []
@@ -86,7 +115,7 @@ def build(verbose=False, force=False):
   for s in srcs:
     o = os.path.join(PKG_DIR, 'build', os.path.basename(s) + '.o')
     objs.append(o)
-    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o]
+    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', f'-DTFPP_SOURCE_HASH=0x{want:016x}ULL', '-c', s, '-o', o]
     procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
   for cmd, p in procs:
     outp = p.communicate()[0].decode()
@@ -98,6 +127,8 @@ def build(verbose=False, force=False):
   r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=False)
   if r.returncode != 0:
     raise RuntimeError('link failed: ' + r.stdout.decode())
+  with open(HASH_PATH, 'w', encoding='utf-8') as f:
+    f.write(f'{want:016x}\n')
   return LIB_PATH
 
 
@@ -173,6 +204,11 @@ class _Lib:
       raise TfppError(f'struct layout mismatch: library {list(sizes[:4])} vs ctypes {mine}')
     if self._dll.tfpp_version() != 1:
       raise TfppError('ABI version mismatch')
+    got = ctypes.c_uint64(0)
+    self._fns['tfpp_source_hash'](ctypes.byref(got))
+    if os.environ.get('TFPP_SKIP_HASH_CHECK', '0') != '1' and int(got.value) != source_hash():
+      raise TfppError(f'{LIB_PATH} was built from other sources (hash {int(got.value):016x}, sources {source_hash():016x}): '
+                      'rebuild with `python -c "import __graft_entry__ as g; g.build()"`')
     return self
 
   def __getattr__(self, name):

@@ -391,6 +391,17 @@ extern "C" int tfpp_adamw_amsgrad(float* p, const float* g, float* m, float* v, 
 
 extern "C" int tfpp_version(void) { return TFPP_ABI_VERSION; }
 
+// Hash of the kernel sources this binary was built from (passed in by carla_garage_amd/_lib.py::build): the loader compares it
+// with the sources next to it, so a stale libtfpp_hip.so (git-ignored, shipped out of band) is rejected instead of tested.
+#ifndef TFPP_SOURCE_HASH
+#define TFPP_SOURCE_HASH 0ULL
+#endif
+extern "C" int tfpp_source_hash(uint64_t* out) {
+  if (!out) return TFPP_EINVAL;
+  *out = (uint64_t)TFPP_SOURCE_HASH;
+  return 0;
+}
+
 extern "C" int tfpp_struct_sizes(int* out, int n) {
   if (!out || n < 4) return TFPP_EINVAL;
   out[0] = (int)sizeof(tfpp_conv_params);

@@ -1008,6 +1008,12 @@ extern "C" int tfpp_zero(void* p, int64_t bytes, void* stream) {
   return e == hipSuccess ? 0 : -(int)e;
 }
 
+extern "C" int tfpp_fill_bytes(void* p, int value, int64_t bytes, void* stream) {
+  if (!p || bytes < 0) return TFPP_EINVAL;
+  hipError_t e = hipMemsetAsync(p, value & 0xff, (size_t)bytes, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // multi-tensor weight packing: every per-step weight image (conv forward / data-gradient layouts, head-padded QKV,
 // transposes, fp32 -> bf16 casts) in ONE launch, driven by a device-resident descriptor table.

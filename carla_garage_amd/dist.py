@@ -23,9 +23,18 @@ def world_size(group=None):
   return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def exchange_enabled(group=None):
+  """True when the gradient collectives are really issued: more than one rank, or a process group of ONE rank with
+  TFPP_FORCE_COLLECTIVES=1 (a 1-GPU box then runs the complete RCCL code path -- launch, stream ordering, the two-graph step
+  with the all-reduce between the replays -- which is how tests/test_dist_gpu.py covers it without a second GPU)."""
+  if not (dist.is_available() and dist.is_initialized()):
+    return False
+  return dist.get_world_size(group) > 1 or os.environ.get('TFPP_FORCE_COLLECTIVES', '0') == '1'
+
+
 def broadcast_state(flat_param, buffers, group=None, src=0):
   """Rank ``src``'s parameters and buffers everywhere (what the DDP constructor does, train.py:516)."""
-  if world_size(group) == 1:
+  if not exchange_enabled(group):
     return
   dist.broadcast(flat_param, src, group=group)
   for b in buffers:
@@ -36,7 +45,7 @@ def all_reduce_gradients(flat_grad, group=None, chunk_elems=None):
   """SUM all-reduce of the flat gradient arena (the average is folded into the optimizer's grad_scale = 1/world).
   ``chunk_elems`` splits the arena into fewer, larger collectives than DDP's 25 MB buckets (default: one)."""
   w = world_size(group)
-  if w == 1:
+  if not exchange_enabled(group):
     return 1.0
   if chunk_elems is None or chunk_elems >= flat_grad.numel():
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
@@ -51,7 +60,7 @@ def all_reduce_gradients(flat_grad, group=None, chunk_elems=None):
 def all_reduce_async(tensor, group=None):
   """SUM all-reduce of a slice of the gradient arena, returned as a work handle (``.wait()`` orders the current stream after
   it).  Used to send the part of the gradients that is finished early while the rest of backward still runs."""
-  if world_size(group) == 1 or tensor.numel() == 0:
+  if not exchange_enabled(group) or tensor.numel() == 0:
     return None
   return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=True)
 

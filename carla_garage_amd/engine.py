@@ -27,6 +27,23 @@ def _key(t):
   return (t.data_ptr(), t.numel())
 
 
+DEBUG_POISON = os.environ.get('TFPP_DEBUG_POISON', '0') == '1'
+
+
+def _release(tensors):
+  """Drop the keep-alive references of tensors that crossed streams.  TFPP_DEBUG_POISON=1 (tools/stress_step.py): a tensor whose only
+  remaining owner is this list is filled with NaN bytes first (on the current stream, i.e. after the joins that justify the release),
+  so a consumer that was NOT ordered before the release computes on NaN instead of on silently recycled memory."""
+  if DEBUG_POISON:
+    import sys
+    for i in range(len(tensors)):
+      t = tensors[i]
+      if t is not None and t.is_cuda and sys.getrefcount(t) <= 3 and t._base is None and t.is_contiguous():  # list slot + local + argument
+        ops.lib.tfpp_fill_bytes(ops.ptr(t), 0xFF, t.numel() * t.element_size(), ops.stream())
+      del t
+  tensors.clear()
+
+
 class Lanes:
   """HIP streams of the two encoder branches.  Lane 0 is the caller's stream (image branch, fusion transformers, heads), lane 1
   a second stream for the LiDAR branch: its kernels (a quarter of the pixels: small, latency-bound launches) overlap with the
@@ -48,6 +65,7 @@ class Lanes:
   def begin(self, device):
     """Call at the start of a forward / backward pass: lane 0 = the stream current right now."""
     self.cur = 0
+    _release(self.held)
     self.held = []
     if not self.enabled or torch.device(device).type != 'cuda':
       self.main = None
@@ -158,7 +176,7 @@ class Tape:
     if self._grads is None:
       return
     if self.lanes is not None and self._multi:
-      held = self.lanes.held
+      held, self.lanes.held = self.lanes.held, []  # keep-alives of the first segment survive until the end of the second
       self.lanes.begin(self.lanes.main.device)  # lane 0 = the stream current now (the same capture stream in a hipGraph)
       self.lanes.held = held
       # fork lane 1 from lane 0 before anything runs on it: this segment may be the start of a new hipGraph capture, and a stream
@@ -244,6 +262,7 @@ class Tape:
 
   def _finish(self):
     if self._multi:
+      _release(self.lanes.held)
       self.lanes.held = []
     self._grads = None
     self.frozen = {}
@@ -296,6 +315,7 @@ class SideLane:
     if self.keep:
       self.flush()
       torch.cuda.current_stream().wait_stream(self.stream)
+      _release(self.keep)
       self.keep = []
 
 
@@ -353,6 +373,8 @@ class Engine:
     self.flat_grad = None
     self._consts = {}
     self._packed_key = None
+    self._generation = 0
+    self._plans, self._plan, self._plan_key = {}, None, None
     self.lanes = Lanes()
     self.side = SideLane()
     self.side.lanes = self.lanes
@@ -443,8 +465,14 @@ class Engine:
 
   # ------------------------------------------------------------------------------------------------ weights
   def _weights_key(self, dtype, need_t):
-    return (dtype, need_t, tuple((p.data_ptr(), p._version) for p in self.m.parameters()),
+    return (dtype, need_t, self.training, self._generation, tuple((p.data_ptr(), p._version) for p in self.m.parameters()),
             tuple((b.data_ptr(), b._version) for b in self.m.buffers()) if not self.training else None)
+
+  def invalidate(self):
+    """Parameters / BatchNorm buffers were written through raw pointers (fused optimizer, BN running statistics, hipGraph
+    replays): tensor._version cannot see that, so the trainer bumps the generation and the next prepare() repacks the weight
+    images and re-folds the BatchNorm statistics."""
+    self._generation += 1
 
   def prepare(self, dtype, training, need_grad):
     """(Re)pack weights for ``dtype`` when parameters changed; fold BN for eval."""
@@ -456,23 +484,32 @@ class Engine:
     self._packed_key = self._weights_key(dtype, need_grad)
 
   def repack(self, dtype, need_t):
-    """Refresh every kernel-layout weight image.  The first call records all packing requests into a PackPlan
-    (persistent destinations); later calls replay the whole plan as one launch."""
+    """Refresh every kernel-layout weight image.  The first call for a (dtype, need_t) combination records all packing requests
+    into a PackPlan with persistent destinations; later calls replay that plan as one launch.  Plans are kept per combination
+    (train: forward + transposed images, eval: forward only), so alternating train / eval neither re-allocates the images nor
+    frees buffers a captured hipGraph still writes into."""
     key = (dtype, need_t, str(self.device), tuple(p.data_ptr() for p in self.m.parameters()))
-    if getattr(self, '_plan', None) is not None and self._plan_key == key:
-      self._plan.launch()
-      self._refresh_small()
-      return
-    plan = ops.PackPlan()
-    ops.PACK_PLAN = plan
-    try:
-      self._repack_build(dtype, need_t)
-    finally:
-      ops.PACK_PLAN = None
-    plan.finalize(self.device)
-    plan.launch()
-    self._plan, self._plan_key = plan, key
+    ent = self._plans.get(key)
+    if ent is None:
+      plan = ops.PackPlan()
+      ops.PACK_PLAN = plan
+      try:
+        self._repack_build(dtype, need_t)
+      finally:
+        ops.PACK_PLAN = None
+      plan.finalize(self.device)
+      ent = self._plans[key] = dict(plan=plan, specs={k: (s.wp, s.wt) for k, s in self.specs.items()},
+                                    attn={k: {n: st.get(n) for n in self.ATTN_IMAGES} for k, st in getattr(self, '_attn', {}).items()})
+    elif self._plan_key != key:  # switch the specs back to this plan's images
+      for k, (wp, wt) in ent['specs'].items():
+        self.specs[k].wp, self.specs[k].wt = wp, wt
+      for k, imgs in ent['attn'].items():
+        self._attn[k].update(imgs)
+    self._plan, self._plan_key = ent['plan'], key
+    ent['plan'].launch()
     self._refresh_small()
+
+  ATTN_IMAGES = ('wqkv', 'bqkv', 'wproj', 'wqkv_t', 'wproj_t')
 
   def _refresh_small(self):
     """Padded biases and (eval) folded BatchNorm scale/shift: tiny per-layer launches."""
@@ -562,6 +599,7 @@ class Engine:
         off += ops.pad_to(p.numel(), 4)
       self._gid = {id(p): n for n, p in params}
     ops.zero_(self.flat_grad)
+    ops.clear_stats_rows(self.device)  # the fused BatchNorm statistics start every step from zeroed rows, whatever happened before
 
   def g(self, param):
     n = self._gid.get(id(param))

@@ -12,6 +12,23 @@ import torch
 # unsafe calls made by the capturing thread itself.
 CAPTURE_MODE = 'thread_local'
 
+_CAPTURE_STREAMS = {}
+
+
+def capture_stream(device):
+  """One capture stream per device for every graph of this module: the per-stream scratch buffers of ops.py are keyed by stream, so
+  all captures share one set, prepared (allocated, statistics rows zeroed) before the capture starts."""
+  from . import ops
+  device = torch.device(device)
+  st = _CAPTURE_STREAMS.get(str(device))
+  if st is None:
+    st = _CAPTURE_STREAMS[str(device)] = torch.cuda.Stream(device)
+  st.wait_stream(torch.cuda.current_stream(device))
+  with torch.cuda.stream(st):
+    ops.clone_scratch_for_current_stream(device)
+  torch.cuda.current_stream(device).wait_stream(st)
+  return st
+
 
 class GraphedForward:
   """``y = GraphedForward(model, rgb, lidar_bev, target_point, ego_vel, command)(...)`` -- eval-mode, no-grad forward."""
@@ -24,7 +41,8 @@ class GraphedForward:
         model(*self.static_in)
     torch.cuda.synchronize()
     self.graph = torch.cuda.CUDAGraph()
-    with torch.inference_mode(), torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
+    st = capture_stream(self.static_in[0].device)
+    with torch.inference_mode(), torch.cuda.graph(self.graph, stream=st, capture_error_mode=CAPTURE_MODE):
       self.static_out = model(*self.static_in)
     torch.cuda.synchronize()
 
@@ -43,22 +61,27 @@ class GraphedTrainStep:
   (Tape.mark): their slice of the arena is all-reduced while the second graph replays."""
 
   def __init__(self, trainer, batch, warmup=2):
+    """NOTE: the ``warmup`` eager steps are real training steps (parameters, optimizer state and ``step_count`` advance)."""
     self.trainer = trainer
     self.static_batch = {k: v.clone() for k, v in batch.items()}
     for _ in range(warmup):
       trainer.train_step(self.static_batch)
+    if trainer.step_count == 0:
+      raise RuntimeError('GraphedTrainStep: run at least one eager train_step first (warmup >= 1): the capture must not be the call '
+                         'that sizes and allocates the scratch buffers')
     torch.cuda.synchronize()
     self.split = trainer.overlap_enabled()
     self.graph = torch.cuda.CUDAGraph()
     self.graph2 = None
+    st = capture_stream(trainer.eng.device)
     if self.split:
-      with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
+      with torch.cuda.graph(self.graph, stream=st, capture_error_mode=CAPTURE_MODE):
         self.vals = trainer._step_part1(self.static_batch)
       self.graph2 = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode=CAPTURE_MODE):
+      with torch.cuda.graph(self.graph2, pool=self.graph.pool(), stream=st, capture_error_mode=CAPTURE_MODE):
         trainer._step_part2()
     else:
-      with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
+      with torch.cuda.graph(self.graph, stream=st, capture_error_mode=CAPTURE_MODE):
         self.vals = trainer._step_body(self.static_batch)
     torch.cuda.synchronize()
 

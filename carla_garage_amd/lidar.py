@@ -30,7 +30,7 @@ class LidarHistogram:
     # the reference compares the float32 heights with Python floats, i.e. in float32 (NumPy weak-scalar rule)
     self.max_height = float(np.float32(c.max_height_lidar))
     self.split = float(np.float32(c.lidar_split_height))
-    self.counts = torch.empty(2 * self.nx * self.ny, device=self.device, dtype=torch.int32)
+    self._counts = {}  # int32 scratch per stream: calls on different streams must not share it
 
   def __call__(self, lidar, use_ground_plane=False, out=None):
     if isinstance(lidar, np.ndarray):
@@ -42,9 +42,13 @@ class LidarHistogram:
     if out is None:
       out = torch.empty((ch, self.ny, self.nx), device=self.device, dtype=torch.float32)
     lib.load()
+    st = ops.stream()
+    counts = self._counts.get(st)
+    if counts is None:
+      counts = self._counts[st] = torch.empty(2 * self.nx * self.ny, device=self.device, dtype=torch.int32)
     lib.tfpp_lidar_histogram(ops.ptr(pts) if pts.numel() else None, pts.shape[0], pts.shape[1], ops.ptr(self.xe), self.nx, ops.ptr(self.ye),
-                             self.ny, ops.ptr(self.counts), ops.ptr(out), self.max_height, self.split, int(use_ground_plane), self.hist_max,
-                             ops.stream())
+                             self.ny, ops.ptr(counts), ops.ptr(out), self.max_height, self.split, int(use_ground_plane), self.hist_max,
+                             st)
     return out
 
 
@@ -53,7 +57,9 @@ _CACHE = {}
 
 def lidar_to_histogram_features(config, lidar, use_ground_plane, device='cuda'):
   """Function form with the reference's argument meaning (``self.config`` made explicit); returns a CUDA tensor (C, H, W)."""
-  key = (id(config), str(device))
+  c = config  # keyed by the grid itself (an id() can be reused by another config after garbage collection)
+  key = (float(c.min_x), float(c.max_x), float(c.min_y), float(c.max_y), int(c.pixels_per_meter), int(c.hist_max_per_pixel),
+         float(c.max_height_lidar), float(c.lidar_split_height), str(device))
   h = _CACHE.get(key)
   if h is None:
     h = _CACHE[key] = LidarHistogram(config, device)

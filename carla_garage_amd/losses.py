@@ -161,6 +161,13 @@ def reference_form_losses(model, args):
   if cfg.detect_boxes:
     for i, n in enumerate(('loss_center_heatmap', 'loss_wh', 'loss_offset', 'loss_yaw_class', 'loss_yaw_res')):
       callers[n] = args['pred_bounding_box'][i]
+  # the fused kernels read the internal (NHWC) tensors of the last forward: refuse predictions that are not the tensors that
+  # forward returned (a second forward in between, post-processed / re-ordered predictions) instead of silently using others
+  mine = model.__dict__.get('_last_output_ptrs', set())
+  for n, c in callers.items():
+    if c is not None and c.data_ptr() not in mine:
+      raise RuntimeError(f'compute_loss: the prediction passed for {n} is not an output of the last forward() of this model '
+                         '(the MI355X path evaluates the losses on that call\'s internal tensors)')
   want_grad = torch.is_grad_enabled()
   names, vals, seeds = fused_losses(model, t, labels, None, want_grad)
   out = {}

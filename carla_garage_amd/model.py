@@ -240,6 +240,8 @@ class LidarCenterNet(nn.Module):
       internal = eng.forward(rgb, lidar_bev, target_point, ego_vel, command)
       self.__dict__['_last_internal'] = internal
       outs, _ = self._export(internal)
+    # compute_loss() evaluates the losses on the internal tensors of THIS call: remember which caller-facing tensors belong to it
+    self.__dict__['_last_output_ptrs'] = {o.data_ptr() for o in outs}
     return self._assemble(list(outs))
 
   # ------------------------------------------------------------------------------------------------ losses

@@ -129,8 +129,8 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
   return dst
 
 
-def conv_wgrad(dy, x, dw, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=0, G=1, ks_g=None, n_g=None, c_real=None,
-               row_map=None, col_map=None, x_ld=None, dy_ld=None, dw_ld=None, splits=0):
+def _wgrad_params(dy, x, dw, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=0, G=1, ks_g=None, n_g=None, c_real=None,
+                  row_map=None, col_map=None, x_ld=None, dy_ld=None, dw_ld=None, splits=0):
   p = WgradParams()
   p.dy, p.x, p.dw = ptr(dy), ptr(x), ptr(dw)
   p.row_map, p.col_map = ptr(row_map), ptr(col_map)
@@ -146,6 +146,20 @@ def conv_wgrad(dy, x, dw, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=
   assert dw.dtype == torch.float32
   ws = splitk_workspace(dy.device)
   p.ws, p.ws_floats = ptr(ws), ws.numel()
+  return p
+
+
+def conv_wgrad_plan(dy, x, dw, **kw):
+  """(kernel variant, pixel slices, second-stage sum?) the dispatcher uses for this weight gradient -- tests / bench bookkeeping."""
+  p = _wgrad_params(dy, x, dw, **kw)
+  plan = (ctypes.c_int * 3)()
+  lib.raw('tfpp_conv_wgrad_stage')(ctypes.byref(p), dt(dy), -1, plan, stream())
+  return plan[0], plan[1], plan[2]
+
+
+def conv_wgrad(dy, x, dw, **kw):
+  p = _wgrad_params(dy, x, dw, **kw)
+  B, Hd, Wd, Hs, Ws, G, R, S, stride = p.B, p.Hd, p.Wd, p.Hs, p.Ws, p.G, p.R, p.S, p.stride
   if lib.profiler is not None:  # one profiled call per kernel: first stage and slice sum are timed separately
     plan = (ctypes.c_int * 3)()
     lib.raw('tfpp_conv_wgrad_stage')(ctypes.byref(p), dt(dy), -1, plan, stream())  # plan only: no launch, not timed
@@ -310,9 +324,40 @@ def stats_rows_buffer(c, device, rows=64):
   buf = _STATS_ROWS.get(key)
   need = rows * 2 * c
   if buf is None or buf.numel() < need:
-    buf = torch.zeros(max(need, 64 * 2 * 1512), device=device, dtype=torch.float32)
+    if torch.cuda.is_current_stream_capturing():
+      # a buffer born inside a capture would be zeroed by that graph only, and a grown one would strand the pointers an earlier
+      # capture holds: run one eager step of the same shapes before capturing (GraphedTrainStep / GraphedForward warm-ups do)
+      raise RuntimeError('BatchNorm statistics rows must be allocated before hipGraph capture: run one eager warm-up step first')
+    buf = zero_(torch.empty(max(need, 64 * 2 * 1512), device=device, dtype=torch.float32))
     _STATS_ROWS[key] = buf
   return buf
+
+
+def clear_stats_rows(device):
+  """Zero the accumulation rows of every stream of ``device`` (start of a training step, on the caller's stream: the lanes
+  fork from it afterwards).  The rows are self-clearing in normal operation; this makes a step independent of an exception or
+  an aborted capture having left addends behind."""
+  dev = str(torch.device(device))
+  for (d, _), buf in _STATS_ROWS.items():
+    if d == dev or d.split(':')[0] == dev:
+      zero_(buf)
+
+
+def clone_scratch_for_current_stream(device):
+  """Give the CURRENT stream its own set of scratch buffers (split-K / weight-gradient slices, BatchNorm partials and statistics
+  rows, column-reduction partials), sized like the largest set any stream of ``device`` already owns.  graph.py calls this on the
+  capture stream before a capture: the step has run eagerly on another stream by then, so every buffer the captured launches need
+  exists (and the statistics rows are zeroed) before the capture begins -- nothing is allocated, zero-filled or grown inside it."""
+  dev = str(torch.device(device))
+  key = _scratch_key(device)
+  for table, zeroed in ((_SPLITK_WS, False), (_BN_SCRATCH, False), (_STATS_ROWS, True), (_REDUCE_SCRATCH, False)):
+    sizes = [buf.numel() for (d, _), buf in table.items() if d == dev]
+    if not sizes:
+      continue
+    cur = table.get(key)
+    if cur is None or cur.numel() < max(sizes):
+      buf = torch.empty(max(sizes), device=device, dtype=torch.float32)
+      table[key] = zero_(buf) if zeroed else buf
 
 
 def reduce_scratch(b, c, device):

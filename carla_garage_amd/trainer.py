@@ -21,10 +21,13 @@ class Trainer:
 
   def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, process_group=None, use_graph=False):
     self.model = model
-    self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+    if getattr(model.config, 'use_optim_groups', False):
+      raise NotImplementedError('MI355X trainer: one AdamW parameter group (team_code/config.py:263 default use_optim_groups=False)')
+    self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay  # lr is read at every step: schedulers just set it
     self.pg = process_group
     self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
     self.step_count = 0
+    self.exchange = True  # False: skip the gradient collectives (bench.py times a local step beside the real one: exposed communication)
     self.use_graph = use_graph
     self.graph = None
     self._static = None
@@ -64,6 +67,7 @@ class Trainer:
     eng, model = self.eng, self.model
     eng.training = True
     eng.dtype = model.compute_dtype
+    eng.invalidate()  # this step rewrites the BatchNorm running statistics (and the optimizer the parameters) through raw pointers
     eng.repack(eng.dtype, True)
     eng.alloc_grads()
     ops.inc_u64(self.seed_offset)
@@ -86,6 +90,7 @@ class Trainer:
     return vals
 
   def _optimizer(self, step):
+    self.eng.invalidate()
     ops.adamw_amsgrad(self.flat_param, self.eng.flat_grad, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, self.lr, self.betas[0],
                       self.betas[1], self.eps, self.weight_decay, step, grad_scale=1.0 / self.world)
 
@@ -105,23 +110,78 @@ class Trainer:
     return vals
 
   def overlap_enabled(self):
-    return self.world > 1 or os.environ.get('TFPP_SPLIT_STEP', '0') == '1'
+    return (self.exchange and tdist.exchange_enabled(self.pg)) or os.environ.get('TFPP_SPLIT_STEP', '0') == '1'
 
   def reduce_early(self):
     """Asynchronous all-reduce of flat_grad[early_offset:] (RCCL runs it on its own stream, ordered after what this stream has
     issued so far).  Returns the handle finish_step() waits on, or None when there is nothing to overlap."""
-    if self.world == 1:
+    if not self.exchange:
       return None
     return tdist.all_reduce_async(self.eng.flat_grad[self.eng.early_offset:], self.pg)
 
   def finish_step(self, early=None):
     """rest of the gradient exchange + optimizer (kept outside any captured graph)."""
-    if early is None:
+    if not self.exchange:
+      pass
+    elif early is None:
       tdist.all_reduce_gradients(self.eng.flat_grad, self.pg)
     else:
       tdist.all_reduce_gradients(self.eng.flat_grad[:self.eng.early_offset], self.pg)
       early.wait()
     self._optimizer(self.step_count)
+
+  # ---------------------------------------------------------------------------------------------- checkpoint / resume
+  def _arena_slices(self):
+    """[(index in model.parameters() order, arena offset, parameter)] of the trainable parameters."""
+    index = {id(p): i for i, p in enumerate(self.model.parameters())}
+    out, off = [], 0
+    for _, p in arena_order(self.model)[0]:
+      out.append((index[id(p)], off, p))
+      off += ops.pad_to(p.numel(), 4)
+    return out
+
+  def state_dict(self):
+    """The optimizer state in the layout ``torch.optim.AdamW(model.parameters(), lr, amsgrad=True).state_dict()`` has in the
+    reference (team_code/train.py:529-531, saved as optimizer_%04d.pth at train.py:967-976): per-parameter ``step``, ``exp_avg``,
+    ``exp_avg_sq``, ``max_exp_avg_sq`` keyed by the position in ``model.parameters()`` (frozen parameters have no state), one
+    parameter group.  Values are clones cut out of the flat arenas."""
+    n_params = len(list(self.model.parameters()))
+    state = {}
+    if self.step_count > 0:
+      for i, off, p in self._arena_slices():
+        n = p.numel()
+        state[i] = {'step': torch.tensor(float(self.step_count)),
+                    'exp_avg': self.exp_avg[off:off + n].view(p.shape).clone(),
+                    'exp_avg_sq': self.exp_avg_sq[off:off + n].view(p.shape).clone(),
+                    'max_exp_avg_sq': self.max_exp_avg_sq[off:off + n].view(p.shape).clone()}
+    group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.weight_decay, 'amsgrad': True,
+             'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+             'params': list(range(n_params))}
+    return {'state': state, 'param_groups': [group]}
+
+  def load_state_dict(self, sd):
+    """Resume from ``state_dict()`` or from an optimizer_%04d.pth the reference wrote (train.py:533-534)."""
+    g = sd['param_groups'][0]
+    if len(sd['param_groups']) != 1 or not g.get('amsgrad', False):
+      raise ValueError('expected the single amsgrad AdamW parameter group of team_code/train.py:529-531')
+    self.lr, self.betas, self.eps, self.weight_decay = float(g['lr']), tuple(g['betas']), float(g['eps']), float(g['weight_decay'])
+    steps = set()
+    for i, off, p in self._arena_slices():
+      st = sd['state'].get(i)
+      n = p.numel()
+      for name, arena in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq), ('max_exp_avg_sq', self.max_exp_avg_sq)):
+        dst = arena[off:off + n]
+        if st is None:
+          ops.zero_(dst)
+        else:
+          src = st[name].detach().to(dst.device, F32).contiguous()
+          ops.copy_rows(src, dst, 1, n, 0, 0, 0, 0)
+      if st is not None:
+        steps.add(int(float(st['step'])))
+    if len(steps) > 1:
+      raise ValueError(f'per-parameter step counts differ ({sorted(steps)}): the fused optimizer keeps one step counter')
+    self.step_count = steps.pop() if steps else 0
+    self.eng.invalidate()
 
   def total_loss(self, vals):
     w = torch.tensor([self.loss_weights[n] for n in self.loss_names])

@@ -33,6 +33,8 @@ extern "C" {
 #define TFPP_ACT_TANH 4
 
 int tfpp_version(void);
+/* 64-bit hash of the csrc/ + include/ sources the library was compiled from (0: built without it); checked at load. */
+int tfpp_source_hash(uint64_t* out);
 /* sizeof() of the parameter structs, in declaration order, so the ctypes mirror can be verified. */
 int tfpp_struct_sizes(int* out, int n);
 
@@ -278,6 +280,7 @@ int tfpp_sum_f32(const float* x, float* out, int64_t n, void* stream);
 int tfpp_copy_rows(const void* src, void* dst, int B, int64_t n, int64_t src_bs, int64_t src_off, int64_t dst_bs, int64_t dst_off,
                    int accumulate, int dtype_in, int dtype_out, void* stream);
 int tfpp_zero(void* p, int64_t bytes, void* stream); /* hipMemsetAsync(p, 0, bytes) */
+int tfpp_fill_bytes(void* p, int value, int64_t bytes, void* stream); /* hipMemsetAsync(p, value, bytes): debug poisoning (TFPP_DEBUG_POISON) */
 
 /* ---------------------------------------------------------------------------------------------------------
  * GRU waypoint / checkpoint decoder (model.py:857-867): h0 = enc(target_point); nn.GRU(256->64) over T steps;

@@ -13,6 +13,8 @@ Files written
   tfpp_eval_bs1.npz        config 2 (eval forward, bs=1, fp32): all outputs (large maps strided) + checksums
   tfpp_train_bs2.npz       train-mode forward (dropout 0) + compute_loss + backward, bs=2: the 10 losses,
                            per-parameter gradient norms and sampled gradient values, BN statistics update
+  tfpp_train_bs12.npz      the same step at bs=12 (BASELINE config 3's batch: the kernel variants bench.py runs); `python -m
+                           oracle.make_golden bs12` writes only this file
   tfpp_wp_eval_bs1.npz     WP variant (use_wp_gru=1, use_controller_input_prediction=0): pred_wp
 """
 import json
@@ -74,37 +76,14 @@ def sample_idx(n):
   return np.unique(np.linspace(0, n - 1, GRAD_SAMPLES).astype(np.int64))
 
 
-def main():
-  if not ref_harness.available():
-    sys.exit('needs /root/reference (build container)')
-  os.makedirs(GOLDEN, exist_ok=True)
-  torch.set_num_threads(os.cpu_count())
-
-  # ---- default TF++ ---------------------------------------------------------------------------
-  model, _ = ref_harness.build_reference_model()
-  cfg = P.PortConfig()
-  ref_sd = model.state_dict()
-  schema = [[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in ref_sd.items()]
-  with open(os.path.join(GOLDEN, 'state_dict_schema.json'), 'w', encoding='utf-8') as f:
-    json.dump({'n_trainable': sum(p.numel() for p in model.parameters() if p.requires_grad), 'entries': schema}, f)
-  sd = P.make_state_dict(cfg)
-  model.load_state_dict(sd, strict=True)
-
-  model.eval()
-  inp = P.make_inputs(1, cfg)
-  with torch.inference_mode():
-    out = model(*inp)
-  d = pack_outputs(out)
-  d['weights_checksum'] = np.array([float(v.double().sum()) for v in sd.values()])
-  d['inputs_checksum'] = np.array([float(x.double().sum()) for x in inp])
-  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_eval_bs1.npz'), **d)
-  print('eval bs1:', {k: v.shape for k, v in d.items()})
-
-  # ---- training step (dropout disabled so it is deterministic; BN in train mode) ----------------
+def write_train_golden(model, cfg, bs, fname):
+  """One train-mode step of the reference at batch size ``bs`` (dropout 0, batch-statistic BN): the 10 losses, per-parameter
+  gradient norms + sampled gradient values, the BN running-statistic sums after the step and the small forward outputs."""
   model.train()
+  model.zero_grad(set_to_none=True)
   disable_dropout(model)
-  inp = P.make_inputs(2, cfg)
-  lab = P.make_labels(2, cfg)
+  inp = P.make_inputs(bs, cfg)
+  lab = P.make_labels(bs, cfg)
   out = model(*inp)
   losses = model.compute_loss(**reference_loss_kwargs(out, lab))
   w = P.loss_weights(cfg)
@@ -132,8 +111,48 @@ def main():
   t['running_sums'] = np.array([float(new_sd[k].double().sum()) for k in rk])
   t.update({'fwd_' + k: v for k, v in pack_outputs(out).items() if k.startswith('bb_') or k.startswith('pred_t') or
             k.startswith('pred_c') or k.endswith('_sum')})
-  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_train_bs2.npz'), **t)
-  print('train bs2: total', total.item(), {k: float(v) for k, v in losses.items()})
+  np.savez_compressed(os.path.join(GOLDEN, fname), **t)
+  print(f'train bs{bs}: total', total.item(), {k: float(v) for k, v in losses.items()})
+  model.zero_grad(set_to_none=True)
+
+
+def main():
+  only = set(sys.argv[1:])  # e.g. `python -m oracle.make_golden bs12` writes only the bs=12 training fixture
+  if not ref_harness.available():
+    sys.exit('needs /root/reference (build container)')
+  os.makedirs(GOLDEN, exist_ok=True)
+  torch.set_num_threads(os.cpu_count())
+
+  # ---- default TF++ ---------------------------------------------------------------------------
+  model, _ = ref_harness.build_reference_model()
+  cfg = P.PortConfig()
+  ref_sd = model.state_dict()
+  schema = [[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in ref_sd.items()]
+  with open(os.path.join(GOLDEN, 'state_dict_schema.json'), 'w', encoding='utf-8') as f:
+    json.dump({'n_trainable': sum(p.numel() for p in model.parameters() if p.requires_grad), 'entries': schema}, f)
+  sd = P.make_state_dict(cfg)
+  model.load_state_dict(sd, strict=True)
+  if only == {'bs12'}:
+    write_train_golden(model, cfg, 12, 'tfpp_train_bs12.npz')
+    return
+
+  model.eval()
+  inp = P.make_inputs(1, cfg)
+  with torch.inference_mode():
+    out = model(*inp)
+  d = pack_outputs(out)
+  d['weights_checksum'] = np.array([float(v.double().sum()) for v in sd.values()])
+  d['inputs_checksum'] = np.array([float(x.double().sum()) for x in inp])
+  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_eval_bs1.npz'), **d)
+  print('eval bs1:', {k: v.shape for k, v in d.items()})
+
+  # ---- training step (dropout disabled so it is deterministic; BN in train mode) ----------------
+  write_train_golden(model, cfg, 2, 'tfpp_train_bs2.npz')
+  if True:
+    # BASELINE config 3's batch size: the kernel variants bench.py runs (128x128 LDS-DMA tiles, the bs=12 weight-gradient
+    # plans) are only reached at this size, so the parity tests need a reference step at it too
+    model.load_state_dict(sd, strict=True)  # the bs=2 step updated the BN running statistics
+    write_train_golden(model, cfg, 12, 'tfpp_train_bs12.npz')
 
   # ---- WP variant -----------------------------------------------------------------------------
   del model

@@ -1,0 +1,58 @@
+"""GPU tests of the data-parallel entry (-m gpu): the RCCL path is executed for real with a one-rank process group (a gpurun box has
+one GPU; the 2/4/8-GPU curve is the driver's to measure), and bench.py refuses to report an N-GPU number from fewer devices."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
+
+
+def test_one_rank_rccl_group_runs_the_overlapped_exchange_eager_and_as_two_hipgraphs():
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+  p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dist_gpu_worker.py')], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                     timeout=600, check=False)
+  text = p.stdout.decode()
+  assert p.returncode == 0, text[-3000:]
+  line = [l for l in text.splitlines() if l.startswith('RESULT ')][-1]
+  r = json.loads(line[len('RESULT '):])
+  try:
+    with open(os.path.join(ROOT, 'gpurun_out', 'model_report.jsonl'), 'a', encoding='utf-8') as f:
+      f.write(json.dumps({'test': 'rccl_one_rank', 'errs': r}) + '\n')
+  except OSError:
+    pass
+  assert r['backend'] == 'nccl' and r['world'] == 1
+  assert r['calls_local'] == 0                                   # the local step issues no collective
+  assert r['calls_eager_step'] == 2 and r['async_eager_step'] == 1  # early slice (async, between the segments) + the rest
+  assert r['bytes_eager_step'] == r['arena_bytes']               # together exactly one pass over the 481 MB arena
+  assert r['calls_graph_step'] == 2 and r['async_graph_step'] == 1
+  # a one-rank SUM is the identity: the split / exchanged step must reproduce the single-segment local step (fp32, same tolerance as
+  # tests/test_model.py::test_streams_and_hipgraph_do_not_change_the_training_step)
+  assert r['loss_eager'] < 1e-4 and r['grad_eager'] < 2e-2 and r['param_eager'] < 1e-6, r
+  assert r['loss_graph'] < 5e-3 and r['grad_graph'] < 8e-2, r
+
+
+def test_bench_refuses_to_report_more_gpus_than_it_runs_on():
+  """`python bench.py --gpus 2` without a launcher used to run one rank and print n_gpus: 1."""
+  import torch
+  if torch.cuda.device_count() >= 2:
+    pytest.skip('this box really has >= 2 GPUs')
+  env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+  p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env,
+                     stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, check=False)
+  assert p.returncode != 0
+  assert 'refusing' in p.stdout.decode() and '"n_gpus"' not in p.stdout.decode()
+  env.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')  # a launcher that started fewer ranks than --gpus says
+  p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env,
+                     stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, check=False)
+  assert p.returncode != 0 and 'WORLD_SIZE=1' in p.stdout.decode()

@@ -127,6 +127,11 @@ def test_eval_forward_fp32_vs_reference_golden_and_oracle():
     _report('eval_fp32', errs)
   bad = {k: v for k, v in errs.items() if v > U.REL_TOL_FP32}
   assert not bad, bad
+  # the metric above is max|d| / max|ref| (one global scale, blind to errors on small elements): the three north-star outputs --
+  # waypoints/checkpoints, target-speed logits, BEV heat-map -- are additionally held to |d| <= atol + rtol |ref| element-wise
+  gold = U.load_golden('tfpp_eval_bs1.npz')
+  for key, a in (('pred_checkpoint', out[2]), ('pred_target_speed', out[1]), ('bb_heatmap', out[6][0])):
+    np.testing.assert_allclose(U.to_np(a), gold[key], rtol=1e-3, atol=1e-5 * float(np.abs(gold[key]).max()), err_msg=key)
   assert out[0] is None and out[7] is None and out[8] is None and out[9] is None and out[6][5] is None
   assert out[3].shape == (1, 7, 256, 1024) and out[5].shape == (1, 256, 1024) and out[3].dtype == torch.float32
 
@@ -165,19 +170,16 @@ def _zero_dropout(m):
   m.config.embd_pdrop = m.config.resid_pdrop = m.config.attn_pdrop = 0.0
 
 
-@pytest.mark.gpu
-def test_train_step_fp32_vs_reference_golden():
-  """train-mode forward (batch statistics), fused losses, hand-written backward: losses 1e-3, gradient norms 3e-2
-  (two CPU fp32 implementations of this network already differ by ~1e-2 in train-mode gradients, tests/test_oracle.py)."""
+def _engine_train_step(m, bs):
+  """train-mode forward (batch statistics, dropout 0), fused losses, hand-written backward on the engine; returns
+  (loss names, loss values [numpy], engine with .grads filled)."""
   from carla_garage_amd.engine import Tape
   from carla_garage_amd.losses import fused_losses, normalized_loss_weights
-  g = U.load_golden('tfpp_train_bs2.npz')
-  m = _model().train()
   _zero_dropout(m)
   eng = m._engine()
-  batch = {k: v.cuda() for k, v in P.make_labels(2).items()}
-  inp = [x.cuda() for x in P.make_inputs(2)]
-  eng.prepare(torch.float32, True, True)
+  batch = {k: v.cuda() for k, v in P.make_labels(bs).items()}
+  inp = [x.cuda() for x in P.make_inputs(bs)]
+  eng.prepare(m.compute_dtype, True, True)
   eng.alloc_grads()
   eng.tape = Tape()
   t = eng.forward(*inp)
@@ -185,24 +187,160 @@ def test_train_step_fp32_vs_reference_golden():
   tape, eng.tape = eng.tape, None
   tape.backward(seeds)
   torch.cuda.synchronize()
-  vals = vals.cpu().numpy()
-  errs = {}
-  gl = dict(zip([str(x) for x in g['loss_names']], g['losses']))
-  for n, v in zip(names, vals):
-    errs[n] = abs(v - gl[n]) / abs(gl[n])
-  worst = {}
+  return names, vals.cpu().numpy(), eng
+
+
+# Gradient parity bars.  Two CPU fp32 implementations of this network (the reference and oracle/tfpp_port.py) differ by up to
+# 5.4e-3 in per-tensor gradient norms and by up to 0.08 x (rms + |ref|) on single elements (bs = 12, LiDAR-branch BatchNorm biases:
+# train-mode BN makes the gradients ill-conditioned), so: norms at 1e-2, sampled ELEMENTS at |d| <= 0.15 x (rms + |ref|) -- a
+# transposed or permuted weight gradient misses that by an order of magnitude, which a norm check cannot see.
+GRAD_NORM_TOL, GRAD_ELEM_TOL = 1e-2, 0.15
+
+
+def _compare_grads(eng, g):
+  worst_norm, worst_elem = {}, {}
   for name, (norm, gmax), samples in zip(g['grad_names'], g['grad_norms'], g['grad_samples']):
-    if gmax < 1e-5:
+    if gmax < 1e-5:  # structurally zero (key biases, pre-BN biases)
       continue
-    mine = eng.grads[str(name)].double().norm().item()
-    worst[str(name)] = abs(mine - norm) / norm
-  top = dict(sorted(worst.items(), key=lambda kv: -kv[1])[:15])
+    mine = eng.grads[str(name)].detach().flatten()
+    worst_norm[str(name)] = abs(mine.double().norm().item() - norm) / norm
+    idx = U.sample_idx(mine.numel())
+    got = mine[torch.from_numpy(idx).to(mine.device)].float().cpu().numpy()
+    ref = samples[:len(idx)]
+    rms = norm / np.sqrt(mine.numel())
+    worst_elem[str(name)] = float(np.max(np.abs(got - ref) / (rms + np.abs(ref))))
+  return worst_norm, worst_elem
+
+
+def _check_train_step_vs_golden(bs, fname, tag):
+  g = U.load_golden(fname)
+  m = _model().train()
+  names, vals, eng = _engine_train_step(m, bs)
+  gl = dict(zip([str(x) for x in g['loss_names']], g['losses']))
+  errs = {n: abs(v - gl[n]) / abs(gl[n]) for n, v in zip(names, vals)}
+  worst_norm, worst_elem = _compare_grads(eng, g)
+  top = dict(sorted(worst_norm.items(), key=lambda kv: -kv[1])[:8])
+  tope = dict(sorted(worst_elem.items(), key=lambda kv: -kv[1])[:8])
   sd = m.state_dict()
   rs = {str(n): abs(float(sd[str(n)].double().sum()) - s) / (abs(s) + 1.0) for n, s in zip(g['running_names'], g['running_sums'])}
-  _report('train_fp32', {'losses': errs, 'grad_norm_worst': top, 'running_worst': max(rs.values())})
+  _report(tag, {'losses': errs, 'grad_norm_worst': top, 'grad_elem_worst': tope, 'running_worst': max(rs.values())})
   assert max(errs.values()) <= 1e-3, errs
-  assert max(worst.values()) <= 3e-2, top
+  assert max(worst_norm.values()) <= GRAD_NORM_TOL, top
+  assert max(worst_elem.values()) <= GRAD_ELEM_TOL, tope
   assert max(rs.values()) <= 1e-3
+  return m, eng
+
+
+@pytest.mark.gpu
+def test_train_step_fp32_vs_reference_golden():
+  """train-mode forward (batch statistics), fused losses, hand-written backward at bs = 2: losses 1e-3, per-parameter gradient
+  norms and sampled gradient elements (see GRAD_*_TOL), BN running statistics."""
+  _check_train_step_vs_golden(2, 'tfpp_train_bs2.npz', 'train_fp32')
+
+
+@pytest.mark.gpu
+def test_train_step_bs12_fp32_vs_reference_golden():
+  """BASELINE config 3's batch size.  bs = 12 is where the dispatcher switches to the kernels bench.py runs (8-wave 128x128 LDS-DMA
+  tiles with fused BN statistics and the M-major XCD order, the bs=12 weight-gradient plans): the reference's own step at that size
+  (tests/golden/tfpp_train_bs12.npz, oracle/make_golden.py) is compared with the fp32 HIP step."""
+  _check_train_step_vs_golden(12, 'tfpp_train_bs12.npz', 'train_fp32_bs12')
+
+
+@pytest.mark.gpu
+def test_train_step_bs12_bf16_vs_fp32_hip_and_golden():
+  """The benchmarked precision: the bf16 step at bs = 12 (deterministic since the one-row-per-M-tile BN statistics) against the
+  reference's fp32 losses and against the fp32 HIP step's gradients.  Tolerances are what bf16 storage through 100+ layers with
+  batch-statistic BN measures on MI355X (profiles/r02_model_parity_report.jsonl), with head room of about 2x: losses 3e-2 relative,
+  gradient norms 0.15 relative for tensors carrying >= 1e-3 of the largest norm."""
+  g = U.load_golden('tfpp_train_bs12.npz')
+  m32 = _model('fp32').train()
+  _, v32, e32 = _engine_train_step(m32, 12)
+  ref = {n: e32.grads[n].detach().double().norm().item() for n in e32.grads}
+  del m32, e32
+  torch.cuda.empty_cache()
+  m16 = _model('bf16').train()
+  names, v16, e16 = _engine_train_step(m16, 12)
+  gl = dict(zip([str(x) for x in g['loss_names']], g['losses']))
+  lerr = {n: abs(v - gl[n]) / abs(gl[n]) for n, v in zip(names, v16)}
+  big = max(ref.values())
+  nerr = {n: abs(e16.grads[n].detach().double().norm().item() - r) / r for n, r in ref.items() if r >= 1e-3 * big}
+  top = dict(sorted(nerr.items(), key=lambda kv: -kv[1])[:8])
+  _report('train_bf16_bs12', {'losses_vs_reference': lerr, 'losses_vs_fp32_hip': {n: abs(a - b) / abs(b) for n, a, b in zip(names, v16, v32)},
+                               'grad_norm_vs_fp32_hip_worst': top, 'tensors_compared': len(nerr)})
+  assert np.isfinite(v16).all()
+  assert max(lerr.values()) <= 3e-2, lerr
+  assert max(nerr.values()) <= 0.15, top
+
+
+@pytest.mark.gpu
+def test_eval_after_training_steps_uses_current_weights_and_running_statistics():
+  """the fused optimizer and the BN running-statistic updates write through raw pointers, which tensor._version
+  cannot see.  eval -> train steps -> eval must run on the updated weights and the re-folded running statistics: compared with a
+  freshly constructed model that loads the trained state_dict."""
+  from carla_garage_amd.trainer import Trainer
+  m = _model('fp32')
+  inp = [x.cuda() for x in P.make_inputs(1)]
+  m.eval()
+  with torch.inference_mode():
+    o0 = m(*inp)
+    before = [o0[1].clone(), o0[2].clone(), o0[6][0].clone()]
+  batch = {k: v.cuda() for k, v in P.make_labels(2).items()}
+  for k, v in zip(('rgb', 'lidar_bev', 'target_point', 'ego_vel', 'command'), P.make_inputs(2)):
+    batch[k] = v.cuda()
+  tr = Trainer(m, lr=1e-3)
+  for _ in range(2):
+    tr.train_step(batch)
+  m.eval()
+  with torch.inference_mode():
+    out = m(*inp)
+    after = [out[1], out[2], out[6][0]]
+  fresh = LidarCenterNet(GlobalConfig(tfpp_dtype='fp32'))
+  fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, strict=True)
+  fresh.cuda().eval()
+  with torch.inference_mode():
+    o2 = fresh(*inp)
+    want = [o2[1], o2[2], o2[6][0]]
+  torch.cuda.synchronize()
+  for a, w, b in zip(after, want, before):
+    assert U.rel_err(U.to_np(a), U.to_np(w)) <= 1e-5  # same kernels, same weights
+    assert U.rel_err(U.to_np(a), U.to_np(b)) > 1e-4   # and it really changed with the two optimizer steps
+
+
+@pytest.mark.gpu
+def test_trainer_state_dict_round_trip_and_reference_layout():
+  """Trainer.state_dict() has the layout of the reference's optimizer_%04d.pth (torch.optim.AdamW(model.parameters(), amsgrad=True),
+  team_code/train.py:529-534,967-976): torch's own AdamW loads it; save -> fresh trainer -> load -> the next step is identical."""
+  from carla_garage_amd.trainer import Trainer
+  batch = {k: v.cuda() for k, v in P.make_labels(2).items()}
+  for k, v in zip(('rgb', 'lidar_bev', 'target_point', 'ego_vel', 'command'), P.make_inputs(2)):
+    batch[k] = v.cuda()
+  m = _model('fp32').train()
+  _zero_dropout(m)
+  tr = Trainer(m, lr=1e-4)
+  tr.train_step(batch)
+  tr.train_step(batch)
+  torch.cuda.synchronize()
+  osd = tr.state_dict()
+  msd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+  n_train = sum(1 for p in m.parameters() if p.requires_grad)
+  assert len(osd['state']) == n_train and osd['param_groups'][0]['params'] == list(range(len(list(m.parameters()))))
+  probe = torch.optim.AdamW([torch.nn.Parameter(torch.zeros_like(p, device='cpu')) for p in m.parameters()], lr=1.0, amsgrad=True)
+  probe.load_state_dict({'state': {k: {a: b.cpu() for a, b in v.items()} for k, v in osd['state'].items()}, 'param_groups': osd['param_groups']})
+  assert probe.param_groups[0]['lr'] == 1e-4
+  tr.train_step(batch)
+  torch.cuda.synchronize()
+  want = tr.flat_param.detach().clone()
+  m2 = LidarCenterNet(GlobalConfig(tfpp_dtype='fp32'))
+  m2.load_state_dict(msd, strict=True)
+  m2.cuda().train()
+  _zero_dropout(m2)
+  tr2 = Trainer(m2, lr=3e-4)
+  tr2.load_state_dict(osd)
+  assert tr2.step_count == 2 and tr2.lr == 1e-4
+  tr2.train_step(batch)
+  torch.cuda.synchronize()
+  d = (tr2.flat_param - want).abs().max().item() / want.abs().max().item()
+  assert d <= 1e-6, d
 
 
 @pytest.mark.gpu
@@ -223,13 +361,22 @@ def test_dropin_autograd_path_matches_engine_path():
   g = U.load_golden('tfpp_train_bs2.npz')
   np.testing.assert_allclose(float(total), float(g['total_loss']), rtol=1e-3)
   params = dict(m.named_parameters())
-  worst = 0.0
-  for name, (norm, gmax) in zip(g['grad_names'], g['grad_norms']):
+  worst = worst_el = 0.0
+  for name, (norm, gmax), samples in zip(g['grad_names'], g['grad_norms'], g['grad_samples']):
     if gmax < 1e-5:
       continue
-    worst = max(worst, abs(params[str(name)].grad.double().norm().item() - norm) / norm)
-  _report('dropin', {'worst_grad_norm': worst})
-  assert worst <= 3e-2
+    mine = params[str(name)].grad.detach().flatten()
+    worst = max(worst, abs(mine.double().norm().item() - norm) / norm)
+    idx = U.sample_idx(mine.numel())
+    got = mine[torch.from_numpy(idx).to(mine.device)].float().cpu().numpy()
+    worst_el = max(worst_el, float(np.max(np.abs(got - samples[:len(idx)]) / (norm / np.sqrt(mine.numel()) + np.abs(samples[:len(idx)])))))
+  _report('dropin', {'worst_grad_norm': worst, 'worst_grad_elem': worst_el})
+  assert worst <= GRAD_NORM_TOL and worst_el <= GRAD_ELEM_TOL
+  # compute_loss evaluates the losses on the internal tensors of the last forward: predictions that are not that call's outputs
+  # (here: a clone) are refused instead of silently producing the losses of other tensors
+  with pytest.raises(RuntimeError):
+    m.compute_loss(pred_wp=out[0], pred_target_speed=out[1].clone(), pred_checkpoint=out[2], pred_semantic=out[3],
+                   pred_bev_semantic=out[4], pred_depth=out[5], pred_bounding_box=out[6], pred_wp_1=out[8], selected_path=out[9], **lab)
 
 
 @pytest.mark.gpu

@@ -84,9 +84,10 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_fwd_dgrad_wgrad(ops, case, dtype):
+def _conv_case(ops, case, dtype, expect=None, plans=None):
+  """forward (+ scale / shift / residual / ReLU epilogue), data gradient and weight gradient of one convolution against
+  torch.nn.functional on the CPU.  expect: {'fwd': variant, 'dgrad': variant} asserted through tfpp_conv_gemm_variant BEFORE the
+  comparison, so the test is known to exercise that kernel; plans: dict that receives the weight-gradient plan."""
   name, B, H, W, Cin, Cout, k, stride, G = case
   pad = k // 2
   x = rnd(B, Cin, H, W, dtype=dtype, seed=1)
@@ -104,12 +105,14 @@ def test_conv_fwd_dgrad_wgrad(ops, case, dtype):
   xd = dev(nhwc(x), dtype)
   wp = ops.pack_conv_weight(dev(w), dtype, G=G)
   y = torch.empty((B, Ho, Wo, Cout), device=DEV, dtype=dtype)
-  ops.conv_gemm(xd, wp, y, B=B, Hs=H, Ws=W, Cs=Cin, Hd=Ho, Wd=Wo, Cd=Cout, R=k, S=k, stride=stride, pad=pad, G=G,
-                act=ops.ACT_RELU, scale=dev(scale), shift=dev(shift), res=dev(nhwc(res), dtype))
+  geo = dict(B=B, Hs=H, Ws=W, Cs=Cin, Hd=Ho, Wd=Wo, Cd=Cout, R=k, S=k, stride=stride, pad=pad, G=G)
+  if expect is not None:
+    var, _ = ops.conv_gemm(xd, wp, y, plan_only=True, **geo)
+    assert var == expect['fwd'], f'{name}: forward dispatches to variant {var}, expected {expect["fwd"]}'
+  ops.conv_gemm(xd, wp, y, act=ops.ACT_RELU, scale=dev(scale), shift=dev(shift), res=dev(nhwc(res), dtype), **geo)
   check(name + '.fwd', nchw(y.float().cpu()), want, dtype)
   if name.startswith('splitk'):
-    _, splits = ops.conv_gemm(xd, wp, y, B=B, Hs=H, Ws=W, Cs=Cin, Hd=Ho, Wd=Wo, Cd=Cout, R=k, S=k, stride=stride, pad=pad, G=G,
-                              plan_only=True)
+    _, splits = ops.conv_gemm(xd, wp, y, plan_only=True, **geo)
     assert splits > 1, 'expected the split-K path for this shape'
 
   # gradients of the plain convolution
@@ -118,11 +121,85 @@ def test_conv_fwd_dgrad_wgrad(ops, case, dtype):
   dyd = dev(nhwc(dy), dtype)
   wt = ops.pack_conv_weight(dev(w), dtype, G=G, transpose=True)
   dx = torch.empty((B, H, W, Cin), device=DEV, dtype=dtype)
-  ops.conv_gemm(dyd, wt, dx, B=B, Hs=Ho, Ws=Wo, Cs=Cout, Hd=H, Wd=W, Cd=Cin, R=k, S=k, stride=stride, pad=pad, G=G, mode=1)
+  dgeo = dict(B=B, Hs=Ho, Ws=Wo, Cs=Cout, Hd=H, Wd=W, Cd=Cin, R=k, S=k, stride=stride, pad=pad, G=G, mode=1)
+  if expect is not None:
+    var, _ = ops.conv_gemm(dyd, wt, dx, plan_only=True, **dgeo)
+    assert var == expect['dgrad'], f'{name}: data gradient dispatches to variant {var}, expected {expect["dgrad"]}'
+  ops.conv_gemm(dyd, wt, dx, **dgeo)
   check(name + '.dgrad', nchw(dx.float().cpu()), xr.grad, dtype)
   dw = torch.zeros((Cout, Cin // G, k, k), device=DEV, dtype=torch.float32)
-  ops.conv_wgrad(dyd, xd, dw, B=B, Hs=H, Ws=W, Cs=Cin, Hd=Ho, Wd=Wo, Cd=Cout, R=k, S=k, stride=stride, pad=pad, G=G)
+  if plans is not None:
+    plans[name] = ops.conv_wgrad_plan(dyd, xd, dw, **geo)
+  ops.conv_wgrad(dyd, xd, dw, **geo)
   check(name + '.wgrad', dw.cpu(), wr.grad, dtype)
+  return dict(x=xd, y=y, conv=conv, geo=geo, wp=wp)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(ops, case, dtype):
+  _conv_case(ops, case, dtype)
+
+
+# The shapes the benchmark (BASELINE config 3: bs = 12, bf16) actually runs, with the kernel variants it runs them on.
+# tfpp_conv_gemm_variant: 200 = 8-wave 128x128 LDS-DMA ring (>= 256 tiles), 201 = 64x128 LDS-DMA, 2 = LDS-staged 64x64 ...
+# weight-gradient plan {variant, slices, second stage}: see tfpp_conv_wgrad_stage.
+TRUE_SHAPES = [
+    # name, B, H, W, Cin, Cout, k, stride, groups, expected forward variant, expected dgrad variant
+    (('fusion_mlp_fc1', 3840, 1, 1, 1512, 6048, 1, 1, 1), 200, 200),   # transfuser.py:392 at C = 1512: 3840 x 6048 x 1512
+    (('fusion_mlp_fc2', 3840, 1, 1, 6048, 1512, 1, 1, 1), 200, 200),
+    (('fusion_proj', 3840, 1, 1, 1512, 1512, 1, 1, 1), 200, 200),      # attention projection / QKV slices: 3840 x 1512 x 1512
+    (('s3_conv1x1', 12, 16, 64, 576, 576, 1, 1, 1), 200, 200),         # image stage-3 1x1 convs: M = 12288, M-major XCD order
+    (('s4_conv1x1', 12, 8, 32, 1512, 1512, 1, 1, 1), 200, 200),        # stage 4: M = 3072
+]
+
+
+@pytest.mark.parametrize('entry', TRUE_SHAPES, ids=[e[0][0] for e in TRUE_SHAPES])
+def test_conv_benchmark_shapes_on_the_benchmark_kernels(ops, entry):
+  case, vf, vd = entry
+  plans = {}
+  _conv_case(ops, case, torch.bfloat16, expect={'fwd': vf, 'dgrad': vd}, plans=plans)
+  report(case[0] + '.variants', 0.0, f'fwd {vf} dgrad {vd} wgrad plan {plans[case[0]]}')
+  var, slices, second = plans[case[0]]
+  assert var in WGRAD_GLDS_VARIANTS, plans  # the LDS-DMA weight-gradient kernels, not the LDS-staged fallback
+  if case[0] in WGRAD_EXPECT:
+    assert (var, slices > 1, second) == WGRAD_EXPECT[case[0]], plans
+
+
+WGRAD_GLDS_VARIANTS = (2, 4)  # 2: 64x64 tiles, 4: 128x128 tiles (8 waves)
+WGRAD_EXPECT = {}
+
+
+def test_conv_fused_bn_statistics_on_the_128x128_lds_dma_kernel(ops):
+  """Image stage-3 1x1 conv at bs = 12 (M = 12288, N = K = 576) with the BatchNorm statistics fused into the epilogue of the 8-wave
+  128x128 LDS-DMA kernel (one accumulation row per M-tile, M-major XCD order): raw output and per-channel sum / sum of squares
+  against torch on the CPU, then finalize -> scale/shift/saved statistics against F.batch_norm."""
+  dtype = torch.bfloat16
+  B, H, W, C = 12, 16, 64, 576
+  x = rnd(B, C, H, W, dtype=dtype, seed=41)
+  w = (rnd(C, C, 1, 1, dtype=dtype, seed=42) * (1.0 / math.sqrt(C))).to(dtype).float()
+  conv = F.conv2d(x, w)
+  xd = dev(nhwc(x), dtype)
+  wp = ops.pack_conv_weight(dev(w), dtype)
+  raw = torch.empty((B, H, W, C), device=DEV, dtype=dtype)
+  geo = dict(B=B, Hs=H, Ws=W, Cs=C, Hd=H, Wd=W, Cd=C)
+  var, _ = ops.conv_gemm(xd, wp, raw, plan_only=True, **geo)
+  assert var == 200
+  nrows, acc = ops.conv_gemm(xd, wp, raw, stats_acc=True, **geo)
+  assert nrows == (B * H * W) // 128
+  torch.cuda.synchronize()
+  rows = acc[:nrows * 2 * C].view(nrows, 2, C).double().sum(0).cpu()
+  check('bnstats200.raw', nchw(raw.float().cpu()), conv, dtype)
+  check('bnstats200.sum', rows[0].float(), conv.sum((0, 2, 3)), torch.float32, scale=5.0)
+  check('bnstats200.sumsq', rows[1].float(), (conv * conv).sum((0, 2, 3)), torch.float32, scale=5.0)
+  gamma, beta = rnd(C, seed=43, lo=0.5, hi=1.5), rnd(C, seed=44)
+  rm, rv, nbt = torch.zeros(C), torch.ones(C), torch.zeros((), dtype=torch.long)
+  want = F.batch_norm(conv, rm.clone(), rv.clone(), gamma, beta, True, 0.1, 1e-5)
+  scale, shift, mean, invstd = (torch.empty(C, device=DEV) for _ in range(4))
+  ops.bn_finalize_partials(acc, nrows, dev(gamma), dev(beta), dev(rm), dev(rv), dev(nbt), scale, shift, mean, invstd, B * H * W)
+  y = ops.affine_act(raw, scale=scale, shift=shift)
+  check('bnstats200.bn', nchw(y.float().cpu()), want, dtype, scale=2.0)
+  assert float(acc[:nrows * 2 * C].abs().max()) == 0.0  # the rows cleared themselves for the next layer
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

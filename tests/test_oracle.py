@@ -59,29 +59,43 @@ def test_port_wp_variant_vs_reference_golden(cfg):
   assert out[1] is None and out[2] is None
 
 
-def test_port_train_step_vs_reference_golden(cfg):
-  g = U.load_golden('tfpp_train_bs2.npz')
+def _port_train_step_vs_golden(cfg, bs, fname):
+  g = U.load_golden(fname)
   cfg0 = dataclasses.replace(cfg, embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0, decoder_dropout=0.0)
   sd = P.make_state_dict(cfg0)
   frozen = lambda k: ('valid_bev' in k or 'running' in k or k.startswith('loss_'))
   sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not frozen(k) else v.clone())
         for k, v in sd.items()}
-  out = P.forward(sd, cfg0, *P.make_inputs(2, cfg0), training=True)
-  total, losses = P.total_loss(sd, cfg0, out, P.make_labels(2, cfg0))
+  out = P.forward(sd, cfg0, *P.make_inputs(bs, cfg0), training=True)
+  total, losses = P.total_loss(sd, cfg0, out, P.make_labels(bs, cfg0))
   assert list(losses.keys()) == list(g['loss_names'])
   np.testing.assert_allclose(np.array([v.item() for v in losses.values()]), g['losses'], rtol=2e-5)
   np.testing.assert_allclose(total.item(), g['total_loss'], rtol=2e-5)
   total.backward()
-  # gradients: this network is ill-conditioned in fp32 train-mode BN (two CPU implementations of the same
-  # math differ by ~1e-2 on the LiDAR branch), so compare norms at 3e-2 and skip structurally-zero gradients
-  for name, (norm, gmax) in zip(g['grad_names'], g['grad_norms']):
+  # gradients: this network is ill-conditioned in fp32 train-mode BN (two CPU implementations of the same math differ by 5.4e-3
+  # in per-tensor norms and by up to 0.08 x (rms + |ref|) on single elements of the LiDAR-branch BN biases), so norms are held to
+  # 1e-2, the sampled ELEMENTS the reference wrote to 0.15 x (rms + |ref|); structurally-zero gradients are skipped
+  for name, (norm, gmax), samples in zip(g['grad_names'], g['grad_norms'], g['grad_samples']):
     if gmax < 1e-5:
       continue
-    mine = sd[str(name)].grad.double().norm().item()
-    assert abs(mine - norm) <= 3e-2 * norm, f'{name}: grad norm {mine} vs {norm}'
+    mine = sd[str(name)].grad.detach().flatten()
+    assert abs(mine.double().norm().item() - norm) <= 1e-2 * norm, f'{name}: grad norm {mine.double().norm().item()} vs {norm}'
+    idx = U.sample_idx(mine.numel())
+    ref = samples[:len(idx)]
+    err = np.max(np.abs(mine[idx].numpy() - ref) / (norm / np.sqrt(mine.numel()) + np.abs(ref)))
+    assert err <= 0.15, f'{name}: sampled gradient elements differ by {err:.3f} x (rms + |ref|)'
   # BN running statistics were updated (momentum 0.1) exactly like the reference
   for name, s in zip(g['running_names'], g['running_sums']):
     assert abs(float(sd[str(name)].double().sum()) - s) <= 1e-4 * (abs(s) + 1.0), name
+
+
+def test_port_train_step_vs_reference_golden(cfg):
+  _port_train_step_vs_golden(cfg, 2, 'tfpp_train_bs2.npz')
+
+
+def test_port_train_step_bs12_vs_reference_golden(cfg):
+  """BASELINE config 3's batch size (the fixture the GPU parity test of the benchmarked kernel variants uses)."""
+  _port_train_step_vs_golden(cfg, 12, 'tfpp_train_bs12.npz')
 
 
 @pytest.mark.skipif(not ref_harness.available(), reason='needs /root/reference (build container only)')
