@@ -14,9 +14,10 @@ int conv_halo_variant(const tfpp_conv_params& p);
 int conv_halo_mtiles(const tfpp_conv_params& p);
 int conv_gemm_halo(const tfpp_conv_params& p, hipStream_t st);
 
-// weight gradient with the LDS-DMA ring + hardware transpose reads (gemm_wgrad_glds.hip), bf16, 64 x 64 tiles
+// weight gradient with the LDS-DMA ring + hardware transpose reads (gemm_wgrad_glds.hip), bf16; tile = 64 (4 waves) or 128 (8 waves)
 bool wgrad_glds_supported(const tfpp_wgrad_params& p, int dtype);
-int conv_wgrad_glds(const tfpp_wgrad_params& p, hipStream_t st);
+bool wgrad_glds128_preferred(const tfpp_wgrad_params& p);
+int conv_wgrad_glds(const tfpp_wgrad_params& p, int tile, hipStream_t st);
 
 // 3x3 / stride 1 weight gradient with LDS-staged halo tiles (wgrad3x3_halo.hip), bf16, n_g, ks_g <= 64: slices per group (0 = n/a)
 int wgrad_halo_slices(const tfpp_wgrad_params& p, int dtype);

@@ -517,7 +517,8 @@ static int launch_wgrad(const tfpp_wgrad_params& p, hipStream_t st) {
 }
 
 // The plan of one weight-gradient call: which kernel, how many pixel slices, whether a second-stage sum follows.
-// variant: 0 = LDS-staged 32x32, 1 = LDS-staged 64x64, 2 = LDS-DMA ring 64x64 (gemm_wgrad_glds.hip), 3 = 3x3 halo (wgrad3x3_halo.hip)
+// variant: 0 = LDS-staged 32x32, 1 = LDS-staged 64x64, 2 = LDS-DMA ring 64x64, 3 = 3x3 halo (wgrad3x3_halo.hip),
+//          4 = LDS-DMA ring 128x128 with 8 waves (gemm_wgrad_glds.hip)
 struct WgradPlan { int variant, splits, reduce; };
 template <typename T> static int plan_wgrad(tfpp_wgrad_params& p, WgradPlan& pl) {
   constexpr int VEC = ElemTraits<T>::VEC;
@@ -530,12 +531,16 @@ template <typename T> static int plan_wgrad(tfpp_wgrad_params& p, WgradPlan& pl)
     return 0;
   }
   const bool small = (p.n_g <= 32 || KK <= 32);
-  const int bm = small ? 32 : 64, bn = bm;  // 128x128 weight-gradient tiles measured slower (fewer workgroups)
+  const bool glds = !small && wgrad_glds_supported(p, ElemTraits<T>::DT);
+  // wide layers with enough work to amortise the deeper ring: 128x128 tiles, 8 waves (>= 4 GFLOP per group keeps >= ~8 stages per
+  // workgroup at one round of the chip)
+  const bool big = glds && wgrad_glds128_preferred(p) && 2.0 * (double)P * p.n_g * KK >= 4e9;
+  const int bm = small ? 32 : (big ? 128 : 64), bn = bm;
+  const long tiles = (long)cdiv(p.n_g, bm) * cdiv(KK, bn) * p.G;
   if (p.splits <= 0) {
-    // enough workgroups to fill 256 CUs several times over, but at least 512 pixels of reduction each
-    const long tiles = (long)cdiv(p.n_g, bm) * cdiv(KK, bn) * p.G;
-    long want = (1536 + tiles - 1) / tiles;
-    long maxs = (P + 511) / 512;
+    long want, maxs = (P + 511) / 512;  // at least 512 pixels of reduction per workgroup
+    if (big) want = 256 / tiles;        // one workgroup (96 KB of LDS) per CU: about one round of the chip, no pixel split from 256 tiles
+    else want = (1536 + tiles - 1) / tiles;  // 4-wave workgroups: enough of them to fill 256 CUs several times over
     p.splits = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
     if (p.splits >= 8) p.splits = p.splits / 8 * 8;  // whole XCD rounds
     if (p.splits < 1) p.splits = 1;
@@ -546,7 +551,7 @@ template <typename T> static int plan_wgrad(tfpp_wgrad_params& p, WgradPlan& pl)
     if (fit >= 2) p.splits = (int)fit;
     else p.ws = nullptr;  // atomics
   }
-  pl.variant = small ? 0 : (wgrad_glds_supported(p, ElemTraits<T>::DT) ? 2 : 1);
+  pl.variant = small ? 0 : (glds ? (big ? 4 : 2) : 1);
   pl.splits = p.splits;
   pl.reduce = (p.ws && p.splits > 1) ? 1 : 0;
   return 0;
@@ -554,8 +559,9 @@ template <typename T> static int plan_wgrad(tfpp_wgrad_params& p, WgradPlan& pl)
 
 template <typename T> static int run_wgrad_stage1(const tfpp_wgrad_params& p, const WgradPlan& pl, hipStream_t st) {
   switch (pl.variant) {
+    case 4: return conv_wgrad_glds(p, 128, st);
     case 3: return conv_wgrad_halo(p, pl.splits, st);
-    case 2: return conv_wgrad_glds(p, st);
+    case 2: return conv_wgrad_glds(p, 64, st);
     case 1: return launch_wgrad<T, 64, 64, 32, 32>(p, st);
     default: return launch_wgrad<T, 32, 32, 16, 16>(p, st);
   }
@@ -590,7 +596,7 @@ extern "C" int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stre
 }
 
 // The same in separately launchable pieces (per-kernel timing in bench.py): stage 1 = first-stage kernel, 2 = slice sum,
-// -1 = plan only.  plan_out[3] = {variant (0 LDS 32x32, 1 LDS 64x64, 2 LDS-DMA ring 64x64, 3 3x3 halo), slices, has second stage}.
+// -1 = plan only.  plan_out[3] = {variant (0 LDS 32x32, 1 LDS 64x64, 2 LDS-DMA ring 64x64, 3 3x3 halo, 4 LDS-DMA ring 128x128), slices, has second stage}.
 extern "C" int tfpp_conv_wgrad_stage(const tfpp_wgrad_params* p, int dtype, int stage, int* plan_out, void* stream) {
   if (!p || !p->dy || !p->x || !p->dw || stage == 0 || stage > 2) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;

@@ -1,14 +1,24 @@
 // Weight gradient with a multi-stage LDS-DMA ring, bf16:  dW[n][kk] += sum_pixels dY[pix][n] * Xgather[pix][kk].
 //
 // Both operands are "k-major" for this product (the reduction index, the pixel, is the slow index of the NHWC tensors), so a
-// 32-pixel stage of dY (BM channels) and of X (BN gathered (tap, channel) columns) is copied HBM/L2 -> LDS by
+// BKP-pixel stage of dY (TM channels) and of X (TN gathered (tap, channel) columns) is copied HBM/L2 -> LDS by
 // global_load_lds_dwordx4 exactly as it lies in memory -- [pixel][channel chunk] -- and the MFMA fragments (8 consecutive
 // pixels per lane) are produced by the hardware transpose read ds_read_b64_tr_b16.  NSTAGE stages in flight, one raw
 // s_barrier per stage, counted vmcnt (same skeleton as gemm_glds.hip).  LDS-DMA writes lane-linear, so the image is the
 // linear [pixel][CH x 16 B] and the bank-conflict swizzle is applied to the SOURCE chunk index and again on the read:
-//     slot of (pixel p, chunk c) = c ^ F(p),   F(p) = 2*((p>>1)&1) + 4*((p>>3)&1)          (64-channel rows, 128 B)
-// A transpose read takes, per 16-lane group, 4 pixel rows x 32 B; within the 32 lanes the hardware serves together the rows
-// are {0..3, 8..11} (+16): rows of equal parity alias in the 64 banks and F moves them to distinct 32-byte pairs.
+//     64-channel rows (128 B):  slot of (pixel p, chunk c) = c ^ (2*((p>>1)&1) + 4*((p>>3)&1))
+//     128-channel rows (256 B): slot of (pixel p, chunk c) = c ^ (2*(p&3)      + 8*((p>>3)&1))
+// A transpose read takes, per 16-lane group, 4 pixel rows x 32 B; the 32 lanes the hardware serves together address the rows
+// {0..3, 8..11} (+16) at one 32-byte column: un-swizzled they alias in the 64 banks (8-way on 256-byte rows, which are exactly one
+// bank row each); the XOR moves the eight rows to eight distinct 32-byte pairs.  Adding 4 or 32 to p (second read of a fragment,
+// second k-step of a stage) does not change the swizzle, so one base offset per fragment serves all of its reads.
+//
+// Two instantiations:
+//   64 x 64 tile, 4 waves (2x2), 32 pixels per stage, 4 stages: the small / medium layers, pixel reduction split over many
+//     workgroups (slices summed by wgrad_reduce_kernel);
+//   128 x 128 tile, 8 waves (2x4), 64 pixels per stage (two MFMA k-steps per barrier), 3 stages = 96 KB: the wide layers
+//     (fusion linears 6048 x 1512: 564 tiles, no pixel split, the tile is added straight into dW; RegNet stage 3/4 1x1 convs with a
+//     moderate split).  Twice the operand reuse per byte brought into LDS and 16 instead of 4 MFMAs per wave between barriers.
 // The single-buffered kernel in gemm_kernels.hip (load -> ds_write -> barrier -> MFMA -> barrier per 64 pixels) measured
 // 25-35 us of main loop on the 576x576 / 216x216 layers; this one keeps NSTAGE-1 stages of loads behind the MFMAs.
 #include "gemm_core.cuh"
@@ -27,40 +37,66 @@ __device__ __forceinline__ u32x2_t lds_read_tr16_b64_asm(unsigned addr) {
 }
 
 namespace {
-constexpr int BM = 64, BN = 64, BKP = 32;          // tile: 64 output rows (n) x 64 columns (kk), 32 pixels per stage
-constexpr int ROW_BYTES = 128, CH = 8;             // 64 channels x 2 B per pixel row, 16-byte chunks per row
-constexpr int A_BYTES = BKP * ROW_BYTES, STAGE_BYTES = 2 * A_BYTES;
+template <int T> __device__ __forceinline__ int swz(int p);
+template <> __device__ __forceinline__ int swz<64>(int p) { return 2 * ((p >> 1) & 1) + 4 * ((p >> 3) & 1); }
+template <> __device__ __forceinline__ int swz<128>(int p) { return 2 * (p & 3) + 8 * ((p >> 3) & 1); }
 
-__device__ __forceinline__ int swz(int p) { return 2 * ((p >> 1) & 1) + 4 * ((p >> 3) & 1); }
-
-template <int NSTAGE>
-__global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(tfpp_wgrad_params p) {
+template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE>
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wgrad_params p) {
   typedef bf16_t T;
-  constexpr int FM = 2, FN = 2, LOADS = 2;  // 2x2 waves, wave tile 32 x 32; one A and one B DMA per wave per stage
+  constexpr int NT = WGM * WGN * 64, NWAVES = WGM * WGN;
+  constexpr int WM = TM / WGM, WN = TN / WGN, FM = WM / 16, FN = WN / 16, KS = BKP / 32;
+  constexpr int ROW_A = TM * 2, ROW_B = TN * 2, CH_A = TM / 8, CH_B = TN / 8;  // bytes / 16-byte chunks per pixel row
+  constexpr int A_BYTES = BKP * ROW_A, B_BYTES = BKP * ROW_B, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INST = A_BYTES / 16 / NT, B_INST = B_BYTES / 16 / NT, LOADS = A_INST + B_INST;
+  static_assert(A_INST * 16 * NT == A_BYTES && B_INST * 16 * NT == B_BYTES, "stage must divide over the threads");
+  static_assert(LOADS * (NSTAGE - 2) < 64, "vmcnt is a 6-bit counter");
+  static_assert(KS <= 2 && (KS - 1) * (FM + FN) * 2 <= 15, "lgkmcnt ladder: one or two k-steps per stage, 4-bit counter");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int KK = p.R * p.S * p.ks_g;
-  // 1-D grid.  Workgroup id -> XCD id % 8.  With the slices a multiple of 8, XCD x walks slices x, x+8, ... and, inside a slice, all
-  // (n, kk) tiles back to back: the slice's dY / X pixel slab (1-2 MB) is fetched into that XCD's L2 once and shared by every tile.
-  // (x = slice fastest, as the LDS-staged kernel orders them, spreads the tiles of a slab over the whole launch: measured 2.6x
-  // the algorithmic bytes at the fabric.)
-  const int tiles_m = (p.n_g + BM - 1) / BM, tiles_n = (KK + BN - 1) / BN, ntiles = tiles_m * tiles_n;
-  int g, split, tile;
+  // 1-D grid.  Workgroup id -> XCD id % 8.
+  //  * pixel slices a multiple of 8: XCD x walks slices x, x+8, ... and, inside a slice, all (n, kk) tiles back to back: the slice's
+  //    dY / X pixel slab (1-2 MB) is fetched into that XCD's L2 once and shared by every tile (x = slice fastest, as the LDS-staged
+  //    kernel orders them, spreads the tiles of a slab over the whole launch: measured 2.6x the algorithmic bytes at the fabric);
+  //  * otherwise (one slice, or a few): XCD x owns every 8th tile along the LONGER tile axis and walks the shorter axis back to
+  //    back, so an XCD fetches 1/8 of the large operand plus the small one (each XCD computing a compact block of the tile grid is
+  //    the best 8 separate L2s allow: ~2.3x the algorithmic bytes at 128x128 tiles, absorbed by the Infinity Cache).
+  const int tiles_m = (p.n_g + TM - 1) / TM, tiles_n = (KK + TN - 1) / TN, ntiles = tiles_m * tiles_n;
+  int g, split, tile_m, tile_n;
   {
     const int id = blockIdx.x, per_g = p.splits * ntiles;
     g = id / per_g;
     const int r = id - g * per_g;
+    int tile;
     if ((p.splits & 7) == 0) {
       const int xcd = r & 7, j = r >> 3;
       tile = j % ntiles;
       split = (j / ntiles) * 8 + xcd;
+      tile_m = tile % tiles_m;
+      tile_n = tile / tiles_m;
     } else {
       split = r % p.splits;
       tile = r / p.splits;
+      const bool m_long = tiles_m >= tiles_n;
+      const int nl = m_long ? tiles_m : tiles_n, ns = m_long ? tiles_n : tiles_m;  // long / short axis
+      const int full = (nl >> 3) << 3;
+      int tl, ts;
+      if (tile < full * ns) {
+        const int xcd = tile & 7, j = tile >> 3;
+        ts = j % ns;
+        tl = (j / ns) * 8 + xcd;
+      } else {  // the last (< 8) tiles of the long axis keep the plain order
+        const int q = tile - full * ns;
+        ts = q % ns;
+        tl = full + q / ns;
+      }
+      tile_m = m_long ? tl : ts;
+      tile_n = m_long ? ts : tl;
     }
   }
-  const int bm0 = (tile % tiles_m) * BM, bn0 = (tile / tiles_m) * BN;
+  const int bm0 = tile_m * TM, bn0 = tile_n * TN;
   const long P = (long)p.B * p.Hd * p.Wd;
   const long per = ((P + p.splits - 1) / p.splits + BKP - 1) / BKP * BKP;
   const long p_beg = (long)split * per, p_end = (p_beg + per < P) ? p_beg + per : P;
@@ -70,33 +106,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(tfpp_wgrad_params 
   const T* zero = reinterpret_cast<const T*>(tfpp_zero_page);
   const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)smem;
 
-  // this thread's chunk of every stage: slot q = tid -> pixel row pk = q / 8, physical chunk cp = q % 8, logical chunk cp ^ F(pk)
-  const int pk = tid >> 3, cl = (tid & 7) ^ swz(pk);
-  const int a_n = bm0 + cl * 8;   // dY channel of the chunk
-  const int b_kk = bn0 + cl * 8;  // gathered column (tap, channel) of the chunk
-  const bool a_ok = a_n < p.n_g, b_ok = b_kk < KK;
-  const int b_rs = b_ok ? b_kk / p.ks_g : 0, b_c = b_kk - b_rs * p.ks_g, b_r = b_rs / p.S, b_s = b_rs - b_r * p.S;
+  // this thread's chunks of every stage: DMA i of the workgroup fills bytes [i*NT*16, (i+1)*NT*16) of the stage half, thread tid the
+  // 16 bytes at slot q = i*NT + tid -> pixel row pk = q / CH, physical chunk cp = q % CH, logical chunk cp ^ swz(pk)
+  int a_pk[A_INST], a_n[A_INST];
+  bool a_ok[A_INST];
+#pragma unroll
+  for (int i = 0; i < A_INST; ++i) {
+    const int q = i * NT + tid;
+    a_pk[i] = q / CH_A;
+    a_n[i] = bm0 + (((q % CH_A) ^ swz<TM>(a_pk[i])) * 8);  // dY channel of the chunk
+    a_ok[i] = a_n[i] < p.n_g;
+  }
+  int b_pk[B_INST], b_c[B_INST], b_r[B_INST], b_s[B_INST];
+  bool b_ok[B_INST];
+#pragma unroll
+  for (int j = 0; j < B_INST; ++j) {
+    const int q = j * NT + tid;
+    b_pk[j] = q / CH_B;
+    const int kk = bn0 + (((q % CH_B) ^ swz<TN>(b_pk[j])) * 8);  // gathered column (tap, channel) of the chunk
+    b_ok[j] = kk < KK;
+    const int rs = b_ok[j] ? kk / p.ks_g : 0;
+    b_c[j] = kk - rs * p.ks_g;
+    b_r[j] = rs / p.S;
+    b_s[j] = rs - b_r[j] * p.S;
+  }
   const bool pointwise = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
   const int hw = p.Hd * p.Wd;
 
   auto issue = [&](int st) {  // LDS-DMA of pixel stage st into ring slot st % NSTAGE
     const unsigned stage = lds_base + (unsigned)((st % NSTAGE) * STAGE_BYTES);
-    const long pix = p_beg + (long)st * BKP + pk;
-    const T* ga = zero;
-    const T* gb = zero;
-    if (pix < p_end) {
-      if (a_ok) ga = dy + (size_t)pix * p.dy_ld + a_n;
-      if (b_ok) {
-        if (pointwise) gb = x + (size_t)pix * p.x_ld + b_c;
+    const long pix0 = p_beg + (long)st * BKP;
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+      const long pix = pix0 + a_pk[i];
+      const T* ga = (pix < p_end && a_ok[i]) ? dy + (size_t)pix * p.dy_ld + a_n[i] : zero;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)ga, (lds_void_t*)(stage + (unsigned)((i * NWAVES + wave) * 1024)), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_INST; ++j) {
+      const long pix = pix0 + b_pk[j];
+      const T* gb = zero;
+      if (pix < p_end && b_ok[j]) {
+        if (pointwise) gb = x + (size_t)pix * p.x_ld + b_c[j];
         else {
           const int b = (int)(pix / hw), rem = (int)(pix - (long)b * hw), hd = rem / p.Wd, wd = rem - hd * p.Wd;
-          const int hs = hd * p.stride - p.pad + b_r, ws = wd * p.stride - p.pad + b_s;
-          if (hs >= 0 && hs < p.Hs && ws >= 0 && ws < p.Ws) gb = x + ((size_t)(b * p.Hs + hs) * p.Ws + ws) * p.x_ld + b_c;
+          const int hs = hd * p.stride - p.pad + b_r[j], ws = wd * p.stride - p.pad + b_s[j];
+          if (hs >= 0 && hs < p.Hs && ws >= 0 && ws < p.Ws) gb = x + ((size_t)(b * p.Hs + hs) * p.Ws + ws) * p.x_ld + b_c[j];
         }
       }
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)gb, (lds_void_t*)(stage + (unsigned)(A_BYTES + (j * NWAVES + wave) * 1024)), 16, 0, 0);
     }
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)ga, (lds_void_t*)(stage + (unsigned)(wave * 1024)), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)gb, (lds_void_t*)(stage + (unsigned)(A_BYTES + wave * 1024)), 16, 0, 0);
   };
 
   f32x4_t acc[FM][FN];
@@ -105,20 +164,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(tfpp_wgrad_params 
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // transpose-read offsets (fixed): lane (m = l & 15, kg = l >> 4) addresses pixel row kg*8 + (m >> 2) [+4 for the second read],
-  // 8 bytes at channel quad (frag_row0 / 4 + (m & 3)) -> chunk (frag_row0 / 8 + (m & 3) / 2), half (m & 3) & 1
+  // transpose-read offsets (fixed): lane (m = l & 15, kg = l >> 4) addresses pixel row kg*8 + (m >> 2) [+4 for the second read,
+  // +32 per k-step], 8 bytes at channel quad (frag_row0 / 4 + (m & 3)) -> chunk (frag_row0 / 8 + (m & 3) / 2), half (m & 3) & 1
   const int m16 = lane & 15, kg = lane >> 4;
   const int prow = kg * 8 + (m16 >> 2);
   unsigned a_off[FM], b_off[FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    const int c = (wm * 32 + i * 16) / 8 + ((m16 & 3) >> 1);
-    a_off[i] = (unsigned)(prow * ROW_BYTES + ((c ^ swz(prow)) * 16) + (m16 & 1) * 8);
+    const int c = (wm * WM + i * 16) / 8 + ((m16 & 3) >> 1);
+    a_off[i] = (unsigned)(prow * ROW_A + ((c ^ swz<TM>(prow)) * 16) + (m16 & 1) * 8);
   }
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
-    const int c = (wn * 32 + j * 16) / 8 + ((m16 & 3) >> 1);
-    b_off[j] = (unsigned)(A_BYTES + prow * ROW_BYTES + ((c ^ swz(prow)) * 16) + (m16 & 1) * 8);
+    const int c = (wn * WN + j * 16) / 8 + ((m16 & 3) >> 1);
+    b_off[j] = (unsigned)(A_BYTES + prow * ROW_B + ((c ^ swz<TN>(prow)) * 16) + (m16 & 1) * 8);
   }
 
 #pragma unroll
@@ -136,22 +195,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(tfpp_wgrad_params 
     __builtin_amdgcn_s_barrier();  // stage st landed for every wave; every wave is done with stage st-1
     if (st + NSTAGE - 1 < nst) issue(st + NSTAGE - 1);
     const unsigned stage = lds_base + (unsigned)((st % NSTAGE) * STAGE_BYTES);
-    Frag<T> fa[FM], fb[FN];
-    u32x2_t lo[FM + FN], hi[FM + FN];
+    // all transpose reads of the stage are issued up front (DS operations retire in order): the MFMAs of k-step ks start once its
+    // own (FM + FN) * 2 reads have landed, while the reads of the later k-steps are still in flight
+    u32x2_t lo[KS][FM + FN], hi[KS][FM + FN];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) { lo[i] = lds_read_tr16_b64_asm(stage + a_off[i]); hi[i] = lds_read_tr16_b64_asm(stage + a_off[i] + 4 * ROW_BYTES); }
+    for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-    for (int j = 0; j < FN; ++j) { lo[FM + j] = lds_read_tr16_b64_asm(stage + b_off[j]); hi[FM + j] = lds_read_tr16_b64_asm(stage + b_off[j] + 4 * ROW_BYTES); }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < FM; ++i) {
+        const unsigned a = stage + a_off[i] + (unsigned)(ks * 32 * ROW_A);
+        lo[ks][i] = lds_read_tr16_b64_asm(a);
+        hi[ks][i] = lds_read_tr16_b64_asm(a + 4 * ROW_A);
+      }
 #pragma unroll
-    for (int i = 0; i < FM; ++i) fa[i].v = make_uint4(lo[i][0], lo[i][1], hi[i][0], hi[i][1]);
+      for (int j = 0; j < FN; ++j) {
+        const unsigned b = stage + b_off[j] + (unsigned)(ks * 32 * ROW_B);
+        lo[ks][FM + j] = lds_read_tr16_b64_asm(b);
+        hi[ks][FM + j] = lds_read_tr16_b64_asm(b + 4 * ROW_B);
+      }
+    }
 #pragma unroll
-    for (int j = 0; j < FN; ++j) fb[j].v = make_uint4(lo[FM + j][0], lo[FM + j][1], hi[FM + j][0], hi[FM + j][1]);
+    for (int ks = 0; ks < KS; ++ks) {
+      constexpr int PER = (FM + FN) * 2;
+      if (ks == KS - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PER * (KS - 1)) : "memory");  // the reads of the later k-step may stay in flight
+      __builtin_amdgcn_sched_barrier(0);
+      Frag<T> fa[FM], fb[FN];
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+      for (int i = 0; i < FM; ++i) fa[i].v = make_uint4(lo[ks][i][0], lo[ks][i][1], hi[ks][i][0], hi[ks][i][1]);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) frag_mma(fa[i], fb[j], acc[i][j]);
+      for (int j = 0; j < FN; ++j) fb[j].v = make_uint4(lo[ks][FM + j][0], lo[ks][FM + j][1], hi[ks][FM + j][0], hi[ks][FM + j][1]);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) frag_mma(fa[i], fb[j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // ---- epilogue: slice -> workspace [split][G*n_g][KK] (summed by wgrad_reduce_kernel), or straight into dw
@@ -162,11 +240,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(tfpp_wgrad_params 
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = bm0 + wm * 32 + i * 16 + kg * 4 + r;
+        const int n = bm0 + wm * WM + i * 16 + kg * 4 + r;
         if (n >= p.n_g) continue;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-          const int kk = bn0 + wn * 32 + j * 16 + m16;
+          const int kk = bn0 + wn * WN + j * 16 + m16;
           if (kk < KK) wsp[(size_t)n * KK + kk] = acc[i][j][r];
         }
       }
@@ -176,14 +254,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(tfpp_wgrad_params 
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = bm0 + wm * 32 + i * 16 + kg * 4 + r;
+      const int n = bm0 + wm * WM + i * 16 + kg * 4 + r;
       if (n >= p.n_g) continue;
       int row = g * p.n_g + n;
       if (p.row_map) row = p.row_map[row];
       if (row < 0) continue;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int kk = bn0 + wn * 32 + j * 16 + m16;
+        const int kk = bn0 + wn * WN + j * 16 + m16;
         if (kk >= KK) continue;
         long col;
         if (p.col_map) {
@@ -200,6 +278,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(tfpp_wgrad_params 
       }
     }
 }
+
+template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE> int launch_wgrad_glds(const tfpp_wgrad_params& p, hipStream_t st) {
+  const int KK = p.R * p.S * p.ks_g;
+  constexpr size_t lds = (size_t)NSTAGE * BKP * (TM + TN) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_glds_kernel<TM, TN, WGM, WGN, BKP, NSTAGE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((long)p.G * p.splits * cdiv(p.n_g, TM) * cdiv(KK, TN)));
+  hipLaunchKernelGGL((conv_wgrad_glds_kernel<TM, TN, WGM, WGN, BKP, NSTAGE>), grid, dim3(WGM * WGN * 64), lds, st, p);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
 }  // namespace
 
 bool wgrad_glds_supported(const tfpp_wgrad_params& p, int dtype) {
@@ -209,11 +302,16 @@ bool wgrad_glds_supported(const tfpp_wgrad_params& p, int dtype) {
          ((uintptr_t)p.dy & 15) == 0 && ((uintptr_t)p.x & 15) == 0;
 }
 
-int conv_wgrad_glds(const tfpp_wgrad_params& p, hipStream_t st) {
-  constexpr int NSTAGE = 4;
+// 128 x 128 tiles pay when both dimensions fill them reasonably (>= 75 % of the padded tile area is real work)
+bool wgrad_glds128_preferred(const tfpp_wgrad_params& p) {
+  static const int on = [] { const char* e = std::getenv("TFPP_WGRAD_GLDS128"); return (e && e[0] == '0') ? 0 : 1; }();
   const int KK = p.R * p.S * p.ks_g;
-  dim3 grid((unsigned)((long)p.G * p.splits * cdiv(p.n_g, BM) * cdiv(KK, BN)));
-  hipLaunchKernelGGL(conv_wgrad_glds_kernel<NSTAGE>, grid, dim3(256), (size_t)NSTAGE * STAGE_BYTES, st, p);
-  TFPP_CHECK_LAUNCH();
-  return 0;
+  if (!on || p.n_g < 128 || KK < 128) return false;
+  const double fill = ((double)p.n_g * KK) / ((double)cdiv(p.n_g, 128) * 128 * cdiv(KK, 128) * 128);
+  return fill >= 0.75;
+}
+
+int conv_wgrad_glds(const tfpp_wgrad_params& p, int tile, hipStream_t st) {
+  if (tile == 128) return launch_wgrad_glds<128, 128, 2, 4, 64, 3>(p, st);
+  return launch_wgrad_glds<64, 64, 2, 2, 32, 4>(p, st);
 }

@@ -163,7 +163,7 @@ def conv_wgrad(dy, x, dw, **kw):
   if lib.profiler is not None:  # one profiled call per kernel: first stage and slice sum are timed separately
     plan = (ctypes.c_int * 3)()
     lib.raw('tfpp_conv_wgrad_stage')(ctypes.byref(p), dt(dy), -1, plan, stream())  # plan only: no launch, not timed
-    kind = ('lds32x32', 'lds64x64', 'glds64x64', 'halo3x3')[plan[0]]
+    kind = ('lds32x32', 'lds64x64', 'glds64x64', 'halo3x3', 'glds128x128')[plan[0]]
     fam = f'conv_wgrad<{"f32" if dy.dtype == torch.float32 else "bf16"},{kind}>'
     if PROFILE_SHAPES:
       fam += f' P={B * Hd * Wd} N={p.n_g} K={R * S * p.ks_g} G={G} k{R}s{stride}'

@@ -108,7 +108,8 @@ typedef struct {
 } tfpp_wgrad_params;
 int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stream);
 /* the same call in separately launchable pieces (per-kernel timing): stage 1 = first-stage kernel, 2 = slice sum, -1 = plan only;
- * plan_out[3] (nullable) = {variant: 0 LDS-staged 32x32, 1 LDS-staged 64x64, 2 LDS-DMA ring 64x64, 3 3x3 halo; slices; has second stage} */
+ * plan_out[3] (nullable) = {variant: 0 LDS-staged 32x32, 1 LDS-staged 64x64, 2 LDS-DMA ring 64x64, 3 3x3 halo, 4 LDS-DMA ring 128x128
+ * (8 waves); slices; has second stage} */
 int tfpp_conv_wgrad_stage(const tfpp_wgrad_params* p, int dtype, int stage, int* plan_out, void* stream);
 
 /* Strided batched GEMM C[z] = act(alpha * A[z] x B[z]^T-or-not + bias): attention products

@@ -12,7 +12,10 @@ from carla_garage_amd import ops  # noqa: E402
 SHAPES = [
     # name, B, H, W, Cin, Cout, k, stride, groups
     ('fusion_mlp0 3840x6048x1512', 3840, 1, 1, 1512, 6048, 1, 1, 1),
+    ('fusion_mlp2 3840x1512x6048', 3840, 1, 1, 6048, 1512, 1, 1, 1),
     ('fusion_proj 3840x1512x1512', 3840, 1, 1, 1512, 1512, 1, 1, 1),
+    ('fusion576_mlp0 3840x2304x576', 3840, 1, 1, 576, 2304, 1, 1, 1),
+    ('s4_1x1 3072x1512x1512', 12, 8, 32, 1512, 1512, 1, 1, 1),
     ('s3_1x1 12288x576x576', 12, 16, 64, 576, 576, 1, 1, 1),
     ('lid_s3_1x1 3072x576x576', 12, 16, 16, 576, 576, 1, 1, 1),
     ('lid_s4_1x1 768x1512x1512', 12, 8, 8, 1512, 1512, 1, 1, 1),
@@ -69,7 +72,9 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.iters
-    print(f'{"wgrad" if args.wgrad else "conv "} {name:32s} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TFLOP/s', flush=True)
+    geo = dict(B=B, Hs=H, Ws=W, Cs=Cin, Hd=Ho, Wd=Wo, Cd=Cout, R=k, S=k, stride=st, pad=pad, G=G)
+    plan = ops.conv_wgrad_plan(y, x, dw, **geo) if args.wgrad else ops.conv_gemm(x, wp, y, plan_only=True, **geo)
+    print(f'{"wgrad" if args.wgrad else "conv "} {name:32s} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TFLOP/s  plan {plan}', flush=True)
 
 
 if __name__ == '__main__':
