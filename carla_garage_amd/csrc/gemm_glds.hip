@@ -30,15 +30,27 @@ __device__ __forceinline__ uint4 lds_read_b128_asm(unsigned addr) {
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
-template <int BM, int BN, int NSTAGE, int WGM, int WGN>
+// physical 16-byte slot of logical chunk kc in row `row` of a stage image with CPR chunks per row (CPR = 4: 64-byte rows, the
+// {0,2,3,1}[(row>>2)&3] table above; CPR = 8: 128-byte rows, two rows per 256-byte bank row: XOR with (row>>1)&7 sends the 16 rows of
+// a ds_read_b128 lane group to 16 distinct slots)
+template <int CPR> __device__ __forceinline__ int glds_swz(int row) {
+  if constexpr (CPR == 4) return (0x1320 >> (((row >> 2) & 3) * 4)) & 3;
+  else return (row >> 1) & 7;
+}
+
+// KS: MFMA k-steps (of 32) per stage = per barrier.  KS = 2 halves the barriers, waits and address arithmetic per MFMA (the
+// per-stage overhead of ~40 non-MFMA instructions against 8 MFMAs was the measured limit of the KS = 1 kernel).
+template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_conv_params p, int trace, int m_major) {
   typedef bf16_t T;
   constexpr int NT = WGM * WGN * 64, NWAVES = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
-  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int A_INST = BM * 4 / NT, B_INST = BN * 4 / NT;  // 16-byte chunks per thread per tile
-  static_assert((BM * 4) % NT == 0 && (BN * 4) % NT == 0, "tile must divide over the threads");
+  constexpr int BKT = 32 * KS, CPR = 4 * KS, ROWB = 64 * KS;  // K elements / 16-byte chunks / bytes per stage row
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INST = BM * CPR / NT, B_INST = BN * CPR / NT;  // 16-byte chunks per thread per tile
+  static_assert((BM * CPR) % NT == 0 && (BN * CPR) % NT == 0, "tile must divide over the threads");
   constexpr int LOADS = A_INST + B_INST;              // LDS-DMA instructions per wave per tile
+  static_assert((FM + FN) * (KS - 1) <= 15, "lgkmcnt is a 4-bit counter");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TRACE(0);
@@ -76,9 +88,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
   const bool pointwise = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
 #pragma unroll
   for (int i = 0; i < A_INST; ++i) {
-    const int q = i * NT + tid, row = q >> 2, slot = q & 3;
-    const int f = (0x1320 >> (((row >> 2) & 3) * 4)) & 3;  // F = {0,2,3,1}
-    a_kc[i] = slot ^ f;
+    const int q = i * NT + tid, row = q / CPR, slot = q % CPR;
+    a_kc[i] = slot ^ glds_swz<CPR>(row);
     const int m = bm0 + row;
     a_ptr[i] = nullptr;
     if (m < M) {
@@ -95,30 +106,53 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
   const T* b_ptr[B_INST];
 #pragma unroll
   for (int j = 0; j < B_INST; ++j) {
-    const int q = j * NT + tid, row = q >> 2, slot = q & 3;
-    const int f = (0x1320 >> (((row >> 2) & 3) * 4)) & 3;
-    b_kc[j] = slot ^ f;
+    const int q = j * NT + tid, row = q / CPR, slot = q % CPR;
+    b_kc[j] = slot ^ glds_swz<CPR>(row);
     const int n = bn0 + row;
     b_ptr[j] = (n < p.n_g) ? wk + (size_t)n * K : nullptr;
   }
 
   // K tiles of this workgroup: all of them, or one slice of a split-K launch
-  int kt_beg = 0, nkt = (K + 31) / 32;
+  int kt_beg = 0, nkt = (K + BKT - 1) / BKT;
   if (p.splitk > 1) {
     const int per = (nkt + p.splitk - 1) / p.splitk;
     kt_beg = split * per;
     nkt = (kt_beg + per < nkt ? kt_beg + per : nkt) - kt_beg;
     if (nkt < 0) nkt = 0;
   }
-  auto issue = [&](int kt) {  // LDS-DMA of this workgroup's K-tile kt into ring slot kt % NSTAGE
+  // Incremental addressing (SQ_INSTS_VALU / SQ_INSTS_MFMA measured 5.8 with per-tile address generation): a chunk of a pointwise
+  // layer and every weight chunk keep a running pointer that advances by one K-tile (64 bytes) per issue; rows outside the problem
+  // point at the zero page with step 0, the K tail (K % 32 != 0) exists only in the last tile and is masked there.
+  const int last_kt = nkt - 1;
+  const bool ktail = ((kt_beg + nkt) * BKT > K);  // the last tile of this workgroup reaches past K (wave-uniform)
+  const T* a_cur[A_INST];
+  int a_stepe[A_INST];  // elements per tile: 32 or 0
+#pragma unroll
+  for (int i = 0; i < A_INST; ++i) {
+    const bool lin = pointwise && a_ptr[i] != nullptr;
+    a_cur[i] = lin ? a_ptr[i] + kt_beg * BKT + a_kc[i] * 8 : zero;
+    a_stepe[i] = lin ? BKT : 0;
+  }
+  const T* b_cur[B_INST];
+  int b_stepe[B_INST];
+#pragma unroll
+  for (int j = 0; j < B_INST; ++j) {
+    b_cur[j] = b_ptr[j] ? b_ptr[j] + kt_beg * BKT + b_kc[j] * 8 : zero;
+    b_stepe[j] = b_ptr[j] ? BKT : 0;
+  }
+  auto issue = [&](int kt) {  // LDS-DMA of this workgroup's K-tile kt into ring slot kt % NSTAGE; called with kt = 0, 1, 2, ... in order
     const unsigned stage = lds_base + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
+    const bool last = ktail && kt == last_kt;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
-      const int k0 = (kt_beg + kt) * 32 + a_kc[i] * 8;
-      const T* gp = zero;
-      if (k0 < K && a_b[i] >= 0) {
-        if (pointwise) gp = a_ptr[i] + k0;
-        else {
+      const T* gp = a_cur[i];
+      if (pointwise) {
+        if (last && (kt_beg + kt) * BKT + a_kc[i] * 8 >= K) gp = zero;
+        a_cur[i] += a_stepe[i];
+      } else {
+        const int k0 = (kt_beg + kt) * BKT + a_kc[i] * 8;
+        gp = zero;
+        if (k0 < K && a_b[i] >= 0) {
           const int rs = k0 / p.ks_g, c = k0 - rs * p.ks_g, r = rs / p.S, s = rs - r * p.S;
           int hs, ws;
           bool ok;
@@ -137,8 +171,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
     }
 #pragma unroll
     for (int j = 0; j < B_INST; ++j) {
-      const int k0 = (kt_beg + kt) * 32 + b_kc[j] * 8;
-      const T* gp = (k0 < K && b_ptr[j]) ? b_ptr[j] + k0 : zero;
+      const T* gp = b_cur[j];
+      if (last && (kt_beg + kt) * BKT + b_kc[j] * 8 >= K) gp = zero;
+      b_cur[j] += b_stepe[j];
       __builtin_amdgcn_global_load_lds((gbl_void_t*)gp, (lds_void_t*)(stage + (unsigned)(A_BYTES + (j * NWAVES + wave) * 1024)), 16, 0, 0);
     }
   };
@@ -149,18 +184,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // fragment read offsets inside a stage (fixed): row*64 + ((l>>4) ^ F[(row>>2)&3]) * 16
+  // fragment read offsets inside a stage (fixed): row * ROWB + ((ks*4 + (l>>4)) ^ swz(row)) * 16
   const int r16 = lane & 15, kgrp = lane >> 4;
-  unsigned a_off[FM], b_off[FN];
+  unsigned a_off[KS][FM], b_off[KS][FN];
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int row = wm * WM + i * 16 + r16;
-    a_off[i] = (unsigned)(row * 64 + ((kgrp ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3)) * 16));
-  }
+  for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int row = wn * WN + j * 16 + r16;
-    b_off[j] = (unsigned)(A_BYTES + row * 64 + ((kgrp ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3)) * 16));
+    for (int i = 0; i < FM; ++i) {
+      const int row = wm * WM + i * 16 + r16;
+      a_off[ks][i] = (unsigned)(row * ROWB + (((ks * 4 + kgrp) ^ glds_swz<CPR>(row)) * 16));
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int row = wn * WN + j * 16 + r16;
+      b_off[ks][j] = (unsigned)(A_BYTES + row * ROWB + (((ks * 4 + kgrp) ^ glds_swz<CPR>(row)) * 16));
+    }
   }
 
   TRACE(1);
@@ -183,17 +221,26 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
     if (kt == 0) TRACE(3);
     if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1);
     const unsigned stage = lds_base + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
-    Frag<T> fa[FM], fb[FN];
+    Frag<T> fa[KS][FM], fb[KS][FN];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) fa[i].v = lds_read_b128_asm(stage + a_off[i]);
+    for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-    for (int j = 0; j < FN; ++j) fb[j].v = lds_read_b128_asm(stage + b_off[j]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < FM; ++i) fa[ks][i].v = lds_read_b128_asm(stage + a_off[ks][i]);
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+      for (int j = 0; j < FN; ++j) fb[ks][j].v = lds_read_b128_asm(stage + b_off[ks][j]);
+    }
 #pragma unroll
-      for (int j = 0; j < FN; ++j) frag_mma(fa[i], fb[j], acc[i][j]);
+    for (int ks = 0; ks < KS; ++ks) {
+      // DS operations retire in order: the MFMAs of k-step ks wait for its own FM + FN reads only
+      if (ks == KS - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((FM + FN) * (KS - 1 - ks)) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) frag_mma(fa[ks][i], fb[ks][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   TRACE(4);
@@ -298,13 +345,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
   TRACE(5);
 }
 
-template <int BM, int BN, int NSTAGE, int WGM, int WGN> static int launch_glds(const tfpp_conv_params& p, hipStream_t st) {
+template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1> static int launch_glds(const tfpp_conv_params& p, hipStream_t st) {
   const long M = (long)p.B * p.Hd * p.Wd;
   dim3 grid(cdiv(p.n_g, BN), cdiv(M, BM), p.G * (p.splitk > 1 ? p.splitk : 1));
-  const size_t lds = (size_t)NSTAGE * (BM + BN) * 64;
+  const size_t lds = (size_t)NSTAGE * (BM + BN) * 64 * KS;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -313,7 +360,7 @@ template <int BM, int BN, int NSTAGE, int WGM, int WGN> static int launch_glds(c
   static const int mm_env = [] { const char* e = std::getenv("TFPP_GLDS_M_MAJOR"); return e ? std::atoi(e) : -1; }();
   const long w_bytes = (long)p.n_g * p.R * p.S * p.ks_g * 2;
   const int m_major = mm_env >= 0 ? mm_env : (w_bytes <= (6l << 20) ? 1 : 0);
-  hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN>), grid, dim3(WGM * WGN * 64), lds, st, p, trace, m_major);
+  hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS>), grid, dim3(WGM * WGN * 64), lds, st, p, trace, m_major);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -348,6 +395,9 @@ int conv_gemm_glds(const tfpp_conv_params& p, hipStream_t st) {
       case 4: return launch_glds<128, 128, 3, 2, 4>(p, st);
       case 5: return launch_glds<128, 128, 2, 2, 4>(p, st);
       case 6: return launch_glds<128, 128, 4, 2, 2>(p, st);
+      case 10: return launch_glds<128, 128, 3, 2, 4, 2>(p, st);  // 64-deep stages, 3 x 32 KB
+      case 11: return launch_glds<128, 128, 2, 2, 4, 2>(p, st);  // 64-deep stages, 2 x 32 KB (two workgroups per CU)
+      case 12: return launch_glds<128, 128, 4, 2, 4, 2>(p, st);  // 64-deep stages, 4 x 32 KB
       default: return launch_glds<128, 128, 4, 2, 4>(p, st);  // 8 waves: 516 vs 317-390 TFLOP/s on 3840x6048x1512
     }
   }

@@ -30,9 +30,9 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 static __device__ __attribute__((aligned(16))) unsigned int tfpp_zero_page[4] = {0u, 0u, 0u, 0u};  // LDS-DMA cannot zero-fill
 
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u32x2_t lds_read_tr16_b64_asm(unsigned addr) {
+template <int OFF> __device__ __forceinline__ u32x2_t lds_read_tr16_b64_asm(unsigned addr) {  // OFF: 16-bit immediate byte offset
   u32x2_t v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
 
@@ -107,18 +107,32 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wg
   const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)smem;
 
   // this thread's chunks of every stage: DMA i of the workgroup fills bytes [i*NT*16, (i+1)*NT*16) of the stage half, thread tid the
-  // 16 bytes at slot q = i*NT + tid -> pixel row pk = q / CH, physical chunk cp = q % CH, logical chunk cp ^ swz(pk)
-  int a_pk[A_INST], a_n[A_INST];
-  bool a_ok[A_INST];
+  // 16 bytes at slot q = i*NT + tid -> pixel row pk = q / CH, physical chunk cp = q % CH, logical chunk cp ^ swz(pk).
+  // Addressing is incremental: every chunk keeps a running source pointer that advances by one stage (BKP pixels) per issue -- two
+  // VALU adds per DMA instead of a 64-bit multiply-add plus range checks (the first version spent ~130 VALU and ~150 SALU
+  // instructions per stage there, against 16 MFMAs: SQ_INSTS_VALU / SQ_INSTS_MFMA = 8.1).  Chunks outside the tile (channel >= n_g,
+  // column >= KK) point at the zero page with step 0; pixels past the end of the slice exist only in the last stage and are
+  // masked there.  3x3 / strided layers (no constant stride between stages) keep per-stage address generation, in 32-bit arithmetic.
+  const bool pointwise = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
+  const int hw = p.Hd * p.Wd;
+  const int npix = (int)(p_end - p_beg);             // pixels of this slice (> 0 when nst > 0)
+  const int tail = npix - (nst - 1) * BKP;           // valid pixel rows of the last stage (1 .. BKP)
+  int a_pk[A_INST];
+  const T* a_cur[A_INST];
+  long a_step[A_INST];
 #pragma unroll
   for (int i = 0; i < A_INST; ++i) {
     const int q = i * NT + tid;
     a_pk[i] = q / CH_A;
-    a_n[i] = bm0 + (((q % CH_A) ^ swz<TM>(a_pk[i])) * 8);  // dY channel of the chunk
-    a_ok[i] = a_n[i] < p.n_g;
+    const int n = bm0 + (((q % CH_A) ^ swz<TM>(a_pk[i])) * 8);  // dY channel of the chunk
+    const bool ok = n < p.n_g;
+    a_cur[i] = ok ? dy + (size_t)(p_beg + a_pk[i]) * p.dy_ld + n : zero;
+    a_step[i] = ok ? (long)BKP * p.dy_ld : 0;
   }
   int b_pk[B_INST], b_c[B_INST], b_r[B_INST], b_s[B_INST];
   bool b_ok[B_INST];
+  const T* b_cur[B_INST];
+  long b_step[B_INST];
 #pragma unroll
   for (int j = 0; j < B_INST; ++j) {
     const int q = j * NT + tid;
@@ -129,29 +143,35 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wg
     b_c[j] = kk - rs * p.ks_g;
     b_r[j] = rs / p.S;
     b_s[j] = rs - b_r[j] * p.S;
+    const bool lin = pointwise && b_ok[j];
+    b_cur[j] = lin ? x + (size_t)(p_beg + b_pk[j]) * p.x_ld + b_c[j] : zero;
+    b_step[j] = lin ? (long)BKP * p.x_ld : 0;
   }
-  const bool pointwise = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
-  const int hw = p.Hd * p.Wd;
 
-  auto issue = [&](int st) {  // LDS-DMA of pixel stage st into ring slot st % NSTAGE
+  auto issue = [&](int st) {  // LDS-DMA of pixel stage st into ring slot st % NSTAGE; called with st = 0, 1, 2, ... in order
     const unsigned stage = lds_base + (unsigned)((st % NSTAGE) * STAGE_BYTES);
-    const long pix0 = p_beg + (long)st * BKP;
+    const bool last = (st == nst - 1) && tail < BKP;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
-      const long pix = pix0 + a_pk[i];
-      const T* ga = (pix < p_end && a_ok[i]) ? dy + (size_t)pix * p.dy_ld + a_n[i] : zero;
+      const T* ga = a_cur[i];
+      if (last && a_pk[i] >= tail) ga = zero;
+      a_cur[i] += a_step[i];
       __builtin_amdgcn_global_load_lds((gbl_void_t*)ga, (lds_void_t*)(stage + (unsigned)((i * NWAVES + wave) * 1024)), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_INST; ++j) {
-      const long pix = pix0 + b_pk[j];
-      const T* gb = zero;
-      if (pix < p_end && b_ok[j]) {
-        if (pointwise) gb = x + (size_t)pix * p.x_ld + b_c[j];
-        else {
-          const int b = (int)(pix / hw), rem = (int)(pix - (long)b * hw), hd = rem / p.Wd, wd = rem - hd * p.Wd;
-          const int hs = hd * p.stride - p.pad + b_r[j], ws = wd * p.stride - p.pad + b_s[j];
-          if (hs >= 0 && hs < p.Hs && ws >= 0 && ws < p.Ws) gb = x + ((size_t)(b * p.Hs + hs) * p.Ws + ws) * p.x_ld + b_c[j];
+      const T* gb = b_cur[j];
+      if (pointwise) {
+        if (last && b_pk[j] >= tail) gb = zero;
+        b_cur[j] += b_step[j];
+      } else {
+        gb = zero;
+        const int pl = st * BKP + b_pk[j];  // pixel inside the slice
+        if (pl < npix && b_ok[j]) {
+          const unsigned pix = (unsigned)(p_beg + pl);  // P < 2^31 (checked by the dispatcher)
+          const unsigned b = pix / (unsigned)hw, rem = pix - b * (unsigned)hw, hd = rem / (unsigned)p.Wd, wd = rem - hd * (unsigned)p.Wd;
+          const int hs = (int)hd * p.stride - p.pad + b_r[j], ws = (int)wd * p.stride - p.pad + b_s[j];
+          if (hs >= 0 && hs < p.Hs && ws >= 0 && ws < p.Ws) gb = x + ((size_t)((int)b * p.Hs + hs) * p.Ws + ws) * p.x_ld + b_c[j];
         }
       }
       __builtin_amdgcn_global_load_lds((gbl_void_t*)gb, (lds_void_t*)(stage + (unsigned)(A_BYTES + (j * NWAVES + wave) * 1024)), 16, 0, 0);
@@ -198,19 +218,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wg
     // all transpose reads of the stage are issued up front (DS operations retire in order): the MFMAs of k-step ks start once its
     // own (FM + FN) * 2 reads have landed, while the reads of the later k-steps are still in flight
     u32x2_t lo[KS][FM + FN], hi[KS][FM + FN];
+    unsigned a_adr[FM], b_adr[FN];  // one VALU add per fragment; the k-step / second-read displacements are instruction immediates
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int i = 0; i < FM; ++i) a_adr[i] = stage + a_off[i];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) b_adr[j] = stage + b_off[j];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      lo[0][i] = lds_read_tr16_b64_asm<0>(a_adr[i]);
+      hi[0][i] = lds_read_tr16_b64_asm<4 * ROW_A>(a_adr[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      lo[0][FM + j] = lds_read_tr16_b64_asm<0>(b_adr[j]);
+      hi[0][FM + j] = lds_read_tr16_b64_asm<4 * ROW_B>(b_adr[j]);
+    }
+    if constexpr (KS == 2) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const unsigned a = stage + a_off[i] + (unsigned)(ks * 32 * ROW_A);
-        lo[ks][i] = lds_read_tr16_b64_asm(a);
-        hi[ks][i] = lds_read_tr16_b64_asm(a + 4 * ROW_A);
+        lo[1][i] = lds_read_tr16_b64_asm<32 * ROW_A>(a_adr[i]);
+        hi[1][i] = lds_read_tr16_b64_asm<36 * ROW_A>(a_adr[i]);
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const unsigned b = stage + b_off[j] + (unsigned)(ks * 32 * ROW_B);
-        lo[ks][FM + j] = lds_read_tr16_b64_asm(b);
-        hi[ks][FM + j] = lds_read_tr16_b64_asm(b + 4 * ROW_B);
+        lo[1][FM + j] = lds_read_tr16_b64_asm<32 * ROW_B>(b_adr[j]);
+        hi[1][FM + j] = lds_read_tr16_b64_asm<36 * ROW_B>(b_adr[j]);
       }
     }
 #pragma unroll

@@ -220,7 +220,7 @@ def _check_train_step_vs_golden(bs, fname, tag):
   m = _model().train()
   names, vals, eng = _engine_train_step(m, bs)
   gl = dict(zip([str(x) for x in g['loss_names']], g['losses']))
-  errs = {n: abs(v - gl[n]) / abs(gl[n]) for n, v in zip(names, vals)}
+  errs = {n: float(abs(v - gl[n]) / abs(gl[n])) for n, v in zip(names, vals)}
   worst_norm, worst_elem = _compare_grads(eng, g)
   top = dict(sorted(worst_norm.items(), key=lambda kv: -kv[1])[:8])
   tope = dict(sorted(worst_elem.items(), key=lambda kv: -kv[1])[:8])
@@ -268,11 +268,11 @@ def test_train_step_bs12_bf16_vs_fp32_hip_and_golden():
   m16 = _model('bf16').train()
   names, v16, e16 = _engine_train_step(m16, 12)
   gl = dict(zip([str(x) for x in g['loss_names']], g['losses']))
-  lerr = {n: abs(v - gl[n]) / abs(gl[n]) for n, v in zip(names, v16)}
+  lerr = {n: float(abs(v - gl[n]) / abs(gl[n])) for n, v in zip(names, v16)}
   big = max(ref.values())
   nerr = {n: abs(e16.grads[n].detach().double().norm().item() - r) / r for n, r in ref.items() if r >= 1e-3 * big}
   top = dict(sorted(nerr.items(), key=lambda kv: -kv[1])[:8])
-  _report('train_bf16_bs12', {'losses_vs_reference': lerr, 'losses_vs_fp32_hip': {n: abs(a - b) / abs(b) for n, a, b in zip(names, v16, v32)},
+  _report('train_bf16_bs12', {'losses_vs_reference': lerr, 'losses_vs_fp32_hip': {n: float(abs(a - b) / abs(b)) for n, a, b in zip(names, v16, v32)},
                                'grad_norm_vs_fp32_hip_worst': top, 'tensors_compared': len(nerr)})
   assert np.isfinite(v16).all()
   assert max(lerr.values()) <= BF16_LOSS_TOL, lerr

@@ -32,6 +32,8 @@ def main():
   ap.add_argument('--iters', type=int, default=10)
   ap.add_argument('--only', default='')
   ap.add_argument('--wgrad', action='store_true')
+  ap.add_argument('--dgrad', action='store_true')
+  ap.add_argument('--eager', action='store_true', help='plain launches, no hipGraph (for rocprofv3 --pmc passes)')
   ap.add_argument('--shape', action='append', default=[], help='B,H,W,Cin,Cout,k,stride,G (repeatable; replaces the built-in list)')
   args = ap.parse_args()
   dev = 'cuda'
@@ -59,6 +61,15 @@ def main():
 
     run()
     torch.cuda.synchronize()
+    if args.eager:
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      for _ in range(args.iters):
+        run()
+      e1.record()
+      torch.cuda.synchronize()
+      print(f'eager {name:32s} {e0.elapsed_time(e1) / args.iters * 1e3:9.1f} us', flush=True)
+      continue
     # replay `iters` launches from a hipGraph: measures GPU time, not the Python launch rate
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
