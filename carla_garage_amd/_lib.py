@@ -14,7 +14,7 @@ ROOT = os.path.dirname(PKG_DIR)
 HEADER = os.path.join(ROOT, 'include', 'tfpp.h')
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libtfpp_hip.so')
-SOURCES = ['gemm_kernels.hip', 'gemm_glds.hip', 'gemm_wgrad_glds.hip', 'conv3x3_halo.hip', 'wgrad3x3_halo.hip', 'pointwise_kernels.hip', 'norm_kernels.hip', 'misc_kernels.hip', 'lidar_kernels.hip']
+SOURCES = ['gemm_kernels.hip', 'gemm_glds.hip', 'gemm_wgrad_glds.hip', 'attention_kernels.hip', 'conv3x3_halo.hip', 'wgrad3x3_halo.hip', 'pointwise_kernels.hip', 'norm_kernels.hip', 'misc_kernels.hip', 'lidar_kernels.hip']
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU, ACT_TANH = 0, 1, 2, 3, 4
@@ -43,6 +43,12 @@ class BgemmParams(ctypes.Structure):
               ('ldb', i64), ('ldc', i64), ('a_bs0', i64), ('a_bs1', i64), ('b_bs0', i64), ('b_bs1', i64), ('c_bs0', i64),
               ('c_bs1', i64), ('batch0', i32), ('batch1', i32), ('a_km', i32), ('b_km', i32), ('act', i32), ('c_f32', i32),
               ('alpha', f32), ('beta', f32)]
+
+
+class AttnParams(ctypes.Structure):
+  _fields_ = [('q', vp), ('k', vp), ('v', vp), ('o', vp), ('lse', vp), ('d_o', vp), ('dq', vp), ('dk', vp), ('dv', vp), ('delta', vp),
+              ('debug_p', vp), ('B', i32), ('nh', i32), ('T', i32), ('d', i32), ('ld_q', i64), ('ld_kv', i64), ('ld_o', i64),
+              ('scale', f32), ('p_drop', f32), ('seed', ctypes.c_uint64), ('seed_offset', vp)]
 
 
 class PackDesc(ctypes.Structure):
@@ -199,9 +205,10 @@ class _Lib:
       self._fns[name] = fn
     sizes = (ctypes.c_int * 8)()
     n = self._dll.tfpp_struct_sizes(sizes, 8)
-    mine = [ctypes.sizeof(ConvParams), ctypes.sizeof(WgradParams), ctypes.sizeof(BgemmParams), ctypes.sizeof(PackDesc)]
-    if n != 4 or list(sizes[:4]) != mine:
-      raise TfppError(f'struct layout mismatch: library {list(sizes[:4])} vs ctypes {mine}')
+    mine = [ctypes.sizeof(ConvParams), ctypes.sizeof(WgradParams), ctypes.sizeof(BgemmParams), ctypes.sizeof(PackDesc),
+            ctypes.sizeof(AttnParams)]
+    if n != 5 or list(sizes[:5]) != mine:
+      raise TfppError(f'struct layout mismatch: library {list(sizes[:5])} vs ctypes {mine}')
     if self._dll.tfpp_version() != 1:
       raise TfppError('ABI version mismatch')
     got = ctypes.c_uint64(0)

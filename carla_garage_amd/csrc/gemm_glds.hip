@@ -395,9 +395,8 @@ int conv_gemm_glds(const tfpp_conv_params& p, hipStream_t st) {
       case 4: return launch_glds<128, 128, 3, 2, 4>(p, st);
       case 5: return launch_glds<128, 128, 2, 2, 4>(p, st);
       case 6: return launch_glds<128, 128, 4, 2, 2>(p, st);
-      case 10: return launch_glds<128, 128, 3, 2, 4, 2>(p, st);  // 64-deep stages, 3 x 32 KB
-      case 11: return launch_glds<128, 128, 2, 2, 4, 2>(p, st);  // 64-deep stages, 2 x 32 KB (two workgroups per CU)
-      case 12: return launch_glds<128, 128, 4, 2, 4, 2>(p, st);  // 64-deep stages, 4 x 32 KB
+      case 10: return launch_glds<128, 128, 3, 2, 4, 2>(p, st);  // 64-deep stages (two k-steps per barrier), 3 x 32 KB: measured SLOWER
+                                                                 // (455 vs 498 TFLOP/s on 3840x6048x1512, 320 vs 389 on 12288x576x576)
       default: return launch_glds<128, 128, 4, 2, 4>(p, st);  // 8 waves: 516 vs 317-390 TFLOP/s on 3840x6048x1512
     }
   }

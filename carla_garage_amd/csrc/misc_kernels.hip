@@ -403,12 +403,13 @@ extern "C" int tfpp_source_hash(uint64_t* out) {
 }
 
 extern "C" int tfpp_struct_sizes(int* out, int n) {
-  if (!out || n < 4) return TFPP_EINVAL;
+  if (!out || n < 5) return TFPP_EINVAL;
   out[0] = (int)sizeof(tfpp_conv_params);
   out[1] = (int)sizeof(tfpp_wgrad_params);
   out[2] = (int)sizeof(tfpp_bgemm_params);
   out[3] = (int)sizeof(tfpp_pack_desc);
-  return 4;
+  out[4] = (int)sizeof(tfpp_attn_params);
+  return 5;
 }
 
 // *p += 1 : per-step counter added to every dropout seed (captured in the training-step hipGraph)

@@ -750,13 +750,21 @@ class Engine:
 
   def attention(self, q, k, v, B, nh, tq, tk, d, ld_q, ld_kv, scale, p_drop, out_ld):
     """Batched multi-head attention core on head-major slices.  q/k/v are views (with data_ptr offsets) into token
-    matrices with row strides ld_q / ld_kv; output [B, tq, nh*d(out_ld)]."""
+    matrices with row strides ld_q / ld_kv; output [B, tq, nh*d(out_ld)].  The fusion transformers (bf16, 320 tokens) run the
+    fused kernels of csrc/attention_kernels.hip: scores, softmax and dropout stay in registers, only the per-row log-sum-exp is
+    kept for backward.  The fp32 planning decoder (11 x 65 tokens) keeps batched GEMM + softmax."""
     dev, dt_ = q.device, q.dtype
+    p = p_drop if self.training else 0.0
+    seed = self.next_seed() if p > 0 else 0
+    geo = dict(B=B, nh=nh, T=tq, d=d, ld_q=ld_q, ld_kv=ld_kv, ld_o=out_ld, scale=scale)
+    if tq == tk and dt_ == torch.bfloat16 and ops.attn_supported(q, **geo):
+      O = torch.empty((B, tq, out_ld), device=dev, dtype=dt_)
+      lse = torch.empty(B * nh * tq, device=dev, dtype=F32) if self.tape is not None else None
+      ops.attn_fwd(q, k, v, O, lse, p_drop=p, seed=seed, **geo)
+      return O, ('fused', lse, O), None, (p, seed)
     S = torch.empty((B, nh, tq, tk), device=dev, dtype=dt_)
     ops.bgemm(q, k, S, M=tq, N=tk, K=d, lda=ld_q, ldb=ld_kv, ldc=tk, batch0=B, batch1=nh, a_bs=(tq * ld_q, d), b_bs=(tk * ld_kv, d),
               c_bs=(nh * tq * tk, tq * tk))
-    p = p_drop if self.training else 0.0
-    seed = self.next_seed() if p > 0 else 0
     P, Pd = ops.softmax_fwd(S, B * nh * tq, tk, tk, alpha=scale, p_drop=p, seed=seed)
     O = torch.empty((B, tq, out_ld), device=dev, dtype=dt_)
     ops.bgemm(Pd, v, O, M=tq, N=d, K=tk, lda=tk, ldb=ld_kv, ldc=out_ld, batch0=B, batch1=nh, a_bs=(nh * tq * tk, tq * tk),
@@ -767,6 +775,12 @@ class Engine:
     """Writes dq/dk/dv (views with the same strides as q/k/v)."""
     p, seed = drop
     dev, dt_ = dO.device, dO.dtype
+    if isinstance(P, tuple) and P[0] == 'fused':
+      _, lse, O = P
+      delta = torch.empty(B * nh * tq, device=dev, dtype=F32)
+      ops.attn_bwd(q, k, v, O, lse, dO, dq, dk, dv, delta, B=B, nh=nh, T=tq, d=d, ld_q=ld_q, ld_kv=ld_kv, ld_o=out_ld, scale=scale, p_drop=p,
+                   seed=seed)
+      return
     # dV = Pd^T dO
     ops.bgemm(Pd, dO, dv, M=tk, N=d, K=tq, lda=tk, ldb=out_ld, ldc=ld_kv, batch0=B, batch1=nh, a_bs=(nh * tq * tk, tq * tk),
               b_bs=(tq * out_ld, d), c_bs=(tk * ld_kv, d), a_km=True, b_km=True)

@@ -5,7 +5,7 @@ import ctypes
 
 import torch
 
-from ._lib import (lib, ConvParams, WgradParams, BgemmParams, PackDesc, F32, BF16, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU,
+from ._lib import (lib, ConvParams, WgradParams, BgemmParams, PackDesc, AttnParams, F32, BF16, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU,
                    ACT_TANH)
 
 import os as _os
@@ -194,6 +194,41 @@ def bgemm(A, B, C, *, M, N, K, lda, ldb, ldc, batch0=1, batch1=1, a_bs=(0, 0), b
     lib.profiler.tag(f'bgemm<{"f32" if A.dtype == torch.float32 else "bf16"}>', 2.0 * batch0 * batch1 * M * N * K)
   lib.tfpp_bgemm(ctypes.byref(p), dt(A), stream())
   return C
+
+
+# ------------------------------------------------------------------------------------------------ fused attention
+def _attn_params(q, k, v, o, lse, *, B, nh, T, d, ld_q, ld_kv, ld_o, scale, p_drop=0.0, seed=0, d_o=None, dq=None, dk=None, dv=None,
+                 delta=None, debug_p=None):
+  p = AttnParams()
+  p.q, p.k, p.v, p.o, p.lse = ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse)
+  p.d_o, p.dq, p.dk, p.dv, p.delta, p.debug_p = ptr(d_o), ptr(dq), ptr(dk), ptr(dv), ptr(delta), ptr(debug_p)
+  p.B, p.nh, p.T, p.d, p.ld_q, p.ld_kv, p.ld_o = B, nh, T, d, ld_q, ld_kv, ld_o
+  p.scale, p.p_drop, p.seed, p.seed_offset = scale, p_drop, seed, ptr(SEED_OFFSET)
+  return p
+
+
+def attn_supported(q, **kw):
+  """True when the fused attention kernels (csrc/attention_kernels.hip) handle this problem: bf16, T a multiple of 64 up to 320,
+  storage head dim a multiple of 8 up to 384.  Everything else (the fp32 11 x 65 planning decoder) keeps bgemm + softmax."""
+  if not q.is_cuda:
+    return False
+  p = _attn_params(q, q, q, q, None, **kw)
+  return bool(lib.raw('tfpp_attn_supported')(ctypes.byref(p), dt(q)))
+
+
+def attn_fwd(q, k, v, o, lse, debug_p=None, **kw):
+  p = _attn_params(q, k, v, o, lse, debug_p=debug_p, **kw)
+  if lib.profiler is not None:
+    lib.profiler.tag('attn_fwd<bf16,fused>', 4.0 * kw['B'] * kw['nh'] * kw['T'] * kw['T'] * kw['d'])
+  lib.tfpp_attn_fwd(ctypes.byref(p), dt(q), stream())
+  return o
+
+
+def attn_bwd(q, k, v, o, lse, d_o, dq, dk, dv, delta, **kw):
+  p = _attn_params(q, k, v, o, lse, d_o=d_o, dq=dq, dk=dk, dv=dv, delta=delta, **kw)
+  if lib.profiler is not None:
+    lib.profiler.tag('attn_bwd<bf16,fused>', 14.0 * kw['B'] * kw['nh'] * kw['T'] * kw['T'] * kw['d'])
+  lib.tfpp_attn_bwd(ctypes.byref(p), dt(q), stream())
 
 
 # ------------------------------------------------------------------------------------------------ packing

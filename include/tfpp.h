@@ -129,6 +129,32 @@ typedef struct {
 int tfpp_bgemm(const tfpp_bgemm_params* p, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Fused multi-head self-attention of the fusion transformers (team_code/transfuser.py:362-380: q k^T / sqrt(d) -> softmax ->
+ * attn_drop -> @ v), forward and backward, bf16.  q, k, v are head-major column slices of token matrices: element (b, t, h, e) at
+ * base + (b*T + t) * ld + h*d + e; o / d_o likewise with ld_o.  T a multiple of 64, <= 320; d (storage head dim, zero-padded) a
+ * multiple of 8, <= 384.  The scores stay in registers; the forward saves lse[b*nh*T] = log sum_j exp(scale * s_ij) and the
+ * backward recomputes the probabilities from it.  Dropout uses the hash, seed and element index (row * T + key) of
+ * tfpp_softmax_fwd, so fused and unfused paths draw the same masks.  delta: backward scratch [B*nh*T] floats.
+ * debug_p (nullable): the forward also writes the dropped-out probabilities [B*nh*T][T] fp32 (tests). */
+typedef struct {
+  const void* q; const void* k; const void* v;
+  void* o;              /* forward: output; backward: the saved forward output (read) */
+  float* lse;           /* forward: written; backward: read */
+  const void* d_o;      /* backward: gradient of o */
+  void* dq; void* dk; void* dv; /* backward outputs, strides of q / k / v */
+  float* delta;         /* backward scratch */
+  float* debug_p;
+  int B, nh, T, d;
+  int64_t ld_q, ld_kv, ld_o;
+  float scale, p_drop;
+  uint64_t seed;
+  const uint64_t* seed_offset;
+} tfpp_attn_params;
+int tfpp_attn_supported(const tfpp_attn_params* p, int dtype); /* 1 if the fused kernels handle (p, dtype) */
+int tfpp_attn_fwd(const tfpp_attn_params* p, int dtype, void* stream);
+int tfpp_attn_bwd(const tfpp_attn_params* p, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Weight packing (state_dict layout -> kernel layout, also casts fp32 -> dtype).
  * tfpp_pack_conv_weight: OIHW [Cout][cin_g][R][S] ->
  *     transpose=0 (forward)       [G][n_pad][(r*S+s)*ks_pad + c]      (zero rows n>=n_g, zero channels c>=cin_g)

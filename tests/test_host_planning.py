@@ -96,14 +96,17 @@ def test_stats_rows_are_the_tiles_of_the_selected_kernel(L):
 
 def test_weight_gradient_plan(L):
   v, s, r = wplan(L, wgrad(12, 16, 64, 576, 576))
-  assert v == 2 and s > 1 and s % 8 == 0 and r == 1                # LDS-DMA ring, whole XCD rounds of slices, slice sum follows
+  assert v == 4 and s > 1 and s % 8 == 0 and r == 1                # 8-wave 128x128 LDS-DMA ring (8 GFLOP), whole XCD rounds of slices, slice sum
+  v, s, r = wplan(L, wgrad(12, 16, 16, 576, 576))
+  assert v == 2 and s > 1 and r == 1                               # LiDAR branch (2 GFLOP): 64x64 tiles, more slices
+  assert wplan(L, wgrad(12, 32, 128, 216, 216))[0] == 2            # 216 channels fill 128-wide tiles to 71 % only: 64x64
   assert wplan(L, wgrad(12, 256, 1024, 32, 32, k=3))[0] == 3       # 3x3 halo
   assert wplan(L, wgrad(12, 16, 64, 576, 576, k=3, G=24))[0] == 3
   assert wplan(L, wgrad(12, 64, 64, 64, 64, k=3))[0] == 2          # 64-channel inputs on a small map: implicit GEMM wins
   assert wplan(L, wgrad(12, 64, 256, 72, 72), F32)[0] == 1         # fp32: LDS-staged 64x64
   assert wplan(L, wgrad(12, 128, 512, 8, 32, k=3, stride=2))[0] == 0  # stem: N <= 32, stride 2
   v, s, r = wplan(L, wgrad(3840, 1, 1, 1512, 6048))
-  assert v == 2 and s == 1 and r == 0                              # enough tiles: single slice, written straight into the gradient
+  assert v == 4 and s == 1 and r == 0                              # 576 tiles of 128x128: single slice, added straight into the gradient
   v, s, r = wplan(L, wgrad(12, 16, 64, 576, 576, ws=False))
   assert r == 0 and s >= 1                                         # no workspace: atomics, no second stage
   p = wgrad(12, 16, 64, 576, 576)

@@ -167,7 +167,8 @@ def test_conv_benchmark_shapes_on_the_benchmark_kernels(ops, entry):
 
 
 WGRAD_GLDS_VARIANTS = (2, 4)  # 2: 64x64 tiles, 4: 128x128 tiles (8 waves)
-WGRAD_EXPECT = {}
+WGRAD_EXPECT = {'fusion_mlp_fc1': (4, False, 0), 'fusion_mlp_fc2': (4, False, 0), 'fusion_proj': (4, False, 0), 's3_conv1x1': (4, True, 1),
+                's4_conv1x1': (4, False, 0)}  # (variant, pixel split?, second-stage sum)
 
 
 def test_conv_fused_bn_statistics_on_the_128x128_lds_dma_kernel(ops):
@@ -702,3 +703,107 @@ def test_bn1d_scalar(ops):
   check('bn1d.train', ops.bn1d_scalar(dev(x), rmd, rvd, nbt, True), want_tr, torch.float32)
   check('bn1d.rm', rmd.cpu(), rm2, torch.float32)
   check('bn1d.rv', rvd.cpu(), rv2, torch.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------- fused attention
+ATTN_DIMS = [(18, 24), (54, 56), (144, 144), (378, 384)]  # (real head dim, storage head dim) of the four fusion scales
+
+
+def _attn_problem(d_real, dp, B=2, nh=4, T=320, seed=0):
+  """qkv token matrix [B*T, 3*nh*dp] in the engine's layout (head-major, padding columns zero) + the fp32 reference tensors"""
+  g = torch.Generator().manual_seed(100 + dp + seed)
+  qkv = torch.zeros(B, T, 3, nh, dp)
+  qkv[..., :d_real] = torch.randn(B, T, 3, nh, d_real, generator=g)
+  qkv = qkv.to(torch.bfloat16).float()
+  q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).contiguous() for i in range(3))  # [B, nh, T, dp]
+  return qkv.reshape(B * T, 3 * nh * dp), q, k, v
+
+
+def _attn_views(qkv_d, nh, dp):
+  flat = qkv_d.view(-1)
+  return flat[0:], flat[nh * dp:], flat[2 * nh * dp:]
+
+
+@pytest.mark.parametrize('dims', ATTN_DIMS, ids=[f'd{a}' for a, _ in ATTN_DIMS])
+def test_fused_attention_forward_backward_vs_torch(ops, dims):
+  """tfpp_attn_fwd / tfpp_attn_bwd against softmax(q k^T / sqrt(d)) v and its autograd in fp32 on the CPU (bf16-rounded inputs),
+  without dropout.  S = 320 tokens, 4 heads, every head dim of the model."""
+  d_real, dp = dims
+  B, nh, T = 2, 4, 320
+  dtype = torch.bfloat16
+  qkv, q, k, v = _attn_problem(d_real, dp)
+  scale = 1.0 / math.sqrt(d_real)
+  qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+  P = F.softmax(qr @ kr.transpose(-1, -2) * scale, -1)
+  want = (P @ vr).permute(0, 2, 1, 3).reshape(B, T, nh * dp)  # [B, T, nh*dp]
+  qkv_d = dev(qkv, dtype)
+  qd, kd, vd = _attn_views(qkv_d, nh, dp)
+  geo = dict(B=B, nh=nh, T=T, d=dp, ld_q=3 * nh * dp, ld_kv=3 * nh * dp, ld_o=nh * dp, scale=scale)
+  assert ops.attn_supported(qd, **geo)
+  O = torch.empty((B, T, nh * dp), device=DEV, dtype=dtype)
+  lse = torch.empty(B * nh * T, device=DEV)
+  dbg = torch.empty((B * nh * T, T), device=DEV)
+  ops.attn_fwd(qd, kd, vd, O, lse, debug_p=dbg, **geo)
+  check(f'attn{d_real}.fwd', O, want, dtype)
+  check(f'attn{d_real}.p', dbg.view(B, nh, T, T), P, torch.float32, scale=50.0)  # exp of bf16-product scores: 1e-2 relative
+  want_lse = torch.logsumexp(q @ k.transpose(-1, -2) * scale, -1)
+  check(f'attn{d_real}.lse', lse.view(B, nh, T), want_lse, torch.float32, scale=50.0)
+  dO = rnd(B, T, nh * dp, dtype=dtype, seed=7)
+  want.backward(dO)
+  dqkv = torch.zeros_like(qkv_d)
+  dq, dk, dv = _attn_views(dqkv, nh, dp)
+  delta = torch.empty(B * nh * T, device=DEV)
+  ops.attn_bwd(qd, kd, vd, O, lse, dev(dO, dtype), dq, dk, dv, delta, **geo)
+  got = dqkv.float().cpu().view(B, T, 3, nh, dp)
+  for i, (name, ref) in enumerate((('dq', qr.grad), ('dk', kr.grad), ('dv', vr.grad))):
+    check(f'attn{d_real}.{name}', got[:, :, i].permute(0, 2, 1, 3), ref, dtype, scale=2.0)
+
+
+def test_fused_attention_dropout_matches_the_unfused_path(ops):
+  """With attention dropout the fused kernels draw the masks of tfpp_softmax_fwd (same hash, seed and element index): forward and
+  backward are compared with the bgemm -> softmax(+dropout) -> bgemm path on the same inputs, and the keep ratio is checked."""
+  d_real, dp = 54, 56
+  B, nh, T = 2, 4, 320
+  dtype = torch.bfloat16
+  qkv, q, k, v = _attn_problem(d_real, dp, seed=3)
+  scale, p_drop, seed = 1.0 / math.sqrt(d_real), 0.1, 4242
+  qkv_d = dev(qkv, dtype)
+  qd, kd, vd = _attn_views(qkv_d, nh, dp)
+  npk = 3 * nh * dp
+  geo = dict(B=B, nh=nh, T=T, d=dp, ld_q=npk, ld_kv=npk, ld_o=nh * dp, scale=scale)
+  O = torch.empty((B, T, nh * dp), device=DEV, dtype=dtype)
+  lse = torch.empty(B * nh * T, device=DEV)
+  dbg = torch.empty((B * nh * T, T), device=DEV)
+  ops.attn_fwd(qd, kd, vd, O, lse, debug_p=dbg, p_drop=p_drop, seed=seed, **geo)
+  keep = (dbg != 0).float().mean().item()
+  assert abs(keep - 0.9) < 0.01, keep
+  # unfused reference path (the round-1 implementation)
+  S = torch.empty((B, nh, T, T), device=DEV, dtype=dtype)
+  ops.bgemm(qd, kd, S, M=T, N=T, K=dp, lda=npk, ldb=npk, ldc=T, batch0=B, batch1=nh, a_bs=(T * npk, dp), b_bs=(T * npk, dp), c_bs=(nh * T * T, T * T))
+  P, Pd = ops.softmax_fwd(S, B * nh * T, T, T, alpha=scale, p_drop=p_drop, seed=seed)
+  assert torch.equal(Pd.float().view(-1, T) != 0, dbg != 0)  # identical masks
+  O2 = torch.empty_like(O)
+  ops.bgemm(Pd, vd, O2, M=T, N=dp, K=T, lda=T, ldb=npk, ldc=nh * dp, batch0=B, batch1=nh, a_bs=(nh * T * T, T * T), b_bs=(T * npk, dp),
+            c_bs=(T * nh * dp, dp), b_km=True)
+  check('attn_dropout.fwd', O, O2.float(), dtype, scale=2.0)
+  # backward against torch autograd with the mask the kernel drew
+  M = (dbg != 0).float().cpu().view(B, nh, T, T) / (1.0 - p_drop)
+  qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+  want = ((F.softmax(qr @ kr.transpose(-1, -2) * scale, -1) * M) @ vr).permute(0, 2, 1, 3).reshape(B, T, nh * dp)
+  dO = rnd(B, T, nh * dp, dtype=dtype, seed=9)
+  want.backward(dO)
+  dqkv = torch.zeros_like(qkv_d)
+  dq, dk, dv = _attn_views(dqkv, nh, dp)
+  delta = torch.empty(B * nh * T, device=DEV)
+  ops.attn_bwd(qd, kd, vd, O, lse, dev(dO, dtype), dq, dk, dv, delta, p_drop=p_drop, seed=seed, **geo)
+  got = dqkv.float().cpu().view(B, T, 3, nh, dp)
+  for i, (name, ref) in enumerate((('dq', qr.grad), ('dk', kr.grad), ('dv', vr.grad))):
+    check(f'attn_dropout.{name}', got[:, :, i].permute(0, 2, 1, 3), ref, dtype, scale=2.0)
+
+
+def test_fused_attention_rejects_what_it_does_not_cover(ops):
+  x = torch.zeros(4096, device=DEV, dtype=torch.bfloat16)
+  geo = dict(B=1, nh=8, T=11, d=32, ld_q=256, ld_kv=512, ld_o=256, scale=1.0)
+  assert not ops.attn_supported(x, **geo)                 # planning decoder: 11 queries
+  assert not ops.attn_supported(x.float(), **dict(geo, T=320))  # fp32
+  assert ops.attn_supported(x, **dict(geo, T=320))
