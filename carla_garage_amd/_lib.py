@@ -28,7 +28,8 @@ class ConvParams(ctypes.Structure):
               ('Ws', i32), ('Cs', i32), ('Hd', i32), ('Wd', i32), ('Cd', i32), ('R', i32), ('S', i32), ('stride', i32),
               ('pad', i32), ('G', i32), ('ks_g', i32), ('n_g', i32), ('mode', i32), ('act', i32), ('dst_nchw', i32),
               ('alpha', f32), ('src_ld', i64), ('dst_ld', i64), ('res_ld', i64), ('dst_f32', i32), ('stats_partial', vp), ('stats_rows', i32), ('splitk_ws', vp),
-              ('splitk_ws_floats', i64), ('splitk', i32)]
+              ('splitk_ws_floats', i64), ('splitk', i32), ('bns_y', vp), ('bns_x', vp), ('bns_mean', vp), ('bns_invstd', vp),
+              ('bns_partial', vp), ('bns_ld', i64), ('bns_relu', i32)]
 
 
 class WgradParams(ctypes.Structure):

@@ -116,13 +116,31 @@ __device__ __forceinline__ float attn_softmax(f32x4_t (&S)[ATT_KF], int nkf, flo
   return mx + __logf(sum);
 }
 
-// stage one 128-wide d chunk [dc, dc + 128) of a [T][*] token matrix (row stride ld) into the swizzled V image; chunks past d are zero
+// stage one 128-wide d chunk [dc, dc + 128) of a [T][*] token matrix (row stride ld) into the swizzled V image; chunks past d are zero.
+// The loads go out in batches of 10 per thread before the first LDS store (a load -> store -> load chain costs one L2 latency per
+// 16 bytes: the first version of this kernel spent most of its time here).
 __device__ __forceinline__ void stage_vimg(const bf16_t* __restrict__ vh, long ld, int T, int d, int dc, int cpr, unsigned char* vimg, int tid) {
-  const int total = T * cpr;  // cpr: 16-byte chunks per row actually used (2 per 16-wide output fragment)
-  for (int c = tid; c < total; c += 256) {
-    const int row = c / cpr, ch = c - row * cpr, d0 = dc + ch * 8;
-    const uint4 v = (d0 < d) ? *reinterpret_cast<const uint4*>(vh + (size_t)row * ld + d0) : make_uint4(0, 0, 0, 0);
-    *reinterpret_cast<uint4*>(vimg + vimg_off(row, ch)) = v;
+  const int total = T * cpr;  // cpr: 16-byte chunks per row actually used (2 per 16-wide output fragment; a power of two in this model)
+  const int sh = __builtin_ctz(cpr);
+  const bool pow2 = (cpr & (cpr - 1)) == 0;
+  constexpr int U = 10;
+  for (int c0 = tid; c0 < total; c0 += 256 * U) {
+    uint4 r[U];
+    int off[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * 256;
+      r[u] = make_uint4(0, 0, 0, 0);
+      off[u] = -1;
+      if (c < total) {
+        const int row = pow2 ? (c >> sh) : (c / cpr), ch = c - row * cpr, d0 = dc + ch * 8;
+        off[u] = vimg_off(row, ch);
+        if (d0 < d) r[u] = *reinterpret_cast<const uint4*>(vh + (size_t)row * ld + d0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (off[u] >= 0) *reinterpret_cast<uint4*>(vimg + off[u]) = r[u];
   }
 }
 

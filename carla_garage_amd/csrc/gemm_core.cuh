@@ -120,10 +120,75 @@ __device__ __forceinline__ bool epi_vec_ok(const tfpp_conv_params& p) {
 }
 template <int FN> struct EpiStrip { static constexpr int PITCH = FN * 16 + 4, FLOATS = 16 * PITCH; };
 
+// Fused BatchNorm-backward statistics (tfpp_conv_params.bns_*): in the vector epilogue a lane always finishes the SAME 8 channels
+// (chunk lane % (2 FN) of its wave's column strip), so it keeps the two sums of those channels in registers over all passes.
+template <int FN> struct BnsAcc {
+  float s0[8], s1[8], mu[8], is[8];
+  __device__ __forceinline__ void init(const tfpp_conv_params& p, int lane, int n_base, int g) {
+    constexpr int CH = FN * 2;
+    const int n = n_base + (lane % CH) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; }
+    if (p.bns_partial && n < p.n_g) {
+      const int ch = g * p.n_g + n;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { mu[e] = p.bns_mean[ch + e]; is[e] = p.bns_invstd[ch + e]; }
+    }
+  }
+  // values: the 8 finished results of pixel m (already rounded to bf16 and unpacked), channel ch
+  __device__ __forceinline__ void add(const tfpp_conv_params& p, const float* gv, long m, int ch) {
+    float xv[8], g[8];
+    load_vec<bf16_t>(reinterpret_cast<const bf16_t*>(p.bns_x) + (size_t)m * p.bns_ld + ch, xv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = gv[e];
+    if (p.bns_relu) {
+      float yv[8];
+      load_vec<bf16_t>(reinterpret_cast<const bf16_t*>(p.bns_y) + (size_t)m * p.bns_ld + ch, yv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s0[e] += g[e]; s1[e] += g[e] * (xv[e] - mu[e]) * is[e]; }
+  }
+  // Combine the lanes of a wave, then the WGM waves that share a column strip, and store row `mtile` of bns_partial.
+  // sm: WGM * WGN * 2 FN * 16 floats of LDS nobody else is using; contains a __syncthreads (call from uniform control flow).
+  template <int WGM, int WGN>
+  __device__ __forceinline__ void finish(const tfpp_conv_params& p, float* sm, int wm, int wn, int lane, int mtile, int n_base, int g) {
+    constexpr int CH = FN * 2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = CH; o < 64; o <<= 1) { s0[e] += __shfl_xor(s0[e], o, 64); s1[e] += __shfl_xor(s1[e], o, 64); }
+    }
+    if (lane < CH) {
+      float* d = sm + ((wm * WGN + wn) * CH + lane) * 16;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { d[e] = s0[e]; d[8 + e] = s1[e]; }
+    }
+    __syncthreads();
+    if (wm == 0 && lane < CH) {
+      const int n = n_base + lane * 8, ctot = p.G * p.n_g;
+      if (n < p.n_g) {
+        float a[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] = 0.f;
+        for (int w2 = 0; w2 < WGM; ++w2) {
+          const float* d = sm + ((w2 * WGN + wn) * CH + lane) * 16;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) a[e] += d[e];
+        }
+        float* row = p.bns_partial + (size_t)mtile * 2 * ctot + g * p.n_g + n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { row[e] = a[e]; row[ctot + e] = a[8 + e]; }
+      }
+    }
+  }
+};
+
 // one pass: rows m_pass .. m_pass + rows_valid - 1 (<= 16), columns n_base .. n_base + 16 FN - 1 of group g
 template <int FN>
 __device__ __forceinline__ void epi_pass_bf16(const tfpp_conv_params& p, const f32x4_t (&acc)[FN], float* strip, int lane, long m_pass,
-                                              int rows_valid, int n_base, int g) {
+                                              int rows_valid, int n_base, int g, BnsAcc<FN>* bns = nullptr) {
   constexpr int PITCH = EpiStrip<FN>::PITCH, CH = FN * 2, NCHUNK = 16 * CH;
   const int p16 = lane & 15, kg = lane >> 4;
 #pragma unroll
@@ -161,7 +226,13 @@ __device__ __forceinline__ void epi_pass_bf16(const tfpp_conv_params& p, const f
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
       }
-      store_vec<bf16_t>(reinterpret_cast<bf16_t*>(p.dst) + (size_t)m * p.dst_ld + ch, v);
+      const uint4 packed = pack16<bf16_t>(v);
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.dst) + (size_t)m * p.dst_ld + ch) = packed;
+      if (bns) {
+        float gv[8];
+        unpack16<bf16_t>(packed, gv);  // the rounded values: exactly what the BatchNorm backward reads back
+        bns->add(p, gv, m, ch);
+      }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip is rewritten by the next pass

@@ -154,10 +154,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
     if (epi_vec_ok(p)) {  // coalesced: 16-row passes through a per-wave LDS strip (see gemm_core.cuh)
       __syncthreads();
       float* strip = reinterpret_cast<float*>(smem_raw) + wave * EpiStrip<C::FN>::FLOATS;
+      BnsAcc<C::FN> bns;  // fused BatchNorm-backward statistics of the tensor whose gradient this launch completes (tfpp.h)
+      const bool do_bns = p.bns_partial != nullptr;  // workgroup-uniform
+      bns.init(p, lane, bn0 + wn * WN, g);
 #pragma unroll
       for (int i = 0; i < C::FM; ++i) {
         const int m_pass = bm0 + wm * WM + i * 16;
-        epi_pass_bf16<C::FN>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g);
+        epi_pass_bf16<C::FN>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g, do_bns ? &bns : nullptr);
+      }
+      if (do_bns) {
+        __syncthreads();  // the strips are dead
+        bns.template finish<C::WAVES_M, C::WAVES_N>(p, reinterpret_cast<float*>(smem_raw), wm, wn, lane, mtile, bn0 + wn * WN, g);
       }
       return;
     }
@@ -260,7 +267,7 @@ template <typename T> static int launch_splitk_epilogue(const tfpp_conv_params& 
 // K slices for a problem that yields `tiles` output tiles with K stages of depth bk: only when the grid would leave most
 // of the chip idle (<= 192 workgroups) and every slice keeps >= 2 K stages.
 static int conv_splits(const tfpp_conv_params& p, long tiles, int bk) {
-  if (!p.splitk_ws || p.stats_partial || tiles > 192) return 1;
+  if (!p.splitk_ws || p.stats_partial || p.bns_partial || tiles > 192) return 1;
   const int K = p.R * p.S * p.ks_g, ntot = p.G * p.n_g;
   if (ntot % 4) return 1;
   long sp = (512 + tiles - 1) / tiles;
@@ -315,6 +322,20 @@ extern "C" int tfpp_conv_gemm_splits(const tfpp_conv_params* p, int dtype) {
   return conv_splits_for(*p, dtype);
 }
 
+// fused BatchNorm-backward statistics need the vector epilogue (bf16 NHWC destination, 8-channel granularity, aligned bases)
+static bool conv_bns_ok(const tfpp_conv_params& p, int dtype) {
+  if (dtype != TFPP_BF16 || p.dst_nchw || p.dst_f32 || ((p.n_g | (int)p.dst_ld | (int)p.bns_ld) & 7) || ((uintptr_t)p.dst & 15)) return false;
+  if (p.res && ((((int)p.res_ld) & 7) || ((uintptr_t)p.res & 15))) return false;
+  return true;
+}
+extern "C" int tfpp_conv_gemm_bns_ok(const tfpp_conv_params* p, int dtype) {
+  if (!p) return TFPP_EINVAL;
+  tfpp_conv_params q = *p;
+  q.bns_partial = reinterpret_cast<float*>(16);  // plan as if the feature were on (it disables split-K)
+  if (q.bns_ld == 0) q.bns_ld = q.dst_ld;
+  return conv_bns_ok(q, dtype) ? 1 : 0;
+}
+
 // exact number of M-tiles (= distinct stats_partial rows) of the kernel the dispatcher runs for (p, dtype)
 extern "C" int tfpp_conv_gemm_stats_rows(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
@@ -331,6 +352,8 @@ template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStr
   if (((uintptr_t)p.src & 15) || ((uintptr_t)p.w & 15)) return TFPP_EINVAL;
   const long M = (long)p.B * p.Hd * p.Wd;
   if (M >= (1l << 31) || M * (long)p.dst_ld >= (1l << 40)) return TFPP_EINVAL;
+  if (p.bns_partial && (!conv_bns_ok(p, ElemTraits<T>::DT) || !p.bns_x || !p.bns_mean || !p.bns_invstd || (p.bns_relu && !p.bns_y)))
+    return TFPP_EINVAL;  // the caller asks tfpp_conv_gemm_bns_ok first
   if (conv_halo_supported(p, ElemTraits<T>::DT)) return conv_gemm_halo(p, st);
   tfpp_conv_params q = p;
   q.splitk = conv_splits_for(p, ElemTraits<T>::DT);

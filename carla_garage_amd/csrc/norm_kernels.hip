@@ -377,6 +377,110 @@ extern "C" int tfpp_bn_bwd_apply(const void* dy, const void* y, const void* x, c
   return 0;
 }
 
+extern "C" int tfpp_bn_bwd_apply_rows(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
+                                      const float* save_invstd, float* partial, int nrows, float* coef, void* dx, void* dres,
+                                      float* dgamma, float* dbeta, int64_t rows, int C, int relu_mask, int dtype, void* stream) {
+  if (!dy || !x || !dx || !partial || nrows < 1 || !coef || !save_mean || !save_invstd || (relu_mask && !y)) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int VEC = dtype == TFPP_F32 ? 4 : 8;
+  if (C % VEC) return TFPP_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, nrows, (double*)nullptr, gamma, save_mean, save_invstd, coef,
+                     dgamma, dbeta, (long)rows, C);
+  if (dtype == TFPP_F32) launch_bn_bwd_apply<float>(dy, y, x, coef, dx, dres, (long)rows, C, relu_mask, st);
+  else launch_bn_bwd_apply<bf16_t>(dy, y, x, coef, dx, dres, (long)rows, C, relu_mask, st);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// squeeze-excite backward apply with the BatchNorm-backward statistics of the layer in front of it fused in (conv2 of a RegNet
+// bottleneck: dx is the complete gradient of a2 = relu(BN2(raw2))):  dx = dy * gate[b,c] + dpool[b,c] / HW, and per workgroup
+// one row of  sum g, sum g * xhat  with g = dx (rounded) * (a2 > 0).  Column-fixed layout, one grid z-slice per sample so that
+// the gate stays in registers; rows of partial: b * gridDim.x + blockIdx.x.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void se_bwd_apply_bns_kernel(const T* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dpool,
+                                        const T* __restrict__ y, const T* __restrict__ x, const float* __restrict__ mean,
+                                        const float* __restrict__ invstd, T* __restrict__ dx, float* __restrict__ partial, long HW, int C, int sw,
+                                        int rp) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int CV = C / VEC;
+  int rr, cv;
+  const bool active = col_thread(sw, rp, CV, rr, cv);
+  const int b = blockIdx.z;
+  float acc[2 * VEC];
+#pragma unroll
+  for (int e = 0; e < 2 * VEC; ++e) acc[e] = 0.f;
+  if (active) {
+    const int c0 = cv * VEC;
+    float gt[VEC], dp[VEC], mu[VEC], is[VEC];
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      gt[e] = gate[(size_t)b * C + c0 + e];
+      dp[e] = dpool[(size_t)b * C + c0 + e] * inv;
+      mu[e] = mean[c0 + e];
+      is[e] = invstd[c0 + e];
+    }
+    const long stride = (long)gridDim.x * rp;
+    for (long r = (long)blockIdx.x * rp + rr; r < HW; r += stride) {
+      const size_t off = ((size_t)b * HW + r) * C + c0;
+      float v[VEC], yv[VEC], xv[VEC];
+      load_vec<T>(dy + off, v);
+      load_vec<T>(y + off, yv);
+      load_vec<T>(x + off, xv);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = v[e] * gt[e] + dp[e];
+      const uint4 packed = pack16<T>(v);
+      *reinterpret_cast<uint4*>(dx + off) = packed;
+      unpack16<T>(packed, v);  // the rounded values the BatchNorm backward reads back
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float g = yv[e] > 0.f ? v[e] : 0.f;
+        acc[e] += g;
+        acc[VEC + e] += g * (xv[e] - mu[e]) * is[e];
+      }
+    }
+  }
+  __shared__ float sm[2 * VEC * 256];
+  col_block_reduce<2 * VEC>(acc, sw, rp, rr, sm);
+  if (active && rr == 0) {
+    float* out = partial + ((size_t)b * gridDim.x + blockIdx.x) * 2 * C;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      out[cv * VEC + e] = acc[e];
+      out[C + cv * VEC + e] = acc[VEC + e];
+    }
+  }
+}
+
+static inline int se_bns_blocks_x(int B, long HW, int CV) {
+  const ColLayout l = col_layout(CV);
+  return col_blocks_x(HW, l, 4, 2048, B);
+}
+extern "C" int tfpp_se_bwd_apply_bns_rows(int B, int HW, int C, int dtype) {
+  const int VEC = dtype == TFPP_F32 ? 4 : 8;
+  if (B < 1 || HW < 1 || C % VEC) return TFPP_EINVAL;
+  return B * se_bns_blocks_x(B, HW, C / VEC);
+}
+extern "C" int tfpp_se_bwd_apply_bns(const void* dy, const float* gate, const float* dpool, const void* y, const void* x, const float* save_mean,
+                                     const float* save_invstd, void* dx, float* partial, int B, int HW, int C, int dtype, void* stream) {
+  if (!dy || !gate || !dpool || !y || !x || !save_mean || !save_invstd || !dx || !partial) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int VEC = dtype == TFPP_F32 ? 4 : 8;
+  if (C % VEC) return TFPP_EINVAL;
+  const ColLayout l = col_layout(C / VEC);
+  dim3 grid((unsigned)se_bns_blocks_x(B, HW, C / VEC), (unsigned)l.ny, (unsigned)B);
+  if (dtype == TFPP_F32)
+    hipLaunchKernelGGL(se_bwd_apply_bns_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, gate, dpool, (const float*)y, (const float*)x, save_mean,
+                       save_invstd, (float*)dx, partial, (long)HW, C, l.sw, l.rp);
+  else
+    hipLaunchKernelGGL(se_bwd_apply_bns_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, gate, dpool, (const bf16_t*)y, (const bf16_t*)x,
+                       save_mean, save_invstd, (bf16_t*)dx, partial, (long)HW, C, l.sw, l.rp);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row kept in registers (C <= 64 * MAXV * VEC)
 // ---------------------------------------------------------------------------------------------------------------

@@ -45,16 +45,26 @@ def _release(tensors):
 
 
 class Lanes:
-  """HIP streams of the two encoder branches.  Lane 0 is the caller's stream (image branch, fusion transformers, heads), lane 1
-  a second stream for the LiDAR branch: its kernels (a quarter of the pixels: small, latency-bound launches) overlap with the
-  image branch between fusion points, in forward and -- through the lane tag on every tape node -- in backward.  Captured into
-  the hipGraphs as parallel branches.  TFPP_BRANCH_STREAMS=0 keeps everything on one stream."""
+  """HIP streams of the concurrent branches of the network.  Lane 0 is the caller's stream (image branch, fusion transformers,
+  perspective decoders); lane 1 carries the LiDAR branch between the fusion points (a quarter of the pixels: small, latency-bound
+  launches that overlap with the image branch) and afterwards the fp32 planning head.  Every tape node carries the lane it was
+  recorded on, so backward mirrors the split.  Captured into the hipGraphs as parallel branches.  TFPP_BRANCH_STREAMS=0 keeps
+  everything on one stream.  The class handles any number of lanes; a third one for the BEV pyramid + CenterNet / BEV-semantic
+  heads (TFPP_HEAD_LANE=1) works eagerly but hipStreamEndCapture of ROCm 7.0 segfaults on the resulting four-stream capture
+  (round 2, gpurun_out/r02_crash.log), so it is off by default and those layers stay on lane 0."""
 
   def __init__(self):
     self.enabled = os.environ.get('TFPP_BRANCH_STREAMS', '1') != '0'
-    self.main = self.branch = None
+    self.head_lane = 2 if (self.enabled and os.environ.get('TFPP_HEAD_LANE', '0') == '1') else 0
+    self.main = None
+    self.branches = {}    # lane -> torch.cuda.Stream (created on first use, kept for the life of the engine)
+    self.active = set()   # lanes forked since the last join
     self.cur = 0
     self.held = []
+
+  @property
+  def branch(self):  # lane 1 (kept for callers that only know the two-lane layout)
+    return self.branches.get(1)
 
   def hold(self, *tensors):
     """Keep tensors that cross lanes alive until the next pass begins: the caching allocator only orders reuse within
@@ -67,39 +77,53 @@ class Lanes:
     self.cur = 0
     _release(self.held)
     self.held = []
+    self.active = set()
     if not self.enabled or torch.device(device).type != 'cuda':
       self.main = None
       return
     self.main = torch.cuda.current_stream(device)
-    if self.branch is None:
-      self.branch = torch.cuda.Stream(device)
 
   def on(self):
     return self.main is not None
 
   def stream(self, k):
-    return self.main if k == 0 else self.branch
+    if k == 0:
+      return self.main
+    st = self.branches.get(k)
+    if st is None:
+      st = self.branches[k] = torch.cuda.Stream(self.main.device)
+    return st
+
+  def touch(self, k):
+    """Lane k is about to receive work: order it after everything issued so far on lane 0 the first time since the last join (a
+    stream that never waited on the capturing stream would not be part of a hipGraph capture)."""
+    if k != 0 and k not in self.active:
+      self.stream(k).wait_stream(self.main)
+      self.active.add(k)
 
   def streams(self):
-    return [self.main, self.branch] if self.on() else []
+    return [self.main] + [self.branches[k] for k in sorted(self.active)] if self.on() else []
 
   @contextlib.contextmanager
   def fork(self, k=1):
     """Run the body on lane k, ordered after everything issued so far on lane 0."""
-    if not self.on():
+    if not self.on() or k == 0:
       yield
       return
-    self.branch.wait_stream(self.main)
+    st = self.stream(k)
+    st.wait_stream(self.main)
+    self.active.add(k)
     prev, self.cur = self.cur, k
     try:
-      with torch.cuda.stream(self.branch):
+      with torch.cuda.stream(st):
         yield
     finally:
       self.cur = prev
 
   def join(self):
     if self.on():
-      self.main.wait_stream(self.branch)
+      for k in sorted(self.active):
+        self.main.wait_stream(self.branches[k])
 
 
 class Tape:
@@ -119,9 +143,23 @@ class Tape:
     self._rest = []
     self.split_index = None
     self.finalizers = []  # run once at the end of backward (joins side streams)
+    self.uses = {}        # key -> number of recorded nodes that consume the tensor (forward)
+    self.contrib = {}     # key -> gradient contributions received so far (backward)
+    self.on_accumulate = None  # callback(key): a gradient that was already handed out as "complete" received another addend
 
   def record(self, outs, ins, fn, lane=0):
     self.nodes.append((outs, ins, fn, lane))
+    for t in ins:
+      if t is not None:
+        k = _key(t)
+        self.uses[k] = self.uses.get(k, 0) + 1
+
+  def is_last_contribution(self, t):
+    """True while backward runs a node whose gradient for ``t`` is the last one ``t`` will receive: every other recorded consumer
+    has already contributed.  The producer of that last addend then owns the COMPLETE gradient (with take_pending folded into its
+    epilogue) and may compute reductions over it on the fly (fused BatchNorm-backward statistics)."""
+    k = _key(t)
+    return self.uses.get(k, 0) - self.contrib.get(k, 0) == 1
 
   def freeze(self, t):
     self.frozen[id(t)] = t
@@ -140,7 +178,7 @@ class Tape:
     if like is not None and (cur.dtype != like.dtype or cur.numel() != like.numel()):
       return None
     if self._multi and self._glane[k] != self._lane:
-      self.lanes.stream(self._lane).wait_stream(self.lanes.stream(self._glane[k]))
+      self._sync(self._lane, self._glane[k])
       self.lanes.hold(cur)
     del self._grads[k]
     self._glane.pop(k, None)
@@ -156,6 +194,7 @@ class Tape:
     joined, so every gradient those nodes produce is complete) and ``backward_resume()`` runs the rest -- the trainer all-reduces
     the finished part of the gradient arena while the second segment computes."""
     self._grads, self._refs, self._glane, self._lane = {}, {}, {}, 0
+    self.contrib = {}
     lanes = self.lanes
     if lanes is not None and seeds:
       lanes.begin(seeds[0][1].device)
@@ -179,10 +218,9 @@ class Tape:
       held, self.lanes.held = self.lanes.held, []  # keep-alives of the first segment survive until the end of the second
       self.lanes.begin(self.lanes.main.device)  # lane 0 = the stream current now (the same capture stream in a hipGraph)
       self.lanes.held = held
-      # fork lane 1 from lane 0 before anything runs on it: this segment may be the start of a new hipGraph capture, and a stream
-      # that has not yet waited on the capturing stream is not part of the capture (its kernels would run eagerly and be missing
-      # from the replay); the first lane-1 node of the segment can consume a gradient that was produced on lane 1 itself
-      self.lanes.branch.wait_stream(self.lanes.main)
+      # a branch lane is forked from lane 0 (Lanes.touch) before its first node of this segment runs: the segment may be the start
+      # of a new hipGraph capture, and a stream that has not yet waited on the capturing stream is not part of the capture (its
+      # kernels would run eagerly and be missing from the replay), even if the gradient it consumes was produced on that lane itself
     Tape.current = self
     rest, self._rest = self._rest, []
     self._run(rest)
@@ -191,6 +229,8 @@ class Tape:
 
   def _sync(self, to_lane, from_lane):
     if self._multi and to_lane != from_lane:
+      self.lanes.touch(to_lane)
+      self.lanes.touch(from_lane)  # a producer lane idle since the last join (second backward segment) joins this pass / capture first
       self.lanes.stream(to_lane).wait_stream(self.lanes.stream(from_lane))
 
   def _acc(self, t, g, lane):
@@ -198,7 +238,10 @@ class Tape:
       return
     grads, refs, glane = self._grads, self._refs, self._glane
     k = _key(t)
+    self.contrib[k] = self.contrib.get(k, 0) + 1
     cur = grads.get(k)
+    if cur is not None and self.on_accumulate is not None:
+      self.on_accumulate(k)
     if cur is None:
       grads[k] = g
       refs[id(g)] = refs.get(id(g), 0) + 1
@@ -232,6 +275,8 @@ class Tape:
         gouts.append(g)
       if all(g is None for g in gouts):
         continue
+      if multi and lane != 0:
+        lanes.touch(lane)
       ctx = torch.cuda.stream(lanes.stream(lane)) if multi and lane != 0 else contextlib.nullcontext()
       with ctx:
         self._lane = lane
@@ -319,6 +364,8 @@ class SideLane:
       self.keep = []
 
 
+FUSE_BN_BWD = os.environ.get('TFPP_FUSE_BN_BWD', '1') != '0'
+
 EARLY_GRAD_PREFIXES = ('backbone.image_encoder.s4', 'backbone.lidar_encoder.s4', 'backbone.transformers.3', 'backbone.lidar_channel_to_img.3',
                        'backbone.img_channel_to_lidar.3', 'backbone.c5_conv', 'backbone.up_conv')
 
@@ -373,6 +420,7 @@ class Engine:
     self.flat_grad = None
     self._consts = {}
     self._packed_key = None
+    self._bn_of, self._bn_pre = {}, {}  # per forward: key(y) -> (spec, raw, relu) of conv+BN layers / key(y) -> fused backward sums
     self._generation = 0
     self._plans, self._plan, self._plan_key = {}, None, None
     self.lanes = Lanes()
@@ -605,6 +653,25 @@ class Engine:
     n = self._gid.get(id(param))
     return None if n is None else self.grads[n]
 
+  # ------------------------------------------------------------------------------------------------ fused BatchNorm-backward sums
+  def _bns_request(self, x, query):
+    """Called by the backward of a node that is about to produce a gradient for ``x``.  When x is the output of a train-mode
+    conv + BatchNorm (+ ReLU) layer, this gradient is the last one x receives (Tape.is_last_contribution) and the producing kernel
+    supports it (``query()`` -> (ok, rows)), returns the descriptor that makes the kernel emit that layer's BatchNorm-backward
+    sums in its epilogue (tfpp_conv_params.bns_*) -- the layer's own backward then skips the reduction pass over dy, y and x."""
+    if not FUSE_BN_BWD or x.dtype != torch.bfloat16 or Tape.current is None:
+      return None
+    info = self._bn_of.get(_key(x))
+    if info is None or not Tape.current.is_last_contribution(x):
+      return None
+    ok, nrows = query()
+    if not ok:
+      return None
+    sL, rawL, relu = info
+    c = x.shape[-1]
+    return dict(y=x, x=rawL, mean=sL.save_mean, invstd=sL.save_invstd, relu=relu, nrows=nrows,
+                partial=torch.empty(nrows * 2 * c, device=x.device, dtype=F32))
+
   # ------------------------------------------------------------------------------------------------ primitives
   def rec(self, outs, ins, fn):
     if self.tape is not None:
@@ -638,6 +705,8 @@ class Engine:
                                s.bn.num_batches_tracked, s.scale, s.shift, s.save_mean, s.save_invstd, B * Ho * Wo,
                                s.bn.momentum, s.bn.eps)
       y = ops.affine_act(raw, scale=s.scale, shift=s.shift, res=res, act=act)
+      if self.tape is not None and act in (ACT_NONE, ACT_RELU):
+        self._bn_of[_key(y)] = (s, raw, act == ACT_RELU)  # lets the producer of d(y) fuse this layer's BatchNorm-backward sums
     if self.tape is not None:
 
       def bwd(dy):
@@ -657,8 +726,13 @@ class Engine:
             self.side.run(Tape.current, bias_grad, dz)
           dconv = dz
         elif bn_train:
-          dconv, dres = ops.bn_bwd(dy, y, raw, s.bn.weight.detach(), s.save_mean, s.save_invstd, None, self.g(s.bn.weight),
-                                   self.g(s.bn.bias), relu_mask=(act == ACT_RELU), want_dres=res is not None)
+          pre = self._bn_pre.pop(_key(y), None)
+          if pre is not None and pre[2] is dy:  # the kernel that wrote dy already reduced sum g / sum g*xhat per tile (one pass saved)
+            dconv, dres = ops.bn_bwd_rows(dy, y, raw, s.bn.weight.detach(), s.save_mean, s.save_invstd, pre[0], pre[1], self.g(s.bn.weight),
+                                          self.g(s.bn.bias), relu_mask=(act == ACT_RELU), want_dres=res is not None)
+          else:
+            dconv, dres = ops.bn_bwd(dy, y, raw, s.bn.weight.detach(), s.save_mean, s.save_invstd, None, self.g(s.bn.weight),
+                                     self.g(s.bn.bias), relu_mask=(act == ACT_RELU), want_dres=res is not None)
         gsrc = dconv if dconv.dtype == x.dtype else ops.cast(dconv, x.dtype)
         if s.weight.requires_grad:
           self.side.run(Tape.current, lambda: ops.conv_wgrad(
@@ -669,8 +743,12 @@ class Engine:
           dx = torch.empty((B, H, W, Cs), device=x.device, dtype=x.dtype)
           # a gradient already pending for x (the other path of a residual / FPN fan-out) is added in the GEMM epilogue
           pend = Tape.current.take_pending(x, dx) if os.environ.get('TFPP_FUSE_GRAD_ACC', '1') != '0' else None
-          ops.conv_gemm(gsrc, s.wt, dx, B=B, Hs=Ho, Ws=Wo, Cs=s.n_store, Hd=H, Wd=W, Cd=Cs, R=k, S=k, stride=st, pad=pd, G=G,
-                        ks_g=s.n_store // G, n_g=Cs // G, mode=1, res=pend)
+          dgeo = dict(B=B, Hs=Ho, Ws=Wo, Cs=s.n_store, Hd=H, Wd=W, Cd=Cs, R=k, S=k, stride=st, pad=pd, G=G, ks_g=s.n_store // G, n_g=Cs // G,
+                      mode=1, res=pend)
+          bns = self._bns_request(x, lambda: ops.conv_gemm(gsrc, s.wt, dx, bns_query=True, **dgeo))
+          ops.conv_gemm(gsrc, s.wt, dx, bns=bns, **dgeo)
+          if bns is not None:
+            self._bn_pre[_key(x)] = (bns['partial'], bns['nrows'], dx)
         return dx, dres
 
       self.rec([y], [x, res], bwd)
@@ -815,6 +893,13 @@ class Engine:
         dgate = ops.se_dgate(dy, x)
         dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
                                 self.g(se.fc2.weight), self.g(se.fc2.bias))
+        info = self._bn_of.get(_key(x)) if (FUSE_BN_BWD and x.dtype == torch.bfloat16) else None
+        if info is not None and info[2] and Tape.current.is_last_contribution(x):
+          # x = relu(BN(raw)) of conv2: this IS its complete gradient -> emit the BatchNorm-backward sums in the same pass
+          sL, rawL, _ = info
+          dx, partial, nrows = ops.se_bwd_apply_bns(dy, gate, dpool, x, rawL, sL.save_mean, sL.save_invstd)
+          self._bn_pre[_key(x)] = (partial, nrows, dx)
+          return dx
         return ops.se_bwd_apply(dy, gate, dpool)
 
       self.rec([y], [x], bwd)
@@ -1052,6 +1137,9 @@ class Engine:
     B = rgb.shape[0]
     bb = m.backbone
     out = {}
+    self._bn_of, self._bn_pre = {}, {}
+    if self.tape is not None:
+      self.tape.on_accumulate = lambda key: self._bn_pre.pop(key, None)  # a "complete" gradient got another addend: sums are stale
     self.lanes.begin(dev)
     if cfg.normalize_imagenet:
       mul = self._const('img_mul', lambda: torch.tensor([1.0 / (255.0 * s) for s in (0.229, 0.224, 0.225)]))
@@ -1085,15 +1173,31 @@ class Engine:
     lanes.join()
     out['image_feature_grid'], out['fused_features'] = xi, xl
 
-    # BEV feature pyramid (transfuser.py:131-137)
+    # BEV feature pyramid (transfuser.py:131-137) with the CenterNet and BEV-semantic heads: 64 x 64 maps, ~25 small launches -> lane 2,
+    # beside the planning head (lane 1) and the full-resolution perspective decoders (lane 0)
     bev = None
-    if cfg.detect_boxes or cfg.use_bev_semantic:
-      p5 = self.conv(xl, 'backbone.c5_conv', act=ACT_RELU)
-      p4 = self.upsample(p5, p5.shape[1] * cfg.bev_upsample_factor, p5.shape[2] * cfg.bev_upsample_factor)
-      p4 = self.conv(p4, 'backbone.up_conv5', act=ACT_RELU)
-      p3 = self.upsample(p4, cfg.lidar_resolution_height // cfg.bev_down_sample_factor,
-                         cfg.lidar_resolution_width // cfg.bev_down_sample_factor)
-      bev = self.conv(p3, 'backbone.up_conv4', act=ACT_RELU)
+    out['pred_bev_semantic'] = None
+    out['bb'] = None
+    lanes.hold(xl)
+    with lanes.fork(lanes.head_lane):
+      if cfg.detect_boxes or cfg.use_bev_semantic:
+        p5 = self.conv(xl, 'backbone.c5_conv', act=ACT_RELU)
+        p4 = self.upsample(p5, p5.shape[1] * cfg.bev_upsample_factor, p5.shape[2] * cfg.bev_upsample_factor)
+        p4 = self.conv(p4, 'backbone.up_conv5', act=ACT_RELU)
+        p3 = self.upsample(p4, cfg.lidar_resolution_height // cfg.bev_down_sample_factor,
+                           cfg.lidar_resolution_width // cfg.bev_down_sample_factor)
+        bev = self.conv(p3, 'backbone.up_conv4', act=ACT_RELU)
+      if cfg.use_bev_semantic:
+        y = self.conv(bev, 'bev_semantic_decoder.0', act=ACT_RELU)
+        y = self.conv(y, 'bev_semantic_decoder.2')
+        mask = m.valid_bev_pixels.detach().view(-1)
+        out['pred_bev_semantic'] = self.upsample(y, cfg.lidar_resolution_height, cfg.lidar_resolution_width, mul=mask)
+      if cfg.detect_boxes:
+        bbs = []
+        for br in m.head.BRANCHES:
+          h = self.conv(bev, f'head.{br}_head.0', act=ACT_RELU)
+          bbs.append(self.conv(h, f'head.{br}_head.2', act=ACT_SIGMOID if br == 'heatmap' else ACT_NONE))
+        out['bb'] = bbs
     out['bev'] = bev
 
     # planning head, fp32 (model.py:299-358)
@@ -1174,19 +1278,6 @@ class Engine:
     # auxiliary dense heads
     out['pred_semantic'] = self.perspective_decoder(xi, 'semantic_decoder') if cfg.use_semantic else None
     out['pred_depth'] = self.activation(self.perspective_decoder(xi, 'depth_decoder'), ACT_SIGMOID) if cfg.use_depth else None
-    out['pred_bev_semantic'] = None
-    if cfg.use_bev_semantic:
-      y = self.conv(bev, 'bev_semantic_decoder.0', act=ACT_RELU)
-      y = self.conv(y, 'bev_semantic_decoder.2')
-      mask = m.valid_bev_pixels.detach().view(-1)
-      out['pred_bev_semantic'] = self.upsample(y, cfg.lidar_resolution_height, cfg.lidar_resolution_width, mul=mask)
-    out['bb'] = None
-    if cfg.detect_boxes:
-      bbs = []
-      for br in m.head.BRANCHES:
-        h = self.conv(bev, f'head.{br}_head.0', act=ACT_RELU)
-        bbs.append(self.conv(h, f'head.{br}_head.2', act=ACT_SIGMOID if br == 'heatmap' else ACT_NONE))
-      out['bb'] = bbs
     self.lanes.join()
     return out
 

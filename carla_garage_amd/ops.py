@@ -72,7 +72,7 @@ def splitk_workspace(device):
 
 def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=0, G=1, ks_g=None, n_g=None, mode=0,
               act=ACT_NONE, scale=None, shift=None, res=None, alpha=1.0, dst_nchw=False, src_ld=None, dst_ld=None,
-              res_ld=None, stats_ws=None, stats_acc=None, plan_only=False):
+              res_ld=None, stats_ws=None, stats_acc=None, plan_only=False, bns=None, bns_query=False):
   """stats_ws (double[2*Cd]): also produce per-channel sum / sum of squares of the result (fused BatchNorm statistics).
   stats_acc (True, or zeroed fp32 accumulation rows from stats_rows_buffer()): leave the statistics in the rows for
   bn_finalize_partials and return (number of rows used, rows buffer)."""
@@ -90,6 +90,12 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
   p.dst_f32 = int(dst.dtype == torch.float32 and src.dtype != torch.float32)
   ws = splitk_workspace(src.device)
   p.splitk_ws, p.splitk_ws_floats, p.splitk = ptr(ws), ws.numel(), 0
+  if bns_query:  # (can the kernel that runs here emit the fused BatchNorm-backward statistics?, rows of bns_partial it would write)
+    p.bns_ld = Cd
+    return bool(lib.raw('tfpp_conv_gemm_bns_ok')(ctypes.byref(p), dt(src))), lib.raw('tfpp_conv_gemm_stats_rows')(ctypes.byref(p), dt(src))
+  if bns is not None:  # fused BatchNorm-backward statistics of the tensor whose gradient this call completes (tfpp.h)
+    p.bns_y, p.bns_x, p.bns_mean, p.bns_invstd = ptr(bns['y']), ptr(bns['x']), ptr(bns['mean']), ptr(bns['invstd'])
+    p.bns_partial, p.bns_ld, p.bns_relu = ptr(bns['partial']), Cd, int(bns['relu'])
   if plan_only:  # (kernel variant, K slices) the dispatcher would use -- tests / bench bookkeeping
     return lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p), dt(src)), lib.raw('tfpp_conv_gemm_splits')(ctypes.byref(p), dt(src))
   scratch = None
@@ -450,6 +456,18 @@ def bn_bwd(dy, y, x, gamma, save_mean, save_invstd, ws, dgamma, dbeta, relu_mask
   return dx, dres
 
 
+def bn_bwd_rows(dy, y, x, gamma, save_mean, save_invstd, partial, nrows, dgamma, dbeta, relu_mask, want_dres=False):
+  """bn_bwd with the stage-1 sums already produced by the kernel that wrote dy (conv_gemm(bns=...), se_bwd_apply_bns)."""
+  c = x.shape[-1]
+  rows = x.numel() // c
+  coef = torch.empty(3 * c, device=x.device, dtype=torch.float32)
+  dx = torch.empty_like(x)
+  dres = torch.empty_like(x) if want_dres else None
+  lib.tfpp_bn_bwd_apply_rows(ptr(_chk(dy)), ptr(y), ptr(_chk(x)), ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(partial), nrows, ptr(coef),
+                             ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), rows, c, int(relu_mask), dt(x), stream())
+  return dx, dres
+
+
 def bn1d_scalar(x, rm, rv, nbt, training, momentum=0.1, eps=1e-5):
   y = torch.empty_like(x)
   lib.tfpp_bn1d_scalar(ptr(_chk(x)), ptr(y), ptr(rm), ptr(rv), ptr(nbt), x.numel(), int(training), momentum, eps, stream())
@@ -495,6 +513,18 @@ def se_bwd_apply(dy, gate, dpool):
   dx = torch.empty_like(dy)
   lib.tfpp_se_bwd_apply(ptr(_chk(dy)), ptr(gate), ptr(dpool), ptr(dx), b, h * w, c, dt(dy), stream())
   return dx
+
+
+def se_bwd_apply_bns(dy, gate, dpool, y, x, save_mean, save_invstd):
+  """se_bwd_apply that also emits the BatchNorm-backward sums of the layer in front of the squeeze-excite block; returns
+  (dx, partial rows, number of rows)."""
+  b, h, w, c = dy.shape
+  nrows = lib.raw('tfpp_se_bwd_apply_bns_rows')(b, h * w, c, dt(dy))
+  partial = torch.empty(nrows * 2 * c, device=dy.device, dtype=torch.float32)
+  dx = torch.empty_like(dy)
+  lib.tfpp_se_bwd_apply_bns(ptr(_chk(dy)), ptr(gate), ptr(dpool), ptr(_chk(y)), ptr(_chk(x)), ptr(save_mean), ptr(save_invstd), ptr(dx), ptr(partial),
+                            b, h * w, c, dt(dy), stream())
+  return dx, partial, nrows
 
 
 # ------------------------------------------------------------------------------------------------ pooling / resampling

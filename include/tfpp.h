@@ -70,6 +70,19 @@ typedef struct {
                            tile and a second kernel sums the slices and applies the epilogue */
   int64_t splitk_ws_floats;
   int splitk;           /* must be 0 (set by the dispatcher on its own copy) */
+  /* Fused BatchNorm-backward statistics (mode 1, bf16 NHWC destination, no split-K: see tfpp_conv_gemm_bns_ok).  When this call
+   * produces the COMPLETE gradient g' of a tensor y = act(BN(x)) (the forward input of the convolution), the epilogue also emits,
+   * per M-tile t and destination channel c, the sums the BatchNorm backward needs:
+   *     g = g' * (y > 0 if bns_relu)        bns_partial[t][c] = sum g        bns_partial[t][Cd + c] = sum g * (x - mean[c]) * invstd[c]
+   * (plain stores, every cell written exactly once: deterministic, nothing to zero) -- tfpp_bn_bwd_apply_rows finishes the job and
+   * the separate read pass of tfpp_bn_bwd_reduce over g', y and x disappears.  g is taken after rounding to bf16, i.e. exactly the
+   * values tfpp_bn_bwd_apply_rows reads back. */
+  const void* bns_y;        /* nullable unless bns_relu: forward value of the tensor whose gradient is produced, [M][bns_ld] */
+  const void* bns_x;        /* the BatchNorm input (raw convolution output), [M][bns_ld] */
+  const float* bns_mean; const float* bns_invstd;
+  float* bns_partial;       /* nullable = feature off; [tfpp_conv_gemm_stats_rows()][2*Cd] */
+  int64_t bns_ld;
+  int bns_relu;
 } tfpp_conv_params;
 /* number of K slices the dispatcher would use for p (1 = no split) */
 int tfpp_conv_gemm_splits(const tfpp_conv_params* p, int dtype);
@@ -244,6 +257,11 @@ int tfpp_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float
 int tfpp_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
                       const float* save_invstd, double* ws, float* scratch, void* dx, void* dres, float* dgamma, float* dbeta,
                       int64_t rows, int C, int relu_mask, int dtype, void* stream);
+/* bn_bwd_apply with the stage-1 sums supplied by the caller: `partial` = nrows rows of [2*C] (sum g, sum g*xhat), written by the
+ * fused epilogue of the producing kernel (tfpp_conv_params.bns_partial, tfpp_se_bwd_apply's bns variant); coef: 3*C floats scratch. */
+int tfpp_bn_bwd_apply_rows(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
+                           const float* save_invstd, float* partial, int nrows, float* coef, void* dx, void* dres, float* dgamma,
+                           float* dbeta, int64_t rows, int C, int relu_mask, int dtype, void* stream);
 /* BatchNorm1d(1, affine=False) on the ego speed (model.py:216,311), fp32 [B]. */
 int tfpp_bn1d_scalar(const float* x, float* y, float* running_mean, float* running_var, int64_t* nbt, int B, int training,
                      float momentum, float eps, void* stream);
@@ -264,6 +282,12 @@ int tfpp_se_gate_bwd(const float* dgate, const float* gate, const float* hidden,
                      const float* w2, float* dz1_scratch /* [B*RD] */, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
                      int B, int C, int RD, void* stream);
 int tfpp_se_bwd_apply(const void* dy, const float* gate, const float* dpool, void* dx, int B, int HW, int C, int dtype, void* stream);
+/* se_bwd_apply with the BatchNorm-backward statistics of the preceding layer fused in (conv2 of a RegNet bottleneck: dx is the
+ * complete gradient of y = relu(BN(x))): also writes tfpp_se_bwd_apply_bns_rows(B, HW, C, dtype) rows [2*C] of (sum g, sum g*xhat),
+ * g = dx * (y > 0), for tfpp_bn_bwd_apply_rows. */
+int tfpp_se_bwd_apply_bns_rows(int B, int HW, int C, int dtype);
+int tfpp_se_bwd_apply_bns(const void* dy, const float* gate, const float* dpool, const void* y, const void* x, const float* save_mean,
+                          const float* save_invstd, void* dx, float* partial, int B, int HW, int C, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Pooling / resampling: F.adaptive_avg_pool2d with uniform windows (transfuser.py:230-231) and F.interpolate
