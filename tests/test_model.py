@@ -280,6 +280,43 @@ def test_train_step_bs12_bf16_vs_fp32_hip_and_golden():
 
 
 @pytest.mark.gpu
+def test_fused_batchnorm_backward_sums_do_not_change_the_bf16_step():
+  """The BatchNorm-backward sums emitted by the epilogue of the kernel that completes d(y) (engine._bns_request) replace the separate
+  reduction pass: the bf16 step with the fusion must reproduce the step without it (same rounded gradients go into the sums, only
+  the summation order differs), and it must really be taken on most BatchNorm layers."""
+  from carla_garage_amd import engine as E
+  from carla_garage_amd import ops
+  out = {}
+  calls = {}
+  real_rows, real_full = ops.bn_bwd_rows, ops.bn_bwd
+  try:
+    for fused in (False, True):
+      E.FUSE_BN_BWD = fused
+      calls[fused] = [0, 0]
+
+      def count_rows(*a, _f=fused, **k):
+        calls[_f][0] += 1
+        return real_rows(*a, **k)
+
+      def count_full(*a, _f=fused, **k):
+        calls[_f][1] += 1
+        return real_full(*a, **k)
+
+      ops.bn_bwd_rows, ops.bn_bwd = count_rows, count_full
+      m = _model('bf16').train()
+      names, vals, eng = _engine_train_step(m, 4)
+      out[fused] = (vals, eng.flat_grad.detach().double().cpu().numpy().copy())
+  finally:
+    E.FUSE_BN_BWD = True
+    ops.bn_bwd_rows, ops.bn_bwd = real_rows, real_full
+  assert calls[False][0] == 0 and calls[True][0] >= 100, calls   # 136 BatchNorm layers; stage / fusion boundaries keep the reduce pass
+  lerr = float(np.max(np.abs(out[True][0] - out[False][0]) / np.abs(out[False][0])))
+  gerr = float(np.linalg.norm(out[True][1] - out[False][1]) / np.linalg.norm(out[False][1]))
+  _report('fused_bn_bwd', {'fused_layers': calls[True][0], 'unfused_layers': calls[True][1], 'loss_rel': lerr, 'grad_rel_l2': gerr})
+  assert lerr <= 1e-6 and gerr <= 2e-2, (lerr, gerr)
+
+
+@pytest.mark.gpu
 def test_eval_after_training_steps_uses_current_weights_and_running_statistics():
   """the fused optimizer and the BN running-statistic updates write through raw pointers, which tensor._version
   cannot see.  eval -> train steps -> eval must run on the updated weights and the re-folded running statistics: compared with a

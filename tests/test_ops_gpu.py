@@ -807,3 +807,77 @@ def test_fused_attention_rejects_what_it_does_not_cover(ops):
   assert not ops.attn_supported(x, **geo)                 # planning decoder: 11 queries
   assert not ops.attn_supported(x.float(), **dict(geo, T=320))  # fp32
   assert ops.attn_supported(x, **dict(geo, T=320))
+
+
+# ---------------------------------------------------------------------------------------------------------------- fused BN-backward sums
+BNS_CASES = [
+    # name, B, H, W, Cin (= channels of the gradient produced), Cout (= channels of the incoming gradient), k, stride, groups, expected dgrad variant
+    ('lds128x32', 4, 24, 40, 72, 72, 1, 1, 1, 0),        # stage-1 1x1 conv: LDS-staged 128x32 tiles, 3 column tiles
+    ('glds128', 12, 16, 64, 576, 576, 1, 1, 1, 200),     # stage-3 1x1 conv at bs = 12: 8-wave LDS-DMA kernel, M-major order
+    ('glds64', 4, 16, 16, 576, 576, 1, 1, 1, 201),       # LiDAR branch: 64x128 LDS-DMA tiles
+    ('halo', 2, 16, 64, 72, 72, 3, 1, 3, 302),           # grouped 3x3: halo kernel, one row per 8x32 tile
+    ('strided', 2, 16, 32, 48, 48, 3, 2, 2, 0),          # stride-2 grouped 3x3 (first block of a stage)
+]
+
+
+@pytest.mark.parametrize('case', BNS_CASES, ids=[c[0] for c in BNS_CASES])
+def test_dgrad_epilogue_emits_the_batchnorm_backward_sums(ops, case):
+  """tfpp_conv_params.bns_*: the data-gradient GEMM that completes d(y), y = relu(BN(x)), also writes per M-tile the sums
+  sum g and sum g * xhat (g = d(y) masked by y > 0).  Reference: torch on the CPU from the gradient tensor the kernel itself wrote."""
+  name, B, H, W, Cin, Cout, k, stride, G, variant = case
+  dtype = torch.bfloat16
+  pad = k // 2
+  Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+  dy = dev(nhwc(rnd(B, Cout, Ho, Wo, dtype=dtype, seed=1)), dtype)
+  w = (rnd(Cout, Cin // G, k, k, dtype=dtype, seed=2) * (1.0 / math.sqrt(Cin // G * k * k))).to(dtype).float()
+  wt = ops.pack_conv_weight(dev(w), dtype, G=G, transpose=True)
+  xraw = rnd(B, H, W, Cin, dtype=dtype, seed=3)                   # BN input of the layer whose output gradient is produced
+  mean, invstd = rnd(Cin, seed=4) * 0.3, rnd(Cin, seed=5, lo=0.5, hi=2.0)
+  y = torch.relu((xraw - mean) * invstd + rnd(Cin, seed=6) * 0.5).to(dtype).float()  # its forward value (any tensor with a zero pattern)
+  pend = rnd(B, H, W, Cin, dtype=dtype, seed=7)                   # pending residual gradient added in the epilogue
+  dx = torch.empty((B, H, W, Cin), device=DEV, dtype=dtype)
+  geo = dict(B=B, Hs=Ho, Ws=Wo, Cs=Cout, Hd=H, Wd=W, Cd=Cin, R=k, S=k, stride=stride, pad=pad, G=G, mode=1, res=dev(pend, dtype))
+  var, _ = ops.conv_gemm(dy, wt, dx, plan_only=True, **geo)
+  assert var == variant, var
+  ok, nrows = ops.conv_gemm(dy, wt, dx, bns_query=True, **geo)
+  assert ok and nrows > 0
+  partial = torch.full((nrows, 2, Cin), float('nan'), device=DEV)
+  ops.conv_gemm(dy, wt, dx, bns=dict(y=dev(y, dtype), x=dev(xraw, dtype), mean=dev(mean), invstd=dev(invstd), partial=partial, relu=True), **geo)
+  dx2 = torch.empty_like(dx)
+  ops.conv_gemm(dy, wt, dx2, **geo)
+  assert torch.equal(dx, dx2)  # the gradient itself is unchanged by the fused sums
+  g = dx.float().cpu() * (y > 0)
+  want0 = g.reshape(-1, Cin).double().sum(0)
+  want1 = (g * (xraw - mean) * invstd).reshape(-1, Cin).double().sum(0)
+  got = partial.double().sum(0).cpu()
+  assert torch.isfinite(partial).all()  # every (tile, channel) cell was written
+  scale = g.abs().reshape(-1, Cin).double().sum(0).max().item()
+  assert (got[0] - want0).abs().max().item() <= 1e-5 * scale, (got[0] - want0).abs().max().item() / scale
+  assert (got[1] - want1).abs().max().item() <= 3e-5 * scale * 2.0
+  # and the second half of the BatchNorm backward from those rows equals the unfused path
+  gamma = rnd(Cin, seed=8, lo=0.5, hi=1.5)
+  dg1, db1, dg2, db2 = (torch.zeros(Cin, device=DEV) for _ in range(4))
+  a, ares = ops.bn_bwd_rows(dx, dev(y, dtype), dev(xraw, dtype), dev(gamma), dev(mean), dev(invstd), partial.view(-1), nrows, dg1, db1, True, want_dres=True)
+  b, bres = ops.bn_bwd(dx, dev(y, dtype), dev(xraw, dtype), dev(gamma), dev(mean), dev(invstd), None, dg2, db2, relu_mask=True, want_dres=True)
+  check(name + '.bn_bwd_rows.dx', a, b.float(), dtype)
+  assert torch.equal(ares, bres)
+  check(name + '.bn_bwd_rows.dgamma', dg1, dg2, torch.float32, scale=5.0)
+  check(name + '.bn_bwd_rows.dbeta', db1, db2, torch.float32, scale=5.0)
+
+
+def test_se_bwd_apply_with_fused_batchnorm_backward_sums(ops):
+  dtype = torch.bfloat16
+  B, H, W, C = 3, 16, 20, 216
+  dy = dev(rnd(B, H, W, C, dtype=dtype, seed=1), dtype)
+  gate, dpool = dev(rnd(B, C, seed=2, lo=0.0, hi=1.0)), dev(rnd(B, C, seed=3))
+  xraw = rnd(B, H, W, C, dtype=dtype, seed=4)
+  mean, invstd = rnd(C, seed=5) * 0.3, rnd(C, seed=6, lo=0.5, hi=2.0)
+  y = torch.relu((xraw - mean) * invstd).to(dtype).float()
+  want_dx = ops.se_bwd_apply(dy, gate, dpool)
+  dx, partial, nrows = ops.se_bwd_apply_bns(dy, gate, dpool, dev(y, dtype), dev(xraw, dtype), dev(mean), dev(invstd))
+  assert torch.equal(dx, want_dx)
+  g = dx.float().cpu() * (y > 0)
+  got = partial.view(nrows, 2, C).double().sum(0).cpu()
+  scale = g.abs().reshape(-1, C).double().sum(0).max().item()
+  assert (got[0] - g.reshape(-1, C).double().sum(0)).abs().max().item() <= 1e-5 * scale
+  assert (got[1] - (g * (xraw - mean) * invstd).reshape(-1, C).double().sum(0)).abs().max().item() <= 6e-5 * scale
