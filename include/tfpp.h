@@ -95,6 +95,8 @@ int tfpp_conv_gemm_mtiles(const tfpp_conv_params* p);
 /* exact number of M-tiles of the kernel that runs for (p, dtype): with stats_rows = that, every (row, channel) cell of
  * stats_partial receives exactly one addend and the fused BatchNorm statistics are bit-reproducible */
 int tfpp_conv_gemm_stats_rows(const tfpp_conv_params* p, int dtype);
+/* 1 if the kernel the dispatcher runs for (p, dtype) supports the fused BatchNorm-backward statistics (bns_* fields) */
+int tfpp_conv_gemm_bns_ok(const tfpp_conv_params* p, int dtype);
 /* debugging aid (TFPP_GLDS_TRACE=1): per-workgroup phase timestamps of the last LDS-DMA GEMM launch; returns slots per workgroup */
 int tfpp_debug_glds_trace(uint64_t* out, int n_blocks);
 

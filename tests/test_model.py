@@ -63,6 +63,19 @@ def test_library_exports_every_declared_symbol():
   _lib.lib.load()  # raises if a declared symbol is missing or a struct mirror has the wrong size
 
 
+def test_every_library_call_of_the_host_code_is_declared_in_the_header():
+  """The ctypes binding is generated from include/tfpp.h: a call of an undeclared entry point would only fail on the GPU box."""
+  import glob
+  import re
+  decl = set(_lib.declared_functions())
+  used = set()
+  for path in glob.glob(os.path.join(os.path.dirname(_lib.__file__), '*.py')) + [os.path.join(_lib.ROOT, 'bench.py')]:
+    with open(path, encoding='utf-8') as f:
+      text = f.read()
+    used |= set(re.findall(r"lib\.(tfpp_\w+)\(", text)) | set(re.findall(r"raw\('(tfpp_\w+)'\)", text))
+  assert len(used) > 50 and not (used - decl), sorted(used - decl)
+
+
 def test_cpu_tensors_are_rejected_not_silently_computed(model_cpu):
   inp = P.make_inputs(1)
   with pytest.raises(RuntimeError):
