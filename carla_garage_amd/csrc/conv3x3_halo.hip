@@ -151,13 +151,20 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
   if (epi_vec_ok(p)) {  // coalesced 16-pixel passes through a per-wave LDS strip (staging buffers are dead)
     __syncthreads();
     float* strip = reinterpret_cast<float*>(smem) + wave * EpiStrip<FN>::FLOATS;
-    BnsAcc<FN> bns;  // fused BatchNorm-backward statistics (tfpp.h): one row of bns_partial per 8 x 32 pixel tile
+    BnsAcc<FN, FM> bns;  // fused BatchNorm-backward statistics (tfpp.h): one row of bns_partial per 8 x 32 pixel tile
     const bool do_bns = p.bns_partial != nullptr;  // workgroup-uniform
     bns.init(p, lane, 0, g);
+    if (do_bns) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int h = h0 + 2 * wave + (i >> 1), wc = w0 + (i & 1) * 16;
+        bns.prefetch(p, lane, i, (long)(b * H + h) * W + wc, h < H ? W - wc : 0, 0, g);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int h = h0 + 2 * wave + (i >> 1), wc = w0 + (i & 1) * 16;
-      epi_pass_bf16<FN>(p, acc[i], strip, lane, (long)(b * H + h) * W + wc, h < H ? W - wc : 0, 0, g, do_bns ? &bns : nullptr);
+      epi_pass_bf16<FN, FM>(p, acc[i], strip, lane, (long)(b * H + h) * W + wc, h < H ? W - wc : 0, 0, g, do_bns ? &bns : nullptr, i);
     }
     if (do_bns) {
       __syncthreads();  // the strips are dead

@@ -122,10 +122,13 @@ template <int FN> struct EpiStrip { static constexpr int PITCH = FN * 16 + 4, FL
 
 // Fused BatchNorm-backward statistics (tfpp_conv_params.bns_*): in the vector epilogue a lane always finishes the SAME 8 channels
 // (chunk lane % (2 FN) of its wave's column strip), so it keeps the two sums of those channels in registers over all passes.
-template <int FN> struct BnsAcc {
+// The y / x operands of every pass are fetched up front (prefetch()): issued back to back they cost one memory latency per
+// workgroup; loaded inside the passes they cost one per pass (the first version made the data-gradient GEMMs ~10 % slower).
+template <int FN, int FM> struct BnsAcc {
+  static constexpr int CH = FN * 2, NCHUNK = 16 * CH, CI = (NCHUNK + 63) / 64;
   float s0[8], s1[8], mu[8], is[8];
+  uint4 yq[FM][CI], xq[FM][CI];
   __device__ __forceinline__ void init(const tfpp_conv_params& p, int lane, int n_base, int g) {
-    constexpr int CH = FN * 2;
     const int n = n_base + (lane % CH) * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; }
@@ -135,15 +138,29 @@ template <int FN> struct BnsAcc {
       for (int e = 0; e < 8; ++e) { mu[e] = p.bns_mean[ch + e]; is[e] = p.bns_invstd[ch + e]; }
     }
   }
-  // values: the 8 finished results of pixel m (already rounded to bf16 and unpacked), channel ch
-  __device__ __forceinline__ void add(const tfpp_conv_params& p, const float* gv, long m, int ch) {
+  // operands of pass i (rows m_pass .. m_pass + rows_valid - 1): same lane -> (row, chunk) map as epi_pass_bf16
+  __device__ __forceinline__ void prefetch(const tfpp_conv_params& p, int lane, int i, long m_pass, int rows_valid, int n_base, int g) {
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const int q = lane + c * 64, row = q / CH, n = n_base + (q - row * CH) * 8;
+      yq[i][c] = make_uint4(0, 0, 0, 0);
+      xq[i][c] = make_uint4(0, 0, 0, 0);
+      if (q < NCHUNK && row < rows_valid && n < p.n_g) {
+        const size_t off = (size_t)(m_pass + row) * p.bns_ld + g * p.n_g + n;
+        xq[i][c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bns_x) + off);
+        if (p.bns_relu) yq[i][c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bns_y) + off);
+      }
+    }
+  }
+  // gv: the 8 finished results (already rounded to bf16 and unpacked) of chunk c of pass i
+  __device__ __forceinline__ void add(const tfpp_conv_params& p, const float* gv, int i, int c) {
     float xv[8], g[8];
-    load_vec<bf16_t>(reinterpret_cast<const bf16_t*>(p.bns_x) + (size_t)m * p.bns_ld + ch, xv);
+    unpack16<bf16_t>(xq[i][c], xv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) g[e] = gv[e];
     if (p.bns_relu) {
       float yv[8];
-      load_vec<bf16_t>(reinterpret_cast<const bf16_t*>(p.bns_y) + (size_t)m * p.bns_ld + ch, yv);
+      unpack16<bf16_t>(yq[i][c], yv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
     }
@@ -154,7 +171,6 @@ template <int FN> struct BnsAcc {
   // sm: WGM * WGN * 2 FN * 16 floats of LDS nobody else is using; contains a __syncthreads (call from uniform control flow).
   template <int WGM, int WGN>
   __device__ __forceinline__ void finish(const tfpp_conv_params& p, float* sm, int wm, int wn, int lane, int mtile, int n_base, int g) {
-    constexpr int CH = FN * 2;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -186,9 +202,9 @@ template <int FN> struct BnsAcc {
 };
 
 // one pass: rows m_pass .. m_pass + rows_valid - 1 (<= 16), columns n_base .. n_base + 16 FN - 1 of group g
-template <int FN>
+template <int FN, int FM = 1>
 __device__ __forceinline__ void epi_pass_bf16(const tfpp_conv_params& p, const f32x4_t (&acc)[FN], float* strip, int lane, long m_pass,
-                                              int rows_valid, int n_base, int g, BnsAcc<FN>* bns = nullptr) {
+                                              int rows_valid, int n_base, int g, BnsAcc<FN, FM>* bns = nullptr, int ipass = 0) {
   constexpr int PITCH = EpiStrip<FN>::PITCH, CH = FN * 2, NCHUNK = 16 * CH;
   const int p16 = lane & 15, kg = lane >> 4;
 #pragma unroll
@@ -231,7 +247,7 @@ __device__ __forceinline__ void epi_pass_bf16(const tfpp_conv_params& p, const f
       if (bns) {
         float gv[8];
         unpack16<bf16_t>(packed, gv);  // the rounded values: exactly what the BatchNorm backward reads back
-        bns->add(p, gv, m, ch);
+        bns->add(p, gv, ipass, c);
       }
     }
   }

@@ -308,13 +308,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
   if (epi_vec_ok(p)) {  // coalesced: 16-row passes through a per-wave LDS strip (the ring is free)
     __syncthreads();
     float* strip = reinterpret_cast<float*>(smem) + wave * EpiStrip<FN>::FLOATS;
-    BnsAcc<FN> bns;  // fused BatchNorm-backward statistics (tfpp.h)
+    BnsAcc<FN, FM> bns;  // fused BatchNorm-backward statistics (tfpp.h)
     const bool do_bns = p.bns_partial != nullptr;  // workgroup-uniform
     bns.init(p, lane, bn0 + wn * WN, g);
+    if (do_bns) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) bns.prefetch(p, lane, i, bm0 + wm * WM + i * 16, M - (bm0 + wm * WM + i * 16), bn0 + wn * WN, g);
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int m_pass = bm0 + wm * WM + i * 16;
-      epi_pass_bf16<FN>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g, do_bns ? &bns : nullptr);
+      epi_pass_bf16<FN, FM>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g, do_bns ? &bns : nullptr, i);
     }
     if (do_bns) {
       __syncthreads();  // the strips are dead

@@ -154,13 +154,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
     if (epi_vec_ok(p)) {  // coalesced: 16-row passes through a per-wave LDS strip (see gemm_core.cuh)
       __syncthreads();
       float* strip = reinterpret_cast<float*>(smem_raw) + wave * EpiStrip<C::FN>::FLOATS;
-      BnsAcc<C::FN> bns;  // fused BatchNorm-backward statistics of the tensor whose gradient this launch completes (tfpp.h)
+      BnsAcc<C::FN, C::FM> bns;  // fused BatchNorm-backward statistics of the tensor whose gradient this launch completes (tfpp.h)
       const bool do_bns = p.bns_partial != nullptr;  // workgroup-uniform
       bns.init(p, lane, bn0 + wn * WN, g);
+      if (do_bns) {
+#pragma unroll
+        for (int i = 0; i < C::FM; ++i) bns.prefetch(p, lane, i, bm0 + wm * WM + i * 16, M - (bm0 + wm * WM + i * 16), bn0 + wn * WN, g);
+      }
 #pragma unroll
       for (int i = 0; i < C::FM; ++i) {
         const int m_pass = bm0 + wm * WM + i * 16;
-        epi_pass_bf16<C::FN>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g, do_bns ? &bns : nullptr);
+        epi_pass_bf16<C::FN, C::FM>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g, do_bns ? &bns : nullptr, i);
       }
       if (do_bns) {
         __syncthreads();  // the strips are dead

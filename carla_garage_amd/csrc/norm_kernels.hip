@@ -282,14 +282,35 @@ extern "C" int tfpp_bn_fold(const float* gamma, const float* beta, const float* 
 
 // dx = gamma*invstd*(g - ws0/rows - xhat*ws1/rows) = A[c]*g + Bc[c]*x + D[c] ; dres = g.
 // coefficient kernel (per channel) also accumulates dgamma += ws1, dbeta += ws0.
+// WIDE = false: one wave per channel (few rows); WIDE = true: one 256-thread workgroup per channel (one row per M-tile of the kernel
+// that produced the gradient: up to a few thousand rows), combined through LDS in a fixed order.
+template <bool WIDE>
 __global__ void bn_bwd_coef_kernel(float* __restrict__ partial, int nrows, double* __restrict__ ws, const float* __restrict__ gamma,
                                    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ coef,
                                    float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int C) {
-  const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = WIDE ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
   double s0, s1;
-  partial_pair_sum(partial, nrows, C, c, lane, false, s0, s1);
-  if (lane != 0) return;
+  if (WIDE) {
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < nrows; k += 256) {
+      const float* row = partial + (size_t)k * 2 * C;
+      a += (double)row[c];
+      b += (double)row[C + c];
+    }
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
+    __shared__ double sm[2][4];
+    if (lane == 0) { sm[0][wave] = a; sm[1][wave] = b; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s0 = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
+    s1 = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+  } else {
+    if (c >= C) return;
+    partial_pair_sum(partial, nrows, C, c, lane, false, s0, s1);
+    if (lane != 0) return;
+  }
   const double n = (double)rows;
   const double gm = gamma ? (double)gamma[c] : 1.0, is = (double)invstd[c], mu = (double)mean[c];
   const double A = gm * is, Bc = -gm * is * is * s1 / n, D = -gm * is * s0 / n - Bc * mu;
@@ -369,7 +390,7 @@ extern "C" int tfpp_bn_bwd_apply(const void* dy, const void* y, const void* x, c
   const int VEC = dtype == TFPP_F32 ? 4 : 8;
   if (C % VEC) return TFPP_EINVAL;
   float* coef = scratch + (size_t)BN_MAX_PARTIALS * 2 * C;  // after the stage-1 partials
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 3) / 4), dim3(256), 0, st, scratch, bn_reduce_blocks((long)rows, C / VEC, 1), ws, gamma,
+  hipLaunchKernelGGL(bn_bwd_coef_kernel<false>, dim3((C + 3) / 4), dim3(256), 0, st, scratch, bn_reduce_blocks((long)rows, C / VEC, 1), ws, gamma,
                      save_mean, save_invstd, coef, dgamma, dbeta, (long)rows, C);
   if (dtype == TFPP_F32) launch_bn_bwd_apply<float>(dy, y, x, coef, dx, dres, (long)rows, C, relu_mask, st);
   else launch_bn_bwd_apply<bf16_t>(dy, y, x, coef, dx, dres, (long)rows, C, relu_mask, st);
@@ -384,8 +405,12 @@ extern "C" int tfpp_bn_bwd_apply_rows(const void* dy, const void* y, const void*
   hipStream_t st = (hipStream_t)stream;
   const int VEC = dtype == TFPP_F32 ? 4 : 8;
   if (C % VEC) return TFPP_EINVAL;
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, nrows, (double*)nullptr, gamma, save_mean, save_invstd, coef,
-                     dgamma, dbeta, (long)rows, C);
+  if (nrows > 256)
+    hipLaunchKernelGGL(bn_bwd_coef_kernel<true>, dim3(C), dim3(256), 0, st, partial, nrows, (double*)nullptr, gamma, save_mean, save_invstd, coef,
+                       dgamma, dbeta, (long)rows, C);
+  else
+    hipLaunchKernelGGL(bn_bwd_coef_kernel<false>, dim3((C + 3) / 4), dim3(256), 0, st, partial, nrows, (double*)nullptr, gamma, save_mean, save_invstd,
+                       coef, dgamma, dbeta, (long)rows, C);
   if (dtype == TFPP_F32) launch_bn_bwd_apply<float>(dy, y, x, coef, dx, dres, (long)rows, C, relu_mask, st);
   else launch_bn_bwd_apply<bf16_t>(dy, y, x, coef, dx, dres, (long)rows, C, relu_mask, st);
   TFPP_CHECK_LAUNCH();

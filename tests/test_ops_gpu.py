@@ -845,7 +845,10 @@ def test_dgrad_epilogue_emits_the_batchnorm_backward_sums(ops, case):
   ops.conv_gemm(dy, wt, dx, bns=dict(y=dev(y, dtype), x=dev(xraw, dtype), mean=dev(mean), invstd=dev(invstd), partial=partial, relu=True), **geo)
   dx2 = torch.empty_like(dx)
   ops.conv_gemm(dy, wt, dx2, **geo)
-  assert torch.equal(dx, dx2)  # the gradient itself is unchanged by the fused sums
+  if ops.conv_gemm(dy, wt, dx2, plan_only=True, **geo)[1] == 1:
+    assert torch.equal(dx, dx2)  # the gradient itself is unchanged by the fused sums
+  else:  # the plain call splits K (few tiles); the fused one cannot: same values up to the summation order
+    check(name + '.dx_vs_splitk', dx, dx2.float(), dtype)
   g = dx.float().cpu() * (y > 0)
   want0 = g.reshape(-1, Cin).double().sum(0)
   want1 = (g * (xraw - mean) * invstd).reshape(-1, Cin).double().sum(0)
