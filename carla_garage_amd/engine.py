@@ -364,7 +364,12 @@ class SideLane:
       self.keep = []
 
 
-FUSE_BN_BWD = os.environ.get('TFPP_FUSE_BN_BWD', '1') != '0'
+# BatchNorm-backward sums (sum g, sum g*xhat) produced by the kernel that completes the gradient instead of a separate reduction pass:
+#   0 off;  1 (default) only where the producer is the elementwise squeeze-excite backward (conv2 of every bottleneck: +0.3 ms in that
+#   kernel, -0.56 ms of tfpp_bn_bwd_reduce);  2 also in the epilogue of the data-gradient GEMMs -- correct (tests), but measured SLOWER
+#   at bs = 12: those GEMMs are short (K = 72 .. 576) and latency-bound, the extra y / x loads and the cross-lane reduction lengthen
+#   every workgroup: +6.2 ms of GEMM time against -2.2 ms of reduction passes (38.9 vs 35.8 ms/step, round 2, same box).
+FUSE_BN_BWD = int(os.environ.get('TFPP_FUSE_BN_BWD', '1'))
 
 EARLY_GRAD_PREFIXES = ('backbone.image_encoder.s4', 'backbone.lidar_encoder.s4', 'backbone.transformers.3', 'backbone.lidar_channel_to_img.3',
                        'backbone.img_channel_to_lidar.3', 'backbone.c5_conv', 'backbone.up_conv')
@@ -659,7 +664,7 @@ class Engine:
     conv + BatchNorm (+ ReLU) layer, this gradient is the last one x receives (Tape.is_last_contribution) and the producing kernel
     supports it (``query()`` -> (ok, rows)), returns the descriptor that makes the kernel emit that layer's BatchNorm-backward
     sums in its epilogue (tfpp_conv_params.bns_*) -- the layer's own backward then skips the reduction pass over dy, y and x."""
-    if not FUSE_BN_BWD or x.dtype != torch.bfloat16 or Tape.current is None:
+    if FUSE_BN_BWD < 2 or x.dtype != torch.bfloat16 or Tape.current is None:
       return None
     info = self._bn_of.get(_key(x))
     if info is None or not Tape.current.is_last_contribution(x):
@@ -893,7 +898,7 @@ class Engine:
         dgate = ops.se_dgate(dy, x)
         dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
                                 self.g(se.fc2.weight), self.g(se.fc2.bias))
-        info = self._bn_of.get(_key(x)) if (FUSE_BN_BWD and x.dtype == torch.bfloat16) else None
+        info = self._bn_of.get(_key(x)) if (FUSE_BN_BWD >= 1 and x.dtype == torch.bfloat16) else None
         if info is not None and info[2] and Tape.current.is_last_contribution(x):
           # x = relu(BN(raw)) of conv2: this IS its complete gradient -> emit the BatchNorm-backward sums in the same pass
           sL, rawL, _ = info
