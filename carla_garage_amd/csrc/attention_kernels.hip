@@ -26,7 +26,7 @@ constexpr int K_SLICE_BYTES = ATT_KF * 16 * 64;           // K image: [320 keys]
 constexpr int V_IMG_BYTES = ATT_KF * 16 * ATT_DC * 2;     // V image: [320 keys][128 d] bf16 = 80 KB
 constexpr int O_STRIP_BYTES = 16 * ATT_DC * 2;            // per wave: 16 queries x 128 d bf16 = 4 KB (aliases the K image)
 
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) { return f2bf_pack2(a, b); }
 
 // K image: 64-byte rows, chunk kc (16 B) of key row r at r * 64 + ((kc ^ (r & 3)) * 16): the 16 rows of a ds_read_b128 lane group
 // (4 rows per 256-byte bank row) land on distinct 16-byte slots
@@ -43,7 +43,7 @@ struct AttnGeo {
 template <int NKS>
 __device__ __forceinline__ void attn_scores(const bf16_t* __restrict__ qh, long ld_q, const bf16_t* __restrict__ kh, long ld_kv, int T, int d,
                                             int q_row, unsigned char* kimg, int tid, int lane, f32x4_t (&S)[ATT_KF]) {
-  const int nkf = T >> 4, p16 = lane & 15, kg = lane >> 4;
+  const int p16 = lane & 15, kg = lane >> 4;
   // this lane's Q operand (B fragment): 8 consecutive d of its query, one 16-byte load per k-step
   uint4 qf[NKS];
 #pragma unroll
@@ -53,36 +53,39 @@ __device__ __forceinline__ void attn_scores(const bf16_t* __restrict__ qh, long 
   }
 #pragma unroll
   for (int f = 0; f < ATT_KF; ++f) S[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  // K slice staging: T * 4 chunks of 16 bytes per k-step, 256 threads -> up to 5 chunks per thread, prefetched one k-step ahead
+  // K slice staging: T * 4 chunks of 16 bytes per k-step, 256 threads -> 5 chunks per thread, prefetched PF k-steps ahead (a k-step
+  // is only 20 MFMAs per wave: one L2 latency per k-step was the whole cost of this phase with a one-deep prefetch)
   constexpr int KIT = ATT_KF * 16 * 4 / 256;
-  uint4 kreg[KIT];
-  auto kload = [&](int ks) {
+  constexpr int PF = NKS < 3 ? NKS : 3;
+  uint4 kreg[PF][KIT];
+  auto kload = [&](int ks, uint4 (&dst)[KIT]) {
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
       const int c = tid + it * 256, row = c >> 2, kc = c & 3, d0 = ks * 32 + kc * 8;
-      kreg[it] = (row < T && d0 < d) ? *reinterpret_cast<const uint4*>(kh + (size_t)row * ld_kv + d0) : make_uint4(0, 0, 0, 0);
+      dst[it] = (row < T && d0 < d) ? *reinterpret_cast<const uint4*>(kh + (size_t)row * ld_kv + d0) : make_uint4(0, 0, 0, 0);
     }
   };
-  kload(0);
+#pragma unroll
+  for (int ks = 0; ks < PF; ++ks) kload(ks, kreg[ks]);
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     unsigned char* img = kimg + (ks & 1) * K_SLICE_BYTES;
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
       const int c = tid + it * 256, row = c >> 2, kc = c & 3;
-      *reinterpret_cast<uint4*>(img + kimg_off(row, kc)) = kreg[it];
+      *reinterpret_cast<uint4*>(img + kimg_off(row, kc)) = kreg[ks % PF][it];
     }
     __syncthreads();  // slice ks visible; every wave is past its reads of slice ks - 1 (the buffer written next iteration)
-    if (ks + 1 < NKS) kload(ks + 1);
+    if (ks + PF < NKS) kload(ks + PF, kreg[ks % PF]);
+    // rows >= T of the image are zero (kload), so the fragments past the sequence contribute exact zeros: no predicates in the
+    // MFMA loop (a uniform branch per fragment kept the compiler from batching the 20 LDS reads in front of the MFMAs)
+    Frag<bf16_t> a[ATT_KF];
 #pragma unroll
-    for (int f = 0; f < ATT_KF; ++f) {
-      if (f < nkf) {
-        Frag<bf16_t> a, b;
-        a.v = *reinterpret_cast<const uint4*>(img + kimg_off(f * 16 + p16, kg));
-        b.v = qf[ks];
-        frag_mma(a, b, S[f]);
-      }
-    }
+    for (int f = 0; f < ATT_KF; ++f) a[f].v = *reinterpret_cast<const uint4*>(img + kimg_off(f * 16 + p16, kg));
+    Frag<bf16_t> b;
+    b.v = qf[ks];
+#pragma unroll
+    for (int f = 0; f < ATT_KF; ++f) frag_mma(a[f], b, S[f]);
   }
 }
 
@@ -157,6 +160,24 @@ __device__ __forceinline__ void vimg_frag(const unsigned char* vimg, int kk, int
                    (unsigned)(unsigned short)v1[2] | ((unsigned)(unsigned short)v1[3] << 16));
 }
 
+// o = A (fragments af: ATT_KF/2 contraction blocks of 32) x image chunk, NF output fragments of 16 columns (compile-time: the
+// image is zero past the real width and af is zero past the sequence, so over-computing is exact and keeps the loops branch-free)
+template <int NF>
+__device__ __forceinline__ void frags_times_image(const uint4 (&af)[ATT_KF / 2], const unsigned char* vimg, int lane, f32x4_t (&o)[ATT_DC / 16]) {
+#pragma unroll
+  for (int n = 0; n < ATT_DC / 16; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < ATT_KF / 2; ++kk) {
+    Frag<bf16_t> a, bfr[NF];
+    a.v = af[kk];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) vimg_frag(vimg, kk, n, lane, bfr[n]);
+#pragma unroll
+    for (int n = 0; n < NF; ++n) frag_mma(a, bfr[n], o[n]);
+  }
+}
+template <int NKS> struct AttnNF { static constexpr int value = NKS <= 1 ? 2 : (NKS <= 2 ? 4 : ATT_DC / 16); };
+
 template <int NKS>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(tfpp_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -171,9 +192,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(tfpp_attn_params p) {
   const bf16_t* vh = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * T * p.ld_kv + (size_t)h * d;
   bf16_t* oh = reinterpret_cast<bf16_t*>(p.o) + (size_t)b * T * p.ld_o + (size_t)h * d;
 
+  // phase trace (tools/attn_micro.py --trace): the forward does not use p.delta; when given, workgroup (0, 0) stamps its phases there
+  const bool trace = p.delta != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+  const unsigned long long t0 = trace ? wall_clock64() : 0ull;
+#define ATT_STAMP(k) do { if (trace) p.delta[k] = (float)(wall_clock64() - t0); } while (0)
   f32x4_t S[ATT_KF];
   attn_scores<NKS>(qh, p.ld_q, kh, p.ld_kv, T, d, q0 + p16, kimg, tid, lane, S);
+  ATT_STAMP(0);
   const float lse = attn_softmax(S, nkf, p.scale);
+  ATT_STAMP(1);
   const size_t row = (size_t)bh * T + q0 + p16;  // flat (batch, head, query) index: dropout counter and lse / debug rows
   if (kg == 0 && p.lse) p.lse[row] = lse;
 
@@ -204,26 +231,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(tfpp_attn_params p) {
   for (int dc = 0; dc < d; dc += ATT_DC) {
     const int nd = (d - dc < ATT_DC) ? d - dc : ATT_DC, nfr = (nd + 15) >> 4;
     __syncthreads();  // previous chunk's readers are done with the V image (first pass: the K image is dead too)
-    stage_vimg(vh, p.ld_kv, T, d, dc, nfr * 2, vimg, tid);
+    if (dc == 0) ATT_STAMP(2);
+    stage_vimg(vh, p.ld_kv, T, d, dc, AttnNF<NKS>::value * 2, vimg, tid);
     __syncthreads();
+    if (dc == 0) ATT_STAMP(3);
     f32x4_t o[ATT_DC / 16];
-#pragma unroll
-    for (int n = 0; n < ATT_DC / 16; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < ATT_KF / 2; ++kk) {
-      if (2 * kk < nkf) {
-        Frag<bf16_t> a;
-        a.v = pf[kk];
-#pragma unroll
-        for (int n = 0; n < ATT_DC / 16; ++n) {
-          if (n < nfr) {
-            Frag<bf16_t> bfr;
-            vimg_frag(vimg, kk, n, lane, bfr);
-            frag_mma(a, bfr, o[n]);
-          }
-        }
-      }
-    }
+    frags_times_image<AttnNF<NKS>::value>(pf, vimg, lane, o);
+    if (dc == 0) ATT_STAMP(4);
     // C layout: o[n][r] = O[query kg*4 + r][d = dc + n*16 + p16] -> bf16 strip [16][128] -> 16-byte row segments
     bf16_t* st = reinterpret_cast<bf16_t*>(strip);
 #pragma unroll
@@ -269,28 +283,6 @@ __device__ __forceinline__ void store_strip_chunk(const f32x4_t (&o)[ATT_DC / 16
   for (int c = lane; c < 16 * cpr; c += 64) {
     const int r = c / cpr, ch = c - r * cpr, d0 = dc + ch * 8;
     if (d0 < d) *reinterpret_cast<uint4*>(dst + (size_t)(row0 + r) * ld + d0) = *reinterpret_cast<const uint4*>(st + r * ATT_DC + ch * 8);
-  }
-}
-
-// acc (+)= A(frags af, ATT_KF/2 contraction blocks of 32) x image chunk
-__device__ __forceinline__ void frags_times_image(const uint4 (&af)[ATT_KF / 2], int nkf, const unsigned char* vimg, int nfr, int lane,
-                                                  f32x4_t (&o)[ATT_DC / 16]) {
-#pragma unroll
-  for (int n = 0; n < ATT_DC / 16; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kk = 0; kk < ATT_KF / 2; ++kk) {
-    if (2 * kk < nkf) {
-      Frag<bf16_t> a;
-      a.v = af[kk];
-#pragma unroll
-      for (int n = 0; n < ATT_DC / 16; ++n) {
-        if (n < nfr) {
-          Frag<bf16_t> bfr;
-          vimg_frag(vimg, kk, n, lane, bfr);
-          frag_mma(a, bfr, o[n]);
-        }
-      }
-    }
   }
 }
 
@@ -360,10 +352,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(tfpp_attn_params p) {
   for (int dc = 0; dc < d; dc += ATT_DC) {
     const int nd = (d - dc < ATT_DC) ? d - dc : ATT_DC, nfr = (nd + 15) >> 4;
     __syncthreads();
-    stage_vimg(kh, p.ld_kv, T, d, dc, nfr * 2, vimg, tid);  // dQ = dS K: K as the transposable image
+    stage_vimg(kh, p.ld_kv, T, d, dc, AttnNF<NKS>::value * 2, vimg, tid);  // dQ = dS K: K as the transposable image
     __syncthreads();
     f32x4_t o[ATT_DC / 16];
-    frags_times_image(dsf, nkf, vimg, nfr, lane, o);
+    frags_times_image<AttnNF<NKS>::value>(dsf, vimg, lane, o);
     store_strip_chunk(o, nfr, strip, dqh, p.ld_q, q0, dc, d, lane);
   }
 }
@@ -430,14 +422,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(tfpp_attn_params p) {
     const int nd = (d - dc < ATT_DC) ? d - dc : ATT_DC, nfr = (nd + 15) >> 4;
     f32x4_t o[ATT_DC / 16];
     __syncthreads();
-    stage_vimg(doh, p.ld_o, T, d, dc, nfr * 2, vimg, tid);  // dV = Pd^T dO
+    stage_vimg(doh, p.ld_o, T, d, dc, AttnNF<NKS>::value * 2, vimg, tid);  // dV = Pd^T dO
     __syncthreads();
-    frags_times_image(pdf, nkf, vimg, nfr, lane, o);
+    frags_times_image<AttnNF<NKS>::value>(pdf, vimg, lane, o);
     store_strip_chunk(o, nfr, strip, dvh, p.ld_kv, k0, dc, d, lane);
     __syncthreads();
-    stage_vimg(qh, p.ld_q, T, d, dc, nfr * 2, vimg, tid);   // dK = dS^T Q
+    stage_vimg(qh, p.ld_q, T, d, dc, AttnNF<NKS>::value * 2, vimg, tid);   // dK = dS^T Q
     __syncthreads();
-    frags_times_image(dsf, nkf, vimg, nfr, lane, o);
+    frags_times_image<AttnNF<NKS>::value>(dsf, vimg, lane, o);
     store_strip_chunk(o, nfr, strip, dkh, p.ld_kv, k0, dc, d, lane);
   }
 }

@@ -13,11 +13,14 @@ enum { TFPP_F32 = 0, TFPP_BF16 = 1 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_GELU = 3, ACT_TANH = 4 };
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                          // round-to-nearest-even
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even: the native conversion (gfx950 v_cvt_pk_bf16_f32, one instruction per PAIR; the integer
+// formulation it replaces cost ~6 VALU per value and was a visible share of every latency-bound epilogue)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ unsigned f2bf_pack2(float lo, float hi) {  // (bf16(lo) | bf16(hi) << 16)
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename T> struct ElemTraits;
@@ -50,8 +53,7 @@ template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
   return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
 }
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
-  return make_uint4((unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16), (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16),
-                    (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16), (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16));
+  return make_uint4(f2bf_pack2(f[0], f[1]), f2bf_pack2(f[2], f[3]), f2bf_pack2(f[4], f[5]), f2bf_pack2(f[6], f[7]));
 }
 
 template <typename T> __device__ __forceinline__ void load_vec(const T* p, float* f) {

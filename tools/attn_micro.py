@@ -61,6 +61,15 @@ def main():
       ops.bgemm(dP, q, dk, M=T, N=dp, K=T, lda=T, ldb=npk, ldc=npk, batch0=B, batch1=nh, a_bs=(nh * T * T, T * T), b_bs=(T * npk, dp),
                 c_bs=(T * npk, dp), a_km=True, b_km=True)
 
+    if '--trace' in sys.argv:  # phase stamps of workgroup (0, 0): 100 MHz ticks since kernel start
+      tr = torch.zeros(8, device='cuda')
+      p = ops._attn_params(q, k, v, O, lse, delta=tr, **geo)
+      import ctypes
+      from carla_garage_amd._lib import lib
+      lib.tfpp_attn_fwd(ctypes.byref(p), 1, ops.stream())
+      torch.cuda.synchronize()
+      names = ('scores', 'softmax', 'sync', 'V staged', 'PV chunk0', 'O chunk0 stored', 'end')
+      print('  trace d=%d: ' % d_real + ', '.join('%s %.1f us' % (n, t / 100.0) for n, t in zip(names, tr.cpu().tolist())))
     f_fwd = timed(lambda: ops.attn_fwd(q, k, v, O, lse, **geo))
     f_bwd = timed(lambda: ops.attn_bwd(q, k, v, O, lse, dO, dq, dk, dv, delta, **geo))
     u_fwd = timed(unfused_fwd)
