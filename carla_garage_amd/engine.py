@@ -441,7 +441,9 @@ class Engine:
   def _build_specs(self):
     m = self.m
     bb = m.backbone
-    for br, enc in (('image_encoder', bb.image_encoder), ('lidar_encoder', bb.lidar_encoder)):
+    self.aim = self.cfg.backbone == 'aim'  # team_code/aim.py: image branch only, no LiDAR branch, no fusion transformers
+    branches = [('image_encoder', bb.image_encoder)] + ([] if self.aim else [('lidar_encoder', bb.lidar_encoder)])
+    for br, enc in branches:
       p = f'backbone.{br}'
       self._spec(f'{p}.stem', enc['stem'].conv.weight, bn=enc['stem'].bn, stride=2, pad=1, cin_store=8)
       for si in range(1, 5):
@@ -453,7 +455,7 @@ class Engine:
           self._spec(q + '.conv3', blk.conv3.conv.weight, bn=blk.conv3.bn)
           if blk.downsample is not None:
             self._spec(q + '.downsample', blk.downsample.conv.weight, bn=blk.downsample.bn, stride=blk.stride)
-    for i in range(4):
+    for i in range(0 if self.aim else 4):
       for nme in ('lidar_channel_to_img', 'img_channel_to_lidar'):
         conv = getattr(bb, nme)[i]
         self._spec(f'backbone.{nme}.{i}', conv.weight, conv.bias)
@@ -600,7 +602,7 @@ class Engine:
           s.save_invstd = torch.empty(s.cout, device=dev, dtype=F32)
           s.ws = torch.empty(2 * s.cout, device=dev, dtype=torch.float64)
     # fusion-transformer QKV: fused, head-padded images
-    for i, g in enumerate(self.m.backbone.transformers):
+    for i, g in enumerate(getattr(self.m.backbone, 'transformers', [])):
       c, nh = g.n_embd, self.cfg.n_head
       d = c // nh
       dp = ops.pad_to(d, 8)
@@ -1152,30 +1154,38 @@ class Engine:
       xi = ops.nchw_to_nhwc_affine(rgb.float().contiguous(), dt_, 8, mul, add)
     else:
       xi = ops.nchw_to_nhwc_affine(rgb.float().contiguous(), dt_, 8)
-    lidar_in = lidar_bev.float().contiguous()
     lanes = self.lanes
-    lanes.hold(lidar_in)
-    with lanes.fork():  # the LiDAR branch runs on its own stream between the fusion points
-      xl = ops.nchw_to_nhwc_affine(lidar_in, dt_, 8)
-      xl = self.conv(xl, 'backbone.lidar_encoder.stem', act=ACT_RELU, x_grad=False)
-    xi = self.conv(xi, 'backbone.image_encoder.stem', act=ACT_RELU, x_grad=False)
-    for i in range(4):
-      with lanes.fork():
-        xl = self.stage(xl, f'backbone.lidar_encoder.s{i + 1}', bb.lidar_encoder[f's{i + 1}'])
-        lt = self.pool_tokens(xl, cfg.lidar_vert_anchors, cfg.lidar_horz_anchors)
-        lt = self.conv(lt, f'backbone.lidar_channel_to_img.{i}')
-      xi = self.stage(xi, f'backbone.image_encoder.s{i + 1}', bb.image_encoder[f's{i + 1}'])
-      it = self.pool_tokens(xi, cfg.img_vert_anchors, cfg.img_horz_anchors)
+    if self.aim:  # team_code/aim.py:32-61: the image branch alone; fused_features = the stage-4 feature grid
+      xi = self.conv(xi, 'backbone.image_encoder.stem', act=ACT_RELU, x_grad=False)
+      for i in range(4):
+        xi = self.stage(xi, f'backbone.image_encoder.s{i + 1}', bb.image_encoder[f's{i + 1}'])
+        if i == 2 and self.tape is not None:
+          self.tape.mark()
+      xl = xi
+    else:
+      lidar_in = lidar_bev.float().contiguous()
+      lanes.hold(lidar_in)
+      with lanes.fork():  # the LiDAR branch runs on its own stream between the fusion points
+        xl = ops.nchw_to_nhwc_affine(lidar_in, dt_, 8)
+        xl = self.conv(xl, 'backbone.lidar_encoder.stem', act=ACT_RELU, x_grad=False)
+      xi = self.conv(xi, 'backbone.image_encoder.stem', act=ACT_RELU, x_grad=False)
+      for i in range(4):
+        with lanes.fork():
+          xl = self.stage(xl, f'backbone.lidar_encoder.s{i + 1}', bb.lidar_encoder[f's{i + 1}'])
+          lt = self.pool_tokens(xl, cfg.lidar_vert_anchors, cfg.lidar_horz_anchors)
+          lt = self.conv(lt, f'backbone.lidar_channel_to_img.{i}')
+        xi = self.stage(xi, f'backbone.image_encoder.s{i + 1}', bb.image_encoder[f's{i + 1}'])
+        it = self.pool_tokens(xi, cfg.img_vert_anchors, cfg.img_horz_anchors)
+        lanes.join()
+        io, lo = self.gpt(i, it, lt)
+        lanes.hold(lt, lo)
+        with lanes.fork():
+          lo = self.conv(lo, f'backbone.img_channel_to_lidar.{i}')
+          xl = self.upsample_add(lo, xl)
+        xi = self.upsample_add(io, xi)
+        if i == 2 and self.tape is not None:
+          self.tape.mark()  # everything recorded from here on only touches the "early" parameters (finishes_early)
       lanes.join()
-      io, lo = self.gpt(i, it, lt)
-      lanes.hold(lt, lo)
-      with lanes.fork():
-        lo = self.conv(lo, f'backbone.img_channel_to_lidar.{i}')
-        xl = self.upsample_add(lo, xl)
-      xi = self.upsample_add(io, xi)
-      if i == 2 and self.tape is not None:
-        self.tape.mark()  # everything recorded from here on only touches the "early" parameters (finishes_early)
-    lanes.join()
     out['image_feature_grid'], out['fused_features'] = xi, xl
 
     # BEV feature pyramid (transfuser.py:131-137) with the CenterNet and BEV-semantic heads: 64 x 64 maps, ~25 small launches -> lane 2,

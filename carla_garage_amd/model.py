@@ -75,10 +75,13 @@ class LidarCenterNet(nn.Module):
   def __init__(self, config):
     super().__init__()
     self.config = config
-    if config.backbone != 'transFuser':
-      # model.py:45-46 raises for unknown names; 'aim' / 'bev_encoder' exist in the reference but are outside this
-      # path's scope
-      raise ValueError('The chosen vision backbone does not exist on the MI355X path. The options are: transFuser')
+    if config.backbone not in ('transFuser', 'aim'):
+      # model.py:45-46 raises for unknown names; 'bev_encoder' exists in the reference but is not built yet
+      raise ValueError('The chosen vision backbone does not exist on the MI355X path. The options are: transFuser, aim')
+    if config.backbone == 'aim' and (config.use_semantic or config.use_depth or config.detect_boxes or config.use_bev_semantic):
+      # the reference itself cannot build these heads on the AIM backbone (model.py:71 reads backbone.perspective_upsample_factor,
+      # which team_code/aim.py does not define; there is no BEV feature grid): BASELINE config 1 switches them off
+      raise ValueError('backbone="aim" needs use_semantic = use_depth = detect_boxes = use_bev_semantic = 0')
     if not config.transformer_decoder_join or cfg_get(config, 'tp_attention', False) or cfg_get(config, 'multi_wp_output', False):
       raise ValueError('MI355X path: only transformer_decoder_join=True, tp_attention=False, multi_wp_output=False')
     if not (config.use_wp_gru or config.use_controller_input_prediction):
@@ -101,10 +104,10 @@ class LidarCenterNet(nn.Module):
       self.checkpoint_query = nn.Parameter(torch.zeros(1, config.predict_checkpoint_len + 1, d))
 
     # ---- sub-modules in the reference's registration order
-    self.backbone = M.TransfuserBackbone(config)
+    self.backbone = M.TransfuserBackbone(config) if config.backbone == 'transFuser' else M.AIMBackbone(config)
     if config.detect_boxes:
       self.head = M.LidarCenterNetHead(config)
-    up = self.backbone.perspective_upsample_factor
+    up = getattr(self.backbone, 'perspective_upsample_factor', 1)
     dec_args = (config.deconv_channel_num_0, config.deconv_channel_num_1, config.deconv_channel_num_2,
                 up // config.deconv_scale_factor_0, up // config.deconv_scale_factor_1)
     if config.use_semantic:

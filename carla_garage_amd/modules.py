@@ -155,6 +155,20 @@ class TransfuserBackbone(nn.Module):
       self.c5_conv = nn.Conv2d(widths[-1], ch, 1)
 
 
+class AIMBackbone(nn.Module):
+  """Container for team_code/aim.py:10-30: one RegNetY-3.2GF image encoder, no LiDAR branch, no fusion (BASELINE config 1)."""
+  forward = _no_forward
+
+  def __init__(self, config):
+    super().__init__()
+    if config.image_architecture != 'regnety_032':
+      raise ValueError(f'the MI355X path implements the regnety_032 image branch (got {config.image_architecture})')
+    self.config = config
+    self.image_encoder = RegNetY(3)
+    self.num_image_features = REGNETY_032['widths'][-1]
+    self.num_features = REGNETY_032['widths'][-1]
+
+
 class LidarCenterNetHead(nn.Module):
   """Container for team_code/center_net.py:23-47 (single-frame: 5 branches)."""
   forward = _no_forward

@@ -15,6 +15,7 @@ Files written
                            per-parameter gradient norms and sampled gradient values, BN statistics update
   tfpp_train_bs12.npz      the same step at bs=12 (BASELINE config 3's batch: the kernel variants bench.py runs); `python -m
                            oracle.make_golden bs12` writes only this file
+  tfpp_aim.npz             BASELINE config 1: image-only AIM backbone, eval forward bs=1 + train step bs=2 (`... make_golden aim`)
   tfpp_wp_eval_bs1.npz     WP variant (use_wp_gru=1, use_controller_input_prediction=0): pred_wp
 """
 import json
@@ -43,6 +44,8 @@ def pack_outputs(out):
     d['pred_target_speed'] = _np(out[1])
   if out[2] is not None:
     d['pred_checkpoint'] = _np(out[2])
+  if out[3] is None:  # image-only AIM configuration: planning outputs only
+    return d
   sem, bev, dep = _np(out[3]), _np(out[4]), _np(out[5])
   d['pred_semantic_strided'] = sem[:, :, ::SEM_STRIDE, ::SEM_STRIDE].copy()
   d['pred_bev_semantic_strided'] = bev[:, :, ::BEV_STRIDE, ::BEV_STRIDE].copy()
@@ -74,6 +77,50 @@ GRAD_SAMPLES = 16
 
 def sample_idx(n):
   return np.unique(np.linspace(0, n - 1, GRAD_SAMPLES).astype(np.int64))
+
+
+AIM_OVERRIDES = dict(backbone='aim', use_semantic=0, use_depth=0, detect_boxes=0, use_bev_semantic=0)  # BASELINE config 1
+
+
+def write_aim_golden():
+  """BASELINE config 1: the image-only AIM backbone (team_code/aim.py) -- eval forward at bs = 1 and one train-mode step at bs = 2
+  (the two planning losses, weights 0.5 / 0.5 as team_code/train.py:383-456 normalises them).  The deterministic state_dict is the
+  TransFuser++ one restricted to the keys the AIM model has (same sub-architectures, same shapes)."""
+  model, _ = ref_harness.build_reference_model(**AIM_OVERRIDES)
+  cfg = P.PortConfig()
+  full = P.make_state_dict(cfg)
+  sd = {k: full[k] for k in model.state_dict().keys()}
+  model.load_state_dict(sd, strict=True)
+  model.eval()
+  inp = P.make_inputs(1, cfg)
+  with torch.inference_mode():
+    out = model(*inp)
+  assert out[3] is None and out[6] is None
+  d = {'eval_pred_target_speed': _np(out[1]), 'eval_pred_checkpoint': _np(out[2]), 'keys': np.array(list(sd.keys()))}
+  model.train()
+  disable_dropout(model)
+  inp, lab = P.make_inputs(2, cfg), P.make_labels(2, cfg)
+  out = model(*inp)
+  losses = model.compute_loss(**reference_loss_kwargs(out, lab))
+  assert sorted(losses.keys()) == ['loss_checkpoint', 'loss_target_speed'], losses.keys()
+  total = 0.5 * losses['loss_target_speed'] + 0.5 * losses['loss_checkpoint']
+  total.backward()
+  d['loss_names'] = np.array(list(losses.keys()))
+  d['losses'] = np.array([v.item() for v in losses.values()])
+  names, norms, samples = [], [], []
+  for k, p in model.named_parameters():
+    if p.grad is None:
+      continue
+    g = p.grad.detach().flatten()
+    names.append(k)
+    norms.append([g.double().norm().item(), g.abs().max().item()])
+    smp = np.zeros(GRAD_SAMPLES, np.float32)
+    idx = sample_idx(g.numel())
+    smp[:len(idx)] = _np(g[idx])
+    samples.append(smp)
+  d['grad_names'], d['grad_norms'], d['grad_samples'] = np.array(names), np.array(norms), np.stack(samples)
+  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_aim.npz'), **d)
+  print('aim: losses', dict(zip(d['loss_names'], d['losses'])), 'params with grad', len(names))
 
 
 def write_train_golden(model, cfg, bs, fname):
@@ -135,6 +182,9 @@ def main():
   if only == {'bs12'}:
     write_train_golden(model, cfg, 12, 'tfpp_train_bs12.npz')
     return
+  if only == {'aim'}:
+    write_aim_golden()
+    return
 
   model.eval()
   inp = P.make_inputs(1, cfg)
@@ -153,6 +203,9 @@ def main():
     # plans) are only reached at this size, so the parity tests need a reference step at it too
     model.load_state_dict(sd, strict=True)  # the bs=2 step updated the BN running statistics
     write_train_golden(model, cfg, 12, 'tfpp_train_bs12.npz')
+
+  # ---- AIM (BASELINE config 1) ----------------------------------------------------------------
+  write_aim_golden()
 
   # ---- WP variant -----------------------------------------------------------------------------
   del model

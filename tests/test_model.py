@@ -63,6 +63,20 @@ def test_library_exports_every_declared_symbol():
   _lib.lib.load()  # raises if a declared symbol is missing or a struct mirror has the wrong size
 
 
+AIM_CFG = dict(backbone='aim', use_semantic=0, use_depth=0, detect_boxes=0, use_bev_semantic=0)  # BASELINE config 1
+
+
+def test_aim_state_dict_schema_matches_reference():
+  """BASELINE config 1 (image-only AIM backbone, team_code/aim.py): same keys in the same order as the reference model."""
+  g = U.load_golden('tfpp_aim.npz')
+  m = LidarCenterNet(GlobalConfig(**AIM_CFG))
+  assert list(m.state_dict().keys()) == [str(k) for k in g['keys']]
+  full = P.make_state_dict()
+  m.load_state_dict({k: full[k] for k in m.state_dict().keys()}, strict=True)
+  with pytest.raises(ValueError):
+    LidarCenterNet(GlobalConfig(backbone='aim'))  # the reference cannot build the dense heads on AIM either (model.py:71)
+
+
 def test_every_library_call_of_the_host_code_is_declared_in_the_header():
   """The ctypes binding is generated from include/tfpp.h: a call of an undeclared entry point would only fail on the GPU box."""
   import glob
@@ -161,6 +175,49 @@ def test_eval_forward_bf16_close_to_fp32_reference():
   _report('eval_bf16', errs)
   bad = {k: v for k, v in errs.items() if v > 5e-2}
   assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_aim_backbone_forward_and_train_step_vs_reference_golden():
+  """BASELINE config 1 on the HIP path: the image-only AIM backbone (one RegNetY branch -> change_channel -> 257-token planning
+  decoder).  Eval forward at bs = 1 within 1e-3 of the reference, train-mode step at bs = 2: losses, gradient norms and sampled
+  gradient elements (tests/golden/tfpp_aim.npz, written by the reference through oracle/make_golden.py)."""
+  from carla_garage_amd.engine import Tape
+  from carla_garage_amd.losses import fused_losses, normalized_loss_weights
+  g = U.load_golden('tfpp_aim.npz')
+  m = LidarCenterNet(GlobalConfig(tfpp_dtype='fp32', **AIM_CFG))
+  full = P.make_state_dict()
+  m.load_state_dict({k: full[k] for k in m.state_dict().keys()}, strict=True)
+  m.cuda().eval()
+  with torch.inference_mode():
+    out = m(*[x.cuda() for x in P.make_inputs(1)])
+  assert out[3] is None and out[4] is None and out[5] is None and out[6] is None
+  e1 = U.assert_close(U.to_np(out[1]), g['eval_pred_target_speed'], U.REL_TOL_FP32, 'pred_target_speed')
+  e2 = U.assert_close(U.to_np(out[2]), g['eval_pred_checkpoint'], U.REL_TOL_FP32, 'pred_checkpoint')
+  m.train()
+  _zero_dropout(m)
+  eng = m._engine()
+  batch = {k: v.cuda() for k, v in P.make_labels(2).items()}
+  eng.prepare(torch.float32, True, True)
+  eng.alloc_grads()
+  eng.tape = Tape()
+  t = eng.forward(*[x.cuda() for x in P.make_inputs(2)])
+  w = normalized_loss_weights(m.config)
+  assert w == {'loss_target_speed': 0.5, 'loss_checkpoint': 0.5}
+  names, vals, seeds = fused_losses(m, t, batch, w, True)
+  tape, eng.tape = eng.tape, None
+  tape.backward(seeds)
+  torch.cuda.synchronize()
+  gl = dict(zip([str(x) for x in g['loss_names']], g['losses']))
+  lerr = {n: float(abs(v - gl[n]) / abs(gl[n])) for n, v in zip(names, vals.cpu().numpy())}
+  worst_norm, worst_elem = _compare_grads(eng, g)
+  _report('aim', {'eval': [e1, e2], 'losses': lerr, 'grad_norm_worst': max(worst_norm.values()), 'grad_elem_worst': max(worst_elem.values()),
+                  'tensors': len(worst_norm)})
+  assert max(lerr.values()) <= 1e-3, lerr
+  over = {n: e for n, e in worst_norm.items() if e > (GRAD_NORM_TOL_SE_FC1 if '.se.fc1.' in n else GRAD_NORM_TOL)}
+  assert not over, over
+  assert max(worst_elem.values()) <= GRAD_ELEM_TOL
+  assert len(worst_norm) > 350  # every trainable tensor of the image branch and the planning head was compared
 
 
 @pytest.mark.gpu
