@@ -321,15 +321,19 @@ def test_train_step_bs12_fp32_vs_reference_golden():
   _check_train_step_vs_golden(12, 'tfpp_train_bs12.npz', 'train_fp32_bs12')
 
 
-BF16_LOSS_TOL, BF16_GRAD_NORM_TOL = 1e-1, 0.5
+BF16_LOSS_TOL = 5e-2  # measured worst: loss_yaw_res 2.2e-2 (a loss of ~1e-2 absolute, i.e. 2e-4 absolute error), every other loss <= 4.5e-3
+# measured worst gradient-norm deviations (568 tensors): SE fc1 / attention query-key 0.16-0.33 (their fp32 gradients are differences of
+# nearly cancelling terms: the softmax / sigmoid-gate Jacobians), everything else <= 0.155
+BF16_GRAD_NORM_TOL, BF16_GRAD_NORM_TOL_CANCELLING = 0.3, 0.65
+_CANCELLING = ('.se.fc', '.attn.query.', '.attn.key.')
 
 
 @pytest.mark.gpu
 def test_train_step_bs12_bf16_vs_fp32_hip_and_golden():
   """The benchmarked precision: the bf16 step at bs = 12 (deterministic since the one-row-per-M-tile BN statistics) against the
   reference's fp32 losses and against the fp32 HIP step's gradients.  Tolerances are what bf16 storage through 100+ layers with
-  batch-statistic BN measures on MI355X (profiles/r02_model_parity_report.jsonl), with head room of about 2x: losses 3e-2 relative,
-  gradient norms 0.15 relative for tensors carrying >= 1e-3 of the largest norm."""
+  batch-statistic BN measures on MI355X (profiles/r02_model_parity_report.jsonl), with head room of about 2x (see the constants above);
+  gradient norms are compared for tensors carrying >= 1e-3 of the largest norm."""
   g = U.load_golden('tfpp_train_bs12.npz')
   m32 = _model('fp32').train()
   _, v32, e32 = _engine_train_step(m32, 12)
@@ -347,7 +351,8 @@ def test_train_step_bs12_bf16_vs_fp32_hip_and_golden():
                                'grad_norm_vs_fp32_hip_worst': top, 'tensors_compared': len(nerr)})
   assert np.isfinite(v16).all()
   assert max(lerr.values()) <= BF16_LOSS_TOL, lerr
-  assert max(nerr.values()) <= BF16_GRAD_NORM_TOL, top
+  bad = {n: e for n, e in nerr.items() if e > (BF16_GRAD_NORM_TOL_CANCELLING if any(t in n for t in _CANCELLING) else BF16_GRAD_NORM_TOL)}
+  assert not bad, bad
 
 
 @pytest.mark.gpu
