@@ -512,7 +512,7 @@ def test_streams_and_hipgraph_do_not_change_the_training_step():
   and the gradient arena must agree to the run-to-run noise of the single-stream path itself (order of the fp32 atomics
   of the fused BatchNorm statistics: ~1e-6 on the losses, ~2e-3 relative L2 on the gradients of step 1; a race between
   streams shows up orders of magnitude above that).  bf16 is not used here: with train-mode BN at batch 2 its
-  run-to-run gradient noise is 0.2 relative L2 on one stream already (tools/streams_probe.py)."""
+  run-to-run gradient noise is 0.2 relative L2 on one stream already (tools/stress_step.py, phase B)."""
   from carla_garage_amd.graph import GraphedTrainStep
   from carla_garage_amd.trainer import Trainer
   batch = {k: v.cuda() for k, v in P.make_labels(2).items()}
