@@ -36,6 +36,11 @@ if qkey:
 agg = collections.defaultdict(lambda: [0, 0])
 for r in step:
     k = r["Kernel_Name"][:100]; agg[k][0] += 1; agg[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+with open(sys.argv[2].replace("kernels.txt", "trace.csv"), "w") as out:  # the whole last step, one line per kernel, for offline timeline analysis
+    out.write("queue,start_us,dur_us,kernel\n")
+    for r in step:
+        out.write("%s,%.2f,%.2f,%s\n" % (r[qkey] if qkey else "0", (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                                      r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace(",", ";")[:70]))
 with open(sys.argv[2], "w") as out:
     out.write("# kernel | calls | total_ms | avg_us   (one hipGraph-replayed training step, bs=12 bf16)\n")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
