@@ -19,7 +19,7 @@ constexpr int TH = 8, TW = 32, HH = TH + 2, HWID = TW + 2;
 
 // CV = Cin_g / 8 at compile time (0: run-time loop): with CV known the staging loops are fully unrolled, so a thread issues all of
 // its ~11 global loads before the first LDS store instead of paying one memory latency per 16-byte chunk.
-template <int FN, int CV>
+template <int FN, int CV, bool BNS = false>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, int tiles_w, int tiles_h, int ksteps_rt) {
   typedef bf16_t T;
   constexpr int FM = 4;
@@ -151,24 +151,27 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
   if (epi_vec_ok(p)) {  // coalesced 16-pixel passes through a per-wave LDS strip (staging buffers are dead)
     __syncthreads();
     float* strip = reinterpret_cast<float*>(smem) + wave * EpiStrip<FN>::FLOATS;
-    BnsAcc<FN, FM> bns;  // fused BatchNorm-backward statistics (tfpp.h): one row of bns_partial per 8 x 32 pixel tile
-    const bool do_bns = p.bns_partial != nullptr;  // workgroup-uniform
-    bns.init(p, lane, 0, g);
-    if (do_bns) {
+    if constexpr (BNS) {  // fused BatchNorm-backward statistics (tfpp.h): one row of bns_partial per 8 x 32 pixel tile; own instantiation
+      BnsAcc<FN, FM> bns;
+      bns.init(p, lane, 0, g);
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const int h = h0 + 2 * wave + (i >> 1), wc = w0 + (i & 1) * 16;
         bns.prefetch(p, lane, i, (long)(b * H + h) * W + wc, h < H ? W - wc : 0, 0, g);
       }
-    }
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int h = h0 + 2 * wave + (i >> 1), wc = w0 + (i & 1) * 16;
-      epi_pass_bf16<FN, FM>(p, acc[i], strip, lane, (long)(b * H + h) * W + wc, h < H ? W - wc : 0, 0, g, do_bns ? &bns : nullptr, i);
-    }
-    if (do_bns) {
+      for (int i = 0; i < FM; ++i) {
+        const int h = h0 + 2 * wave + (i >> 1), wc = w0 + (i & 1) * 16;
+        epi_pass_bf16<FN, FM, true>(p, acc[i], strip, lane, (long)(b * H + h) * W + wc, h < H ? W - wc : 0, 0, g, &bns, i);
+      }
       __syncthreads();  // the strips are dead
       bns.template finish<4, 1>(p, reinterpret_cast<float*>(smem), wave, 0, lane, (int)blockIdx.x, 0, g);
+    } else {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int h = h0 + 2 * wave + (i >> 1), wc = w0 + (i & 1) * 16;
+        epi_pass_bf16<FN, FM, false>(p, acc[i], strip, lane, (long)(b * H + h) * W + wc, h < H ? W - wc : 0, 0, g);
+      }
     }
     return;
   }
@@ -212,7 +215,8 @@ template <int FN, int CV> int launch_halo(const tfpp_conv_params& p, hipStream_t
   const int tiles_w = cdiv(p.Wd, TW), tiles_h = cdiv(p.Hd, TH), ksteps = (9 * p.ks_g + 31) / 32;
   const size_t lds = halo_lds_bytes(p, FN);
   dim3 grid((unsigned)(tiles_w * tiles_h * p.B), (unsigned)p.G);
-  hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
+  if (p.bns_partial) hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, true>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
+  else hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, false>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

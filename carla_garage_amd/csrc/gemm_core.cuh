@@ -202,7 +202,10 @@ template <int FN, int FM> struct BnsAcc {
 };
 
 // one pass: rows m_pass .. m_pass + rows_valid - 1 (<= 16), columns n_base .. n_base + 16 FN - 1 of group g
-template <int FN, int FM = 1>
+// BNS is a template parameter and the callers branch on p.bns_partial around two instantiations: with a run-time `bns` pointer (null or
+// not) the BnsAcc object could not be kept in registers and EVERY bf16 conv launch paid 128 B/thread of scratch initialisation (2-3x the
+// bytes of C in WRITE_SIZE, profiles/r02_pmc_calibration.txt).
+template <int FN, int FM = 1, bool BNS = false>
 __device__ __forceinline__ void epi_pass_bf16(const tfpp_conv_params& p, const f32x4_t (&acc)[FN], float* strip, int lane, long m_pass,
                                               int rows_valid, int n_base, int g, BnsAcc<FN, FM>* bns = nullptr, int ipass = 0) {
   constexpr int PITCH = EpiStrip<FN>::PITCH, CH = FN * 2, NCHUNK = 16 * CH;
@@ -244,7 +247,7 @@ __device__ __forceinline__ void epi_pass_bf16(const tfpp_conv_params& p, const f
       }
       const uint4 packed = pack16<bf16_t>(v);
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.dst) + (size_t)m * p.dst_ld + ch) = packed;
-      if (bns) {
+      if constexpr (BNS) {
         float gv[8];
         unpack16<bf16_t>(packed, gv);  // the rounded values: exactly what the BatchNorm backward reads back
         bns->add(p, gv, ipass, c);

@@ -40,7 +40,7 @@ template <int CPR> __device__ __forceinline__ int glds_swz(int row) {
 
 // KS: MFMA k-steps (of 32) per stage = per barrier.  KS = 2 halves the barriers, waits and address arithmetic per MFMA (the
 // per-stage overhead of ~40 non-MFMA instructions against 8 MFMAs was the measured limit of the KS = 1 kernel).
-template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1>
+template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1, bool BNS = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_conv_params p, int trace, int m_major) {
   typedef bf16_t T;
   constexpr int NT = WGM * WGN * 64, NWAVES = WGM * WGN;
@@ -308,21 +308,24 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
   if (epi_vec_ok(p)) {  // coalesced: 16-row passes through a per-wave LDS strip (the ring is free)
     __syncthreads();
     float* strip = reinterpret_cast<float*>(smem) + wave * EpiStrip<FN>::FLOATS;
-    BnsAcc<FN, FM> bns;  // fused BatchNorm-backward statistics (tfpp.h)
-    const bool do_bns = p.bns_partial != nullptr;  // workgroup-uniform
-    bns.init(p, lane, bn0 + wn * WN, g);
-    if (do_bns) {
+    if constexpr (BNS) {  // fused BatchNorm-backward statistics (tfpp.h): its own instantiation, the plain kernel does not pay its registers
+      BnsAcc<FN, FM> bns;
+      bns.init(p, lane, bn0 + wn * WN, g);
 #pragma unroll
       for (int i = 0; i < FM; ++i) bns.prefetch(p, lane, i, bm0 + wm * WM + i * 16, M - (bm0 + wm * WM + i * 16), bn0 + wn * WN, g);
-    }
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int m_pass = bm0 + wm * WM + i * 16;
-      epi_pass_bf16<FN, FM>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g, do_bns ? &bns : nullptr, i);
-    }
-    if (do_bns) {
+      for (int i = 0; i < FM; ++i) {
+        const int m_pass = bm0 + wm * WM + i * 16;
+        epi_pass_bf16<FN, FM, true>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g, &bns, i);
+      }
       __syncthreads();  // the strips are dead
       bns.template finish<WGM, WGN>(p, reinterpret_cast<float*>(smem), wm, wn, lane, mtile, bn0 + wn * WN, g);
+    } else {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int m_pass = bm0 + wm * WM + i * 16;
+        epi_pass_bf16<FN, FM, false>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g);
+      }
     }
     TRACE(5);
     return;
@@ -362,7 +365,9 @@ template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1> static int l
   const size_t lds = (size_t)NSTAGE * (BM + BN) * 64 * KS;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -371,7 +376,8 @@ template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1> static int l
   static const int mm_env = [] { const char* e = std::getenv("TFPP_GLDS_M_MAJOR"); return e ? std::atoi(e) : -1; }();
   const long w_bytes = (long)p.n_g * p.R * p.S * p.ks_g * 2;
   const int m_major = mm_env >= 0 ? mm_env : (w_bytes <= (6l << 20) ? 1 : 0);
-  hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS>), grid, dim3(WGM * WGN * 64), lds, st, p, trace, m_major);
+  if (p.bns_partial) hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, true>), grid, dim3(WGM * WGN * 64), lds, st, p, trace, m_major);
+  else hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, false>), grid, dim3(WGM * WGN * 64), lds, st, p, trace, m_major);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

@@ -8,7 +8,7 @@
 // ---------------------------------------------------------------------------------------------------------------
 // conv / linear forward and data gradient
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, int BKT>
+template <typename T, int BM, int BN, int WM, int WN, int BKT, bool BNS = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_kernel(tfpp_conv_params p) {
   using C = TileCfg<T, BM, BN, WM, WN, BKT>;
   constexpr int VEC = C::VEC, KV = C::KV, NT = C::NT, BK = C::BK;
@@ -154,21 +154,24 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
     if (epi_vec_ok(p)) {  // coalesced: 16-row passes through a per-wave LDS strip (see gemm_core.cuh)
       __syncthreads();
       float* strip = reinterpret_cast<float*>(smem_raw) + wave * EpiStrip<C::FN>::FLOATS;
-      BnsAcc<C::FN, C::FM> bns;  // fused BatchNorm-backward statistics of the tensor whose gradient this launch completes (tfpp.h)
-      const bool do_bns = p.bns_partial != nullptr;  // workgroup-uniform
-      bns.init(p, lane, bn0 + wn * WN, g);
-      if (do_bns) {
+      if constexpr (BNS) {  // fused BatchNorm-backward statistics of the tensor whose gradient this launch completes (tfpp.h); own instantiation
+        BnsAcc<C::FN, C::FM> bns;
+        bns.init(p, lane, bn0 + wn * WN, g);
 #pragma unroll
         for (int i = 0; i < C::FM; ++i) bns.prefetch(p, lane, i, bm0 + wm * WM + i * 16, M - (bm0 + wm * WM + i * 16), bn0 + wn * WN, g);
-      }
 #pragma unroll
-      for (int i = 0; i < C::FM; ++i) {
-        const int m_pass = bm0 + wm * WM + i * 16;
-        epi_pass_bf16<C::FN, C::FM>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g, do_bns ? &bns : nullptr, i);
-      }
-      if (do_bns) {
+        for (int i = 0; i < C::FM; ++i) {
+          const int m_pass = bm0 + wm * WM + i * 16;
+          epi_pass_bf16<C::FN, C::FM, true>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g, &bns, i);
+        }
         __syncthreads();  // the strips are dead
         bns.template finish<C::WAVES_M, C::WAVES_N>(p, reinterpret_cast<float*>(smem_raw), wm, wn, lane, mtile, bn0 + wn * WN, g);
+      } else {
+#pragma unroll
+        for (int i = 0; i < C::FM; ++i) {
+          const int m_pass = bm0 + wm * WM + i * 16;
+          epi_pass_bf16<C::FN, C::FM, false>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, g);
+        }
       }
       return;
     }
@@ -213,6 +216,13 @@ static int launch_conv(const tfpp_conv_params& p, hipStream_t st) {
     hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WM, WN, 32>), grid, dim3(C::NT), 0, st, p);
     TFPP_CHECK_LAUNCH();
     return 0;
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (p.bns_partial) {
+      hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WM, WN, BKT, true>), grid, dim3(C::NT), 0, st, p);
+      TFPP_CHECK_LAUNCH();
+      return 0;
+    }
   }
   hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, WM, WN, BKT>), grid, dim3(C::NT), 0, st, p);
   TFPP_CHECK_LAUNCH();
@@ -330,6 +340,7 @@ extern "C" int tfpp_conv_gemm_splits(const tfpp_conv_params* p, int dtype) {
 static bool conv_bns_ok(const tfpp_conv_params& p, int dtype) {
   if (dtype != TFPP_BF16 || p.dst_nchw || p.dst_f32 || ((p.n_g | (int)p.dst_ld | (int)p.bns_ld) & 7) || ((uintptr_t)p.dst & 15)) return false;
   if (p.res && ((((int)p.res_ld) & 7) || ((uintptr_t)p.res & 15))) return false;
+  if (p.R * p.S * p.ks_g <= 32) return false;  // the one-stage tiny-K instantiation has no statistics variant
   return true;
 }
 extern "C" int tfpp_conv_gemm_bns_ok(const tfpp_conv_params* p, int dtype) {

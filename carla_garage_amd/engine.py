@@ -366,9 +366,10 @@ class SideLane:
 
 # BatchNorm-backward sums (sum g, sum g*xhat) produced by the kernel that completes the gradient instead of a separate reduction pass:
 #   0 off;  1 (default) only where the producer is the elementwise squeeze-excite backward (conv2 of every bottleneck: +0.3 ms in that
-#   kernel, -0.56 ms of tfpp_bn_bwd_reduce);  2 also in the epilogue of the data-gradient GEMMs -- correct (tests), but measured SLOWER
-#   at bs = 12: those GEMMs are short (K = 72 .. 576) and latency-bound, the extra y / x loads and the cross-lane reduction lengthen
-#   every workgroup: +6.2 ms of GEMM time against -2.2 ms of reduction passes (38.9 vs 35.8 ms/step, round 2, same box).
+#   kernel, -0.56 ms of tfpp_bn_bwd_reduce);  2 also in the epilogue of the data-gradient GEMMs (their own kernel instantiations) --
+#   correct (tests) and neutral at bs = 12: 32.16 vs 32.19 ms/step (round 2, same box, profiles/r02_kernel_table_fuse_bn_bwd{1,2}.txt): the
+#   reduction passes it removes are replaced by longer GEMM epilogues on the same critical chain.  The first measurement of mode 2
+#   (38.9 vs 35.8 ms) was taken while a run-time `bns` pointer kept the statistics object of EVERY bf16 conv launch in scratch memory.
 FUSE_BN_BWD = int(os.environ.get('TFPP_FUSE_BN_BWD', '1'))
 
 EARLY_GRAD_PREFIXES = ('backbone.image_encoder.s4', 'backbone.lidar_encoder.s4', 'backbone.transformers.3', 'backbone.lidar_channel_to_img.3',

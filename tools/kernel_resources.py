@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Register / scratch / occupancy table of every gfx950 kernel in carla_garage_amd/csrc (hipcc -S, no GPU needed).
+  python tools/kernel_resources.py [--scratch-only] [file.hip ...]
+A non-zero ScratchSize in a hot kernel means private-memory traffic (it shows up in FETCH_SIZE / WRITE_SIZE as bytes the algorithm never
+asked for: round 2 found 128 B/thread of it in the GEMM epilogues); TotalNumVgprs > 128 in a 512-thread kernel means one workgroup per CU."""
+import glob
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def demangle(names):
+  try:
+    out = subprocess.run(['c++filt'], input='\n'.join(names), capture_output=True, text=True, check=True).stdout.split('\n')
+    return dict(zip(names, out))
+  except Exception:  # pylint: disable=broad-except
+    return {n: n for n in names}
+
+
+def table(path):
+  with tempfile.TemporaryDirectory() as td:
+    s_path = os.path.join(td, 'k.s')
+    r = subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-DTFPP_SOURCE_HASH=0', path, '-o', s_path],
+                       capture_output=True, text=True)
+    if r.returncode:
+      raise RuntimeError(r.stderr[-2000:])
+    s = open(s_path).read()
+  rows = []
+  for m in re.finditer(r'\.amdhsa_kernel (\S+).*?; NumVgprs: (\d+)\n; NumAgprs: (\d+)\n; TotalNumVgprs: (\d+)\n; ScratchSize: (\d+)\n.*?; Occupancy: (\d+)\n.*?; LDSByteSize: (\d+)', s, re.S):
+    rows.append((m.group(1),) + tuple(int(v) for v in m.groups()[1:]))
+  return rows
+
+
+def main():
+  args = [a for a in sys.argv[1:] if not a.startswith('--')]
+  scratch_only = '--scratch-only' in sys.argv
+  files = args or sorted(glob.glob(os.path.join(ROOT, 'carla_garage_amd', 'csrc', '*.hip')))
+  bad = 0
+  for f in files:
+    rows = table(f)
+    names = demangle([r[0] for r in rows])
+    for name, v, a, t, sc, occ, lds in rows:
+      if scratch_only and sc == 0:
+        continue
+      bad += sc > 0
+      print('%-24s %-100s vgpr %3d agpr %3d total %3d scratch %4d occupancy %d static-lds %d' % (os.path.basename(f), names[name][:100], v, a, t, sc, occ, lds))
+  return 1 if (scratch_only and bad) else 0
+
+
+if __name__ == '__main__':
+  sys.exit(main())

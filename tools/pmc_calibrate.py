@@ -22,7 +22,7 @@ def main():
   y = torch.empty_like(x)
   sc = torch.ones(256, device=dev)
   sh = torch.zeros(256, device=dev)
-  M, K, N = 3840, 1512, 6048
+  M, K, N = (int(os.environ.get(k, d)) for k, d in (('CAL_M', 3840), ('CAL_K', 1512), ('CAL_N', 6048)))  # default: the fusion MLP of stage 4
   a = (torch.rand(M, 1, 1, K, device=dev) - 0.5).to(torch.bfloat16)
   w = ops.pack_conv_weight((torch.rand(N, K, 1, 1, device=dev) - 0.5) * 0.1, torch.bfloat16)
   c = torch.empty(M, 1, 1, N, device=dev, dtype=torch.bfloat16)

@@ -12,7 +12,9 @@ done
 python - "$REPO" <<'PY'
 import csv, glob, json, sys, collections
 repo = sys.argv[1]
-known = {'fillBuffer': (0, 256 * 1024 * 1024 * 4), 'affine_act': ((1 << 20) * 256 * 2, (1 << 20) * 256 * 2), 'conv_gemm_glds': ((3840 * 1512 + 1512 * 6048) * 2, 3840 * 6048 * 2)}
+import os
+M, K, N = (int(os.environ.get(k, d)) for k, d in (('CAL_M', 3840), ('CAL_K', 1512), ('CAL_N', 6048)))
+known = {'fillBuffer': (0, 256 * 1024 * 1024 * 4), 'affine_act': ((1 << 20) * 256 * 2, (1 << 20) * 256 * 2), 'conv_gemm_glds': ((M * K + K * N) * 2, M * N * 2)}
 out = {}
 for ci, cname in enumerate(('FETCH_SIZE', 'WRITE_SIZE')):
     fs = glob.glob(f'/tmp/cal_{cname}/**/*counter_collection.csv', recursive=True)
