@@ -30,6 +30,22 @@ __device__ __forceinline__ uint4 lds_read_b128_asm(unsigned addr) {
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+template <int OFF> __device__ __forceinline__ uint4 lds_read_b128_imm(unsigned addr) {  // OFF: 16-bit immediate byte offset
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+// N fragments 1024 bytes (16 rows of 64) apart from one base address, in issue order 0 .. N-1
+template <int I, int N> struct LdsFragReads {
+  static __device__ __forceinline__ void run(Frag<bf16_t>* f, unsigned base) {
+    f[I].v = lds_read_b128_imm<I * 1024>(base);
+    LdsFragReads<I + 1, N>::run(f, base);
+  }
+};
+template <int N> struct LdsFragReads<N, N> {
+  static __device__ __forceinline__ void run(Frag<bf16_t>*, unsigned) {}
+};
+
 // physical 16-byte slot of logical chunk kc in row `row` of a stage image with CPR chunks per row (CPR = 4: 64-byte rows, the
 // {0,2,3,1}[(row>>2)&3] table above; CPR = 8: 128-byte rows, two rows per 256-byte bank row: XOR with (row>>1)&7 sends the 16 rows of
 // a ds_read_b128 lane group to 16 distinct slots)
@@ -40,7 +56,12 @@ template <int CPR> __device__ __forceinline__ int glds_swz(int row) {
 
 // KS: MFMA k-steps (of 32) per stage = per barrier.  KS = 2 halves the barriers, waits and address arithmetic per MFMA (the
 // per-stage overhead of ~40 non-MFMA instructions against 8 MFMAs was the measured limit of the KS = 1 kernel).
-template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1, bool BNS = false>
+// PW: pointwise layers (1x1, stride 1, no padding: every fusion linear and RegNet 1x1 conv -- all this kernel is used for in the model) run
+// a lean K loop: 32-bit running offsets against a uniform base (row / column indices clamped into range instead of redirected to the zero
+// page; only the K tail of the last tile takes the general pointer path), one vector add per load and per operand base, immediate
+// offsets on the fragment reads.  The general loop below it executes ~300 instructions per tile and wave -- tools/glds_trace.py with every
+// load, read and MFMA compiled out still measured 358 ns per tile, as much as the complete 8-MFMA tile should take.
+template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1, bool BNS = false, bool PW = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_conv_params p, int trace, int m_major) {
   typedef bf16_t T;
   constexpr int NT = WGM * WGN * 64, NWAVES = WGM * WGN;
@@ -76,170 +97,284 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
       mtile = full + r / gx;
     }
   }
+  if constexpr (PW) {  // integer divisions run on the vector ALU: tell the compiler the results are wave-uniform (scalar loop control)
+    mtile = __builtin_amdgcn_readfirstlane(mtile); ntile = __builtin_amdgcn_readfirstlane(ntile);
+    g = __builtin_amdgcn_readfirstlane(g); split = __builtin_amdgcn_readfirstlane(split);
+  }
   const int bm0 = mtile * BM, bn0 = ntile * BN;
   const T* __restrict__ src = reinterpret_cast<const T*>(p.src) + g * p.ks_g;
   const T* __restrict__ wk = reinterpret_cast<const T*>(p.w) + (size_t)g * p.n_g * K;
   const T* zero = reinterpret_cast<const T*>(tfpp_zero_page);
   const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)smem;  // LDS byte address of the ring
 
-  // ---- per-thread chunk bookkeeping (fixed over the K loop)
-  int a_kc[A_INST], a_b[A_INST], a_h0[A_INST], a_w0[A_INST];
-  const T* a_ptr[A_INST];  // pointwise fast path
-  const bool pointwise = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
-#pragma unroll
-  for (int i = 0; i < A_INST; ++i) {
-    const int q = i * NT + tid, row = q / CPR, slot = q % CPR;
-    a_kc[i] = slot ^ glds_swz<CPR>(row);
-    const int m = bm0 + row;
-    a_ptr[i] = nullptr;
-    if (m < M) {
-      const int hw = p.Hd * p.Wd, b = m / hw, pix = m - b * hw, hd = pix / p.Wd, wd = pix - hd * p.Wd;
-      a_b[i] = b;
-      if (p.mode == 0) { a_h0[i] = hd * p.stride - p.pad; a_w0[i] = wd * p.stride - p.pad; }
-      else { a_h0[i] = hd + p.pad; a_w0[i] = wd + p.pad; }
-      if (pointwise) a_ptr[i] = src + ((size_t)(b * p.Hs + a_h0[i]) * p.Ws + a_w0[i]) * p.src_ld;
-    } else {
-      a_b[i] = -1; a_h0[i] = 0; a_w0[i] = 0;
-    }
-  }
-  int b_kc[B_INST];
-  const T* b_ptr[B_INST];
-#pragma unroll
-  for (int j = 0; j < B_INST; ++j) {
-    const int q = j * NT + tid, row = q / CPR, slot = q % CPR;
-    b_kc[j] = slot ^ glds_swz<CPR>(row);
-    const int n = bn0 + row;
-    b_ptr[j] = (n < p.n_g) ? wk + (size_t)n * K : nullptr;
-  }
-
-  // K tiles of this workgroup: all of them, or one slice of a split-K launch
-  int kt_beg = 0, nkt = (K + BKT - 1) / BKT;
-  if (p.splitk > 1) {
-    const int per = (nkt + p.splitk - 1) / p.splitk;
-    kt_beg = split * per;
-    nkt = (kt_beg + per < nkt ? kt_beg + per : nkt) - kt_beg;
-    if (nkt < 0) nkt = 0;
-  }
-  // Incremental addressing (SQ_INSTS_VALU / SQ_INSTS_MFMA measured 5.8 with per-tile address generation): a chunk of a pointwise
-  // layer and every weight chunk keep a running pointer that advances by one K-tile (64 bytes) per issue; rows outside the problem
-  // point at the zero page with step 0, the K tail (K % 32 != 0) exists only in the last tile and is masked there.
-  const int last_kt = nkt - 1;
-  const bool ktail = ((kt_beg + nkt) * BKT > K);  // the last tile of this workgroup reaches past K (wave-uniform)
-  const T* a_cur[A_INST];
-  int a_stepe[A_INST];  // elements per tile: 32 or 0
-#pragma unroll
-  for (int i = 0; i < A_INST; ++i) {
-    const bool lin = pointwise && a_ptr[i] != nullptr;
-    a_cur[i] = lin ? a_ptr[i] + kt_beg * BKT + a_kc[i] * 8 : zero;
-    a_stepe[i] = lin ? BKT : 0;
-  }
-  const T* b_cur[B_INST];
-  int b_stepe[B_INST];
-#pragma unroll
-  for (int j = 0; j < B_INST; ++j) {
-    b_cur[j] = b_ptr[j] ? b_ptr[j] + kt_beg * BKT + b_kc[j] * 8 : zero;
-    b_stepe[j] = b_ptr[j] ? BKT : 0;
-  }
-  auto issue = [&](int kt) {  // LDS-DMA of this workgroup's K-tile kt into ring slot kt % NSTAGE; called with kt = 0, 1, 2, ... in order
-    const unsigned stage = lds_base + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
-    const bool last = ktail && kt == last_kt;  // wave-uniform
-#pragma unroll
-    for (int i = 0; i < A_INST; ++i) {
-      const T* gp = a_cur[i];
-      if (pointwise) {
-        if (last && (kt_beg + kt) * BKT + a_kc[i] * 8 >= K) gp = zero;
-        a_cur[i] += a_stepe[i];
-      } else {
-        const int k0 = (kt_beg + kt) * BKT + a_kc[i] * 8;
-        gp = zero;
-        if (k0 < K && a_b[i] >= 0) {
-          const int rs = k0 / p.ks_g, c = k0 - rs * p.ks_g, r = rs / p.S, s = rs - r * p.S;
-          int hs, ws;
-          bool ok;
-          if (p.mode == 0) {
-            hs = a_h0[i] + r; ws = a_w0[i] + s;
-            ok = (hs >= 0) & (hs < p.Hs) & (ws >= 0) & (ws < p.Ws);
-          } else {
-            const int th = a_h0[i] - r, tw = a_w0[i] - s;
-            hs = th / p.stride; ws = tw / p.stride;
-            ok = (th >= 0) & (tw >= 0) & (hs * p.stride == th) & (ws * p.stride == tw) & (hs < p.Hs) & (ws < p.Ws);
-          }
-          if (ok) gp = src + ((size_t)(a_b[i] * p.Hs + hs) * p.Ws + ws) * p.src_ld + c;
-        }
-      }
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)gp, (lds_void_t*)(stage + (unsigned)((i * NWAVES + wave) * 1024)), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < B_INST; ++j) {
-      const T* gp = b_cur[j];
-      if (last && (kt_beg + kt) * BKT + b_kc[j] * 8 >= K) gp = zero;
-      b_cur[j] += b_stepe[j];
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)gp, (lds_void_t*)(stage + (unsigned)(A_BYTES + (j * NWAVES + wave) * 1024)), 16, 0, 0);
-    }
-  };
-
   f32x4_t acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // fragment read offsets inside a stage (fixed): row * ROWB + ((ks*4 + (l>>4)) ^ swz(row)) * 16
   const int r16 = lane & 15, kgrp = lane >> 4;
-  unsigned a_off[KS][FM], b_off[KS][FN];
+
+  if constexpr (PW) {
+    static_assert(KS == 1, "the lean loop is written for one k-step per stage");
+    // K tiles of this workgroup: all of them, or one slice of a split-K launch
+    int kt_beg = 0, nkt = (K + BKT - 1) / BKT;
+    if (p.splitk > 1) {
+      const int per = (nkt + p.splitk - 1) / p.splitk;
+      kt_beg = split * per;
+      nkt = (kt_beg + per < nkt ? kt_beg + per : nkt) - kt_beg;
+      if (nkt < 0) nkt = 0;
+    }
+    kt_beg = __builtin_amdgcn_readfirstlane(kt_beg);
+    nkt = __builtin_amdgcn_readfirstlane(nkt);
+    const int last_kt = nkt - 1;
+    const bool ktail = ((kt_beg + nkt) * BKT > K);  // the last tile of this workgroup reaches past K (wave-uniform)
+    const char* a_base = reinterpret_cast<const char*>(src);  // uniform
+    const char* b_base = reinterpret_cast<const char*>(wk);
+    unsigned a_vo[A_INST], b_vo[B_INST];  // byte offsets of this thread's chunks in the next tile to issue (the launcher checked 32 bits)
+    bool a_tz[A_INST], b_tz[B_INST];      // chunk lies beyond K in the last tile
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int row = wm * WM + i * 16 + r16;
-      a_off[ks][i] = (unsigned)(row * ROWB + (((ks * 4 + kgrp) ^ glds_swz<CPR>(row)) * 16));
+    for (int i = 0; i < A_INST; ++i) {
+      const int q = i * NT + tid, row = q / CPR, kc = (q % CPR) ^ glds_swz<CPR>(row);
+      const int m = bm0 + row < M ? bm0 + row : M - 1;  // rows past the end repeat the last one: finite data, never stored
+      a_vo[i] = (unsigned)m * (unsigned)p.src_ld * 2u + (unsigned)(kt_beg * BKT + kc * 8) * 2u;
+      a_tz[i] = (kt_beg + last_kt) * BKT + kc * 8 >= K;
     }
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int row = wn * WN + j * 16 + r16;
-      b_off[ks][j] = (unsigned)(A_BYTES + row * ROWB + (((ks * 4 + kgrp) ^ glds_swz<CPR>(row)) * 16));
+    for (int j = 0; j < B_INST; ++j) {
+      const int q = j * NT + tid, row = q / CPR, kc = (q % CPR) ^ glds_swz<CPR>(row);
+      const int n = bn0 + row < p.n_g ? bn0 + row : p.n_g - 1;
+      b_vo[j] = (unsigned)n * (unsigned)K * 2u + (unsigned)(kt_beg * BKT + kc * 8) * 2u;
+      b_tz[j] = (kt_beg + last_kt) * BKT + kc * 8 >= K;
     }
-  }
-
-  TRACE(1);
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+    const unsigned ring_end = lds_base + NSTAGE * STAGE_BYTES;
+    auto issue = [&](unsigned stage, bool last) {  // `last` is wave-uniform; both variants issue LOADS loads per thread, in the same order
+      if (!last) {
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < nkt) issue(s);
-  TRACE(2);
+        for (int i = 0; i < A_INST; ++i) {
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_base + a_vo[i]), (lds_void_t*)(stage + (i * NWAVES + wave_u) * 1024u), 16, 0, 0);
+          a_vo[i] += BKT * 2;
+        }
+#pragma unroll
+        for (int j = 0; j < B_INST; ++j) {
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_base + b_vo[j]), (lds_void_t*)(stage + A_BYTES + (j * NWAVES + wave_u) * 1024u), 16, 0, 0);
+          b_vo[j] += BKT * 2;
+        }
+      } else {  // K % 32 != 0: chunks beyond K read the zero page (NaN * 0 must not happen on either operand)
+        const char* zero = reinterpret_cast<const char*>(tfpp_zero_page);
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i)
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_tz[i] ? zero : a_base + a_vo[i]), (lds_void_t*)(stage + (i * NWAVES + wave_u) * 1024u), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < B_INST; ++j)
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_tz[j] ? zero : b_base + b_vo[j]), (lds_void_t*)(stage + A_BYTES + (j * NWAVES + wave_u) * 1024u), 16, 0, 0);
+      }
+    };
+    // fragment reads: row * 64 + ((kgrp ^ swz(row)) * 16); the swizzle depends on row bits 2..3 only, so fragment row i / column j
+    // of a wave differ from fragment 0 by i (j) * 1024 bytes -- an immediate
+    const int arow = wm * WM + r16, brow = wn * WN + r16;
+    const unsigned a_off0 = (unsigned)(arow * ROWB + ((kgrp ^ glds_swz<CPR>(arow)) * 16));
+    const unsigned b_off0 = (unsigned)(A_BYTES + brow * ROWB + ((kgrp ^ glds_swz<CPR>(brow)) * 16));
+    auto tile_mma = [&](unsigned stage) {
+      Frag<T> fa[FM], fb[FN];
+      const unsigned ab = stage + a_off0, bb = stage + b_off0;
+      LdsFragReads<0, FN>::run(fb, bb);
+      LdsFragReads<0, FM>::run(fa, ab);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {  // DS operations retire in order: row i needs the FN weight fragments and rows 0..i
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM - 1 - i) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) frag_mma(fa[i], fb[j], acc[i][j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    // tiles issued after kt and still allowed in flight: min(NSTAGE-2, nkt-1-kt)
-    const int ahead = (nkt - 1 - kt) < (NSTAGE - 2) ? (nkt - 1 - kt) : (NSTAGE - 2);
-    switch (ahead) {  // wave-uniform
+    TRACE(1);
+    unsigned wr = lds_base, rd = lds_base;
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+      if (s < nkt) { issue(wr, ktail && s == last_kt); wr += STAGE_BYTES; }
+    TRACE(2);
+    TRACE(3);
+    int kt = 0;
+#pragma unroll 1
+    for (; kt + NSTAGE - 1 < nkt; ++kt) {  // steady state: NSTAGE - 2 younger tiles stay in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LOADS) : "memory");
+      __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; every wave is done with tile kt - 1, whose slot is refilled now
+      issue(wr, ktail && kt + NSTAGE - 1 == last_kt);
+      wr += STAGE_BYTES;
+      if (wr == ring_end) wr = lds_base;
+      tile_mma(rd);
+      rd += STAGE_BYTES;
+      if (rd == ring_end) rd = lds_base;
+    }
+#pragma unroll 1
+    for (; kt < nkt; ++kt) {  // drain: nkt - 1 - kt (<= NSTAGE - 2) younger tiles in flight
+      switch (nkt - 1 - kt) {  // wave-uniform
 #define TFPP_WAIT_CASE(A) case A: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A) * LOADS < 63 ? (A) * LOADS : 63) : "memory"); break
-      TFPP_WAIT_CASE(0); TFPP_WAIT_CASE(1); TFPP_WAIT_CASE(2); TFPP_WAIT_CASE(3); TFPP_WAIT_CASE(4); TFPP_WAIT_CASE(5);
-      TFPP_WAIT_CASE(6); TFPP_WAIT_CASE(7); TFPP_WAIT_CASE(8); TFPP_WAIT_CASE(9); TFPP_WAIT_CASE(10);
+        TFPP_WAIT_CASE(1); TFPP_WAIT_CASE(2); TFPP_WAIT_CASE(3); TFPP_WAIT_CASE(4); TFPP_WAIT_CASE(5); TFPP_WAIT_CASE(6);
 #undef TFPP_WAIT_CASE
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      tile_mma(rd);
+      rd += STAGE_BYTES;
+      if (rd == ring_end) rd = lds_base;
     }
-    __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; every wave is done with tile kt-1
-    if (kt == 0) TRACE(3);
-    if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1);
-    const unsigned stage = lds_base + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
-    Frag<T> fa[KS][FM], fb[KS][FN];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i) fa[ks][i].v = lds_read_b128_asm(stage + a_off[ks][i]);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) fb[ks][j].v = lds_read_b128_asm(stage + b_off[ks][j]);
+  } else {
+    // ---- per-thread chunk bookkeeping (fixed over the K loop)
+    int a_kc[A_INST], a_b[A_INST], a_h0[A_INST], a_w0[A_INST];
+    const T* a_ptr[A_INST];  // pointwise fast path
+    const bool pointwise = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
+  #pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+      const int q = i * NT + tid, row = q / CPR, slot = q % CPR;
+      a_kc[i] = slot ^ glds_swz<CPR>(row);
+      const int m = bm0 + row;
+      a_ptr[i] = nullptr;
+      if (m < M) {
+        const int hw = p.Hd * p.Wd, b = m / hw, pix = m - b * hw, hd = pix / p.Wd, wd = pix - hd * p.Wd;
+        a_b[i] = b;
+        if (p.mode == 0) { a_h0[i] = hd * p.stride - p.pad; a_w0[i] = wd * p.stride - p.pad; }
+        else { a_h0[i] = hd + p.pad; a_w0[i] = wd + p.pad; }
+        if (pointwise) a_ptr[i] = src + ((size_t)(b * p.Hs + a_h0[i]) * p.Ws + a_w0[i]) * p.src_ld;
+      } else {
+        a_b[i] = -1; a_h0[i] = 0; a_w0[i] = 0;
+      }
     }
-#pragma unroll
+    int b_kc[B_INST];
+    const T* b_ptr[B_INST];
+  #pragma unroll
+    for (int j = 0; j < B_INST; ++j) {
+      const int q = j * NT + tid, row = q / CPR, slot = q % CPR;
+      b_kc[j] = slot ^ glds_swz<CPR>(row);
+      const int n = bn0 + row;
+      b_ptr[j] = (n < p.n_g) ? wk + (size_t)n * K : nullptr;
+    }
+
+    // K tiles of this workgroup: all of them, or one slice of a split-K launch
+    int kt_beg = 0, nkt = (K + BKT - 1) / BKT;
+    if (p.splitk > 1) {
+      const int per = (nkt + p.splitk - 1) / p.splitk;
+      kt_beg = split * per;
+      nkt = (kt_beg + per < nkt ? kt_beg + per : nkt) - kt_beg;
+      if (nkt < 0) nkt = 0;
+    }
+    // Incremental addressing (SQ_INSTS_VALU / SQ_INSTS_MFMA measured 5.8 with per-tile address generation): a chunk of a pointwise
+    // layer and every weight chunk keep a running pointer that advances by one K-tile (64 bytes) per issue; rows outside the problem
+    // point at the zero page with step 0, the K tail (K % 32 != 0) exists only in the last tile and is masked there.
+    const int last_kt = nkt - 1;
+    const bool ktail = ((kt_beg + nkt) * BKT > K);  // the last tile of this workgroup reaches past K (wave-uniform)
+    const T* a_cur[A_INST];
+    int a_stepe[A_INST];  // elements per tile: 32 or 0
+  #pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+      const bool lin = pointwise && a_ptr[i] != nullptr;
+      a_cur[i] = lin ? a_ptr[i] + kt_beg * BKT + a_kc[i] * 8 : zero;
+      a_stepe[i] = lin ? BKT : 0;
+    }
+    const T* b_cur[B_INST];
+    int b_stepe[B_INST];
+  #pragma unroll
+    for (int j = 0; j < B_INST; ++j) {
+      b_cur[j] = b_ptr[j] ? b_ptr[j] + kt_beg * BKT + b_kc[j] * 8 : zero;
+      b_stepe[j] = b_ptr[j] ? BKT : 0;
+    }
+    auto issue = [&](int kt) {  // LDS-DMA of this workgroup's K-tile kt into ring slot kt % NSTAGE; called with kt = 0, 1, 2, ... in order
+      const unsigned stage = lds_base + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
+      const bool last = ktail && kt == last_kt;  // wave-uniform
+  #pragma unroll
+      for (int i = 0; i < A_INST; ++i) {
+        const T* gp = a_cur[i];
+        if (pointwise) {
+          if (last && (kt_beg + kt) * BKT + a_kc[i] * 8 >= K) gp = zero;
+          a_cur[i] += a_stepe[i];
+        } else {
+          const int k0 = (kt_beg + kt) * BKT + a_kc[i] * 8;
+          gp = zero;
+          if (k0 < K && a_b[i] >= 0) {
+            const int rs = k0 / p.ks_g, c = k0 - rs * p.ks_g, r = rs / p.S, s = rs - r * p.S;
+            int hs, ws;
+            bool ok;
+            if (p.mode == 0) {
+              hs = a_h0[i] + r; ws = a_w0[i] + s;
+              ok = (hs >= 0) & (hs < p.Hs) & (ws >= 0) & (ws < p.Ws);
+            } else {
+              const int th = a_h0[i] - r, tw = a_w0[i] - s;
+              hs = th / p.stride; ws = tw / p.stride;
+              ok = (th >= 0) & (tw >= 0) & (hs * p.stride == th) & (ws * p.stride == tw) & (hs < p.Hs) & (ws < p.Ws);
+            }
+            if (ok) gp = src + ((size_t)(a_b[i] * p.Hs + hs) * p.Ws + ws) * p.src_ld + c;
+          }
+        }
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)gp, (lds_void_t*)(stage + (unsigned)((i * NWAVES + wave) * 1024)), 16, 0, 0);
+      }
+  #pragma unroll
+      for (int j = 0; j < B_INST; ++j) {
+        const T* gp = b_cur[j];
+        if (last && (kt_beg + kt) * BKT + b_kc[j] * 8 >= K) gp = zero;
+        b_cur[j] += b_stepe[j];
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)gp, (lds_void_t*)(stage + (unsigned)(A_BYTES + (j * NWAVES + wave) * 1024)), 16, 0, 0);
+      }
+    };
+
+    // fragment read offsets inside a stage (fixed): row * ROWB + ((ks*4 + (l>>4)) ^ swz(row)) * 16
+    unsigned a_off[KS][FM], b_off[KS][FN];
+  #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      // DS operations retire in order: the MFMAs of k-step ks wait for its own FM + FN reads only
-      if (ks == KS - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((FM + FN) * (KS - 1 - ks)) : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) frag_mma(fa[ks][i], fb[ks][j], acc[i][j]);
-      __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * WM + i * 16 + r16;
+        a_off[ks][i] = (unsigned)(row * ROWB + (((ks * 4 + kgrp) ^ glds_swz<CPR>(row)) * 16));
+      }
+  #pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int row = wn * WN + j * 16 + r16;
+        b_off[ks][j] = (unsigned)(A_BYTES + row * ROWB + (((ks * 4 + kgrp) ^ glds_swz<CPR>(row)) * 16));
+      }
+    }
+
+    TRACE(1);
+  #pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+      if (s < nkt) issue(s);
+    TRACE(2);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+      // tiles issued after kt and still allowed in flight: min(NSTAGE-2, nkt-1-kt)
+      const int ahead = (nkt - 1 - kt) < (NSTAGE - 2) ? (nkt - 1 - kt) : (NSTAGE - 2);
+      switch (ahead) {  // wave-uniform
+  #define TFPP_WAIT_CASE(A) case A: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A) * LOADS < 63 ? (A) * LOADS : 63) : "memory"); break
+        TFPP_WAIT_CASE(0); TFPP_WAIT_CASE(1); TFPP_WAIT_CASE(2); TFPP_WAIT_CASE(3); TFPP_WAIT_CASE(4); TFPP_WAIT_CASE(5);
+        TFPP_WAIT_CASE(6); TFPP_WAIT_CASE(7); TFPP_WAIT_CASE(8); TFPP_WAIT_CASE(9); TFPP_WAIT_CASE(10);
+  #undef TFPP_WAIT_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; every wave is done with tile kt-1
+      if (kt == 0) TRACE(3);
+      if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1);
+      const unsigned stage = lds_base + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
+      Frag<T> fa[KS][FM], fb[KS][FN];
+  #pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+  #pragma unroll
+        for (int i = 0; i < FM; ++i) fa[ks][i].v = lds_read_b128_asm(stage + a_off[ks][i]);
+  #pragma unroll
+        for (int j = 0; j < FN; ++j) fb[ks][j].v = lds_read_b128_asm(stage + b_off[ks][j]);
+      }
+  #pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        // DS operations retire in order: the MFMAs of k-step ks wait for its own FM + FN reads only
+        if (ks == KS - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((FM + FN) * (KS - 1 - ks)) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+        for (int i = 0; i < FM; ++i)
+  #pragma unroll
+          for (int j = 0; j < FN; ++j) frag_mma(fa[ks][i], fb[ks][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
@@ -363,21 +498,30 @@ template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1> static int l
   const long M = (long)p.B * p.Hd * p.Wd;
   dim3 grid(cdiv(p.n_g, BN), cdiv(M, BM), p.G * (p.splitk > 1 ? p.splitk : 1));
   const size_t lds = (size_t)NSTAGE * (BM + BN) * 64 * KS;
+  constexpr bool HAS_PW = (KS == 1);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void* fns[4] = {reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, false, false>),
+                          reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, true, false>),
+                          reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, false, HAS_PW>),
+                          reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, true, HAS_PW>)};
+    for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   static const int trace = [] { const char* e = std::getenv("TFPP_GLDS_TRACE"); return (e && e[0] == '1') ? 1 : 0; }();
   // small weight panels (<= 6 MB per group, measured: 1512x1512 gains, 6048x1512 loses): M-major order (see the kernel)
   static const int mm_env = [] { const char* e = std::getenv("TFPP_GLDS_M_MAJOR"); return e ? std::atoi(e) : -1; }();
-  const long w_bytes = (long)p.n_g * p.R * p.S * p.ks_g * 2;
+  const long K = (long)p.R * p.S * p.ks_g;
+  const long w_bytes = (long)p.n_g * K * 2;
   const int m_major = mm_env >= 0 ? mm_env : (w_bytes <= (6l << 20) ? 1 : 0);
-  if (p.bns_partial) hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, true>), grid, dim3(WGM * WGN * 64), lds, st, p, trace, m_major);
-  else hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, false>), grid, dim3(WGM * WGN * 64), lds, st, p, trace, m_major);
+  // lean loop: pointwise layer, every byte offset of one group's operands fits 32 bits (TFPP_GLDS_PW=0: the general loop, for A/B runs)
+  static const int pw_env = [] { const char* e = std::getenv("TFPP_GLDS_PW"); return e ? std::atoi(e) : 1; }();
+  const bool pw = HAS_PW && pw_env && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.Hs == p.Hd && p.Ws == p.Wd &&
+                  M * (long)p.src_ld * 2 < (1l << 32) && w_bytes < (1l << 32);
+#define TFPP_GLDS_LAUNCH(BNS_, PW_) hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, BNS_, PW_>), grid, dim3(WGM * WGN * 64), lds, st, p, trace, m_major)
+  if (pw) { if (p.bns_partial) TFPP_GLDS_LAUNCH(true, HAS_PW); else TFPP_GLDS_LAUNCH(false, HAS_PW); }
+  else { if (p.bns_partial) TFPP_GLDS_LAUNCH(true, false); else TFPP_GLDS_LAUNCH(false, false); }
+#undef TFPP_GLDS_LAUNCH
   TFPP_CHECK_LAUNCH();
   return 0;
 }

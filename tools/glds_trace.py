@@ -4,7 +4,7 @@ import ctypes
 import os
 import sys
 
-os.environ['TFPP_GLDS_TRACE'] = '1'
+os.environ['TFPP_GLDS_TRACE'] = str(int(os.environ.get('TFPP_GLDS_TRACE', '1')) | 1)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -33,6 +33,12 @@ def main():
   for k, nme in enumerate(names):
     col = (t[:, k] - t0) / 100.0
     print(f'  {nme:16s} min {col.min():7.2f}  median {np.median(col):7.2f}  max {col.max():7.2f}')
+  tm = np.median(t[:, 0]) + 0.5 * np.median(t[:, 5] - t[:, 0])
+  for frac in (0.25, 0.5, 0.75):
+    tq = t[:, 0].min() + frac * (t[:, 5].max() - t[:, 0].min())
+    print(f'  workgroups resident at {int(frac * 100)} % of the launch: {int(((t[:, 0] <= tq) & (t[:, 5] > tq)).sum())}  (256 CUs)')
+  nkt = (K + 31) // 32
+  print(f'  K loop per k-step (median): {np.median(t[:, 4] - t[:, 3]) / 100.0 / nkt * 1000:.0f} ns for {nkt} k-steps; launch span {(t[:, 5].max() - t0) / 100.0:.1f} us')
   d = np.diff(t, axis=1) / 100.0
   print('  per-workgroup phase durations (median us):', ' '.join(f'{nme}={np.median(d[:, k]):.2f}' for k, nme in enumerate(['setup', 'issue', 'first-wait', 'kloop', 'epilogue'])))
 
