@@ -35,14 +35,14 @@ template <int OFF> __device__ __forceinline__ uint4 lds_read_b128_imm(unsigned a
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
-// N fragments 1024 bytes (16 rows of 64) apart from one base address, in issue order 0 .. N-1
-template <int I, int N> struct LdsFragReads {
+// N fragments STEP bytes (16 rows) apart from one base address, in issue order 0 .. N-1
+template <int I, int N, int STEP> struct LdsFragReads {
   static __device__ __forceinline__ void run(Frag<bf16_t>* f, unsigned base) {
-    f[I].v = lds_read_b128_imm<I * 1024>(base);
-    LdsFragReads<I + 1, N>::run(f, base);
+    f[I].v = lds_read_b128_imm<I * STEP>(base);
+    LdsFragReads<I + 1, N, STEP>::run(f, base);
   }
 };
-template <int N> struct LdsFragReads<N, N> {
+template <int N, int STEP> struct LdsFragReads<N, N, STEP> {
   static __device__ __forceinline__ void run(Frag<bf16_t>*, unsigned) {}
 };
 
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
   constexpr int A_INST = BM * CPR / NT, B_INST = BN * CPR / NT;  // 16-byte chunks per thread per tile
   static_assert((BM * CPR) % NT == 0 && (BN * CPR) % NT == 0, "tile must divide over the threads");
   constexpr int LOADS = A_INST + B_INST;              // LDS-DMA instructions per wave per tile
-  static_assert((FM + FN) * (KS - 1) <= 15, "lgkmcnt is a 4-bit counter");
+  static_assert((FM - 1) + (FM + FN) * (KS - 1) <= 15, "lgkmcnt is a 4-bit counter");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TRACE(0);
@@ -115,7 +115,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
   const int r16 = lane & 15, kgrp = lane >> 4;
 
   if constexpr (PW) {
-    static_assert(KS == 1, "the lean loop is written for one k-step per stage");
     // K tiles of this workgroup: all of them, or one slice of a split-K launch
     int kt_beg = 0, nkt = (K + BKT - 1) / BKT;
     if (p.splitk > 1) {
@@ -170,22 +169,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
           __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_tz[j] ? zero : b_base + b_vo[j]), (lds_void_t*)(stage + A_BYTES + (j * NWAVES + wave_u) * 1024u), 16, 0, 0);
       }
     };
-    // fragment reads: row * 64 + ((kgrp ^ swz(row)) * 16); the swizzle depends on row bits 2..3 only, so fragment row i / column j
-    // of a wave differ from fragment 0 by i (j) * 1024 bytes -- an immediate
+    // fragment reads: row * ROWB + (((ks * 4 + kgrp) ^ swz(row)) * 16); the swizzle depends on row bits 1..3 only, so fragment row i /
+    // column j of a wave differ from fragment 0 by i (j) * 16 rows -- an immediate
     const int arow = wm * WM + r16, brow = wn * WN + r16;
-    const unsigned a_off0 = (unsigned)(arow * ROWB + ((kgrp ^ glds_swz<CPR>(arow)) * 16));
-    const unsigned b_off0 = (unsigned)(A_BYTES + brow * ROWB + ((kgrp ^ glds_swz<CPR>(brow)) * 16));
+    unsigned a_off0[KS], b_off0[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      a_off0[ks] = (unsigned)(arow * ROWB + (((ks * 4 + kgrp) ^ glds_swz<CPR>(arow)) * 16));
+      b_off0[ks] = (unsigned)(A_BYTES + brow * ROWB + (((ks * 4 + kgrp) ^ glds_swz<CPR>(brow)) * 16));
+    }
     auto tile_mma = [&](unsigned stage) {
-      Frag<T> fa[FM], fb[FN];
-      const unsigned ab = stage + a_off0, bb = stage + b_off0;
-      LdsFragReads<0, FN>::run(fb, bb);
-      LdsFragReads<0, FM>::run(fa, ab);
+      Frag<T> fa[KS][FM], fb[KS][FN];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {  // DS operations retire in order: row i needs the FN weight fragments and rows 0..i
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM - 1 - i) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
+      for (int ks = 0; ks < KS; ++ks) {
+        LdsFragReads<0, FN, 16 * ROWB>::run(fb[ks], stage + b_off0[ks]);
+        LdsFragReads<0, FM, 16 * ROWB>::run(fa[ks], stage + a_off0[ks]);
+      }
 #pragma unroll
-        for (int j = 0; j < FN; ++j) frag_mma(fa[i], fb[j], acc[i][j]);
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {  // DS operations retire in order: row i of k-step ks needs its FN weight fragments and rows 0..i
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((FM - 1 - i) + (FM + FN) * (KS - 1 - ks)) : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) frag_mma(fa[ks][i], fb[ks][j], acc[i][j]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -498,7 +506,7 @@ template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1> static int l
   const long M = (long)p.B * p.Hd * p.Wd;
   dim3 grid(cdiv(p.n_g, BN), cdiv(M, BM), p.G * (p.splitk > 1 ? p.splitk : 1));
   const size_t lds = (size_t)NSTAGE * (BM + BN) * 64 * KS;
-  constexpr bool HAS_PW = (KS == 1);
+  constexpr bool HAS_PW = true;
   static bool attr_set = false;
   if (!attr_set) {
     const void* fns[4] = {reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, false, false>),
@@ -526,20 +534,31 @@ template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1> static int l
   return 0;
 }
 
-// variant codes 200 + : 0 = 128x128, 1 = 64x128
+// variant codes 200 + : 0 = 128x128, 1 = 64x128, 2 = 256x128 (1024 threads)
+// All three stage 64-deep K tiles, i.e. 128-byte rows: with 32-deep tiles every LDS-DMA request fetched half a cache line and the L2
+// request rate (2.4e7 requests per 3840x6048x1512 launch, ~77 % of one request per channel and clock) bounded the kernel at ~500 TFLOP/s
+// whatever the MFMA / LDS schedule; whole-line requests: 128x128 651, 256x128 821 TFLOP/s (round 2, tools/gemm_micro.py).
 int conv_glds_variant(const tfpp_conv_params& p) {
   const long M = (long)p.B * p.Hd * p.Wd;
+  const long K = (long)p.R * p.S * p.ks_g;
   const long tiles = (long)cdiv(M, 128) * cdiv(p.n_g, 128) * p.G;
   static const int min_tiles = [] { const char* e = std::getenv("TFPP_GLDS_128_MIN_TILES"); return e ? std::atoi(e) : 256; }();
+  // 256x128: a third fewer operand bytes per FLOP again; needs a long K loop (>= 16 stages) to pay for its 144 KB ring prologue and
+  // >= 128 workgroups.  Measured against 128x128 (TFLOP/s): 3840x6048x1512 821 / 651, 3840x1512x6048 796 / 673, 3840x1512x1512 580 / 538,
+  // 3072x1512x1512 484 / 453, 12288x576x576 535 / 530, 3840x2304x576 406 / 468.
+  static const int min_k256 = [] { const char* e = std::getenv("TFPP_GLDS_256_MIN_K"); return e ? std::atoi(e) : 1024; }();
+  const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
+  if (pointwise && K >= min_k256 && (long)cdiv(M, 256) * cdiv(p.n_g, 128) * p.G >= 128) return 202;
   return tiles >= min_tiles ? 200 : 201;
 }
+int conv_glds_bm(int variant) { return variant == 202 ? 256 : (variant == 200 ? 128 : 64); }
 
 bool conv_glds_supported(const tfpp_conv_params& p, int dtype) {
   static const int min_k = [] { const char* e = std::getenv("TFPP_GLDS_MIN_K"); return e ? std::atoi(e) : 512; }();
   return dtype == TFPP_BF16 && p.n_g >= 128 && p.ks_g % 8 == 0 && p.src_ld % 8 == 0 && p.R * p.S * p.ks_g >= min_k;
 }
 
-static int glds_cfg() {  // TFPP_GLDS_CFG: tuning switch (stages x wave grid)
+static int glds_cfg() {  // TFPP_GLDS_CFG: tuning switch (stages x wave grid x k-steps per stage)
   static const int v = [] {
     const char* e = std::getenv("TFPP_GLDS_CFG");
     return e ? std::atoi(e) : 0;
@@ -548,25 +567,20 @@ static int glds_cfg() {  // TFPP_GLDS_CFG: tuning switch (stages x wave grid)
 }
 
 int conv_gemm_glds(const tfpp_conv_params& p, hipStream_t st) {
-  const int c = glds_cfg();
-  if (conv_glds_variant(p) == 200) {
+  const int c = glds_cfg(), var = conv_glds_variant(p);
+  if (var == 202) return launch_glds<256, 128, 3, 4, 4, 2>(p, st);  // 16 waves, 3 x 48 KB
+  if (var == 200) {
     switch (c) {
-      case 1: return launch_glds<128, 128, 3, 2, 2>(p, st);
-      case 2: return launch_glds<128, 128, 2, 2, 2>(p, st);
-      case 4: return launch_glds<128, 128, 3, 2, 4>(p, st);
-      case 5: return launch_glds<128, 128, 2, 2, 4>(p, st);
-      case 6: return launch_glds<128, 128, 4, 2, 2>(p, st);
-      case 10: return launch_glds<128, 128, 3, 2, 4, 2>(p, st);  // 64-deep stages (two k-steps per barrier), 3 x 32 KB: measured SLOWER
-                                                                 // (455 vs 498 TFLOP/s on 3840x6048x1512, 320 vs 389 on 12288x576x576)
-      default: return launch_glds<128, 128, 4, 2, 4>(p, st);  // 8 waves: 516 vs 317-390 TFLOP/s on 3840x6048x1512
+      case 1: return launch_glds<128, 128, 4, 2, 4, 1>(p, st);  // round-1 shape: 32-deep stages (half-line requests), 4 x 16 KB
+      case 10: return launch_glds<128, 128, 3, 2, 4, 2>(p, st);  // 3 x 32 KB: one workgroup per CU
+      default: return launch_glds<128, 128, 2, 2, 4, 2>(p, st);  // 8 waves, 2 x 32 KB: two workgroups per CU
     }
   }
   switch (c) {
-    case 2: return launch_glds<64, 128, 2, 2, 2>(p, st);
-    case 6: return launch_glds<64, 128, 4, 2, 2>(p, st);
-    case 7: return launch_glds<64, 128, 8, 2, 2>(p, st);
-    case 8: return launch_glds<64, 128, 6, 2, 2>(p, st);
-    default: return launch_glds<64, 128, 3, 2, 2>(p, st);
+    case 1: return launch_glds<64, 128, 3, 2, 2, 1>(p, st);  // round-1 shape
+    case 31: return launch_glds<64, 128, 2, 2, 2, 2>(p, st);
+    case 32: return launch_glds<64, 128, 4, 2, 2, 2>(p, st);
+    default: return launch_glds<64, 128, 3, 2, 2, 2>(p, st);  // 4 waves, 3 x 24 KB: two workgroups per CU
   }
 }
 

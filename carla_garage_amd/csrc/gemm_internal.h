@@ -3,9 +3,10 @@
 #include <hip/hip_runtime.h>
 #include "../../include/tfpp.h"
 
-// multi-stage LDS-DMA implicit GEMM (gemm_glds.hip), bf16, N >= 128; variant codes 200 (128x128) / 201 (64x128)
+// multi-stage LDS-DMA implicit GEMM (gemm_glds.hip), bf16, N >= 128; variant codes 200 (128x128) / 201 (64x128) / 202 (256x128)
 bool conv_glds_supported(const tfpp_conv_params& p, int dtype);
 int conv_glds_variant(const tfpp_conv_params& p);
+int conv_glds_bm(int variant);  // rows per M-tile
 int conv_gemm_glds(const tfpp_conv_params& p, hipStream_t st);
 
 // 3x3 / stride 1 / pad 1 with the input tile staged once in LDS (conv3x3_halo.hip), bf16, n_g <= 64; variant codes 300 + FN

@@ -323,7 +323,8 @@ static int conv_splits_for(const tfpp_conv_params& p, int dtype) {
   const long M = (long)p.B * p.Hd * p.Wd;
   if (conv_halo_supported(p, dtype)) return 1;
   if (use_glds_impl() && conv_glds_supported(p, dtype)) {
-    const int bm = conv_glds_variant(p) == 200 ? 128 : 64;
+    const int var = conv_glds_variant(p), bm = conv_glds_bm(var);
+    if (var == 202) return 1;  // >= 128 workgroups of 16 waves with >= 16 stages each: splitting K only adds the second pass
     return conv_splits(p, (long)cdiv(M, bm) * cdiv(p.n_g, 128) * p.G, 64);
   }
   static const int bm[4] = {128, 128, 64, 128}, bn[4] = {32, 64, 64, 128};
@@ -356,7 +357,7 @@ extern "C" int tfpp_conv_gemm_stats_rows(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
   const long M = (long)p->B * p->Hd * p->Wd;
   if (conv_halo_supported(*p, dtype)) return conv_halo_mtiles(*p);
-  if (use_glds_impl() && conv_glds_supported(*p, dtype)) return cdiv(M, conv_glds_variant(*p) == 200 ? 128 : 64);
+  if (use_glds_impl() && conv_glds_supported(*p, dtype)) return cdiv(M, conv_glds_bm(conv_glds_variant(*p)));
   static const int bm[4] = {128, 128, 64, 128};
   return cdiv(M, bm[conv_variant(*p)]);
 }

@@ -117,7 +117,7 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
     if var >= 300:
       tile = f'halo8x32x{(var - 300) * 16}'
     elif var >= 200:
-      tile = ('glds128x128', 'glds64x128')[var - 200]
+      tile = ('glds128x128', 'glds64x128', 'glds256x128')[var - 200]
     else:
       tile = ('128x32', '128x64', '64x64', '128x128')[var]
     fam = f'conv_gemm<{"f32" if src.dtype == torch.float32 else "bf16"},{tile}>'

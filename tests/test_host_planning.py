@@ -63,7 +63,9 @@ def test_conv_kernel_selection(L):
   # RegNet stage-3 1x1 conv of the image branch: LDS-DMA ring, 128x128 tiles from 256 tiles on
   assert variant(L, conv(12, 16, 64, 576, 576)) == 200
   assert variant(L, conv(12, 16, 16, 576, 576)) == 201          # LiDAR branch: too few tiles for 128x128
-  assert variant(L, conv(3840, 1, 1, 1512, 6048)) == 200        # fusion MLP
+  assert variant(L, conv(3840, 1, 1, 1512, 6048)) == 202        # fusion MLP: K >= 1024 and >= 128 tiles of 256x128 (16 waves)
+  assert variant(L, conv(3840, 1, 1, 576, 2304)) == 200         # K = 576: too short for the 144 KB ring
+  assert variant(L, conv(12, 8, 32, 1512, 1512)) == 202         # image stage-4 1x1 conv
   assert variant(L, conv(12, 16, 64, 576, 576), F32) in (2, 3)  # fp32 never takes the bf16-only kernels
   assert variant(L, conv(12, 32, 128, 216, 216)) in (0, 1, 2, 3)  # K = 216 < 512: LDS-staged
   # 3x3 stride-1 with few channels per group: LDS-halo kernel (300 + 16-channel output fragments)

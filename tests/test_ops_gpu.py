@@ -142,15 +142,18 @@ def test_conv_fwd_dgrad_wgrad(ops, case, dtype):
 
 
 # The shapes the benchmark (BASELINE config 3: bs = 12, bf16) actually runs, with the kernel variants it runs them on.
-# tfpp_conv_gemm_variant: 200 = 8-wave 128x128 LDS-DMA ring (>= 256 tiles), 201 = 64x128 LDS-DMA, 2 = LDS-staged 64x64 ...
+# tfpp_conv_gemm_variant: 202 = 16-wave 256x128 LDS-DMA ring (K >= 1024, >= 128 tiles), 200 = 8-wave 128x128 (>= 256 tiles), 201 = 64x128,
+# 2 = LDS-staged 64x64 ...
 # weight-gradient plan {variant, slices, second stage}: see tfpp_conv_wgrad_stage.
 TRUE_SHAPES = [
     # name, B, H, W, Cin, Cout, k, stride, groups, expected forward variant, expected dgrad variant
-    (('fusion_mlp_fc1', 3840, 1, 1, 1512, 6048, 1, 1, 1), 200, 200),   # transfuser.py:392 at C = 1512: 3840 x 6048 x 1512
-    (('fusion_mlp_fc2', 3840, 1, 1, 6048, 1512, 1, 1, 1), 200, 200),
-    (('fusion_proj', 3840, 1, 1, 1512, 1512, 1, 1, 1), 200, 200),      # attention projection / QKV slices: 3840 x 1512 x 1512
+    (('fusion_mlp_fc1', 3840, 1, 1, 1512, 6048, 1, 1, 1), 202, 202),   # transfuser.py:392 at C = 1512: 3840 x 6048 x 1512
+    (('fusion_mlp_fc2', 3840, 1, 1, 6048, 1512, 1, 1, 1), 202, 202),
+    (('fusion_proj', 3840, 1, 1, 1512, 1512, 1, 1, 1), 202, 202),      # attention projection / QKV slices: 3840 x 1512 x 1512
+    (('fusion576_mlp_fc1', 3840, 1, 1, 576, 2304, 1, 1, 1), 200, 201),  # the C = 576 transformer: K = 576 is too short for the 144 KB ring; dgrad: 150 tiles
     (('s3_conv1x1', 12, 16, 64, 576, 576, 1, 1, 1), 200, 200),         # image stage-3 1x1 convs: M = 12288, M-major XCD order
-    (('s4_conv1x1', 12, 8, 32, 1512, 1512, 1, 1, 1), 200, 200),        # stage 4: M = 3072
+    (('s4_conv1x1', 12, 8, 32, 1512, 1512, 1, 1, 1), 202, 202),        # stage 4: M = 3072
+    (('lidar_s3_conv1x1', 12, 16, 16, 576, 576, 1, 1, 1), 201, 201),   # LiDAR branch: 64x128 tiles
 ]
 
 
@@ -171,12 +174,13 @@ WGRAD_EXPECT = {'fusion_mlp_fc1': (4, False, 0), 'fusion_mlp_fc2': (4, False, 0)
                 's4_conv1x1': (4, False, 0)}  # (variant, pixel split?, second-stage sum)
 
 
-def test_conv_fused_bn_statistics_on_the_128x128_lds_dma_kernel(ops):
-  """Image stage-3 1x1 conv at bs = 12 (M = 12288, N = K = 576) with the BatchNorm statistics fused into the epilogue of the 8-wave
-  128x128 LDS-DMA kernel (one accumulation row per M-tile, M-major XCD order): raw output and per-channel sum / sum of squares
-  against torch on the CPU, then finalize -> scale/shift/saved statistics against F.batch_norm."""
+@pytest.mark.parametrize('B,H,W,C,variant,bm', [(12, 16, 64, 576, 200, 128), (12, 8, 32, 1512, 202, 256)], ids=['s3_128x128', 's4_256x128'])
+def test_conv_fused_bn_statistics_on_the_lds_dma_kernels(ops, B, H, W, C, variant, bm):
+  """Image stage-3 / stage-4 1x1 convs at bs = 12 (M = 12288, N = K = 576; M = 3072, N = K = 1512) with the BatchNorm statistics fused
+  into the epilogue of the 8-wave 128x128 / 16-wave 256x128 LDS-DMA kernels (one accumulation row per M-tile, M-major XCD order): raw
+  output and per-channel sum / sum of squares against torch on the CPU, then finalize -> scale/shift/saved statistics against
+  F.batch_norm."""
   dtype = torch.bfloat16
-  B, H, W, C = 12, 16, 64, 576
   x = rnd(B, C, H, W, dtype=dtype, seed=41)
   w = (rnd(C, C, 1, 1, dtype=dtype, seed=42) * (1.0 / math.sqrt(C))).to(dtype).float()
   conv = F.conv2d(x, w)
@@ -185,9 +189,9 @@ def test_conv_fused_bn_statistics_on_the_128x128_lds_dma_kernel(ops):
   raw = torch.empty((B, H, W, C), device=DEV, dtype=dtype)
   geo = dict(B=B, Hs=H, Ws=W, Cs=C, Hd=H, Wd=W, Cd=C)
   var, _ = ops.conv_gemm(xd, wp, raw, plan_only=True, **geo)
-  assert var == 200
+  assert var == variant
   nrows, acc = ops.conv_gemm(xd, wp, raw, stats_acc=True, **geo)
-  assert nrows == (B * H * W) // 128
+  assert nrows == (B * H * W) // bm
   torch.cuda.synchronize()
   rows = acc[:nrows * 2 * C].view(nrows, 2, C).double().sum(0).cpu()
   check('bnstats200.raw', nchw(raw.float().cpu()), conv, dtype)
@@ -815,6 +819,7 @@ BNS_CASES = [
     ('lds128x32', 4, 24, 40, 72, 72, 1, 1, 1, 0),        # stage-1 1x1 conv: LDS-staged 128x32 tiles, 3 column tiles
     ('glds128', 12, 16, 64, 576, 576, 1, 1, 1, 200),     # stage-3 1x1 conv at bs = 12: 8-wave LDS-DMA kernel, M-major order
     ('glds64', 4, 16, 16, 576, 576, 1, 1, 1, 201),       # LiDAR branch: 64x128 LDS-DMA tiles
+    ('glds256', 12, 8, 32, 1512, 1512, 1, 1, 1, 202),    # stage-4 1x1 conv at bs = 12: 16-wave 256x128 LDS-DMA kernel
     ('halo', 2, 16, 64, 72, 72, 3, 1, 3, 302),           # grouped 3x3: halo kernel, one row per 8x32 tile
     ('strided', 2, 16, 32, 48, 48, 3, 2, 2, 0),          # stride-2 grouped 3x3 (first block of a stage)
 ]
