@@ -313,7 +313,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wg
 
 template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE> int launch_wgrad_glds(const tfpp_wgrad_params& p, hipStream_t st) {
   const int KK = p.R * p.S * p.ks_g;
-  constexpr size_t lds = (size_t)NSTAGE * BKP * (TM + TN) * 2;
+  // TFPP_WGRAD_MIN_LDS (bytes): occupancy limiter for A/B runs -- weight gradients run beside the latency-bound dY chain of the other
+  // streams; a larger allocation leaves fewer of their workgroups per CU and so more wave slots for that chain.
+  static const size_t min_lds = [] { const char* e = std::getenv("TFPP_WGRAD_MIN_LDS"); return e ? (size_t)std::atol(e) : (size_t)0; }();
+  constexpr size_t need = (size_t)NSTAGE * BKP * (TM + TN) * 2;
+  const size_t lds = need > min_lds ? need : min_lds;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_glds_kernel<TM, TN, WGM, WGN, BKP, NSTAGE>),

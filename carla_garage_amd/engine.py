@@ -314,6 +314,9 @@ class Tape:
     Tape.current = None
 
 
+_SKIP_SIDE_WORK = os.environ.get('TFPP_DEBUG_SKIP_SIDE_WORK', '0') == '1'
+
+
 class SideLane:
   """A second HIP stream for backward work that is off the critical path: weight gradients only feed the optimizer, so
   they trail the dY chain on their own stream and fill the CUs the small latency-bound kernels of the main chain leave
@@ -331,6 +334,8 @@ class SideLane:
     self.pending = []
 
   def run(self, tape, fn, *tensors):
+    if _SKIP_SIDE_WORK:  # timing experiment only (gradients are wrong): how long is the step without any weight-gradient work?
+      return
     if not self.enabled or tape is None or not tensors[0].is_cuda:
       fn()
       return
