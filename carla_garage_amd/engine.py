@@ -403,7 +403,7 @@ class ConvSpec:
   def __init__(self, name, weight, bias=None, bn=None, stride=1, pad=0, groups=1, cin_store=None, head=False):
     self.name = name
     self.weight, self.bias, self.bn = weight, bias, bn
-    w4 = weight if weight.dim() == 4 else weight.view(weight.shape[0], weight.shape[1], 1, 1)
+    w4 = weight if weight.dim() == 4 else weight.view(weight.shape[0], -1, 1, 1)  # Linear [out, in]; Conv3d [out, in, kt, kh, kw] used as a GEMM
     self.cout, self.cin_g, self.k = w4.shape[0], w4.shape[1], w4.shape[2]
     self.stride, self.pad, self.groups = stride, pad, groups
     self.head = head  # fp32 planning-head layer
@@ -448,7 +448,13 @@ class Engine:
     m = self.m
     bb = m.backbone
     self.aim = self.cfg.backbone == 'aim'  # team_code/aim.py: image branch only, no LiDAR branch, no fusion transformers
-    branches = [('image_encoder', bb.image_encoder)] + ([] if self.aim else [('lidar_encoder', bb.lidar_encoder)])
+    self.video = (not self.aim) and getattr(bb, 'lidar_video', False)  # BASELINE config 5: Video-Swin LiDAR branch (swin.py)
+    self.swin = None
+    if self.video:
+      from .swin import VideoSwin
+      self.swin = VideoSwin(self)
+      self.swin.build_specs()
+    branches = [('image_encoder', bb.image_encoder)] + ([] if (self.aim or self.video) else [('lidar_encoder', bb.lidar_encoder)])
     for br, enc in branches:
       p = f'backbone.{br}'
       self._spec(f'{p}.stem', enc['stem'].conv.weight, bn=enc['stem'].bn, stride=2, pad=1, cin_store=8)
@@ -587,7 +593,7 @@ class Engine:
     for s in self.specs.values():
       dt_ = F32 if s.head else dtype
       w = s.weight.detach()
-      w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
+      w4 = w if w.dim() == 4 else w.view(w.shape[0], -1, 1, 1)
       ks_pad = s.cin_store // s.groups
       plain = (dt_ == F32 and s.k == 1 and ks_pad == s.cin_g and s.n_store == s.cout and s.groups == 1)
       if plain:
@@ -1171,26 +1177,45 @@ class Engine:
     else:
       lidar_in = lidar_bev.float().contiguous()
       lanes.hold(lidar_in)
+      nt = bb.lidar_time_frames if self.video else 1  # time frames of the LiDAR feature maps (transfuser.py:50)
       with lanes.fork():  # the LiDAR branch runs on its own stream between the fusion points
-        xl = ops.nchw_to_nhwc_affine(lidar_in, dt_, 8)
-        xl = self.conv(xl, 'backbone.lidar_encoder.stem', act=ACT_RELU, x_grad=False)
+        if self.video:
+          xl = self.swin.stem(lidar_in)  # [B, 3, 64, 64, 96]
+        else:
+          xl = ops.nchw_to_nhwc_affine(lidar_in, dt_, 8)
+          xl = self.conv(xl, 'backbone.lidar_encoder.stem', act=ACT_RELU, x_grad=False)
       xi = self.conv(xi, 'backbone.image_encoder.stem', act=ACT_RELU, x_grad=False)
       for i in range(4):
         with lanes.fork():
-          xl = self.stage(xl, f'backbone.lidar_encoder.s{i + 1}', bb.lidar_encoder[f's{i + 1}'])
+          if self.video:
+            xl = self.swin.layer(i, xl)  # [B, 3, H, W, C]
+            xl = xl.view(B * nt, xl.shape[2], xl.shape[3], xl.shape[4])  # the time frames as batch entries for the 2-D pooling / resampling
+          else:
+            xl = self.stage(xl, f'backbone.lidar_encoder.s{i + 1}', bb.lidar_encoder[f's{i + 1}'])
           lt = self.pool_tokens(xl, cfg.lidar_vert_anchors, cfg.lidar_horz_anchors)
           lt = self.conv(lt, f'backbone.lidar_channel_to_img.{i}')
+          lt = lt.view(B, nt * lt.shape[1], lt.shape[2], lt.shape[3])  # tokens in (t, h, w) order (transfuser.py:319)
         xi = self.stage(xi, f'backbone.image_encoder.s{i + 1}', bb.image_encoder[f's{i + 1}'])
         it = self.pool_tokens(xi, cfg.img_vert_anchors, cfg.img_horz_anchors)
         lanes.join()
         io, lo = self.gpt(i, it, lt)
         lanes.hold(lt, lo)
         with lanes.fork():
-          lo = self.conv(lo, f'backbone.img_channel_to_lidar.{i}')
-          xl = self.upsample_add(lo, xl)
+          lo = self.conv(lo.view(B * nt, lo.shape[1] // nt, lo.shape[2], lo.shape[3]), f'backbone.img_channel_to_lidar.{i}')
+          xl = self.upsample_add(lo, xl)  # trilinear with an unchanged time axis = bilinear per frame (transfuser.py:243-248)
+          if self.video:
+            xl = xl.view(B, nt, xl.shape[1], xl.shape[2], xl.shape[3])
         xi = self.upsample_add(io, xi)
         if i == 2 and self.tape is not None:
           self.tape.mark()  # everything recorded from here on only touches the "early" parameters (finishes_early)
+      if self.video:  # transfuser.py:176-180: average the remaining time frames
+        with lanes.fork():
+          _, _, hh_, ww_, cc_ = xl.shape
+          acc = ops.zeros((B, hh_, ww_, cc_), dt_, dev)
+          for t_ in range(nt):
+            ops.copy_rows(xl, acc, B, hh_ * ww_ * cc_, nt * hh_ * ww_ * cc_, t_ * hh_ * ww_ * cc_, hh_ * ww_ * cc_, 0, accumulate=True)
+          third = self._const(f'time_mean{nt}x{cc_}', lambda: torch.full((cc_,), 1.0 / nt))
+          xl = ops.affine_act(acc, scale=third, shift=self._const(f'zeros{cc_}', lambda: torch.zeros(cc_)))
       lanes.join()
     out['image_feature_grid'], out['fused_features'] = xi, xl
 

@@ -226,7 +226,8 @@ class LidarCenterNet(nn.Module):
     pred_depth = next(it) if cfg.use_depth else None
     bb = None
     if cfg.detect_boxes:
-      bb = tuple(next(it) for _ in self.head.BRANCHES) + (None, None)
+      bb = tuple(next(it) for _ in self.head.BRANCHES)
+      bb = bb + (None,) * (7 - len(bb))  # velocity / brake only exist with temporal input (center_net.py:66-75)
     return pred_wp, pred_ts, pred_cp, pred_sem, pred_bev, pred_depth, bb, None, None, None
 
   def forward(self, rgb, lidar_bev, target_point, ego_vel, command):

@@ -127,32 +127,146 @@ class GPT(nn.Module):
         m.weight.data.fill_(getattr(config, 'gpt_layer_norm_init_weight', 1.0))
 
 
+SWIN3D_TINY = dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window_size=(8, 7, 7), patch_size=(2, 4, 4), mlp_ratio=4)
+
+
+class WindowAttention3D(nn.Module):
+  """Container for team_code/video_swin_transformer.py:87-137: relative_position_bias_table (parameter), relative_position_index
+  (buffer, part of the state_dict), qkv, proj."""
+  forward = _no_forward
+
+  def __init__(self, dim, window_size, num_heads):
+    super().__init__()
+    self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
+    wd, wh, ww = window_size
+    self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1), num_heads))
+    coords = torch.stack(torch.meshgrid(torch.arange(wd), torch.arange(wh), torch.arange(ww), indexing='ij')).flatten(1)  # 3, n
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += wd - 1
+    rel[:, :, 1] += wh - 1
+    rel[:, :, 2] += ww - 1
+    rel[:, :, 0] *= (2 * wh - 1) * (2 * ww - 1)
+    rel[:, :, 1] *= 2 * ww - 1
+    self.register_buffer('relative_position_index', rel.sum(-1))
+    self.qkv = nn.Linear(dim, dim * 3, bias=True)
+    self.proj = nn.Linear(dim, dim)
+    nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
+
+
+class SwinMlp(nn.Module):
+  forward = _no_forward
+
+  def __init__(self, dim, hidden):
+    super().__init__()
+    self.fc1 = nn.Linear(dim, hidden)
+    self.fc2 = nn.Linear(hidden, dim)
+
+
+class SwinBlock3D(nn.Module):
+  forward = _no_forward
+
+  def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio):
+    super().__init__()
+    self.window_size, self.shift_size = window_size, shift_size
+    self.norm1 = nn.LayerNorm(dim)
+    self.attn = WindowAttention3D(dim, window_size, num_heads)
+    self.norm2 = nn.LayerNorm(dim)
+    self.mlp = SwinMlp(dim, int(dim * mlp_ratio))
+
+
+class PatchMerging(nn.Module):
+  forward = _no_forward
+
+  def __init__(self, dim):
+    super().__init__()
+    self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+    self.norm = nn.LayerNorm(4 * dim)
+
+
+class SwinLayer(nn.Module):
+  forward = _no_forward
+
+  def __init__(self, dim, depth, num_heads, window_size, mlp_ratio, downsample):
+    super().__init__()
+    shift = tuple(i // 2 for i in window_size)
+    self.blocks = nn.ModuleList(
+        [SwinBlock3D(dim, num_heads, window_size, (0, 0, 0) if i % 2 == 0 else shift, mlp_ratio) for i in range(depth)])
+    self.downsample = PatchMerging(dim) if downsample else None
+
+
+class PatchEmbed3D(nn.Module):
+  forward = _no_forward
+
+  def __init__(self, patch_size, in_chans, embed_dim):
+    super().__init__()
+    self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+    self.norm = nn.LayerNorm(embed_dim)  # patch_norm=True is the reference's default (video_swin_transformer.py:510)
+
+
+class CustomNorm(nn.Module):
+  forward = _no_forward
+
+  def __init__(self, num_features):
+    super().__init__()
+    self.norm = nn.LayerNorm(num_features)
+
+
+class SwinTransformer3D(nn.Module):
+  """Container for team_code/video_swin_transformer.py:470-585 as transfuser.py:44-50 builds it (Swin-T, in_chans = 1): children
+  patch_embed, layers.layer0..3, norm.  The feature taps transfuser.py iterates (return_layers, :553-560) are layer0..2 (after their
+  PatchMerging) and layer3 + norm: 192 / 384 / 768 / 768 channels at 1/8, 1/16, 1/32, 1/32 resolution, 3 time frames."""
+  forward = _no_forward
+
+  def __init__(self, in_chans=1, arch=None):
+    super().__init__()
+    a = arch or SWIN3D_TINY
+    self.arch = a
+    self.patch_embed = PatchEmbed3D(a['patch_size'], in_chans, a['embed_dim'])
+    self.layers = nn.ModuleDict()
+    n = len(a['depths'])
+    for i in range(n):
+      self.layers[f'layer{i}'] = SwinLayer(a['embed_dim'] * 2**i, a['depths'][i], a['num_heads'][i], a['window_size'], a['mlp_ratio'], i < n - 1)
+    self.num_features = a['embed_dim'] * 2**(n - 1)
+    self.norm = CustomNorm(self.num_features)
+    self.feature_chs = [a['embed_dim'] * 2**min(i + 1, n - 1) for i in range(n)]  # 192, 384, 768, 768
+    # init_weights is never called by the reference (transfuser.py:45-47): nn defaults + the trunc_normal bias tables
+
+
 class TransfuserBackbone(nn.Module):
   """Container for team_code/transfuser.py:16-129 (default 2-D RegNet LiDAR branch)."""
   forward = _no_forward
 
   def __init__(self, config):
     super().__init__()
-    if config.image_architecture != 'regnety_032' or config.lidar_architecture != 'regnety_032':
-      raise ValueError('the MI355X path implements the regnety_032 image / LiDAR branches '
+    if config.image_architecture != 'regnety_032' or config.lidar_architecture not in ('regnety_032', 'video_swin_tiny'):
+      raise ValueError('the MI355X path implements the regnety_032 image branch and the regnety_032 / video_swin_tiny LiDAR branches '
                        f'(got {config.image_architecture} / {config.lidar_architecture})')
     self.config = config
+    self.lidar_video = config.lidar_architecture == 'video_swin_tiny'
     in_ch = config.lidar_seq_len * (2 if config.use_ground_plane else 1)
     self.image_encoder = RegNetY(3)
-    self.lidar_encoder = RegNetY(in_ch)
     widths = REGNETY_032['widths']
-    n_tok = config.img_vert_anchors * config.img_horz_anchors + config.lidar_vert_anchors * config.lidar_horz_anchors
+    if self.lidar_video:  # transfuser.py:44-50,66-81: 3 time frames per scale, Conv3d 1x1x1 channel adapters
+      self.lidar_encoder = SwinTransformer3D(1 + int(config.use_ground_plane))
+      lidar_chs, frames = self.lidar_encoder.feature_chs, 3
+      conv = lambda a, b: nn.Conv3d(a, b, kernel_size=1)
+    else:
+      self.lidar_encoder = RegNetY(in_ch)
+      lidar_chs, frames = widths, 1
+      conv = lambda a, b: nn.Conv2d(a, b, 1)
+    self.lidar_time_frames = frames
+    n_tok = config.img_vert_anchors * config.img_horz_anchors + frames * config.lidar_vert_anchors * config.lidar_horz_anchors
     self.transformers = nn.ModuleList([GPT(c, config, n_tok) for c in widths])
-    self.lidar_channel_to_img = nn.ModuleList([nn.Conv2d(c, c, 1) for c in widths])
-    self.img_channel_to_lidar = nn.ModuleList([nn.Conv2d(c, c, 1) for c in widths])
+    self.lidar_channel_to_img = nn.ModuleList([conv(lc, c) for lc, c in zip(lidar_chs, widths)])
+    self.img_channel_to_lidar = nn.ModuleList([conv(c, lc) for lc, c in zip(lidar_chs, widths)])
     self.num_image_features = widths[-1]
-    self.num_features = widths[-1]
+    self.num_features = lidar_chs[-1]
     self.perspective_upsample_factor = 32 // config.perspective_downsample_factor
     ch = config.bev_features_chanels
     if config.detect_boxes or config.use_bev_semantic:
       self.up_conv5 = nn.Conv2d(ch, ch, 3, padding=1)
       self.up_conv4 = nn.Conv2d(ch, ch, 3, padding=1)
-      self.c5_conv = nn.Conv2d(widths[-1], ch, 1)
+      self.c5_conv = nn.Conv2d(lidar_chs[-1], ch, 1)
 
 
 class AIMBackbone(nn.Module):
@@ -170,7 +284,7 @@ class AIMBackbone(nn.Module):
 
 
 class LidarCenterNetHead(nn.Module):
-  """Container for team_code/center_net.py:23-47 (single-frame: 5 branches)."""
+  """Container for team_code/center_net.py:23-47: 5 branches, plus velocity / brake when the input is temporal (:29-31)."""
   forward = _no_forward
   BRANCHES = ('heatmap', 'wh', 'offset', 'yaw_class', 'yaw_res')
 
@@ -179,6 +293,9 @@ class LidarCenterNetHead(nn.Module):
     self.config = config
     c = config.bb_input_channel
     outs = dict(heatmap=config.num_bb_classes, wh=2, offset=2, yaw_class=config.num_dir_bins, yaw_res=1)
+    if not (config.lidar_seq_len == 1 and config.seq_len == 1):
+      self.BRANCHES = self.BRANCHES + ('velocity', 'brake')
+      outs.update(velocity=1, brake=2)
     for n in self.BRANCHES:
       setattr(self, n + '_head', nn.Sequential(nn.Conv2d(c, c, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(c, outs[n], 1)))
     self.out_channels = outs

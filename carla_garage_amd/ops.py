@@ -606,6 +606,30 @@ def softmax_bwd(p, dp, rows, cols, ld, alpha=1.0, p_drop=0.0, seed=0):
   return dp
 
 
+def patchify3d(x, dtype):
+  """x: fp32 (B, T, H, W) -> [B * T/2 * H/4 * W/4, 32] (video_swin_transformer.py:427-467)."""
+  B, T, H, W = x.shape
+  out = torch.empty((B * (T // 2) * (H // 4) * (W // 4), 32), device=x.device, dtype=dtype)
+  lib.tfpp_patchify3d(ptr(_chk(x)), ptr(out), B, T, H, W, dt(out), stream())
+  return out
+
+
+def gather_rows(src, idx, rows, C, add=None, out=None, src_ld=None, dst_ld=None, dst_off=0):
+  """out[r, dst_off : dst_off + C] = src[idx[r], :C] (zeros where idx[r] < 0) (+ add[r, :C]); idx: int32 device tensor."""
+  if out is None:
+    out = torch.empty((rows, C), device=src.device, dtype=src.dtype)
+  dst_ld = dst_ld or C
+  lib.tfpp_gather_rows(ptr(src), ptr(idx), ptr(add), ptr(out.view(-1)[dst_off:]), rows, C, src_ld or C, dst_ld, C, dt(src), stream())
+  return out
+
+
+def softmax_window_bias(s, table, rel_index, mask, windows, heads, n, alpha, ld=None):
+  """In place on s [windows, heads, n, ld] (video_swin_transformer.py:146-163)."""
+  lib.tfpp_softmax_window_bias(ptr(s), ptr(table), ptr(rel_index), ptr(mask), windows, heads, n, ld or n, mask.shape[0] if mask is not None else 1,
+                               alpha, dt(s), stream())
+  return s
+
+
 def add_dropout(a, b, p_drop=0.0, seed=0, out=None):
   if out is None:
     out = torch.empty_like(b)

@@ -304,6 +304,22 @@ int tfpp_bilinear_bwd(const void* dy, const float* mul, void* dx, int B, int Hi,
                       int64_t dx_ld, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Video-Swin LiDAR backbone (BASELINE config 5; team_code/video_swin_transformer.py, consumed at transfuser.py:44-50,151-155).
+ * patchify3d: im2col of PatchEmbed3D's Conv3d(1, 96, kernel = stride = (2, 4, 4)) (:427-467): x fp32 (B, T, H, W) ->
+ *   rows (b, t/2, h/4, w/4) x 32 values ordered (kt, kh, kw); the projection itself is tfpp_conv_gemm with K = 32.
+ * gather_rows: dst[r][0..C) = (idx[r] >= 0 ? src[idx[r]][0..C) : 0) + (add ? add[r][0..C) : 0).  With index tables built once per
+ *   stage on the host this is F.pad + torch.roll + window_partition of SwinTransformerBlock3D.forward_part1 (:233-249), its inverse
+ *   window_reverse + roll + crop fused with the shortcut add (:250-260,276), and the four strided slices + cat of PatchMerging (:305-309).
+ * softmax_window_bias: WindowAttention3D.forward (:146-163), in place on the scores of `windows` x `heads` matrices of n x n (row pitch
+ *   ld): softmax_j(alpha * s + table[rel_index[i][j]][h] + mask[w % n_mask][i][j]); table = relative_position_bias_table (fp32),
+ *   rel_index = the [:n, :n] corner of relative_position_index as int32, mask = compute_mask's 0 / -100 matrices or NULL.  n <= 256. */
+int tfpp_patchify3d(const float* x, void* out, int B, int T, int H, int W, int dtype, void* stream);
+int tfpp_gather_rows(const void* src, const int32_t* idx, const void* add, void* dst, int64_t rows, int C, int64_t src_ld,
+                     int64_t dst_ld, int64_t add_ld, int dtype, void* stream);
+int tfpp_softmax_window_bias(void* s, const float* table, const int32_t* rel_index, const float* mask, int64_t windows, int heads,
+                             int n, int64_t ld, int n_mask, float alpha, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Token ops: LayerNorm (transfuser.py:388-389,288; nn.TransformerDecoderLayer norms), row softmax with the
  * 1/sqrt(d) scale and attention dropout (transfuser.py:372-374), residual add + dropout (transfuser.py:399-400),
  * positional-embedding add (transfuser.py:325; model.py:302,318), activation gradients, bias gradients.

@@ -123,6 +123,40 @@ def write_aim_golden():
   print('aim: losses', dict(zip(d['loss_names'], d['losses'])), 'params with grad', len(names))
 
 
+SWIN_OVERRIDES = dict(lidar_architecture='video_swin_tiny', lidar_seq_len=6)  # BASELINE config 5
+
+
+def write_swin_golden():
+  """BASELINE config 5: TransFuser++ with the Video-Swin LiDAR branch (team_code/video_swin_transformer.py; 6 LiDAR frames -> 3 time
+  frames per scale, temporal velocity / brake heads) -- eval forward at bs = 1 on the unmodified reference, plus strided taps of the
+  LiDAR branch (patch embedding, every BasicLayer, the fused feature grid) for localising a mismatch."""
+  import dataclasses
+  model, _ = ref_harness.build_reference_model(**SWIN_OVERRIDES)
+  cfg = dataclasses.replace(P.PortConfig(), lidar_seq_len=6)
+  sd = P.generic_state_dict(model.state_dict(), base=P.make_state_dict(P.PortConfig()))
+  model.load_state_dict(sd, strict=True)
+  model.eval()
+  taps = {}
+  enc = model.backbone.lidar_encoder
+
+  def tap(name):
+    return lambda mod, inp, out: taps.__setitem__(name, _np(out)[:, ::8, :, ::4, ::4].copy())
+
+  hooks = [enc.patch_embed.register_forward_hook(tap('swin_patch_embed'))]
+  hooks += [enc.layers[f'layer{i}'].register_forward_hook(tap(f'swin_layer{i}')) for i in range(4)]
+  inp = P.make_inputs(1, cfg)
+  with torch.inference_mode():
+    out = model(*inp)
+  for h in hooks:
+    h.remove()
+  d = pack_outputs(out)
+  d['bb_velocity'], d['bb_brake'] = _np(out[6][5]), _np(out[6][6])
+  d.update(taps)
+  d['keys'] = np.array(list(sd.keys()))
+  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_swin_eval_bs1.npz'), **d)
+  print('swin: target speed logits', d['pred_target_speed'], 'heatmap max', d['bb_heatmap'].max(), {k: v.shape for k, v in taps.items()})
+
+
 def write_train_golden(model, cfg, bs, fname):
   """One train-mode step of the reference at batch size ``bs`` (dropout 0, batch-statistic BN): the 10 losses, per-parameter
   gradient norms + sampled gradient values, the BN running-statistic sums after the step and the small forward outputs."""
@@ -169,6 +203,9 @@ def main():
     sys.exit('needs /root/reference (build container)')
   os.makedirs(GOLDEN, exist_ok=True)
   torch.set_num_threads(os.cpu_count())
+  if only == {'swin'}:
+    write_swin_golden()
+    return
 
   # ---- default TF++ ---------------------------------------------------------------------------
   model, _ = ref_harness.build_reference_model()

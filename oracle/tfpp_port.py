@@ -317,6 +317,39 @@ def make_state_dict(cfg=None, seed=0):
   return sd
 
 
+def generic_state_dict(model_sd, base=None, seed=0):
+  """Deterministic randomised values for ANY state_dict schema (configurations beyond the default TransFuser++ one, e.g. the Video-Swin
+  LiDAR branch of BASELINE config 5): keys present in ``base`` with the same shape keep their values, integer buffers are kept as they
+  are, every other tensor is drawn from oracle/detrand.py by a rule on its name and shape."""
+  out = {}
+  for k, v in model_sd.items():
+    shape = tuple(v.shape)
+    if base is not None and k in base and tuple(base[k].shape) == shape:
+      out[k] = base[k]
+    elif not v.dtype.is_floating_point:
+      out[k] = v.clone()
+    elif k in ('valid_bev_pixels', 'valid_bev_pixels_inv'):
+      out[k] = v.clone()
+    else:
+      if k.endswith('relative_position_bias_table'):
+        t = detrand.uniform(k, shape, -0.5, 0.5, seed)
+      elif 'running_var' in k:
+        t = detrand.uniform(k, shape, 0.6, 1.6, seed)
+      elif len(shape) == 1 and k.endswith('.weight'):
+        t = detrand.uniform(k, shape, 0.6, 1.4, seed)  # normalisation gains
+      elif k.endswith('.bias') or len(shape) <= 1:
+        t = detrand.uniform(k, shape, -0.1, 0.1, seed)
+      elif 'pos_emb' in k:
+        t = detrand.uniform(k, shape, -0.05, 0.05, seed)
+      elif 'query' in k or 'embed' in k:
+        t = detrand.uniform(k, shape, 0.0, 1.0, seed)
+      else:
+        a = math.sqrt(3.0 / int(np.prod(shape[1:])))
+        t = detrand.uniform(k, shape, -a, a, seed)
+      out[k] = torch.from_numpy(t).reshape(shape)
+  return out
+
+
 def make_inputs(batch, cfg=None, seed=1234):
   """Synthetic camera + LiDAR batch of SURVEY.md §8(d) (value ranges of team_code/train.py:750,
   team_code/data.py:887-889), generated with oracle/detrand.py."""

@@ -234,6 +234,52 @@ def test_wp_variant_forward():
   assert out[1] is None and out[2] is None
 
 
+def _swin_model(dtype):
+  """BASELINE config 5: TransFuser++ with the Video-Swin LiDAR branch (6 LiDAR frames), deterministic weights by name."""
+  cfg = GlobalConfig(lidar_architecture='video_swin_tiny', lidar_seq_len=6, tfpp_dtype=dtype)
+  m = LidarCenterNet(cfg)
+  m.load_state_dict(P.generic_state_dict(m.state_dict(), base=P.make_state_dict(P.PortConfig())), strict=True)
+  return m.cuda().eval(), dataclasses.replace(P.PortConfig(), lidar_seq_len=6)
+
+
+@pytest.mark.gpu
+def test_video_swin_eval_forward_fp32_vs_reference_golden():
+  """team_code/video_swin_transformer.py through the HIP path (carla_garage_amd/swin.py) against the unmodified reference
+  (tests/golden/tfpp_swin_eval_bs1.npz, oracle/make_golden.py swin): the taps of the LiDAR branch, then the model outputs incl. the
+  temporal velocity / brake heads, 1e-3 relative (north_star)."""
+  g = U.load_golden('tfpp_swin_eval_bs1.npz')
+  m, pc = _swin_model('fp32')
+  assert list(m.state_dict().keys()) == [str(k) for k in g['keys']]
+  eng = m._engine()
+  eng.swin.taps = {}
+  with torch.inference_mode():
+    out = m(*[x.cuda() for x in P.make_inputs(1, pc)])
+  errs = {}
+  for name, t in eng.swin.taps.items():  # (B, D, H, W, C) -> the golden's (B, C, D, H, W) strided view
+    got = U.to_np(t.float().permute(0, 4, 1, 2, 3))[:, ::8, :, ::4, ::4]
+    errs[name] = U.rel_err(got, g[name])
+  errs['pred_target_speed'] = U.rel_err(U.to_np(out[1]), g['pred_target_speed'])
+  errs['pred_checkpoint'] = U.rel_err(U.to_np(out[2]), g['pred_checkpoint'])
+  for i, n in enumerate(('heatmap', 'wh', 'offset', 'yaw_class', 'yaw_res', 'velocity', 'brake')):
+    errs['bb_' + n] = U.rel_err(U.to_np(out[6][i]), g['bb_' + n])
+  errs['pred_bev_semantic'] = U.rel_err(U.to_np(out[4])[:, :, ::U.BEV_STRIDE, ::U.BEV_STRIDE], g['pred_bev_semantic_strided'])
+  errs['pred_semantic'] = U.rel_err(U.to_np(out[3])[:, :, ::U.SEM_STRIDE, ::U.SEM_STRIDE], g['pred_semantic_strided'])
+  _report('swin_eval_fp32_bs1', errs)
+  assert max(errs.values()) <= 1e-3, errs
+
+
+@pytest.mark.gpu
+def test_video_swin_eval_forward_bf16_close_to_fp32_reference():
+  g = U.load_golden('tfpp_swin_eval_bs1.npz')
+  m, pc = _swin_model('bf16')
+  with torch.inference_mode():
+    out = m(*[x.cuda() for x in P.make_inputs(1, pc)])
+  errs = {'pred_target_speed': U.rel_err(U.to_np(out[1]), g['pred_target_speed']), 'pred_checkpoint': U.rel_err(U.to_np(out[2]), g['pred_checkpoint']),
+          'bb_heatmap': U.rel_err(U.to_np(out[6][0]), g['bb_heatmap'])}
+  _report('swin_eval_bf16_bs1', errs)
+  assert max(errs.values()) <= 5e-2, errs
+
+
 def _zero_dropout(m):
   for mod in m.modules():
     if isinstance(mod, torch.nn.Dropout):
