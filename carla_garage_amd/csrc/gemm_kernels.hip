@@ -634,6 +634,40 @@ extern "C" int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stre
   return TFPP_EINVAL;
 }
 
+// Workspace the dispatcher would like for one call (the library never allocates, the caller passes workspace in):
+// the plan is made as if the workspace were unlimited and its size returned; a smaller (or no) workspace only reduces the number of
+// K / pixel slices.  op 0: tfpp_conv_gemm split-K slices (tfpp_conv_params.splitk_ws), op 1: tfpp_conv_wgrad pixel slices
+// (tfpp_wgrad_params.ws), op 2: BatchNorm scratch for C = *(const int*)params channels, op 3: column-sum scratch for C channels.
+extern "C" int tfpp_workspace_bytes(int op, const void* params, int dtype, int64_t* bytes_out) {
+  if (!params || !bytes_out) return TFPP_EINVAL;
+  *bytes_out = 0;
+  if (op == 0) {
+    tfpp_conv_params q = *static_cast<const tfpp_conv_params*>(params);
+    q.splitk_ws = reinterpret_cast<float*>(16);
+    q.splitk_ws_floats = (int64_t)1 << 60;
+    const int sp = conv_splits_for(q, dtype);
+    if (sp > 1) *bytes_out = (int64_t)sp * q.B * q.Hd * q.Wd * q.G * q.n_g * 4;
+    return 0;
+  }
+  if (op == 1) {
+    tfpp_wgrad_params q = *static_cast<const tfpp_wgrad_params*>(params);
+    q.ws = reinterpret_cast<float*>(16);
+    q.ws_floats = (int64_t)1 << 60;
+    WgradPlan pl;
+    const int rc = dtype == TFPP_F32 ? plan_wgrad<float>(q, pl) : plan_wgrad<bf16_t>(q, pl);
+    if (rc != 0) return rc;
+    if (pl.reduce) *bytes_out = (int64_t)pl.splits * q.G * q.n_g * q.R * q.S * q.ks_g * 4;
+    return 0;
+  }
+  if (op == 2 || op == 3) {
+    const int C = *static_cast<const int*>(params);
+    if (C < 1) return TFPP_EINVAL;
+    *bytes_out = (int64_t)(op == 2 ? tfpp_bn_scratch_floats(C) : tfpp_reduce_scratch_floats(1, C)) * 4;
+    return 0;
+  }
+  return TFPP_EINVAL;
+}
+
 // The same in separately launchable pieces (per-kernel timing in bench.py): stage 1 = first-stage kernel, 2 = slice sum,
 // -1 = plan only.  plan_out[3] = {variant (0 LDS 32x32, 1 LDS 64x64, 2 LDS-DMA ring 64x64, 3 3x3 halo, 4 LDS-DMA ring 128x128), slices, has second stage}.
 extern "C" int tfpp_conv_wgrad_stage(const tfpp_wgrad_params* p, int dtype, int stage, int* plan_out, void* stream) {

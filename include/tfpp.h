@@ -122,6 +122,12 @@ typedef struct {
   int64_t ws_floats;
 } tfpp_wgrad_params;
 int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stream);
+/* Preferred workspace of one call in bytes (the library never allocates): the size at which the dispatcher's plan is not
+ * limited by the workspace.  op 0: split-K slices of tfpp_conv_gemm (params = tfpp_conv_params, field splitk_ws); op 1: pixel slices of
+ * tfpp_conv_wgrad (params = tfpp_wgrad_params, field ws); op 2 / 3: BatchNorm / column-sum scratch for C = *(const int*)params channels.
+ * A smaller workspace is legal everywhere: the kernels then use fewer slices (or atomics). */
+int tfpp_workspace_bytes(int op, const void* params, int dtype, int64_t* bytes_out);
+
 /* the same call in separately launchable pieces (per-kernel timing): stage 1 = first-stage kernel, 2 = slice sum, -1 = plan only;
  * plan_out[3] (nullable) = {variant: 0 LDS-staged 32x32, 1 LDS-staged 64x64, 2 LDS-DMA ring 64x64, 3 3x3 halo, 4 LDS-DMA ring 128x128
  * (8 waves); slices; has second stage} */

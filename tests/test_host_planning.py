@@ -139,3 +139,26 @@ def test_pack_plan_modes_and_workgroups(L):
   assert d.a[7] == 0
   d = desc(2, 70 * 96, (70, 96, 1))                                # transposed pack2d
   assert plan(ctypes.byref(d)) == 2 * 3 and d.a[7] == 2
+
+
+def test_workspace_bytes_is_the_size_of_the_unconstrained_plan(L):
+  """tfpp_workspace_bytes: slices x output of the plan the dispatcher makes when the workspace does not limit it."""
+  def ws(op, p, dt=BF16):
+    out = ctypes.c_int64(-1)
+    L.tfpp_workspace_bytes(op, ctypes.byref(p), dt, ctypes.byref(out))  # raises TfppError on a non-zero return code
+    return out.value
+
+  p = conv(12, 8, 8, 1512, 128, k=3, ws=False)  # K = 13608 over 6 output tiles: split-K
+  p2 = conv(12, 8, 8, 1512, 128, k=3)
+  p2.splitk_ws_floats = 1 << 40
+  s = splits(L, p2)
+  assert s > 1 and ws(0, p) == s * 12 * 8 * 8 * 128 * 4
+  assert ws(0, conv(3840, 1, 1, 1512, 6048)) == 0  # 720 workgroups: no K split, no workspace
+  w = wgrad(12, 16, 64, 576, 576, ws=False)
+  w2 = wgrad(12, 16, 64, 576, 576)
+  w2.ws_floats = 1 << 40
+  plan = wplan(L, w2)
+  assert plan[1] > 1 and plan[2] == 1 and ws(1, w) == plan[1] * 576 * 576 * 4
+  assert ws(1, wgrad(3840, 1, 1, 1512, 6048)) == 0  # 576 tiles of 128x128: one slice, written straight into the gradient
+  c = ctypes.c_int(576)
+  assert ws(2, c) == L.raw('tfpp_bn_scratch_floats')(576) * 4 and ws(3, c) == L.raw('tfpp_reduce_scratch_floats')(1, 576) * 4

@@ -1,0 +1,69 @@
+"""Rotated-box IoU / greedy NMS (carla_garage_amd/postprocess.py) -- transfuser_utils.py:409-450.  The reference needs shapely, which is
+not installed here, so these are known-answer and property tests: closed-form overlaps, a dense point-sampling estimate of
+random rotated pairs, and the suppression order of the reference's loop restated on the IoU matrix."""
+import math
+
+import numpy as np
+
+from carla_garage_amd.postprocess import iou_bbs, non_maximum_suppression, rect_corners
+
+
+def test_iou_known_answers():
+  a = [0.0, 0.0, 1.0, 2.0, 0.3]
+  assert abs(iou_bbs(a, a) - 1.0) < 1e-12
+  assert iou_bbs([0, 0, 1, 1, 0.0], [5, 0, 1, 1, 0.7]) == 0.0
+  # axis-aligned 2x2 squares shifted by 1: intersection 2, union 6
+  assert abs(iou_bbs([0, 0, 1, 1, 0.0], [1, 0, 1, 1, 0.0]) - 2.0 / 6.0) < 1e-12
+  # the same square turned by 45 degrees: the intersection is a regular octagon of area 8 (sqrt 2 - 1)
+  oct_area = 8.0 * (math.sqrt(2.0) - 1.0)
+  assert abs(iou_bbs([0, 0, 1, 1, 0.0], [0, 0, 1, 1, math.pi / 4]) - oct_area / (8.0 - oct_area)) < 1e-12
+  # half extents: width 2 / height 1 box inside a 4 x 4 one -> 8 / 64
+  assert abs(iou_bbs([0, 0, 2, 1, 0.0], [0, 0, 4, 4, 0.0]) - 8.0 / 64.0) < 1e-12
+  # a quarter turn swaps the extents
+  assert abs(iou_bbs([0, 0, 2, 1, math.pi / 2], [0, 0, 1, 2, 0.0]) - 1.0) < 1e-9
+
+
+def _inside(pts, corners):
+  ok = np.ones(len(pts), bool)
+  for i in range(4):
+    a, b = corners[i], corners[(i + 1) % 4]
+    ok &= (b[0] - a[0]) * (pts[:, 1] - a[1]) - (b[1] - a[1]) * (pts[:, 0] - a[0]) >= 0
+  return ok
+
+
+def test_iou_against_point_sampling_and_symmetry():
+  rng = np.random.RandomState(0)
+  g = np.linspace(-8, 8, 1601)
+  pts = np.stack(np.meshgrid(g, g), -1).reshape(-1, 2)
+  for _ in range(12):
+    b1 = [rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(0.5, 2.5), rng.uniform(0.5, 2.5), rng.uniform(-math.pi, math.pi)]
+    b2 = [rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(0.5, 2.5), rng.uniform(0.5, 2.5), rng.uniform(-math.pi, math.pi)]
+    ia, ib = _inside(pts, rect_corners(*b1)), _inside(pts, rect_corners(*b2))
+    est = (ia & ib).sum() / max((ia | ib).sum(), 1)
+    got = iou_bbs(b1, b2)
+    assert abs(got - est) < 5e-3, (got, est)
+    assert abs(got - iou_bbs(b2, b1)) < 1e-12 and 0.0 <= got <= 1.0
+
+
+def test_nms_follows_the_reference_loop():
+  rng = np.random.RandomState(1)
+  groups = []
+  for _ in range(3):  # three "models", six boxes each, clustered so that many overlap
+    groups.append([np.array([rng.normal(0, 2.0), rng.normal(0, 2.0), 1.0 + rng.rand(), 2.0 + rng.rand(), rng.uniform(-0.3, 0.3), 0.0, 0.0, 0.0,
+                             rng.rand()]) for _ in range(6)])
+  thr = 0.2
+  kept = non_maximum_suppression(groups, thr)
+  flat = [b for g in groups for b in g]
+  conf = np.array([b[-1] for b in flat])
+  idx = list(np.argsort(conf))  # the reference's bookkeeping (transfuser_utils.py:417-429) on indices
+  want = []
+  while idx:
+    cur = idx.pop()
+    want.append(cur)
+    idx = [j for j in idx if iou_bbs(flat[cur], flat[j]) <= thr]
+  assert [float(b[-1]) for b in kept] == [float(conf[i]) for i in want]
+  assert all(kept[i][-1] >= kept[i + 1][-1] for i in range(len(kept) - 1))
+  for i in range(len(kept)):
+    for j in range(i + 1, len(kept)):
+      assert iou_bbs(kept[i], kept[j]) <= thr
+  assert non_maximum_suppression([[], []], thr) == []
