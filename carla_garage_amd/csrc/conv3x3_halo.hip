@@ -10,19 +10,25 @@
 // With Cin_g = 32 the 64 lanes of a fragment read 1 KB of contiguous LDS (conflict-free); weight rows are skewed by 16 B.
 // One barrier per workgroup (after staging); 4 waves x (2 rows x 32 pixels) x FN 16-channel fragments.
 // Data gradient (mode 1) at stride 1 is the same gather with the tap offsets negated (the caller passes the transposed pack).
+// GEO 1 / 2 (round 2): the stride-2 3x3 convs that open every RegNet stage.  Forward: the 8 x 32 OUTPUT tile reads a 17 x 65 input halo
+// and the pixel -> LDS address map is scaled by 2.  Data gradient: dx = stride-1 correlation of the ZERO-STUFFED dy (Z[2a][2b] = dy[a][b])
+// with the same transposed pack, so only the loader changes (3 of 4 halo pixels are zeros; the layers are HBM-bound, the idle MFMA
+// work is free).  The implicit GEMM ran these at 119 / 242 us (stage 1, bs = 12) against a 28 us HBM bound.
 #include "gemm_core.cuh"
 #include "gemm_internal.h"
 #include <cstdlib>
 
 namespace {
-constexpr int TH = 8, TW = 32, HH = TH + 2, HWID = TW + 2;
+constexpr int TH = 8, TW = 32;
+template <int GEO> struct HaloGeo { static constexpr int HH = GEO == 1 ? 2 * TH + 1 : TH + 2, HWID = GEO == 1 ? 2 * TW + 1 : TW + 2; };
 
 // CV = Cin_g / 8 at compile time (0: run-time loop): with CV known the staging loops are fully unrolled, so a thread issues all of
 // its ~11 global loads before the first LDS store instead of paying one memory latency per 16-byte chunk.
-template <int FN, int CV, bool BNS = false>
+template <int FN, int CV, bool BNS = false, int GEO = 0>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, int tiles_w, int tiles_h, int ksteps_rt) {
   typedef bf16_t T;
-  constexpr int FM = 4;
+  constexpr int FM = 4, HH = HaloGeo<GEO>::HH, HWID = HaloGeo<GEO>::HWID;
+  static_assert(!(BNS && GEO != 0), "the statistics epilogue exists for the stride-1 geometry only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cin = CV ? CV * 8 : p.ks_g, cv = cin >> 3, K = 9 * cin;
@@ -45,9 +51,18 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
   auto halo_chunk = [&](int q) {
     const int pix = q / cv, c = q - pix * cv;
     const int hr = pix / HWID, hc = pix - hr * HWID;
-    const int h = h0 + hr - 1, w = w0 + hc - 1;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (h >= 0 && h < H && w >= 0 && w < W) v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * H + h) * W + w) * p.src_ld + c * 8);
+    if constexpr (GEO == 0) {
+      const int h = h0 + hr - 1, w = w0 + hc - 1;
+      if (h >= 0 && h < H && w >= 0 && w < W) v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * H + h) * W + w) * p.src_ld + c * 8);
+    } else if constexpr (GEO == 1) {  // forward, stride 2: input pixel (2 h0 - 1 + hr, 2 w0 - 1 + hc) of the Hs x Ws source
+      const int h = 2 * h0 + hr - 1, w = 2 * w0 + hc - 1;
+      if (h >= 0 && h < p.Hs && w >= 0 && w < p.Ws) v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.Hs + h) * p.Ws + w) * p.src_ld + c * 8);
+    } else {  // data gradient, stride 2: the zero-stuffed gradient Z[2a][2b] = dy[a][b]
+      const int hz = h0 + hr - 1, wz = w0 + hc - 1;
+      if (hz >= 0 && wz >= 0 && !((hz | wz) & 1) && (hz >> 1) < p.Hs && (wz >> 1) < p.Ws)
+        v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.Hs + (hz >> 1)) * p.Ws + (wz >> 1)) * p.src_ld + c * 8);
+    }
     return v;
   };
   auto weight_chunk = [&](int q) {
@@ -90,7 +105,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
   const int p16 = lane & 15, kg = lane >> 4;
   int a_pix[FM];
 #pragma unroll
-  for (int i = 0; i < FM; ++i) a_pix[i] = (2 * wave + (i >> 1) + 1) * HWID + (i & 1) * 16 + p16 + 1;
+  for (int i = 0; i < FM; ++i)
+    a_pix[i] = GEO == 1 ? 2 * (2 * wave + (i >> 1)) * HWID + 2 * ((i & 1) * 16 + p16) + HWID + 1  // centre tap of output pixel (row, col)
+                        : (2 * wave + (i >> 1) + 1) * HWID + (i & 1) * 16 + p16 + 1;
   const int sgn = p.mode == 0 ? 1 : -1;
   for (int j = 0; j < ksteps; ++j) {
     const int kk0 = j * 32 + kg * 8;
@@ -206,15 +223,35 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
   }
 }
 
+int halo_geo(const tfpp_conv_params& p) { return p.stride == 1 ? 0 : (p.mode == 0 ? 1 : 2); }
+
 size_t halo_lds_bytes(const tfpp_conv_params& p, int fn) {
   const int ksteps = (9 * p.ks_g + 31) / 32;
-  return (size_t)HH * HWID * p.ks_g * 2 + (size_t)fn * 16 * (ksteps * 32 + 8) * 2;
+  const int hpix = halo_geo(p) == 1 ? HaloGeo<1>::HH * HaloGeo<1>::HWID : HaloGeo<0>::HH * HaloGeo<0>::HWID;
+  return (size_t)hpix * p.ks_g * 2 + (size_t)fn * 16 * (ksteps * 32 + 8) * 2;
 }
 
 template <int FN, int CV> int launch_halo(const tfpp_conv_params& p, hipStream_t st) {
   const int tiles_w = cdiv(p.Wd, TW), tiles_h = cdiv(p.Hd, TH), ksteps = (9 * p.ks_g + 31) / 32;
   const size_t lds = halo_lds_bytes(p, FN);
   dim3 grid((unsigned)(tiles_w * tiles_h * p.B), (unsigned)p.G);
+  const int geo = halo_geo(p);
+  if (geo != 0) {
+    if constexpr (FN <= 2 && (CV == 0 || CV == 3)) {  // RegNet group width 24 (unrolled staging) or the run-time loop
+      if (p.bns_partial) return TFPP_EINVAL;
+      static bool attr_set = false;
+      if (!attr_set) {  // the 17 x 65 input halo of the stride-2 forward needs > 64 KB with 24 channels
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<FN, CV, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+        attr_set = true;
+      }
+      if (geo == 1) hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, false, 1>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
+      else hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, false, 2>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
+      TFPP_CHECK_LAUNCH();
+      return 0;
+    } else {
+      return TFPP_EINVAL;  // conv_halo_supported does not route such shapes here
+    }
+  }
   if (p.bns_partial) hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, true>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
   else hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, false>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
   TFPP_CHECK_LAUNCH();
@@ -222,6 +259,7 @@ template <int FN, int CV> int launch_halo(const tfpp_conv_params& p, hipStream_t
 }
 
 template <int FN> int launch_halo_cv(const tfpp_conv_params& p, hipStream_t st) {
+  if (p.stride != 1) return (p.ks_g >> 3) == 3 ? launch_halo<FN, 3>(p, st) : launch_halo<FN, 0>(p, st);
   switch (p.ks_g >> 3) {  // the channel counts of this model get the unrolled staging; anything else the run-time loop
     case 1: return launch_halo<FN, 1>(p, st);
     case 2: return launch_halo<FN, 2>(p, st);
@@ -237,9 +275,15 @@ template <int FN> int launch_halo_cv(const tfpp_conv_params& p, hipStream_t st) 
 bool conv_halo_supported(const tfpp_conv_params& p, int dtype) {
   static const int on = [] { const char* e = std::getenv("TFPP_CONV_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
   if (!on || dtype != TFPP_BF16) return false;
-  if (p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || p.Hs != p.Hd || p.Ws != p.Wd) return false;
+  if (p.R != 3 || p.S != 3 || p.pad != 1) return false;
   if (p.ks_g % 8 || p.src_ld % 8 || p.n_g > 64 || p.Wd < 32 || p.Hd < 4) return false;
   const int fn = p.n_g <= 16 ? 1 : (p.n_g <= 32 ? 2 : 4);
+  if (p.stride == 2) {  // even feature maps only: forward Hs = 2 Hd, data gradient Hd = 2 Hs (TFPP_CONV_HALO_S2=0: implicit GEMM)
+    static const int s2 = [] { const char* e = std::getenv("TFPP_CONV_HALO_S2"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool geo_ok = p.mode == 0 ? (p.Hs == 2 * p.Hd && p.Ws == 2 * p.Wd) : (p.Hd == 2 * p.Hs && p.Wd == 2 * p.Ws);
+    return s2 && geo_ok && fn <= 2 && !p.bns_partial && halo_lds_bytes(p, fn) <= 120 * 1024;
+  }
+  if (p.stride != 1 || p.Hs != p.Hd || p.Ws != p.Wd) return false;
   return halo_lds_bytes(p, fn) <= 65536;
 }
 

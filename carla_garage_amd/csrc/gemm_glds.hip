@@ -509,10 +509,11 @@ template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1> static int l
   constexpr bool HAS_PW = true;
   static bool attr_set = false;
   if (!attr_set) {
+    constexpr bool BNS_OK = (WGM * WGN <= 8);
     const void* fns[4] = {reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, false, false>),
-                          reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, true, false>),
+                          reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, BNS_OK, false>),
                           reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, false, HAS_PW>),
-                          reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, true, HAS_PW>)};
+                          reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, BNS_OK, HAS_PW>)};
     for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -527,8 +528,11 @@ template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1> static int l
   const bool pw = HAS_PW && pw_env && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.Hs == p.Hd && p.Ws == p.Wd &&
                   M * (long)p.src_ld * 2 < (1l << 32) && w_bytes < (1l << 32);
 #define TFPP_GLDS_LAUNCH(BNS_, PW_) hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, BNS_, PW_>), grid, dim3(WGM * WGN * 64), lds, st, p, trace, m_major)
-  if (pw) { if (p.bns_partial) TFPP_GLDS_LAUNCH(true, HAS_PW); else TFPP_GLDS_LAUNCH(false, HAS_PW); }
-  else { if (p.bns_partial) TFPP_GLDS_LAUNCH(true, false); else TFPP_GLDS_LAUNCH(false, false); }
+  // 16-wave workgroups (128 VGPRs per lane) have no room for the statistics accumulators: conv_glds_variant does not pick them then
+  constexpr bool HAS_BNS = (WGM * WGN <= 8);
+  if (p.bns_partial && !HAS_BNS) return TFPP_EINVAL;
+  if (pw) { if (p.bns_partial) TFPP_GLDS_LAUNCH(HAS_BNS, HAS_PW); else TFPP_GLDS_LAUNCH(false, HAS_PW); }
+  else { if (p.bns_partial) TFPP_GLDS_LAUNCH(HAS_BNS, false); else TFPP_GLDS_LAUNCH(false, false); }
 #undef TFPP_GLDS_LAUNCH
   TFPP_CHECK_LAUNCH();
   return 0;
@@ -548,7 +552,7 @@ int conv_glds_variant(const tfpp_conv_params& p) {
   // 3072x1512x1512 484 / 453, 12288x576x576 535 / 530, 3840x2304x576 406 / 468.
   static const int min_k256 = [] { const char* e = std::getenv("TFPP_GLDS_256_MIN_K"); return e ? std::atoi(e) : 1024; }();
   const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
-  if (pointwise && K >= min_k256 && (long)cdiv(M, 256) * cdiv(p.n_g, 128) * p.G >= 128) return 202;
+  if (pointwise && K >= min_k256 && (long)cdiv(M, 256) * cdiv(p.n_g, 128) * p.G >= 128 && !p.bns_partial) return 202;
   return tiles >= min_tiles ? 200 : 201;
 }
 int conv_glds_bm(int variant) { return variant == 202 ? 256 : (variant == 200 ? 128 : 64); }

@@ -230,14 +230,25 @@ static int launch_conv(const tfpp_conv_params& p, hipStream_t st) {
 }
 
 // tile choice: minimise padded N work, prefer wide tiles; small problems get 64x64 tiles for more workgroups.
-// 0: 128x32   1: 128x64   2: 64x64   3: 128x128
+// 0: 128x32   1: 128x64   2: 64x64   3: 128x128   4: 128x96 (8 waves of 32x48)
+static const int kConvBm[5] = {128, 128, 64, 128, 128}, kConvBn[5] = {32, 64, 64, 128, 96};
 static int conv_variant(const tfpp_conv_params& p) {
   const long M = (long)p.B * p.Hd * p.Wd;
   const int N = p.n_g;
+  // 72 channels (RegNet stage 1) in ONE 96-wide tile: with 3 x 32 the activation tile is fetched by three workgroups and the launch has
+  // three times the workgroups for the same bytes (HBM-bound layers: K = 32..216); bf16 only (fp32 LDS budget), TFPP_CONV_96=0: 3 x 32
+  static const int use96 = [] { const char* e = std::getenv("TFPP_CONV_96"); return (e && e[0] == '0') ? 0 : 1; }();
+  // (not with the BatchNorm-backward statistics epilogue: its cross-lane reduction needs a power-of-two number of chunks per row)
+  if (N > 64 && N <= 96 && use96 && M >= 4096 && !p.bns_partial) return 4;
   if (N <= 32 || (N > 64 && N <= 96)) return 0;  // 24/32 -> one tile, 72 -> 3 x 32
   if (N <= 64) return 1;
   const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128) * p.G;
   return tiles128 < 1024 ? 2 : 3;  // latency-bound regime: keep >= 4 workgroups per CU in flight
+}
+
+static int conv_variant_for(const tfpp_conv_params& p, int dtype) {
+  const int v = conv_variant(p);
+  return (v == 4 && dtype != TFPP_BF16) ? 0 : v;
 }
 
 // Second stage of split-K: dst = epilogue(sum_s ws[s][m][ch]); 4 channels per thread.
@@ -299,8 +310,7 @@ extern "C" int tfpp_conv_gemm_mtiles(const tfpp_conv_params* p) {
     const int a = conv_halo_mtiles(*p), b = cdiv((long)p->B * p->Hd * p->Wd, 64);
     return a > b ? a : b;
   }
-  static const int bm[4] = {128, 128, 64, 128};
-  return cdiv((long)p->B * p->Hd * p->Wd, bm[conv_variant(*p)]);  // only an upper bound for the row count is needed
+  return cdiv((long)p->B * p->Hd * p->Wd, kConvBm[conv_variant(*p)]);  // (variant 4 and 0 share BM) only an upper bound for the row count is needed
 }
 
 // TFPP_CONV_GLDS=0 disables the multi-stage LDS-DMA kernel (gemm_glds.hip) for A/B measurements
@@ -316,7 +326,7 @@ extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
   if (conv_halo_supported(*p, dtype)) return conv_halo_variant(*p);
   if (use_glds_impl() && conv_glds_supported(*p, dtype)) return conv_glds_variant(*p);
-  return conv_variant(*p);
+  return conv_variant_for(*p, dtype);
 }
 
 static int conv_splits_for(const tfpp_conv_params& p, int dtype) {
@@ -327,9 +337,8 @@ static int conv_splits_for(const tfpp_conv_params& p, int dtype) {
     if (var == 202) return 1;  // >= 128 workgroups of 16 waves with >= 16 stages each: splitting K only adds the second pass
     return conv_splits(p, (long)cdiv(M, bm) * cdiv(p.n_g, 128) * p.G, 64);
   }
-  static const int bm[4] = {128, 128, 64, 128}, bn[4] = {32, 64, 64, 128};
-  const int v = conv_variant(p);
-  return conv_splits(p, (long)cdiv(M, bm[v]) * cdiv(p.n_g, bn[v]) * p.G, dtype == TFPP_BF16 ? 64 : 32);
+  const int v = conv_variant_for(p, dtype);
+  return conv_splits(p, (long)cdiv(M, kConvBm[v]) * cdiv(p.n_g, kConvBn[v]) * p.G, dtype == TFPP_BF16 ? 64 : 32);
 }
 
 extern "C" int tfpp_conv_gemm_splits(const tfpp_conv_params* p, int dtype) {
@@ -358,8 +367,7 @@ extern "C" int tfpp_conv_gemm_stats_rows(const tfpp_conv_params* p, int dtype) {
   const long M = (long)p->B * p->Hd * p->Wd;
   if (conv_halo_supported(*p, dtype)) return conv_halo_mtiles(*p);
   if (use_glds_impl() && conv_glds_supported(*p, dtype)) return cdiv(M, conv_glds_bm(conv_glds_variant(*p)));
-  static const int bm[4] = {128, 128, 64, 128};
-  return cdiv(M, bm[conv_variant(*p)]);
+  return cdiv(M, kConvBm[conv_variant_for(*p, dtype)]);
 }
 
 template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStream_t st) {
@@ -376,7 +384,12 @@ template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStr
   int rc;
   if (use_glds_impl() && conv_glds_supported(p, ElemTraits<T>::DT)) rc = conv_gemm_glds(q, st);
   else {
-    switch (conv_variant(p)) {
+    switch (conv_variant_for(p, ElemTraits<T>::DT)) {
+      case 4:
+        if constexpr (sizeof(T) == 2) {
+          rc = launch_conv<T, 128, 96, 32, 48>(q, st);  // (64x96 tiles measured the same: 24.1 vs 24.7 us on 196608x72x72)
+          break;
+        }
       case 0: rc = launch_conv<T, 128, 32, 32, 32>(q, st); break;
       case 1: rc = launch_conv<T, 128, 64, 64, 32>(q, st); break;
       case 2: rc = launch_conv<T, 64, 64, 32, 32>(q, st); break;

@@ -574,7 +574,7 @@ extern "C" int tfpp_layernorm_fwd(const void* x, const float* gamma, const float
 // dx only: the parameter gradients are a separate column reduction (layernorm_param_grad_kernel), which keeps this kernel's
 // live state to the row itself (g, xhat, gamma) instead of two more per-channel accumulators.
 template <typename T, int LN_MAXV>
-__global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                      const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx, long rows, int C,
                                      int rows_per_wave) {
   constexpr int VEC = ElemTraits<T>::VEC;

@@ -92,6 +92,7 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
   p.splitk_ws, p.splitk_ws_floats, p.splitk = ptr(ws), ws.numel(), 0
   if bns_query:  # (can the kernel that runs here emit the fused BatchNorm-backward statistics?, rows of bns_partial it would write)
     p.bns_ld = Cd
+    p.bns_partial = 16  # never dereferenced: plan as the launch with the statistics will be planned (tile variant, no split-K)
     return bool(lib.raw('tfpp_conv_gemm_bns_ok')(ctypes.byref(p), dt(src))), lib.raw('tfpp_conv_gemm_stats_rows')(ctypes.byref(p), dt(src))
   if bns is not None:  # fused BatchNorm-backward statistics of the tensor whose gradient this call completes (tfpp.h)
     p.bns_y, p.bns_x, p.bns_mean, p.bns_invstd = ptr(bns['y']), ptr(bns['x']), ptr(bns['mean']), ptr(bns['invstd'])
@@ -119,7 +120,7 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
     elif var >= 200:
       tile = ('glds128x128', 'glds64x128', 'glds256x128')[var - 200]
     else:
-      tile = ('128x32', '128x64', '64x64', '128x128')[var]
+      tile = ('128x32', '128x64', '64x64', '128x128', '128x96')[var]
     fam = f'conv_gemm<{"f32" if src.dtype == torch.float32 else "bf16"},{tile}>'
     if PROFILE_SHAPES:
       fam += f' m{mode} M={B * Hd * Wd} N={p.n_g} K={R * S * p.ks_g} G={G} k{R}s{stride}'

@@ -73,7 +73,9 @@ def test_conv_kernel_selection(L):
   assert variant(L, conv(12, 256, 1024, 32, 8, k=3)) == 301
   assert variant(L, conv(12, 16, 64, 576, 576, k=3, G=24)) == 302
   assert variant(L, conv(12, 16, 64, 576, 576, k=3, G=24, mode=1)) == 302
-  assert variant(L, conv(12, 32, 128, 216, 216, k=3, stride=2, G=9)) < 100   # stride 2: implicit GEMM
+  assert variant(L, conv(12, 32, 128, 216, 216, k=3, stride=2, G=9)) == 302  # stride 2, even maps: halo kernel with a 17 x 65 input halo
+  assert variant(L, conv(12, 16, 64, 216, 216, k=3, stride=2, G=9, mode=1)) < 100  # its data gradient as built here (Hd = Hs/2) is not a stride-2 transpose
+  assert variant(L, conv(12, 33, 128, 216, 216, k=3, stride=2, G=9)) < 100   # odd height: implicit GEMM
   assert variant(L, conv(12, 8, 8, 1512, 128, k=3)) >= 200 and variant(L, conv(12, 8, 8, 1512, 128, k=3)) < 300  # W < 32: no halo tiles
 
 

@@ -21,6 +21,8 @@ SHAPES = [
     ('lid_s4_1x1 768x1512x1512', 12, 8, 8, 1512, 1512, 1, 1, 1),
     ('s2_1x1 49152x216x216', 12, 32, 128, 216, 216, 1, 1, 1),
     ('s1_1x1 196608x72x72', 12, 64, 256, 72, 72, 1, 1, 1),
+    ('s1_in 786432x72x32', 12, 128, 512, 32, 72, 1, 1, 1),
+    ('s1_conv3 196608x72x216?', 12, 64, 256, 216, 72, 1, 1, 1),
     ('s3_g3x3 12288 g24', 12, 16, 64, 576, 576, 3, 1, 24),
     ('dec_3x3 3.1Mx32x288', 12, 256, 1024, 32, 32, 3, 1, 1),
     ('head_3x3 49152x64x576', 12, 64, 64, 64, 64, 3, 1, 1),

@@ -30,8 +30,11 @@ def table(path):
       raise RuntimeError(r.stderr[-2000:])
     s = open(s_path).read()
   rows = []
-  for m in re.finditer(r'\.amdhsa_kernel (\S+).*?; NumVgprs: (\d+)\n; NumAgprs: (\d+)\n; TotalNumVgprs: (\d+)\n; ScratchSize: (\d+)\n.*?; Occupancy: (\d+)\n.*?; LDSByteSize: (\d+)', s, re.S):
-    rows.append((m.group(1),) + tuple(int(v) for v in m.groups()[1:]))
+  # per kernel: .amdhsa_kernel NAME ... ; NumVgprs / NumAgprs / TotalNumVgprs / ScratchSize ... ; LDSByteSize ... ; Occupancy (in this order)
+  for blk in s.split('.amdhsa_kernel ')[1:]:
+    name = blk.split(None, 1)[0]
+    g = lambda key: int(re.search(r'; ' + key + r': (\d+)', blk).group(1))
+    rows.append((name, g('NumVgprs'), g('NumAgprs'), g('TotalNumVgprs'), g('ScratchSize'), g('Occupancy'), g('LDSByteSize')))
   return rows
 
 
