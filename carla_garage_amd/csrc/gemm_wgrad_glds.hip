@@ -41,7 +41,11 @@ template <int T> __device__ __forceinline__ int swz(int p);
 template <> __device__ __forceinline__ int swz<64>(int p) { return 2 * ((p >> 1) & 1) + 4 * ((p >> 3) & 1); }
 template <> __device__ __forceinline__ int swz<128>(int p) { return 2 * (p & 3) + 8 * ((p >> 3) & 1); }
 
-template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE>
+// PW: pointwise layers (every linear / 1x1 conv: all but the 3x3 heads) take a lean pixel loop -- scalar loop control, 32-bit running byte
+// offsets against the uniform operand bases, out-of-tile channels clamped into the row instead of redirected to the zero page (they only
+// feed gradient rows / columns that are never stored), the zero page only for the pixel tail of the last stage.  The general loop
+// spends ~110 non-MFMA instructions per 16 MFMAs (run-time pointwise / tap branches, 64-bit pointer selects).
+template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE, bool PW = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wgrad_params p) {
   typedef bf16_t T;
   constexpr int NT = WGM * WGN * 64, NWAVES = WGM * WGN;
@@ -96,6 +100,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wg
       tile_n = m_long ? ts : tl;
     }
   }
+  if constexpr (PW) {  // the divisions above run on the vector ALU: the results are wave-uniform (scalar loop control below)
+    g = __builtin_amdgcn_readfirstlane(g); split = __builtin_amdgcn_readfirstlane(split);
+    tile_m = __builtin_amdgcn_readfirstlane(tile_m); tile_n = __builtin_amdgcn_readfirstlane(tile_n);
+  }
   const int bm0 = tile_m * TM, bn0 = tile_n * TN;
   const long P = (long)p.B * p.Hd * p.Wd;
   const long per = ((P + p.splits - 1) / p.splits + BKP - 1) / BKP * BKP;
@@ -106,78 +114,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wg
   const T* zero = reinterpret_cast<const T*>(tfpp_zero_page);
   const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)smem;
 
-  // this thread's chunks of every stage: DMA i of the workgroup fills bytes [i*NT*16, (i+1)*NT*16) of the stage half, thread tid the
-  // 16 bytes at slot q = i*NT + tid -> pixel row pk = q / CH, physical chunk cp = q % CH, logical chunk cp ^ swz(pk).
-  // Addressing is incremental: every chunk keeps a running source pointer that advances by one stage (BKP pixels) per issue -- two
-  // VALU adds per DMA instead of a 64-bit multiply-add plus range checks (the first version spent ~130 VALU and ~150 SALU
-  // instructions per stage there, against 16 MFMAs: SQ_INSTS_VALU / SQ_INSTS_MFMA = 8.1).  Chunks outside the tile (channel >= n_g,
-  // column >= KK) point at the zero page with step 0; pixels past the end of the slice exist only in the last stage and are
-  // masked there.  3x3 / strided layers (no constant stride between stages) keep per-stage address generation, in 32-bit arithmetic.
-  const bool pointwise = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
   const int hw = p.Hd * p.Wd;
   const int npix = (int)(p_end - p_beg);             // pixels of this slice (> 0 when nst > 0)
   const int tail = npix - (nst - 1) * BKP;           // valid pixel rows of the last stage (1 .. BKP)
-  int a_pk[A_INST];
-  const T* a_cur[A_INST];
-  long a_step[A_INST];
-#pragma unroll
-  for (int i = 0; i < A_INST; ++i) {
-    const int q = i * NT + tid;
-    a_pk[i] = q / CH_A;
-    const int n = bm0 + (((q % CH_A) ^ swz<TM>(a_pk[i])) * 8);  // dY channel of the chunk
-    const bool ok = n < p.n_g;
-    a_cur[i] = ok ? dy + (size_t)(p_beg + a_pk[i]) * p.dy_ld + n : zero;
-    a_step[i] = ok ? (long)BKP * p.dy_ld : 0;
-  }
-  int b_pk[B_INST], b_c[B_INST], b_r[B_INST], b_s[B_INST];
-  bool b_ok[B_INST];
-  const T* b_cur[B_INST];
-  long b_step[B_INST];
-#pragma unroll
-  for (int j = 0; j < B_INST; ++j) {
-    const int q = j * NT + tid;
-    b_pk[j] = q / CH_B;
-    const int kk = bn0 + (((q % CH_B) ^ swz<TN>(b_pk[j])) * 8);  // gathered column (tap, channel) of the chunk
-    b_ok[j] = kk < KK;
-    const int rs = b_ok[j] ? kk / p.ks_g : 0;
-    b_c[j] = kk - rs * p.ks_g;
-    b_r[j] = rs / p.S;
-    b_s[j] = rs - b_r[j] * p.S;
-    const bool lin = pointwise && b_ok[j];
-    b_cur[j] = lin ? x + (size_t)(p_beg + b_pk[j]) * p.x_ld + b_c[j] : zero;
-    b_step[j] = lin ? (long)BKP * p.x_ld : 0;
-  }
-
-  auto issue = [&](int st) {  // LDS-DMA of pixel stage st into ring slot st % NSTAGE; called with st = 0, 1, 2, ... in order
-    const unsigned stage = lds_base + (unsigned)((st % NSTAGE) * STAGE_BYTES);
-    const bool last = (st == nst - 1) && tail < BKP;  // wave-uniform
-#pragma unroll
-    for (int i = 0; i < A_INST; ++i) {
-      const T* ga = a_cur[i];
-      if (last && a_pk[i] >= tail) ga = zero;
-      a_cur[i] += a_step[i];
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)ga, (lds_void_t*)(stage + (unsigned)((i * NWAVES + wave) * 1024)), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < B_INST; ++j) {
-      const T* gb = b_cur[j];
-      if (pointwise) {
-        if (last && b_pk[j] >= tail) gb = zero;
-        b_cur[j] += b_step[j];
-      } else {
-        gb = zero;
-        const int pl = st * BKP + b_pk[j];  // pixel inside the slice
-        if (pl < npix && b_ok[j]) {
-          const unsigned pix = (unsigned)(p_beg + pl);  // P < 2^31 (checked by the dispatcher)
-          const unsigned b = pix / (unsigned)hw, rem = pix - b * (unsigned)hw, hd = rem / (unsigned)p.Wd, wd = rem - hd * (unsigned)p.Wd;
-          const int hs = (int)hd * p.stride - p.pad + b_r[j], ws = (int)wd * p.stride - p.pad + b_s[j];
-          if (hs >= 0 && hs < p.Hs && ws >= 0 && ws < p.Ws) gb = x + ((size_t)((int)b * p.Hs + hs) * p.Ws + ws) * p.x_ld + b_c[j];
-        }
-      }
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)gb, (lds_void_t*)(stage + (unsigned)(A_BYTES + (j * NWAVES + wave) * 1024)), 16, 0, 0);
-    }
-  };
-
   f32x4_t acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -200,21 +139,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wg
     b_off[j] = (unsigned)(A_BYTES + prow * ROW_B + ((c ^ swz<TN>(prow)) * 16) + (m16 & 1) * 8);
   }
 
-#pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < nst) issue(s);
-
-  for (int st = 0; st < nst; ++st) {
-    const int ahead = (nst - 1 - st) < (NSTAGE - 2) ? (nst - 1 - st) : (NSTAGE - 2);
-    switch (ahead) {  // wave-uniform
-#define TFPP_WAIT_CASE(A) case A: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A) * LOADS) : "memory"); break
-      TFPP_WAIT_CASE(0); TFPP_WAIT_CASE(1); TFPP_WAIT_CASE(2); TFPP_WAIT_CASE(3); TFPP_WAIT_CASE(4); TFPP_WAIT_CASE(5); TFPP_WAIT_CASE(6);
-#undef TFPP_WAIT_CASE
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();  // stage st landed for every wave; every wave is done with stage st-1
-    if (st + NSTAGE - 1 < nst) issue(st + NSTAGE - 1);
-    const unsigned stage = lds_base + (unsigned)((st % NSTAGE) * STAGE_BYTES);
+  auto stage_mma = [&](unsigned stage) {
     // all transpose reads of the stage are issued up front (DS operations retire in order): the MFMAs of k-step ks start once its
     // own (FM + FN) * 2 reads have landed, while the reads of the later k-steps are still in flight
     u32x2_t lo[KS][FM + FN], hi[KS][FM + FN];
@@ -261,6 +186,171 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wg
 #pragma unroll
         for (int j = 0; j < FN; ++j) frag_mma(fa[i], fb[j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  if constexpr (PW) {
+    const int nst_u = __builtin_amdgcn_readfirstlane(nst);
+    const char* a_base = reinterpret_cast<const char*>(dy);
+    const char* b_base = reinterpret_cast<const char*>(x);
+    unsigned a_vo[A_INST], b_vo[B_INST];
+    bool a_tz[A_INST], b_tz[B_INST];  // pixel row beyond the slice in the last stage
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+      const int q = i * NT + tid, pk = q / CH_A;
+      int n = bm0 + (((q % CH_A) ^ swz<TM>(pk)) * 8);
+      n = n < p.n_g ? n : p.n_g - 8;  // (n_g % 8 == 0) finite data of this row; feeds gradient rows that are never stored
+      a_vo[i] = ((unsigned)(p_beg + pk) * (unsigned)p.dy_ld + (unsigned)n) * 2u;
+      a_tz[i] = pk >= tail;
+    }
+#pragma unroll
+    for (int j = 0; j < B_INST; ++j) {
+      const int q = j * NT + tid, pk = q / CH_B;
+      int kk = bn0 + (((q % CH_B) ^ swz<TN>(pk)) * 8);
+      kk = kk < KK ? kk : KK - 8;
+      b_vo[j] = ((unsigned)(p_beg + pk) * (unsigned)p.x_ld + (unsigned)kk) * 2u;
+      b_tz[j] = pk >= tail;
+    }
+    const unsigned a_step = (unsigned)BKP * (unsigned)p.dy_ld * 2u, b_step = (unsigned)BKP * (unsigned)p.x_ld * 2u;
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+    const unsigned ring_end = lds_base + NSTAGE * STAGE_BYTES;
+    auto issue = [&](unsigned stage, bool last) {  // `last` is wave-uniform; both variants issue LOADS loads per thread, in the same order
+      if (!last) {
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i) {
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_base + a_vo[i]), (lds_void_t*)(stage + (i * NWAVES + wave_u) * 1024u), 16, 0, 0);
+          a_vo[i] += a_step;
+        }
+#pragma unroll
+        for (int j = 0; j < B_INST; ++j) {
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_base + b_vo[j]), (lds_void_t*)(stage + A_BYTES + (j * NWAVES + wave_u) * 1024u), 16, 0, 0);
+          b_vo[j] += b_step;
+        }
+      } else {  // pixel rows past the end of the slice contribute nothing: both operands read the zero page there
+        const char* zp = reinterpret_cast<const char*>(tfpp_zero_page);
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i)
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_tz[i] ? zp : a_base + a_vo[i]), (lds_void_t*)(stage + (i * NWAVES + wave_u) * 1024u), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < B_INST; ++j)
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_tz[j] ? zp : b_base + b_vo[j]), (lds_void_t*)(stage + A_BYTES + (j * NWAVES + wave_u) * 1024u), 16, 0, 0);
+      }
+    };
+    const bool ptail = tail < BKP;  // wave-uniform
+    unsigned wr = lds_base, rd = lds_base;
+#pragma unroll
+    for (int s2 = 0; s2 < NSTAGE - 1; ++s2)
+      if (s2 < nst_u) { issue(wr, ptail && s2 == nst_u - 1); wr += STAGE_BYTES; }
+    int st = 0;
+#pragma unroll 1
+    for (; st + NSTAGE - 1 < nst_u; ++st) {  // steady state: NSTAGE - 2 younger stages stay in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LOADS) : "memory");
+      __builtin_amdgcn_s_barrier();  // stage st landed for every wave; every wave is done with stage st - 1, whose slot is refilled now
+      issue(wr, ptail && st + NSTAGE - 1 == nst_u - 1);
+      wr += STAGE_BYTES;
+      if (wr == ring_end) wr = lds_base;
+      stage_mma(rd);
+      rd += STAGE_BYTES;
+      if (rd == ring_end) rd = lds_base;
+    }
+#pragma unroll 1
+    for (; st < nst_u; ++st) {  // drain
+      switch (nst_u - 1 - st) {  // wave-uniform, <= NSTAGE - 2
+#define TFPP_WAIT_CASE(A) case A: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A) * LOADS) : "memory"); break
+        TFPP_WAIT_CASE(1); TFPP_WAIT_CASE(2); TFPP_WAIT_CASE(3); TFPP_WAIT_CASE(4); TFPP_WAIT_CASE(5); TFPP_WAIT_CASE(6);
+#undef TFPP_WAIT_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      stage_mma(rd);
+      rd += STAGE_BYTES;
+      if (rd == ring_end) rd = lds_base;
+    }
+  } else {
+    // this thread's chunks of every stage: DMA i of the workgroup fills bytes [i*NT*16, (i+1)*NT*16) of the stage half, thread tid the
+    // 16 bytes at slot q = i*NT + tid -> pixel row pk = q / CH, physical chunk cp = q % CH, logical chunk cp ^ swz(pk).
+    // Addressing is incremental: every chunk keeps a running source pointer that advances by one stage (BKP pixels) per issue -- two
+    // VALU adds per DMA instead of a 64-bit multiply-add plus range checks (the first version spent ~130 VALU and ~150 SALU
+    // instructions per stage there, against 16 MFMAs: SQ_INSTS_VALU / SQ_INSTS_MFMA = 8.1).  Chunks outside the tile (channel >= n_g,
+    // column >= KK) point at the zero page with step 0; pixels past the end of the slice exist only in the last stage and are
+    // masked there.  3x3 / strided layers (no constant stride between stages) keep per-stage address generation, in 32-bit arithmetic.
+    const bool pointwise = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
+    int a_pk[A_INST];
+    const T* a_cur[A_INST];
+    long a_step[A_INST];
+  #pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+      const int q = i * NT + tid;
+      a_pk[i] = q / CH_A;
+      const int n = bm0 + (((q % CH_A) ^ swz<TM>(a_pk[i])) * 8);  // dY channel of the chunk
+      const bool ok = n < p.n_g;
+      a_cur[i] = ok ? dy + (size_t)(p_beg + a_pk[i]) * p.dy_ld + n : zero;
+      a_step[i] = ok ? (long)BKP * p.dy_ld : 0;
+    }
+    int b_pk[B_INST], b_c[B_INST], b_r[B_INST], b_s[B_INST];
+    bool b_ok[B_INST];
+    const T* b_cur[B_INST];
+    long b_step[B_INST];
+  #pragma unroll
+    for (int j = 0; j < B_INST; ++j) {
+      const int q = j * NT + tid;
+      b_pk[j] = q / CH_B;
+      const int kk = bn0 + (((q % CH_B) ^ swz<TN>(b_pk[j])) * 8);  // gathered column (tap, channel) of the chunk
+      b_ok[j] = kk < KK;
+      const int rs = b_ok[j] ? kk / p.ks_g : 0;
+      b_c[j] = kk - rs * p.ks_g;
+      b_r[j] = rs / p.S;
+      b_s[j] = rs - b_r[j] * p.S;
+      const bool lin = pointwise && b_ok[j];
+      b_cur[j] = lin ? x + (size_t)(p_beg + b_pk[j]) * p.x_ld + b_c[j] : zero;
+      b_step[j] = lin ? (long)BKP * p.x_ld : 0;
+    }
+
+    auto issue = [&](int st) {  // LDS-DMA of pixel stage st into ring slot st % NSTAGE; called with st = 0, 1, 2, ... in order
+      const unsigned stage = lds_base + (unsigned)((st % NSTAGE) * STAGE_BYTES);
+      const bool last = (st == nst - 1) && tail < BKP;  // wave-uniform
+  #pragma unroll
+      for (int i = 0; i < A_INST; ++i) {
+        const T* ga = a_cur[i];
+        if (last && a_pk[i] >= tail) ga = zero;
+        a_cur[i] += a_step[i];
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)ga, (lds_void_t*)(stage + (unsigned)((i * NWAVES + wave) * 1024)), 16, 0, 0);
+      }
+  #pragma unroll
+      for (int j = 0; j < B_INST; ++j) {
+        const T* gb = b_cur[j];
+        if (pointwise) {
+          if (last && b_pk[j] >= tail) gb = zero;
+          b_cur[j] += b_step[j];
+        } else {
+          gb = zero;
+          const int pl = st * BKP + b_pk[j];  // pixel inside the slice
+          if (pl < npix && b_ok[j]) {
+            const unsigned pix = (unsigned)(p_beg + pl);  // P < 2^31 (checked by the dispatcher)
+            const unsigned b = pix / (unsigned)hw, rem = pix - b * (unsigned)hw, hd = rem / (unsigned)p.Wd, wd = rem - hd * (unsigned)p.Wd;
+            const int hs = (int)hd * p.stride - p.pad + b_r[j], ws = (int)wd * p.stride - p.pad + b_s[j];
+            if (hs >= 0 && hs < p.Hs && ws >= 0 && ws < p.Ws) gb = x + ((size_t)((int)b * p.Hs + hs) * p.Ws + ws) * p.x_ld + b_c[j];
+          }
+        }
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)gb, (lds_void_t*)(stage + (unsigned)(A_BYTES + (j * NWAVES + wave) * 1024)), 16, 0, 0);
+      }
+    };
+
+  #pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+      if (s < nst) issue(s);
+
+    for (int st = 0; st < nst; ++st) {
+      const int ahead = (nst - 1 - st) < (NSTAGE - 2) ? (nst - 1 - st) : (NSTAGE - 2);
+      switch (ahead) {  // wave-uniform
+  #define TFPP_WAIT_CASE(A) case A: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A) * LOADS) : "memory"); break
+        TFPP_WAIT_CASE(0); TFPP_WAIT_CASE(1); TFPP_WAIT_CASE(2); TFPP_WAIT_CASE(3); TFPP_WAIT_CASE(4); TFPP_WAIT_CASE(5); TFPP_WAIT_CASE(6);
+  #undef TFPP_WAIT_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();  // stage st landed for every wave; every wave is done with stage st-1
+      if (st + NSTAGE - 1 < nst) issue(st + NSTAGE - 1);
+      stage_mma(lds_base + (unsigned)((st % NSTAGE) * STAGE_BYTES));
     }
   }
 
@@ -320,12 +410,20 @@ template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE> int launch_wgra
   const size_t lds = need > min_lds ? need : min_lds;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_glds_kernel<TM, TN, WGM, WGN, BKP, NSTAGE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_glds_kernel<TM, TN, WGM, WGN, BKP, NSTAGE, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_glds_kernel<TM, TN, WGM, WGN, BKP, NSTAGE, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   dim3 grid((unsigned)((long)p.G * p.splits * cdiv(p.n_g, TM) * cdiv(KK, TN)));
-  hipLaunchKernelGGL((conv_wgrad_glds_kernel<TM, TN, WGM, WGN, BKP, NSTAGE>), grid, dim3(WGM * WGN * 64), lds, st, p);
+  // lean loop: pointwise layer whose operand byte offsets fit 32 bits (TFPP_WGRAD_PW=0: the general loop, for A/B runs)
+  static const int pw_env = [] { const char* e = std::getenv("TFPP_WGRAD_PW"); return e ? std::atoi(e) : 1; }();
+  const long P = (long)p.B * p.Hd * p.Wd;
+  const bool pw = pw_env && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.Hs == p.Hd && p.Ws == p.Wd && p.n_g >= 8 && KK >= 8 &&
+                  (P + 2 * BKP) * (long)p.dy_ld * 2 < (1l << 32) && (P + 2 * BKP) * (long)p.x_ld * 2 < (1l << 32);
+  if (pw) hipLaunchKernelGGL((conv_wgrad_glds_kernel<TM, TN, WGM, WGN, BKP, NSTAGE, true>), grid, dim3(WGM * WGN * 64), lds, st, p);
+  else hipLaunchKernelGGL((conv_wgrad_glds_kernel<TM, TN, WGM, WGN, BKP, NSTAGE, false>), grid, dim3(WGM * WGN * 64), lds, st, p);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -348,6 +446,14 @@ bool wgrad_glds128_preferred(const tfpp_wgrad_params& p) {
 }
 
 int conv_wgrad_glds(const tfpp_wgrad_params& p, int tile, hipStream_t st) {
-  if (tile == 128) return launch_wgrad_glds<128, 128, 2, 4, 64, 3>(p, st);
+  static const int cfg = [] { const char* e = std::getenv("TFPP_WGRAD_CFG"); return e ? std::atoi(e) : 0; }();
+  if (tile == 128) {
+    // two rings of 2 x 32 KB share a CU when the launch has at least ~2 workgroups per CU (fusion MLP 3840x6048x1512: 561 vs 477 TFLOP/s);
+    // with fewer workgroups the deeper 3 x 32 KB ring of a lone workgroup wins (3840x1512x1512, 144 workgroups: 331 vs 281)
+    const long wgs = (long)p.G * p.splits * cdiv(p.n_g, 128) * cdiv(p.R * p.S * p.ks_g, 128);
+    if (cfg == 1 || (cfg == 0 && wgs >= 400)) return launch_wgrad_glds<128, 128, 2, 4, 64, 2>(p, st);
+    return launch_wgrad_glds<128, 128, 2, 4, 64, 3>(p, st);
+  }
+  if (cfg == 2) return launch_wgrad_glds<64, 64, 2, 2, 64, 3>(p, st);  // 64-pixel stages
   return launch_wgrad_glds<64, 64, 2, 2, 32, 4>(p, st);
 }
