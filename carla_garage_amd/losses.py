@@ -11,7 +11,13 @@ from . import ops
 from .engine import F32, EPS_F32
 
 LOSS_ORDER = ('loss_wp', 'loss_target_speed', 'loss_checkpoint', 'loss_semantic', 'loss_bev_semantic', 'loss_depth',
-              'loss_center_heatmap', 'loss_wh', 'loss_offset', 'loss_yaw_class', 'loss_yaw_res')
+              'loss_center_heatmap', 'loss_wh', 'loss_offset', 'loss_yaw_class', 'loss_yaw_res', 'loss_velocity', 'loss_brake')
+BB_LOSSES = ('loss_center_heatmap', 'loss_wh', 'loss_offset', 'loss_yaw_class', 'loss_yaw_res', 'loss_velocity', 'loss_brake')
+
+
+def temporal(cfg):
+  """center_net.py:29-31,119-123: velocity / brake heads and losses exist when the input has more than one frame."""
+  return not (cfg.lidar_seq_len == 1 and cfg.seq_len == 1)
 
 
 def active_losses(cfg):
@@ -28,6 +34,8 @@ def active_losses(cfg):
     names.append('loss_depth')
   if cfg.detect_boxes:
     names += ['loss_center_heatmap', 'loss_wh', 'loss_offset', 'loss_yaw_class', 'loss_yaw_res']
+    if temporal(cfg):
+      names += ['loss_velocity', 'loss_brake']
   return names
 
 
@@ -85,7 +93,7 @@ def _one_loss(model, name, t, labels, slot, weight, want_grad, af_sum):
     ops.reg_loss(p, labels['depth_label'].contiguous(), slot, B=B, C=1, HW=H * W, ld=ld, kind=0, weight=weight, dpred=d)
     return p, d
   # CenterNet head
-  idx = {'loss_center_heatmap': 0, 'loss_wh': 1, 'loss_offset': 2, 'loss_yaw_class': 3, 'loss_yaw_res': 4}[name]
+  idx = BB_LOSSES.index(name)
   p = t['bb'][idx]
   d = grad_like(p)
   B, H, W, ld = p.shape
@@ -99,6 +107,12 @@ def _one_loss(model, name, t, labels, slot, weight, want_grad, af_sum):
     ops.reg_loss(p, labels['offset_label'].contiguous(), slot, C=2, kind=0, elem_weight=pw, wC=2, denom_mul=2.0, **common)
   elif name == 'loss_yaw_res':
     ops.reg_loss(p, labels['yaw_res_label'].contiguous(), slot, C=1, kind=1, elem_weight=pw, wC=2, w_bcast=True, **common)
+  elif name == 'loss_velocity':  # L1 * pixel_weight[:, 0:1] / avg_factor (center_net.py:120)
+    ops.reg_loss(p, labels['velocity_label'].contiguous(), slot, C=1, kind=0, elem_weight=pw, wC=2, w_bcast=True, **common)
+  elif name == 'loss_brake':     # CE over 2 classes * pixel_weight[:, 0] / avg_factor (center_net.py:121)
+    ws = torch.empty(2, device=dev, dtype=F32)
+    ops.ce_loss(p, labels['brake_target_label'], slot, ws, rows=B * H * W, C=2, ld=ld, HW=H * W, pix_weight=pw,
+                pw_bstride=2 * H * W, denom=af_sum, denom_eps=EPS_F32, weight=weight, dpred=d)
   else:
     ws = torch.empty(2, device=dev, dtype=F32)
     ops.ce_loss(p, labels['yaw_class_label'], slot, ws, rows=B * H * W, C=cfg.num_dir_bins, ld=ld, HW=H * W, pix_weight=pw,
@@ -153,13 +167,13 @@ def reference_form_losses(model, args):
     raise RuntimeError('compute_loss must follow forward() of the same model (no stand-alone PyTorch loss path)')
   cfg = model.config
   label_keys = ('waypoint_label', 'target_speed_label', 'checkpoint_label', 'semantic_label', 'bev_semantic_label', 'depth_label',
-                'center_heatmap_label', 'wh_label', 'yaw_class_label', 'yaw_res_label', 'offset_label', 'pixel_weight_label',
-                'avg_factor_label')
+                'center_heatmap_label', 'wh_label', 'yaw_class_label', 'yaw_res_label', 'offset_label', 'velocity_label',
+                'brake_target_label', 'pixel_weight_label', 'avg_factor_label')
   labels = {k: args[k] for k in label_keys if args.get(k) is not None}
   callers = {'loss_wp': args['pred_wp'], 'loss_target_speed': args['pred_target_speed'], 'loss_checkpoint': args['pred_checkpoint'],
              'loss_semantic': args['pred_semantic'], 'loss_bev_semantic': args['pred_bev_semantic'], 'loss_depth': args['pred_depth']}
   if cfg.detect_boxes:
-    for i, n in enumerate(('loss_center_heatmap', 'loss_wh', 'loss_offset', 'loss_yaw_class', 'loss_yaw_res')):
+    for i, n in enumerate(BB_LOSSES[:7 if temporal(cfg) else 5]):
       callers[n] = args['pred_bounding_box'][i]
   # the fused kernels read the internal (NHWC) tensors of the last forward: refuse predictions that are not the tensors that
   # forward returned (a second forward in between, post-processed / re-ordered predictions) instead of silently using others

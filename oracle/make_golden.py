@@ -53,8 +53,9 @@ def pack_outputs(out):
   for name, a in (('pred_semantic', sem), ('pred_bev_semantic', bev), ('pred_depth', dep)):
     d[name + '_sum'] = np.array([a.astype(np.float64).sum(), np.abs(a.astype(np.float64)).sum()])
     d[name + '_rowsum'] = a.astype(np.float64).sum(axis=-1).astype(np.float32)  # catches any mis-placed row
-  for i, name in enumerate(('heatmap', 'wh', 'offset', 'yaw_class', 'yaw_res')):
-    d['bb_' + name] = _np(out[6][i])
+  for i, name in enumerate(('heatmap', 'wh', 'offset', 'yaw_class', 'yaw_res', 'velocity', 'brake')):
+    if out[6][i] is not None:
+      d['bb_' + name] = _np(out[6][i])
   return d
 
 
@@ -157,6 +158,16 @@ def write_swin_golden():
   print('swin: target speed logits', d['pred_target_speed'], 'heatmap max', d['bb_heatmap'].max(), {k: v.shape for k, v in taps.items()})
 
 
+def write_temporal_golden():
+  """lidar_seq_len = 6 on the default 2-D RegNet LiDAR branch (6 stacked BEV frames as input channels): the velocity / brake CenterNet
+  heads and their losses (center_net.py:29-31,119-123) -- one train-mode step at bs = 2 on the unmodified reference."""
+  import dataclasses
+  model, _ = ref_harness.build_reference_model(lidar_seq_len=6)
+  cfg = dataclasses.replace(P.PortConfig(), lidar_seq_len=6)
+  model.load_state_dict(P.generic_state_dict(model.state_dict(), base=P.make_state_dict(P.PortConfig())), strict=True)
+  write_train_golden(model, cfg, 2, 'tfpp_train_temporal_bs2.npz')
+
+
 def write_train_golden(model, cfg, bs, fname):
   """One train-mode step of the reference at batch size ``bs`` (dropout 0, batch-statistic BN): the 10 losses, per-parameter
   gradient norms + sampled gradient values, the BN running-statistic sums after the step and the small forward outputs."""
@@ -205,6 +216,9 @@ def main():
   torch.set_num_threads(os.cpu_count())
   if only == {'swin'}:
     write_swin_golden()
+    return
+  if only == {'temporal'}:
+    write_temporal_golden()
     return
 
   # ---- default TF++ ---------------------------------------------------------------------------

@@ -699,6 +699,8 @@ def loss_weights(cfg):
       'loss_yaw_class': 1.0,
       'loss_yaw_res': 1.0,
   }
+  if not (cfg.lidar_seq_len == 1 and getattr(cfg, 'seq_len', 1) == 1):  # train.py:423-426 zeroes them for single-frame input only
+    w['loss_velocity'] = w['loss_brake'] = 1.0
   s = sum(w.values())
   return {k: v / s for k, v in w.items()}
 

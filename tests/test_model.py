@@ -287,15 +287,15 @@ def _zero_dropout(m):
   m.config.embd_pdrop = m.config.resid_pdrop = m.config.attn_pdrop = 0.0
 
 
-def _engine_train_step(m, bs):
+def _engine_train_step(m, bs, port_cfg=None):
   """train-mode forward (batch statistics, dropout 0), fused losses, hand-written backward on the engine; returns
   (loss names, loss values [numpy], engine with .grads filled)."""
   from carla_garage_amd.engine import Tape
   from carla_garage_amd.losses import fused_losses, normalized_loss_weights
   _zero_dropout(m)
   eng = m._engine()
-  batch = {k: v.cuda() for k, v in P.make_labels(bs).items()}
-  inp = [x.cuda() for x in P.make_inputs(bs)]
+  batch = {k: v.cuda() for k, v in P.make_labels(bs, port_cfg).items()}
+  inp = [x.cuda() for x in P.make_inputs(bs, port_cfg)]
   eng.prepare(m.compute_dtype, True, True)
   eng.alloc_grads()
   eng.tape = Tape()
@@ -332,10 +332,10 @@ def _compare_grads(eng, g):
   return worst_norm, worst_elem
 
 
-def _check_train_step_vs_golden(bs, fname, tag):
+def _check_train_step_vs_golden(bs, fname, tag, model=None, port_cfg=None):
   g = U.load_golden(fname)
-  m = _model().train()
-  names, vals, eng = _engine_train_step(m, bs)
+  m = (model if model is not None else _model()).train()
+  names, vals, eng = _engine_train_step(m, bs, port_cfg)
   gl = dict(zip([str(x) for x in g['loss_names']], g['losses']))
   errs = {n: float(abs(v - gl[n]) / abs(gl[n])) for n, v in zip(names, vals)}
   worst_norm, worst_elem = _compare_grads(eng, g)
@@ -365,6 +365,18 @@ def test_train_step_bs12_fp32_vs_reference_golden():
   tiles with fused BN statistics and the M-major XCD order, the bs=12 weight-gradient plans): the reference's own step at that size
   (tests/golden/tfpp_train_bs12.npz, oracle/make_golden.py) is compared with the fp32 HIP step."""
   _check_train_step_vs_golden(12, 'tfpp_train_bs12.npz', 'train_fp32_bs12')
+
+
+@pytest.mark.gpu
+def test_temporal_lidar_train_step_fp32_vs_reference_golden():
+  """lidar_seq_len = 6 on the default RegNet LiDAR branch (6 BEV frames as input channels): the velocity / brake CenterNet heads and
+  their losses (center_net.py:29-31,119-123) -- losses, gradients and BN statistics of one train step against the unmodified reference."""
+  m = LidarCenterNet(GlobalConfig(lidar_seq_len=6))
+  m.load_state_dict(P.generic_state_dict(m.state_dict(), base=P.make_state_dict(P.PortConfig())), strict=True)
+  g = U.load_golden('tfpp_train_temporal_bs2.npz')
+  assert [str(x) for x in g['loss_names']][-2:] == ['loss_velocity', 'loss_brake']
+  _check_train_step_vs_golden(2, 'tfpp_train_temporal_bs2.npz', 'train_fp32_temporal', model=m.cuda(),
+                              port_cfg=dataclasses.replace(P.PortConfig(), lidar_seq_len=6))
 
 
 BF16_LOSS_TOL = 5e-2  # measured worst: loss_yaw_res 2.2e-2 (a loss of ~1e-2 absolute, i.e. 2e-4 absolute error), every other loss <= 4.5e-3
