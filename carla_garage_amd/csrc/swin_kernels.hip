@@ -132,3 +132,72 @@ extern "C" int tfpp_softmax_window_bias(void* s, const float* table, const int32
   TFPP_CHECK_LAUNCH();
   return 0;
 }
+
+// Stochastic depth (timm DropPath, video_swin_transformer.py:216,276-281): y[b] = x[b] * (keep_b / (1 - p)), keep_b ~ Bernoulli(1 - p) per
+// SAMPLE, drawn from the dropout hash on (seed + per-step device counter, b) so that backward (the same call on the gradient) and hipGraph
+// replays see the right masks.  rows_per_sample rows of C channels per sample.
+template <typename T>
+__global__ void drop_path_kernel(const T* __restrict__ x, T* __restrict__ y, long n_chunks, long chunks_per_sample, float p, float inv_keep,
+                                 unsigned long long seed, const unsigned long long* __restrict__ seed_off) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  if (seed_off) seed += *seed_off * 0x9E3779B97F4A7C15ull;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_chunks) return;
+  const float s = dropout_scale(seed, (unsigned long long)(i / chunks_per_sample), p, inv_keep);
+  float v[VEC];
+  load_vec<T>(x + i * VEC, v);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) v[e] *= s;
+  store_vec<T>(y + i * VEC, v);
+}
+
+extern "C" int tfpp_drop_path(const void* x, void* y, int64_t samples, int64_t elems_per_sample, float p, uint64_t seed, const uint64_t* seed_offset,
+                              int dtype, void* stream) {
+  const int VEC = dtype == TFPP_F32 ? 4 : 8;
+  if (!x || !y || samples < 1 || elems_per_sample < VEC || elems_per_sample % VEC || p < 0.f || p >= 1.f) return TFPP_EINVAL;
+  const long n = (long)samples * (elems_per_sample / VEC);
+  dim3 grid((unsigned)((n + 255) / 256));
+  const float inv_keep = 1.f / (1.f - p);
+  if (dtype == TFPP_F32)
+    hipLaunchKernelGGL(drop_path_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n, (long)(elems_per_sample / VEC), p,
+                       inv_keep, (unsigned long long)seed, (const unsigned long long*)seed_offset);
+  else
+    hipLaunchKernelGGL(drop_path_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n, (long)(elems_per_sample / VEC), p,
+                       inv_keep, (unsigned long long)seed, (const unsigned long long*)seed_offset);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// Gradient of relative_position_bias_table: dtable[rel_index[i][j]][h] += scale * sum_w ds[w][h][i][j] (ds = gradient of the pre-softmax
+// scores as tfpp_softmax_bwd leaves it, i.e. already multiplied by alpha: scale = 1 / alpha).  One thread per (h, i, j): the sum over
+// windows is a strided walk (consecutive lanes = consecutive j), then one fp32 atomic per thread (<= n^2 heads atomics per launch, spread
+// over (2Wd-1)(2Wh-1)(2Ww-1) heads addresses).
+template <typename T>
+__global__ void window_bias_grad_kernel(const T* __restrict__ ds, const int* __restrict__ rel_index, float* __restrict__ dtable, long windows,
+                                        int heads, int n, long ld, float scale) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)heads * n * n) return;
+  const int j = (int)(t % n);
+  const int i = (int)((t / n) % n);
+  const int h = (int)(t / ((long)n * n));
+  const T* p = ds + ((size_t)h * n + i) * ld + j;
+  const size_t wstride = (size_t)heads * n * ld;
+  float acc = 0.f;
+  for (long w = 0; w < windows; ++w) acc += ElemTraits<T>::to_f(p[w * wstride]);
+  atomicAdd(dtable + (size_t)rel_index[(size_t)i * n + j] * heads + h, acc * scale);
+}
+
+extern "C" int tfpp_window_bias_grad(const void* ds, const int32_t* rel_index, float* dtable, int64_t windows, int heads, int n, int64_t ld,
+                                     float scale, int dtype, void* stream) {
+  if (!ds || !rel_index || !dtable || windows < 1 || heads < 1 || n < 1 || ld < n) return TFPP_EINVAL;
+  const long total = (long)heads * n * n;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == TFPP_F32)
+    hipLaunchKernelGGL(window_bias_grad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)ds, (const int*)rel_index, dtable,
+                       (long)windows, heads, n, (long)ld, scale);
+  else
+    hipLaunchKernelGGL(window_bias_grad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ds, (const int*)rel_index, dtable,
+                       (long)windows, heads, n, (long)ld, scale);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}

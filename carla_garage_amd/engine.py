@@ -377,7 +377,7 @@ class SideLane:
 #   (38.9 vs 35.8 ms) was taken while a run-time `bns` pointer kept the statistics object of EVERY bf16 conv launch in scratch memory.
 FUSE_BN_BWD = int(os.environ.get('TFPP_FUSE_BN_BWD', '1'))
 
-EARLY_GRAD_PREFIXES = ('backbone.image_encoder.s4', 'backbone.lidar_encoder.s4', 'backbone.transformers.3', 'backbone.lidar_channel_to_img.3',
+EARLY_GRAD_PREFIXES = ('backbone.image_encoder.s4', 'backbone.lidar_encoder.s4', 'backbone.lidar_encoder.layers.layer3', 'backbone.lidar_encoder.norm', 'backbone.transformers.3', 'backbone.lidar_channel_to_img.3',
                        'backbone.img_channel_to_lidar.3', 'backbone.c5_conv', 'backbone.up_conv')
 
 
@@ -937,7 +937,7 @@ class Engine:
 
       def bwd(dy):
         dx = ops.zeros((B, H, W, C), x.dtype, x.device)
-        ops.avgpool_bwd_add(dy, dx, ho, wo)
+        ops.avgpool_bwd_add(dy.view(y.shape), dx, ho, wo)  # (a consumer may have recorded a reshaped view: gradients are keyed by storage)
         return dx
 
       self.rec([y], [x], bwd)
@@ -949,7 +949,7 @@ class Engine:
     _, ho, wo, _ = base.shape
     y = ops.bilinear_fwd(tok, ho, wo, base=base)
     if self.tape is not None:
-      self.rec([y], [tok, base], lambda dy: (ops.bilinear_bwd(dy, hi, wi), dy))
+      self.rec([y], [tok, base], lambda dy: (ops.bilinear_bwd(dy.view(y.shape), hi, wi), dy))
     return y
 
   def upsample(self, x, ho, wo, mul=None):
@@ -1215,7 +1215,19 @@ class Engine:
           for t_ in range(nt):
             ops.copy_rows(xl, acc, B, hh_ * ww_ * cc_, nt * hh_ * ww_ * cc_, t_ * hh_ * ww_ * cc_, hh_ * ww_ * cc_, 0, accumulate=True)
           third = self._const(f'time_mean{nt}x{cc_}', lambda: torch.full((cc_,), 1.0 / nt))
-          xl = ops.affine_act(acc, scale=third, shift=self._const(f'zeros{cc_}', lambda: torch.zeros(cc_)))
+          zero_c = self._const(f'zeros{cc_}', lambda: torch.zeros(cc_))
+          xl5 = xl
+          xl = ops.affine_act(acc, scale=third, shift=zero_c)
+          if self.tape is not None:
+
+            def bwd_mean(dm, nt=nt, n=hh_ * ww_ * cc_, shape=tuple(xl5.shape)):
+              ds = ops.affine_act(dm.view(shape[0], shape[2], shape[3], shape[4]), scale=third, shift=zero_c)
+              dx5 = torch.empty(shape, device=dm.device, dtype=dm.dtype)
+              for t_ in range(nt):
+                ops.copy_rows(ds, dx5, shape[0], n, n, 0, nt * n, t_ * n)
+              return dx5
+
+            self.rec([xl], [xl5], bwd_mean)
       lanes.join()
     out['image_feature_grid'], out['fused_features'] = xi, xl
 

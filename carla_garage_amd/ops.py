@@ -631,6 +631,17 @@ def softmax_window_bias(s, table, rel_index, mask, windows, heads, n, alpha, ld=
   return s
 
 
+def drop_path(x, samples, p, seed):
+  """timm DropPath: one keep / drop draw per sample (video_swin_transformer.py:216,276-281)."""
+  y = torch.empty_like(x)
+  lib.tfpp_drop_path(ptr(_chk(x)), ptr(y), samples, x.numel() // samples, p, seed, ptr(SEED_OFFSET), dt(x), stream())
+  return y
+
+
+def window_bias_grad(ds, rel_index, dtable, windows, heads, n, ld, scale):
+  lib.tfpp_window_bias_grad(ptr(ds), ptr(rel_index), ptr(dtable), windows, heads, n, ld, scale, dt(ds), stream())
+
+
 def add_dropout(a, b, p_drop=0.0, seed=0, out=None):
   if out is None:
     out = torch.empty_like(b)

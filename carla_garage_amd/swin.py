@@ -7,13 +7,18 @@ multiples, the cyclic shift, window partition / reverse and the 2x2 merge are si
 geometry on the host (the reference caches its shift masks the same way, :329-342); linears are the implicit-GEMM kernels, the
 147 x 147 window attention is two strided batched GEMMs around tfpp_softmax_window_bias.
 
-Inference only this round: no tape nodes are recorded (training config 5 still raises)."""
+Training: every step records its adjoint on the engine's tape.  The gathers are permutations (plus zero padding), so their adjoints are
+the same kernel with the inverse table; the attention core keeps P for backward (dP = dO V^T, dV = P^T dO, dS through tfpp_softmax_bwd,
+dQ = dS K, dK = dS^T Q, bias-table gradient by tfpp_window_bias_grad); DropPath (stochastic depth, rates 0 .. 0.2 over the 12 blocks,
+:535) is tfpp_drop_path on the residual branch in window / token layout (one draw per sample)."""
 import math
 
 import torch
 
 from . import ops
 from ._lib import ACT_GELU, ACT_NONE
+
+DROP_PATH_RATE = 0.2  # SwinTransformer3D's default, which transfuser.py:45-47 does not override
 
 
 def window_geometry(dims, window_size, shift_size):
@@ -78,6 +83,16 @@ def merge_maps(B, D, H, W):
   return [src[:, :, i::2, j::2].reshape(-1).int() for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))], Hp // 2, Wp // 2
 
 
+def merge_inverse_map(B, D, H, W):
+  """Adjoint of merge_maps: for every input token the row of the concatenated [n_out * 4, C] view that holds its copy."""
+  Hp, Wp = H + H % 2, W + W % 2
+  out = torch.arange(B * D * (Hp // 2) * (Wp // 2)).view(B, D, Hp // 2, Wp // 2)
+  inv = torch.empty((B, D, Hp, Wp), dtype=torch.int64)
+  for j, (i0, j0) in enumerate(((0, 0), (1, 0), (0, 1), (1, 1))):
+    inv[:, :, i0::2, j0::2] = out * 4 + j
+  return inv[:, :, :H, :W].reshape(-1).int()
+
+
 class VideoSwin:
   """Runs ``backbone.lidar_encoder`` (modules.SwinTransformer3D) through the engine's kernels."""
 
@@ -85,6 +100,7 @@ class VideoSwin:
     self.e = engine
     self.enc = engine.m.backbone.lidar_encoder
     self._maps = {}
+    self.drop_path_rate = DROP_PATH_RATE  # tests set 0 to compare with a reference whose DropPath modules are switched off
     self.taps = None  # tests: dict that receives the (B, D, H, W, C) output of the patch embedding and of every layer
 
   def build_specs(self):
@@ -110,8 +126,6 @@ class VideoSwin:
   def stem(self, lidar):
     """lidar: fp32 (B, T, H, W) -> tokens [B, T/2, H/4, W/4, 96] (patch_embed + norm; pos_drop is the identity at p = 0)."""
     e = self.e
-    if e.tape is not None:
-      raise NotImplementedError('the Video-Swin LiDAR branch is inference-only on the HIP path this round (no backward)')
     B, T, H, W = lidar.shape
     rows = ops.patchify3d(lidar, e.dtype)
     x = e.linear(rows, 'backbone.lidar_encoder.patch_embed.proj', x_grad=False)
@@ -120,34 +134,83 @@ class VideoSwin:
       self.taps['swin_patch_embed'] = x
     return x
 
-  def block(self, x, key, blk, B, D, H, W):
+  def drop_path(self, y, samples, p):
+    """timm DropPath on a residual branch (identity in eval mode / at rate 0)."""
+    e = self.e
+    if not e.training or p <= 0.0:
+      return y
+    seed = e.next_seed()
+    out = ops.drop_path(y, samples, p, seed)
+    if e.tape is not None:
+      e.rec([out], [y], lambda d: ops.drop_path(d, samples, p, seed))
+    return out
+
+  def block(self, x, key, blk, B, D, H, W, dp_rate=0.0):
     """SwinTransformerBlock3D.forward (:262-288) on rows x [B*D*H*W, C]."""
     e = self.e
     C = x.shape[-1]
+    ntok = B * D * H * W
     ws, ss = window_geometry((D, H, W), blk.window_size, blk.shift_size)
     fwd, rev, mask, nW, n = self._dev(('win', B, D, H, W, ws, ss), lambda: window_maps(B, D, H, W, ws, ss))
     heads = blk.attn.num_heads
     d = C // heads
+    scale = d**-0.5
     rel = self._dev(('rel', id(blk.attn), n), lambda: blk.attn.relative_position_index[:n, :n].contiguous().int().cpu())  # (:151-152)
+    table = blk.attn.relative_position_bias_table
     h = e.layernorm(x, blk.norm1)
     nwin = B * nW
-    xw = ops.gather_rows(h, fwd, nwin * n + 8, C)                      # pad + roll + window_partition
-    qkv = e.linear(xw, key + '.attn.qkv')                              # [nwin*n + 8, 3C]: q | k | v, head-major inside each
+    nslot = nwin * n
+    xw = ops.gather_rows(h, fwd, nslot + 8, C)                         # pad + roll + window_partition (+ 8 spare zero rows)
+    if e.tape is not None:
+      e.rec([xw], [h], lambda dxw: ops.gather_rows(dxw, rev, ntok, C))  # adjoint: every real token reads the gradient of its slot
+    qkv = e.linear(xw, key + '.attn.qkv')                              # [nslot + 8, 3C]: q | k | v, head-major inside each
     flat = qkv.view(-1)
     q, k, v = flat[0:], flat[C:], flat[2 * C:]
     npad = ops.pad_to(n, 8)
+    sbs = (heads * n * npad, n * npad)
     S = ops.zeros((nwin, heads, n, npad), x.dtype, x.device)           # pad columns stay 0: the P.V product runs K = npad
-    ops.bgemm(q, k, S, M=n, N=n, K=d, lda=3 * C, ldb=3 * C, ldc=npad, batch0=nwin, batch1=heads, a_bs=(n * 3 * C, d), b_bs=(n * 3 * C, d),
-              c_bs=(heads * n * npad, n * npad))
-    ops.softmax_window_bias(S, blk.attn.relative_position_bias_table.detach(), rel, mask, nwin, heads, n, d**-0.5, ld=npad)
-    O = torch.empty((nwin * n, C), device=x.device, dtype=x.dtype)
-    ops.bgemm(S, v, O, M=n, N=d, K=npad, lda=npad, ldb=3 * C, ldc=C, batch0=nwin, batch1=heads, a_bs=(heads * n * npad, n * npad),
-              b_bs=(n * 3 * C, d), c_bs=(n * C, d), b_km=True)
+    ops.bgemm(q, k, S, M=n, N=n, K=d, lda=3 * C, ldb=3 * C, ldc=npad, batch0=nwin, batch1=heads, a_bs=(n * 3 * C, d), b_bs=(n * 3 * C, d), c_bs=sbs)
+    ops.softmax_window_bias(S, table.detach(), rel, mask, nwin, heads, n, scale, ld=npad)
+    O = torch.empty((nslot, C), device=x.device, dtype=x.dtype)
+    ops.bgemm(S, v, O, M=n, N=d, K=npad, lda=npad, ldb=3 * C, ldc=C, batch0=nwin, batch1=heads, a_bs=sbs, b_bs=(n * 3 * C, d), c_bs=(n * C, d),
+              b_km=True)
+    if e.tape is not None:
+
+      def bwd_attn(dO, P=S):
+        dqkv = ops.zeros(tuple(qkv.shape), qkv.dtype, qkv.device)
+        df = dqkv.view(-1)
+        dq, dk, dv = df[0:], df[C:], df[2 * C:]
+        kw = dict(batch0=nwin, batch1=heads)
+        dP = ops.zeros((nwin, heads, n, npad), P.dtype, P.device)
+        ops.bgemm(dO, v, dP, M=n, N=n, K=d, lda=C, ldb=3 * C, ldc=npad, a_bs=(n * C, d), b_bs=(n * 3 * C, d), c_bs=sbs, **kw)            # dP = dO V^T
+        ops.bgemm(P, dO, dv, M=n, N=d, K=n, lda=npad, ldb=C, ldc=3 * C, a_bs=sbs, b_bs=(n * C, d), c_bs=(n * 3 * C, d), a_km=True, b_km=True,
+                  **kw)                                                                                                                     # dV = P^T dO
+        ops.softmax_bwd(P, dP, nwin * heads * n, n, npad, alpha=scale)                                                                      # dP := dS
+        if table.requires_grad:
+          ops.window_bias_grad(dP, rel, e.g(table), nwin, heads, n, npad, 1.0 / scale)
+        ops.bgemm(dP, k, dq, M=n, N=d, K=npad, lda=npad, ldb=3 * C, ldc=3 * C, a_bs=sbs, b_bs=(n * 3 * C, d), c_bs=(n * 3 * C, d), b_km=True, **kw)  # dQ = dS K
+        ops.bgemm(dP, q, dk, M=n, N=d, K=n, lda=npad, ldb=3 * C, ldc=3 * C, a_bs=sbs, b_bs=(n * 3 * C, d), c_bs=(n * 3 * C, d), a_km=True, b_km=True,
+                  **kw)                                                                                                                     # dK = dS^T Q
+        return dqkv
+
+      e.rec([O], [qkv], bwd_attn)
     y = e.linear(O, key + '.attn.proj')
-    x = ops.gather_rows(y, rev, B * D * H * W, C, add=x)               # window_reverse + roll back + crop + shortcut
-    h = e.layernorm(x, blk.norm2)
-    h = e.linear(h, key + '.mlp.fc1', act=ACT_GELU)
-    return e.linear(h, key + '.mlp.fc2', act=ACT_NONE, res=x)
+    y = self.drop_path(y, B, dp_rate)                                  # window layout: the windows of a sample are contiguous
+    x2 = ops.gather_rows(y, rev, ntok, C, add=x)                       # window_reverse + roll back + crop + shortcut
+    if e.tape is not None:
+      fwd_slots = fwd[:nslot]
+      e.rec([x2], [y, x], lambda dx2: (ops.gather_rows(dx2, fwd_slots, nslot, C), dx2))
+    h = e.layernorm(x2, blk.norm2)
+    if e.tape is None and not (e.training and dp_rate > 0.0):
+      h = e.linear(h, key + '.mlp.fc1', act=ACT_GELU)
+      return e.linear(h, key + '.mlp.fc2', act=ACT_NONE, res=x2)
+    h1 = e.linear(h, key + '.mlp.fc1')
+    a = ops.affine_act(h1, act=ACT_GELU)
+    if e.tape is not None:
+      e.rec([a], [h1], lambda da: ops.act_bwd(da, h1, ACT_GELU))      # exact GELU derivative needs the pre-activation
+    m = e.linear(a, key + '.mlp.fc2')
+    m = self.drop_path(m, B, dp_rate)
+    return e.add(x2, m)
 
   def layer(self, i, x):
     """BasicLayer i (:404-424) (+ the final CustomNorm after layer 3, transfuser.py iterates 'layer3' and 'norm' as one block).
@@ -157,8 +220,11 @@ class VideoSwin:
     layer = self.enc.layers[lname]
     B, D, H, W, C = x.shape
     rows = x.reshape(B * D * H * W, C)
+    depths = self.enc.arch['depths']
+    total = sum(depths)
     for j, blk in enumerate(layer.blocks):
-      rows = self.block(rows, f'backbone.lidar_encoder.layers.{lname}.blocks.{j}', blk, B, D, H, W)
+      k = sum(depths[:i]) + j  # stochastic depth decay rule: linspace(0, rate, sum(depths)) (:535)
+      rows = self.block(rows, f'backbone.lidar_encoder.layers.{lname}.blocks.{j}', blk, B, D, H, W, self.drop_path_rate * k / (total - 1))
     if layer.downsample is not None:
       maps = self._dev(('merge', B, D, H, W), lambda: tuple(merge_maps(B, D, H, W)[0]))
       H2, W2 = (H + H % 2) // 2, (W + W % 2) // 2
@@ -166,6 +232,10 @@ class VideoSwin:
       cat = torch.empty((n_out, 4 * C), device=x.device, dtype=x.dtype)
       for j, idx in enumerate(maps):
         ops.gather_rows(rows, idx, n_out, C, out=cat, dst_ld=4 * C, dst_off=j * C)
+      if e.tape is not None:
+        inv = self._dev(('merge_inv', B, D, H, W), lambda: merge_inverse_map(B, D, H, W))
+        ntok_in = B * D * H * W
+        e.rec([cat], [rows], lambda dcat, C=C, inv=inv, ntok_in=ntok_in: ops.gather_rows(dcat.view(-1, C), inv, ntok_in, C))  # (C changes below)
       cat = e.layernorm(cat, layer.downsample.norm)
       rows = e.linear(cat, f'backbone.lidar_encoder.layers.{lname}.downsample.reduction')
       H, W, C = H2, W2, 2 * C

@@ -324,6 +324,15 @@ int tfpp_gather_rows(const void* src, const int32_t* idx, const void* add, void*
                      int64_t dst_ld, int64_t add_ld, int dtype, void* stream);
 int tfpp_softmax_window_bias(void* s, const float* table, const int32_t* rel_index, const float* mask, int64_t windows, int heads,
                              int n, int64_t ld, int n_mask, float alpha, int dtype, void* stream);
+/* Training of the same branch.  drop_path: timm DropPath as SwinTransformerBlock3D uses it (:216,276-281): y = x * keep_b / (1 - p) with one
+ *   Bernoulli draw per SAMPLE (samples x elems_per_sample elements), from the dropout hash of tfpp_softmax_fwd on (seed, b); the backward is the
+ *   same call on the gradient.  window_bias_grad: dtable[rel_index[i][j]][h] += scale * sum_w ds[w][h][i][j], the gradient of
+ *   relative_position_bias_table from the score gradient tfpp_softmax_bwd produced (scale = 1 / alpha undoes its alpha).  The gathers are their
+ *   own adjoints with the inverse index table (gather_rows with rev / fwd swapped). */
+int tfpp_drop_path(const void* x, void* y, int64_t samples, int64_t elems_per_sample, float p, uint64_t seed, const uint64_t* seed_offset,
+                   int dtype, void* stream);
+int tfpp_window_bias_grad(const void* ds, const int32_t* rel_index, float* dtable, int64_t windows, int heads, int n, int64_t ld,
+                          float scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Token ops: LayerNorm (transfuser.py:388-389,288; nn.TransformerDecoderLayer norms), row softmax with the

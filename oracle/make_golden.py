@@ -67,6 +67,8 @@ def reference_loss_kwargs(out, lab):
 
 def disable_dropout(model):
   for mod in model.modules():
+    if hasattr(mod, 'drop_prob'):  # timm DropPath (stochastic depth of the Video-Swin blocks)
+      mod.drop_prob = 0.0
     if isinstance(mod, torch.nn.Dropout):
       mod.p = 0.0
     if isinstance(mod, torch.nn.MultiheadAttention):
@@ -158,6 +160,16 @@ def write_swin_golden():
   print('swin: target speed logits', d['pred_target_speed'], 'heatmap max', d['bb_heatmap'].max(), {k: v.shape for k, v in taps.items()})
 
 
+def write_swin_train_golden():
+  """BASELINE config 5, one train-mode step at bs = 2 on the unmodified reference (dropout and stochastic depth off, batch-statistic BN in the
+  image branch): the 12 losses, per-parameter gradient norms + samples (incl. every Swin block and the relative-position bias tables)."""
+  import dataclasses
+  model, _ = ref_harness.build_reference_model(**SWIN_OVERRIDES)
+  cfg = dataclasses.replace(P.PortConfig(), lidar_seq_len=6)
+  model.load_state_dict(P.generic_state_dict(model.state_dict(), base=P.make_state_dict(P.PortConfig())), strict=True)
+  write_train_golden(model, cfg, 2, 'tfpp_swin_train_bs2.npz')
+
+
 def write_temporal_golden():
   """lidar_seq_len = 6 on the default 2-D RegNet LiDAR branch (6 stacked BEV frames as input channels): the velocity / brake CenterNet
   heads and their losses (center_net.py:29-31,119-123) -- one train-mode step at bs = 2 on the unmodified reference."""
@@ -216,6 +228,9 @@ def main():
   torch.set_num_threads(os.cpu_count())
   if only == {'swin'}:
     write_swin_golden()
+    return
+  if only == {'swin_train'}:
+    write_swin_train_golden()
     return
   if only == {'temporal'}:
     write_temporal_golden()

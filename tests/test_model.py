@@ -269,6 +269,18 @@ def test_video_swin_eval_forward_fp32_vs_reference_golden():
 
 
 @pytest.mark.gpu
+def test_video_swin_train_step_fp32_vs_reference_golden():
+  """BASELINE config 5 trains: one step at bs = 2 (stochastic depth and dropout off on both sides) against the unmodified reference --
+  the 12 losses, gradient norms and sampled gradient elements of every parameter (Swin blocks, relative-position bias tables, patch
+  embedding / merging, Conv3d adapters), BN running statistics of the image branch."""
+  m = LidarCenterNet(GlobalConfig(lidar_architecture='video_swin_tiny', lidar_seq_len=6))
+  m.load_state_dict(P.generic_state_dict(m.state_dict(), base=P.make_state_dict(P.PortConfig())), strict=True)
+  m.cuda()
+  m._engine().swin.drop_path_rate = 0.0
+  _check_train_step_vs_golden(2, 'tfpp_swin_train_bs2.npz', 'train_fp32_swin', model=m, port_cfg=dataclasses.replace(P.PortConfig(), lidar_seq_len=6))
+
+
+@pytest.mark.gpu
 def test_video_swin_eval_forward_bf16_close_to_fp32_reference():
   g = U.load_golden('tfpp_swin_eval_bs1.npz')
   m, pc = _swin_model('bf16')
