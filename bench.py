@@ -164,8 +164,8 @@ def inference_latency(model, cfg, device, log, iters=20):
 
 def video_swin_forward(device, log, bs=4, iters=10):
   """BASELINE config 5 (TransFuser++ with the Video-Swin LiDAR branch, 6 LiDAR frames -> 3 time frames per scale, bs = 4 per GPU):
-  inference forward in bf16, random-init weights, synthetic frames; samples/s of eager launches and of the hipGraph replay.  The
-  branch has no backward on the HIP path yet, so this is a forward figure, reported beside the training metric, never as ``value``."""
+  inference forward and training step in bf16, random-init weights, synthetic frames, as hipGraph replays.  Reported beside the headline
+  metric (BASELINE config 3), never as ``value``."""
   from carla_garage_amd.config import GlobalConfig
   from carla_garage_amd.graph import GraphedForward
   from carla_garage_amd.model import LidarCenterNet
@@ -201,6 +201,34 @@ def video_swin_forward(device, log, bs=4, iters=10):
     out['hipgraph_ms_per_batch'] = None
     log(f'video-swin hipGraph capture failed: {type(e).__name__}: {e}')
   log(f'video-swin forward bs={bs}: {out}')
+  # the same configuration trained: fwd + 12 losses + bwd + AdamW(amsgrad), train-mode BN, dropout and stochastic depth on
+  try:
+    from carla_garage_amd.graph import GraphedTrainStep
+    from carla_garage_amd.trainer import Trainer
+    model.train()
+    tb = dict(b)
+    hb, wb = cfg.lidar_resolution_height // cfg.bev_down_sample_factor, cfg.lidar_resolution_width // cfg.bev_down_sample_factor
+    tb['velocity_label'] = torch.rand(bs, 1, hb, wb, generator=g).to(device) * 8.0
+    tb['brake_target_label'] = torch.randint(0, 2, (bs, hb, wb), generator=g).to(device)
+    tr = Trainer(model, lr=cfg.lr)
+    tr.train_step(tb)
+    step = GraphedTrainStep(tr, tb)
+    for _ in range(2):
+      step(tb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+      vals = step(tb)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / iters
+    out['train_hipgraph_ms_per_step'] = round(ms, 3)
+    out['train_samples_per_s'] = round(bs / (ms * 1e-3), 1)
+    out['train_final_weighted_loss'] = round(float(tr.total_loss(vals)), 5)
+    del step, tr
+  except Exception as e:  # pylint: disable=broad-except
+    out['train_hipgraph_ms_per_step'] = None
+    log(f'video-swin training step failed: {type(e).__name__}: {e}')
+  log(f'video-swin bs={bs}: {out}')
   del model
   torch.cuda.empty_cache()
   return out

@@ -892,3 +892,53 @@ def test_se_bwd_apply_with_fused_batchnorm_backward_sums(ops):
   scale = g.abs().reshape(-1, C).double().sum(0).max().item()
   assert (got[0] - g.reshape(-1, C).double().sum(0)).abs().max().item() <= 1e-5 * scale
   assert (got[1] - (g * (xraw - mean) * invstd).reshape(-1, C).double().sum(0)).abs().max().item() <= 6e-5 * scale
+
+
+def test_swin_gather_softmax_bias_and_training_kernels(ops):
+  """csrc/swin_kernels.hip against torch on the CPU: gather_rows (+ add, -1 = zero row, column offset), the window softmax with
+  relative-position bias and shift mask, its bias-table gradient, patchify3d, and DropPath (per-sample draws, backward = the same mask)."""
+  for dtype in (torch.float32, torch.bfloat16):
+    C, rows_in, rows_out = 24, 50, 77
+    src = rnd(rows_in, C, dtype=dtype, seed=1)
+    add = rnd(rows_out, C, dtype=dtype, seed=2)
+    g = torch.Generator().manual_seed(3)
+    idx = torch.randint(-1, rows_in, (rows_out,), generator=g).int()
+    want = torch.where(idx[:, None] >= 0, src[idx.clamp(min=0).long()], torch.zeros(1)) + add
+    got = ops.gather_rows(dev(src, dtype), idx.to(DEV), rows_out, C, add=dev(add, dtype))
+    check(f'gather_rows.{dtype}', got, want, dtype)
+    out = torch.zeros((rows_out, 2 * C), device=DEV, dtype=dtype)
+    ops.gather_rows(dev(src, dtype), idx.to(DEV), rows_out, C, out=out, dst_ld=2 * C, dst_off=C)
+    check(f'gather_rows.offset.{dtype}', out[:, C:], want - add, dtype)
+    assert float(out[:, :C].abs().max()) == 0.0
+    # window softmax: 5 windows (mask period 3... use n_mask = 5), 3 heads, n = 21
+    W, Hh, n, npad, T = 5, 3, 21, 24, 40
+    s = rnd(W, Hh, n, npad, dtype=dtype, seed=4)
+    table = rnd(T, Hh, seed=5)
+    rel = torch.randint(0, T, (n, n), generator=g).int()
+    mask = torch.where(torch.rand(W, n, n, generator=g) < 0.2, torch.tensor(-100.0), torch.tensor(0.0))
+    alpha = 0.37
+    logits = s[..., :n].float() * alpha + table[rel.long()].permute(2, 0, 1)[None] + mask[:, None]
+    wantp = torch.softmax(logits, -1)
+    sd = dev(s, dtype)
+    ops.softmax_window_bias(sd, dev(table), rel.to(DEV), dev(mask), W, Hh, n, alpha, ld=npad)
+    check(f'softmax_window_bias.{dtype}', sd[..., :n], wantp, dtype)
+    # bias-table gradient from a score gradient ds (already multiplied by alpha, as tfpp_softmax_bwd leaves it)
+    ds = rnd(W, Hh, n, npad, dtype=dtype, seed=6)
+    dt_ = torch.zeros(T, Hh, device=DEV)
+    ops.window_bias_grad(dev(ds, dtype), rel.to(DEV), dt_, W, Hh, n, npad, 1.0 / alpha)
+    wantg = torch.zeros(T, Hh)
+    wantg.index_put_((rel.long().reshape(-1),), (ds[..., :n].float().sum(0) / alpha).permute(1, 2, 0).reshape(-1, Hh), accumulate=True)
+    check(f'window_bias_grad.{dtype}', dt_, wantg, torch.float32, scale=4.0)
+  x = rnd(2, 4, 8, 12, seed=7)  # (B, T, H, W) fp32 frames
+  pt = ops.patchify3d(dev(x), torch.float32)
+  wantpt = x.view(2, 2, 2, 2, 4, 3, 4).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, 32)
+  assert torch.equal(pt.cpu(), wantpt)
+  # DropPath: per-sample scale 0 or 1/(1-p); the same seed reproduces the mask (backward), another seed draws another one
+  xs = torch.ones((64, 5, 8), device=DEV)
+  a = ops.drop_path(xs, 64, 0.25, 1234).cpu()
+  b = ops.drop_path(xs, 64, 0.25, 1234).cpu()
+  c = ops.drop_path(xs, 64, 0.25, 99).cpu()
+  assert torch.equal(a, b) and not torch.equal(a, c)
+  per = a.view(64, -1)
+  assert ((per == per[:, :1]).all()) and all(v == 0.0 or abs(v - 1.0 / 0.75) < 1e-6 for v in per[:, 0].tolist())
+  assert 5 <= int((per[:, 0] == 0).sum()) <= 30  # 16 expected of 64
