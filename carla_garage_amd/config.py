@@ -34,6 +34,8 @@ class GlobalConfig:
     self.min_x, self.max_x, self.min_y, self.max_y = -32, 32, -32, 32  # config.py:135-138
     self.min_z_projection, self.max_z_projection = -10, 14  # config.py:141-142
     self.bev_grid_height_downsample_factor = 1.0
+    self.image_u_net_output_features = 512  # config.py:463 (bev_encoder backbone)
+    self.bev_latent_dim = 32  # config.py:464
     # training / model selection (config.py:185-256)
     self.detect_boxes = 1
     self.backbone = 'transFuser'

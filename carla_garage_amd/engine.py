@@ -448,13 +448,19 @@ class Engine:
     m = self.m
     bb = m.backbone
     self.aim = self.cfg.backbone == 'aim'  # team_code/aim.py: image branch only, no LiDAR branch, no fusion transformers
-    self.video = (not self.aim) and getattr(bb, 'lidar_video', False)  # BASELINE config 5: Video-Swin LiDAR branch (swin.py)
+    self.bev = self.cfg.backbone == 'bev_encoder'  # team_code/bev_encoder.py: lift to BEV + second RegNet (bev.py)
+    self.bev_runner = None
+    if self.bev:
+      from .bev import BevEncoderRunner
+      self.bev_runner = BevEncoderRunner(self)
+      self.bev_runner.build_specs()
+    self.video = (not (self.aim or self.bev)) and getattr(bb, 'lidar_video', False)  # BASELINE config 5: Video-Swin LiDAR branch (swin.py)
     self.swin = None
     if self.video:
       from .swin import VideoSwin
       self.swin = VideoSwin(self)
       self.swin.build_specs()
-    branches = [('image_encoder', bb.image_encoder)] + ([] if (self.aim or self.video) else [('lidar_encoder', bb.lidar_encoder)])
+    branches = [] if self.bev else [('image_encoder', bb.image_encoder)] + ([] if (self.aim or self.video) else [('lidar_encoder', bb.lidar_encoder)])
     for br, enc in branches:
       p = f'backbone.{br}'
       self._spec(f'{p}.stem', enc['stem'].conv.weight, bn=enc['stem'].bn, stride=2, pad=1, cin_store=8)
@@ -467,7 +473,7 @@ class Engine:
           self._spec(q + '.conv3', blk.conv3.conv.weight, bn=blk.conv3.bn)
           if blk.downsample is not None:
             self._spec(q + '.downsample', blk.downsample.conv.weight, bn=blk.downsample.bn, stride=blk.stride)
-    for i in range(0 if self.aim else 4):
+    for i in range(0 if (self.aim or self.bev) else 4):
       for nme in ('lidar_channel_to_img', 'img_channel_to_lidar'):
         conv = getattr(bb, nme)[i]
         self._spec(f'backbone.{nme}.{i}', conv.weight, conv.bias)
@@ -1174,6 +1180,8 @@ class Engine:
         if i == 2 and self.tape is not None:
           self.tape.mark()
       xl = xi
+    elif self.bev:  # team_code/bev_encoder.py:146-233
+      xi, xl = self.bev_runner.forward(xi, lidar_bev.float().contiguous())
     else:
       lidar_in = lidar_bev.float().contiguous()
       lanes.hold(lidar_in)

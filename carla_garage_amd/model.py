@@ -75,9 +75,8 @@ class LidarCenterNet(nn.Module):
   def __init__(self, config):
     super().__init__()
     self.config = config
-    if config.backbone not in ('transFuser', 'aim'):
-      # model.py:45-46 raises for unknown names; 'bev_encoder' exists in the reference but is not built yet
-      raise ValueError('The chosen vision backbone does not exist on the MI355X path. The options are: transFuser, aim')
+    if config.backbone not in ('transFuser', 'aim', 'bev_encoder'):
+      raise ValueError('The chosen vision backbone does not exist. The options are: transFuser, aim, bev_encoder')  # model.py:45-46
     if config.backbone == 'aim' and (config.use_semantic or config.use_depth or config.detect_boxes or config.use_bev_semantic):
       # the reference itself cannot build these heads on the AIM backbone (model.py:71 reads backbone.perspective_upsample_factor,
       # which team_code/aim.py does not define; there is no BEV feature grid): BASELINE config 1 switches them off
@@ -104,7 +103,7 @@ class LidarCenterNet(nn.Module):
       self.checkpoint_query = nn.Parameter(torch.zeros(1, config.predict_checkpoint_len + 1, d))
 
     # ---- sub-modules in the reference's registration order
-    self.backbone = M.TransfuserBackbone(config) if config.backbone == 'transFuser' else M.AIMBackbone(config)
+    self.backbone = {'transFuser': M.TransfuserBackbone, 'aim': M.AIMBackbone, 'bev_encoder': M.BevEncoder}[config.backbone](config)
     if config.detect_boxes:
       self.head = M.LidarCenterNetHead(config)
     up = getattr(self.backbone, 'perspective_upsample_factor', 1)

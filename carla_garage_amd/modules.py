@@ -269,6 +269,51 @@ class TransfuserBackbone(nn.Module):
       self.c5_conv = nn.Conv2d(lidar_chs[-1], ch, 1)
 
 
+class UpsamplingConcat(nn.Module):
+  """Container for team_code/bev_encoder.py:252-272: two 3x3 convs (no bias), each followed by InstanceNorm2d + ReLU (no parameters)."""
+  forward = _no_forward
+
+  def __init__(self, cin, cout):
+    super().__init__()
+    self.conv = nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1, bias=False), nn.InstanceNorm2d(cout), nn.ReLU(inplace=True),
+                              nn.Conv2d(cout, cout, 3, padding=1, bias=False), nn.InstanceNorm2d(cout), nn.ReLU(inplace=True))
+
+
+class BevEncoder(nn.Module):
+  """Container for team_code/bev_encoder.py:15-137 (SimpleBEV-style lift of the image features into the BEV grid, LiDAR concatenated in BEV,
+  a second RegNet on the fused grid).  Both RegNets lose their last stage (:36-38,77-79)."""
+  forward = _no_forward
+
+  def __init__(self, config):
+    super().__init__()
+    if config.image_architecture != 'regnety_032' or config.lidar_architecture != 'regnety_032':
+      raise ValueError('the MI355X path implements bev_encoder with regnety_032 image / BEV networks '
+                       f'(got {config.image_architecture} / {config.lidar_architecture})')
+    self.config = config
+    grid, valid = projection_grid(config)
+    self.grid = nn.Parameter(grid, requires_grad=False)
+    self.bev_projection_normalizer = nn.Parameter(torch.finfo(torch.float32).eps + valid.sum(dim=3).unsqueeze(1), requires_grad=False)
+    self.valid_bev_pixels = nn.Parameter(valid.max(dim=3)[0].unsqueeze(1).transpose(2, 3).contiguous(), requires_grad=False)
+    in_ch = config.lidar_seq_len * (2 if config.use_ground_plane else 1)
+    self.image_encoder = RegNetY(3)
+    del self.image_encoder['s4']
+    self.bev_encoder = RegNetY(in_ch + config.bev_latent_dim)
+    del self.bev_encoder['s4']
+    widths = REGNETY_032['widths']
+    self.num_features = widths[2]
+    self.perspective_upsample_factor = 16 // config.perspective_downsample_factor
+    ch = config.bev_features_chanels
+    if config.detect_boxes or config.use_bev_semantic:
+      self.up_conv5 = nn.Conv2d(ch, ch, 3, padding=1)
+      self.up_conv4 = nn.Conv2d(ch, ch, 3, padding=1)
+      self.c5_conv = nn.Conv2d(self.num_features, ch, 1)
+    self.upsampling_layer = UpsamplingConcat(widths[1] + widths[2], config.image_u_net_output_features)
+    self.depth_layer = nn.Conv2d(config.image_u_net_output_features, config.bev_latent_dim, kernel_size=1)
+    self.bev_compressor = nn.Sequential(nn.Conv2d(config.bev_latent_dim, config.bev_latent_dim, 3, padding=1, bias=False),
+                                        nn.InstanceNorm2d(config.bev_latent_dim), nn.GELU())
+    self.num_image_features = config.bev_latent_dim
+
+
 class AIMBackbone(nn.Module):
   """Container for team_code/aim.py:10-30: one RegNetY-3.2GF image encoder, no LiDAR branch, no fusion (BASELINE config 1)."""
   forward = _no_forward
@@ -345,6 +390,35 @@ class GRUWaypointsPredictorInterFuser(nn.Module):
       self.encoder = nn.Linear(target_point_size, hidden_size)
     self.target_point_size, self.hidden_size, self.waypoints = target_point_size, hidden_size, waypoints
     self.decoder = nn.Linear(hidden_size, 2)
+
+
+def projection_grid(config):
+  """team_code/transfuser_utils.py:596-665 (create_projection_grid): for every voxel centre of the (depth, width, height) grid around the car
+  the camera pixel a pinhole projection puts it on, in the reference's normalised coordinates ((u, v) / (0.5 size - 0.5) - 1, third
+  component 0), and the mask of voxels that land inside the image in front of the camera.  Returns grid (1, d, w, h, 3), valid (1, d, w, h)."""
+  mpp = 1.0 / config.pixels_per_meter
+  xs = torch.arange(config.min_x, config.max_x, mpp) + 0.5 * mpp  # lateral (width)
+  ys = torch.arange(config.min_y, config.max_y, mpp) + 0.5 * mpp  # forward (depth)
+  mz = mpp * config.bev_grid_height_downsample_factor
+  zs = torch.arange(config.min_z_projection, config.max_z_projection, mz) + 0.5 * mz
+  fwd, lat, up = torch.meshgrid(ys, xs, zs, indexing='ij')
+  d, w, h = fwd.shape
+  cam = torch.tensor(config.camera_pos, dtype=torch.float32)
+  pts = torch.stack((fwd, lat, up), 0).reshape(3, -1) - cam.unsqueeze(1)
+  f = config.camera_width / (2.0 * np.tan(config.camera_fov * np.pi / 360.0))
+  intr = torch.from_numpy(np.array([[f, 0.0, config.camera_width / 2.0], [0.0, f, config.camera_height / 2.0],
+                                    [0.0, 0.0, 1.0]])).to(torch.float32)
+  proj = intr @ torch.stack((pts[1], pts[2], pts[0]))
+  depth = proj[2:3]
+  grid = torch.zeros_like(proj)
+  grid[:2] = proj[:2] / depth
+  grid = grid.view(3, d, w, h)
+  inside = (grid[0:1] >= 0.0) & (grid[0:1] < config.camera_width) & (grid[1:2] >= 0.0) & (grid[1:2] < config.camera_height) & \
+      (depth.view(1, d, w, h) > 0.0)
+  grid[0:1] = grid[0:1] / (0.5 * config.camera_width - 0.5) - 1.0
+  grid[1:2] = grid[1:2] / (0.5 * config.camera_height - 0.5) - 1.0
+  grid = grid.reshape(1, 3, d, w, h, 1).transpose(1, 5).squeeze(1)
+  return grid.contiguous(), inside.to(torch.float32)
 
 
 def visibility_mask(config):

@@ -469,6 +469,33 @@ def bn_bwd_rows(dy, y, x, gamma, save_mean, save_invstd, partial, nrows, dgamma,
   return dx, dres
 
 
+def instance_norm_fwd(x, act=ACT_NONE, eps=1e-5):
+  """nn.InstanceNorm2d (affine=False, no running statistics) on NHWC x, optionally fused with ReLU: BatchNorm arithmetic on each sample's
+  rows (team_code/bev_encoder.py:120,262-267).  Returns (y, saved mean [B,C], saved invstd [B,C])."""
+  B, H, W, C = x.shape
+  dev = x.device
+  ws = torch.empty((B, 2 * C), device=dev, dtype=torch.float64)
+  scale, shift, mean, invstd = (torch.empty((B, C), device=dev, dtype=torch.float32) for _ in range(4))
+  y = torch.empty_like(x)
+  for b in range(B):
+    bn_stats(x[b], ws[b])
+    bn_finalize(ws[b], None, None, None, None, None, scale[b], shift[b], mean[b], invstd[b], H * W, eps=eps)
+    affine_act(x[b], y[b], scale=scale[b], shift=shift[b], act=act)
+  return y, mean, invstd
+
+
+def instance_norm_bwd(dy, y, x, mean, invstd, relu):
+  B, H, W, C = x.shape
+  dy = dy.view(B, H, W, C)
+  dx = torch.empty_like(x)
+  scratch = bn_scratch(C, x.device)
+  for b in range(B):
+    lib.tfpp_bn_bwd_reduce(ptr(dy[b]), ptr(y[b]), ptr(x[b]), ptr(mean[b]), ptr(invstd[b]), ptr(scratch), None, H * W, C, int(relu), dt(x), stream())
+    lib.tfpp_bn_bwd_apply(ptr(dy[b]), ptr(y[b]), ptr(x[b]), None, ptr(mean[b]), ptr(invstd[b]), None, ptr(scratch), ptr(dx[b]), None, None, None,
+                          H * W, C, int(relu), dt(x), stream())
+  return dx
+
+
 def bn1d_scalar(x, rm, rv, nbt, training, momentum=0.1, eps=1e-5):
   y = torch.empty_like(x)
   lib.tfpp_bn1d_scalar(ptr(_chk(x)), ptr(y), ptr(rm), ptr(rv), ptr(nbt), x.numel(), int(training), momentum, eps, stream())
@@ -629,6 +656,21 @@ def softmax_window_bias(s, table, rel_index, mask, windows, heads, n, alpha, ld=
   lib.tfpp_softmax_window_bias(ptr(s), ptr(table), ptr(rel_index), ptr(mask), windows, heads, n, ld or n, mask.shape[0] if mask is not None else 1,
                                alpha, dt(s), stream())
   return s
+
+
+def bev_lift_fwd(feat, coords, scale, D, W, Z):
+  """feat [B, Hf, Wf, C] -> [B, W, D, C] (team_code/bev_encoder.py:180-201)."""
+  B, Hf, Wf, C = feat.shape
+  out = torch.empty((B, W, D, C), device=feat.device, dtype=feat.dtype)
+  lib.tfpp_bev_lift_fwd(ptr(_chk(feat)), ptr(coords), ptr(scale), ptr(out), B, Hf, Wf, C, D, W, Z, dt(feat), stream())
+  return out
+
+
+def bev_lift_bwd(dout, coords, scale, Hf, Wf, D, W, Z):
+  B, _, _, C = dout.shape
+  dfeat = zeros((B, Hf, Wf, C), torch.float32, dout.device)
+  lib.tfpp_bev_lift_bwd(ptr(_chk(dout)), ptr(coords), ptr(scale), ptr(dfeat), B, Hf, Wf, C, D, W, Z, dt(dout), stream())
+  return dfeat
 
 
 def drop_path(x, samples, p, seed):

@@ -310,6 +310,16 @@ int tfpp_bilinear_bwd(const void* dy, const float* mul, void* dx, int B, int Hi,
                       int64_t dx_ld, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * bev_encoder backbone (team_code/bev_encoder.py:180-201): camera -> BEV lift.  out[b][i][j][c] = scale[i][j] * sum_z bilinear(feat[b], coords[j][i][z])
+ * with feat (B, Hf, Wf, C) NHWC, coords (D, W, Z, 2) sample positions in feature pixels (grid_sample's align_corners=False un-normalisation
+ * of create_projection_grid's output, zeros padding), scale (W, D) = valid_bev_pixels / bev_projection_normalizer in the transposed (image)
+ * orientation; out (B, W, D, C).  bwd: dfeat (fp32, caller-zeroed) += adjoint, fp32 atomics. */
+int tfpp_bev_lift_fwd(const void* feat, const float* coords, const float* scale, void* out, int B, int Hf, int Wf, int C, int D, int W,
+                      int Z, int dtype, void* stream);
+int tfpp_bev_lift_bwd(const void* dout, const float* coords, const float* scale, float* dfeat, int B, int Hf, int Wf, int C, int D, int W,
+                      int Z, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Video-Swin LiDAR backbone (BASELINE config 5; team_code/video_swin_transformer.py, consumed at transfuser.py:44-50,151-155).
  * patchify3d: im2col of PatchEmbed3D's Conv3d(1, 96, kernel = stride = (2, 4, 4)) (:427-467): x fp32 (B, T, H, W) ->
  *   rows (b, t/2, h/4, w/4) x 32 values ordered (kt, kh, kw); the projection itself is tfpp_conv_gemm with K = 32.

@@ -170,6 +170,30 @@ def write_swin_train_golden():
   write_train_golden(model, cfg, 2, 'tfpp_swin_train_bs2.npz')
 
 
+def write_bev_golden():
+  """backbone = 'bev_encoder' (team_code/bev_encoder.py): eval forward at bs = 1 (+ taps of the lifted BEV features and the fused grid) and one
+  train-mode step at bs = 2 on the unmodified reference."""
+  model, _ = ref_harness.build_reference_model(backbone='bev_encoder')
+  cfg = P.PortConfig()
+  sd = P.generic_state_dict(model.state_dict(), base=P.make_state_dict(cfg))
+  model.load_state_dict(sd, strict=True)
+  model.eval()
+  taps = {}
+  hooks = [model.backbone.depth_layer.register_forward_hook(lambda m, i, o: taps.__setitem__('bev_depth_layer', _np(o)[:, ::4, ::4, ::8].copy())),
+           model.backbone.bev_compressor.register_forward_hook(lambda m, i, o: taps.__setitem__('bev_compressed', _np(o)[:, ::4, ::8, ::8].copy())),
+           model.backbone.bev_compressor[0].register_forward_hook(lambda m, i, o: taps.__setitem__('bev_lifted', _np(i[0])[:, ::4, ::8, ::8].copy()))]
+  with torch.inference_mode():
+    out = model(*P.make_inputs(1, cfg))
+  for h in hooks:
+    h.remove()
+  d = pack_outputs(out)
+  d.update(taps)
+  d['keys'] = np.array(list(sd.keys()))
+  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_bev_eval_bs1.npz'), **d)
+  print('bev eval:', d['pred_target_speed'], {k: v.shape for k, v in taps.items()})
+  write_train_golden(model, cfg, 2, 'tfpp_bev_train_bs2.npz')
+
+
 def write_temporal_golden():
   """lidar_seq_len = 6 on the default 2-D RegNet LiDAR branch (6 stacked BEV frames as input channels): the velocity / brake CenterNet
   heads and their losses (center_net.py:29-31,119-123) -- one train-mode step at bs = 2 on the unmodified reference."""
@@ -231,6 +255,9 @@ def main():
     return
   if only == {'swin_train'}:
     write_swin_train_golden()
+    return
+  if only == {'bev'}:
+    write_bev_golden()
     return
   if only == {'temporal'}:
     write_temporal_golden()

@@ -328,8 +328,8 @@ def generic_state_dict(model_sd, base=None, seed=0):
       out[k] = base[k]
     elif not v.dtype.is_floating_point:
       out[k] = v.clone()
-    elif k in ('valid_bev_pixels', 'valid_bev_pixels_inv'):
-      out[k] = v.clone()
+    elif k.split('.')[-1] in ('valid_bev_pixels', 'valid_bev_pixels_inv', 'grid', 'bev_projection_normalizer'):
+      out[k] = v.clone()  # geometry constants registered as (frozen) parameters
     else:
       if k.endswith('relative_position_bias_table'):
         t = detrand.uniform(k, shape, -0.5, 0.5, seed)

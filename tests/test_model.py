@@ -234,6 +234,48 @@ def test_wp_variant_forward():
   assert out[1] is None and out[2] is None
 
 
+def _bev_model(dtype='fp32'):
+  m = LidarCenterNet(GlobalConfig(backbone='bev_encoder', tfpp_dtype=dtype))
+  m.load_state_dict(P.generic_state_dict(m.state_dict(), base=P.make_state_dict(P.PortConfig())), strict=True)
+  return m.cuda()
+
+
+@pytest.mark.gpu
+def test_bev_encoder_eval_forward_fp32_vs_reference_golden():
+  """backbone = 'bev_encoder' (team_code/bev_encoder.py) through the HIP path (carla_garage_amd/bev.py) against the unmodified reference:
+  the depth layer, the camera -> BEV lift, the compressed BEV features, then every model output, 1e-3 relative."""
+  g = U.load_golden('tfpp_bev_eval_bs1.npz')
+  m = _bev_model().eval()
+  assert list(m.state_dict().keys()) == [str(k) for k in g['keys']]
+  eng = m._engine()
+  eng.bev_runner.taps = {}
+  with torch.inference_mode():
+    out = m(*[x.cuda() for x in P.make_inputs(1)])
+  t = eng.bev_runner.taps
+  errs = {'bev_depth_layer': U.rel_err(U.to_np(t['depth'].float().permute(0, 3, 1, 2))[:, ::4, ::4, ::8], g['bev_depth_layer']),
+          'bev_lifted': U.rel_err(U.to_np(t['lifted'].float().permute(0, 3, 1, 2))[:, ::4, ::8, ::8], g['bev_lifted']),
+          'bev_compressed': U.rel_err(U.to_np(t['compressed'].float().permute(0, 3, 1, 2))[:, ::4, ::8, ::8], g['bev_compressed'])}
+  errs['pred_target_speed'] = U.rel_err(U.to_np(out[1]), g['pred_target_speed'])
+  errs['pred_checkpoint'] = U.rel_err(U.to_np(out[2]), g['pred_checkpoint'])
+  for i, n in enumerate(('heatmap', 'wh', 'offset', 'yaw_class', 'yaw_res')):
+    errs['bb_' + n] = U.rel_err(U.to_np(out[6][i]), g['bb_' + n])
+  errs['pred_bev_semantic'] = U.rel_err(U.to_np(out[4])[:, :, ::U.BEV_STRIDE, ::U.BEV_STRIDE], g['pred_bev_semantic_strided'])
+  errs['pred_semantic'] = U.rel_err(U.to_np(out[3])[:, :, ::U.SEM_STRIDE, ::U.SEM_STRIDE], g['pred_semantic_strided'])
+  errs['pred_depth'] = U.rel_err(U.to_np(out[5])[:, ::U.DEPTH_STRIDE, ::U.DEPTH_STRIDE], g['pred_depth_strided'])
+  _report('bev_eval_fp32_bs1', errs)
+  assert max(errs.values()) <= 1e-3, errs
+
+
+@pytest.mark.gpu
+def test_bev_encoder_train_step_fp32_vs_reference_golden():
+  """One train step at bs = 2 (batch-statistic BN in both RegNets, InstanceNorm, the lift's adjoint) against the unmodified reference.
+  This configuration is ill-conditioned in fp32: the reference's OWN gradients in fp32 and fp64 (same weights, same batch, CPU) differ by
+  4.9e-2 on image_encoder.s1.b1.se.fc1, 2.0e-2 on bev_encoder.s1.b2.se.fc1, ~1e-2 across both RegNets, and its losses by 3e-4 (yaw_res) /
+  1e-4 (checkpoint) -- the BEV RegNet normalises 2 x 16 x 16 samples per channel in stage 3.  The bars are twice that spread; the new
+  operators themselves are pinned tightly in tests/test_ops_gpu.py::test_bev_lift_and_instance_norm_vs_torch."""
+  _check_train_step_vs_golden(2, 'tfpp_bev_train_bs2.npz', 'train_fp32_bev', model=_bev_model(), norm_tol=5e-2, norm_tol_se=1e-1, elem_tol=0.4)
+
+
 def _swin_model(dtype):
   """BASELINE config 5: TransFuser++ with the Video-Swin LiDAR branch (6 LiDAR frames), deterministic weights by name."""
   cfg = GlobalConfig(lidar_architecture='video_swin_tiny', lidar_seq_len=6, tfpp_dtype=dtype)
@@ -344,7 +386,7 @@ def _compare_grads(eng, g):
   return worst_norm, worst_elem
 
 
-def _check_train_step_vs_golden(bs, fname, tag, model=None, port_cfg=None):
+def _check_train_step_vs_golden(bs, fname, tag, model=None, port_cfg=None, norm_tol=None, norm_tol_se=None, elem_tol=None):
   g = U.load_golden(fname)
   m = (model if model is not None else _model()).train()
   names, vals, eng = _engine_train_step(m, bs, port_cfg)
@@ -357,9 +399,10 @@ def _check_train_step_vs_golden(bs, fname, tag, model=None, port_cfg=None):
   rs = {str(n): abs(float(sd[str(n)].double().sum()) - s) / (abs(s) + 1.0) for n, s in zip(g['running_names'], g['running_sums'])}
   _report(tag, {'losses': errs, 'grad_norm_worst': top, 'grad_elem_worst': tope, 'running_worst': max(rs.values())})
   assert max(errs.values()) <= 1e-3, errs
-  over = {n: e for n, e in worst_norm.items() if e > (GRAD_NORM_TOL_SE_FC1 if '.se.fc1.' in n else GRAD_NORM_TOL)}
+  tol, tol_se = norm_tol or GRAD_NORM_TOL, norm_tol_se or GRAD_NORM_TOL_SE_FC1
+  over = {n: e for n, e in worst_norm.items() if e > (tol_se if '.se.fc' in n else tol)}
   assert not over, over
-  assert max(worst_elem.values()) <= GRAD_ELEM_TOL, tope
+  assert max(worst_elem.values()) <= (elem_tol or GRAD_ELEM_TOL), tope
   assert max(rs.values()) <= 1e-3
   return m, eng
 

@@ -942,3 +942,41 @@ def test_swin_gather_softmax_bias_and_training_kernels(ops):
   per = a.view(64, -1)
   assert ((per == per[:, :1]).all()) and all(v == 0.0 or abs(v - 1.0 / 0.75) < 1e-6 for v in per[:, 0].tolist())
   assert 5 <= int((per[:, 0] == 0).sum()) <= 30  # 16 expected of 64
+
+
+def test_bev_lift_and_instance_norm_vs_torch(ops):
+  """tfpp_bev_lift_fwd / _bwd against F.grid_sample exactly as team_code/bev_encoder.py:180-201 calls it (5-D input with a depth-1 volume,
+  align_corners=False, zeros padding, sum over the height axis, normaliser, transpose, visibility mask) on a small grid, forward and the
+  gradient w.r.t. the image features; InstanceNorm2d (+ ReLU) forward / backward against torch."""
+  B, C, Hf, Wf, D, W, Z = 2, 8, 6, 10, 7, 9, 5
+  g = torch.Generator().manual_seed(0)
+  grid = torch.rand(1, D, W, Z, 3, generator=g) * 2.6 - 1.3       # some samples outside [-1, 1]: zeros padding
+  grid[..., 2] = 0.0
+  valid_vox = (torch.rand(1, D, W, Z, generator=g) < 0.6).float()
+  normalizer = torch.finfo(torch.float32).eps + valid_vox.sum(3).unsqueeze(1)          # (1, 1, D, W)
+  valid_pix = valid_vox.max(3)[0].unsqueeze(1).transpose(2, 3).contiguous()             # (1, 1, W, D)
+  feat = rnd(B, C, Hf, Wf, seed=1).requires_grad_(True)
+  samp = F.grid_sample(feat.unsqueeze(2), grid.repeat(B, 1, 1, 1, 1), align_corners=False, padding_mode='zeros')  # (B, C, D, W, Z)
+  want = (samp.sum(4) / normalizer).transpose(2, 3) * valid_pix                       # (B, C, W, D)
+  gout = rnd(B, C, W, D, seed=2)
+  want.backward(gout)
+  coords = torch.stack((((grid[0, ..., 0] + 1) * Wf - 1) * 0.5, ((grid[0, ..., 1] + 1) * Hf - 1) * 0.5), -1).contiguous()
+  scale = (valid_pix[0, 0] / normalizer[0, 0].t()).contiguous()
+  for dtype in (torch.float32, torch.bfloat16):
+    f_nhwc = dev(nhwc(feat.detach()), dtype)
+    out = ops.bev_lift_fwd(f_nhwc, dev(coords), dev(scale), D, W, Z)
+    check(f'bev_lift_fwd.{dtype}', nchw(out.float().cpu()), want.detach(), dtype)
+    dfeat = ops.bev_lift_bwd(dev(nhwc(gout), dtype), dev(coords), dev(scale), Hf, Wf, D, W, Z)
+    check(f'bev_lift_bwd.{dtype}', nchw(dfeat.cpu()), feat.grad, dtype, scale=2.0)
+  for act, relu in ((0, False), (1, True)):
+    x = rnd(3, 16, 9, 11, seed=3).requires_grad_(True)
+    y = F.instance_norm(x)
+    y = torch.relu(y) if relu else y
+    gy = rnd(3, 16, 9, 11, seed=4)
+    y.backward(gy)
+    for dtype in (torch.float32, torch.bfloat16):
+      xd = dev(nhwc(x.detach()), dtype)
+      yd, mean, invstd = ops.instance_norm_fwd(xd, act)
+      check(f'instance_norm_fwd.{dtype}.{relu}', nchw(yd.float().cpu()), y.detach(), dtype, scale=2.0)
+      dx = ops.instance_norm_bwd(dev(nhwc(gy), dtype), yd, xd, mean, invstd, relu)
+      check(f'instance_norm_bwd.{dtype}.{relu}', nchw(dx.float().cpu()), x.grad, dtype, scale=4.0)
