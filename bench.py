@@ -162,7 +162,7 @@ def inference_latency(model, cfg, device, log, iters=20):
   return out
 
 
-def video_swin_forward(device, log, bs=4, iters=10):
+def video_swin_forward(device, log, bs=4, iters=10, train=True):
   """BASELINE config 5 (TransFuser++ with the Video-Swin LiDAR branch, 6 LiDAR frames -> 3 time frames per scale, bs = 4 per GPU):
   inference forward and training step in bf16, random-init weights, synthetic frames, as hipGraph replays.  Reported beside the headline
   metric (BASELINE config 3), never as ``value``."""
@@ -202,7 +202,10 @@ def video_swin_forward(device, log, bs=4, iters=10):
     log(f'video-swin hipGraph capture failed: {type(e).__name__}: {e}')
   log(f'video-swin forward bs={bs}: {out}')
   # the same configuration trained: fwd + 12 losses + bwd + AdamW(amsgrad), train-mode BN, dropout and stochastic depth on
+  # (single-process runs only: a Trainer broadcasts / all-reduces over the default group, and only rank 0 executes this leg)
   try:
+    if not train:
+      raise RuntimeError('skipped in multi-rank runs')
     from carla_garage_amd.graph import GraphedTrainStep
     from carla_garage_amd.trainer import Trainer
     model.train()
@@ -478,7 +481,7 @@ def main():
   if rank == 0 and not args.no_inference:
     fwd = inference_latency(model, cfg, device, log)
     lidar_hist = lidar_histogram_latency(cfg, device, log)
-    swin_fwd = video_swin_forward(device, log)
+    swin_fwd = video_swin_forward(device, log, train=rccl_ranks is None)
   if rccl_ranks is not None:
     dist.barrier()
 
