@@ -49,7 +49,8 @@ class BgemmParams(ctypes.Structure):
 class AttnParams(ctypes.Structure):
   _fields_ = [('q', vp), ('k', vp), ('v', vp), ('o', vp), ('lse', vp), ('d_o', vp), ('dq', vp), ('dk', vp), ('dv', vp), ('delta', vp),
               ('debug_p', vp), ('B', i32), ('nh', i32), ('T', i32), ('d', i32), ('ld_q', i64), ('ld_kv', i64), ('ld_o', i64),
-              ('scale', f32), ('p_drop', f32), ('seed', ctypes.c_uint64), ('seed_offset', vp)]
+              ('scale', f32), ('p_drop', f32), ('seed', ctypes.c_uint64), ('seed_offset', vp), ('bias', vp), ('mask', vp), ('p_out', vp),
+              ('n_mask', i32), ('ld_b', i64), ('ld_p', i64)]
 
 
 class PackDesc(ctypes.Structure):

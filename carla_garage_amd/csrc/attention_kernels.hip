@@ -119,11 +119,53 @@ __device__ __forceinline__ float attn_softmax(f32x4_t (&S)[ATT_KF], int nkf, flo
   return mx + __logf(sum);
 }
 
+// window attention: scores -> probabilities with the dense relative-position bias and shift mask added; keys >= T are excluded.
+// bias / mask rows of this lane's query (pitch-ld_b rows, 16-byte aligned: the lane's 4 keys of a fragment are one float4)
+__device__ __forceinline__ void attn_softmax_window(f32x4_t (&S)[ATT_KF], int nkf, int T, int kg, float scale, const float* __restrict__ brow,
+                                                    const float* __restrict__ mrow) {
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int f = 0; f < ATT_KF; ++f)
+    if (f < nkf) {
+      const int key0 = f * 16 + kg * 4;
+      const float4 bv = *reinterpret_cast<const float4*>(brow + key0);
+      float4 mv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mrow) mv = *reinterpret_cast<const float4*>(mrow + key0);
+      const float add[4] = {bv.x + mv.x, bv.y + mv.y, bv.z + mv.z, bv.w + mv.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        S[f][r] = (key0 + r < T) ? S[f][r] * scale + add[r] : -3.0e38f;
+        mx = fmaxf(mx, S[f][r]);
+      }
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int f = 0; f < ATT_KF; ++f)
+    if (f < nkf) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { S[f][r] = __expf(S[f][r] - mx); sum += S[f][r]; }
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int f = 0; f < ATT_KF; ++f)
+    if (f < nkf) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[f][r] *= inv;
+    }
+}
+
 // stage one 128-wide d chunk [dc, dc + 128) of a [T][*] token matrix (row stride ld) into the swizzled V image; chunks past d are zero.
 // The loads go out in batches of 10 per thread before the first LDS store (a load -> store -> load chain costs one L2 latency per
 // 16 bytes: the first version of this kernel spent most of its time here).
-__device__ __forceinline__ void stage_vimg(const bf16_t* __restrict__ vh, long ld, int T, int d, int dc, int cpr, unsigned char* vimg, int tid) {
-  const int total = T * cpr;  // cpr: 16-byte chunks per row actually used (2 per 16-wide output fragment; a power of two in this model)
+__device__ __forceinline__ void stage_vimg(const bf16_t* __restrict__ vh, long ld, int T, int d, int dc, int cpr, unsigned char* vimg, int tid,
+                                           int t_pad = 0) {
+  // rows T .. t_pad - 1 (window attention: T = 147 inside 32-key contraction blocks) are written as zeros: their probabilities are exact
+  // zeros, but 0 x stale LDS contents could be NaN
+  const int total = (t_pad > T ? t_pad : T) * cpr;  // cpr: 16-byte chunks per row actually used (2 per 16-wide output fragment; a power of two in this model)
   const int sh = __builtin_ctz(cpr);
   const bool pow2 = (cpr & (cpr - 1)) == 0;
   constexpr int U = 10;
@@ -138,7 +180,7 @@ __device__ __forceinline__ void stage_vimg(const bf16_t* __restrict__ vh, long l
       if (c < total) {
         const int row = pow2 ? (c >> sh) : (c / cpr), ch = c - row * cpr, d0 = dc + ch * 8;
         off[u] = vimg_off(row, ch);
-        if (d0 < d) r[u] = *reinterpret_cast<const uint4*>(vh + (size_t)row * ld + d0);
+        if (d0 < d && row < T) r[u] = *reinterpret_cast<const uint4*>(vh + (size_t)row * ld + d0);
       }
     }
 #pragma unroll
@@ -178,13 +220,13 @@ __device__ __forceinline__ void frags_times_image(const uint4 (&af)[ATT_KF / 2],
 }
 template <int NKS> struct AttnNF { static constexpr int value = NKS <= 1 ? 2 : (NKS <= 2 ? 4 : ATT_DC / 16); };
 
-template <int NKS>
+template <int NKS, bool WIN = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(tfpp_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* kimg = smem;                       // 2 x 20 KB (phase 1), later the per-wave output strips
   unsigned char* vimg = smem + 2 * K_SLICE_BYTES;   // 80 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p16 = lane & 15, kg = lane >> 4;
-  const int T = p.T, d = p.d, nkf = T >> 4;
+  const int T = p.T, d = p.d, nkf = WIN ? (T + 15) >> 4 : T >> 4;
   const int bh = blockIdx.y, b = bh / p.nh, h = bh - b * p.nh;
   const int q0 = blockIdx.x * ATT_TQ + wave * 16;
   const bf16_t* qh = reinterpret_cast<const bf16_t*>(p.q) + (size_t)b * T * p.ld_q + (size_t)h * d;
@@ -197,12 +239,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(tfpp_attn_params p) {
   const unsigned long long t0 = trace ? wall_clock64() : 0ull;
 #define ATT_STAMP(k) do { if (trace) p.delta[k] = (float)(wall_clock64() - t0); } while (0)
   f32x4_t S[ATT_KF];
-  attn_scores<NKS>(qh, p.ld_q, kh, p.ld_kv, T, d, q0 + p16, kimg, tid, lane, S);
+  const int qmine = WIN ? ((q0 + p16 < T) ? q0 + p16 : T - 1) : q0 + p16;  // windows: queries past T repeat the last one (never stored)
+  attn_scores<NKS>(qh, p.ld_q, kh, p.ld_kv, T, d, qmine, kimg, tid, lane, S);
   ATT_STAMP(0);
-  const float lse = attn_softmax(S, nkf, p.scale);
+  float lse = 0.f;
+  if constexpr (WIN) {
+    const float* brow = p.bias + ((size_t)h * T + qmine) * p.ld_b;
+    const float* mrow = p.mask ? p.mask + ((size_t)(b % p.n_mask) * T + qmine) * p.ld_b : nullptr;
+    attn_softmax_window(S, nkf, T, kg, p.scale, brow, mrow);
+    if (p.p_out && q0 + p16 < T) {  // probabilities for the backward: 4 consecutive keys = one 8-byte store
+      bf16_t* prow = reinterpret_cast<bf16_t*>(p.p_out) + ((size_t)bh * T + q0 + p16) * p.ld_p;
+#pragma unroll
+      for (int f = 0; f < ATT_KF; ++f)
+        if (f < nkf) {
+          const int key0 = f * 16 + kg * 4;
+          if (key0 + 3 < T) {
+            *reinterpret_cast<uint2*>(prow + key0) = make_uint2(pack_bf16x2(S[f][0], S[f][1]), pack_bf16x2(S[f][2], S[f][3]));
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (key0 + r < T) prow[key0 + r] = f2bf(S[f][r]);
+          }
+        }
+    }
+  } else {
+    lse = attn_softmax(S, nkf, p.scale);
+  }
   ATT_STAMP(1);
   const size_t row = (size_t)bh * T + q0 + p16;  // flat (batch, head, query) index: dropout counter and lse / debug rows
-  if (kg == 0 && p.lse) p.lse[row] = lse;
+  if (!WIN && kg == 0 && p.lse) p.lse[row] = lse;
 
   // dropout (same element index as the unfused path: row * T + key) and bf16 A fragments of P
   unsigned long long seed = p.seed;
@@ -232,7 +297,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(tfpp_attn_params p) {
     const int nd = (d - dc < ATT_DC) ? d - dc : ATT_DC, nfr = (nd + 15) >> 4;
     __syncthreads();  // previous chunk's readers are done with the V image (first pass: the K image is dead too)
     if (dc == 0) ATT_STAMP(2);
-    stage_vimg(vh, p.ld_kv, T, d, dc, AttnNF<NKS>::value * 2, vimg, tid);
+    stage_vimg(vh, p.ld_kv, T, d, dc, AttnNF<NKS>::value * 2, vimg, tid, WIN ? ATT_KF * 16 : 0);  // windows: the P.V loop walks all 320 image rows
     __syncthreads();
     if (dc == 0) ATT_STAMP(3);
     f32x4_t o[ATT_DC / 16];
@@ -250,7 +315,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(tfpp_attn_params p) {
     const int cpr = nfr * 2;
     for (int c = lane; c < 16 * cpr; c += 64) {
       const int r = c / cpr, ch = c - r * cpr, d0 = dc + ch * 8;
-      if (d0 < d) *reinterpret_cast<uint4*>(oh + (size_t)(q0 + r) * p.ld_o + d0) = *reinterpret_cast<const uint4*>(st + r * ATT_DC + ch * 8);
+      if (d0 < d && (!WIN || q0 + r < T))
+        *reinterpret_cast<uint4*>(oh + (size_t)(q0 + r) * p.ld_o + d0) = *reinterpret_cast<const uint4*>(st + r * ATT_DC + ch * 8);
     }
   }
 }
@@ -469,6 +535,47 @@ extern "C" int tfpp_attn_fwd(const tfpp_attn_params* p, int dtype, void* stream)
   if (nks <= 2) return launch_attn_fwd<2>(*p, st);
   if (nks <= 5) return launch_attn_fwd<5>(*p, st);
   return launch_attn_fwd<12>(*p, st);
+}
+
+// ---- window attention (Video-Swin): any T <= 320, d <= 32 in this model (one k-step), dense bias / mask, probabilities saved on request
+extern "C" int tfpp_attn_window_fwd(const tfpp_attn_params* p, int dtype, void* stream) {
+  if (!p || dtype != TFPP_BF16 || !p->q || !p->k || !p->v || !p->o || !p->bias) return TFPP_EINVAL;
+  if (p->T < 1 || p->T > ATT_KF * 16 || p->d < 8 || p->d % 8 != 0 || p->d > 64 || p->p_drop != 0.f) return TFPP_EINVAL;
+  if ((p->ld_q | p->ld_kv | p->ld_o) % 8 != 0 || p->ld_b % 4 != 0 || p->ld_b < ((p->T + 15) / 16) * 16 || (p->mask && p->n_mask < 1)) return TFPP_EINVAL;
+  if (p->p_out && (p->ld_p % 4 != 0 || p->ld_p < p->T)) return TFPP_EINVAL;
+  if (((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v | (uintptr_t)p->o | (uintptr_t)p->bias | (uintptr_t)p->mask) & 15) return TFPP_EINVAL;
+  constexpr size_t lds = 2 * K_SLICE_BYTES + V_IMG_BYTES;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((p->T + ATT_TQ - 1) / ATT_TQ, p->B * p->nh);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  if (p->d <= 32) hipLaunchKernelGGL((attn_fwd_kernel<1, true>), grid, dim3(256), lds, st, *p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<2, true>), grid, dim3(256), lds, st, *p);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ void window_bias_dense_kernel(const float* __restrict__ table, const int* __restrict__ rel_index, float* __restrict__ dense, int heads,
+                                         int n, long ld_b) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)heads * n * ld_b) return;
+  const int j = (int)(t % ld_b);
+  const int i = (int)((t / ld_b) % n);
+  const int h = (int)(t / (ld_b * n));
+  dense[t] = j < n ? table[(size_t)rel_index[(size_t)i * n + j] * heads + h] : 0.f;
+}
+
+extern "C" int tfpp_window_bias_dense(const float* table, const int32_t* rel_index, float* dense, int heads, int n, int64_t ld_b, void* stream) {
+  if (!table || !rel_index || !dense || heads < 1 || n < 1 || ld_b < n) return TFPP_EINVAL;
+  const long total = (long)heads * n * ld_b;
+  hipLaunchKernelGGL(window_bias_dense_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, (const int*)rel_index,
+                     dense, heads, n, (long)ld_b);
+  TFPP_CHECK_LAUNCH();
+  return 0;
 }
 
 template <int NKS> static int launch_attn_bwd(const tfpp_attn_params& p, hipStream_t st) {

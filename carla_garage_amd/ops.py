@@ -673,6 +673,29 @@ def bev_lift_bwd(dout, coords, scale, Hf, Wf, D, W, Z):
   return dfeat
 
 
+def window_bias_dense(table, rel_index, heads, n, ld_b):
+  """relative_position_bias_table[relative_position_index] as dense fp32 [heads, n, ld_b] (columns >= n zero)."""
+  dense = torch.empty((heads, n, ld_b), device=table.device, dtype=torch.float32)
+  lib.tfpp_window_bias_dense(ptr(table), ptr(rel_index), ptr(dense), heads, n, ld_b, stream())
+  return dense
+
+
+def attn_window_fwd(q, k, v, o, bias, mask, p_out, *, B, nh, T, d, ld_q, ld_kv, ld_o, scale):
+  """Fused window attention (bf16): o = softmax(scale q k^T + bias[h] + mask[b % n_mask]) v per (window, head); p_out (optional, bf16
+  [B, nh, T, ld_p]) receives the probabilities for the backward."""
+  p = AttnParams()
+  p.q, p.k, p.v, p.o = ptr(q), ptr(k), ptr(v), ptr(o)
+  p.B, p.nh, p.T, p.d, p.ld_q, p.ld_kv, p.ld_o, p.scale = B, nh, T, d, ld_q, ld_kv, ld_o, scale
+  p.bias, p.mask, p.p_out = ptr(bias), ptr(mask), ptr(p_out)
+  p.n_mask = mask.shape[0] if mask is not None else 1
+  p.ld_b = bias.shape[-1]
+  p.ld_p = p_out.shape[-1] if p_out is not None else 0
+  if lib.profiler is not None:
+    lib.profiler.tag('attn_window_fwd<bf16,fused>', 4.0 * B * nh * T * T * d)
+  lib.tfpp_attn_window_fwd(ctypes.byref(p), dt(q), stream())
+  return o
+
+
 def drop_path(x, samples, p, seed):
   """timm DropPath: one keep / drop draw per sample (video_swin_transformer.py:216,276-281)."""
   y = torch.empty_like(x)

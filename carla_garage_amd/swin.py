@@ -12,12 +12,14 @@ the same kernel with the inverse table; the attention core keeps P for backward 
 dQ = dS K, dK = dS^T Q, bias-table gradient by tfpp_window_bias_grad); DropPath (stochastic depth, rates 0 .. 0.2 over the 12 blocks,
 :535) is tfpp_drop_path on the residual branch in window / token layout (one draw per sample)."""
 import math
+import os
 
 import torch
 
 from . import ops
 from ._lib import ACT_GELU, ACT_NONE
 
+FUSED_WINDOW_ATTN = os.environ.get('TFPP_FUSED_WINDOW_ATTN', '1') != '0'  # bf16: fused LDS window attention (0: bgemm -> softmax -> bgemm)
 DROP_PATH_RATE = 0.2  # SwinTransformer3D's default, which transfuser.py:45-47 does not override
 
 
@@ -168,12 +170,23 @@ class VideoSwin:
     q, k, v = flat[0:], flat[C:], flat[2 * C:]
     npad = ops.pad_to(n, 8)
     sbs = (heads * n * npad, n * npad)
-    S = ops.zeros((nwin, heads, n, npad), x.dtype, x.device)           # pad columns stay 0: the P.V product runs K = npad
-    ops.bgemm(q, k, S, M=n, N=n, K=d, lda=3 * C, ldb=3 * C, ldc=npad, batch0=nwin, batch1=heads, a_bs=(n * 3 * C, d), b_bs=(n * 3 * C, d), c_bs=sbs)
-    ops.softmax_window_bias(S, table.detach(), rel, mask, nwin, heads, n, scale, ld=npad)
     O = torch.empty((nslot, C), device=x.device, dtype=x.dtype)
-    ops.bgemm(S, v, O, M=n, N=d, K=npad, lda=npad, ldb=3 * C, ldc=C, batch0=nwin, batch1=heads, a_bs=sbs, b_bs=(n * 3 * C, d), c_bs=(n * C, d),
-              b_km=True)
+    if x.dtype == torch.bfloat16 and FUSED_WINDOW_ATTN:
+      # one workgroup per (window, head, 64 queries): K, V and the 147 x 147 scores of a window stay on the CU (attention_kernels.hip);
+      # training keeps the probabilities (bf16, pitch npad, pad columns zero) for the unfused backward below
+      ld_b = ops.pad_to(n, 16)
+      bias = ops.window_bias_dense(table.detach(), rel, heads, n, ld_b)
+      maskp = None
+      if mask is not None:
+        maskp = self._dev(('maskp', B, D, H, W, ws, ss, ld_b), lambda: torch.nn.functional.pad(mask.cpu(), (0, ld_b - n)).contiguous())
+      S = ops.zeros((nwin, heads, n, npad), x.dtype, x.device) if e.tape is not None else None
+      ops.attn_window_fwd(q, k, v, O, bias, maskp, S, B=nwin, nh=heads, T=n, d=d, ld_q=3 * C, ld_kv=3 * C, ld_o=C, scale=scale)
+    else:
+      S = ops.zeros((nwin, heads, n, npad), x.dtype, x.device)         # pad columns stay 0: the P.V product runs K = npad
+      ops.bgemm(q, k, S, M=n, N=n, K=d, lda=3 * C, ldb=3 * C, ldc=npad, batch0=nwin, batch1=heads, a_bs=(n * 3 * C, d), b_bs=(n * 3 * C, d), c_bs=sbs)
+      ops.softmax_window_bias(S, table.detach(), rel, mask, nwin, heads, n, scale, ld=npad)
+      ops.bgemm(S, v, O, M=n, N=d, K=npad, lda=npad, ldb=3 * C, ldc=C, batch0=nwin, batch1=heads, a_bs=sbs, b_bs=(n * 3 * C, d), c_bs=(n * C, d),
+                b_km=True)
     if e.tape is not None:
 
       def bwd_attn(dO, P=S):

@@ -170,10 +170,22 @@ typedef struct {
   float scale, p_drop;
   uint64_t seed;
   const uint64_t* seed_offset;
+  /* window attention (tfpp_attn_window_fwd, Video-Swin WindowAttention3D): dense additive terms and the saved probabilities */
+  const float* bias;   /* [nh][T][ld_b]: relative-position bias of (head, query, key) */
+  const float* mask;   /* [n_mask][T][ld_b]: shift mask of window b % n_mask, or NULL */
+  void* p_out;         /* NULL, or bf16 [B][nh][T][ld_p]: softmax probabilities for the backward (columns >= T are left untouched) */
+  int n_mask;
+  int64_t ld_b, ld_p;
 } tfpp_attn_params;
 int tfpp_attn_supported(const tfpp_attn_params* p, int dtype); /* 1 if the fused kernels handle (p, dtype) */
 int tfpp_attn_fwd(const tfpp_attn_params* p, int dtype, void* stream);
 int tfpp_attn_bwd(const tfpp_attn_params* p, int dtype, void* stream);
+/* The same forward for the 3-D shifted-window attention of the Video-Swin branch (team_code/video_swin_transformer.py:139-166): B = windows,
+ * T = tokens per window (147: any T <= 320), softmax(scale * q k^T + bias[h] + mask[b % n_mask]) v; bias / mask are dense fp32 with row pitch
+ * ld_b (a multiple of 4, >= T); no dropout.  One workgroup per (window, head, 64 queries): K, V and the scores of a window never leave the CU.
+ * window_bias_dense expands relative_position_bias_table through relative_position_index into that dense layout. */
+int tfpp_attn_window_fwd(const tfpp_attn_params* p, int dtype, void* stream);
+int tfpp_window_bias_dense(const float* table, const int32_t* rel_index, float* dense, int heads, int n, int64_t ld_b, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Weight packing (state_dict layout -> kernel layout, also casts fp32 -> dtype).

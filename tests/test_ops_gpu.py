@@ -980,3 +980,41 @@ def test_bev_lift_and_instance_norm_vs_torch(ops):
       check(f'instance_norm_fwd.{dtype}.{relu}', nchw(yd.float().cpu()), y.detach(), dtype, scale=2.0)
       dx = ops.instance_norm_bwd(dev(nhwc(gy), dtype), yd, xd, mean, invstd, relu)
       check(f'instance_norm_bwd.{dtype}.{relu}', nchw(dx.float().cpu()), x.grad, dtype, scale=4.0)
+
+
+@pytest.mark.parametrize('n,heads,with_mask', [(147, 3, True), (147, 6, False), (64, 24, True), (192, 3, True)])
+def test_fused_window_attention_vs_torch(ops, n, heads, with_mask):
+  """tfpp_attn_window_fwd (Video-Swin WindowAttention3D, video_swin_transformer.py:139-166) on bf16 q / k / v slices of a fused QKV matrix
+  (head-major, d = 32): output and saved probabilities against torch fp32 on the bf16-rounded inputs; bias expanded by
+  tfpp_window_bias_dense from a random table / index, shift mask of 0 / -100 with period n_mask."""
+  dtype = torch.bfloat16
+  W, d, n_mask = 7, 32, 3
+  C = heads * d
+  g = torch.Generator().manual_seed(n + heads)
+  qkv = rnd(W * n + 8, 3 * C, dtype=dtype, seed=5)
+  table = rnd(500, heads, seed=6)
+  rel = torch.randint(0, 500, (n, n), generator=g).int()
+  mask = torch.where(torch.rand(n_mask, n, n, generator=g) < 0.3, torch.tensor(-100.0), torch.tensor(0.0)) if with_mask else None
+  scale = d**-0.5
+  x = qkv[:W * n].float().view(W, n, 3, heads, d).permute(2, 0, 3, 1, 4)      # 3, W, heads, n, d
+  logits = (x[0] * scale) @ x[1].transpose(-2, -1) + table[rel.long()].permute(2, 0, 1)[None]
+  if with_mask:
+    logits = logits + mask[torch.arange(W) % n_mask][:, None]
+  P = torch.softmax(logits, -1)
+  want = (P @ x[2]).transpose(1, 2).reshape(W * n, C)
+  qd = dev(qkv, dtype)
+  flat = qd.view(-1)
+  ld_b, npad = ((n + 15) // 16) * 16, ((n + 7) // 8) * 8
+  bias = ops.window_bias_dense(dev(table), rel.to(DEV), heads, n, ld_b)
+  check('window_bias_dense', bias[..., :n], table[rel.long()].permute(2, 0, 1), torch.float32)
+  maskp = dev(F.pad(mask, (0, ld_b - n))) if with_mask else None
+  O = torch.full((W * n, C), float('nan'), device=DEV, dtype=dtype)
+  Pout = torch.zeros((W, heads, n, npad), device=DEV, dtype=dtype)
+  ops.attn_window_fwd(flat[0:], flat[C:], flat[2 * C:], O, bias, maskp, Pout, B=W, nh=heads, T=n, d=d, ld_q=3 * C, ld_kv=3 * C, ld_o=C, scale=scale)
+  check(f'attn_window_fwd.O.n{n}h{heads}', O, want, dtype, scale=2.0)
+  check(f'attn_window_fwd.P.n{n}h{heads}', Pout[..., :n], P, dtype, scale=2.0)
+  assert float(Pout[..., n:].abs().max()) == 0.0 if npad > n else True
+  # and without saving the probabilities (inference)
+  O2 = torch.empty_like(O)
+  ops.attn_window_fwd(flat[0:], flat[C:], flat[2 * C:], O2, bias, maskp, None, B=W, nh=heads, T=n, d=d, ld_q=3 * C, ld_kv=3 * C, ld_o=C, scale=scale)
+  assert torch.equal(O, O2)
