@@ -102,6 +102,46 @@ extern "C" int tfpp_cast(const void* in, void* out, int64_t n, int dtype_in, int
   return 0;
 }
 
+// Narrow host dtypes of the reference's collated batch (uint8 camera frames and semantic maps, int32 detection targets: team_code/data.py:511-522,
+// 725-728) widened on the GPU to what train.py:688-766 asks ``.to(device, dtype=...)`` for, so that PCIe carries 1 or 4 bytes per value instead of
+// 4 or 8.  16 source bytes per thread.
+template <typename S, typename D>
+__global__ void widen_kernel(const S* __restrict__ in, D* __restrict__ out, long nvec, long n) {
+  constexpr int V = 16 / sizeof(S);
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nvec) {
+    const uint4 raw = reinterpret_cast<const uint4*>(in)[i];
+    const S* v = reinterpret_cast<const S*>(&raw);
+    D r[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) r[k] = (D)v[k];
+    constexpr int Q = V * sizeof(D) / 16;
+    uint4* o = reinterpret_cast<uint4*>(out) + i * Q;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) o[k] = reinterpret_cast<const uint4*>(r)[k];
+  } else if (i == nvec) {
+    for (long j = nvec * V; j < n; ++j) out[j] = (D)in[j];
+  }
+}
+
+template <typename S, typename D>
+static int launch_widen(const void* in, void* out, int64_t n, hipStream_t st) {
+  const long nvec = n / (16 / (long)sizeof(S));
+  hipLaunchKernelGGL((widen_kernel<S, D>), dim3((unsigned)((nvec + 1 + 255) / 256)), dim3(256), 0, st, (const S*)in, (D*)out, nvec, (long)n);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tfpp_widen(const void* in, void* out, int64_t n, int src_kind, int dst_kind, void* stream) {
+  if (!in || !out || n < 0 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (src_kind == 0 && dst_kind == 0) return launch_widen<unsigned char, float>(in, out, n, st);
+  if (src_kind == 0 && dst_kind == 1) return launch_widen<unsigned char, long long>(in, out, n, st);
+  if (src_kind == 1 && dst_kind == 0) return launch_widen<int, float>(in, out, n, st);
+  if (src_kind == 1 && dst_kind == 1) return launch_widen<int, long long>(in, out, n, st);
+  return TFPP_EINVAL;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // layout changes at the boundary
 // ---------------------------------------------------------------------------------------------------------------

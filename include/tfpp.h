@@ -199,6 +199,9 @@ int tfpp_pack_conv_weight(const float* w, void* out, int Cout, int cin_g, int R,
 int tfpp_pack2d(const float* in, void* out, const int* row_map, const int* col_map, int rows_out, int cols_out, int64_t in_ld,
                 int64_t out_ld, int transpose_in, int dtype, void* stream);
 int tfpp_cast(const void* in, void* out, int64_t n, int dtype_in, int dtype_out, void* stream);
+/* Widening of the narrow host dtypes of an uploaded batch on the device (team_code/train.py:688-766 does ``.to(device, dtype=...)`` from pageable
+ * memory): src_kind 0 = uint8, 1 = int32; dst_kind 0 = fp32, 1 = int64.  16-byte aligned buffers. */
+int tfpp_widen(const void* in, void* out, int64_t n, int src_kind, int dst_kind, void* stream);
 /* All per-step weight images in ONE launch: a device-resident table of descriptors (kind 0/1 = tfpp_pack_conv_weight
  * forward / transposed with a = {Cout, cin_g, R, S, G, ks_pad, n_pad}; kind 2 = tfpp_pack2d with a = {rows_out, cols_out,
  * transpose_in}).  Descriptor i owns workgroups [blk_start, blk_start + tfpp_pack_desc_plan(&desc_i)). */

@@ -1,0 +1,101 @@
+"""DeviceBatchPrefetcher (carla_garage_amd/data.py) against the reference's synchronous upload (team_code/train.py:688-766): same device
+tensors (bit-exact: integer / exactly representable conversions), same losses when the train step consumes them, slot reuse under
+back-to-back steps."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_batches(cfg, n, bs=2):
+  import bench
+  from carla_garage_amd.data import to_reference_batch
+  return [to_reference_batch(bench.synthetic_batch(bs, cfg, None, 100 + i), cfg) for i in range(n)]
+
+
+def _reference_upload(b, cfg, dev):
+  """what train.py does, key by key"""
+  from carla_garage_amd.data import KEYMAP
+  out = {}
+  for src, dst, dt, need in KEYMAP:
+    if not need(cfg):
+      continue
+    t = b[src]
+    if src == 'route':
+      t = t[:, :cfg.predict_checkpoint_len]
+    t = t.to(dev, dtype=dt)
+    if src == 'speed':
+      t = t.unsqueeze(1)
+    out[dst] = t
+  return out
+
+
+@pytest.mark.parametrize('src,dst', [(torch.uint8, torch.float32), (torch.uint8, torch.int64), (torch.int32, torch.float32), (torch.int32, torch.int64)])
+def test_widen_kernel(src, dst):
+  from carla_garage_amd._lib import lib
+  from carla_garage_amd.ops import ptr, stream
+  kinds = {torch.uint8: 0, torch.int32: 1, torch.float32: 0, torch.int64: 1}
+  for n in (0, 1, 3, 4, 15, 16, 17, 4099, 3 * 384 * 1024 * 2):
+    x = torch.randint(0, 256, (max(n, 1),), device='cuda').to(src)[:n]
+    if src == torch.int32:
+      x = x * 65537 - 1000
+    y = torch.full((max(n, 1) + 8,), -1, dtype=dst, device='cuda')
+    lib.tfpp_widen(ptr(x) if n else ptr(y), ptr(y), n, kinds[src], kinds[dst], stream())
+    assert torch.equal(y[:n], x.to(dst))
+    assert torch.all(y[n:] == -1)
+
+
+def test_prefetcher_matches_reference_upload():
+  from carla_garage_amd.config import GlobalConfig
+  from carla_garage_amd.data import DeviceBatchPrefetcher
+  cfg = GlobalConfig()
+  host = _host_batches(cfg, 5)
+  got = []
+  for b in DeviceBatchPrefetcher(host, cfg):
+    got.append({k: v.clone() for k, v in b.items()})  # the slot is recycled two batches later
+    # a long-running consumer on the compute stream: the slot must not be overwritten before it has run
+    torch.cuda._sleep(20_000_000)
+  assert len(got) == len(host)
+  for b, h in zip(got, host):
+    ref = _reference_upload(h, cfg, 'cuda')
+    assert set(ref) == set(b)
+    for k in ref:
+      assert b[k].dtype == ref[k].dtype and b[k].shape == ref[k].shape, k
+      assert torch.equal(b[k], ref[k]), k
+
+
+def test_slot_not_overwritten_while_consumer_pending():
+  """consumer reads the slot late on the compute stream (after a long sleep kernel); contents must still be that batch's"""
+  from carla_garage_amd.config import GlobalConfig
+  from carla_garage_amd.data import DeviceBatchPrefetcher
+  cfg = GlobalConfig()
+  host = _host_batches(cfg, 6)
+  sums = []
+  for b in DeviceBatchPrefetcher(host, cfg):
+    torch.cuda._sleep(50_000_000)
+    sums.append(b['rgb'].double().sum() + b['depth_label'].double().sum())
+  torch.cuda.synchronize()
+  for s, h in zip(sums, host):
+    assert float(s) == float(h['rgb'].double().sum() + h['depth'].double().sum())
+
+
+def test_train_steps_from_prefetcher_equal_resident_batches():
+  from carla_garage_amd.config import GlobalConfig
+  from carla_garage_amd.data import DeviceBatchPrefetcher
+  from carla_garage_amd.model import LidarCenterNet
+  from carla_garage_amd.trainer import Trainer
+  cfg = GlobalConfig()
+  host = _host_batches(cfg, 3)
+  runs = []
+  for mode in range(2):
+    torch.manual_seed(0)
+    m = LidarCenterNet(cfg).cuda().train()
+    for mod in m.modules():
+      if isinstance(mod, torch.nn.Dropout):
+        mod.p = 0.0
+    m.config.embd_pdrop = m.config.resid_pdrop = m.config.attn_pdrop = 0.0
+    tr = Trainer(m, lr=1e-5)
+    it = DeviceBatchPrefetcher(host, cfg) if mode else (_reference_upload(h, cfg, 'cuda') for h in host)
+    runs.append(torch.stack([tr.train_step(b).clone() for b in it]).cpu())
+  # same inputs -> same losses up to the run-to-run noise of the fp32 atomics in the step (a wrong or stale slot moves them by O(1))
+  torch.testing.assert_close(runs[0], runs[1], rtol=1e-2, atol=1e-3)
