@@ -165,3 +165,137 @@ extern "C" int tfpp_centernet_decode(const float* heat, const float* wh, const f
   TFPP_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// CenterNet training targets from the box list, on the GPU (the target rasterisation of the loader
+// workers).  Replaces CARLA_Data.get_targets (team_code/data.py:697-790) with gaussian_radius / gen_gaussian_target / gaussian2d
+// (team_code/gaussian_target.py:11-61,166-187) and angle2class (team_code/center_net.py:240-254).  The reference runs it on the
+// unpadded float64 rows of parse_bounding_boxes, so the scalar path is float64 here too with FMA contraction off (bit-exact maps);
+// only the gaussian patch is float32 (expf: within 2 ulp of numpy's).  One workgroup per sample, boxes in list order (a later box
+// overwrites the scalar targets of an earlier one in the same cell, the heat-map keeps the maximum).
+constexpr int TG_THREADS = 256;
+
+__device__ double tg_gaussian_radius(double height, double width, double mo) {
+#pragma clang fp contract(off)
+  const double b1 = height + width;
+  const double c1 = width * height * (1.0 - mo) / (1.0 + mo);
+  const double r1 = (b1 - sqrt(b1 * b1 - 4.0 * c1)) / 2.0;
+  const double b2 = 2.0 * (height + width);
+  const double c2 = (1.0 - mo) * width * height;
+  const double r2 = (b2 - sqrt(b2 * b2 - 16.0 * c2)) / 8.0;
+  const double a3 = 4.0 * mo;
+  const double b3 = -2.0 * mo * (height + width);
+  const double c3 = (mo - 1.0) * width * height;
+  const double r3 = (b3 + sqrt(b3 * b3 - 4.0 * a3 * c3)) / (2.0 * a3);
+  return fmin(r1, fmin(r2, r3));
+}
+
+// numpy's float64 remainder / floor_divide (npy_divmod): the result takes the sign of the divisor
+__device__ double tg_mod(double a, double b) {
+#pragma clang fp contract(off)
+  double m = fmod(a, b);
+  if (m != 0.0) {
+    if ((b < 0.0) != (m < 0.0)) m += b;
+  } else {
+    m = copysign(0.0, b);
+  }
+  return m;
+}
+__device__ double tg_floordiv(double a, double b) {
+#pragma clang fp contract(off)
+  double m = fmod(a, b);
+  double div = (a - m) / b;
+  if (m != 0.0 && ((b < 0.0) != (m < 0.0))) div -= 1.0;
+  if (div == 0.0) return copysign(0.0, a / b);
+  double fl = floor(div);
+  if (div - fl > 0.5) fl += 1.0;
+  return fl;
+}
+
+__global__ __launch_bounds__(TG_THREADS) void centernet_targets_kernel(const double* __restrict__ boxes, const int* __restrict__ counts,
+                                                                       float* __restrict__ heat, float* __restrict__ wh,
+                                                                       float* __restrict__ offset, long long* __restrict__ yaw_class,
+                                                                       float* __restrict__ yaw_res, float* __restrict__ velocity,
+                                                                       long long* __restrict__ brake, float* __restrict__ pw,
+                                                                       float* __restrict__ avg, int max_boxes, int ncls, int H, int W,
+                                                                       int nbins, double wr, double hr, double mo) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.x, tid = threadIdx.x, hw = H * W;
+  heat += (size_t)b * ncls * hw;
+  wh += (size_t)b * 2 * hw;
+  offset += (size_t)b * 2 * hw;
+  pw += (size_t)b * 2 * hw;
+  yaw_class += (size_t)b * hw;
+  yaw_res += (size_t)b * hw;
+  velocity += (size_t)b * hw;
+  brake += (size_t)b * hw;
+  for (int i = tid; i < ncls * hw; i += TG_THREADS) heat[i] = 0.f;
+  for (int i = tid; i < 2 * hw; i += TG_THREADS) wh[i] = offset[i] = pw[i] = 0.f;
+  for (int i = tid; i < hw; i += TG_THREADS) {
+    yaw_class[i] = 0;
+    brake[i] = 0;
+    yaw_res[i] = velocity[i] = 0.f;
+  }
+  __syncthreads();
+  const int n = min(counts[b], max_boxes);
+  const double two_pi = 2.0 * 3.141592653589793;
+  for (int j = 0; j < n; ++j) {
+    const double* bx = boxes + ((size_t)b * max_boxes + j) * 8;
+    const double ctx = bx[0] * wr, cty = bx[1] * hr;
+    const int x = (int)ctx, y = (int)cty, cls = (int)bx[7];  // astype(int): toward zero
+    if (x < 0 || x >= W || y < 0 || y >= H || cls < 0 || cls >= ncls) continue;  // the reference would raise / wrap; block-uniform branch
+    const double ex = bx[2] * wr, ey = bx[3] * hr;
+    const double rr = tg_gaussian_radius(ey, ex, mo);
+    const int radius = rr >= 3.0 ? (rr < 4096.0 ? (int)rr : 4096) : 2;  // max(2, int(radius))
+    const double sigma = (double)(2 * radius + 1) / 6.0;
+    const float den = (float)(2.0 * sigma * sigma);
+    const int left = min(x, radius), right = min(W - x, radius + 1), top = min(y, radius), bottom = min(H - y, radius + 1);
+    const int rw = left + right, rh = top + bottom;
+    float* hc = heat + (size_t)cls * hw;
+    for (int i = tid; i < rw * rh; i += TG_THREADS) {
+      const int yy = i / rw, dy = yy - top, dx = i - yy * rw - left;
+      float g = expf(-(float)(dx * dx + dy * dy) / den);
+      if (g < 1.1920929e-7f) g = 0.f;  // gaussian_target.py:28 (the patch maximum is exp(0) = 1)
+      float* p = hc + (y + dy) * W + (x + dx);
+      *p = fmaxf(*p, g);
+    }
+    if (tid == 0) {
+      const int c = y * W + x;
+      wh[c] = (float)ex;
+      wh[hw + c] = (float)ey;
+      const double per = two_pi / (double)nbins;
+      const double shifted = tg_mod(tg_mod(bx[4], two_pi) + per / 2.0, two_pi);
+      const double k = tg_floordiv(shifted, per);
+      yaw_class[c] = (long long)k;
+      yaw_res[c] = (float)(shifted - (k * per + per / 2.0));
+      velocity[c] = (float)bx[5];
+      brake[c] = (long long)rint(bx[6]);  // int(round(.)): half to even
+      offset[c] = (float)(ctx - (double)x);
+      offset[hw + c] = (float)(cty - (double)y);
+      pw[c] = pw[hw + c] = 1.f;
+    }
+    __syncthreads();
+  }
+  __shared__ int ones;
+  if (tid == 0) ones = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = tid; i < ncls * hw; i += TG_THREADS) mine += heat[i] == 1.f;
+  if (mine) atomicAdd(&ones, mine);
+  __syncthreads();
+  if (tid == 0) avg[b] = (float)max(1, ones);
+}
+
+extern "C" int tfpp_centernet_targets(const double* boxes, const int32_t* counts, float* heat, float* wh, float* offset, int64_t* yaw_class,
+                                      float* yaw_res, float* velocity, int64_t* brake, float* pixel_weight, float* avg_factor, int B,
+                                      int max_boxes, int ncls, int H, int W, int num_dir_bins, double width_ratio, double height_ratio,
+                                      double min_overlap, void* stream) {
+  if (!boxes || !counts || !heat || !wh || !offset || !yaw_class || !yaw_res || !velocity || !brake || !pixel_weight || !avg_factor || B < 1 ||
+      max_boxes < 1 || ncls < 1 || H < 1 || W < 1 || num_dir_bins < 1 || !(min_overlap > 0.0 && min_overlap < 1.0))
+    return TFPP_EINVAL;
+  hipLaunchKernelGGL(centernet_targets_kernel, dim3((unsigned)B), dim3(TG_THREADS), 0, (hipStream_t)stream, boxes, counts, heat, wh, offset,
+                     (long long*)yaw_class, yaw_res, velocity, (long long*)brake, pixel_weight, avg_factor, max_boxes, ncls, H, W, num_dir_bins,
+                     width_ratio, height_ratio, min_overlap);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}

@@ -53,13 +53,18 @@ class DeviceBatchPrefetcher:
   widening kernels) on the copy stream; the consumer thread only waits for the slot's event on its compute stream.  A yielded batch stays
   valid until the consumer asks for the next one AND the work it enqueued meanwhile on the current stream has run."""
 
-  def __init__(self, loader, config, device='cuda', slots=2):
+  def __init__(self, loader, config, device='cuda', slots=2, rasterise_on_device=False):
+    """rasterise_on_device: the host batches carry ``bounding_boxes_f64`` (B, n, 8) float64 + ``num_bounding_boxes`` (B,) (collate_boxes)
+    instead of the nine CenterNet label maps, which are then drawn on the GPU by rasterise_targets right after the upload."""
     self.loader, self.cfg, self.device = loader, config, torch.device(device)
+    self.rasterise = bool(rasterise_on_device and config.detect_boxes)
     if self.device.index is None:
       self.device = torch.device('cuda', torch.cuda.current_device())
     self.copy_stream = torch.cuda.Stream(self.device)
     self.slots = [dict(pin={}, dev={}, ready=torch.cuda.Event(), used=False) for _ in range(slots)]
-    self.keys = [(src, dst, dt) for src, dst, dt, need in KEYMAP if need(config)]
+    self.keys = [(src, dst, dt) for src, dst, dt, need in KEYMAP if need(config) and not (self.rasterise and dst in TARGET_KEYS)]
+    if self.rasterise:
+      self.keys += [('bounding_boxes_f64', 'bounding_boxes_f64', torch.float64), ('num_bounding_boxes', 'num_bounding_boxes', torch.int32)]
 
   def _host_view(self, src, t):
     if not torch.is_tensor(t):
@@ -95,6 +100,13 @@ class DeviceBatchPrefetcher:
           lib.tfpp_widen(ptr(d), ptr(wide), d.numel(), _NARROW[t.dtype], _WIDE[dt], ops.stream())
           d = wide
         out[dst] = d
+      if self.rasterise:
+        boxes, counts = out.pop('bounding_boxes_f64'), out.pop('num_bounding_boxes')
+        tg = slot['dev'].get('/targets')
+        if tg is not None and tg['wh_label'].shape[0] != boxes.shape[0]:
+          tg = None
+        slot['dev']['/targets'] = tg = rasterise_targets(boxes, counts, self.cfg, out=tg)
+        out.update(tg)
       slot['ready'].record(self.copy_stream)
     slot['used'] = True
     return out
@@ -137,6 +149,55 @@ class DeviceBatchPrefetcher:
       stop.set()
       free_q.put(None)
       th.join()
+
+
+TARGET_KEYS = ('center_heatmap_label', 'wh_label', 'offset_label', 'yaw_class_label', 'yaw_res_label', 'velocity_label', 'brake_target_label',
+               'pixel_weight_label', 'avg_factor_label')
+MIN_OVERLAP = 0.1  # data.py:753
+
+
+def rasterise_targets(boxes, counts, config, out=None):
+  """CenterNet label maps of a batch on the GPU (tfpp_centernet_targets; replaces the per-sample CARLA_Data.get_targets of the loader
+  workers, team_code/data.py:588-600,697-790).  boxes: (B, max_boxes, 8) float64 device tensor of parse_bounding_boxes rows, counts: (B,)
+  int32 valid rows per sample.  Returns the nine ``*_label`` tensors in the trainer's layout (``out``: a dict of them to overwrite)."""
+  if not (boxes.is_cuda and boxes.dtype == torch.float64 and boxes.dim() == 3 and boxes.shape[2] == 8 and boxes.is_contiguous()):
+    raise ValueError('rasterise_targets: boxes must be a contiguous (B, max_boxes, 8) float64 device tensor')
+  if not (counts.is_cuda and counts.dtype == torch.int32 and counts.shape == (boxes.shape[0],)):
+    raise ValueError('rasterise_targets: counts must be a (B,) int32 device tensor')
+  B, nb = boxes.shape[0], boxes.shape[1]
+  H = config.lidar_resolution_height // config.bev_down_sample_factor
+  W = config.lidar_resolution_width // config.bev_down_sample_factor
+  C = config.num_bb_classes
+  if out is None:
+    f = dict(device=boxes.device, dtype=torch.float32)
+    i = dict(device=boxes.device, dtype=torch.int64)
+    out = dict(center_heatmap_label=torch.empty((B, C, H, W), **f), wh_label=torch.empty((B, 2, H, W), **f),
+               offset_label=torch.empty((B, 2, H, W), **f), yaw_class_label=torch.empty((B, H, W), **i),
+               yaw_res_label=torch.empty((B, 1, H, W), **f), velocity_label=torch.empty((B, 1, H, W), **f),
+               brake_target_label=torch.empty((B, H, W), **i), pixel_weight_label=torch.empty((B, 2, H, W), **f),
+               avg_factor_label=torch.empty((B,), **f))
+  o = out
+  lib.tfpp_centernet_targets(ptr(boxes), ptr(counts), ptr(o['center_heatmap_label']), ptr(o['wh_label']), ptr(o['offset_label']),
+                             ptr(o['yaw_class_label']), ptr(o['yaw_res_label']), ptr(o['velocity_label']), ptr(o['brake_target_label']),
+                             ptr(o['pixel_weight_label']), ptr(o['avg_factor_label']), B, nb, C, H, W, config.num_dir_bins,
+                             float(W / config.lidar_resolution_width), float(H / config.lidar_resolution_height), MIN_OVERLAP, ops.stream())
+  return out
+
+
+def collate_boxes(box_lists, max_boxes=None):
+  """Host-side collation for rasterise_on_device: a list (one entry per sample) of the float64 (n_i, 8) arrays parse_bounding_boxes returns
+  (team_code/data.py:565-570, BEFORE the float32 padding of data.py:571-585) -> (boxes (B, max_i n_i, 8) float64, counts (B,) int32)."""
+  import numpy as np
+  arrs = [np.asarray(b, dtype=np.float64).reshape(-1, 8) for b in box_lists]
+  n = max([a.shape[0] for a in arrs] + [1]) if max_boxes is None else max_boxes
+  boxes = np.zeros((len(arrs), n, 8), np.float64)
+  counts = np.zeros(len(arrs), np.int32)
+  for i, a in enumerate(arrs):
+    if a.shape[0] > n:
+      raise ValueError(f'collate_boxes: sample {i} has {a.shape[0]} boxes, max_boxes = {n}')
+    boxes[i, :a.shape[0]] = a
+    counts[i] = a.shape[0]
+  return torch.from_numpy(boxes), torch.from_numpy(counts)
 
 
 def to_reference_batch(batch, config, rgb_uint8=True):

@@ -236,6 +236,18 @@ int tfpp_lidar_histogram(const float* points, int64_t n, int point_stride, const
 int tfpp_centernet_decode(const float* heat, const float* wh, const float* offset, const float* yaw_class, const float* yaw_res, float* out,
                           int B, int ncls, int H, int W, int k, int num_dir_bins, float width_ratio, float height_ratio, void* stream);
 
+/* CenterNet training targets from the box list, the rasterisation the loader workers do per sample (replaces
+ * CARLA_Data.get_targets, team_code/data.py:697-790, incl. gaussian_target.py:11-61,166-187 and center_net.py:240-254).
+ * boxes: (B, max_boxes, 8) float64 rows x, y, extent_x, extent_y, yaw, speed, brake, class in BEV image pixels exactly as
+ * parse_bounding_boxes emits them (data.py:565-570, unpadded there: counts[b] rows are valid); outputs are the trainer's label tensors:
+ * heat (B, ncls, H, W), wh / offset / pixel_weight (B, 2, H, W), yaw_res / velocity (B, 1, H, W) fp32, yaw_class / brake (B, H, W) int64,
+ * avg_factor (B) = max(1, number of heat-map cells equal to 1).  Every output is fully written (no pre-zeroing).  Scalar targets are
+ * bit-exact with the reference (float64 path); heat-map values within 2 ulp (float32 exp). */
+int tfpp_centernet_targets(const double* boxes, const int32_t* counts, float* heat, float* wh, float* offset, int64_t* yaw_class,
+                           float* yaw_res, float* velocity, int64_t* brake, float* pixel_weight, float* avg_factor, int B, int max_boxes,
+                           int ncls, int H, int W, int num_dir_bins, double width_ratio, double height_ratio, double min_overlap,
+                           void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Boundary layout changes.  nchw_to_nhwc_affine = normalize_imagenet (transfuser_utils.py:542-551) fused with
  * NCHW->NHWC and zero channel padding to `cpad`: out[b,h,w,c] = c<C ? in[b,c,h,w]*mul[c]+add[c] : 0 (mul/add nullable).

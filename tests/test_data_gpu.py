@@ -99,3 +99,36 @@ def test_train_steps_from_prefetcher_equal_resident_batches():
     runs.append(torch.stack([tr.train_step(b).clone() for b in it]).cpu())
   # same inputs -> same losses up to the run-to-run noise of the fp32 atomics in the step (a wrong or stale slot moves them by O(1))
   torch.testing.assert_close(runs[0], runs[1], rtol=1e-2, atol=1e-3)
+
+
+def test_prefetcher_rasterises_targets_on_device():
+  """host batches carry the float64 box lists instead of the nine label maps: same label tensors as the oracle's rasterisation uploaded"""
+  import numpy as np
+  from oracle import targets_port
+  from carla_garage_amd.config import GlobalConfig
+  from carla_garage_amd.data import TARGET_KEYS, DeviceBatchPrefetcher, collate_boxes
+  cfg = GlobalConfig()
+  bs = 3
+  host, want = [], []
+  label_src = {'center_heatmap', 'wh', 'offset', 'yaw_class', 'yaw_res', 'velocity', 'brake_target', 'pixel_weight', 'avg_factor'}
+  for i, h in enumerate(_host_batches(cfg, 4, bs=bs)):
+    lists = [targets_port.make_boxes((5 * i + 11 * j) % 31, 50 + 10 * i + j) for j in range(bs)]
+    h = {k: v for k, v in h.items() if k not in label_src}
+    h['bounding_boxes_f64'], h['num_bounding_boxes'] = collate_boxes(lists)
+    host.append(h)
+    want.append([targets_port.get_targets(b) for b in lists])
+  names = dict(center_heatmap_target='center_heatmap_label', wh_target='wh_label', offset_target='offset_label', yaw_class_target='yaw_class_label',
+               yaw_res_target='yaw_res_label', velocity_target='velocity_label', brake_target='brake_target_label', pixel_weight='pixel_weight_label')
+  n = 0
+  for b, w in zip(DeviceBatchPrefetcher(host, cfg, rasterise_on_device=True), want):
+    assert set(TARGET_KEYS) <= set(b) and 'bounding_boxes_f64' not in b
+    got = {k: b[k].cpu().numpy() for k in TARGET_KEYS}
+    for j, (t, avg) in enumerate(w):
+      for k, mine in names.items():
+        if k == 'center_heatmap_target':
+          assert np.abs(got[mine][j] - t[k]).max() <= 2.5e-7
+        else:
+          assert np.array_equal(got[mine][j], t[k].astype(got[mine].dtype)), (k, j)
+      assert float(got['avg_factor_label'][j]) == float(avg)
+    n += 1
+  assert n == 4
