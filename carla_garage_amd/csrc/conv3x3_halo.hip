@@ -284,7 +284,8 @@ bool conv_halo_supported(const tfpp_conv_params& p, int dtype) {
     return s2 && geo_ok && fn <= 2 && !p.bns_partial && halo_lds_bytes(p, fn) <= 120 * 1024;
   }
   if (p.stride != 1 || p.Hs != p.Hd || p.Ws != p.Wd) return false;
-  return halo_lds_bytes(p, fn) <= 65536;
+  static const int max_lds = [] { const char* e = std::getenv("TFPP_CONV_HALO_MAX_LDS"); return e ? std::atoi(e) : 65536; }();
+  return halo_lds_bytes(p, fn) <= max_lds;
 }
 
 int conv_halo_variant(const tfpp_conv_params& p) { return 300 + (p.n_g <= 16 ? 1 : (p.n_g <= 32 ? 2 : 4)); }

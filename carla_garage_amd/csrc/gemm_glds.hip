@@ -558,7 +558,7 @@ int conv_glds_variant(const tfpp_conv_params& p) {
 int conv_glds_bm(int variant) { return variant == 202 ? 256 : (variant == 200 ? 128 : 64); }
 
 bool conv_glds_supported(const tfpp_conv_params& p, int dtype) {
-  static const int min_k = [] { const char* e = std::getenv("TFPP_GLDS_MIN_K"); return e ? std::atoi(e) : 512; }();
+  static const int min_k = [] { const char* e = std::getenv("TFPP_GLDS_MIN_K"); return e ? std::atoi(e) : 200; }();  // 512 until round 2: the stage-2 1x1 convs (K = 216) gain 0.45 ms/step on the 64-deep ring
   return dtype == TFPP_BF16 && p.n_g >= 128 && p.ks_g % 8 == 0 && p.src_ld % 8 == 0 && p.R * p.S * p.ks_g >= min_k;
 }
 

@@ -91,19 +91,57 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-// Sum of the partial rows of one channel pair (sum, sum-of-products) in double, one wave64 per channel: lanes take the
-// rows (independent loads, one or a few per lane), then a shuffle reduction.  clear: re-zero what was read (the conv
-// epilogue accumulates into rows that are zero between uses, so no memset launch is needed).
-__device__ __forceinline__ void partial_pair_sum(float* partial, int nrows, int C, int c, int lane, bool clear, double& s0, double& s1) {
+// Column sums of the partial rows (sum half | sum-of-products half, row-major [nrows][2C]) in double, COALESCED and in a fixed order: a
+// workgroup of NT threads owns 32 channels; thread (rg, cl) walks rows rg, rg + RG, ... (RG = NT / 32) reading the 128-byte segments
+// [c0, c0 + 32) of both halves, so a wave touches 4 cache lines per row pair instead of the 64 lines per load of a lane-per-row walk of one
+// column (round 2: the lane-per-row finalize cost 9.4 us per BatchNorm layer, 136 launches on the critical chain).  The RG partial sums are
+// combined through LDS by the rg = 0 threads in index order: independent of scheduling, bit-reproducible.  clear: re-zero what was read (the
+// conv epilogue accumulates into rows that are zero between uses, so no memset launch is needed).  Returns true in the threads that hold a
+// channel's totals.
+template <int NT>
+__device__ __forceinline__ bool partial_cols_sum(float* __restrict__ partial, int nrows, int C, bool clear, int& c, double& s0, double& s1) {
+  constexpr int RG = NT / 32;
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  c = (int)blockIdx.x * 32 + cl;
   double a = 0.0, b = 0.0;
-  for (int k = lane; k < nrows; k += 64) {
-    float* row = partial + (size_t)k * 2 * C;
-    a += (double)row[c];
-    b += (double)row[C + c];
-    if (clear) { row[c] = 0.f; row[C + c] = 0.f; }
+  if (c < C) {
+    int k = rg;
+    for (; k + 3 * RG < nrows; k += 4 * RG) {
+      float va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float* row = partial + (size_t)(k + u * RG) * 2 * C;
+        va[u] = row[c];
+        vb[u] = row[C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a += (double)va[u]; b += (double)vb[u]; }
+      if (clear) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float* row = partial + (size_t)(k + u * RG) * 2 * C;
+          row[c] = 0.f;
+          row[C + c] = 0.f;
+        }
+      }
+    }
+    for (; k < nrows; k += RG) {
+      float* row = partial + (size_t)k * 2 * C;
+      a += (double)row[c];
+      b += (double)row[C + c];
+      if (clear) { row[c] = 0.f; row[C + c] = 0.f; }
+    }
   }
-  s0 = wave_sum_f64(a);
-  s1 = wave_sum_f64(b);
+  __shared__ double sm[2][RG][33];
+  sm[0][rg][cl] = a;
+  sm[1][rg][cl] = b;
+  __syncthreads();
+  if (rg != 0 || c >= C) return false;
+  s0 = 0.0;
+  s1 = 0.0;
+#pragma unroll 8
+  for (int r = 0; r < RG; ++r) { s0 += sm[0][r][cl]; s1 += sm[1][r][cl]; }
+  return true;
 }
 
 // ws[v] = sum_k partial[k][v] in double; one wave per value
@@ -198,37 +236,16 @@ extern "C" int tfpp_bn_finalize(const double* ws, const float* gamma, const floa
 // The same from accumulation rows (tfpp_conv_params.stats_partial); re-zeroes the rows it consumed.  WIDE = false: one wave
 // per channel (<= 256 rows); WIDE = true: one 256-thread workgroup per channel (one row per M-tile on the large feature
 // maps: up to 1536 rows), combined through LDS in a fixed order -- the sum is independent of scheduling either way.
-template <bool WIDE>
-__global__ void bn_finalize_partials_kernel(float* __restrict__ partial, int nrows, const float* __restrict__ gamma,
+template <int NT>
+__global__ __launch_bounds__(NT) void bn_finalize_partials_kernel(float* __restrict__ partial, int nrows, const float* __restrict__ gamma,
                                             const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv,
                                             long long* __restrict__ nbt, float* __restrict__ scale, float* __restrict__ shift,
                                             float* __restrict__ save_mean, float* __restrict__ save_invstd, long rows, int C, float momentum,
                                             float eps, int clear) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = WIDE ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
-  if (c == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
-  double s0 = 0.0, s1 = 0.0;
-  if (WIDE) {
-    double a = 0.0, b = 0.0;
-    for (int k = threadIdx.x; k < nrows; k += 256) {
-      float* row = partial + (size_t)k * 2 * C;
-      a += (double)row[c];
-      b += (double)row[C + c];
-      if (clear) { row[c] = 0.f; row[C + c] = 0.f; }
-    }
-    a = wave_sum_f64(a);
-    b = wave_sum_f64(b);
-    __shared__ double sm[2][4];
-    if (lane == 0) { sm[0][wave] = a; sm[1][wave] = b; }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    s0 = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
-    s1 = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
-  } else {
-    if (c >= C) return;
-    partial_pair_sum(partial, nrows, C, c, lane, clear != 0, s0, s1);
-    if (lane != 0) return;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  int c;
+  double s0, s1;
+  if (!partial_cols_sum<NT>(partial, nrows, C, clear != 0, c, s0, s1)) return;
   const double n = (double)rows;
   const double m = s0 / n;
   double var = s1 / n - m * m;
@@ -250,11 +267,12 @@ extern "C" int tfpp_bn_finalize_partials(float* partial, int nrows, int clear, c
                                          float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
                                          float* save_invstd, int64_t rows, int C, float momentum, float eps, void* stream) {
   if (!partial || nrows < 1 || !scale || !shift) return TFPP_EINVAL;
-  if (nrows > 256)
-    hipLaunchKernelGGL(bn_finalize_partials_kernel<true>, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nrows, gamma, beta, running_mean,
-                       running_var, (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd, (long)rows, C, momentum, eps, clear);
+  if (nrows > 128)
+    hipLaunchKernelGGL(bn_finalize_partials_kernel<1024>, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial, nrows, gamma, beta,
+                       running_mean, running_var, (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd, (long)rows, C,
+                       momentum, eps, clear);
   else
-    hipLaunchKernelGGL(bn_finalize_partials_kernel<false>, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nrows, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_partials_kernel<256>, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, nrows, gamma, beta,
                        running_mean, running_var, (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd, (long)rows, C,
                        momentum, eps, clear);
   TFPP_CHECK_LAUNCH();
@@ -284,33 +302,13 @@ extern "C" int tfpp_bn_fold(const float* gamma, const float* beta, const float* 
 // coefficient kernel (per channel) also accumulates dgamma += ws1, dbeta += ws0.
 // WIDE = false: one wave per channel (few rows); WIDE = true: one 256-thread workgroup per channel (one row per M-tile of the kernel
 // that produced the gradient: up to a few thousand rows), combined through LDS in a fixed order.
-template <bool WIDE>
-__global__ void bn_bwd_coef_kernel(float* __restrict__ partial, int nrows, double* __restrict__ ws, const float* __restrict__ gamma,
+template <int NT>
+__global__ __launch_bounds__(NT) void bn_bwd_coef_kernel(float* __restrict__ partial, int nrows, double* __restrict__ ws, const float* __restrict__ gamma,
                                    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ coef,
                                    float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int C) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = WIDE ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+  int c;
   double s0, s1;
-  if (WIDE) {
-    double a = 0.0, b = 0.0;
-    for (int k = threadIdx.x; k < nrows; k += 256) {
-      const float* row = partial + (size_t)k * 2 * C;
-      a += (double)row[c];
-      b += (double)row[C + c];
-    }
-    a = wave_sum_f64(a);
-    b = wave_sum_f64(b);
-    __shared__ double sm[2][4];
-    if (lane == 0) { sm[0][wave] = a; sm[1][wave] = b; }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    s0 = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
-    s1 = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
-  } else {
-    if (c >= C) return;
-    partial_pair_sum(partial, nrows, C, c, lane, false, s0, s1);
-    if (lane != 0) return;
-  }
+  if (!partial_cols_sum<NT>(partial, nrows, C, false, c, s0, s1)) return;
   const double n = (double)rows;
   const double gm = gamma ? (double)gamma[c] : 1.0, is = (double)invstd[c], mu = (double)mean[c];
   const double A = gm * is, Bc = -gm * is * is * s1 / n, D = -gm * is * s0 / n - Bc * mu;
@@ -382,6 +380,16 @@ static void launch_bn_bwd_apply(const void* dy, const void* y, const void* x, co
 #undef BA
 }
 
+static void launch_bn_bwd_coef(float* partial, int nrows, double* ws, const float* gamma, const float* mean, const float* invstd, float* coef,
+                               float* dgamma, float* dbeta, long rows, int C, hipStream_t st) {
+  if (nrows > 128)
+    hipLaunchKernelGGL(bn_bwd_coef_kernel<1024>, dim3((C + 31) / 32), dim3(1024), 0, st, partial, nrows, ws, gamma, mean, invstd, coef, dgamma, dbeta,
+                       rows, C);
+  else
+    hipLaunchKernelGGL(bn_bwd_coef_kernel<256>, dim3((C + 31) / 32), dim3(256), 0, st, partial, nrows, ws, gamma, mean, invstd, coef, dgamma, dbeta,
+                       rows, C);
+}
+
 extern "C" int tfpp_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
                                  const float* save_invstd, double* ws, float* scratch, void* dx, void* dres, float* dgamma,
                                  float* dbeta, int64_t rows, int C, int relu_mask, int dtype, void* stream) {
@@ -390,8 +398,7 @@ extern "C" int tfpp_bn_bwd_apply(const void* dy, const void* y, const void* x, c
   const int VEC = dtype == TFPP_F32 ? 4 : 8;
   if (C % VEC) return TFPP_EINVAL;
   float* coef = scratch + (size_t)BN_MAX_PARTIALS * 2 * C;  // after the stage-1 partials
-  hipLaunchKernelGGL(bn_bwd_coef_kernel<false>, dim3((C + 3) / 4), dim3(256), 0, st, scratch, bn_reduce_blocks((long)rows, C / VEC, 1), ws, gamma,
-                     save_mean, save_invstd, coef, dgamma, dbeta, (long)rows, C);
+  launch_bn_bwd_coef(scratch, bn_reduce_blocks((long)rows, C / VEC, 1), ws, gamma, save_mean, save_invstd, coef, dgamma, dbeta, (long)rows, C, st);
   if (dtype == TFPP_F32) launch_bn_bwd_apply<float>(dy, y, x, coef, dx, dres, (long)rows, C, relu_mask, st);
   else launch_bn_bwd_apply<bf16_t>(dy, y, x, coef, dx, dres, (long)rows, C, relu_mask, st);
   TFPP_CHECK_LAUNCH();
@@ -405,12 +412,7 @@ extern "C" int tfpp_bn_bwd_apply_rows(const void* dy, const void* y, const void*
   hipStream_t st = (hipStream_t)stream;
   const int VEC = dtype == TFPP_F32 ? 4 : 8;
   if (C % VEC) return TFPP_EINVAL;
-  if (nrows > 256)
-    hipLaunchKernelGGL(bn_bwd_coef_kernel<true>, dim3(C), dim3(256), 0, st, partial, nrows, (double*)nullptr, gamma, save_mean, save_invstd, coef,
-                       dgamma, dbeta, (long)rows, C);
-  else
-    hipLaunchKernelGGL(bn_bwd_coef_kernel<false>, dim3((C + 3) / 4), dim3(256), 0, st, partial, nrows, (double*)nullptr, gamma, save_mean, save_invstd,
-                       coef, dgamma, dbeta, (long)rows, C);
+  launch_bn_bwd_coef(partial, nrows, nullptr, gamma, save_mean, save_invstd, coef, dgamma, dbeta, (long)rows, C, st);
   if (dtype == TFPP_F32) launch_bn_bwd_apply<float>(dy, y, x, coef, dx, dres, (long)rows, C, relu_mask, st);
   else launch_bn_bwd_apply<bf16_t>(dy, y, x, coef, dx, dres, (long)rows, C, relu_mask, st);
   TFPP_CHECK_LAUNCH();

@@ -327,7 +327,8 @@ class SideLane:
 
   def __init__(self):
     self.enabled = os.environ.get('TFPP_SIDE_STREAM', '1') != '0'
-    self.batch = int(os.environ.get('TFPP_SIDE_BATCH', '32'))  # launches per fork (one event wait per batch); measured 8: 35.0, 16: 34.4, 32: 33.6, 64: 35.5 ms/step
+    self.batch = int(os.environ.get('TFPP_SIDE_BATCH', '128'))  # launches per fork (one event wait per batch); round 1: 8: 35.0, 16: 34.4, 32: 33.6, 64: 35.5 ms/step;
+    # end of round 2 (same box, faster weight-gradient kernels): 16: 30.9, 32: 30.2-30.4, 64: 31.8, 128: 29.9-30.2, 256: 31.0
     self.stream = None
     self.lanes = None  # Lanes of the engine: a batch may hold closures from both encoder-branch streams
     self.keep = []

@@ -67,7 +67,8 @@ def test_conv_kernel_selection(L):
   assert variant(L, conv(3840, 1, 1, 576, 2304)) == 200         # K = 576: too short for the 144 KB ring
   assert variant(L, conv(12, 8, 32, 1512, 1512)) == 202         # image stage-4 1x1 conv
   assert variant(L, conv(12, 16, 64, 576, 576), F32) in (2, 3)  # fp32 never takes the bf16-only kernels
-  assert variant(L, conv(12, 32, 128, 216, 216)) in (0, 1, 2, 3)  # K = 216 < 512: LDS-staged
+  assert variant(L, conv(12, 32, 128, 216, 216)) == 200           # stage-2 1x1 conv: K = 216 >= 200 runs the 64-deep LDS-DMA ring (K tail through the zero page)
+  assert variant(L, conv(12, 64, 256, 72, 144)) in (0, 1, 2, 3, 4)  # K = 72 < 200: LDS-staged
   # 3x3 stride-1 with few channels per group: LDS-halo kernel (300 + 16-channel output fragments)
   assert variant(L, conv(12, 256, 1024, 32, 32, k=3)) == 302
   assert variant(L, conv(12, 256, 1024, 32, 8, k=3)) == 301

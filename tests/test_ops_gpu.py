@@ -156,6 +156,8 @@ TRUE_SHAPES = [
     (('lidar_s3_conv1x1', 12, 16, 16, 576, 576, 1, 1, 1), 201, 201),   # LiDAR branch: 64x128 tiles
     (('s2_entry_g3x3_s2', 4, 64, 128, 72, 72, 3, 2, 3), 302, 302),     # first block of a RegNet stage: stride-2 grouped 3x3 on the halo kernel
     (('s3_entry_g3x3_s2', 2, 32, 128, 216, 216, 3, 2, 9), 302, 302),   #   (forward: 17 x 65 input halo; data gradient: zero-stuffed dy)
+    (('s2_conv1x1', 12, 32, 128, 216, 216, 1, 1, 1), 200, 200),       # stage-2 1x1 convs: K = 216 = 3 x 64 + 24, the K tail of the 64-deep ring
+    (('lidar_s2_conv1x1', 12, 32, 32, 216, 216, 1, 1, 1), 201, 201),
     (('s1_conv1x1', 2, 64, 256, 72, 72, 1, 1, 1), 4, 4),               # stage-1 1x1 conv: one 128x96 tile column instead of 3 x 32
 ]
 
