@@ -139,6 +139,7 @@ class Tape:
     self.nodes = []
     self.lanes = lanes
     self.frozen = {}      # id(tensor) -> tensor: handed to another stream, must not be accumulated into in place
+    self._graveyard = []
     self._grads = None    # pending gradients while backward() runs (take_pending)
     self._rest = []
     self.split_index = None
@@ -293,6 +294,8 @@ class Tape:
           gins = (gins,)
         for t, g in zip(ins, gins):
           self._acc(t, g, lane)
+        if _KEEP_ALL:  # debugging aid: nothing the backward pass touched is freed (and so reused) before the pass ends
+          self._graveyard.append((outs, ins, fn, gouts, gins))
     self._lane = 0
     if multi:
       lanes.cur = 0
@@ -311,10 +314,14 @@ class Tape:
       self.lanes.held = []
     self._grads = None
     self.frozen = {}
+    self._graveyard = []
     Tape.current = None
 
 
 _SKIP_SIDE_WORK = os.environ.get('TFPP_DEBUG_SKIP_SIDE_WORK', '0') == '1'
+_SIDE_CHECK = os.environ.get('TFPP_DEBUG_SIDE_CHECK', '0') == '1'
+_SIDE_LAG1 = os.environ.get('TFPP_DEBUG_SIDE_LAG1', '0') == '1'
+_KEEP_ALL = os.environ.get('TFPP_DEBUG_KEEP_ALL', '0') == '1'
 
 
 class SideLane:
@@ -327,12 +334,17 @@ class SideLane:
 
   def __init__(self):
     self.enabled = os.environ.get('TFPP_SIDE_STREAM', '1') != '0'
-    self.batch = int(os.environ.get('TFPP_SIDE_BATCH', '128'))  # launches per fork (one event wait per batch); round 1: 8: 35.0, 16: 34.4, 32: 33.6, 64: 35.5 ms/step;
-    # end of round 2 (same box, faster weight-gradient kernels): 16: 30.9, 32: 30.2-30.4, 64: 31.8, 128: 29.9-30.2, 256: 31.0
+    # launches per fork (one event wait per batch); round 1: 8: 35.0, 16: 34.4, 32: 33.6, 64: 35.5 ms/step; end of round 2 (same box): 16: 30.9,
+    # 32: 30.2-30.4, 64: 31.8, 128: 29.9-30.2, 256: 31.0.  Kept at 32 although 128 is 0.25 ms faster: with more than ~64 launches per fork the
+    # replays of the CAPTURED step stop being bit-reproducible (tools/replay_diff.py: weight / bias gradients computed on this lane differ by up
+    # to 1e-4 of their maximum between replays at 96 and 128; 32, 48 and 64 reproduce, and so does the eager step at 128; keeping every tensor
+    # of the pass alive until its end, TFPP_DEBUG_KEEP_ALL=1, changes nothing, so it is not allocator reuse) -- DESIGN.md section 4, open issue.
+    self.batch = int(os.environ.get('TFPP_SIDE_BATCH', '32'))
     self.stream = None
     self.lanes = None  # Lanes of the engine: a batch may hold closures from both encoder-branch streams
     self.keep = []
     self.pending = []
+    self.checks = []
 
   def run(self, tape, fn, *tensors):
     if _SKIP_SIDE_WORK:  # timing experiment only (gradients are wrong): how long is the step without any weight-gradient work?
@@ -347,12 +359,18 @@ class SideLane:
     for t in tensors:
       tape.freeze(t)
       self.keep.append(t)
+      if _SIDE_CHECK:  # debugging aid: nothing may write a tensor between its hand-over to this lane and the join
+        import traceback
+        where = ' <- '.join(f'{f.name}:{f.lineno}' for f in traceback.extract_stack(limit=5)[:-1][::-1])
+        self.checks.append((t, t.double().sum(), t.double().abs().sum(), where))
     self.pending.append(fn)
     if len(self.pending) >= self.batch:
       self.flush()
 
   def flush(self):
     if self.pending:
+      if _SIDE_LAG1:  # debugging aid: the previous batch must have finished before the caller's stream goes on (lag <= one batch)
+        torch.cuda.current_stream().wait_stream(self.stream)
       self.stream.wait_stream(torch.cuda.current_stream())
       if self.lanes is not None:
         for st in self.lanes.streams():
@@ -366,6 +384,14 @@ class SideLane:
     if self.keep:
       self.flush()
       torch.cuda.current_stream().wait_stream(self.stream)
+      if _SIDE_CHECK and self.checks:
+        bad = {}
+        for t, s0, a0, where in self.checks:
+          if float(t.double().sum()) != float(s0) or float(t.double().abs().sum()) != float(a0):
+            bad[where] = bad.get(where, 0) + 1
+        self.checks = []
+        for where, n in bad.items():
+          print(f'[TFPP_DEBUG_SIDE_CHECK] {n} tensor(s) handed to the weight-gradient lane were modified before the join: {where}', flush=True)
       _release(self.keep)
       self.keep = []
 
