@@ -284,7 +284,7 @@ def pmc_traffic(family):
   if sha != ent.get('source_sha16'):
     return None, f"stale: {ent['source_file']} changed since the PMC pass of {ent.get('measured', '?')} (re-run tools/pmc_traffic.sh)"
   traffic = ent['fetch_bytes_per_launch'] + (ent.get('write_bytes_per_launch') or 0)
-  note = ('FETCH_SIZE x2 (gfx950 correction)' + (' + WRITE_SIZE (raw, uncalibrated on gfx950)' if ent.get('write_bytes_per_launch') else '') +
+  note = ('FETCH_SIZE x2 (gfx950 correction)' + (' + WRITE_SIZE x1024 B (calibrated on fill kernels, profiles/r02_pmc_calibration.txt)' if ent.get('write_bytes_per_launch') else '') +
           f", separate counter-only rocprofv3 --pmc passes, {ent.get('measured', '')}, profiles/pmc_traffic.json")
   return traffic, note
 

@@ -320,7 +320,6 @@ class Tape:
 
 _SKIP_SIDE_WORK = os.environ.get('TFPP_DEBUG_SKIP_SIDE_WORK', '0') == '1'
 _SIDE_CHECK = os.environ.get('TFPP_DEBUG_SIDE_CHECK', '0') == '1'
-_SIDE_LAG1 = os.environ.get('TFPP_DEBUG_SIDE_LAG1', '0') == '1'
 _KEEP_ALL = os.environ.get('TFPP_DEBUG_KEEP_ALL', '0') == '1'
 
 
@@ -369,8 +368,6 @@ class SideLane:
 
   def flush(self):
     if self.pending:
-      if _SIDE_LAG1:  # debugging aid: the previous batch must have finished before the caller's stream goes on (lag <= one batch)
-        torch.cuda.current_stream().wait_stream(self.stream)
       self.stream.wait_stream(torch.cuda.current_stream())
       if self.lanes is not None:
         for st in self.lanes.streams():
