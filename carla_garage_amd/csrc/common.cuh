@@ -106,6 +106,33 @@ __device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned
     if (e__ != hipSuccess) return -(int)e__;                  \
   } while (0)
 
+// Byte fill as a KERNEL, never hipMemsetAsync: inside a captured hipGraph a memset becomes a memset node, and the replays of the captured
+// training step were not reproducible once the weight-gradient branch carried a long backlog (round 2: the zero-fill of a gradient buffer
+// followed by kernels writing into it is the first place the replays diverged, with two outcomes) -- a plain kernel node keeps stream order.
+// 16-byte stores on the aligned body, byte stores on the unaligned head / tail.
+static __global__ void tfpp_fill_kernel(unsigned char* __restrict__ p, unsigned v32, long head, long nvec, long tail_off, long bytes) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+  const uint4 val = make_uint4(v32, v32, v32, v32);
+  uint4* body = reinterpret_cast<uint4*>(p + head);
+  for (long j = i; j < nvec; j += stride) body[j] = val;
+  const long edge = head + (bytes - tail_off);
+  for (long j = i; j < edge; j += stride) p[j < head ? j : tail_off + (j - head)] = (unsigned char)v32;
+}
+static inline int tfpp_fill_async(void* ptr, int value, size_t nbytes, hipStream_t st) {
+  if (nbytes == 0) return 0;
+  const long bytes = (long)nbytes;
+  long head = (long)((16 - ((uintptr_t)ptr & 15)) & 15);
+  if (head > bytes) head = bytes;
+  const long nvec = (bytes - head) / 16, tail_off = head + nvec * 16;
+  const unsigned b = (unsigned)value & 0xffu, v32 = b | (b << 8) | (b << 16) | (b << 24);
+  long blocks = (nvec + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(tfpp_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned char*)ptr, v32, head, nvec, tail_off, bytes);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -52,8 +52,8 @@ extern "C" int tfpp_lidar_histogram(const float* points, int64_t n, int point_st
     return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long total = (long)(use_ground_plane ? 2 : 1) * nx * ny;
-  hipError_t e = hipMemsetAsync(counts, 0, (size_t)total * sizeof(int), st);
-  if (e != hipSuccess) return -(int)e;
+  const int e = tfpp_fill_async(counts, 0, (size_t)total * sizeof(int), st);
+  if (e != 0) return e;
   if (n > 0)
     hipLaunchKernelGGL(lidar_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, points, (long)n, point_stride, xedges, nx,
                        yedges, ny, counts, max_height, split_height, use_ground_plane);

@@ -243,8 +243,8 @@ extern "C" int tfpp_ce_loss(const void* pred, const int64_t* label, const float*
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   if (!pix_weight) {
-    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float), st);
-    if (e != hipSuccess) return -(int)e;
+    const int e = tfpp_fill_async(ws, 0, sizeof(float), st);
+    if (e != 0) return e;
     hipLaunchKernelGGL(ce_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const long long*)label, class_weight, vis_mask, (long)HW, ws, (long)rows);
   }
   if (dtype == TFPP_F32)

@@ -1044,14 +1044,13 @@ extern "C" int tfpp_copy_rows(const void* src, void* dst, int B, int64_t n, int6
 
 extern "C" int tfpp_zero(void* p, int64_t bytes, void* stream) {
   if (!p) return TFPP_EINVAL;
-  hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
-  return e == hipSuccess ? 0 : -(int)e;
+  if (bytes < 0) return TFPP_EINVAL;
+  return tfpp_fill_async(p, 0, (size_t)bytes, (hipStream_t)stream);
 }
 
 extern "C" int tfpp_fill_bytes(void* p, int value, int64_t bytes, void* stream) {
   if (!p || bytes < 0) return TFPP_EINVAL;
-  hipError_t e = hipMemsetAsync(p, value & 0xff, (size_t)bytes, (hipStream_t)stream);
-  return e == hipSuccess ? 0 : -(int)e;
+  return tfpp_fill_async(p, value, (size_t)bytes, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

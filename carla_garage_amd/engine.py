@@ -321,6 +321,8 @@ class Tape:
 _SKIP_SIDE_WORK = os.environ.get('TFPP_DEBUG_SKIP_SIDE_WORK', '0') == '1'
 _SIDE_CHECK = os.environ.get('TFPP_DEBUG_SIDE_CHECK', '0') == '1'
 _KEEP_ALL = os.environ.get('TFPP_DEBUG_KEEP_ALL', '0') == '1'
+SIDE_OUT_LOG = []  # (layer, bias gradient from the lane, the same column sum recomputed after the join)
+SIDE_CHECK_LOG = []  # (call site, sum / abs-sum at hand-over, sum / abs-sum at the join) device scalars of a captured step (TFPP_DEBUG_SIDE_CHECK=1)
 
 
 class SideLane:
@@ -344,6 +346,8 @@ class SideLane:
     self.keep = []
     self.pending = []
     self.checks = []
+    self.outs = []
+    self.label = ''
 
   def run(self, tape, fn, *tensors):
     if _SKIP_SIDE_WORK:  # timing experiment only (gradients are wrong): how long is the step without any weight-gradient work?
@@ -360,7 +364,7 @@ class SideLane:
       self.keep.append(t)
       if _SIDE_CHECK:  # debugging aid: nothing may write a tensor between its hand-over to this lane and the join
         import traceback
-        where = ' <- '.join(f'{f.name}:{f.lineno}' for f in traceback.extract_stack(limit=5)[:-1][::-1])
+        where = f'{self.label} ' + ' <- '.join(f'{f.name}:{f.lineno}' for f in traceback.extract_stack(limit=5)[:-1][::-1])
         self.checks.append((t, t.double().sum(), t.double().abs().sum(), where))
     self.pending.append(fn)
     if len(self.pending) >= self.batch:
@@ -382,13 +386,19 @@ class SideLane:
       self.flush()
       torch.cuda.current_stream().wait_stream(self.stream)
       if _SIDE_CHECK and self.checks:
-        bad = {}
-        for t, s0, a0, where in self.checks:
-          if float(t.double().sum()) != float(s0) or float(t.double().abs().sum()) != float(a0):
-            bad[where] = bad.get(where, 0) + 1
+        if torch.cuda.is_current_stream_capturing():  # no host read inside a capture: leave device scalars for the caller to compare after a replay
+          # bias gradients computed on this lane next to the same column sums recomputed on the caller's stream after the join
+          SIDE_OUT_LOG.extend((k, g.clone(), dz.reshape(-1, dz.shape[-1]).float().sum(0)[:n].clone()) for k, dz, g, n in self.outs)
+          SIDE_CHECK_LOG.extend((where, s0, a0, t.double().sum(), t.double().abs().sum()) for t, s0, a0, where in self.checks)
+        else:
+          bad = {}
+          for t, s0, a0, where in self.checks:
+            if float(t.double().sum()) != float(s0) or float(t.double().abs().sum()) != float(a0):
+              bad[where] = bad.get(where, 0) + 1
+          for where, n in bad.items():
+            print(f'[TFPP_DEBUG_SIDE_CHECK] {n} tensor(s) handed to the weight-gradient lane were modified before the join: {where}', flush=True)
         self.checks = []
-        for where, n in bad.items():
-          print(f'[TFPP_DEBUG_SIDE_CHECK] {n} tensor(s) handed to the weight-gradient lane were modified before the join: {where}', flush=True)
+        self.outs = []
       _release(self.keep)
       self.keep = []
 
@@ -759,6 +769,7 @@ class Engine:
     if self.tape is not None:
 
       def bwd(dy):
+        self.side.label = key
         if s.bn is None:
           dz = ops.act_bwd(dy, y, act) if act != ACT_NONE else dy
           dres = dz if res is not None else None
@@ -773,6 +784,8 @@ class Engine:
                 ops.copy_rows(tmp, self.g(s.bias), 1, s.cout, 0, 0, 0, 0, accumulate=True)
 
             self.side.run(Tape.current, bias_grad, dz)
+            if _SIDE_CHECK:
+              self.side.outs.append((key, dz, self.g(s.bias), s.cout))
           dconv = dz
         elif bn_train:
           pre = self._bn_pre.pop(_key(y), None)
@@ -821,6 +834,7 @@ class Engine:
     if self.tape is not None:
 
       def bwd(dy):
+        self.side.label = f'raw_linear {rows}x{n}x{k}'
         dz = ops.act_bwd(dy, y, act) if act != ACT_NONE else dy
         self.side.run(Tape.current, lambda: (gw(dz, x), gb(dz) if gb is not None else None), dz, x)
         dx = torch.empty((rows, k), device=x.device, dtype=x.dtype)

@@ -1020,3 +1020,25 @@ def test_fused_window_attention_vs_torch(ops, n, heads, with_mask):
   O2 = torch.empty_like(O)
   ops.attn_window_fwd(flat[0:], flat[C:], flat[2 * C:], O2, bias, maskp, None, B=W, nh=heads, T=n, d=d, ld_q=3 * C, ld_kv=3 * C, ld_o=C, scale=scale)
   assert torch.equal(O, O2)
+
+
+def test_zero_and_fill_bytes_are_kernels_with_exact_extent(ops):
+  """tfpp_zero / tfpp_fill_bytes (a fill KERNEL since round 2, not a memset node): every alignment of head and tail, nothing outside."""
+  import torch
+  buf = torch.empty(4096 + 64, dtype=torch.uint8, device=DEV)
+  for off in (0, 1, 3, 8, 15, 16, 17):
+    for n in (0, 1, 5, 15, 16, 17, 31, 255, 1000, 4096 - 17):
+      buf.fill_(0xAB)
+      view = buf[off:off + n]
+      if n:
+        ops.lib.tfpp_fill_bytes(ops.ptr(view), 0x5C, n, ops.stream())
+      exp = torch.full_like(buf, 0xAB)
+      exp[off:off + n] = 0x5C
+      assert torch.equal(buf, exp), (off, n)
+      if n:
+        ops.lib.tfpp_zero(ops.ptr(view), n, ops.stream())
+        exp[off:off + n] = 0
+        assert torch.equal(buf, exp), (off, n)
+  big = torch.full((50_000_019,), 1.0, device=DEV)
+  ops.zero_(big[3:-4])
+  assert float(big.sum()) == 7.0 and float(big[:3].sum()) == 3.0

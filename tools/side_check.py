@@ -1,15 +1,50 @@
-"""Debugging aid: one eager bs = 12 training step with TFPP_DEBUG_SIDE_CHECK=1 (every tensor handed to the weight-gradient lane is
-checksummed at hand-over and again at the join)."""
+"""Debugging aid: TFPP_DEBUG_SIDE_CHECK=1 checksums every tensor handed to the weight-gradient lane at hand-over and again at the join.
+Eager: two bs = 12 steps (mismatches are printed by the engine).  --graph: the captured step, replayed; the checksums are device scalars
+inside the graph and are compared here after every replay (a tensor whose contents change between hand-over and join was written by
+somebody while the lane could still read it)."""
 import os
 import sys
 
 os.environ['TFPP_DEBUG_SIDE_CHECK'] = '1'
 sys.path.insert(0, '.')
+import torch  # noqa: E402
 from tools.stress_step import make  # noqa: E402
 
 tr, batch = make(12, 'bf16', True)
-for _ in range(2):
-  tr.train_step(batch)
-import torch  # noqa: E402
-torch.cuda.synchronize()
-print('done')
+if '--graph' not in sys.argv:
+  for _ in range(2):
+    tr.train_step(batch)
+  torch.cuda.synchronize()
+  print('eager: done')
+else:
+  from carla_garage_amd import engine
+  from carla_garage_amd.graph import GraphedTrainStep
+  gs = GraphedTrainStep(tr, batch, warmup=1)
+  log = list(engine.SIDE_CHECK_LOG)
+  print(len(log), 'tensors checked per replay')
+  outs = list(engine.SIDE_OUT_LOG)
+  first = None
+  for r in range(int(os.environ.get('DIAG_REPLAYS', '60'))):
+    gs()
+    torch.cuda.synchronize()
+    bad = {}
+    for where, s0, a0, s1, a1 in log:
+      if float(s0) != float(s1) or float(a0) != float(a1):
+        bad[where] = bad.get(where, 0) + 1
+    if bad:
+      print(f'replay {r}: {sum(bad.values())} modified', dict(list(bad.items())[:6]))
+    cur = [(k, g.clone(), ref.clone()) for k, g, ref in outs]
+    sums = [(where, float(s0), float(a0)) for where, s0, a0, _, _ in log]
+    if r == 0:
+      sums0 = sums
+    else:
+      d = [(i, w) for i, ((w, s_, a_), (_, s0_, a0_)) in enumerate(zip(sums, sums0)) if s_ != s0_ or a_ != a0_]
+      if d:
+        print(f'replay {r}: hand-over checksums differing from replay 0: {len(d)} of {len(sums)}; first:', d[:5])
+    if first is None:
+      first = cur
+    else:
+      lane_var = [k for (k, g, _), (_, g0, _) in zip(cur, first) if not torch.equal(g, g0)]
+      ref_var = [k for (k, _, ref), (_, _, ref0) in zip(cur, first) if not torch.equal(ref, ref0)]
+      if lane_var or ref_var:
+        print(f'replay {r} vs replay 0: {len(lane_var)} of {len(cur)} lane bias gradients differ, {len(ref_var)} recomputed column sums differ;', lane_var[:3], ref_var[:3])
