@@ -410,6 +410,10 @@ class SideLane:
 #   reduction passes it removes are replaced by longer GEMM epilogues on the same critical chain.  The first measurement of mode 2
 #   (38.9 vs 35.8 ms) was taken while a run-time `bns` pointer kept the statistics object of EVERY bf16 conv launch in scratch memory.
 FUSE_BN_BWD = int(os.environ.get('TFPP_FUSE_BN_BWD', '1'))
+# squeeze-excite gate (and its backward) as one per-sample launch after the pooling pass instead of three, parameter gradients on the weight-gradient
+# lane.  Correct (tests) but SLOWER at bs = 12: 31.6 vs 30.0 ms/step (round 2, same box) -- twelve workgroups walking 64 partial rows and two
+# matrices serially lose more than the two saved launches per direction gain; off by default.
+SE_FUSED = os.environ.get('TFPP_SE_FUSED', '0') == '1'
 
 EARLY_GRAD_PREFIXES = ('backbone.image_encoder.s4', 'backbone.lidar_encoder.s4', 'backbone.lidar_encoder.layers.layer3', 'backbone.lidar_encoder.norm', 'backbone.transformers.3', 'backbone.lidar_channel_to_img.3',
                        'backbone.img_channel_to_lidar.3', 'backbone.c5_conv', 'backbone.up_conv')
@@ -945,17 +949,27 @@ class Engine:
 
   def squeeze_excite(self, x, se):
     B, H, W, C = x.shape
-    pool = ops.mean_hw(x)
     w1, b1 = se.fc1.weight.detach().view(se.fc1.weight.shape[0], C), se.fc1.bias.detach()
     w2, b2 = se.fc2.weight.detach().view(C, -1), se.fc2.bias.detach()
-    hidden, gate = ops.se_gate_fwd(pool, w1, b1, w2, b2)
+    fused = SE_FUSED and ops.se_fused_supported(C, w1.shape[0])  # one launch per direction after the pooling pass (stages 1-3)
+    if fused:
+      pool, hidden, gate = ops.se_fwd_fused(x, w1, b1, w2, b2)
+    else:
+      pool = ops.mean_hw(x)
+      hidden, gate = ops.se_gate_fwd(pool, w1, b1, w2, b2)
     y = ops.affine_act(x, gate=gate, rows_per_batch=H * W)
     if self.tape is not None:
 
       def bwd(dy):
-        dgate = ops.se_dgate(dy, x)
-        dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
-                                self.g(se.fc2.weight), self.g(se.fc2.bias))
+        if fused:
+          gd, dz1, dpool = ops.se_bwd_fused(dy, x, gate, hidden, w1, w2)
+          # the gate MLP's parameter gradients only feed the optimizer: weight-gradient lane
+          self.side.run(Tape.current, lambda: ops.se_param_grads(gd, dz1, hidden, pool, self.g(se.fc1.weight), self.g(se.fc1.bias),
+                                                                 self.g(se.fc2.weight), self.g(se.fc2.bias)), gd, dz1, hidden, pool)
+        else:
+          dgate = ops.se_dgate(dy, x)
+          dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
+                                  self.g(se.fc2.weight), self.g(se.fc2.bias))
         info = self._bn_of.get(_key(x)) if (FUSE_BN_BWD >= 1 and x.dtype == torch.bfloat16) else None
         if info is not None and info[2] and Tape.current.is_last_contribution(x):
           # x = relu(BN(raw)) of conv2: this IS its complete gradient -> emit the BatchNorm-backward sums in the same pass

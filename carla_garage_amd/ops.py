@@ -519,6 +519,39 @@ def se_gate_fwd(pool, w1, b1, w2, b2):
   return hidden, gate
 
 
+def se_fused_supported(c, rd):
+  return bool(lib.raw('tfpp_se_fused_supported')(c, rd))
+
+
+def se_fwd_fused(x, w1, b1, w2, b2):
+  """pool, hidden, gate of a squeeze-excite block: the pooling pass + ONE per-sample launch (tfpp_se_fwd_fused)."""
+  b, h, w, c = x.shape
+  rd = w1.shape[0]
+  pool = torch.empty((b, c), device=x.device, dtype=torch.float32)
+  hidden = torch.empty((b, rd), device=x.device, dtype=torch.float32)
+  gate = torch.empty((b, c), device=x.device, dtype=torch.float32)
+  lib.tfpp_se_fwd_fused(ptr(_chk(x)), ptr(reduce_scratch(b, c, x.device)), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(pool), ptr(hidden), ptr(gate),
+                        b, h * w, c, rd, dt(x), stream())
+  return pool, hidden, gate
+
+
+def se_bwd_fused(dy, x, gate, hidden, w1, w2):
+  """(gd, dz1, dpool): the dy*x pooling pass + ONE per-sample launch; gd / dz1 feed se_param_grads."""
+  b, h, w, c = x.shape
+  rd = hidden.shape[1]
+  gd = torch.empty_like(gate)
+  dz1 = torch.empty_like(hidden)
+  dpool = torch.empty_like(gate)
+  lib.tfpp_se_bwd_fused(ptr(_chk(dy)), ptr(_chk(x)), ptr(reduce_scratch(b, c, x.device)), ptr(gate), ptr(hidden), ptr(w1), ptr(w2), ptr(gd), ptr(dz1),
+                        ptr(dpool), b, h * w, c, rd, dt(x), stream())
+  return gd, dz1, dpool
+
+
+def se_param_grads(gd, dz1, hidden, pool, dw1, db1, dw2, db2):
+  b, c = gd.shape
+  lib.tfpp_se_param_grads(ptr(gd), ptr(dz1), ptr(hidden), ptr(pool), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), b, c, hidden.shape[1], stream())
+
+
 def se_dgate(dy, x):
   b, h, w, c = x.shape
   out = torch.empty((b, c), device=x.device, dtype=torch.float32)

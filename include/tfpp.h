@@ -316,6 +316,17 @@ int tfpp_se_dgate(const void* dy, const void* x, float* dgate, float* scratch, i
 int tfpp_se_gate_bwd(const float* dgate, const float* gate, const float* hidden, const float* pool, const float* w1,
                      const float* w2, float* dz1_scratch /* [B*RD] */, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
                      int B, int C, int RD, void* stream);
+/* Squeeze-excite gate with the second stage of the pooling reduction, fc1 + ReLU and fc2 + sigmoid in ONE launch per sample after the pooling
+ * pass (timm SEModule as RegNetY uses it, oracle/timm_regnet.py; replaces tfpp_mean_hw + tfpp_se_gate_fwd where tfpp_se_fused_supported(C, RD)),
+ * and its backward: tfpp_se_dgate + the data half of tfpp_se_gate_bwd in one launch (gd = dgate g (1 - g) [B, C] and dz1 [B, RD] are written
+ * out), the parameter gradients in tfpp_se_param_grads (single writer per element, accumulating).  scratch: tfpp_reduce_scratch_floats(B, C). */
+int tfpp_se_fused_supported(int C, int RD);
+int tfpp_se_fwd_fused(const void* x, float* scratch, const float* w1, const float* b1, const float* w2, const float* b2, float* pool,
+                      float* hidden, float* gate, int B, int HW, int C, int RD, int dtype, void* stream);
+int tfpp_se_bwd_fused(const void* dy, const void* x, float* scratch, const float* gate, const float* hidden, const float* w1, const float* w2,
+                      float* gd, float* dz1, float* dpool, int B, int HW, int C, int RD, int dtype, void* stream);
+int tfpp_se_param_grads(const float* gd, const float* dz1, const float* hidden, const float* pool, float* dw1, float* db1, float* dw2, float* db2,
+                        int B, int C, int RD, void* stream);
 int tfpp_se_bwd_apply(const void* dy, const float* gate, const float* dpool, void* dx, int B, int HW, int C, int dtype, void* stream);
 /* se_bwd_apply with the BatchNorm-backward statistics of the preceding layer fused in (conv2 of a RegNet bottleneck: dx is the
  * complete gradient of y = relu(BN(x))): also writes tfpp_se_bwd_apply_bns_rows(B, HW, C, dtype) rows [2*C] of (sum g, sum g*xhat),

@@ -472,6 +472,41 @@ def test_squeeze_excite(ops, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(3, 10, 14, 72, 8), (12, 16, 64, 576, 144), (2, 8, 8, 216, 54), (12, 16, 16, 576, 144)], ids=lambda v: 'x'.join(map(str, v)))
+def test_squeeze_excite_fused(ops, dtype, shape):
+  """tfpp_se_fwd_fused / tfpp_se_bwd_fused / tfpp_se_param_grads (one launch per direction after the pooling pass) against torch, at the
+  RegNetY stage-1 / stage-2 / stage-3 shapes of both branches; the stage-4 shape must be refused (it keeps the separate kernels)."""
+  B, H, W, C, RD = shape
+  assert ops.se_fused_supported(C, RD) and not ops.se_fused_supported(1512, 378)
+  x = rnd(B, C, H, W, dtype=dtype, seed=51)
+  w1, b1, w2, b2 = rnd(RD, C, seed=52) * 0.3, rnd(RD, seed=53), rnd(C, RD, seed=54) * 0.5, rnd(C, seed=55)
+  ps = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+  pool_ref = ps[0].mean((2, 3))
+  hid_ref = F.relu(F.linear(pool_ref, ps[1], ps[2]))
+  gate_ref = torch.sigmoid(F.linear(hid_ref, ps[3], ps[4]))
+  want = ps[0] * gate_ref.view(B, C, 1, 1)
+  xd = dev(nhwc(x), dtype)
+  pool, hidden, gate = ops.se_fwd_fused(xd, dev(w1), dev(b1), dev(w2), dev(b2))
+  check('sef.pool', pool.cpu(), pool_ref, dtype)
+  check('sef.hidden', hidden.cpu(), hid_ref, dtype)
+  check('sef.gate', gate.cpu(), gate_ref, dtype)
+  dy = rnd(B, C, H, W, dtype=dtype, seed=56)
+  want.backward(dy)
+  dyd = dev(nhwc(dy), dtype)
+  gd, dz1, dpool = ops.se_bwd_fused(dyd, xd, gate, hidden, dev(w1), dev(w2))
+  grads = [torch.full_like(dev(t), 0.25) for t in (w1, b1, w2, b2)]  # accumulating: a non-zero start must survive
+  ops.se_param_grads(gd, dz1, hidden, pool, *grads)
+  dx = ops.se_bwd_apply(dyd, gate, dpool)
+  check('sef.dx', nchw(dx.float().cpu()), ps[0].grad, dtype, scale=3.0)
+  for nme, g, p in zip(('dw1', 'db1', 'dw2', 'db2'), grads, ps[1:]):
+    check('sef.' + nme, g.cpu() - 0.25, p.grad, dtype, scale=3.0)
+  # and against the three-launch path on the same inputs (same arithmetic up to the order of the fixed-order sums)
+  pool2 = ops.mean_hw(xd)
+  hidden2, gate2 = ops.se_gate_fwd(pool2, dev(w1), dev(b1), dev(w2), dev(b2))
+  assert float((gate - gate2).abs().max()) < 1e-5 and float((hidden - hidden2).abs().max()) < 1e-4 * (1 + float(hidden2.abs().max()))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_pool_and_bilinear(ops, dtype):
   B, C = 2, 24
   x = rnd(B, C, 16, 64, dtype=dtype, seed=61)
