@@ -55,6 +55,7 @@ def _scratch_key(device):
 
 
 _SPLITK_WS = {}
+_NO_CONV_SPLITK = _os.environ.get('TFPP_DEBUG_NO_CONV_SPLITK', '0') == '1'
 SPLITK_WS_FLOATS = 16 << 20
 
 
@@ -90,6 +91,8 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
   p.dst_f32 = int(dst.dtype == torch.float32 and src.dtype != torch.float32)
   ws = splitk_workspace(src.device)
   p.splitk_ws, p.splitk_ws_floats, p.splitk = ptr(ws), ws.numel(), 0
+  if _NO_CONV_SPLITK:  # debugging aid: no K split for forward / data-gradient GEMMs while the weight-gradient slices keep their workspace
+    p.splitk_ws, p.splitk_ws_floats = None, 0
   if bns_query:  # (can the kernel that runs here emit the fused BatchNorm-backward statistics?, rows of bns_partial it would write)
     p.bns_ld = Cd
     p.bns_partial = 16  # never dereferenced: plan as the launch with the statistics will be planned (tile variant, no split-K)
