@@ -88,6 +88,7 @@ def source_hash():
   import hashlib
   h = hashlib.sha256()
   files = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cuh', '.h')))
+  h.update(' '.join(HIPCC_FLAGS).encode() + b'\0')  # a library built with other flags is another library
   for path in [os.path.join(CSRC, f) for f in files] + [HEADER]:
     h.update(os.path.basename(path).encode() + b'\0')
     with open(path, 'rb') as f:
@@ -96,6 +97,13 @@ def source_hash():
   return int(h.hexdigest()[:16], 16)
 
 
+# Compile flags of every kernel source.  -fno-slp-vectorize -fno-vectorize: no packed-FP32 VALU instructions (v_pk_fma_f32 / v_pk_add_f32 /
+# v_pk_mul_f32).  Round 3 traced the "result depends on the co-runner" issue of round 2 to them: in layernorm_bwd_kernel the SLP vectorizer
+# turned the two row sums into packed operations with op_sel lane swaps, and waves of that kernel that shared their CU with the persistent
+# MFMA / LDS-transpose weight-gradient kernel returned a wrong sum c1 in ~2 % of the rows (tools/replay_bisect.py), the
+# scalar code never does.  tests/test_kernel_resources.py fails the CPU suite if a packed FP32 instruction reappears in any kernel.
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-fno-vectorize']
+EXTRA_FLAGS = os.environ.get('TFPP_BUILD_FLAGS', '').split()  # experiments only (build(force=True)); the product build has none
 HASH_PATH = LIB_PATH + '.srchash'  # written by build() next to the library (reading the embedded hash would dlopen the old binary)
 
 
@@ -123,7 +131,7 @@ def build(verbose=False, force=False):
   for s in srcs:
     o = os.path.join(PKG_DIR, 'build', os.path.basename(s) + '.o')
     objs.append(o)
-    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', f'-DTFPP_SOURCE_HASH=0x{want:016x}ULL', '-c', s, '-o', o]
+    cmd = ['hipcc'] + HIPCC_FLAGS + ['-fPIC', f'-DTFPP_SOURCE_HASH=0x{want:016x}ULL'] + EXTRA_FLAGS + ['-c', s, '-o', o]
     procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
   for cmd, p in procs:
     outp = p.communicate()[0].decode()

@@ -412,6 +412,28 @@ extern "C" int tfpp_struct_sizes(int* out, int n) {
   return 5;
 }
 
+// order-independent 64-bit hash of a buffer (debugging aid: which tensor differs between two replays of one hipGraph?)
+__global__ void hash_words_kernel(const unsigned int* __restrict__ w, long n, unsigned long long* __restrict__ slot) {
+  unsigned long long h = 0ull;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned long long x = ((unsigned long long)w[i] << 32 | (unsigned long long)(unsigned int)i) ^ ((unsigned long long)(i >> 32) * 0x9E3779B97F4A7C15ull);
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    h += x;
+  }
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+  if ((threadIdx.x & 63) == 0 && h) atomicAdd(slot, h);
+}
+extern "C" int tfpp_hash_words(const void* p, int64_t bytes, uint64_t* slot, void* stream) {
+  if (!p || !slot || bytes < 0 || (bytes & 3)) return TFPP_EINVAL;
+  const long n = bytes >> 2;
+  if (n == 0) return 0;
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(hash_words_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned int*)p, n, (unsigned long long*)slot);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
 // *p += 1 : per-step counter added to every dropout seed (captured in the training-step hipGraph)
 __global__ void inc_u64_kernel(unsigned long long* p) { *p += 1ull; }
 extern "C" int tfpp_inc_u64(uint64_t* p, void* stream) {

@@ -578,7 +578,7 @@ extern "C" int tfpp_layernorm_fwd(const void* x, const float* gamma, const float
 template <typename T, int LN_MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                      const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx, long rows, int C,
-                                     int rows_per_wave) {
+                                     int rows_per_wave, float* __restrict__ dbg) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const int CV = C / VEC;
   const int lane = threadIdx.x & 63;
@@ -608,6 +608,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
     c1 = wave_sum(c1) / (float)C;
     c2 = wave_sum(c2) / (float)C;
+    const unsigned long long disagree = dbg ? __ballot(__float_as_uint(c1) != __builtin_amdgcn_readfirstlane(__float_as_uint(c1))) : 0ull;
+    if (dbg && lane == 0) {  // debugging aid (tfpp_debug_ln_buffer): the row scalars, the wave's MODE register and where it ran
+      unsigned mode, hwid;
+      mode = (unsigned)__builtin_popcountll(disagree);  // lanes whose butterfly result differs from lane 0's
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      float* o = dbg + row * 6;
+      o[0] = c1; o[1] = c2; o[2] = mu; o[3] = rs; o[4] = __uint_as_float(mode); o[5] = __uint_as_float(hwid);
+    }
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
       const int cv = lane + k * 64;
@@ -650,6 +658,13 @@ __global__ void layernorm_param_grad_kernel(const T* __restrict__ dy, const T* _
   }
 }
 
+// debugging aid: the NEXT tfpp_layernorm_bwd launch writes {c1, c2, mean, rstd, MODE register, HW_ID} per row into buf ([rows][6] floats)
+static float* g_ln_debug = nullptr;
+extern "C" int tfpp_debug_ln_buffer(float* buf) {
+  g_ln_debug = buf;
+  return 0;
+}
+
 extern "C" int tfpp_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                                   float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx) return TFPP_EINVAL;
@@ -660,7 +675,9 @@ extern "C" int tfpp_layernorm_bwd(const void* dy, const void* x, const float* ga
   const int rpw = 1;  // dx: one wave per row, no atomics (parameter gradients come from the column-reduction kernel below)
   const long waves = (rows + rpw - 1) / rpw;
   dim3 grid((unsigned)((waves + 3) / 4));
-#define LN_BWD(TT, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, MV>), grid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, gamma, mean, rstd, (TT*)dx, (long)rows, C, rpw)
+  float* dbg = g_ln_debug;  // armed for one launch
+  g_ln_debug = nullptr;
+#define LN_BWD(TT, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, MV>), grid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, gamma, mean, rstd, (TT*)dx, (long)rows, C, rpw, dbg)
 #define LN_BWD_T(TT) do { if (nv <= 1) LN_BWD(TT, 1); else if (nv <= 2) LN_BWD(TT, 2); else if (nv <= 3) LN_BWD(TT, 3); else if (nv <= 4) LN_BWD(TT, 4); else LN_BWD(TT, 6); } while (0)
   if (dtype == TFPP_F32) LN_BWD_T(float); else LN_BWD_T(bf16_t);
   if (dgamma || dbeta) {

@@ -148,7 +148,9 @@ class DeviceBatchPrefetcher:
     finally:
       stop.set()
       free_q.put(None)
-      th.join()
+      # the stager may be blocked inside `for host_batch in self.loader` (a slow or stalled DataLoader) where it cannot see `stop`: it is a
+      # daemon thread, so an early exit of the consumer (break / exception) must not wait for the next host batch indefinitely
+      th.join(timeout=5.0)
 
 
 TARGET_KEYS = ('center_heatmap_label', 'wh_label', 'offset_label', 'yaw_class_label', 'yaw_res_label', 'velocity_label', 'brake_target_label',

@@ -287,11 +287,18 @@ class Tape:
           self._sync(lane, sl)
         if multi and src_lanes - {lane}:
           lanes.hold(*[g for g in gouts if g is not None])
+        if ops.NODE_HASH['on']:
+          lab = _fn_label(fn)
+          for j, g in enumerate(gouts):
+            ops.node_hash(g, f'bwd lane{lane} {lab} consumes gout{j}')
         gins = fn(*gouts)
         if gins is None:
           gins = ()
         if not isinstance(gins, (tuple, list)):
           gins = (gins,)
+        if ops.NODE_HASH['on']:
+          for j, g in enumerate(gins):
+            ops.node_hash(g, f'bwd lane{lane} {lab} produces gin{j}')
         for t, g in zip(ins, gins):
           self._acc(t, g, lane)
         if _KEEP_ALL:  # debugging aid: nothing the backward pass touched is freed (and so reused) before the pass ends
@@ -318,6 +325,22 @@ class Tape:
     Tape.current = None
 
 
+def _fn_label(fn):
+  """Readable name of a backward closure for the debugging tables: qualified name + the layer key / name it closed over."""
+  lab = getattr(fn, '__qualname__', str(fn)).replace('.<locals>', '')
+  try:
+    for nme, cell in zip(fn.__code__.co_freevars, fn.__closure__ or ()):
+      if nme in ('key', 'name', 'prefix') and isinstance(cell.cell_contents, str):
+        lab += f'[{cell.cell_contents}]'
+      elif nme == 's' and isinstance(cell.cell_contents, ConvSpec):
+        lab += f'[{cell.cell_contents.name}]'
+  except ValueError:  # empty cell
+    pass
+  return lab
+
+
+_LN_CHECK = os.environ.get('TFPP_DEBUG_LN_CHECK', '0') == '1'
+LN_KEEP = {}
 _SKIP_SIDE_WORK = os.environ.get('TFPP_DEBUG_SKIP_SIDE_WORK', '0') == '1'
 _SIDE_CHECK = os.environ.get('TFPP_DEBUG_SIDE_CHECK', '0') == '1'
 _KEEP_ALL = os.environ.get('TFPP_DEBUG_KEEP_ALL', '0') == '1'
@@ -336,11 +359,12 @@ class SideLane:
   def __init__(self):
     self.enabled = os.environ.get('TFPP_SIDE_STREAM', '1') != '0'
     # launches per fork (one event wait per batch); round 1: 8: 35.0, 16: 34.4, 32: 33.6, 64: 35.5 ms/step; end of round 2 (same box): 16: 30.9,
-    # 32: 30.2-30.4, 64: 31.8, 128: 29.9-30.2, 256: 31.0.  Kept at 32 although 128 is 0.25 ms faster: with more than ~64 launches per fork the
-    # replays of the CAPTURED step stop being bit-reproducible (tools/replay_diff.py: weight / bias gradients computed on this lane differ by up
-    # to 1e-4 of their maximum between replays at 96 and 128; 32, 48 and 64 reproduce, and so does the eager step at 128; keeping every tensor
-    # of the pass alive until its end, TFPP_DEBUG_KEEP_ALL=1, changes nothing, so it is not allocator reuse) -- DESIGN.md section 4, open issue.
-    self.batch = int(os.environ.get('TFPP_SIDE_BATCH', '32'))
+    # 32: 30.2-30.4, 64: 31.8, 128: 29.9-30.2, 256: 31.0; round 3 (same box, A/B/A/B): 32: 30.10 / 30.18, 128: 29.91 / 30.02.
+    # Round 2 kept 32 because the replays of the captured step were not bit-reproducible at 96 / 128.  Round 3 found the cause
+    # (tools/replay_bisect.py): not the lanes, but packed-FP32 VALU instructions in layernorm_bwd_kernel that return wrong row sums when the
+    # wave shares its CU with the persistent MFMA weight-gradient kernel -- the library is now built without them (_lib.HIPCC_FLAGS) and
+    # tools/stress_step.py passes at 96 and 128 (profiles/r03_stress_step_side_batch128.log).
+    self.batch = int(os.environ.get('TFPP_SIDE_BATCH', '128'))
     self.stream = None
     self.lanes = None  # Lanes of the engine: a batch may hold closures from both encoder-branch streams
     self.keep = []
@@ -739,6 +763,9 @@ class Engine:
   def rec(self, outs, ins, fn):
     if self.tape is not None:
       self.tape.record(outs, ins, fn, self.lanes.cur)
+      if ops.NODE_HASH['on']:
+        for j, o in enumerate(outs):
+          ops.node_hash(o, f'fwd lane{self.lanes.cur} {_fn_label(fn)} out{j}')
 
   def conv(self, x, key, act=ACT_NONE, res=None, x_grad=True, out_f32=False):
     """x: [B,H,W,Cstore] NHWC.  Returns [B,Ho,Wo,n_store]."""
@@ -851,7 +878,38 @@ class Engine:
   def layernorm(self, x, ln):
     y, mean, rstd = ops.layernorm_fwd(x, ln.weight.detach(), ln.bias.detach(), ln.eps, save=self.tape is not None)
     if self.tape is not None:
-      self.rec([y], [x], lambda dy: ops.layernorm_bwd(dy, x, ln.weight.detach(), mean, rstd, self.g(ln.weight), self.g(ln.bias)))
+
+      def bwd(dy):
+        if not _LN_CHECK:
+          return ops.layernorm_bwd(dy, x, ln.weight.detach(), mean, rstd, self.g(ln.weight), self.g(ln.bias))
+        # debugging aid (tools/replay_bisect.py): hash every operand before and after the kernel, and run the kernel twice
+        gam = ln.weight.detach()
+        for nme, t in (('dy', dy), ('x', x), ('mean', mean), ('rstd', rstd), ('gamma', gam)):
+          ops.node_hash(t, f'LN before {nme}')
+        keep = x.shape[-1] == 1512 and x.dtype == torch.bfloat16 and LN_KEEP.get('armed', True)
+        if keep:
+          for nme in ('dbg1', 'dbg2'):
+            if nme not in LN_KEEP:
+              LN_KEEP[nme] = ops.zeros((x.numel() // x.shape[-1], 6), F32, x.device)
+          ops.lib.tfpp_debug_ln_buffer(ops.ptr(LN_KEEP['dbg1']))
+        dx = ops.layernorm_bwd(dy, x, gam, mean, rstd, self.g(ln.weight), self.g(ln.bias))
+        ops.node_hash(dx, 'LN dx first run')
+        for nme, t in (('dy', dy), ('x', x), ('mean', mean), ('rstd', rstd), ('gamma', gam)):
+          ops.node_hash(t, f'LN after {nme}')
+        if keep:
+          ops.lib.tfpp_debug_ln_buffer(ops.ptr(LN_KEEP['dbg2']))
+        dx2 = ops.layernorm_bwd(dy, x, gam, mean, rstd, None, None)
+        ops.node_hash(dx2, 'LN dx second run')
+        ops.node_hash(dx, 'LN dx first run, hashed again')
+        if x.shape[-1] == 1512 and x.dtype == torch.bfloat16 and LN_KEEP.get('armed', True):  # first C = 1512 LayerNorm of the backward pass: keep both results
+          LN_KEEP['armed'] = False
+          for nme, t in (('dx1', dx), ('dx2', dx2), ('dy', dy)):
+            if nme not in LN_KEEP:
+              LN_KEEP[nme] = torch.empty_like(t)  # (allocated by the eager warm-up step, i.e. outside the capture)
+            ops.copy_rows(t, LN_KEEP[nme], 1, t.numel(), 0, 0, 0, 0)
+        return dx
+
+      self.rec([y], [x], bwd)
     return y
 
   def add(self, a, b, p_drop=0.0):
@@ -1215,6 +1273,9 @@ class Engine:
     bb = m.backbone
     out = {}
     self._bn_of, self._bn_pre = {}, {}
+    if ops.NODE_HASH['on'] and self.tape is not None:
+      ops.node_hash_begin(dev)
+      LN_KEEP['armed'] = True
     if self.tape is not None:
       self.tape.on_accumulate = lambda key: self._bn_pre.pop(key, None)  # a "complete" gradient got another addend: sums are stale
     self.lanes.begin(dev)
@@ -1234,6 +1295,8 @@ class Engine:
       xl = xi
     elif self.bev:  # team_code/bev_encoder.py:146-233
       xi, xl = self.bev_runner.forward(xi, lidar_bev.float().contiguous())
+      if self.tape is not None:
+        self.tape.mark()  # every backbone.* parameter of this configuration is "late" (finishes_early): the first backward segment is the heads
     else:
       lidar_in = lidar_bev.float().contiguous()
       lanes.hold(lidar_in)

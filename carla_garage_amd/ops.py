@@ -55,6 +55,17 @@ def _scratch_key(device):
 
 
 _SPLITK_WS = {}
+_RETIRED = []  # scratch buffers replaced by larger ones: never freed, a captured hipGraph may still hold their raw pointers
+
+
+def _replace_scratch(table, key, buf):
+  old = table.get(key)
+  if old is not None:
+    _RETIRED.append(old)
+  table[key] = buf
+  return buf
+
+
 _NO_CONV_SPLITK = _os.environ.get('TFPP_DEBUG_NO_CONV_SPLITK', '0') == '1'
 SPLITK_WS_FLOATS = 16 << 20
 
@@ -348,8 +359,7 @@ def bn_scratch(c, device, min_floats=0):
   key = _scratch_key(device)
   buf = _BN_SCRATCH.get(key)
   if buf is None or buf.numel() < need:
-    buf = torch.empty(max(need, lib.raw('tfpp_bn_scratch_floats')(1512)), device=device, dtype=torch.float32)
-    _BN_SCRATCH[key] = buf
+    buf = _replace_scratch(_BN_SCRATCH, key, torch.empty(max(need, lib.raw('tfpp_bn_scratch_floats')(1512)), device=device, dtype=torch.float32))
   return buf
 
 
@@ -373,8 +383,7 @@ def stats_rows_buffer(c, device, rows=64):
       # a buffer born inside a capture would be zeroed by that graph only, and a grown one would strand the pointers an earlier
       # capture holds: run one eager step of the same shapes before capturing (GraphedTrainStep / GraphedForward warm-ups do)
       raise RuntimeError('BatchNorm statistics rows must be allocated before hipGraph capture: run one eager warm-up step first')
-    buf = zero_(torch.empty(max(need, 64 * 2 * 1512), device=device, dtype=torch.float32))
-    _STATS_ROWS[key] = buf
+    buf = _replace_scratch(_STATS_ROWS, key, zero_(torch.empty(max(need, 64 * 2 * 1512), device=device, dtype=torch.float32)))
   return buf
 
 
@@ -402,7 +411,7 @@ def clone_scratch_for_current_stream(device):
     cur = table.get(key)
     if cur is None or cur.numel() < max(sizes):
       buf = torch.empty(max(sizes), device=device, dtype=torch.float32)
-      table[key] = zero_(buf) if zeroed else buf
+      _replace_scratch(table, key, zero_(buf) if zeroed else buf)  # the replaced buffer stays alive: earlier captures point into it
 
 
 def reduce_scratch(b, c, device):
@@ -411,8 +420,7 @@ def reduce_scratch(b, c, device):
   key = _scratch_key(device)
   buf = _REDUCE_SCRATCH.get(key)
   if buf is None or buf.numel() < need:
-    buf = torch.empty(max(need, lib.raw('tfpp_reduce_scratch_floats')(12, 1512)), device=device, dtype=torch.float32)
-    _REDUCE_SCRATCH[key] = buf
+    buf = _replace_scratch(_REDUCE_SCRATCH, key, torch.empty(max(need, lib.raw('tfpp_reduce_scratch_floats')(12, 1512)), device=device, dtype=torch.float32))
   return buf
 
 
@@ -793,6 +801,35 @@ def zero_(t):
 
 def zeros(shape, dtype=torch.float32, device='cuda'):
   return zero_(torch.empty(shape, device=device, dtype=dtype))
+
+
+# debugging aid (tools/replay_bisect.py): one order-independent 64-bit hash per tape event, written into a device table by kernels that are part of
+# the captured step, so two replays of ONE hipGraph can be compared event by event
+NODE_HASH = {'on': _os.environ.get('TFPP_DEBUG_NODE_HASH', '0') == '1', 'buf': None, 'n': 0, 'labels': [], 'lo': 0, 'hi': 1 << 30, 'slots': 32768}
+if _os.environ.get('TFPP_DEBUG_NODE_HASH_RANGE'):
+  NODE_HASH['lo'], NODE_HASH['hi'] = (int(v) for v in _os.environ['TFPP_DEBUG_NODE_HASH_RANGE'].split(':'))
+
+
+def node_hash_begin(device):
+  st = NODE_HASH
+  if st['buf'] is None:
+    st['buf'] = torch.empty(st['slots'], device=device, dtype=torch.int64)
+  zero_(st['buf'])
+  st['n'] = 0
+  st['labels'] = []
+
+
+def node_hash(t, label):
+  st = NODE_HASH
+  if t is None or not t.is_cuda or not t.is_contiguous() or st['buf'] is None:
+    return
+  i = st['n']
+  st['n'] += 1
+  st['labels'].append(f'{label} {tuple(t.shape)} {str(t.dtype)[6:]}')
+  nbytes = t.numel() * t.element_size()
+  if i >= st['slots'] or not (st['lo'] <= i < st['hi']) or nbytes % 4:
+    return
+  lib.tfpp_hash_words(ptr(t), nbytes, st['buf'].data_ptr() + 8 * i, stream())
 
 
 def sum_f32(x, out):

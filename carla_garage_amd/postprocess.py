@@ -24,10 +24,17 @@ def polygon_area(p):
   return 0.5 * abs(float(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))))
 
 
+def signed_area(p):
+  x, y = p[:, 0], p[:, 1]
+  return 0.5 * float(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1)))
+
+
 def clip_convex(subject, clip):
   """Sutherland-Hodgman: the part of the convex polygon ``subject`` inside the convex, counter-clockwise polygon ``clip``."""
   out = [tuple(p) for p in subject]
   n = len(clip)
+  if signed_area(clip) < 0.0:  # a negative half-extent (raw CenterNet wh regression) flips the ring: shapely does not care, the clipper does
+    clip = clip[::-1]
   for i in range(n):
     a, b = clip[i], clip[(i + 1) % n]
     edge = b - a
@@ -68,7 +75,11 @@ def non_maximum_suppression(bounding_boxes, iou_treshhold):
   boxes = [np.asarray(b) for group in bounding_boxes for b in group]
   if not boxes:
     return []
-  order = list(np.argsort(np.array([float(b[-1]) for b in boxes]), kind='stable'))
+  # the reference sorts an object array with numpy's default argsort (transfuser_utils.py:411,416): the same call, so equal confidences
+  # come out in the same order
+  conf = np.empty(len(boxes), dtype=object)
+  conf[:] = [b[-1] for b in boxes]
+  order = list(np.argsort(conf))
   kept = []
   while order:
     idx = order.pop()

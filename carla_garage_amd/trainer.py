@@ -19,10 +19,18 @@ from .losses import fused_losses, normalized_loss_weights, active_losses
 
 class Trainer:
 
-  def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, process_group=None, use_graph=False):
+  def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, process_group=None, use_graph=False, lazy_state=False):
+    """lazy_state: allocate the three optimizer-state arenas on the first optimizer launch (the drop-in path of dropin.py owns a Trainer
+    for its flat arenas and gradient exchange; the 1.4 GB of AdamW state is only needed when the fused optimizer is the one stepping)."""
     self.model = model
-    if getattr(model.config, 'use_optim_groups', False):
+    if getattr(model.config, 'use_optim_groups', False) and not lazy_state:
       raise NotImplementedError('MI355X trainer: one AdamW parameter group (team_code/config.py:263 default use_optim_groups=False)')
+    prev = model.__dict__.get('_trainer')
+    if prev is not None and prev is not self:
+      prev.detached = True  # the parameters move into THIS trainer's arena: the previous owner's arena is stale from here on
+    model.__dict__['_trainer'] = self
+    self.detached = False
+    self._lazy_state = lazy_state
     self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay  # lr is read at every step: schedulers just set it
     self.pg = process_group
     self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -54,10 +62,26 @@ class Trainer:
       ops.copy_rows(p.detach().contiguous(), dst, 1, n, 0, 0, 0, 0)
       p.data = dst.view(p.shape)
       off += ops.pad_to(n, 4)
-    self.exp_avg = ops.zeros(self.flat_param.shape, F32, dev)
-    self.exp_avg_sq = ops.zeros(self.flat_param.shape, F32, dev)
-    self.max_exp_avg_sq = ops.zeros(self.flat_param.shape, F32, dev)
+      p._tfpp_arena = (self, off - ops.pad_to(n, 4))  # lets carla_garage_amd.optim.FlatAdamW find the arena a parameter lives in
+    self.exp_avg = self.exp_avg_sq = self.max_exp_avg_sq = None
+    if not self._lazy_state:
+      self._alloc_state()
     tdist.broadcast_state(self.flat_param, list(self.model.buffers()), self.pg)  # DDP constructor broadcast, train.py:516
+
+  def _alloc_state(self):
+    if self.exp_avg is None:
+      dev = self.eng.device
+      self.exp_avg = ops.zeros(self.flat_param.shape, F32, dev)
+      self.exp_avg_sq = ops.zeros(self.flat_param.shape, F32, dev)
+      self.max_exp_avg_sq = ops.zeros(self.flat_param.shape, F32, dev)
+
+  def arena_intact(self):
+    """True while every trainable parameter still lives at its place in flat_param (model.cuda() / .to() / .half() after the flattening
+    re-allocate the parameters; the owner then has to flatten again)."""
+    if self.detached:
+      return False
+    base = self.flat_param.data_ptr()
+    return all(p.data_ptr() == base + 4 * off for _, off, p in self._arena_slices())
 
   # ---------------------------------------------------------------------------------------------- one step
   def _step_part1(self, batch, split=True):
@@ -90,6 +114,7 @@ class Trainer:
     return vals
 
   def _optimizer(self, step):
+    self._alloc_state()
     self.eng.invalidate()
     ops.adamw_amsgrad(self.flat_param, self.eng.flat_grad, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, self.lr, self.betas[0],
                       self.betas[1], self.eps, self.weight_decay, step, grad_scale=1.0 / self.world)
@@ -147,6 +172,7 @@ class Trainer:
     parameter group.  Values are clones cut out of the flat arenas."""
     n_params = len(list(self.model.parameters()))
     state = {}
+    self._alloc_state()
     if self.step_count > 0:
       for i, off, p in self._arena_slices():
         n = p.numel()
@@ -165,6 +191,7 @@ class Trainer:
     if len(sd['param_groups']) != 1 or not g.get('amsgrad', False):
       raise ValueError('expected the single amsgrad AdamW parameter group of team_code/train.py:529-531')
     self.lr, self.betas, self.eps, self.weight_decay = float(g['lr']), tuple(g['betas']), float(g['eps']), float(g['weight_decay'])
+    self._alloc_state()
     steps = set()
     for i, off, p in self._arena_slices():
       st = sd['state'].get(i)

@@ -413,6 +413,12 @@ int tfpp_copy_rows(const void* src, void* dst, int B, int64_t n, int64_t src_bs,
                    int accumulate, int dtype_in, int dtype_out, void* stream);
 int tfpp_zero(void* p, int64_t bytes, void* stream); /* hipMemsetAsync(p, 0, bytes) */
 int tfpp_fill_bytes(void* p, int value, int64_t bytes, void* stream); /* hipMemsetAsync(p, value, bytes): debug poisoning (TFPP_DEBUG_POISON) */
+/* debugging aid (tools/replay_bisect.py, TFPP_DEBUG_NODE_HASH): *slot += an order-independent 64-bit hash of the 32-bit words of
+ * p[0, bytes) (bytes a multiple of 4; integer adds only, so equal bytes always give equal sums whatever the block order). */
+int tfpp_hash_words(const void* p, int64_t bytes, uint64_t* slot, void* stream);
+/* debugging aid: the next tfpp_layernorm_bwd launch also writes {c1, c2, mean, rstd, bits of the wave's MODE register, bits of HW_ID} per
+ * row into buf ([rows][6] floats); NULL disarms. */
+int tfpp_debug_ln_buffer(float* buf);
 
 /* ---------------------------------------------------------------------------------------------------------
  * GRU waypoint / checkpoint decoder (model.py:857-867): h0 = enc(target_point); nn.GRU(256->64) over T steps;

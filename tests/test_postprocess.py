@@ -67,3 +67,19 @@ def test_nms_follows_the_reference_loop():
     for j in range(i + 1, len(kept)):
       assert iou_bbs(kept[i], kept[j]) <= thr
   assert non_maximum_suppression([[], []], thr) == []
+
+
+def test_iou_with_negative_half_extents_equals_the_same_rectangles():
+  """The raw wh regression can be negative: shapely's polygon of (-w, h) covers the same points as that of (w, h) (the ring just runs the
+  other way), so the IoU must not change -- the clipper used to return 0 for these."""
+  rng = np.random.RandomState(3)
+  for _ in range(20):
+    b1 = [rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(0.5, 2.0), rng.uniform(0.5, 2.0), rng.uniform(-math.pi, math.pi)]
+    b2 = [rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(0.5, 2.0), rng.uniform(0.5, 2.0), rng.uniform(-math.pi, math.pi)]
+    want = iou_bbs(b1, b2)
+    assert want > 0.0
+    for s1 in ((1, 1), (-1, 1), (1, -1), (-1, -1)):
+      for s2 in ((1, 1), (-1, 1), (1, -1), (-1, -1)):
+        n1 = [b1[0], b1[1], s1[0] * b1[2], s1[1] * b1[3], b1[4]]
+        n2 = [b2[0], b2[1], s2[0] * b2[2], s2[1] * b2[3], b2[4]]
+        assert abs(iou_bbs(n1, n2) - want) < 1e-12

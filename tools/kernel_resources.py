@@ -21,14 +21,25 @@ def demangle(names):
     return {n: n for n in names}
 
 
+_ASM = {}
+
+
+def assembly(path):
+  """gfx950 assembly of one source, compiled with the product's flags (cached per process)."""
+  if path not in _ASM:
+    with tempfile.TemporaryDirectory() as td:
+      s_path = os.path.join(td, 'k.s')
+      sys.path.insert(0, ROOT)
+      from carla_garage_amd._lib import HIPCC_FLAGS  # the flags the product is built with
+      r = subprocess.run(['hipcc'] + HIPCC_FLAGS + ['-S', '--cuda-device-only', '-DTFPP_SOURCE_HASH=0', path, '-o', s_path], capture_output=True, text=True)
+      if r.returncode:
+        raise RuntimeError(r.stderr[-2000:])
+      _ASM[path] = open(s_path).read()
+  return _ASM[path]
+
+
 def table(path):
-  with tempfile.TemporaryDirectory() as td:
-    s_path = os.path.join(td, 'k.s')
-    r = subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-DTFPP_SOURCE_HASH=0', path, '-o', s_path],
-                       capture_output=True, text=True)
-    if r.returncode:
-      raise RuntimeError(r.stderr[-2000:])
-    s = open(s_path).read()
+  s = assembly(path)
   rows = []
   # per kernel: .amdhsa_kernel NAME ... ; NumVgprs / NumAgprs / TotalNumVgprs / ScratchSize ... ; LDSByteSize ... ; Occupancy (in this order)
   for blk in s.split('.amdhsa_kernel ')[1:]:
@@ -36,6 +47,18 @@ def table(path):
     g = lambda key: int(re.search(r'; ' + key + r': (\d+)', blk).group(1))
     rows.append((name, g('NumVgprs'), g('NumAgprs'), g('TotalNumVgprs'), g('ScratchSize'), g('Occupancy'), g('LDSByteSize')))
   return rows
+
+
+def packed_fp32_instructions(path):
+  """{kernel: count} of packed FP32 VALU instructions (v_pk_*_f32) in the gfx950 code of ``path`` -- there must be none (carla_garage_amd/_lib.py)."""
+  out, cur = {}, None
+  for line in assembly(path).split('\n'):
+    m = re.match(r'^(_Z\w+):', line)
+    if m:
+      cur = m.group(1)
+    elif cur and re.search(r'\bv_pk_\w+_f32\b', line):
+      out[cur] = out.get(cur, 0) + 1
+  return out
 
 
 def main():
