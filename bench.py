@@ -264,6 +264,63 @@ def lidar_histogram_latency(cfg, device, log, n=60000, iters=50):
   return r
 
 
+def dropin_step_time(model, cfg, batch, steps, warmup, optimizer, log, ddp=False):
+  """ms/step of the DROP-IN boundary: the module driven exactly as team_code/train.py:776-910 drives the reference's (forward with keyword
+  arguments -> model.compute_loss -> weighted sum with a host read of every loss (train.py:896) -> backward -> optimizer.step ->
+  zero_grad(set_to_none=True)), inside DistributedDataParallel when a process group exists (train.py:516-520).  ``optimizer``: 'fused' =
+  carla_garage_amd.optim.FlatAdamW (the one-line substitution of INTEGRATION.md), 'torch' = the unmodified torch.optim.AdamW(amsgrad=True)
+  of train.py:529-531.  After TFPP_DROPIN_GRAPH_AFTER eager steps the three phases replay as hipGraphs (carla_garage_amd/dropin.py)."""
+  from carla_garage_amd.losses import normalized_loss_weights
+  from carla_garage_amd.optim import FlatAdamW
+  net = model
+  if ddp:
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=None, output_device=None, broadcast_buffers=False, find_unused_parameters=False)
+  opt = (FlatAdamW if optimizer == 'fused' else torch.optim.AdamW)(net.parameters(), lr=cfg.lr, amsgrad=True)
+  w = normalized_loss_weights(cfg)
+  inp = {k: batch[k] for k in ('rgb', 'lidar_bev', 'target_point', 'ego_vel', 'command')}
+  lab = {k: v for k, v in batch.items() if k.endswith('_label')}
+  lab.setdefault('velocity_label', None)
+  lab.setdefault('brake_target_label', None)
+  dev = batch['rgb'].device
+
+  def step():
+    pred = net(**inp)
+    losses = model.compute_loss(pred_wp=pred[0], pred_target_speed=pred[1], pred_checkpoint=pred[2], pred_semantic=pred[3], pred_bev_semantic=pred[4],
+                                pred_depth=pred[5], pred_bounding_box=pred[6], pred_wp_1=pred[8], selected_path=pred[9], **lab)
+    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    detailed = 0.0
+    for key, value in losses.items():
+      loss += w[key] * value
+      detailed += float(w[key] * float(value.item()))  # train.py:896: one host sync per loss
+    loss.backward()
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    return float(loss.item())  # train.py:913
+
+  opt.zero_grad(set_to_none=False)
+  for _ in range(max(warmup, 4)):  # (>= TFPP_DROPIN_GRAPH_AFTER + 2: the timed steps are hipGraph replays)
+    last = step()
+  torch.cuda.synchronize()
+  if ddp:
+    dist.barrier()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    last = step()
+  torch.cuda.synchronize()
+  if ddp:
+    dist.barrier()
+  el = time.perf_counter() - t0
+  if ddp:
+    tm = torch.tensor([el], device=dev, dtype=torch.float64)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    el = float(tm.item())
+  plan = next(iter(model.__dict__['_dropin_step'].plans.values()))
+  r = {'ms_per_step': round(1e3 * el / steps, 3), 'final_weighted_loss': round(last, 5), 'hipgraph': plan.B1 is not None, 'optimizer': optimizer, 'ddp': bool(ddp)}
+  log(f'drop-in step ({optimizer} optimizer{", DDP" if ddp else ""}): {r}')
+  del opt, net
+  return r
+
+
 def pmc_traffic(family):
   """HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written
   by tools/pmc_traffic.sh; bench.py cannot collect PMC counters itself).  An entry records the sha of the kernel source it was
@@ -300,6 +357,7 @@ def main():
   ap.add_argument('--no-roofline', action='store_true')
   ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay of the step body')
   ap.add_argument('--no-inference', action='store_true', help='skip the bs=1 forward latency measurement')
+  ap.add_argument('--no-dropin', action='store_true', help='skip the drop-in boundary leg (module driven as team_code/train.py drives it)')
   ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel-family time table to stderr')
   ap.add_argument('--force-collectives', action='store_true',
                   help='initialise a process group and issue the gradient all-reduces even with one rank (exercises the RCCL path on one GPU)')
@@ -477,6 +535,20 @@ def main():
         tf = x['flops'] / (x['ms'] * 1e-3) / 1e12 if x['flops'] else 0.0
         print(f'{f:42s} calls/step {x["calls"] // nprof:5d}  ms/step {x["ms"] / nprof:9.3f}  {100 * x["ms"] / total_ms:5.1f}%  {tf:8.1f} TFLOP/s',
               file=sys.stderr)
+  dropin = None
+  if not args.no_dropin:
+    # the same kernels behind the boundary BASELINE.json::north_star names (LidarCenterNet.forward + train.py's loop), every rank takes part
+    try:
+      dropin = {'fused_optimizer': dropin_step_time(model, cfg, batch, args.steps, args.warmup, 'fused', log, ddp=rccl_ranks is not None)}
+      if rccl_ranks is None:
+        dropin['torch_adamw'] = dropin_step_time(model, cfg, batch, max(3, args.steps // 2), 4, 'torch', log)
+      dropin['samples_per_s'] = round(args.batch_size * world / (dropin['fused_optimizer']['ms_per_step'] * 1e-3), 1)
+      dropin['note'] = ('module driven as team_code/train.py:776-910 drives the reference (DistributedDataParallel when ranks > 1, compute_loss, '
+                        '.item() per loss, loss.backward(), optimizer.step(), zero_grad(set_to_none=True)); fused_optimizer = carla_garage_amd.optim.FlatAdamW '
+                        'in place of optim.AdamW (INTEGRATION.md), torch_adamw = the unmodified optimizer')
+    except Exception as e:  # pylint: disable=broad-except
+      log(f'drop-in leg failed: {type(e).__name__}: {e}')
+      dropin = {'error': f'{type(e).__name__}: {e}'}
   fwd = lidar_hist = swin_fwd = None
   if rank == 0 and not args.no_inference:
     fwd = inference_latency(model, cfg, device, log)
@@ -507,6 +579,8 @@ def main():
       line['video_swin_forward_bs4'] = swin_fwd
     if comm is not None:
       line['gradient_exchange'] = comm
+    if dropin is not None:
+      line['dropin'] = dropin
     if roof is not None:
       line['roofline'] = roof
       if roof_mfma is not None and roof_mfma['kernel'] != roof['kernel']:

@@ -41,28 +41,54 @@ def broadcast_state(flat_param, buffers, group=None, src=0):
     dist.broadcast(b, src, group=group)
 
 
-def all_reduce_gradients(flat_grad, group=None, chunk_elems=None):
-  """SUM all-reduce of the flat gradient arena (the average is folded into the optimizer's grad_scale = 1/world).
+def _reduce_op(avg, group=None):
+  """(op, post-scale): RCCL averages inside the collective (ReduceOp.AVG); gloo (the CPU tests) sums and the caller scales."""
+  if not avg:
+    return dist.ReduceOp.SUM, None
+  if dist.get_backend(group) == 'nccl':
+    return dist.ReduceOp.AVG, None
+  return dist.ReduceOp.SUM, 1.0 / world_size(group)
+
+
+def all_reduce_gradients(flat_grad, group=None, chunk_elems=None, avg=False):
+  """SUM all-reduce of the flat gradient arena (the average is folded into the optimizer's grad_scale = 1/world), or with ``avg`` the
+  mean (the drop-in path: torch optimizers expect averaged ``.grad`` as DistributedDataParallel leaves them, train.py:516-520).
   ``chunk_elems`` splits the arena into fewer, larger collectives than DDP's 25 MB buckets (default: one)."""
   w = world_size(group)
   if not exchange_enabled(group):
     return 1.0
+  op, post = _reduce_op(avg, group)
   if chunk_elems is None or chunk_elems >= flat_grad.numel():
-    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(flat_grad, op=op, group=group)
   else:
-    works = [dist.all_reduce(flat_grad[o:o + chunk_elems], op=dist.ReduceOp.SUM, group=group, async_op=True)
+    works = [dist.all_reduce(flat_grad[o:o + chunk_elems], op=op, group=group, async_op=True)
              for o in range(0, flat_grad.numel(), chunk_elems)]
     for wk in works:
       wk.wait()
+  if post is not None:
+    flat_grad.mul_(post)
   return 1.0 / w
 
 
-def all_reduce_async(tensor, group=None):
-  """SUM all-reduce of a slice of the gradient arena, returned as a work handle (``.wait()`` orders the current stream after
+class _ScaledWork:
+  """Work handle of an averaged all-reduce on a backend without ReduceOp.AVG: wait, then scale."""
+
+  def __init__(self, work, tensor, scale):
+    self.work, self.tensor, self.scale = work, tensor, scale
+
+  def wait(self):
+    self.work.wait()
+    self.tensor.mul_(self.scale)
+
+
+def all_reduce_async(tensor, group=None, avg=False):
+  """SUM (or mean) all-reduce of a slice of the gradient arena, returned as a work handle (``.wait()`` orders the current stream after
   it).  Used to send the part of the gradients that is finished early while the rest of backward still runs."""
   if not exchange_enabled(group) or tensor.numel() == 0:
     return None
-  return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=True)
+  op, post = _reduce_op(avg, group)
+  work = dist.all_reduce(tensor, op=op, group=group, async_op=True)
+  return work if post is None else _ScaledWork(work, tensor, post)
 
 
 def max_over_ranks(value, device, group=None):

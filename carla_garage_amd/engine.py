@@ -722,18 +722,27 @@ class Engine:
     return self._attn.setdefault((i, l), {})
 
   # ------------------------------------------------------------------------------------------------ gradients
-  def alloc_grads(self):
+  def alloc_grads(self, zero=True):
+    """(Re)create the flat gradient arena when the set of trainable parameters changed; ``zero``: start the step from a zeroed arena (every
+    gradient kernel accumulates).  The drop-in path zeroes (or keeps: gradient accumulation) the arena itself and passes zero=False."""
+    sig = tuple(id(p) for p in self.m.parameters() if p.requires_grad)
+    if self.flat_grad is not None and sig == getattr(self, '_grad_sig', None) and self.flat_grad.device == self.device:
+      if zero:
+        ops.zero_(self.flat_grad)
+        ops.clear_stats_rows(self.device)
+      return
+    self._grad_sig = sig
     params, self.early_offset = arena_order(self.m)
     total = sum(ops.pad_to(p.numel(), 4) for _, p in params)
     if self.flat_grad is None or self.flat_grad.numel() != total or self.flat_grad.device != self.device:
       self.flat_grad = torch.empty(total, device=self.device, dtype=F32)
-      self.grads = {}
-      off = 0
-      for n, p in params:
-        self.grads[n] = self.flat_grad[off:off + p.numel()].view(p.shape)
-        off += ops.pad_to(p.numel(), 4)
-      self._gid = {id(p): n for n, p in params}
-    ops.zero_(self.flat_grad)
+    self.grads = {}
+    off = 0
+    for n, p in params:
+      self.grads[n] = self.flat_grad[off:off + p.numel()].view(p.shape)
+      off += ops.pad_to(p.numel(), 4)
+    self._gid = {id(p): n for n, p in params}
+    ops.zero_(self.flat_grad)  # (a new arena always starts from zero)
     ops.clear_stats_rows(self.device)  # the fused BatchNorm statistics start every step from zeroed rows, whatever happened before
 
   def g(self, param):
@@ -1135,8 +1144,10 @@ class Engine:
     def gb_qkv(dz):
       tmp = ops.zeros(npk, F32, dz.device)
       ops.colsum(dz, tmp, B * T, npk, npk)
+      un = torch.empty(3 * C, device=dz.device, dtype=F32)
       for j, lin in enumerate((blk.attn.query, blk.attn.key, blk.attn.value)):
-        ops.pack2d(tmp[j * nh * dp:], self.g(lin.bias), 1, C, nh * dp, C, col_map=st['inv'])
+        ops.pack2d(tmp[j * nh * dp:], un[j * C:], 1, C, nh * dp, C, col_map=st['inv'])
+        ops.copy_rows(un[j * C:], self.g(lin.bias), 1, C, 0, 0, 0, 0, accumulate=True)  # every gradient kernel ADDS to the arena (gradient accumulation)
 
     qkv = self.raw_linear(h.view(B * T, C), st['wqkv'], st['bqkv'], st.get('wqkv_t'), gw_qkv, gb_qkv, npk, C)
     q, k, v = qkv.view(-1)[0:], qkv.view(-1)[nh * dp:], qkv.view(-1)[2 * nh * dp:]

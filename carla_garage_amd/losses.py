@@ -139,12 +139,13 @@ def fused_losses(model, t, labels, weights=None, want_grad=True):
 
 
 class _LossNode(torch.autograd.Function):
-  """0-d loss connected to the caller-facing prediction tensor; backward returns dLoss/dpred in the caller layout."""
+  """0-d loss connected to the caller-facing prediction tensor; backward returns dLoss/dpred in the caller layout.  (General path: the
+  predictions handed to compute_loss are not the ones the last training forward returned; dropin.py has the fast one.)"""
 
   @staticmethod
   def forward(ctx, pred_caller, value, to_caller_grad):
     ctx.to_caller_grad = to_caller_grad
-    return value.clone()
+    return value.detach()
 
   @staticmethod
   def backward(ctx, g):
@@ -159,12 +160,44 @@ def _scale_by_device_scalar(x, g):
   return ops.affine_act(x.reshape(-1, ld), scale=v).view(x.shape)
 
 
+def _internal_from_callers(model, args):
+  """The engine's internal prediction tensors (NHWC, channel-padded, compute dtype) rebuilt from caller-facing ones (fp32 NCHW): lets
+  compute_loss evaluate predictions that are NOT the outputs of the last forward (kept from an earlier step, cloned, post-processed),
+  as the reference's compute_loss can (team_code/model.py:394-445)."""
+  cfg, dt_ = model.config, model.compute_dtype
+  t = dict(pred_wp=None, pred_target_speed=None, pred_checkpoint=None, pred_semantic=None, pred_bev_semantic=None, pred_depth=None, bb=None)
+
+  def dense(x, pad):
+    x = x.detach().float().contiguous()
+    if x.dim() == 3:
+      x = x.unsqueeze(1)
+    return ops.nchw_to_nhwc_pad(x, dt_, ops.pad_to(x.shape[1], pad))
+
+  if args.get('pred_wp') is not None:
+    t['pred_wp'] = args['pred_wp'].detach().float().contiguous()
+  if args.get('pred_target_speed') is not None:
+    ts = args['pred_target_speed'].detach().float().contiguous()
+    pad = ops.zeros((ts.shape[0], ops.pad_to(ts.shape[1], 8)), F32, ts.device)
+    ops.copy_rows(ts, pad, ts.shape[0], ts.shape[1], ts.shape[1], 0, pad.shape[1], 0)
+    t['pred_target_speed'] = pad
+    t['pred_checkpoint'] = args['pred_checkpoint'].detach().float().contiguous()
+  if args.get('pred_semantic') is not None:
+    t['pred_semantic'] = dense(args['pred_semantic'], 8)
+  if args.get('pred_bev_semantic') is not None:
+    t['pred_bev_semantic'] = dense(args['pred_bev_semantic'], 8)
+  if args.get('pred_depth') is not None:
+    t['pred_depth'] = dense(args['pred_depth'], 8)
+  if cfg.detect_boxes and args.get('pred_bounding_box') is not None:
+    t['bb'] = [dense(b, 8) for b in args['pred_bounding_box'][:7 if temporal(cfg) else 5]]
+  t['fused_features'] = next(v for v in (t['pred_checkpoint'], t['pred_wp'], t['pred_semantic']) if v is not None)  # (device carrier for fused_losses)
+  return t
+
+
 def reference_form_losses(model, args):
-  """Drop-in ``compute_loss``: the predictions must be the tensors returned by the last ``forward`` (as in
-  team_code/train.py:776-820); the losses are evaluated by the fused HIP kernels on the internal tensors."""
-  t = model.__dict__.get('_last_internal')
-  if t is None:
-    raise RuntimeError('compute_loss must follow forward() of the same model (no stand-alone PyTorch loss path)')
+  """Drop-in ``compute_loss`` (team_code/model.py:394-445; called at team_code/train.py:784-820): the losses are evaluated by the fused HIP
+  kernels.  Fast path: the predictions are the outputs of the last training forward (dropin.DropinStep.losses: internal tensors, token
+  gradients, hipGraph replay).  General path: any other caller-facing predictions are converted to the internal layout first and the
+  gradients take the caller layout on their way back through autograd."""
   cfg = model.config
   label_keys = ('waypoint_label', 'target_speed_label', 'checkpoint_label', 'semantic_label', 'bev_semantic_label', 'depth_label',
                 'center_heatmap_label', 'wh_label', 'yaw_class_label', 'yaw_res_label', 'offset_label', 'velocity_label',
@@ -175,14 +208,14 @@ def reference_form_losses(model, args):
   if cfg.detect_boxes:
     for i, n in enumerate(BB_LOSSES[:7 if temporal(cfg) else 5]):
       callers[n] = args['pred_bounding_box'][i]
-  # the fused kernels read the internal (NHWC) tensors of the last forward: refuse predictions that are not the tensors that
-  # forward returned (a second forward in between, post-processed / re-ordered predictions) instead of silently using others
+  step = model.__dict__.get('_dropin_step')
+  if step is not None and step.owns(callers):
+    return step.losses(callers, labels)
   mine = model.__dict__.get('_last_output_ptrs', set())
-  for n, c in callers.items():
-    if c is not None and c.data_ptr() not in mine:
-      raise RuntimeError(f'compute_loss: the prediction passed for {n} is not an output of the last forward() of this model '
-                         '(the MI355X path evaluates the losses on that call\'s internal tensors)')
-  want_grad = torch.is_grad_enabled()
+  t = model.__dict__.get('_last_internal')
+  if t is None or any(c is not None and c.data_ptr() not in mine for c in callers.values()):
+    t = _internal_from_callers(model, args)  # not (all) outputs of the last forward
+  want_grad = torch.is_grad_enabled() and any(c is not None and c.requires_grad for c in callers.values())
   names, vals, seeds = fused_losses(model, t, labels, None, want_grad)
   out = {}
   for i, n in enumerate(names):
@@ -203,5 +236,5 @@ def reference_form_losses(model, args):
 
       out[n] = _LossNode.apply(caller, vals[i], to_caller)
     else:
-      out[n] = vals[i].clone()
+      out[n] = vals[i].detach()
   return out

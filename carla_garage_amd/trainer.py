@@ -75,13 +75,20 @@ class Trainer:
       self.exp_avg_sq = ops.zeros(self.flat_param.shape, F32, dev)
       self.max_exp_avg_sq = ops.zeros(self.flat_param.shape, F32, dev)
 
-  def arena_intact(self):
+  def arena_intact(self, quick=False):
     """True while every trainable parameter still lives at its place in flat_param (model.cuda() / .to() / .half() after the flattening
     re-allocate the parameters; the owner then has to flatten again)."""
     if self.detached:
       return False
     base = self.flat_param.data_ptr()
-    return all(p.data_ptr() == base + 4 * off for _, off, p in self._arena_slices())
+    sl = self._slices_cached()
+    probe = sl if not quick else [sl[0], sl[len(sl) // 2], sl[-1]]
+    return all(p.data_ptr() == base + 4 * off for _, off, p in probe)
+
+  def _slices_cached(self):
+    if getattr(self, '_slices', None) is None:
+      self._slices = self._arena_slices()
+    return self._slices
 
   # ---------------------------------------------------------------------------------------------- one step
   def _step_part1(self, batch, split=True):
@@ -113,11 +120,12 @@ class Trainer:
     self._tape = None
     return vals
 
-  def _optimizer(self, step):
+  def _optimizer(self, step, grad_scale=None):
+    """grad_scale: None = 1 / world (the arena holds the SUM over the ranks); the drop-in path passes 1.0 (already averaged)."""
     self._alloc_state()
     self.eng.invalidate()
     ops.adamw_amsgrad(self.flat_param, self.eng.flat_grad, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, self.lr, self.betas[0],
-                      self.betas[1], self.eps, self.weight_decay, step, grad_scale=1.0 / self.world)
+                      self.betas[1], self.eps, self.weight_decay, step, grad_scale=1.0 / self.world if grad_scale is None else grad_scale)
 
   def train_step(self, batch):
     """batch: dict with rgb, lidar_bev, target_point, ego_vel, command and the *_label tensors (reference layouts).
@@ -137,12 +145,12 @@ class Trainer:
   def overlap_enabled(self):
     return (self.exchange and tdist.exchange_enabled(self.pg)) or os.environ.get('TFPP_SPLIT_STEP', '0') == '1'
 
-  def reduce_early(self):
+  def reduce_early(self, avg=False):
     """Asynchronous all-reduce of flat_grad[early_offset:] (RCCL runs it on its own stream, ordered after what this stream has
     issued so far).  Returns the handle finish_step() waits on, or None when there is nothing to overlap."""
     if not self.exchange:
       return None
-    return tdist.all_reduce_async(self.eng.flat_grad[self.eng.early_offset:], self.pg)
+    return tdist.all_reduce_async(self.eng.flat_grad[self.eng.early_offset:], self.pg, avg=avg)
 
   def finish_step(self, early=None):
     """rest of the gradient exchange + optimizer (kept outside any captured graph)."""

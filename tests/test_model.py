@@ -612,11 +612,13 @@ def test_dropin_autograd_path_matches_engine_path():
     worst_el = max(worst_el, float(np.max(np.abs(got - samples[:len(idx)]) / (norm / np.sqrt(mine.numel()) + np.abs(samples[:len(idx)])))))
   _report('dropin', {'worst_grad_norm': worst, 'worst_grad_elem': worst_el})
   assert worst <= GRAD_NORM_TOL and worst_el <= GRAD_ELEM_TOL
-  # compute_loss evaluates the losses on the internal tensors of the last forward: predictions that are not that call's outputs
-  # (here: a clone) are refused instead of silently producing the losses of other tensors
-  with pytest.raises(RuntimeError):
-    m.compute_loss(pred_wp=out[0], pred_target_speed=out[1].clone(), pred_checkpoint=out[2], pred_semantic=out[3],
-                   pred_bev_semantic=out[4], pred_depth=out[5], pred_bounding_box=out[6], pred_wp_1=out[8], selected_path=out[9], **lab)
+  # predictions that are not the last forward's outputs (here: one clone) take compute_loss's general path (converted to the internal
+  # layout) and give the same losses (tests/test_dropin_gpu.py covers gradients, accumulation, DDP and the hipGraph replays)
+  with torch.no_grad():
+    again = m.compute_loss(pred_wp=out[0], pred_target_speed=out[1].clone(), pred_checkpoint=out[2], pred_semantic=out[3],
+                           pred_bev_semantic=out[4], pred_depth=out[5], pred_bounding_box=out[6], pred_wp_1=out[8], selected_path=out[9], **lab)
+  for k in losses:
+    np.testing.assert_allclose(float(again[k]), float(losses[k]), rtol=2e-5, err_msg=k)
 
 
 @pytest.mark.gpu
