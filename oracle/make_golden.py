@@ -17,6 +17,7 @@ Files written
                            oracle.make_golden bs12` writes only this file
   tfpp_aim.npz             BASELINE config 1: image-only AIM backbone, eval forward bs=1 + train step bs=2 (`... make_golden aim`)
   tfpp_wp_eval_bs1.npz     WP variant (use_wp_gru=1, use_controller_input_prediction=0): pred_wp
+  tfpp_wp_train_bs2.npz    the same variant, one train-mode step at bs = 2 (`python -m oracle.make_golden wp_train`): loss_wp + gradients
 """
 import json
 import os
@@ -204,6 +205,16 @@ def write_temporal_golden():
   write_train_golden(model, cfg, 2, 'tfpp_train_temporal_bs2.npz')
 
 
+def write_wp_train_golden():
+  """The waypoint variant (use_wp_gru=1, use_controller_input_prediction=0; model.py:165-171,333-334,399-404): wp_query (1, 8, 256), the
+  8-step GRU decoder and loss_wp -- one train-mode step at bs = 2 on the unmodified reference."""
+  import dataclasses
+  model, _ = ref_harness.build_reference_model(use_wp_gru=True, use_controller_input_prediction=False)
+  cfg = dataclasses.replace(P.PortConfig(), use_wp_gru=True, use_controller_input_prediction=False)
+  model.load_state_dict(P.make_state_dict(cfg), strict=True)
+  write_train_golden(model, cfg, 2, 'tfpp_wp_train_bs2.npz')
+
+
 def write_train_golden(model, cfg, bs, fname):
   """One train-mode step of the reference at batch size ``bs`` (dropout 0, batch-statistic BN): the 10 losses, per-parameter
   gradient norms + sampled gradient values, the BN running-statistic sums after the step and the small forward outputs."""
@@ -261,6 +272,9 @@ def main():
     return
   if only == {'temporal'}:
     write_temporal_golden()
+    return
+  if only == {'wp_train'}:
+    write_wp_train_golden()
     return
 
   # ---- default TF++ ---------------------------------------------------------------------------

@@ -434,6 +434,19 @@ def test_temporal_lidar_train_step_fp32_vs_reference_golden():
                               port_cfg=dataclasses.replace(P.PortConfig(), lidar_seq_len=6))
 
 
+@pytest.mark.gpu
+def test_wp_variant_train_step_fp32_vs_reference_golden():
+  """The waypoint variant trained (VERDICT r2 missing #5): wp_query, the 8-step GRU decoder and loss_wp (model.py:165-171,333-334,399-404) --
+  losses, per-parameter gradient norms / sampled elements and BN statistics of one step against the unmodified reference
+  (tests/golden/tfpp_wp_train_bs2.npz, `python -m oracle.make_golden wp_train`)."""
+  cfgw = dataclasses.replace(P.PortConfig(), use_wp_gru=True, use_controller_input_prediction=False)
+  m = LidarCenterNet(GlobalConfig(use_wp_gru=True, use_controller_input_prediction=False))
+  m.load_state_dict(P.make_state_dict(cfgw), strict=True)
+  g = U.load_golden('tfpp_wp_train_bs2.npz')
+  assert 'loss_wp' in [str(x) for x in g['loss_names']] and 'wp_decoder.gru.weight_hh_l0' in [str(x) for x in g['grad_names']]
+  _check_train_step_vs_golden(2, 'tfpp_wp_train_bs2.npz', 'train_fp32_wp', model=m.cuda(), port_cfg=cfgw)
+
+
 BF16_LOSS_TOL = 5e-2  # measured worst: loss_yaw_res 2.2e-2 (a loss of ~1e-2 absolute, i.e. 2e-4 absolute error), every other loss <= 4.5e-3
 # measured worst gradient-norm deviations (568 tensors): SE fc1 / attention query-key 0.16-0.33 (their fp32 gradients are differences of
 # nearly cancelling terms: the softmax / sigmoid-gate Jacobians), everything else <= 0.155

@@ -18,7 +18,9 @@ else -- no line of the reference is edited or copied:
     no-op;
   * ``--mi355x``: the one-line swap of INTEGRATION.md -- ``model.LidarCenterNet`` is replaced by ``carla_garage_amd.model.LidarCenterNet``
     before train.py executes ``from model import LidarCenterNet`` (train.py:32).  Everything else (argparse -> GlobalConfig, DDP wrap,
-    ZeroRedundancyOptimizer / AdamW, schedulers, the epoch loop, checkpoint files) is the reference's code.
+    ZeroRedundancyOptimizer / AdamW, schedulers, the epoch loop, checkpoint files) is the reference's code;
+  * ``--fused-optimizer``: the optional second substitution of INTEGRATION.md -- ``optim.AdamW`` / ``ZeroRedundancyOptimizer`` (train.py:527-531)
+    resolve to ``carla_garage_amd.optim.FlatAdamW`` (bench.py 'dropin': 31.1 instead of 34.3 ms/step).
 """
 import argparse
 import os
@@ -193,6 +195,7 @@ def main():
   ap.add_argument('--reference', default='/root/reference', help='checkout of autonomousvision/carla_garage')
   ap.add_argument('--cpu', action='store_true', help='BASELINE config 1: run on the CPU over gloo')
   ap.add_argument('--mi355x', action='store_true', help='swap in carla_garage_amd.model.LidarCenterNet (INTEGRATION.md)')
+  ap.add_argument('--fused-optimizer', action='store_true', help='substitute carla_garage_amd.optim.FlatAdamW for optim.AdamW / ZeroRedundancyOptimizer')
   ap.add_argument('--synthetic', type=int, default=0, help='serve N synthetic frames instead of a dataset')
   args, rest = ap.parse_known_args()
   if rest and rest[0] == '--':
@@ -219,6 +222,16 @@ def main():
     from carla_garage_amd.model import LidarCenterNet
     ref_model.LidarCenterNet = LidarCenterNet
     print('[shim] model.LidarCenterNet -> carla_garage_amd.model.LidarCenterNet', flush=True)
+  if args.fused_optimizer:
+    # the second line of INTEGRATION.md: train.py:527-531 builds optim.AdamW(params, lr, amsgrad=True), optionally inside
+    # ZeroRedundancyOptimizer; both names resolve to carla_garage_amd.optim.FlatAdamW (one fused launch over the flat arenas; ZeRO-1
+    # sharding of 1.9 GB of state is pointless at 288 GB per GPU)
+    import torch.optim
+    import torch.distributed.optim as tdo
+    from carla_garage_amd.optim import FlatAdamW
+    torch.optim.AdamW = FlatAdamW
+    tdo.ZeroRedundancyOptimizer = lambda params, optimizer_class=None, **kw: FlatAdamW(params, **kw)
+    print('[shim] optim.AdamW / ZeroRedundancyOptimizer -> carla_garage_amd.optim.FlatAdamW', flush=True)
   if args.cpu:
     _cpu_torch_proxy()
   sys.argv = [os.path.join(team_code, 'train.py')] + rest
