@@ -184,6 +184,47 @@ extern "C" int tfpp_nchw_to_nhwc_affine(const float* in, void* out, const float*
   return 0;
 }
 
+// The camera frame as the caller holds it: uint8, either HWC (what cv2.imdecode returns, sensor_agent.py:277-286: BGR, swap = 1 turns it into
+// the RGB order the network was trained on) or CHW (the collated loader batch before train.py:750's .to(float32)).  Fused: channel swap +
+// uint8 -> float + normalize_imagenet + NHWC + zero channel padding -- the host no longer transposes or widens, the upload is 4x smaller.
+template <typename T, bool HWC>
+__global__ void u8_to_nhwc_affine_kernel(const unsigned char* __restrict__ in, T* __restrict__ out, const float* __restrict__ mul,
+                                         const float* __restrict__ add, int B, int C, int HW, int cpad, int swap) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one pixel
+  if (i >= (long)B * HW) return;
+  const int b = (int)(i / HW), pix = (int)(i - (long)b * HW);
+  T* o = out + (size_t)i * cpad;
+  for (int c0 = 0; c0 < cpad; c0 += ElemTraits<T>::VEC) {
+    float v[ElemTraits<T>::VEC];
+#pragma unroll
+    for (int e = 0; e < ElemTraits<T>::VEC; ++e) {
+      const int c = c0 + e;
+      float x = 0.f;
+      if (c < C) {
+        const int cs = swap ? C - 1 - c : c;  // source channel
+        x = (float)(HWC ? in[(size_t)i * C + cs] : in[((size_t)b * C + cs) * HW + pix]);
+        if (mul) x = x * mul[c] + add[c];
+      }
+      v[e] = x;
+    }
+    store_vec<T>(o + c0, v);
+  }
+}
+
+extern "C" int tfpp_u8_to_nhwc_affine(const uint8_t* in, void* out, const float* mul, const float* add, int B, int C, int H, int W, int cpad,
+                                      int hwc, int swap, int dtype, void* stream) {
+  if (!in || !out || cpad < C || C < 1) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)B * H * W;
+  if (cpad % (dtype == TFPP_F32 ? 4 : 8)) return TFPP_EINVAL;
+#define U8_LAUNCH(TT, L) hipLaunchKernelGGL((u8_to_nhwc_affine_kernel<TT, L>), grid1d(n), dim3(PW_THREADS), 0, st, in, (TT*)out, mul, add, B, C, H * W, cpad, swap)
+  if (dtype == TFPP_F32) { if (hwc) U8_LAUNCH(float, true); else U8_LAUNCH(float, false); }
+  else { if (hwc) U8_LAUNCH(bf16_t, true); else U8_LAUNCH(bf16_t, false); }
+#undef U8_LAUNCH
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int B, int C, int HW, long in_ld, int act) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1290,12 +1290,16 @@ class Engine:
     if self.tape is not None:
       self.tape.on_accumulate = lambda key: self._bn_pre.pop(key, None)  # a "complete" gradient got another addend: sums are stale
     self.lanes.begin(dev)
+    mul = add = None
     if cfg.normalize_imagenet:
       mul = self._const('img_mul', lambda: torch.tensor([1.0 / (255.0 * s) for s in (0.229, 0.224, 0.225)]))
       add = self._const('img_add', lambda: torch.tensor([-mu / s for mu, s in ((0.485, 0.229), (0.456, 0.224), (0.406, 0.225))]))
-      xi = ops.nchw_to_nhwc_affine(rgb.float().contiguous(), dt_, 8, mul, add)
+    if rgb.dtype == torch.uint8:
+      # the frame as the caller holds it: [B,H,W,3] = cv2's HWC BGR (sensor_agent.py:277-286 after imdecode), [B,3,H,W] = the loader's RGB CHW
+      hwc = rgb.shape[-1] == 3 and rgb.shape[1] != 3
+      xi = ops.u8_to_nhwc_affine(rgb.contiguous(), dt_, 8, mul, add, hwc=hwc, swap=hwc)
     else:
-      xi = ops.nchw_to_nhwc_affine(rgb.float().contiguous(), dt_, 8)
+      xi = ops.nchw_to_nhwc_affine(rgb.float().contiguous(), dt_, 8, mul, add)
     lanes = self.lanes
     if self.aim:  # team_code/aim.py:32-61: the image branch alone; fused_features = the stage-4 feature grid
       xi = self.conv(xi, 'backbone.image_encoder.stem', act=ACT_RELU, x_grad=False)

@@ -335,6 +335,16 @@ def nchw_to_nhwc_affine(x, dtype, cpad, mul=None, add=None):
   return out
 
 
+def u8_to_nhwc_affine(x, dtype, cpad, mul=None, add=None, hwc=None, swap=False):
+  """uint8 camera frames -> normalised NHWC (tfpp_u8_to_nhwc_affine); x: [B,H,W,C] (hwc) or [B,C,H,W]."""
+  if hwc is None:
+    hwc = x.shape[-1] <= 4
+  b, (c, h, w) = x.shape[0], ((x.shape[3], x.shape[1], x.shape[2]) if hwc else x.shape[1:])
+  out = torch.empty((b, h, w, cpad), device=x.device, dtype=dtype)
+  lib.tfpp_u8_to_nhwc_affine(ptr(_chk(x)), ptr(out), ptr(mul), ptr(add), b, c, h, w, cpad, int(hwc), int(swap), dt(out), stream())
+  return out
+
+
 def nhwc_to_nchw(x, c_real, act=ACT_NONE):
   b, h, w, ld = x.shape
   out = torch.empty((b, c_real, h, w), device=x.device, dtype=torch.float32)

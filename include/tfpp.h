@@ -255,6 +255,11 @@ int tfpp_centernet_targets(const double* boxes, const int32_t* counts, float* he
  * model.py:379); nchw_to_nhwc_pad brings the caller's NCHW output-gradients back (padding channels zero). */
 int tfpp_nchw_to_nhwc_affine(const float* in, void* out, const float* mul, const float* add, int B, int C, int H, int W, int cpad,
                              int dtype, void* stream);
+/* the same from the camera frame as the caller holds it (sensor_agent.py:277-286 after cv2.imdecode; train.py:750 before .to(float32)):
+ * uint8, hwc = 1: [B,H,W,C] / hwc = 0: [B,C,H,W]; swap = 1 reverses the channel order (BGR -> RGB):
+ * out[b,h,w,c] = c<C ? float(in[.., swap ? C-1-c : c]) * mul[c] + add[c] : 0. */
+int tfpp_u8_to_nhwc_affine(const uint8_t* in, void* out, const float* mul, const float* add, int B, int C, int H, int W, int cpad, int hwc,
+                           int swap, int dtype, void* stream);
 int tfpp_nhwc_to_nchw(const void* in, float* out, int B, int C, int H, int W, int64_t in_ld, int act, int dtype, void* stream);
 int tfpp_nchw_to_nhwc_pad(const float* in, void* out, int B, int C, int H, int W, int64_t out_ld, int dtype, void* stream);
 

@@ -1077,3 +1077,39 @@ def test_zero_and_fill_bytes_are_kernels_with_exact_extent(ops):
   big = torch.full((50_000_019,), 1.0, device=DEV)
   ops.zero_(big[3:-4])
   assert float(big.sum()) == 7.0 and float(big[:3].sum()) == 3.0
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_uint8_camera_frame_input_equals_the_float_path(ops, dtype):
+  """tfpp_u8_to_nhwc_affine: the frame as sensor_agent.py:277-286 holds it after cv2.imdecode (uint8, HWC, BGR) and as the loader collates it
+  (uint8, CHW, RGB) must give bit-for-bit the tensor the fp32 NCHW RGB path gives (same arithmetic on the same values)."""
+  g = torch.Generator().manual_seed(5)
+  bgr = torch.randint(0, 256, (2, 16, 40, 3), generator=g, dtype=torch.uint8)           # cv2 frame(s)
+  rgb_chw = bgr.flip(-1).permute(0, 3, 1, 2).contiguous()                                # cvtColor(BGR2RGB) + transpose(2, 0, 1)
+  mul = torch.tensor([1.0 / (255.0 * s) for s in (0.229, 0.224, 0.225)])
+  add = torch.tensor([-mu / s for mu, s in ((0.485, 0.229), (0.456, 0.224), (0.406, 0.225))])
+  want = ops.nchw_to_nhwc_affine(rgb_chw.float().to(DEV), dtype, 8, mul.to(DEV), add.to(DEV))
+  a = ops.u8_to_nhwc_affine(bgr.to(DEV), dtype, 8, mul.to(DEV), add.to(DEV), hwc=True, swap=True)
+  b = ops.u8_to_nhwc_affine(rgb_chw.to(DEV), dtype, 8, mul.to(DEV), add.to(DEV), hwc=False, swap=False)
+  assert torch.equal(a, want) and torch.equal(b, want)
+  assert float(a[..., 3:].abs().max()) == 0.0
+
+
+def test_model_forward_accepts_the_uint8_camera_frame(ops):
+  """LidarCenterNet.forward(rgb=<uint8 HWC BGR frame>) == forward(rgb=<float32 NCHW RGB>) (the sensor_agent.py tick without host-side colour
+  conversion, transposition and float widening)."""
+  from carla_garage_amd.config import GlobalConfig
+  from carla_garage_amd.model import LidarCenterNet
+  from oracle import tfpp_port as P
+  m = LidarCenterNet(GlobalConfig())
+  m.load_state_dict(P.make_state_dict(), strict=True)
+  m.cuda().eval()
+  inp = [x.cuda() for x in P.make_inputs(1)]
+  rgb = inp[0].round().clamp(0, 255)
+  frame_bgr = rgb.to(torch.uint8).permute(0, 2, 3, 1).flip(-1).contiguous()
+  with torch.inference_mode():
+    want = m(rgb, *inp[1:])
+    got = m(frame_bgr, *inp[1:])
+    got_chw = m(rgb.to(torch.uint8), *inp[1:])
+  for a, b, c in zip((want[1], want[2], want[6][0], want[3]), (got[1], got[2], got[6][0], got[3]), (got_chw[1], got_chw[2], got_chw[6][0], got_chw[3])):
+    assert torch.equal(a, b) and torch.equal(a, c)

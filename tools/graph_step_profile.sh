@@ -5,7 +5,7 @@ set -e
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-inference --no-roofline > $REPO/gpurun_out/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-inference --no-roofline --no-dropin > $REPO/gpurun_out/prof_bench.log 2>&1
 t=$(find /tmp/prof -name "*kernel_trace.csv" | head -1)
 python - "$t" "$REPO/gpurun_out/graph_step_kernels.txt" <<'PY'
 import csv, sys, collections
