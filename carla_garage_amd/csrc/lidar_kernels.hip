@@ -299,3 +299,153 @@ extern "C" int tfpp_centernet_targets(const double* boxes, const int32_t* counts
   TFPP_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rotated-box IoU + greedy non-maximum suppression on the device (replaces the shapely polygons and the
+// numpy loop of team_code/transfuser_utils.py:409-450, called from sensor_agent.py:491 on the boxes of every model of the ensemble).
+// One workgroup: corners in float64 (rect_polygon: half extents, rotation about the centre, translation), boxes ranked by confidence
+// (descending; equal confidences: higher index first = the order in which the reference pops a stably sorted list), then the greedy loop:
+// the most confident box still alive is kept and every thread clips it against one or two of the remaining boxes (Sutherland-Hodgman in
+// float64, work polygons in LDS) and clears those whose IoU exceeds the threshold.  keep: indices of the kept boxes, most confident first.
+// ---------------------------------------------------------------------------------------------------------------
+#define NMS_THREADS 256
+#define NMS_MAX_BOXES 1024
+
+namespace {
+struct NmsPoly { double x[8], y[8]; };
+
+__device__ __forceinline__ double nms_area2(const double* x, const double* y, int n) {
+#pragma clang fp contract(off)
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const int j = (i + 1 == n) ? 0 : i + 1;
+    s += x[i] * y[j] - y[i] * x[j];
+  }
+  return s;
+}
+
+// corners of box a in (ax, ay), of box b in (bx, by) (any orientation); w0 / w1: two work polygons of this thread in LDS
+__device__ double nms_iou(const double* ax, const double* ay, const double* bx, const double* by, NmsPoly* w0, NmsPoly* w1) {
+#pragma clang fp contract(off)
+  const double sa = nms_area2(ax, ay, 4), sb = nms_area2(bx, by, 4);
+  int n = 4;
+  for (int i = 0; i < 4; ++i) { w0->x[i] = ax[i]; w0->y[i] = ay[i]; }
+  NmsPoly* in = w0;
+  NmsPoly* out = w1;
+  for (int e = 0; e < 4 && n > 0; ++e) {
+    // clip edge e of b, walked counter-clockwise (a negative half extent flips the ring of rect_polygon)
+    const int i0 = sb >= 0.0 ? e : 3 - e, i1 = sb >= 0.0 ? (e + 1) & 3 : (3 - e + 3) & 3;
+    const double px = bx[i0], py = by[i0], ex = bx[i1] - px, ey = by[i1] - py;
+    int m = 0;
+    for (int j = 0; j < n; ++j) {
+      const int jp = j == 0 ? n - 1 : j - 1;
+      const double cx = in->x[j], cy = in->y[j], qx = in->x[jp], qy = in->y[jp];
+      const double sc = ex * (cy - py) - ey * (cx - px), sp = ex * (qy - py) - ey * (qx - px);
+      if (sc >= 0.0) {
+        if (sp < 0.0) {
+          const double t = sp / (sp - sc);
+          out->x[m] = qx + t * (cx - qx); out->y[m] = qy + t * (cy - qy); ++m;
+        }
+        out->x[m] = cx; out->y[m] = cy; ++m;
+      } else if (sp >= 0.0) {
+        const double t = sp / (sp - sc);
+        out->x[m] = qx + t * (cx - qx); out->y[m] = qy + t * (cy - qy); ++m;
+      }
+    }
+    n = m;
+    NmsPoly* tmp = in; in = out; out = tmp;
+  }
+  const double inter = n >= 3 ? 0.5 * fabs(nms_area2(in->x, in->y, n)) : 0.0;
+  const double uni = 0.5 * fabs(sa) + 0.5 * fabs(sb) - inter;
+  return uni > 0.0 ? inter / uni : 0.0;
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_rotated_kernel(const float* __restrict__ boxes, int n, int stride, int conf_idx, double thr,
+                                                                  float min_conf, int* __restrict__ keep, int* __restrict__ count,
+                                                                  double* __restrict__ iou_out) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
+  NmsPoly* work = reinterpret_cast<NmsPoly*>(nms_smem);                        // [2 * NMS_THREADS]
+  double* cx = reinterpret_cast<double*>(work + 2 * NMS_THREADS);               // [n][4]
+  double* cy = cx + (size_t)n * 4;                                              // [n][4]
+  float* conf = reinterpret_cast<float*>(cy + (size_t)n * 4);                   // [n]
+  int* order = reinterpret_cast<int*>(conf + n);                                // [n]
+  int* alive = order + n;                                                       // [n]
+  __shared__ int kept;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += NMS_THREADS) {
+    const float* b = boxes + (size_t)i * stride;
+    const double x = b[0], y = b[1], w = b[2], h = b[3], a = b[4];
+    const double c = cos(a), s = sin(a);
+    const double lx[4] = {-w, w, w, -w}, ly[4] = {-h, -h, h, h};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cx[i * 4 + k] = c * lx[k] - s * ly[k] + x; cy[i * 4 + k] = s * lx[k] + c * ly[k] + y; }
+    conf[i] = b[conf_idx];
+    alive[i] = b[conf_idx] > min_conf;  // (model.py:451: boxes at or below the confidence threshold never enter the suppression)
+  }
+  if (tid == 0) kept = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += NMS_THREADS) {  // rank = number of boxes that go before box i
+    const float ci = conf[i];
+    int r = 0;
+    for (int j = 0; j < n; ++j) r += (conf[j] > ci) || (conf[j] == ci && j > i);
+    order[r] = i;
+  }
+  __syncthreads();
+  if (iou_out)  // debugging / tests: the whole IoU matrix
+    for (int p = tid; p < n * n; p += NMS_THREADS) {
+      const int i = p / n, j = p - i * n;
+      iou_out[p] = i == j ? 1.0 : nms_iou(cx + i * 4, cy + i * 4, cx + j * 4, cy + j * 4, work + 2 * tid, work + 2 * tid + 1);
+    }
+  for (int p = 0; p < n; ++p) {
+    const int i = order[p];
+    if (alive[i]) {  // (uniform: alive[] only changes between the barriers)
+      if (tid == 0) keep[kept++] = i;
+      for (int q = p + 1 + tid; q < n; q += NMS_THREADS) {
+        const int j = order[q];
+        if (alive[j] && nms_iou(cx + i * 4, cy + i * 4, cx + j * 4, cy + j * 4, work + 2 * tid, work + 2 * tid + 1) > thr) alive[j] = 0;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *count = kept;
+}
+}  // namespace
+
+// (B, k, 9) decoded boxes in image pixels -> vehicle coordinates in metres (model.py:447-459 + transfuser_utils.py:388-406): yaw negated,
+// origin moved to the ego pixel, axes swapped (image: y front / x right; CARLA: x front / y right), extents swapped, pixels -> metres.
+__global__ void bb_image_to_metric_kernel(const float* __restrict__ in, float* __restrict__ out, int n, float ppm, float min_x, float min_y) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* b = in + (size_t)i * 9;
+  float* o = out + (size_t)i * 9;
+  // box[:2] - np.array([-(min_x * ppm), -(min_y * ppm)]): float32 box, float64 constants -> float64 difference, stored as float32
+  const float x = (float)((double)b[0] - (-((double)min_x * (double)ppm)));
+  const float y = (float)((double)b[1] - (-((double)min_y * (double)ppm)));
+  o[0] = y / ppm; o[1] = x / ppm; o[2] = b[3] / ppm; o[3] = b[2] / ppm;
+  o[4] = -b[4];
+  o[5] = b[5]; o[6] = b[6]; o[7] = b[7]; o[8] = b[8];
+}
+
+extern "C" int tfpp_bb_image_to_metric(const float* boxes, float* out, int n, float pixels_per_meter, float min_x, float min_y, void* stream) {
+  if (!boxes || !out || n < 0) return TFPP_EINVAL;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(bb_image_to_metric_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream, boxes, out, n, pixels_per_meter, min_x, min_y);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tfpp_nms_rotated(const float* boxes, int n, int stride, int conf_idx, double iou_threshold, float min_conf, int32_t* keep,
+                                int32_t* count, double* iou_out, void* stream) {
+  if (!boxes || !keep || !count || n < 0 || n > NMS_MAX_BOXES || stride < 5 || conf_idx < 0 || conf_idx >= stride) return TFPP_EINVAL;
+  const size_t lds = 2 * NMS_THREADS * sizeof(NmsPoly) + (size_t)n * 8 * sizeof(double) + (size_t)n * 3 * sizeof(int) + 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_rotated_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nms_rotated_kernel, dim3(1), dim3(NMS_THREADS), lds, (hipStream_t)stream, boxes, n, stride, conf_idx, iou_threshold, min_conf, keep, count, iou_out);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}

@@ -87,3 +87,48 @@ def non_maximum_suppression(bounding_boxes, iou_treshhold):
     kept.append(cur)
     order = [j for j in order if iou_bbs(cur, boxes[j]) <= iou_treshhold]
   return kept
+
+
+# ------------------------------------------------------------------------------------------------ on the device
+def nms_rotated_device(boxes, iou_threshold, min_conf=float('-inf'), return_iou=False):
+  """tfpp_nms_rotated on a (N, S >= 6) float32 CUDA tensor whose LAST column is the confidence: (keep [N] int32 row indices, most confident
+  first; count [1] int32) device tensors (+ the (N, N) float64 IoU matrix with ``return_iou``) -- no host synchronisation."""
+  import torch
+  from . import ops
+  from ._lib import lib
+  if not (boxes.is_cuda and boxes.dtype == torch.float32 and boxes.dim() == 2 and boxes.is_contiguous()):
+    raise ValueError('nms_rotated_device: boxes must be a contiguous (N, S) float32 CUDA tensor')
+  n, s = boxes.shape
+  keep = torch.empty(max(n, 1), device=boxes.device, dtype=torch.int32)
+  if n == 0:
+    return (keep, ops.zeros(1, torch.int32, boxes.device)) + ((torch.empty((0, 0), device=boxes.device, dtype=torch.float64),) if return_iou else ())
+  count = torch.empty(1, device=boxes.device, dtype=torch.int32)
+  iou = torch.empty((n, n), device=boxes.device, dtype=torch.float64) if return_iou else None
+  lib.tfpp_nms_rotated(ops.ptr(boxes), n, s, s - 1, float(iou_threshold), float(min_conf), ops.ptr(keep), ops.ptr(count), ops.ptr(iou), ops.stream())
+  return (keep, count, iou) if return_iou else (keep, count)
+
+
+def detect_boxes_nms(models, predictions, iou_threshold):
+  """The box post-processing of one sensor_agent.py tick (456-493) on the device: for every model of the ensemble decode the CenterNet maps
+  (LidarCenterNetHead.get_bboxes), convert the first sample's boxes to vehicle coordinates (convert_features_to_bb_metric), then ONE greedy
+  NMS over all of them.  ``predictions``: one ``pred_bounding_box`` tuple per model.  Returns the reference's list of (9,) float32 arrays, most
+  confident first, after a single device -> host copy of the kept rows."""
+  import torch
+  from . import ops
+  from ._lib import lib
+  from .config import cfg_get
+  rows = []
+  for m, bb in zip(models, predictions):
+    cfg = m.config
+    dec = m.head.get_bboxes(bb[0], bb[1], bb[2], bb[3], bb[4], bb[5], bb[6])[0].contiguous()  # (k, 9), scores descending
+    met = torch.empty_like(dec)
+    lib.tfpp_bb_image_to_metric(ops.ptr(dec), ops.ptr(met), dec.shape[0], float(cfg.pixels_per_meter), float(cfg.min_x), float(cfg.min_y), ops.stream())
+    rows.append(met)
+  allb = rows[0] if len(rows) == 1 else torch.cat(rows, 0).contiguous()
+  thr = float(cfg_get(models[0].config, 'bb_confidence_threshold', 0.3))
+  keep, count = nms_rotated_device(allb, iou_threshold, min_conf=thr)
+  host = torch.cat([keep.view(-1).float(), count.float()]).cpu()  # (kept indices, count) in one copy ...
+  n = int(host[-1])
+  idx = host[:n].long()
+  out = allb[idx.to(allb.device)].cpu().numpy() if n else []      # ... and the kept rows in a second one
+  return [b for b in out]

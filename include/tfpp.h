@@ -236,6 +236,15 @@ int tfpp_lidar_histogram(const float* points, int64_t n, int point_stride, const
 int tfpp_centernet_decode(const float* heat, const float* wh, const float* offset, const float* yaw_class, const float* yaw_res, float* out,
                           int B, int ncls, int H, int W, int k, int num_dir_bins, float width_ratio, float height_ratio, void* stream);
 
+/* Rotated-box IoU + greedy NMS on the device (replaces transfuser_utils.py:409-450: shapely polygons + numpy loop; sensor_agent.py:491):
+ * boxes [n][stride] fp32 rows (x, y, half width, half height, yaw [rad], ..., confidence at conf_idx), n <= 1024.  keep[0..*count) = row
+ * indices of the kept boxes, most confident first (equal confidences: higher row first); iou_out (nullable, [n*n] float64): the IoU matrix. */
+int tfpp_nms_rotated(const float* boxes, int n, int stride, int conf_idx, double iou_threshold, float min_conf, int32_t* keep, int32_t* count,
+                     double* iou_out, void* stream);
+/* rows with confidence <= min_conf never enter the suppression (model.py:451).  tfpp_bb_image_to_metric: the n x 9 rows of
+ * tfpp_centernet_decode (image pixels) -> vehicle coordinates in metres (model.py:447-459 + transfuser_utils.py:388-406), same float32 results. */
+int tfpp_bb_image_to_metric(const float* boxes, float* out, int n, float pixels_per_meter, float min_x, float min_y, void* stream);
+
 /* CenterNet training targets from the box list, the rasterisation the loader workers do per sample (replaces
  * CARLA_Data.get_targets, team_code/data.py:697-790, incl. gaussian_target.py:11-61,166-187 and center_net.py:240-254).
  * boxes: (B, max_boxes, 8) float64 rows x, y, extent_x, extent_y, yaw, speed, brake, class in BEV image pixels exactly as

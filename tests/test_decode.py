@@ -71,3 +71,51 @@ def test_hip_decode_properties_on_model_output():
   distinct[1:] &= ws[1:] != ws[:-1]
   distinct[:-1] &= ws[:-1] != ws[1:]
   assert torch.equal(got[0][distinct], want[0][distinct])
+
+
+@pytest.mark.gpu
+def test_device_nms_against_the_exact_oracle_fixture():
+  """tfpp_nms_rotated (float64 Sutherland-Hodgman in one workgroup) against tests/golden/nms.npz: the IoU matrix of the exact rational oracle
+  to 1e-12, the kept indices in the order the reference's loop keeps them."""
+  import os
+  import numpy as np
+  import torch
+  from carla_garage_amd.postprocess import nms_rotated_device
+  g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'nms.npz')))
+  for tag in 'abc':
+    b, iou, kept, thr = g[f'boxes_{tag}'], g[f'iou_{tag}'], g[f'kept_{tag}'], float(g[f'thr_{tag}'])
+    keep, count, mat = nms_rotated_device(torch.from_numpy(b).cuda(), thr, return_iou=True)
+    n = int(count.item())
+    assert keep[:n].cpu().tolist() == kept.tolist(), tag
+    m = mat.cpu().numpy()
+    np.fill_diagonal(m, 0.0)
+    assert np.abs(m - iou).max() < 1e-12, (tag, np.abs(m - iou).max())
+  # confidence floor: rows at or below it never enter
+  b = g['boxes_b']
+  keep, count = nms_rotated_device(torch.from_numpy(b).cuda(), 0.2, min_conf=0.6)
+  from oracle import nms_port as N
+  sel = np.nonzero(b[:, -1] > 0.6)[0]
+  want = [int(sel[k]) for k in N.nms_reference(b[sel], 0.2, iou=lambda x, y: N.iou_exact(x, y))]
+  assert keep[:int(count.item())].cpu().tolist() == want
+  # empty input
+  keep, count = nms_rotated_device(torch.zeros((0, 9), device='cuda'), 0.2)
+  assert int(count.item()) == 0
+
+
+@pytest.mark.gpu
+def test_device_box_pipeline_equals_the_host_pipeline():
+  """decode -> metric conversion -> NMS over two 'models' entirely on the device (postprocess.detect_boxes_nms) against the host path
+  (convert_features_to_bb_metric + postprocess.non_maximum_suppression), on the reference-written decode fixture."""
+  import numpy as np
+  import torch
+  from carla_garage_amd.config import GlobalConfig
+  from carla_garage_amd.model import LidarCenterNet
+  from carla_garage_amd.postprocess import detect_boxes_nms, non_maximum_suppression
+  m = LidarCenterNet(GlobalConfig()).cuda().eval()
+  maps = tuple(t[:1].cuda() for t in _case('b2')[0]) + (None, None)
+  shifted = (maps[0].roll(3, -1) * 0.97,) + maps[1:]  # a second "model": other boxes, other confidences (equal confidences have no defined order in the reference's argsort)
+  host = non_maximum_suppression([m.convert_features_to_bb_metric(maps), m.convert_features_to_bb_metric(shifted)], 0.2)
+  dev = detect_boxes_nms([m, m], [maps, shifted], 0.2)
+  assert len(dev) == len(host) and len(host) > 0
+  for a, b in zip(dev, host):
+    assert np.array_equal(np.asarray(a, np.float32), np.asarray(b, np.float32))

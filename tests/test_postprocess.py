@@ -83,3 +83,29 @@ def test_iou_with_negative_half_extents_equals_the_same_rectangles():
         n1 = [b1[0], b1[1], s1[0] * b1[2], s1[1] * b1[3], b1[4]]
         n2 = [b2[0], b2[1], s2[0] * b2[2], s2[1] * b2[3], b2[4]]
         assert abs(iou_bbs(n1, n2) - want) < 1e-12
+
+
+def test_host_iou_and_nms_against_the_exact_oracle_fixture():
+  """tests/golden/nms.npz (oracle/make_golden_nms.py): IoU matrices computed in exact rational arithmetic from the float64 corners and the
+  indices the reference's greedy loop keeps.  The host implementation must reproduce the IoUs to rounding and the kept boxes exactly."""
+  import os
+  g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'nms.npz')))
+  for tag in 'abc':
+    b, iou, kept, thr = g[f'boxes_{tag}'], g[f'iou_{tag}'], g[f'kept_{tag}'], float(g[f'thr_{tag}'])
+    n = len(b)
+    step = 1 if n <= 100 else 7
+    for i in range(0, n, step):
+      for j in range(i + 1, n, step):
+        assert abs(iou_bbs(b[i], b[j]) - iou[i, j]) < 1e-12, (tag, i, j)
+    got = non_maximum_suppression([list(b[:n // 2]), list(b[n // 2:])], thr)
+    assert [float(x[-1]) for x in got] == [float(b[k, -1]) for k in kept], tag
+
+
+def test_oracle_exact_iou_equals_closed_forms():
+  from oracle import nms_port as N
+  assert N.iou_exact([0, 0, 1, 1, 0.0], [1, 0, 1, 1, 0.0]) == 2.0 / 6.0
+  assert N.iou_exact([0, 0, 2, 1, 0.0], [0, 0, 4, 4, 0.0]) == 8.0 / 64.0
+  assert N.iou_exact([0, 0, 1, 1, 0.0], [5, 0, 1, 1, 0.7]) == 0.0
+  oct_area = 8.0 * (math.sqrt(2.0) - 1.0)
+  assert abs(N.iou_exact([0, 0, 1, 1, 0.0], [0, 0, 1, 1, math.pi / 4]) - oct_area / (8.0 - oct_area)) < 1e-15
+  assert N.iou_exact([0.3, -0.2, -1.2, 2.0, 0.4], [0.3, -0.2, 1.2, 2.0, 0.4]) == 1.0   # a negative half extent is the same rectangle
