@@ -447,38 +447,91 @@ def test_wp_variant_train_step_fp32_vs_reference_golden():
   _check_train_step_vs_golden(2, 'tfpp_wp_train_bs2.npz', 'train_fp32_wp', model=m.cuda(), port_cfg=cfgw)
 
 
-BF16_LOSS_TOL = 5e-2  # measured worst: loss_yaw_res 2.2e-2 (a loss of ~1e-2 absolute, i.e. 2e-4 absolute error), every other loss <= 4.5e-3
-# measured worst gradient-norm deviations (568 tensors): SE fc1 / attention query-key 0.16-0.33 (their fp32 gradients are differences of
-# nearly cancelling terms: the softmax / sigmoid-gate Jacobians), everything else <= 0.155
-BF16_GRAD_NORM_TOL, BF16_GRAD_NORM_TOL_CANCELLING = 0.3, 0.65
-_CANCELLING = ('.se.fc', '.attn.query.', '.attn.key.')
+BF16_LOSS_TOL = 5e-2  # measured worst: loss_yaw_res 3.4e-2 (a loss of ~1e-2 absolute, i.e. 3e-4 absolute error), every other loss <= 5e-3
+# Gradients of the bf16 step against the fp32 HIP step on identical weights and batch (tools/bf16_evidence.py, round 3; 568 tensors carrying
+# >= 1e-3 of the largest norm).  bf16 rounding through 100+ layers with batch-statistic BatchNorm is chaotic on the ill-conditioned tensors
+# (SE fc1, attention query / key: differences of nearly cancelling terms -- a change of the summation order inside one kernel moved
+# lidar_encoder.s2.b1.se.fc1.weight from 0.33 to 0.75), so the bars are on robust statistics, each about 1.3x what is measured:
+#   whole gradient arena: cosine 0.9940, relative L2 0.110;  per-tensor norm error: median 0.0083, p90 0.071, p99 0.226, max 0.745;
+#   sampled elements (16 per tensor, 9068): 9.5 % beyond 0.5 x (rms + |ref|)
+BF16_ARENA_COSINE, BF16_ARENA_REL_L2 = 0.99, 0.15
+BF16_NORM_MEDIAN, BF16_NORM_P90, BF16_NORM_P99, BF16_NORM_MAX = 0.012, 0.10, 0.30, 1.0
+BF16_ELEM_FRACTION_BEYOND_HALF = 0.13
 
 
 @pytest.mark.gpu
 def test_train_step_bs12_bf16_vs_fp32_hip_and_golden():
-  """The benchmarked precision: the bf16 step at bs = 12 (deterministic since the one-row-per-M-tile BN statistics) against the
-  reference's fp32 losses and against the fp32 HIP step's gradients.  Tolerances are what bf16 storage through 100+ layers with
-  batch-statistic BN measures on MI355X (profiles/r02_model_parity_report.jsonl), with head room of about 2x (see the constants above);
-  gradient norms are compared for tensors carrying >= 1e-3 of the largest norm."""
+  """The benchmarked precision: the bf16 step at bs = 12 against the reference's fp32 losses and against the fp32 HIP step's gradients --
+  losses, the whole gradient arena (cosine / relative L2), the distribution of per-tensor norm errors and sampled ELEMENTS (see the
+  constants above).  tests/test_model.py::test_bf16_trains_like_fp32_over_50_steps is the end-to-end counterpart."""
   g = U.load_golden('tfpp_train_bs12.npz')
   m32 = _model('fp32').train()
   _, v32, e32 = _engine_train_step(m32, 12)
-  ref = {n: e32.grads[n].detach().double().norm().item() for n in e32.grads}
+  ref = {n: e32.grads[n].detach().clone() for n in e32.grads}
   del m32, e32
   torch.cuda.empty_cache()
   m16 = _model('bf16').train()
   names, v16, e16 = _engine_train_step(m16, 12)
   gl = dict(zip([str(x) for x in g['loss_names']], g['losses']))
   lerr = {n: float(abs(v - gl[n]) / abs(gl[n])) for n, v in zip(names, v16)}
-  big = max(ref.values())
-  nerr = {n: abs(e16.grads[n].detach().double().norm().item() - r) / r for n, r in ref.items() if r >= 1e-3 * big}
-  top = dict(sorted(nerr.items(), key=lambda kv: -kv[1])[:8])
+  flat32 = torch.cat([ref[n].flatten().double() for n in ref])
+  flat16 = torch.cat([e16.grads[n].detach().flatten().double() for n in ref])
+  cosine = float((flat32 * flat16).sum() / (flat32.norm() * flat16.norm()))
+  rel_l2 = float((flat16 - flat32).norm() / flat32.norm())
+  big = max(float(r.double().norm()) for r in ref.values())
+  nerr, beyond, total = {}, 0, 0
+  for n, r in ref.items():
+    rn = float(r.double().norm())
+    if rn < 1e-3 * big:
+      continue
+    mine = e16.grads[n].detach()
+    nerr[n] = abs(float(mine.double().norm()) - rn) / rn
+    idx = torch.from_numpy(U.sample_idx(r.numel())).to(r.device)
+    rs, gs = r.flatten()[idx].double(), mine.flatten()[idx].double()
+    rel = (gs - rs).abs() / (rn / np.sqrt(r.numel()) + rs.abs())
+    beyond += int((rel > 0.5).sum())
+    total += int(rel.numel())
+  e = np.array(list(nerr.values()))
+  stats = {'arena_cosine': cosine, 'arena_rel_l2': rel_l2, 'norm_err_median': float(np.median(e)), 'norm_err_p90': float(np.percentile(e, 90)),
+           'norm_err_p99': float(np.percentile(e, 99)), 'norm_err_max': float(e.max()), 'sampled_elements': total, 'beyond_half': beyond / total}
   _report('train_bf16_bs12', {'losses_vs_reference': lerr, 'losses_vs_fp32_hip': {n: float(abs(a - b) / abs(b)) for n, a, b in zip(names, v16, v32)},
-                               'grad_norm_vs_fp32_hip_worst': top, 'tensors_compared': len(nerr)})
+                               'gradients_vs_fp32_hip': stats, 'tensors_compared': len(nerr),
+                               'norm_err_top': dict(sorted(nerr.items(), key=lambda kv: -kv[1])[:6])})
   assert np.isfinite(v16).all()
   assert max(lerr.values()) <= BF16_LOSS_TOL, lerr
-  bad = {n: e for n, e in nerr.items() if e > (BF16_GRAD_NORM_TOL_CANCELLING if any(t in n for t in _CANCELLING) else BF16_GRAD_NORM_TOL)}
-  assert not bad, bad
+  assert cosine >= BF16_ARENA_COSINE and rel_l2 <= BF16_ARENA_REL_L2, stats
+  assert stats['norm_err_median'] <= BF16_NORM_MEDIAN and stats['norm_err_p90'] <= BF16_NORM_P90 and stats['norm_err_p99'] <= BF16_NORM_P99 and \
+      stats['norm_err_max'] <= BF16_NORM_MAX, stats
+  assert stats['beyond_half'] <= BF16_ELEM_FRACTION_BEYOND_HALF, stats
+
+
+@pytest.mark.gpu
+def test_bf16_trains_like_fp32_over_50_steps():
+  """Does the benchmarked precision TRAIN like fp32?  50 optimizer steps (AdamW-amsgrad, lr 1e-4, four different batches of 4 cycled, dropout
+  off), a bf16 Trainer beside an fp32 Trainer from identical weights: the weighted training loss of both falls from ~96 to ~1.5 and the bf16
+  curve stays within a few percent of the fp32 one (measured: max 2.5 %, mean 0.54 %, tools/bf16_evidence.py)."""
+  from carla_garage_amd.trainer import Trainer
+  batches = []
+  for i in range(4):
+    b = {k: v.cuda() for k, v in P.make_labels(4).items()}
+    for k, v in zip(('rgb', 'lidar_bev', 'target_point', 'ego_vel', 'command'), P.make_inputs(4)):
+      b[k] = v.cuda()
+    b['rgb'] = (b['rgb'] + 5.0 * i).clamp(0, 255)
+    batches.append(b)
+  curves = {}
+  for dt in ('fp32', 'bf16'):
+    m = _model(dt).train()
+    _zero_dropout(m)
+    tr = Trainer(m, lr=1e-4)
+    curves[dt] = np.array([tr.total_loss(tr.train_step(batches[s % 4])) for s in range(50)])
+    del tr, m
+    torch.cuda.empty_cache()
+  a, b = curves['fp32'], curves['bf16']
+  dev = np.abs(a - b) / np.abs(a)
+  _report('bf16_vs_fp32_50_steps', {'fp32_first_last': [float(a[0]), float(a[-1])], 'bf16_first_last': [float(b[0]), float(b[-1])],
+                                    'max_rel_dev': float(dev.max()), 'mean_rel_dev': float(dev.mean())})
+  assert np.isfinite(b).all() and a[-1] < 0.05 * a[0] and b[-1] < 0.05 * b[0]
+  assert dev.max() <= 0.04 and dev.mean() <= 0.01, (float(dev.max()), float(dev.mean()))
 
 
 @pytest.mark.gpu
