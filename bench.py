@@ -337,6 +337,24 @@ def dropin_step_time(model, cfg, batch, steps, warmup, optimizer, log, ddp=False
   return r
 
 
+XGMI_LINK_GBS = 153.0  # per direction and link; 7 links per GPU, one to every other GPU of the node (MI355X_MICROARCH.md)
+
+
+def exchange_model(arena_bytes, late_bytes, world):
+  """What the gradient exchange should cost on one 8 x MI355X node, to check the first real multi-GPU run against: S bytes all-reduced over N
+  ranks move 2 S (N-1)/N bytes out of every GPU; a direct (one-shot reduce-scatter + all-gather over the full xGMI mesh) algorithm spreads them
+  over the N-1 links, a ring is bound by one link.  'exposed' = the late slice (stems .. fusion stage 3, reduced after backward); the early slice
+  (heads + stage 4, two thirds of the arena) travels while the second backward segment computes."""
+  n = max(world, 2)
+  per_gpu = lambda b: 2.0 * b * (n - 1) / n
+  ms = lambda b, links: round(per_gpu(b) / (links * XGMI_LINK_GBS * 1e9) * 1e3, 3)
+  return {'ranks_modelled': n, 'arena_bytes': arena_bytes, 'late_slice_bytes': late_bytes,
+          'whole_arena_ms': {'direct': ms(arena_bytes, n - 1), 'ring': ms(arena_bytes, 1)},
+          'exposed_late_slice_ms': {'direct': ms(late_bytes, n - 1), 'ring': ms(late_bytes, 1)},
+          'note': f'{XGMI_LINK_GBS:.0f} GB/s per xGMI link and direction, {n - 1} links used by the direct algorithm; plus the mid-backward join of the lanes '
+                  '(1.7 ms measured on one GPU with TFPP_SPLIT_STEP=1)'}
+
+
 def pmc_traffic(family):
   """HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written
   by tools/pmc_traffic.sh; bench.py cannot collect PMC counters itself).  An entry records the sha of the kernel source it was
@@ -505,7 +523,8 @@ def main():
       comm = {'rccl_ranks': rccl_ranks, 'ms_per_step_without_exchange': round(local_ms, 3),
               'exposed_comm_ms_per_step': round(1e3 * elapsed / args.steps - local_ms, 3),
               'allreduce_bytes_per_step': int(trainer.eng.flat_grad.numel()) * 4,
-              'overlap': 'two hipGraph segments, all-reduce of the early-finishing 2/3 of the arena between the replays'}
+              'overlap': 'two hipGraph segments, all-reduce of the early-finishing 2/3 of the arena between the replays',
+              'predicted': exchange_model(int(trainer.eng.flat_grad.numel()) * 4, int(trainer.eng.early_offset) * 4, world)}
       log(f'gradient exchange: {comm}')
     finally:
       trainer.exchange = True

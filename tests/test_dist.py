@@ -82,3 +82,81 @@ def test_single_process_is_a_no_op():
   tdist.broadcast_state(t, [])
   assert tdist.max_over_ranks(3.5, torch.device('cpu')) == 3.5
   assert tdist.all_reduce_async(t) is None
+
+
+def _trainer_schedule_worker(rank, world, port, out):
+  """Drives Trainer.train_step ITSELF (trainer.py: _step_part1 -> reduce_early -> _step_part2 -> finish_step) with the GPU parts stubbed: the
+  backward segments only write this rank's gradients into the two slices of the arena.  What is tested is the bucket schedule: the early
+  slice [early_offset:] is all-reduced asynchronously BETWEEN the segments, the head [:early_offset] after the second one, the optimizer runs
+  after both have completed and sees the SUM over the ranks (the 1/world average is the optimizer's grad_scale)."""
+  import types
+  from carla_garage_amd.trainer import Trainer
+  os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  tdist.init_from_env('gloo')
+  n, off = 5003, 1801
+  events = []
+  tr = Trainer.__new__(Trainer)
+  tr.model = types.SimpleNamespace(train=lambda: None)
+  tr.pg, tr.world, tr.step_count, tr.exchange, tr._lazy_state = None, world, 0, True, False
+  tr.eng = types.SimpleNamespace(flat_grad=torch.zeros(n), early_offset=off, invalidate=lambda: None)
+  mine = torch.arange(n, dtype=torch.float32) * (rank + 1)
+
+  def part1(batch, split=True):
+    assert split
+    tr.eng.flat_grad[off:] = mine[off:]           # the heads / stage-4 gradients are final after the first backward segment ...
+    events.append('segment1')
+    return torch.zeros(3)
+
+  def part2():
+    assert 'early_issued' in events                # ... and are already travelling when the second segment starts
+    tr.eng.flat_grad[:off] = mine[:off]
+    events.append('segment2')
+
+  def optimizer(step, grad_scale=None):
+    events.append('optimizer')
+    tr.seen = tr.eng.flat_grad.clone()
+    tr.scale = 1.0 / tr.world if grad_scale is None else grad_scale
+
+  tr._step_part1, tr._step_part2, tr._optimizer = part1, part2, optimizer
+  real_async, real_sync = tdist.all_reduce_async, tdist.all_reduce_gradients
+
+  class Handle:
+
+    def __init__(self, work):
+      self.work = work
+
+    def wait(self):
+      events.append('early_waited')
+      self.work.wait()
+
+  def rec_async(t, group=None, avg=False):
+    assert t.data_ptr() == tr.eng.flat_grad[off:].data_ptr() and t.numel() == n - off   # exactly the tail slice of the arena
+    events.append('early_issued')
+    return Handle(real_async(t, group, avg=avg))
+
+  def rec_sync(t, group=None, chunk_elems=None, avg=False):
+    assert t.data_ptr() == tr.eng.flat_grad.data_ptr() and t.numel() == off               # exactly the head slice
+    events.append('head_reduced')
+    return real_sync(t, group, chunk_elems, avg=avg)
+
+  tdist.all_reduce_async, tdist.all_reduce_gradients = rec_async, rec_sync
+  assert tr.overlap_enabled()
+  tr.train_step({})
+  # the averaged variant the drop-in path uses (dropin.py): gloo has no ReduceOp.AVG -> SUM + scale after the wait
+  g = mine.clone()
+  h = real_async(g[off:], None, avg=True)
+  real_sync(g[:off], None, avg=True)
+  h.wait()
+  torch.save({'events': events, 'seen': tr.seen, 'scale': tr.scale, 'avg': g}, os.path.join(out, f'sched{rank}.pt'))
+  dist.destroy_process_group()
+
+
+def test_trainer_bucket_schedule_two_ranks(tmp_path):
+  world, port = 2, _free_port()
+  mp.spawn(_trainer_schedule_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+  want = torch.arange(5003, dtype=torch.float32) * 3.0  # rank 0 contributes 1x, rank 1 contributes 2x
+  for r in range(world):
+    d = torch.load(tmp_path / f'sched{r}.pt')
+    assert d['events'] == ['segment1', 'early_issued', 'segment2', 'head_reduced', 'early_waited', 'optimizer'], d['events']
+    assert torch.equal(d['seen'], want) and d['scale'] == 0.5
+    assert torch.equal(d['avg'], want / 2)
