@@ -434,6 +434,16 @@ extern "C" int tfpp_hash_words(const void* p, int64_t bytes, uint64_t* slot, voi
   return 0;
 }
 
+// debugging aid (tools/lane_timeline.py): *slot = the device's constant-rate wall clock (100 MHz) when this launch runs -- a time stamp INSIDE a
+// captured step, on whatever lane it was issued
+__global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+extern "C" int tfpp_stamp(uint64_t* slot, void* stream) {
+  if (!slot) return TFPP_EINVAL;
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)slot);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
 // *p += 1 : per-step counter added to every dropout seed (captured in the training-step hipGraph)
 __global__ void inc_u64_kernel(unsigned long long* p) { *p += 1ull; }
 extern "C" int tfpp_inc_u64(uint64_t* p, void* stream) {

@@ -94,11 +94,15 @@ class Lanes:
       st = self.branches[k] = torch.cuda.Stream(self.main.device)
     return st
 
-  def touch(self, k):
-    """Lane k is about to receive work: order it after everything issued so far on lane 0 the first time since the last join (a
-    stream that never waited on the capturing stream would not be part of a hipGraph capture)."""
+  def touch(self, k, ev=None):
+    """Lane k is about to receive work: the first time since the last join it has to wait for something of this pass (a stream that never
+    waited on the capturing stream would not be part of a hipGraph capture) -- the event of the gradient it is about to consume when there is
+    one (the lane then starts as soon as THAT is ready), else everything issued so far on lane 0."""
     if k != 0 and k not in self.active:
-      self.stream(k).wait_stream(self.main)
+      if ev is not None:
+        self.stream(k).wait_event(ev)
+      else:
+        self.stream(k).wait_stream(self.main)
       self.active.add(k)
 
   def streams(self):
@@ -179,10 +183,11 @@ class Tape:
     if like is not None and (cur.dtype != like.dtype or cur.numel() != like.numel()):
       return None
     if self._multi and self._glane[k] != self._lane:
-      self._sync(self._lane, self._glane[k])
+      self._wait(self._lane, k, self._glane[k])
       self.lanes.hold(cur)
     del self._grads[k]
     self._glane.pop(k, None)
+    self._gevent.pop(k, None)
     self._refs[id(cur)] = self._refs.get(id(cur), 1) - 1
     return cur
 
@@ -195,6 +200,7 @@ class Tape:
     joined, so every gradient those nodes produce is complete) and ``backward_resume()`` runs the rest -- the trainer all-reduces
     the finished part of the gradient arena while the second segment computes."""
     self._grads, self._refs, self._glane, self._lane = {}, {}, {}, 0
+    self._gevent = {}  # key -> event recorded on the producing lane right after the gradient was written (see _wait)
     self.contrib = {}
     lanes = self.lanes
     if lanes is not None and seeds:
@@ -223,6 +229,7 @@ class Tape:
       # of a new hipGraph capture, and a stream that has not yet waited on the capturing stream is not part of the capture (its
       # kernels would run eagerly and be missing from the replay), even if the gradient it consumes was produced on that lane itself
     Tape.current = self
+    self._gevent = {}  # events of the first segment belong to another capture; every lane was joined at its end (coarse waits suffice here)
     rest, self._rest = self._rest, []
     self._run(rest)
     self._join()
@@ -233,6 +240,27 @@ class Tape:
       self.lanes.touch(to_lane)
       self.lanes.touch(from_lane)  # a producer lane idle since the last join (second backward segment) joins this pass / capture first
       self.lanes.stream(to_lane).wait_stream(self.lanes.stream(from_lane))
+
+  def _wait(self, to_lane, k, from_lane):
+    """Lane ``to_lane`` is about to read (or add to) the pending gradient of key ``k`` written on ``from_lane``.  Fine-grained: wait for the EVENT
+    recorded right after that gradient was written, not for the tail of the producing stream.  The tape is walked in reverse recording
+    order, so by the time a LiDAR-lane node is issued the whole backward of the image stage recorded after it is already queued on lane 0:
+    with stream-level waits the LiDAR stages, the planning head and the BEV heads ran strictly one after the other (round 3,
+    tools/lane_timeline.py: lane 0 stalled 2.0 + 2.4 + 1.4 ms at the fusion points, lane 1 sat idle for 3.7 + 2.8 ms)."""
+    if not self._multi or to_lane == from_lane:
+      return
+    ev = self._gevent.get(k) if _FINE_EVENTS else None
+    if ev is None:
+      self._sync(to_lane, from_lane)
+      return
+    self.lanes.touch(to_lane, ev)
+    self.lanes.stream(to_lane).wait_event(ev)
+
+  def _mark_written(self, k, lane):
+    if self._multi and _FINE_EVENTS:
+      ev = torch.cuda.Event()
+      ev.record(self.lanes.stream(lane))
+      self._gevent[k] = ev
 
   def _acc(self, t, g, lane):
     if t is None or g is None:
@@ -247,9 +275,10 @@ class Tape:
       grads[k] = g
       refs[id(g)] = refs.get(id(g), 0) + 1
       glane[k] = lane
+      self._mark_written(k, lane)
       return
     if self._multi and glane[k] != lane:  # the pending gradient was last written on another lane
-      self._sync(lane, glane[k])
+      self._wait(lane, k, glane[k])
       self.lanes.hold(cur, g)
     glane[k] = lane
     if refs.get(id(cur), 0) > 1 or id(cur) in self.frozen:
@@ -260,33 +289,38 @@ class Tape:
       refs[id(new)] = 1
     else:
       ops.axpy(g if g.dtype == cur.dtype else ops.cast(g, cur.dtype), cur, 1.0)
+    self._mark_written(k, lane)
 
   def _run(self, nodes):
     grads, refs, glane, lanes, multi = self._grads, self._refs, self._glane, self.lanes, self._multi
     for outs, ins, fn, lane in reversed(nodes):
       if not multi:
         lane = 0
-      gouts, src_lanes = [], set()
+      gouts, src = [], []
       for o in outs:
         k = _key(o)
         g = grads.pop(k, None)
         if g is not None:
           refs[id(g)] = refs.get(id(g), 1) - 1
-          src_lanes.add(glane.pop(k, 0))
+          src.append((k, glane.pop(k, 0)))
         gouts.append(g)
       if all(g is None for g in gouts):
         continue
-      if multi and lane != 0:
-        lanes.touch(lane)
+      src_lanes = {sl for _, sl in src}
       ctx = torch.cuda.stream(lanes.stream(lane)) if multi and lane != 0 else contextlib.nullcontext()
       with ctx:
         self._lane = lane
         if multi:
           lanes.cur = lane
-        for sl in src_lanes:
-          self._sync(lane, sl)
+        for k, sl in src:
+          self._wait(lane, k, sl)
+          self._gevent.pop(k, None)
+        if multi and lane != 0:
+          lanes.touch(lane)  # (a lane whose first node of this pass consumes only its own gradients: second backward segment)
         if multi and src_lanes - {lane}:
           lanes.hold(*[g for g in gouts if g is not None])
+        if ops.STAMPS['on']:
+          ops.stamp(f'bwd lane{lane} {_fn_label(fn)}')
         if ops.NODE_HASH['on']:
           lab = _fn_label(fn)
           for j, g in enumerate(gouts):
@@ -309,11 +343,14 @@ class Tape:
 
   def _join(self):
     """End of a segment: flush + join the weight-gradient lane, join the encoder lanes."""
+    ops.stamp('bwd lane0 MAIN CHAIN DONE (before the joins)')
     for fin in self.finalizers:
       fin()
     self.finalizers = []
+    ops.stamp('bwd lane0 weight-gradient lane joined')
     if self._multi:
       self.lanes.join()
+    ops.stamp('bwd lane0 all lanes joined')
 
   def _finish(self):
     if self._multi:
@@ -340,6 +377,7 @@ def _fn_label(fn):
 
 
 _LN_CHECK = os.environ.get('TFPP_DEBUG_LN_CHECK', '0') == '1'
+_FINE_EVENTS = os.environ.get('TFPP_FINE_EVENTS', '1') != '0'  # cross-lane gradient dependencies as events instead of stream-level waits (A/B switch)
 LN_KEEP = {}
 _SKIP_SIDE_WORK = os.environ.get('TFPP_DEBUG_SKIP_SIDE_WORK', '0') == '1'
 _SIDE_CHECK = os.environ.get('TFPP_DEBUG_SIDE_CHECK', '0') == '1'
@@ -365,6 +403,8 @@ class SideLane:
     # wave shares its CU with the persistent MFMA weight-gradient kernel -- the library is now built without them (_lib.HIPCC_FLAGS) and
     # tools/stress_step.py passes at 96 and 128 (profiles/r03_stress_step_side_batch128.log).
     self.batch = int(os.environ.get('TFPP_SIDE_BATCH', '128'))
+    self.tail_batch = int(os.environ.get('TFPP_SIDE_TAIL_BATCH', str(self.batch)))
+    self.in_tail = False
     self.stream = None
     self.lanes = None  # Lanes of the engine: a batch may hold closures from both encoder-branch streams
     self.keep = []
@@ -391,7 +431,9 @@ class SideLane:
         where = f'{self.label} ' + ' <- '.join(f'{f.name}:{f.lineno}' for f in traceback.extract_stack(limit=5)[:-1][::-1])
         self.checks.append((t, t.double().sum(), t.double().abs().sum(), where))
     self.pending.append(fn)
-    if len(self.pending) >= self.batch:
+    # near the end of backward (stage 1 and the stems: the largest pixel counts, hence the longest weight-gradient kernels) whatever is still
+    # queued when the main chain finishes is pure tail: fork in small batches there
+    if len(self.pending) >= (self.tail_batch if self.in_tail else self.batch):
       self.flush()
 
   def flush(self):
@@ -401,8 +443,10 @@ class SideLane:
         for st in self.lanes.streams():
           self.stream.wait_stream(st)
       with torch.cuda.stream(self.stream):
+        ops.stamp(f'side lane9 batch of {len(self.pending)} begins')
         for fn in self.pending:
           fn()
+        ops.stamp('side lane9 batch ends')
       self.pending = []
 
   def join(self):
@@ -772,6 +816,8 @@ class Engine:
   def rec(self, outs, ins, fn):
     if self.tape is not None:
       self.tape.record(outs, ins, fn, self.lanes.cur)
+      if ops.STAMPS['on']:
+        ops.stamp(f'fwd lane{self.lanes.cur} {_fn_label(fn)}')
       if ops.NODE_HASH['on']:
         for j, o in enumerate(outs):
           ops.node_hash(o, f'fwd lane{self.lanes.cur} {_fn_label(fn)} out{j}')
@@ -810,6 +856,7 @@ class Engine:
 
       def bwd(dy):
         self.side.label = key
+        self.side.in_tail = ('.s1.' in key or key.endswith('.stem'))
         if s.bn is None:
           dz = ops.act_bwd(dy, y, act) if act != ACT_NONE else dy
           dres = dz if res is not None else None

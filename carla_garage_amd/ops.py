@@ -820,6 +820,27 @@ if _os.environ.get('TFPP_DEBUG_NODE_HASH_RANGE'):
   NODE_HASH['lo'], NODE_HASH['hi'] = (int(v) for v in _os.environ['TFPP_DEBUG_NODE_HASH_RANGE'].split(':'))
 
 
+STAMPS = {'on': _os.environ.get('TFPP_DEBUG_STAMPS', '0') == '1', 'buf': None, 'labels': [], 'n': 0}
+
+
+def stamp(label):
+  """Time stamp of the current stream at this point of the launch sequence (TFPP_DEBUG_STAMPS=1; tools/lane_timeline.py reads the table)."""
+  st = STAMPS
+  if not st['on']:
+    return
+  if st['buf'] is None:
+    st['buf'] = zeros(4096, torch.int64, 'cuda')
+  i = st['n']
+  if i >= 4096:
+    return
+  st['n'] += 1
+  if len(st['labels']) <= i:
+    st['labels'].append(label)
+  else:
+    st['labels'][i] = label
+  lib.tfpp_stamp(st['buf'].data_ptr() + 8 * i, stream())
+
+
 def node_hash_begin(device):
   st = NODE_HASH
   if st['buf'] is None:

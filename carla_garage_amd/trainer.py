@@ -99,13 +99,19 @@ class Trainer:
     eng.training = True
     eng.dtype = model.compute_dtype
     eng.invalidate()  # this step rewrites the BatchNorm running statistics (and the optimizer the parameters) through raw pointers
+    if ops.STAMPS['on']:
+      ops.STAMPS['n'] = 0
+    ops.stamp('step lane0 START')
     eng.repack(eng.dtype, True)
+    ops.stamp('step lane0 weights repacked')
     eng.alloc_grads()
     ops.inc_u64(self.seed_offset)
     eng._seed_ctr = 0  # the per-call part of the seeds is a function of the call site only
     eng.tape = Tape(eng.lanes)
     t = eng.forward(batch['rgb'], batch['lidar_bev'], batch['target_point'], batch['ego_vel'], batch['command'])
+    ops.stamp('step lane0 FORWARD DONE')
     _, vals, seeds = fused_losses(model, t, batch, self.loss_weights, True)
+    ops.stamp('step lane0 losses done')
     self._tape, eng.tape = eng.tape, None
     self._tape.backward(seeds, stop_at_mark=split)
     return vals

@@ -433,6 +433,8 @@ int tfpp_hash_words(const void* p, int64_t bytes, uint64_t* slot, void* stream);
 /* debugging aid: the next tfpp_layernorm_bwd launch also writes {c1, c2, mean, rstd, bits of the wave's MODE register, bits of HW_ID} per
  * row into buf ([rows][6] floats); NULL disarms. */
 int tfpp_debug_ln_buffer(float* buf);
+/* debugging aid (tools/lane_timeline.py): *slot = wall_clock64() (100 MHz) at the time this launch runs on its stream. */
+int tfpp_stamp(uint64_t* slot, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * GRU waypoint / checkpoint decoder (model.py:857-867): h0 = enc(target_point); nn.GRU(256->64) over T steps;
