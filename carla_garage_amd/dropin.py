@@ -154,7 +154,7 @@ class DropinStep:
     eng.training = model.training
     eng.dtype = model.compute_dtype
     eng.invalidate()  # optimizers (fused or torch's, in place) and BatchNorm write parameters / statistics behind tensor._version
-    eng.repack(eng.dtype, True)
+    eng.repack(eng.dtype, True, defer=True)
     ops.clear_stats_rows(eng.device)
     ops.set_seed_offset(self.tr.seed_offset)
     ops.inc_u64(self.tr.seed_offset)

@@ -258,8 +258,12 @@ class PackPlan:
 
   def __init__(self):
     self.descs, self.keep, self.table, self.total_blocks = [], [], None, 0
+    self.early = True     # tag of the descriptors added from now on: needed by the first layers of forward (stems, stage 1) or later
+    self.tags = []
+    self.tables = None    # [(device table, n descriptors, workgroups)] for the early / the late descriptors
 
   def add(self, kind, src, dst, total, a, row_map=None, col_map=None, in_ld=0, out_ld=0):
+    self.tags.append(bool(self.early))
     d = PackDesc()
     d.src, d.dst, d.row_map, d.col_map = ptr(src), ptr(dst), ptr(row_map), ptr(col_map)
     d.total, d.in_ld, d.out_ld, d.kind, d.dtype = total, in_ld, out_ld, kind, dt(dst)
@@ -270,17 +274,22 @@ class PackPlan:
 
   def finalize(self, device):
     plan = lib.raw('tfpp_pack_desc_plan')
-    blk = 0
-    for d in self.descs:
-      d.blk_start = blk
-      blk += plan(ctypes.byref(d))
-    self.total_blocks = blk
-    raw = b''.join(bytes(d) for d in self.descs)
-    self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    self.tables = []
+    for want in (True, False):
+      part = [d for d, t in zip(self.descs, self.tags) if t == want]
+      blk = 0
+      for d in part:
+        d.blk_start = blk
+        blk += plan(ctypes.byref(d))
+      raw = b''.join(bytes(d) for d in part)
+      self.tables.append((torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device) if part else None, len(part), blk))
+    self.total_blocks = sum(t[2] for t in self.tables)
 
-  def launch(self):
-    if self.descs:
-      lib.tfpp_pack_multi(ptr(self.table), len(self.descs), self.total_blocks, stream())
+  def launch(self, part=None):
+    """part None: every descriptor (two launches on the current stream); 0: the early table (stems, stage 1); 1: the rest."""
+    for i, (table, n, blocks) in enumerate(self.tables or []):
+      if n and (part is None or part == i):
+        lib.tfpp_pack_multi(ptr(table), n, blocks, stream())
 
 
 PACK_PLAN = None  # when set, pack_conv_weight / pack2d record into it instead of launching

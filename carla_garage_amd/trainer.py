@@ -102,7 +102,7 @@ class Trainer:
     if ops.STAMPS['on']:
       ops.STAMPS['n'] = 0
     ops.stamp('step lane0 START')
-    eng.repack(eng.dtype, True)
+    eng.repack(eng.dtype, True, defer=True)
     ops.stamp('step lane0 weights repacked')
     eng.alloc_grads()
     ops.inc_u64(self.seed_offset)

@@ -63,8 +63,14 @@ def main():
   for lane in sorted(lanes):
     ev = sorted(lanes[lane])
     agg = collections.OrderedDict()
+    last = {}
     for (x0, ph, lab), (x1, _, _) in zip(ev, ev[1:]):
-      k = f'{ph} {group(lab)}'
+      g = group(lab)
+      if g.startswith('Engine.') and ph in last:
+        g = last[ph]  # nodes without a layer key (squeeze-excite, LayerNorm, adds ...) belong to the block around them
+      else:
+        last[ph] = g
+      k = f'{ph} {g}'
       a = agg.setdefault(k, [0.0, 0, x0])
       a[0] += x1 - x0
       a[1] += 1
