@@ -824,6 +824,164 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void bgemm_kerne
   }
 }
 
+// Small-problem variant (the fp32 planning head: M <= 780 rows, N, K <= 2048 -- forward, data-gradient and weight-gradient products of
+// every Linear of the 6-layer decoder): 32 x 32 output tiles, and the FOUR waves of a workgroup split the K range of one tile between them
+// (each wave has its own LDS stage and accumulators; the partial tiles are added in a fixed order through LDS at the end).  One launch,
+// deterministic, >= 4x the workgroups of the 64 x 64 kernel and a quarter of its K-loop latency: the 64 x 64 kernel needed 20 us for
+// 132 x 256 x 768 (12 workgroups x 24 K-steps), conv_gemm's split-K needed a second launch for the slice sum.
+template <typename T, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void bgemm_ks_kernel(tfpp_bgemm_params p, int vec_ok) {
+  using C = TileCfg<T, 32, 32, 32, 32>;
+  constexpr int VEC = C::VEC, KV = C::KV, BK = C::BK, KW = 4, NL = 64;
+  constexpr int A_ELEMS = A_KM ? C::A_ELEMS_KM : C::A_ELEMS_RM, B_ELEMS = B_KM ? C::B_ELEMS_KM : C::B_ELEMS_RM;
+  constexpr int STAGE = A_ELEMS + B_ELEMS;
+  static_assert(KW * STAGE * sizeof(T) >= KW * NL * 16 * sizeof(float), "the stages are reused for the cross-wave sum");
+  __shared__ __attribute__((aligned(16))) T smem[KW * STAGE];
+  const int lane = threadIdx.x & 63, kw = threadIdx.x >> 6;
+  T* As = smem + kw * STAGE;
+  T* Bs = As + A_ELEMS;
+  const int z = blockIdx.z, z0 = z / p.batch1, z1 = z - z0 * p.batch1;
+  const int bm0 = blockIdx.x * 32, bn0 = blockIdx.y * 32;
+  const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1;
+  const T* __restrict__ Bp = reinterpret_cast<const T*>(p.B) + z0 * p.b_bs0 + z1 * p.b_bs1;
+  const size_t coff = (size_t)z0 * p.c_bs0 + (size_t)z1 * p.c_bs1;
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nkt = (p.K + BK - 1) / BK, per = (nkt + KW - 1) / KW;
+  for (int it = 0; it < per; ++it) {  // (the same trip count in every wave: the barriers below are workgroup barriers)
+    const int kt = kw * per + it;
+    const bool live = kt < nkt;
+    const int kb = kt * BK;
+    if (live) {
+      if constexpr (!A_KM) {
+        constexpr int IT = (32 * KV + NL - 1) / NL;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+          const int v = lane + i * NL;
+          if (v < 32 * KV) {
+            const int row = v / KV, kc = v - row * KV, k0 = kb + kc * VEC, m = bm0 + row;
+            T* d = &As[row * C::LDK + kc * VEC];
+            if (vec_ok) {
+              uint4 val = make_uint4(0, 0, 0, 0);
+              if (m < p.M && k0 < p.K) val = *reinterpret_cast<const uint4*>(A + (size_t)m * p.lda + k0);
+              *reinterpret_cast<uint4*>(d) = val;
+            } else {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) d[e] = (m < p.M && k0 + e < p.K) ? A[(size_t)m * p.lda + k0 + e] : (T)0;
+            }
+          }
+        }
+      } else {
+        constexpr int RV = 32 / VEC, IT = (BK * RV + NL - 1) / NL;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+          const int v = lane + i * NL;
+          if (v < BK * RV) {
+            const int kk = v / RV, rc = v - kk * RV, k = kb + kk, m0 = bm0 + rc * VEC;
+            T* d = &As[kk * C::LDRA + rc * VEC];
+            if (vec_ok) {
+              uint4 val = make_uint4(0, 0, 0, 0);
+              if (k < p.K && m0 < p.M) val = *reinterpret_cast<const uint4*>(A + (size_t)k * p.lda + m0);
+              lds_store_km<T>(d, val);
+            } else {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) d[e] = (k < p.K && m0 + e < p.M) ? A[(size_t)k * p.lda + m0 + e] : (T)0;
+            }
+          }
+        }
+      }
+      if constexpr (!B_KM) {
+        constexpr int IT = (32 * KV + NL - 1) / NL;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+          const int v = lane + i * NL;
+          if (v < 32 * KV) {
+            const int row = v / KV, kc = v - row * KV, k0 = kb + kc * VEC, n = bn0 + row;
+            T* d = &Bs[row * C::LDK + kc * VEC];
+            if (vec_ok) {
+              uint4 val = make_uint4(0, 0, 0, 0);
+              if (n < p.N && k0 < p.K) val = *reinterpret_cast<const uint4*>(Bp + (size_t)n * p.ldb + k0);
+              *reinterpret_cast<uint4*>(d) = val;
+            } else {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) d[e] = (n < p.N && k0 + e < p.K) ? Bp[(size_t)n * p.ldb + k0 + e] : (T)0;
+            }
+          }
+        }
+      } else {
+        constexpr int RV = 32 / VEC, IT = (BK * RV + NL - 1) / NL;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+          const int v = lane + i * NL;
+          if (v < BK * RV) {
+            const int kk = v / RV, rc = v - kk * RV, k = kb + kk, n0 = bn0 + rc * VEC;
+            T* d = &Bs[kk * C::LDRB + rc * VEC];
+            if (vec_ok) {
+              uint4 val = make_uint4(0, 0, 0, 0);
+              if (k < p.K && n0 < p.N) val = *reinterpret_cast<const uint4*>(Bp + (size_t)k * p.ldb + n0);
+              lds_store_km<T>(d, val);
+            } else {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) d[e] = (k < p.K && n0 + e < p.N) ? Bp[(size_t)k * p.ldb + n0 + e] : (T)0;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (live) tile_mma_step<C, T, A_KM, B_KM>(As, Bs, 0, 0, lane, acc);
+    __syncthreads();
+  }
+  // cross-wave sum in a fixed order (wave 0 + 1 + 2 + 3), then the epilogue of bgemm_kernel by wave 0
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((kw * 16) + (i * 2 + j) * 4 + r) * NL + lane] = acc[i][j][r];
+  __syncthreads();
+  if (kw != 0) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = bm0 + i * 16 + (lane >> 4) * 4 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = bn0 + j * 16 + (lane & 15);
+        if (n >= p.N) continue;
+        const int e = (i * 2 + j) * 4 + r;
+        float v = ((red[e * NL + lane] + red[(16 + e) * NL + lane]) + red[(32 + e) * NL + lane]) + red[(48 + e) * NL + lane];
+        v *= p.alpha;
+        if (p.bias) v += p.bias[n];
+        v = apply_act(v, p.act);
+        const size_t o = coff + (size_t)m * p.ldc + n;
+        if (p.c_f32) {
+          float* c = reinterpret_cast<float*>(p.C);
+          c[o] = (p.beta != 0.f) ? v + p.beta * c[o] : v;
+        } else {
+          T* c = reinterpret_cast<T*>(p.C);
+          c[o] = ElemTraits<T>::from_f((p.beta != 0.f) ? v + p.beta * ElemTraits<T>::to_f(c[o]) : v);
+        }
+      }
+    }
+  }
+}
+
+// which kernel tfpp_bgemm runs: 1 = the small-problem kernel above (fp32, few 64 x 64 tiles, a K loop worth splitting), 0 = 64 x 64 tiles
+static int bgemm_variant(const tfpp_bgemm_params& p, int dtype) {
+  static const int on = [] { const char* e = std::getenv("TFPP_BGEMM_KS"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (!on || dtype != TFPP_F32) return 0;
+  const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch0 * p.batch1;
+  return (tiles64 <= 256 && p.K >= 96) ? 1 : 0;
+}
+extern "C" int tfpp_bgemm_variant(const tfpp_bgemm_params* p, int dtype) { return p ? bgemm_variant(*p, dtype) : TFPP_EINVAL; }
+
 template <typename T, bool A_KM, bool B_KM> static int launch_bgemm(const tfpp_bgemm_params& p, hipStream_t st) {
   constexpr int VEC = ElemTraits<T>::VEC;
   auto al = [&](long v) { return (v % VEC) == 0; };
@@ -831,6 +989,13 @@ template <typename T, bool A_KM, bool B_KM> static int launch_bgemm(const tfpp_b
                (((uintptr_t)p.A & 15) == 0) && (((uintptr_t)p.B & 15) == 0);
   vec_ok = vec_ok && (A_KM ? al(p.M) : al(p.K)) && (B_KM ? al(p.N) : al(p.K));
   using C = TileCfg<T, 64, 64, 32, 32>;
+  if constexpr (sizeof(T) == 4) {
+    if (bgemm_variant(p, TFPP_F32) == 1) {
+      hipLaunchKernelGGL((bgemm_ks_kernel<T, A_KM, B_KM>), dim3(cdiv(p.M, 32), cdiv(p.N, 32), p.batch0 * p.batch1), dim3(256), 0, st, p, vec_ok);
+      TFPP_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   dim3 grid(cdiv(p.M, 64), cdiv(p.N, 64), p.batch0 * p.batch1);
   hipLaunchKernelGGL((bgemm_kernel<T, 64, 64, 32, 32, A_KM, B_KM>), grid, dim3(C::NT), 0, st, p, vec_ok);
   TFPP_CHECK_LAUNCH();

@@ -388,6 +388,9 @@ def _fn_label(fn):
 
 _LN_CHECK = os.environ.get('TFPP_DEBUG_LN_CHECK', '0') == '1'
 _SPLIT_PACK = os.environ.get('TFPP_SPLIT_PACK', '1') != '0'  # weight repacking in two launches, the second beside the first layers of forward
+# planning-head Linears on the small-problem batched-GEMM kernel: 0 = never (conv_gemm + split-K / conv_wgrad), 1 = forward, data and weight
+# gradient, 2 = weight gradients only (A/B switch)
+_HEAD_BGEMM = int(os.environ.get('TFPP_HEAD_BGEMM', '0'))  # measured (same box): 0: 26.85, 1: 27.28, 2: 26.95 ms/step
 
 
 def _early_weights(name):
@@ -864,6 +867,9 @@ class Engine:
   def conv(self, x, key, act=ACT_NONE, res=None, x_grad=True, out_f32=False):
     """x: [B,H,W,Cstore] NHWC.  Returns [B,Ho,Wo,n_store]."""
     s = self.specs[key]
+    if (_HEAD_BGEMM == 1 and s.head and s.k == 1 and s.groups == 1 and s.bn is None and res is None and x.dtype == F32 and x.shape[-1] == s.cin_g and
+        s.n_store == s.cout and x.is_cuda):
+      return self.head_linear(x, s, key, act, x_grad)
     B, H, W, Cs = x.shape
     k, st, pd, G = s.k, s.stride, s.pad, s.groups
     Ho, Wo = (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
@@ -922,7 +928,13 @@ class Engine:
             dconv, dres = ops.bn_bwd(dy, y, raw, s.bn.weight.detach(), s.save_mean, s.save_invstd, None, self.g(s.bn.weight),
                                      self.g(s.bn.bias), relu_mask=(act == ACT_RELU), want_dres=res is not None)
         gsrc = dconv if dconv.dtype == x.dtype else ops.cast(dconv, x.dtype)
-        if s.weight.requires_grad:
+        if (_HEAD_BGEMM == 2 and s.head and k == 1 and G == 1 and s.weight.requires_grad and gsrc.dtype == F32 and Cs == s.cin_g and
+            s.n_store == s.cout):
+          # planning-head Linear: dW[n][c] += sum_rows dz[row][n] * x[row][c] as ONE launch of the small-problem kernel (no pixel slices + slice sum)
+          rows_ = B * Ho * Wo
+          self.side.run(Tape.current, lambda: ops.bgemm(gsrc, x, self.g(s.weight).view(s.cout, Cs), M=s.cout, N=Cs, K=rows_, lda=s.n_store, ldb=Cs,
+                                                        ldc=Cs, a_km=True, b_km=True, beta=1.0), gsrc, x)
+        elif s.weight.requires_grad:
           self.side.run(Tape.current, lambda: ops.conv_wgrad(
               gsrc, x, self.g(s.weight), B=B, Hs=H, Ws=W, Cs=Cs, Hd=Ho, Wd=Wo, Cd=s.n_store, R=k, S=k, stride=st, pad=pd, G=G,
               ks_g=Cs // G, n_g=s.n_store // G, c_real=s.cin_g, row_map=s.row_map), gsrc, x)
@@ -940,6 +952,38 @@ class Engine:
         return dx, dres
 
       self.rec([y], [x, res], bwd)
+    return y
+
+  def head_linear(self, x, s, key, act, x_grad):
+    """A Linear of the fp32 planning head (<= 780 rows): forward, data gradient and weight gradient as three launches of the small-problem
+    batched-GEMM kernel (bgemm_ks_kernel: 32 x 32 tiles, K split over the waves of a workgroup) on the parameter as it lies in memory --
+    no split-K second stage, no slice sum, no transposed weight image."""
+    K, N = s.cin_g, s.cout
+    rows = x.numel() // K
+    w = s.weight.detach().view(N, K)
+    y = torch.empty(tuple(x.shape[:-1]) + (N,), device=x.device, dtype=F32)
+    ops.bgemm(x, w, y, M=rows, N=N, K=K, lda=K, ldb=K, ldc=N, bias=None if s.bias is None else s.bias.detach(), act=act)
+    if self.tape is not None:
+
+      def bwd(dy):
+        self.side.label = key
+        self.side.in_tail = False
+        dz = ops.act_bwd(dy, y, act) if act != ACT_NONE else dy
+
+        def param_grads():  # parameter gradients only: weight-gradient lane
+          if s.bias is not None and s.bias.requires_grad:
+            ops.colsum(dz, self.g(s.bias), rows, N, N)
+          if s.weight.requires_grad:  # dW[n][c] += sum_rows dz[row][n] * x[row][c]
+            ops.bgemm(dz, x, self.g(s.weight).view(N, K), M=N, N=K, K=rows, lda=N, ldb=K, ldc=K, a_km=True, b_km=True, beta=1.0)
+
+        self.side.run(Tape.current, param_grads, dz, x)
+        if not x_grad:
+          return None
+        dx = torch.empty(x.shape, device=x.device, dtype=F32)
+        ops.bgemm(dz, w, dx, M=rows, N=K, K=N, lda=N, ldb=K, ldc=K, b_km=True)
+        return dx
+
+      self.rec([y], [x], bwd)
     return y
 
   def linear(self, x, key, act=ACT_NONE, res=None, x_grad=True, out_f32=False):
@@ -1277,13 +1321,19 @@ class Engine:
       n = r1 - r0
 
       def gw(dz, xin):
-        ops.conv_wgrad(dz, xin, self.g(w)[r0:r1], B=rows, Hs=1, Ws=1, Cs=dm, Hd=1, Wd=1, Cd=n, c_real=dm, dw_ld=dm)
+        if _HEAD_BGEMM >= 1:  # dW[r0:r1][c] += sum_rows dz[row][n] * x[row][c]
+          ops.bgemm(dz, xin, self.g(w)[r0:r1], M=n, N=dm, K=rows, lda=n, ldb=dm, ldc=dm, a_km=True, b_km=True, beta=1.0)
+        else:
+          ops.conv_wgrad(dz, xin, self.g(w)[r0:r1], B=rows, Hs=1, Ws=1, Cs=dm, Hd=1, Wd=1, Cd=n, c_real=dm, dw_ld=dm)
 
       def gb(dz):
         ops.colsum(dz, self.g(b)[r0:r1], rows, n, n)
 
       y = torch.empty((rows, n), device=inp.device, dtype=F32)
-      ops.conv_gemm(inp, wd[r0:r1], y, B=rows, Hs=1, Ws=1, Cs=dm, Hd=1, Wd=1, Cd=n, shift=bd[r0:r1])
+      if _HEAD_BGEMM == 1:
+        ops.bgemm(inp, wd[r0:r1], y, M=rows, N=n, K=dm, lda=dm, ldb=dm, ldc=n, bias=bd[r0:r1])
+      else:
+        ops.conv_gemm(inp, wd[r0:r1], y, B=rows, Hs=1, Ws=1, Cs=dm, Hd=1, Wd=1, Cd=n, shift=bd[r0:r1])
       if self.tape is not None:
 
         def bwd(dy):

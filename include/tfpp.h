@@ -148,6 +148,8 @@ typedef struct {
   float beta;           /* C = result + beta*C_old (0: overwrite) */
 } tfpp_bgemm_params;
 int tfpp_bgemm(const tfpp_bgemm_params* p, int dtype, void* stream);
+/* kernel the dispatcher picks for p: 0 = 64 x 64 tiles, 1 = the small-problem kernel (fp32, 32 x 32 tiles, K split over the four waves of a workgroup) */
+int tfpp_bgemm_variant(const tfpp_bgemm_params* p, int dtype);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Fused multi-head self-attention of the fusion transformers (team_code/transfuser.py:362-380: q k^T / sqrt(d) -> softmax ->

@@ -280,6 +280,35 @@ def test_bgemm(ops, case, dtype):
   check('bgemm.' + name, C, want, dtype)
 
 
+KS_CASES = [('linear_fwd', False, False, 132, 768, 256), ('ffn2_fwd', False, False, 132, 256, 2048), ('kv_dgrad', False, True, 780, 256, 512),
+            ('ffn1_wgrad', True, True, 2048, 256, 132), ('kv_wgrad', True, True, 512, 256, 780), ('ragged', False, False, 11, 100, 130),
+            ('tn_ragged', True, False, 40, 96, 200)]
+
+
+@pytest.mark.parametrize('case', KS_CASES, ids=[c[0] for c in KS_CASES])
+def test_bgemm_small_problem_kernel_fp32(ops, case):
+  """The fp32 planning-head products (forward / data gradient / weight gradient of the decoder's Linears) run the 32 x 32-tile kernel whose four
+  waves split K (tfpp_bgemm_variant == 1): every operand layout, ragged edges, bias + activation, and accumulation into C (beta = 1)."""
+  import ctypes
+  from carla_garage_amd._lib import lib, BgemmParams, F32 as F32_
+  name, a_km, b_km, M, N, K = case
+  A = rnd(*((K, M) if a_km else (M, K)), seed=41)
+  Bm = rnd(*((K, N) if b_km else (N, K)), seed=42)
+  bias = rnd(N, seed=43)
+  C0 = rnd(M, N, seed=44)
+  Am = A.t() if a_km else A
+  Bt = Bm if b_km else Bm.t()
+  prm = BgemmParams()
+  prm.M, prm.N, prm.K, prm.batch0, prm.batch1 = M, N, K, 1, 1
+  assert lib.raw('tfpp_bgemm_variant')(ctypes.byref(prm), F32_) == 1
+  C = dev(C0.clone())
+  ops.bgemm(dev(A), dev(Bm), C, M=M, N=N, K=K, lda=A.shape[-1], ldb=Bm.shape[-1], ldc=N, a_km=a_km, b_km=b_km, alpha=1.0, beta=1.0)
+  check('bgemm_ks.acc.' + name, C, Am.double() @ Bt.double() + C0.double(), torch.float32)
+  C = torch.empty((M, N), device=DEV)
+  ops.bgemm(dev(A), dev(Bm), C, M=M, N=N, K=K, lda=A.shape[-1], ldb=Bm.shape[-1], ldc=N, a_km=a_km, b_km=b_km, bias=dev(bias), act=ops.ACT_RELU)
+  check('bgemm_ks.bias_relu.' + name, C, torch.relu(Am.double() @ Bt.double() + bias.double()), torch.float32)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_pack2d(ops, dtype):
   w = rnd(12, 10, seed=31)
