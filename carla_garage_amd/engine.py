@@ -91,7 +91,7 @@ class Lanes:
       return self.main
     st = self.branches.get(k)
     if st is None:
-      st = self.branches[k] = torch.cuda.Stream(self.main.device)
+      st = self.branches[k] = torch.cuda.Stream(self.main.device, priority=-1 if os.environ.get('TFPP_LANE_PRIORITY', '0') == '1' else 0)
     return st
 
   def touch(self, k, ev=None):
@@ -425,6 +425,11 @@ class SideLane:
     self.batch = int(os.environ.get('TFPP_SIDE_BATCH', '128'))
     self.tail_batch = int(os.environ.get('TFPP_SIDE_TAIL_BATCH', str(self.batch)))
     self.in_tail = False
+    self.count = 0
+    fa = os.environ.get('TFPP_SIDE_FLUSH_AT', '')
+    self.flush_at = {int(v) for v in fa.split(',') if v} if fa else None
+    self.forks = [float(v) for v in os.environ.get('TFPP_SIDE_FORKS', '0.43,0.77').split(',') if v and float(v) > 0]
+    self.total_prev = 0  # closures of the previous pass (the eager warm-up in front of a capture counts them)
     self.stream = None
     self.lanes = None  # Lanes of the engine: a batch may hold closures from both encoder-branch streams
     self.keep = []
@@ -451,6 +456,18 @@ class SideLane:
         where = f'{self.label} ' + ' <- '.join(f'{f.name}:{f.lineno}' for f in traceback.extract_stack(limit=5)[:-1][::-1])
         self.checks.append((t, t.double().sum(), t.double().abs().sum(), where))
     self.pending.append(fn)
+    self.count += 1
+    if self.flush_at is None and self.forks and self.total_prev:
+      # fork points as fractions of the pass (the previous pass of this engine counted its closures): round 3 swept them on the bs = 12 step
+      # (334 closures): TWO forks, in the middle of fusion transformer 3's backward (0.43) and when stage 3 of both encoders is done (0.77),
+      # give 26.0 ms/step; any third fork costs ~2 ms, one fork ~2.5 ms, moving the second one 8 closures earlier 1.4 ms (tools/sweep_flush.sh)
+      if self.count in {max(1, int(round(f * self.total_prev))) for f in self.forks}:
+        self.flush()
+      return
+    if self.flush_at is not None:  # explicit fork points (closure counts since the start of the pass) instead of a fixed batch size
+      if self.count in self.flush_at:
+        self.flush()
+      return
     # near the end of backward (stage 1 and the stems: the largest pixel counts, hence the longest weight-gradient kernels) whatever is still
     # queued when the main chain finishes is pure tail: fork in small batches there
     if len(self.pending) >= (self.tail_batch if self.in_tail else self.batch):
@@ -489,6 +506,7 @@ class SideLane:
         self.outs = []
       _release(self.keep)
       self.keep = []
+      self.total_prev, self.count = self.count, 0
 
 
 # BatchNorm-backward sums (sum g, sum g*xhat) produced by the kernel that completes the gradient instead of a separate reduction pass:

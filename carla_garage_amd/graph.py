@@ -13,6 +13,8 @@ import torch
 CAPTURE_MODE = 'thread_local'
 
 _CAPTURE_STREAMS = {}
+import os as _os
+_HIGH_PRIORITY_LANES = _os.environ.get('TFPP_LANE_PRIORITY', '0') == '1'  # main lanes on high-priority streams, the weight-gradient lane on a normal one (A/B switch)
 
 
 def capture_stream(device):
@@ -22,7 +24,7 @@ def capture_stream(device):
   device = torch.device(device)
   st = _CAPTURE_STREAMS.get(str(device))
   if st is None:
-    st = _CAPTURE_STREAMS[str(device)] = torch.cuda.Stream(device)
+    st = _CAPTURE_STREAMS[str(device)] = torch.cuda.Stream(device, priority=-1 if _HIGH_PRIORITY_LANES else 0)
   st.wait_stream(torch.cuda.current_stream(device))
   with torch.cuda.stream(st):
     ops.clone_scratch_for_current_stream(device)
