@@ -1526,33 +1526,6 @@ class Engine:
       lanes.join()
     out['image_feature_grid'], out['fused_features'] = xi, xl
 
-    # BEV feature pyramid (transfuser.py:131-137) with the CenterNet and BEV-semantic heads: 64 x 64 maps, ~25 small launches -> lane 2,
-    # beside the planning head (lane 1) and the full-resolution perspective decoders (lane 0)
-    bev = None
-    out['pred_bev_semantic'] = None
-    out['bb'] = None
-    lanes.hold(xl)
-    with lanes.fork(lanes.head_lane):
-      if cfg.detect_boxes or cfg.use_bev_semantic:
-        p5 = self.conv(xl, 'backbone.c5_conv', act=ACT_RELU)
-        p4 = self.upsample(p5, p5.shape[1] * cfg.bev_upsample_factor, p5.shape[2] * cfg.bev_upsample_factor)
-        p4 = self.conv(p4, 'backbone.up_conv5', act=ACT_RELU)
-        p3 = self.upsample(p4, cfg.lidar_resolution_height // cfg.bev_down_sample_factor,
-                           cfg.lidar_resolution_width // cfg.bev_down_sample_factor)
-        bev = self.conv(p3, 'backbone.up_conv4', act=ACT_RELU)
-      if cfg.use_bev_semantic:
-        y = self.conv(bev, 'bev_semantic_decoder.0', act=ACT_RELU)
-        y = self.conv(y, 'bev_semantic_decoder.2')
-        mask = m.valid_bev_pixels.detach().view(-1)
-        out['pred_bev_semantic'] = self.upsample(y, cfg.lidar_resolution_height, cfg.lidar_resolution_width, mul=mask)
-      if cfg.detect_boxes:
-        bbs = []
-        for br in m.head.BRANCHES:
-          h = self.conv(bev, f'head.{br}_head.0', act=ACT_RELU)
-          bbs.append(self.conv(h, f'head.{br}_head.2', act=ACT_SIGMOID if br == 'heatmap' else ACT_NONE))
-        out['bb'] = bbs
-    out['bev'] = bev
-
     # planning head, fp32 (model.py:299-358)
     # on the LiDAR lane (idle after the backbone): ~250 tiny latency-bound launches that overlap with the dense heads below
     hoist_from = len(self.tape.nodes) if self.tape is not None else 0
@@ -1631,6 +1604,33 @@ class Engine:
 
     if self.tape is not None:
       self.tape.hoist(hoist_from, len(self.tape.nodes))  # backward walks the planning head first (Tape.hoist)
+    # BEV feature pyramid (transfuser.py:131-137) with the CenterNet and BEV-semantic heads: 64 x 64 maps, ~25 small launches -> lane 2,
+    # beside the planning head (lane 1) and the full-resolution perspective decoders (lane 0)
+    bev = None
+    out['pred_bev_semantic'] = None
+    out['bb'] = None
+    lanes.hold(xl)
+    with lanes.fork(lanes.head_lane):
+      if cfg.detect_boxes or cfg.use_bev_semantic:
+        p5 = self.conv(xl, 'backbone.c5_conv', act=ACT_RELU)
+        p4 = self.upsample(p5, p5.shape[1] * cfg.bev_upsample_factor, p5.shape[2] * cfg.bev_upsample_factor)
+        p4 = self.conv(p4, 'backbone.up_conv5', act=ACT_RELU)
+        p3 = self.upsample(p4, cfg.lidar_resolution_height // cfg.bev_down_sample_factor,
+                           cfg.lidar_resolution_width // cfg.bev_down_sample_factor)
+        bev = self.conv(p3, 'backbone.up_conv4', act=ACT_RELU)
+      if cfg.use_bev_semantic:
+        y = self.conv(bev, 'bev_semantic_decoder.0', act=ACT_RELU)
+        y = self.conv(y, 'bev_semantic_decoder.2')
+        mask = m.valid_bev_pixels.detach().view(-1)
+        out['pred_bev_semantic'] = self.upsample(y, cfg.lidar_resolution_height, cfg.lidar_resolution_width, mul=mask)
+      if cfg.detect_boxes:
+        bbs = []
+        for br in m.head.BRANCHES:
+          h = self.conv(bev, f'head.{br}_head.0', act=ACT_RELU)
+          bbs.append(self.conv(h, f'head.{br}_head.2', act=ACT_SIGMOID if br == 'heatmap' else ACT_NONE))
+        out['bb'] = bbs
+    out['bev'] = bev
+
     # auxiliary dense heads
     out['pred_semantic'] = self.perspective_decoder(xi, 'semantic_decoder') if cfg.use_semantic else None
     out['pred_depth'] = self.activation(self.perspective_decoder(xi, 'depth_decoder'), ACT_SIGMOID) if cfg.use_depth else None
