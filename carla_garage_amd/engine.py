@@ -390,6 +390,7 @@ _LN_CHECK = os.environ.get('TFPP_DEBUG_LN_CHECK', '0') == '1'
 _SPLIT_PACK = os.environ.get('TFPP_SPLIT_PACK', '1') != '0'  # weight repacking in two launches, the second beside the first layers of forward
 # planning-head Linears on the small-problem batched-GEMM kernel: 0 = never (conv_gemm + split-K / conv_wgrad), 1 = forward, data and weight
 # gradient, 2 = weight gradients only (A/B switch)
+_SIDE_STREAMS = max(1, int(os.environ.get('TFPP_SIDE_STREAMS', '2')))  # streams the weight-gradient lane alternates between, batch by batch
 _HEAD_BGEMM = int(os.environ.get('TFPP_HEAD_BGEMM', '0'))  # measured (same box): 0: 26.85, 1: 27.28, 2: 26.95 ms/step
 
 
@@ -428,9 +429,10 @@ class SideLane:
     self.count = 0
     fa = os.environ.get('TFPP_SIDE_FLUSH_AT', '')
     self.flush_at = {int(v) for v in fa.split(',') if v} if fa else None
-    self.forks = [float(v) for v in os.environ.get('TFPP_SIDE_FORKS', '0.43,0.77').split(',') if v and float(v) > 0]
+    self.forks = [float(v) for v in os.environ.get('TFPP_SIDE_FORKS', '0.43,0.77,0.95').split(',') if v and float(v) > 0]
     self.total_prev = 0  # closures of the previous pass (the eager warm-up in front of a capture counts them)
     self.stream = None
+    self.streams, self.used, self.batches = [], set(), 0
     self.lanes = None  # Lanes of the engine: a batch may hold closures from both encoder-branch streams
     self.keep = []
     self.pending = []
@@ -446,6 +448,8 @@ class SideLane:
       return
     if self.stream is None:
       self.stream = torch.cuda.Stream(tensors[0].device)
+      self.streams = [self.stream] + [torch.cuda.Stream(tensors[0].device) for _ in range(_SIDE_STREAMS - 1)]
+      self.used = set()
     if not self.keep:
       tape.finalizers.append(self.join)
     for t in tensors:
@@ -475,6 +479,11 @@ class SideLane:
 
   def flush(self):
     if self.pending:
+      # successive batches alternate between the streams of the lane: the last batch of a pass (stage 1 / stems, issued when the main chain is
+      # done) then does not queue behind what is left of the batch before it
+      self.stream = self.streams[self.batches % len(self.streams)]
+      self.batches += 1
+      self.used.add(self.stream)
       self.stream.wait_stream(torch.cuda.current_stream())
       if self.lanes is not None:
         for st in self.lanes.streams():
@@ -489,7 +498,10 @@ class SideLane:
   def join(self):
     if self.keep:
       self.flush()
-      torch.cuda.current_stream().wait_stream(self.stream)
+      for st in self.used:
+        torch.cuda.current_stream().wait_stream(st)
+      self.used = set()
+      self.batches = 0
       if _SIDE_CHECK and self.checks:
         if torch.cuda.is_current_stream_capturing():  # no host read inside a capture: leave device scalars for the caller to compare after a replay
           # bias gradients computed on this lane next to the same column sums recomputed on the caller's stream after the join
