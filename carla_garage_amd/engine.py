@@ -897,7 +897,7 @@ class Engine:
   def conv(self, x, key, act=ACT_NONE, res=None, x_grad=True, out_f32=False):
     """x: [B,H,W,Cstore] NHWC.  Returns [B,Ho,Wo,n_store]."""
     s = self.specs[key]
-    if (_HEAD_BGEMM == 1 and s.head and s.k == 1 and s.groups == 1 and s.bn is None and res is None and x.dtype == F32 and x.shape[-1] == s.cin_g and
+    if ((_HEAD_BGEMM == 1 or (_HEAD_BGEMM == 3 and s.cin_g <= 512 and s.cout <= 1024)) and s.head and s.k == 1 and s.groups == 1 and s.bn is None and res is None and x.dtype == F32 and x.shape[-1] == s.cin_g and
         s.n_store == s.cout and x.is_cuda):
       return self.head_linear(x, s, key, act, x_grad)
     B, H, W, Cs = x.shape
@@ -1351,7 +1351,7 @@ class Engine:
       n = r1 - r0
 
       def gw(dz, xin):
-        if _HEAD_BGEMM >= 1:  # dW[r0:r1][c] += sum_rows dz[row][n] * x[row][c]
+        if _HEAD_BGEMM in (1, 2):  # dW[r0:r1][c] += sum_rows dz[row][n] * x[row][c]
           ops.bgemm(dz, xin, self.g(w)[r0:r1], M=n, N=dm, K=rows, lda=n, ldb=dm, ldc=dm, a_km=True, b_km=True, beta=1.0)
         else:
           ops.conv_wgrad(dz, xin, self.g(w)[r0:r1], B=rows, Hs=1, Ws=1, Cs=dm, Hd=1, Wd=1, Cd=n, c_real=dm, dw_ld=dm)
@@ -1360,7 +1360,7 @@ class Engine:
         ops.colsum(dz, self.g(b)[r0:r1], rows, n, n)
 
       y = torch.empty((rows, n), device=inp.device, dtype=F32)
-      if _HEAD_BGEMM == 1:
+      if _HEAD_BGEMM in (1, 3):
         ops.bgemm(inp, wd[r0:r1], y, M=rows, N=n, K=dm, lda=dm, ldb=dm, ldc=n, bias=bd[r0:r1])
       else:
         ops.conv_gemm(inp, wd[r0:r1], y, B=rows, Hs=1, Ws=1, Cs=dm, Hd=1, Wd=1, Cd=n, shift=bd[r0:r1])

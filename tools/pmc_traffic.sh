@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
   timeout 250 rocprofv3 --pmc $C --kernel-include-regex "$KREGEX" --output-format csv -d /tmp/pmc_$C -- \
-    python $REPO/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-inference --no-roofline > $REPO/gpurun_out/pmc_$C.log 2>&1 || echo "pass $C failed/timeout"
+    python $REPO/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-inference --no-roofline --no-dropin > $REPO/gpurun_out/pmc_$C.log 2>&1 || echo "pass $C failed/timeout"
 done
 python - "$REPO" "$KREGEX" "$FAMILY" "$SRCFILE" <<'PY'
 import csv, glob, hashlib, json, os, sys, time
