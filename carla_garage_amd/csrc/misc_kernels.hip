@@ -190,8 +190,13 @@ template <typename T>
 __global__ void ce_loss_kernel(const T* __restrict__ pred, const long long* __restrict__ label, const float* __restrict__ cw,
                                const float* __restrict__ vis, const float* __restrict__ pix_weight, long pw_bstride, long HW,
                                const float* __restrict__ denom, float denom_eps, const float* __restrict__ ws, float weight,
-                               float* __restrict__ loss_out, T* __restrict__ dpred, long rows, int C, int ld) {
+                               float* __restrict__ loss_out, T* __restrict__ dpred, long rows, int C, int ld, float smoothing) {
   __shared__ float sm[4];
+  // label smoothing (nn.CrossEntropyLoss(weight, label_smoothing), model.py:252-265): per row (1 - a) w[y] nll(y) + a / C sum_c w[c] nll(c),
+  // normalised like the unsmoothed loss by sum_i w[y_i]
+  float wsum = 0.f;
+  if (smoothing > 0.f)
+    for (int c = 0; c < C; ++c) wsum += cw ? cw[c] : 1.f;
   const float den = pix_weight ? (denom[0] + denom_eps) : ws[0];
   const float inv = den > 0.f ? 1.f / den : 0.f;
   float acc = 0.f;
@@ -211,20 +216,29 @@ __global__ void ce_loss_kernel(const T* __restrict__ pred, const long long* __re
       if (pix_weight) w *= pix_weight[(i / HW) * pw_bstride + (i % HW)];
     }
     const float invs = 1.f / s;
+    float smooth_nll = 0.f;
     if (l >= 0) {
       float pl = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) pl = (c == (int)l) ? v[c] * invs : pl;
-      acc += -w * __logf(fmaxf(pl, 1e-38f));
+      acc += -(1.f - smoothing) * w * __logf(fmaxf(pl, 1e-38f));
+      if (smoothing > 0.f) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+          if (c < C) smooth_nll += -(cw ? cw[c] : 1.f) * __logf(fmaxf(v[c] * invs, 1e-38f));
+        acc += smoothing / (float)C * smooth_nll;
+      }
     }
     if (dpred) {
       T* d = dpred + (size_t)i * ld;
-      const float gs = weight * w * inv;
+      const float gs = weight * inv;
+      const float wp = (l >= 0) ? (1.f - smoothing) * w + smoothing / (float)C * wsum : 0.f;  // coefficient of softmax(z)_c
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         if (c < ld) {
           float g = 0.f;
-          if (c < C) g = gs * (v[c] * invs - ((c == (int)l) ? 1.f : 0.f));
+          if (c < C && l >= 0)
+            g = gs * (wp * v[c] * invs - ((c == (int)l) ? (1.f - smoothing) * w : 0.f) - smoothing / (float)C * (cw ? cw[c] : 1.f));
           d[c] = ElemTraits<T>::from_f(g);
         }
       }
@@ -236,8 +250,9 @@ __global__ void ce_loss_kernel(const T* __restrict__ pred, const long long* __re
 
 extern "C" int tfpp_ce_loss(const void* pred, const int64_t* label, const float* class_weight, const float* vis_mask, const float* pix_weight,
                             int64_t pw_bstride, int64_t HW, const float* denom, float denom_eps, float weight, float* loss_out, void* dpred,
-                            float* ws, int64_t rows, int C, int ld, int dtype, void* stream) {
+                            float* ws, int64_t rows, int C, int ld, float smoothing, int dtype, void* stream) {
   if (!pred || !label || !loss_out || !ws || C > 16 || ld > 16 || ld < C || HW < 1 || (pix_weight && !denom)) return TFPP_EINVAL;
+  if (smoothing < 0.f || smoothing >= 1.f || (smoothing > 0.f && pix_weight)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   long blocks = (rows + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -248,9 +263,9 @@ extern "C" int tfpp_ce_loss(const void* pred, const int64_t* label, const float*
     hipLaunchKernelGGL(ce_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const long long*)label, class_weight, vis_mask, (long)HW, ws, (long)rows);
   }
   if (dtype == TFPP_F32)
-    hipLaunchKernelGGL(ce_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (float*)dpred, (long)rows, C, ld);
+    hipLaunchKernelGGL(ce_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (float*)dpred, (long)rows, C, ld, smoothing);
   else
-    hipLaunchKernelGGL(ce_loss_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (bf16_t*)dpred, (long)rows, C, ld);
+    hipLaunchKernelGGL(ce_loss_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (bf16_t*)dpred, (long)rows, C, ld, smoothing);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -386,6 +401,64 @@ extern "C" int tfpp_adamw_amsgrad(float* p, const float* g, float* m, float* v, 
   hipLaunchKernelGGL(adamw_amsgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, (long)n, lr, beta1, beta2,
                      eps, weight_decay, bc1, bc2_sqrt, grad_scale);
   TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// The same update with the step-dependent scalars in DEVICE memory: hyper = {lr, beta1, beta2, eps, weight_decay, grad_scale, bc1, bc2_sqrt}
+// (bc1 = 1 - beta1^step, bc2_sqrt = sqrt(1 - beta2^step), computed by the host exactly as tfpp_adamw_amsgrad computes them).  A launch with
+// constant arguments can sit INSIDE a captured step: the trainer updates the early-finishing two thirds of the parameters on the
+// weight-gradient lane while the rest of backward still runs, and uploads `hyper` before every replay.
+__global__ void adamw_amsgrad_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                         float* __restrict__ vmax, long n, const float* __restrict__ hyper) {
+  const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], wd = hyper[4], grad_scale = hyper[5], bc1 = hyper[6], bc2_sqrt = hyper[7];
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    if (i + 3 < n) {
+      float4 pp = *reinterpret_cast<float4*>(p + i), gg = *reinterpret_cast<const float4*>(g + i), mm = *reinterpret_cast<float4*>(m + i),
+             vv = *reinterpret_cast<float4*>(v + i), xx = *reinterpret_cast<float4*>(vmax + i);
+      float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x; float* xa = &xx.x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gr = ga[e] * grad_scale;
+        pa[e] *= (1.f - lr * wd);
+        ma[e] = beta1 * ma[e] + (1.f - beta1) * gr;
+        va[e] = beta2 * va[e] + (1.f - beta2) * gr * gr;
+        xa[e] = fmaxf(xa[e], va[e]);
+        pa[e] -= (lr / bc1) * ma[e] / (sqrtf(xa[e]) / bc2_sqrt + eps);
+      }
+      *reinterpret_cast<float4*>(p + i) = pp; *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv;
+      *reinterpret_cast<float4*>(vmax + i) = xx;
+    } else {
+      for (long j = i; j < n; ++j) {
+        const float gr = g[j] * grad_scale;
+        float pj = p[j] * (1.f - lr * wd);
+        const float mj = beta1 * m[j] + (1.f - beta1) * gr;
+        const float vj = beta2 * v[j] + (1.f - beta2) * gr * gr;
+        const float xj = fmaxf(vmax[j], vj);
+        pj -= (lr / bc1) * mj / (sqrtf(xj) / bc2_sqrt + eps);
+        p[j] = pj; m[j] = mj; v[j] = vj; vmax[j] = xj;
+      }
+    }
+  }
+}
+
+extern "C" int tfpp_adamw_amsgrad_dev(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, const float* hyper, void* stream) {
+  if (!p || !g || !m || !v || !vmax || !hyper) return TFPP_EINVAL;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) return TFPP_EINVAL;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_amsgrad_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, (long)n, hyper);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// the step-dependent scalars of tfpp_adamw_amsgrad, as it computes them (for the `hyper` vector of tfpp_adamw_amsgrad_dev)
+extern "C" int tfpp_adamw_bias_corrections(float beta1, float beta2, int step, float* bc1_out, float* bc2_sqrt_out) {
+  if (!bc1_out || !bc2_sqrt_out || step < 1) return TFPP_EINVAL;
+  *bc1_out = 1.f - powf(beta1, (float)step);
+  *bc2_sqrt_out = sqrtf(1.f - powf(beta2, (float)step));
   return 0;
 }
 

@@ -148,6 +148,7 @@ class Tape:
     self._rest = []
     self.split_index = None
     self.first = None     # (a, b): nodes recorded in [a, b) are walked FIRST in backward (Tape.hoist)
+    self.on_mark = None   # callback: a single-segment backward has just walked every node recorded after mark() (the early gradients are issued)
     self.finalizers = []  # run once at the end of backward (joins side streams)
     self.uses = {}        # key -> number of recorded nodes that consume the tensor (forward)
     self.contrib = {}     # key -> gradient contributions received so far (backward)
@@ -222,6 +223,7 @@ class Tape:
       a, b = self.first
       todo = todo[:a] + todo[b:] + todo[a:b]  # (_run walks the list backwards)
     self._rest = todo[:split]
+    self._mark_pos = self.split_index if (split == 0 and self.split_index and self.on_mark is not None) else None
     self._run(todo[split:])
     self._join()
     if not self._rest:
@@ -303,7 +305,12 @@ class Tape:
 
   def _run(self, nodes):
     grads, refs, glane, lanes, multi = self._grads, self._refs, self._glane, self.lanes, self._multi
-    for outs, ins, fn, lane in reversed(nodes):
+    mark_pos = getattr(self, '_mark_pos', None)
+    for pos in range(len(nodes) - 1, -1, -1):
+      outs, ins, fn, lane = nodes[pos]
+      if mark_pos is not None and pos == mark_pos - 1:  # everything recorded after mark() has been walked: the early gradients are all issued
+        self._mark_pos = mark_pos = None
+        self.on_mark()
       if not multi:
         lane = 0
       gouts, src = [], []
@@ -433,6 +440,7 @@ class SideLane:
     self.total_prev = 0  # closures of the previous pass (the eager warm-up in front of a capture counts them)
     self.stream = None
     self.streams, self.used, self.batches = [], set(), 0
+    self.after_mark, self.mark_passed = None, False  # hook the trainer arms per step / set by Tape.on_mark
     self.lanes = None  # Lanes of the engine: a batch may hold closures from both encoder-branch streams
     self.keep = []
     self.pending = []
@@ -493,6 +501,14 @@ class SideLane:
         for fn in self.pending:
           fn()
         ops.stamp('side lane9 batch ends')
+        if self.after_mark is not None and self.mark_passed:
+          # (the trainer's optimizer launch for the early-finishing slice of the arena: behind this batch on its stream, and behind the batches
+          # still running on the lane's other streams -- every early gradient was issued before the mark was passed)
+          hook, self.after_mark = self.after_mark, None
+          for st in self.used:
+            if st is not self.stream:
+              self.stream.wait_stream(st)
+          hook()
       self.pending = []
 
   def join(self):

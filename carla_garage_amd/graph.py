@@ -85,6 +85,8 @@ class GraphedTrainStep:
     else:
       with torch.cuda.graph(self.graph, stream=st, capture_error_mode=CAPTURE_MODE):
         self.vals = trainer._step_body(self.static_batch)
+    self.early_opt_in_graph = trainer.early_opt_in_step  # the captured step updates the early slice of the arena itself (trainer._early_optimizer)
+    trainer.early_opt_in_step = False  # (the capture executed nothing)
     torch.cuda.synchronize()
 
   def __call__(self, batch=None):
@@ -95,7 +97,10 @@ class GraphedTrainStep:
         if dst.data_ptr() != src.data_ptr():
           dst.copy_(src, non_blocking=True)
     tr.step_count += 1
+    if self.early_opt_in_graph:
+      tr.upload_hyper(tr.step_count)
     self.graph.replay()
+    tr.early_opt_in_step = self.early_opt_in_graph
     early = None
     if self.graph2 is not None:
       early = tr.reduce_early()

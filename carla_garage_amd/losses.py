@@ -53,6 +53,7 @@ def _one_loss(model, name, t, labels, slot, weight, want_grad, af_sum):
   """Launch the kernel for one loss on internal tensors ``t``; returns (pred_tensor, dpred or None)."""
   cfg = model.config
   dev = slot.device
+  smooth = float(cfg.label_smoothing_alpha) if getattr(cfg, 'use_label_smoothing', False) else 0.0  # model.py:252-265: the three class-weighted CE losses
 
   def grad_like(x):
     return torch.empty_like(x) if want_grad else None
@@ -62,7 +63,7 @@ def _one_loss(model, name, t, labels, slot, weight, want_grad, af_sum):
     d = grad_like(p)
     ws = torch.empty(2, device=dev, dtype=F32)
     ops.ce_loss(p, labels['target_speed_label'], slot, ws, rows=p.shape[0], C=len(cfg.target_speeds), ld=p.shape[1],
-                HW=p.shape[0], class_weight=model.loss_speed.weight, weight=weight, dpred=d)
+                HW=p.shape[0], class_weight=model.loss_speed.weight, weight=weight, dpred=d, smoothing=smooth)
     return p, d
   if name in ('loss_checkpoint', 'loss_wp'):
     p = t['pred_checkpoint'] if name == 'loss_checkpoint' else t['pred_wp']
@@ -76,7 +77,7 @@ def _one_loss(model, name, t, labels, slot, weight, want_grad, af_sum):
     B, H, W, ld = p.shape
     ws = torch.empty(2, device=dev, dtype=F32)
     ops.ce_loss(p, labels['semantic_label'], slot, ws, rows=B * H * W, C=cfg.num_semantic_classes, ld=ld, HW=H * W,
-                class_weight=model.loss_semantic.weight, weight=weight, dpred=d)
+                class_weight=model.loss_semantic.weight, weight=weight, dpred=d, smoothing=smooth)
     return p, d
   if name == 'loss_bev_semantic':
     p = t['pred_bev_semantic']
@@ -84,7 +85,7 @@ def _one_loss(model, name, t, labels, slot, weight, want_grad, af_sum):
     B, H, W, ld = p.shape
     ws = torch.empty(2, device=dev, dtype=F32)
     ops.ce_loss(p, labels['bev_semantic_label'], slot, ws, rows=B * H * W, C=cfg.num_bev_semantic_classes, ld=ld, HW=H * W,
-                class_weight=model.loss_bev_semantic.weight, vis_mask=model.valid_bev_pixels.detach().view(-1), weight=weight, dpred=d)
+                class_weight=model.loss_bev_semantic.weight, vis_mask=model.valid_bev_pixels.detach().view(-1), weight=weight, dpred=d, smoothing=smooth)
     return p, d
   if name == 'loss_depth':
     p = t['pred_depth']  # sigmoid output [B,H,W,8]

@@ -116,12 +116,12 @@ class LidarCenterNet(nn.Module):
 
     # loss modules: containers for the class-weight buffers that live in the reference's state_dict (model.py:243-265)
     sw = torch.tensor(config.target_speed_weights) if config.use_speed_weights else torch.ones(len(config.target_speed_weights))
-    smooth = config.label_smoothing_alpha if config.use_label_smoothing else 0.0
-    if smooth != 0.0 or config.use_focal_loss:
-      raise ValueError('MI355X path: label smoothing / focal speed loss are not implemented (reference defaults are off)')
-    self.loss_speed = nn.CrossEntropyLoss(weight=sw)
-    self.loss_semantic = nn.CrossEntropyLoss(weight=torch.tensor(config.semantic_weights))
-    self.loss_bev_semantic = nn.CrossEntropyLoss(weight=torch.tensor(config.bev_semantic_weights), ignore_index=-1)
+    smooth = config.label_smoothing_alpha if config.use_label_smoothing else 0.0  # applied by the fused CE kernel (losses.py)
+    if config.use_focal_loss:
+      raise ValueError('MI355X path: the focal target-speed loss is not implemented (reference default: off)')
+    self.loss_speed = nn.CrossEntropyLoss(weight=sw, label_smoothing=smooth)
+    self.loss_semantic = nn.CrossEntropyLoss(weight=torch.tensor(config.semantic_weights), label_smoothing=smooth)
+    self.loss_bev_semantic = nn.CrossEntropyLoss(weight=torch.tensor(config.bev_semantic_weights), label_smoothing=smooth, ignore_index=-1)
 
     self.__dict__['engine'] = None  # created lazily, not a sub-module
     self.__dict__['_param_list'] = None

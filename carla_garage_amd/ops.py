@@ -897,9 +897,9 @@ def gru_bwd(dout, save, h0, w_hh, b_hh, w_dec, dw_hh, db_hh, dw_dec, db_dec):
 
 
 def ce_loss(pred, label, loss_out, ws, *, rows, C, ld, HW, class_weight=None, vis_mask=None, pix_weight=None, pw_bstride=0,
-            denom=None, denom_eps=0.0, weight=1.0, dpred=None):
+            denom=None, denom_eps=0.0, weight=1.0, dpred=None, smoothing=0.0):
   lib.tfpp_ce_loss(ptr(pred), ptr(label), ptr(class_weight), ptr(vis_mask), ptr(pix_weight), pw_bstride, HW, ptr(denom), denom_eps,
-                   weight, ptr(loss_out), ptr(dpred), ptr(ws), rows, C, ld, dt(pred), stream())
+                   weight, ptr(loss_out), ptr(dpred), ptr(ws), rows, C, ld, float(smoothing), dt(pred), stream())
 
 
 def reg_loss(pred, target, loss_out, *, B, C, HW, ld, kind, elem_weight=None, wC=1, w_bcast=False, denom=None, denom_eps=0.0,
@@ -911,3 +911,13 @@ def reg_loss(pred, target, loss_out, *, B, C, HW, ld, kind, elem_weight=None, wC
 def adamw_amsgrad(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
   lib.tfpp_adamw_amsgrad(ptr(p), ptr(g), ptr(m), ptr(v), ptr(vmax), p.numel(), lr, beta1, beta2, eps, weight_decay, step, grad_scale,
                          stream())
+
+
+def adamw_amsgrad_dev(p, g, m, v, vmax, hyper):
+  lib.tfpp_adamw_amsgrad_dev(ptr(p), ptr(g), ptr(m), ptr(v), ptr(vmax), p.numel(), ptr(hyper), stream())
+
+
+def adamw_bias_corrections(beta1, beta2, step):
+  a, b = ctypes.c_float(0), ctypes.c_float(0)
+  lib.tfpp_adamw_bias_corrections(float(beta1), float(beta2), int(step), ctypes.byref(a), ctypes.byref(b))
+  return a.value, b.value

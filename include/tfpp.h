@@ -458,7 +458,9 @@ int tfpp_gru_bwd(const float* dout, const float* save, const float* h0, const fl
  *   target[(b*C+c)*HW+pix], elem_weight[(b*wC+(w_bcast?0:c))*HW+pix]; denominator (*denom+denom_eps)*denom_mul or B*C*HW. */
 int tfpp_ce_loss(const void* pred, const int64_t* label, const float* class_weight, const float* vis_mask, const float* pix_weight,
                  int64_t pw_bstride, int64_t HW, const float* denom, float denom_eps, float weight, float* loss_out, void* dpred,
-                 float* ws, int64_t rows, int C, int ld, int dtype, void* stream);
+                 float* ws, int64_t rows, int C, int ld, float label_smoothing, int dtype, void* stream);
+/* label_smoothing a in [0, 1) (nn.CrossEntropyLoss(weight, label_smoothing=a), model.py:252-265; not with pix_weight): per row
+ * (1 - a) w[y] nll(y) + a / C sum_c w[c] nll(c), normalised by sum_rows w[y]. */
 int tfpp_reg_loss(const void* pred, const float* target, const float* elem_weight, int wC, int w_bcast, const float* denom,
                   float denom_eps, float denom_mul, float weight, float* loss_out, void* dpred, int B, int C, int64_t HW, int64_t ld,
                   int kind, int dtype, void* stream);
@@ -468,6 +470,11 @@ int tfpp_reg_loss(const void* pred, const float* target, const float* elem_weigh
  * first (1/world_size after a sum all-reduce). */
 int tfpp_adamw_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1, float beta2,
                        float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* the same update with {lr, beta1, beta2, eps, weight_decay, grad_scale, 1 - beta1^step, sqrt(1 - beta2^step)} read from DEVICE memory, so that
+ * the launch can be part of a captured step (the early-finishing slice of the arena is updated while backward still runs); the host fills
+ * the last two entries with tfpp_adamw_bias_corrections (host function, no launch). */
+int tfpp_adamw_amsgrad_dev(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, const float* hyper, void* stream);
+int tfpp_adamw_bias_corrections(float beta1, float beta2, int step, float* bc1_out, float* bc2_sqrt_out);
 
 #ifdef __cplusplus
 }

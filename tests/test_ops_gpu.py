@@ -1108,6 +1108,30 @@ def test_zero_and_fill_bytes_are_kernels_with_exact_extent(ops):
   assert float(big.sum()) == 7.0 and float(big[:3].sum()) == 3.0
 
 
+@pytest.mark.parametrize('smoothing', [0.0, 0.1])
+def test_ce_loss_label_smoothing_vs_torch(ops, smoothing):
+  """nn.CrossEntropyLoss(weight, label_smoothing, ignore_index=-1) as model.py:252-265 builds it (use_label_smoothing=1): value and gradient of
+  the fused kernel against torch on the CPU, with class weights, ignored rows and channel padding."""
+  g = torch.Generator().manual_seed(77)
+  rows, C, ld = 5000, 7, 8
+  logits = torch.randn(rows, C, generator=g) * 2.0
+  label = torch.randint(0, C, (rows,), generator=g)
+  label[::11] = -1
+  cw = torch.rand(C, generator=g) + 0.5
+  ref_in = logits.clone().requires_grad_(True)
+  want = F.cross_entropy(ref_in, label, weight=cw, ignore_index=-1, label_smoothing=smoothing)
+  want.backward()
+  pred = torch.zeros(rows, ld)
+  pred[:, :C] = logits
+  out = torch.zeros(1, device=DEV)
+  ws = torch.empty(2, device=DEV)
+  dpred = torch.empty((rows, ld), device=DEV)
+  ops.ce_loss(dev(pred), dev(label), out, ws, rows=rows, C=C, ld=ld, HW=rows, class_weight=dev(cw), weight=1.0, dpred=dpred, smoothing=smoothing)
+  check(f'ce_smoothing{smoothing}.loss', out.cpu(), want.detach().reshape(1), torch.float32)
+  check(f'ce_smoothing{smoothing}.grad', dpred[:, :C].cpu(), ref_in.grad, torch.float32)
+  assert float(dpred[:, C:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_uint8_camera_frame_input_equals_the_float_path(ops, dtype):
   """tfpp_u8_to_nhwc_affine: the frame as sensor_agent.py:277-286 holds it after cv2.imdecode (uint8, HWC, BGR) and as the loader collates it
