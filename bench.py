@@ -529,7 +529,7 @@ def main():
     finally:
       trainer.exchange = True
 
-  roof = roof_mfma = None
+  roof = roof_mfma = roof_hbm = roof_fusion = None
   if rank == 0 and rccl_ranks is None and not args.no_roofline:  # per-kernel timing runs extra local steps: single-process runs only
     prof = KernelProfiler()
     lib.profiler = prof
@@ -565,6 +565,11 @@ def main():
     # when the dominant family is itself MFMA-bound
     mf = [(f, x) for f, x in agg.items() if x['flops'] > 0 and (x['bytes'] <= 0 or x['flops'] / x['bytes'] >= ridge)]
     roof_mfma = roof_of(*max(mf, key=lambda fa: fa[1]['ms'])) if mf else None
+    # ... and the dominant HBM-bound GEMM family (the two lead families are within 1 % of each other in time, so which of them is "the"
+    # dominant kernel flips run to run: both are always on the line), plus the north-star kernels by name (fusion-transformer linears)
+    hb = [(f, x) for f, x in agg.items() if x['flops'] > 0 and x['bytes'] > 0 and x['flops'] / x['bytes'] < ridge]
+    roof_hbm = roof_of(*max(hb, key=lambda fa: fa[1]['ms'])) if hb else None
+    roof_fusion = roof_of('conv_gemm<bf16,glds256x128>', agg['conv_gemm<bf16,glds256x128>']) if 'conv_gemm<bf16,glds256x128>' in agg else None
     if args.kernel_table:
       for f, x in sorted(agg.items(), key=lambda fa: -fa[1]['ms']):
         tf = x['flops'] / (x['ms'] * 1e-3) / 1e12 if x['flops'] else 0.0
@@ -649,6 +654,10 @@ def main():
       line['roofline'] = roof
       if roof_mfma is not None and roof_mfma['kernel'] != roof['kernel']:
         line['roofline_mfma'] = roof_mfma
+      if roof_hbm is not None and roof_hbm['kernel'] != roof['kernel']:
+        line['roofline_hbm'] = roof_hbm
+      if roof_fusion is not None and roof_fusion['kernel'] != roof['kernel']:
+        line['roofline_fusion_linears'] = roof_fusion
     if world == 1 and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline()
     print(json.dumps(line), flush=True)

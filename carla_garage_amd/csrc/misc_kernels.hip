@@ -50,12 +50,23 @@ extern "C" int tfpp_gru_fwd(const float* gi, const float* h0, const float* w_hh,
   return 0;
 }
 
-__global__ void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ save, const float* __restrict__ h0,
-                               const float* __restrict__ w_hh, const float* __restrict__ b_hh, const float* __restrict__ w_dec,
-                               float* __restrict__ dgi, float* __restrict__ dh0, float* __restrict__ dw_hh, float* __restrict__ db_hh,
-                               float* __restrict__ dw_dec, float* __restrict__ db_dec, int T, int H) {
+// Backward.  Round 3: the parameter gradients no longer go through atomics (120 adds per address per step, on the first node of the planning head's
+// backward chain: 0.3 ms): every thread keeps "its" row of dW_hh in 64 registers over the T steps, W_hh lies in LDS (row stride H + 1: conflict-free
+// for the row-wise and the column-wise product), each sample writes ONE partial image  part[b] = {dW_hh[3H][H], db_hh[3H], dW_dec[2][H], db_dec[2]}
+// and gru_bwd_reduce_kernel adds the B images in a fixed order (bit-reproducible; it runs on the weight-gradient lane).
+#define GRU_PART(H) (3 * (H) * (H) + 3 * (H) + 2 * (H) + 2)
+__global__ void __launch_bounds__(3 * GRU_MAXH)
+gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ save, const float* __restrict__ h0,
+               const float* __restrict__ w_hh, const float* __restrict__ b_hh, const float* __restrict__ w_dec,
+               float* __restrict__ dgi, float* __restrict__ dh0, float* __restrict__ part, int T, int H) {
+  __shared__ float w[3 * GRU_MAXH * (GRU_MAXH + 1)];
   __shared__ float dh[GRU_MAXH], hp[GRU_MAXH], dgh[3 * GRU_MAXH], ghn[GRU_MAXH], dcum[2], dhn[GRU_MAXH];
-  const int b = blockIdx.x, tid = threadIdx.x;  // 3*H threads
+  const int b = blockIdx.x, tid = threadIdx.x, ldw = H + 1;  // 3*H threads
+  for (int i = tid; i < 3 * H * H; i += 3 * H) w[(i / H) * ldw + (i % H)] = w_hh[i];
+  float acc[GRU_MAXH];
+#pragma unroll
+  for (int k = 0; k < GRU_MAXH; ++k) acc[k] = 0.f;
+  float acc_b = 0.f, acc_d0 = 0.f, acc_d1 = 0.f, acc_bd = 0.f;
   if (tid < H) dh[tid] = 0.f;
   if (tid < 2) dcum[tid] = 0.f;
   __syncthreads();
@@ -68,14 +79,15 @@ __global__ void gru_bwd_kernel(const float* __restrict__ dout, const float* __re
     if (tid < H) {
       const float hn = sv[3 * H + tid];
       dhn[tid] = dh[tid] + w_dec[tid] * dcum[0] + w_dec[H + tid] * dcum[1];
-      atomicAdd(dw_dec + tid, dcum[0] * hn);
-      atomicAdd(dw_dec + H + tid, dcum[1] * hn);
+      acc_d0 += dcum[0] * hn;
+      acc_d1 += dcum[1] * hn;
       // recompute gh_n = W_hn h_{t-1} + b_hn
       float s = b_hh[2 * H + tid];
-      for (int k = 0; k < H; ++k) s += w_hh[(size_t)(2 * H + tid) * H + k] * hp[k];
+      const float* wr = w + (2 * H + tid) * ldw;
+      for (int k = 0; k < H; ++k) s += wr[k] * hp[k];
       ghn[tid] = s;
     }
-    if (tid < 2) atomicAdd(db_dec + tid, dcum[tid]);
+    if (tid < 2) acc_bd += dcum[tid];
     __syncthreads();
     if (tid < H) {
       const float r = sv[tid], z = sv[H + tid], n = sv[2 * H + tid];
@@ -92,27 +104,68 @@ __global__ void gru_bwd_kernel(const float* __restrict__ dout, const float* __re
       dh[tid] = d * z;  // direct path h_{t-1} -> h_t
     }
     __syncthreads();
-    // parameter gradients of the recurrent projection and the gradient w.r.t. h_{t-1}
-    atomicAdd(db_hh + tid, dgh[tid]);
-    for (int k = 0; k < H; ++k) atomicAdd(dw_hh + (size_t)tid * H + k, dgh[tid] * hp[k]);
+    // parameter gradients of the recurrent projection (registers) and the gradient w.r.t. h_{t-1}
+    const float gme = dgh[tid];
+    acc_b += gme;
+#pragma unroll
+    for (int k = 0; k < GRU_MAXH; ++k)
+      if (k < H) acc[k] += gme * hp[k];
     if (tid < H) {
       float s = 0.f;
-      for (int j = 0; j < 3 * H; ++j) s += dgh[j] * w_hh[(size_t)j * H + tid];
+      for (int j = 0; j < 3 * H; ++j) s += dgh[j] * w[j * ldw + tid];
       dh[tid] += s;
     }
     __syncthreads();
   }
   if (tid < H) dh0[(size_t)b * H + tid] = dh[tid];
+  // the partial image of this sample: rows of dW_hh go through LDS (the W_hh copy is dead) so that the global stores are coalesced
+#pragma unroll
+  for (int k = 0; k < GRU_MAXH; ++k)
+    if (k < H) w[tid * ldw + k] = acc[k];
+  __syncthreads();
+  float* pb = part + (size_t)b * GRU_PART(H);
+  for (int i = tid; i < 3 * H * H; i += 3 * H) pb[i] = w[(i / H) * ldw + (i % H)];
+  pb[3 * H * H + tid] = acc_b;
+  if (tid < H) {
+    pb[3 * H * H + 3 * H + tid] = acc_d0;
+    pb[3 * H * H + 3 * H + H + tid] = acc_d1;
+  }
+  if (tid < 2) pb[3 * H * H + 5 * H + tid] = acc_bd;
 }
 
-extern "C" int tfpp_gru_bwd(const float* dout, const float* save, const float* h0, const float* w_hh, const float* b_hh, const float* w_dec,
-                            float* dgi, float* dh0, float* dw_hh, float* db_hh, float* dw_dec, float* db_dec, int B, int T, int H,
-                            void* stream) {
-  if (!dout || !save || !h0 || !w_hh || !b_hh || !w_dec || !dgi || !dh0 || !dw_hh || !db_hh || !dw_dec || !db_dec || H > GRU_MAXH)
-    return TFPP_EINVAL;
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(B), dim3(3 * H), 0, (hipStream_t)stream, dout, save, h0, w_hh, b_hh, w_dec, dgi, dh0, dw_hh, db_hh,
-                     dw_dec, db_dec, T, H);
+// gradient destinations += sum over the B partial images, samples in index order
+__global__ void gru_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw_hh, float* __restrict__ db_hh,
+                                      float* __restrict__ dw_dec, float* __restrict__ db_dec, int B, int H) {
+  const int P = GRU_PART(H), i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += part[(size_t)b * P + i];
+  const int o1 = 3 * H * H, o2 = o1 + 3 * H, o3 = o2 + 2 * H;
+  if (i < o1) dw_hh[i] += s;
+  else if (i < o2) db_hh[i - o1] += s;
+  else if (i < o3) dw_dec[i - o2] += s;
+  else db_dec[i - o3] += s;
+}
+
+extern "C" int tfpp_gru_bwd_partial_floats(int B, int H) { return B * GRU_PART(H); }
+
+extern "C" int tfpp_gru_bwd_reduce(const float* partial, float* dw_hh, float* db_hh, float* dw_dec, float* db_dec, int B, int H, void* stream) {
+  if (!partial || !dw_hh || !db_hh || !dw_dec || !db_dec || H > GRU_MAXH || B < 1) return TFPP_EINVAL;
+  hipLaunchKernelGGL(gru_bwd_reduce_kernel, dim3((GRU_PART(H) + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, dw_hh, db_hh, dw_dec, db_dec, B, H);
   TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// dw_* / db_* may all be null: the caller then runs tfpp_gru_bwd_reduce itself (on another stream, once `partial` is complete)
+extern "C" int tfpp_gru_bwd(const float* dout, const float* save, const float* h0, const float* w_hh, const float* b_hh, const float* w_dec,
+                            float* dgi, float* dh0, float* partial, float* dw_hh, float* db_hh, float* dw_dec, float* db_dec, int B, int T, int H,
+                            void* stream) {
+  if (!dout || !save || !h0 || !w_hh || !b_hh || !w_dec || !dgi || !dh0 || !partial || H > GRU_MAXH || B < 1) return TFPP_EINVAL;
+  const bool any = dw_hh || db_hh || dw_dec || db_dec;
+  if (any && !(dw_hh && db_hh && dw_dec && db_dec)) return TFPP_EINVAL;
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(B), dim3(3 * H), 0, (hipStream_t)stream, dout, save, h0, w_hh, b_hh, w_dec, dgi, dh0, partial, T, H);
+  TFPP_CHECK_LAUNCH();
+  if (any) return tfpp_gru_bwd_reduce(partial, dw_hh, db_hh, dw_dec, db_dec, B, H, stream);
   return 0;
 }
 

@@ -557,6 +557,81 @@ __global__ void layernorm_fwd_kernel(const T* __restrict__ x, const float* __res
   }
 }
 
+// s = a + dropout(b) (written: LayerNorm's backward reads it) and y = LayerNorm(s) in one pass: the post-norm residual step of
+// nn.TransformerDecoderLayer (x = norm(x + dropout(sublayer(x)))).  Dropout: hash, seed and element index (row * C + c) of tfpp_add_dropout.
+template <typename T, int LN_MAXV>
+__global__ void add_layernorm_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ sum, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                         long rows, int C, float eps, float p, float inv_keep, unsigned long long seed,
+                                         const unsigned long long* __restrict__ seed_off) {
+  if (seed_off) seed += *seed_off * 0x9E3779B97F4A7C15ull;
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int CV = C / VEC;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[LN_MAXV][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int cv = lane + k * 64;
+    if (cv < CV) {
+      float bb[VEC];
+      load_vec<T>(a + (size_t)row * C + cv * VEC, v[k]);
+      load_vec<T>(b + (size_t)row * C + cv * VEC, bb);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        if (p > 0.f) bb[e] *= dropout_scale(seed, (unsigned long long)row * C + cv * VEC + e, p, inv_keep);
+        // round the sum to the storage type first: the statistics are those of the tensor the backward (and the unfused path) sees
+        v[k][e] = ElemTraits<T>::to_f(ElemTraits<T>::from_f(bb[e] + v[k][e]));
+        s += v[k][e];
+      }
+      store_vec<T>(sum + (size_t)row * C + cv * VEC, v[k]);
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int cv = lane + k * 64;
+    if (cv < CV) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { const float d = v[k][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) {
+    if (mean_o) mean_o[row] = mean;
+    if (rstd_o) rstd_o[row] = rstd;
+  }
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int cv = lane + k * 64;
+    if (cv < CV) {
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = (v[k][e] - mean) * rstd * gamma[cv * VEC + e] + beta[cv * VEC + e];
+      store_vec<T>(y + (size_t)row * C + cv * VEC, o);
+    }
+  }
+}
+
+extern "C" int tfpp_add_layernorm_fwd(const void* a, const void* b, void* sum, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                      int64_t rows, int C, float eps, float p_drop, uint64_t seed, const uint64_t* seed_offset, int dtype, void* stream) {
+  if (!a || !b || !sum || !y || !gamma || !beta || p_drop < 0.f || p_drop >= 1.f) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int VEC = dtype == TFPP_F32 ? 4 : 8;
+  if (C % VEC || C / VEC > 64 * 6) return TFPP_EINVAL;
+  const int nv = (C / VEC + 63) / 64;
+  const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  dim3 grid((unsigned)((rows + 3) / 4));
+#define ALN_FWD(TT, MV) hipLaunchKernelGGL((add_layernorm_fwd_kernel<TT, MV>), grid, dim3(256), 0, st, (const TT*)a, (const TT*)b, (TT*)sum, gamma, beta, (TT*)y, mean, rstd, (long)rows, C, eps, p_drop, inv_keep, (unsigned long long)seed, (const unsigned long long*)seed_offset)
+#define ALN_FWD_T(TT) do { if (nv <= 1) ALN_FWD(TT, 1); else if (nv <= 2) ALN_FWD(TT, 2); else if (nv <= 3) ALN_FWD(TT, 3); else if (nv <= 4) ALN_FWD(TT, 4); else ALN_FWD(TT, 6); } while (0)
+  if (dtype == TFPP_F32) ALN_FWD_T(float); else ALN_FWD_T(bf16_t);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int tfpp_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int C,
                                   float eps, int dtype, void* stream) {
   if (!x || !y || !gamma || !beta) return TFPP_EINVAL;
@@ -578,7 +653,10 @@ extern "C" int tfpp_layernorm_fwd(const void* x, const float* gamma, const float
 template <typename T, int LN_MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                      const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx, long rows, int C,
-                                     int rows_per_wave, float* __restrict__ dbg) {
+                                     int rows_per_wave, float* __restrict__ dbg, T* __restrict__ dx2, float p, float inv_keep,
+                                     unsigned long long seed, const unsigned long long* __restrict__ seed_off) {
+  // dx2 (nullable): dx times the dropout mask of (seed, row * C + c) -- the gradient of b in  LayerNorm(a + dropout(b))
+  if (dx2 && seed_off) seed += *seed_off * 0x9E3779B97F4A7C15ull;
   constexpr int VEC = ElemTraits<T>::VEC;
   const int CV = C / VEC;
   const int lane = threadIdx.x & 63;
@@ -624,6 +702,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = rs * (g[k][e] - c1 - xh[k][e] * c2);
         store_vec<T>(dx + (size_t)row * C + cv * VEC, o);
+        if (dx2) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)  // (the mask applies to the ROUNDED dx, as the separate add_dropout launch would see it)
+            o[e] = ElemTraits<T>::to_f(ElemTraits<T>::from_f(o[e])) * (p > 0.f ? dropout_scale(seed, (unsigned long long)row * C + cv * VEC + e, p, inv_keep) : 1.f);
+          store_vec<T>(dx2 + (size_t)row * C + cv * VEC, o);
+        }
       }
     }
   }
@@ -665,32 +749,59 @@ extern "C" int tfpp_debug_ln_buffer(float* buf) {
   return 0;
 }
 
-extern "C" int tfpp_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
-                                  float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !dx) return TFPP_EINVAL;
+static int launch_layernorm_param_grad(const void* dy, const void* x, const float* mean, const float* rstd, float* dgamma, float* dbeta, int64_t rows,
+                                       int C, int dtype, hipStream_t st) {
+  long S = rows / 16;
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  const long rpb = (rows + S - 1) / S;
+  dim3 g2((unsigned)((C + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
+  if (dtype == TFPP_F32) hipLaunchKernelGGL(layernorm_param_grad_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, (const float*)x, mean, rstd, dgamma, dbeta, (long)rows, C, rpb);
+  else hipLaunchKernelGGL(layernorm_param_grad_kernel<bf16_t>, g2, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, dgamma, dbeta, (long)rows, C, rpb);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+static int launch_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, void* dx2, float p_drop,
+                                uint64_t seed, const uint64_t* seed_offset, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || p_drop < 0.f || p_drop >= 1.f) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int VEC = dtype == TFPP_F32 ? 4 : 8;
   if (C % VEC || C / VEC > 64 * 6) return TFPP_EINVAL;
   const int nv = (C / VEC + 63) / 64;
-  const int rpw = 1;  // dx: one wave per row, no atomics (parameter gradients come from the column-reduction kernel below)
+  const int rpw = 1;  // dx: one wave per row, no atomics (parameter gradients come from the column-reduction kernel)
   const long waves = (rows + rpw - 1) / rpw;
   dim3 grid((unsigned)((waves + 3) / 4));
   float* dbg = g_ln_debug;  // armed for one launch
   g_ln_debug = nullptr;
-#define LN_BWD(TT, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, MV>), grid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, gamma, mean, rstd, (TT*)dx, (long)rows, C, rpw, dbg)
+  const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+#define LN_BWD(TT, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, MV>), grid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, gamma, mean, rstd, (TT*)dx, (long)rows, C, rpw, dbg, (TT*)dx2, p_drop, inv_keep, (unsigned long long)seed, (const unsigned long long*)seed_offset)
 #define LN_BWD_T(TT) do { if (nv <= 1) LN_BWD(TT, 1); else if (nv <= 2) LN_BWD(TT, 2); else if (nv <= 3) LN_BWD(TT, 3); else if (nv <= 4) LN_BWD(TT, 4); else LN_BWD(TT, 6); } while (0)
   if (dtype == TFPP_F32) LN_BWD_T(float); else LN_BWD_T(bf16_t);
-  if (dgamma || dbeta) {
-    long S = rows / 16;
-    if (S > 64) S = 64;
-    if (S < 1) S = 1;
-    const long rpb = (rows + S - 1) / S;
-    dim3 g2((unsigned)((C + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
-    if (dtype == TFPP_F32) hipLaunchKernelGGL(layernorm_param_grad_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, (const float*)x, mean, rstd, dgamma, dbeta, (long)rows, C, rpb);
-    else hipLaunchKernelGGL(layernorm_param_grad_kernel<bf16_t>, g2, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, dgamma, dbeta, (long)rows, C, rpb);
-  }
   TFPP_CHECK_LAUNCH();
+  if (dgamma || dbeta) return launch_layernorm_param_grad(dy, x, mean, rstd, dgamma, dbeta, rows, C, dtype, st);
   return 0;
+}
+
+extern "C" int tfpp_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                                  float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream) {
+  return launch_layernorm_bwd(dy, x, gamma, mean, rstd, dx, nullptr, 0.f, 0, nullptr, dgamma, dbeta, rows, C, dtype, stream);
+}
+
+// backward of tfpp_add_layernorm_fwd: d_sum (the gradient of a) and d_b = d_sum * dropout mask in one launch; parameter gradients as above
+extern "C" int tfpp_add_layernorm_bwd(const void* dy, const void* sum, const float* gamma, const float* mean, const float* rstd, void* d_sum, void* d_b,
+                                      float* dgamma, float* dbeta, int64_t rows, int C, float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                                      int dtype, void* stream) {
+  if (!d_b) return TFPP_EINVAL;
+  return launch_layernorm_bwd(dy, sum, gamma, mean, rstd, d_sum, d_b, p_drop, seed, seed_offset, dgamma, dbeta, rows, C, dtype, stream);
+}
+
+// the parameter gradients alone (dgamma[c] += sum_r dy * xhat, dbeta[c] += sum_r dy): they only feed the optimizer, so the engine runs them
+// on the weight-gradient lane and keeps the dx kernel alone on the dY chain
+extern "C" int tfpp_layernorm_param_grad(const void* dy, const void* x, const float* mean, const float* rstd, float* dgamma, float* dbeta, int64_t rows,
+                                         int C, int dtype, void* stream) {
+  if (!dy || !x || !mean || !rstd || (!dgamma && !dbeta)) return TFPP_EINVAL;
+  return launch_layernorm_param_grad(dy, x, mean, rstd, dgamma, dbeta, rows, C, dtype, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

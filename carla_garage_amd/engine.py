@@ -203,6 +203,12 @@ class Tape:
     """Split point for a two-segment backward: nodes recorded after this call form the first segment."""
     self.split_index = len(self.nodes)
 
+  def relane(self, a, b, lane):
+    """Backward runs the nodes recorded as a..b-1 on ``lane`` instead of the lane their forward ran on."""
+    for i in range(a, min(b, len(self.nodes))):
+      outs, ins, fn, _ = self.nodes[i]
+      self.nodes[i] = (outs, ins, fn, lane)
+
   def backward(self, seeds, stop_at_mark=False):
     """seeds: list of (tensor, grad).  With ``stop_at_mark`` only the nodes recorded after ``mark()`` are processed (the lanes are
     joined, so every gradient those nodes produce is complete) and ``backward_resume()`` runs the rest -- the trainer all-reduces
@@ -405,6 +411,10 @@ def _early_weights(name):
   """Layers that run before the first fusion point of the default TransFuser backbone (everything else is packed beside them)."""
   return any(name.startswith(p) for p in ('backbone.image_encoder.stem', 'backbone.image_encoder.s1.', 'backbone.lidar_encoder.stem',
                                           'backbone.lidar_encoder.s1.', 'backbone.lidar_channel_to_img.0'))
+_TAIL_ON_MAIN = os.environ.get('TFPP_TAIL_ON_MAIN', '1') != '0'  # backward of LiDAR stage 1 on lane 0 (A/B switch)
+_LN_SIDE = os.environ.get('TFPP_LN_SIDE', '1') != '0'  # LayerNorm parameter gradients on the weight-gradient lane (A/B switch)
+_ADD_LN = os.environ.get('TFPP_ADD_LN', '1') != '0'  # post-norm residual step of the planning decoder as one launch (A/B switch)
+_SMALL_ATTN = os.environ.get('TFPP_SMALL_ATTN', '1') != '0'  # planning-decoder attention as one launch (head_kernels.hip) instead of bgemm -> softmax -> bgemm
 _FINE_EVENTS = os.environ.get('TFPP_FINE_EVENTS', '1') != '0'  # cross-lane gradient dependencies as events instead of stream-level waits (A/B switch)
 LN_KEEP = {}
 _SKIP_SIDE_WORK = os.environ.get('TFPP_DEBUG_SKIP_SIDE_WORK', '0') == '1'
@@ -1065,6 +1075,12 @@ class Engine:
     if self.tape is not None:
 
       def bwd(dy):
+        if not _LN_CHECK and _LN_SIDE:  # dx alone on the dY chain; dgamma / dbeta only feed the optimizer: weight-gradient lane
+          dx = ops.layernorm_bwd(dy, x, ln.weight.detach(), mean, rstd, None, None)
+          self.side.label = 'layernorm'
+          self.side.in_tail = False
+          self.side.run(Tape.current, lambda: ops.layernorm_param_grad(dy, x, mean, rstd, self.g(ln.weight), self.g(ln.bias)), dy, x)
+          return dx
         if not _LN_CHECK:
           return ops.layernorm_bwd(dy, x, ln.weight.detach(), mean, rstd, self.g(ln.weight), self.g(ln.bias))
         # debugging aid (tools/replay_bisect.py): hash every operand before and after the kernel, and run the kernel twice
@@ -1095,6 +1111,26 @@ class Engine:
         return dx
 
       self.rec([y], [x], bwd)
+    return y
+
+  def add_layernorm(self, a, b, p_drop, ln):
+    """LayerNorm(a + dropout(b)) where the sum has no other consumer (post-norm decoder layers): one launch forward, one on the dY chain in
+    backward (+ the parameter gradients on the weight-gradient lane) instead of two and three."""
+    if not _ADD_LN:
+      return self.layernorm(self.add(a, b, p_drop), ln)
+    p = p_drop if self.training else 0.0
+    seed = self.next_seed() if p > 0 else 0
+    y, s, mean, rstd = ops.add_layernorm_fwd(a, b, ln.weight.detach(), ln.bias.detach(), ln.eps, p, seed, save=self.tape is not None)
+    if self.tape is not None:
+
+      def bwd(dy):
+        ds, db = ops.add_layernorm_bwd(dy, s, ln.weight.detach(), mean, rstd, None, None, p, seed)
+        self.side.label = 'layernorm'
+        self.side.in_tail = False
+        self.side.run(Tape.current, lambda: ops.layernorm_param_grad(dy, s, mean, rstd, self.g(ln.weight), self.g(ln.bias)), dy, s)
+        return ds, db
+
+      self.rec([y], [a, b], bwd)
     return y
 
   def add(self, a, b, p_drop=0.0):
@@ -1150,6 +1186,11 @@ class Engine:
       lse = torch.empty(B * nh * tq, device=dev, dtype=F32) if self.tape is not None else None
       ops.attn_fwd(q, k, v, O, lse, p_drop=p, seed=seed, **geo)
       return O, ('fused', lse, O), None, (p, seed)
+    if _SMALL_ATTN and ops.small_attn_supported(tq, tk, d, dt_):  # the planning decoder: one launch per attention (csrc/head_kernels.hip)
+      O = torch.empty((B, tq, out_ld), device=dev, dtype=dt_)
+      P = torch.empty((B, nh, tq, tk), device=dev, dtype=dt_)
+      ops.small_attn_fwd(q, k, v, O, P, B=B, nh=nh, tq=tq, tk=tk, d=d, ld_q=ld_q, ld_kv=ld_kv, ld_o=out_ld, scale=scale, p_drop=p, seed=seed)
+      return O, ('small', P), None, (p, seed)
     S = torch.empty((B, nh, tq, tk), device=dev, dtype=dt_)
     ops.bgemm(q, k, S, M=tq, N=tk, K=d, lda=ld_q, ldb=ld_kv, ldc=tk, batch0=B, batch1=nh, a_bs=(tq * ld_q, d), b_bs=(tk * ld_kv, d),
               c_bs=(nh * tq * tk, tq * tk))
@@ -1168,6 +1209,10 @@ class Engine:
       delta = torch.empty(B * nh * tq, device=dev, dtype=F32)
       ops.attn_bwd(q, k, v, O, lse, dO, dq, dk, dv, delta, B=B, nh=nh, T=tq, d=d, ld_q=ld_q, ld_kv=ld_kv, ld_o=out_ld, scale=scale, p_drop=p,
                    seed=seed)
+      return
+    if isinstance(P, tuple) and P[0] == 'small':
+      ops.small_attn_bwd(q, k, v, P[1], dO, dq, dk, dv, B=B, nh=nh, tq=tq, tk=tk, d=d, ld_q=ld_q, ld_kv=ld_kv, ld_o=out_ld, scale=scale, p_drop=p,
+                         seed=seed)
       return
     # dV = Pd^T dO
     ops.bgemm(Pd, dO, dv, M=tk, N=d, K=tq, lda=tk, ldb=out_ld, ldc=ld_kv, batch0=B, batch1=nh, a_bs=(nh * tq * tk, tq * tk),
@@ -1429,13 +1474,12 @@ class Engine:
     x = query
     for l, layer in enumerate(self.m.join.layers):
       q = f'join.layers.{l}'
-      x = self.layernorm(self.add(x, self.mha(x, None, q + '.self_attn', layer.self_attn, B, tq, tq, True), pd), layer.norm1)
-      x = self.layernorm(self.add(x, self.mha(x, mem, q + '.multihead_attn', layer.multihead_attn, B, tq, tk, False), pd),
-                         layer.norm2)
+      x = self.add_layernorm(x, self.mha(x, None, q + '.self_attn', layer.self_attn, B, tq, tq, True), pd, layer.norm1)
+      x = self.add_layernorm(x, self.mha(x, mem, q + '.multihead_attn', layer.multihead_attn, B, tq, tk, False), pd, layer.norm2)
       h = self.linear(x, q + '.linear1', act=ACT_RELU)
       h = self.dropout(h, pd)
       h = self.linear(h, q + '.linear2')
-      x = self.layernorm(self.add(x, h, pd), layer.norm3)
+      x = self.add_layernorm(x, h, pd, layer.norm3)
     return self.layernorm(x, self.m.join.norm)
 
   def gru_decoder(self, feats, target_point, dec, name, B, T):
@@ -1451,8 +1495,14 @@ class Engine:
     if self.tape is not None:
 
       def bwd(dout):
-        return ops.gru_bwd(dout, save, h0, whh.detach(), bhh.detach(), wdec.detach(), self.g(whh), self.g(bhh), self.g(wdec),
-                           self.g(bdec))
+        # the recurrence's BPTT is the first node of the planning head's backward chain: only dgi / dh0 are produced on it, the per-sample
+        # partial images of the parameter gradients are summed on the weight-gradient lane
+        dgi, dh0, part, reduce = ops.gru_bwd(dout, save, h0, whh.detach(), bhh.detach(), wdec.detach(), self.g(whh), self.g(bhh), self.g(wdec),
+                                             self.g(bdec), defer=True)
+        self.side.label = name + '.gru'
+        self.side.in_tail = False
+        self.side.run(Tape.current, reduce, part)
+        return dgi, dh0
 
       self.rec([out], [gi, h0], bwd)
     return out
@@ -1508,6 +1558,7 @@ class Engine:
           xl = self.conv(xl, 'backbone.lidar_encoder.stem', act=ACT_RELU, x_grad=False)
       xi = self.conv(xi, 'backbone.image_encoder.stem', act=ACT_RELU, x_grad=False)
       for i in range(4):
+        n_lidar = len(self.tape.nodes) if self.tape is not None else 0
         with lanes.fork():
           if self.video:
             xl = self.swin.layer(i, xl)  # [B, 3, H, W, C]
@@ -1517,6 +1568,11 @@ class Engine:
           lt = self.pool_tokens(xl, cfg.lidar_vert_anchors, cfg.lidar_horz_anchors)
           lt = self.conv(lt, f'backbone.lidar_channel_to_img.{i}')
           lt = lt.view(B, nt * lt.shape[1], lt.shape[2], lt.shape[3])  # tokens in (t, h, w) order (transfuser.py:319)
+        if i == 0 and _TAIL_ON_MAIN and self.tape is not None and not self.video:
+          # backward of LiDAR stage 1 on lane 0, behind image stage 1: in the captured step lane 1 does not get to run it before the
+          # weight-gradient batch in flight has drained (tools/lane_timeline.py: 2.4 ms after its inputs are ready), which delays the last
+          # weight-gradient batch -- the tail of the step -- by as much
+          self.tape.relane(n_lidar, len(self.tape.nodes), 0)
         xi = self.stage(xi, f'backbone.image_encoder.s{i + 1}', bb.image_encoder[f's{i + 1}'])
         it = self.pool_tokens(xi, cfg.img_vert_anchors, cfg.img_horz_anchors)
         lanes.join()

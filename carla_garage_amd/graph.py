@@ -75,6 +75,9 @@ class GraphedTrainStep:
     self.split = trainer.overlap_enabled()
     self.graph = torch.cuda.CUDAGraph()
     self.graph2 = None
+    dot = _os.environ.get('TFPP_DEBUG_GRAPH_DOT')  # debugging aid (tools/graph_lists.py): hipGraphDebugDotPrint of the captured step
+    if dot:
+      self.graph.enable_debug_mode()
     st = capture_stream(trainer.eng.device)
     if self.split:
       with torch.cuda.graph(self.graph, stream=st, capture_error_mode=CAPTURE_MODE):
@@ -85,6 +88,8 @@ class GraphedTrainStep:
     else:
       with torch.cuda.graph(self.graph, stream=st, capture_error_mode=CAPTURE_MODE):
         self.vals = trainer._step_body(self.static_batch)
+    if dot:
+      self.graph.debug_dump(dot)
     self.early_opt_in_graph = trainer.early_opt_in_step  # the captured step updates the early slice of the arena itself (trainer._early_optimizer)
     trainer.early_opt_in_step = False  # (the capture executed nothing)
     torch.cuda.synchronize()

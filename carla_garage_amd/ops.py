@@ -685,11 +685,56 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
   return dx
 
 
+def layernorm_param_grad(dy, x, mean, rstd, dgamma, dbeta):
+  c = x.shape[-1]
+  lib.tfpp_layernorm_param_grad(ptr(_chk(dy)), ptr(_chk(x)), ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), x.numel() // c, c, dt(x), stream())
+
+
+def add_layernorm_fwd(a, b, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, save=True):
+  """sum = a + dropout(b); y = LayerNorm(sum).  Returns (y, sum, mean, rstd)."""
+  c = a.shape[-1]
+  rows = a.numel() // c
+  y, s = torch.empty_like(a), torch.empty_like(a)
+  mean = torch.empty(rows, device=a.device, dtype=torch.float32) if save else None
+  rstd = torch.empty(rows, device=a.device, dtype=torch.float32) if save else None
+  lib.tfpp_add_layernorm_fwd(ptr(_chk(a)), ptr(_chk(b)), ptr(s), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, c, eps, p_drop, seed,
+                             ptr(SEED_OFFSET), dt(a), stream())
+  return y, s, mean, rstd
+
+
+def add_layernorm_bwd(dy, s, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, seed=0):
+  """Returns (d_sum, d_b): the gradients of a and b in LayerNorm(a + dropout(b))."""
+  c = s.shape[-1]
+  ds, db = torch.empty_like(s), torch.empty_like(s)
+  lib.tfpp_add_layernorm_bwd(ptr(_chk(dy)), ptr(_chk(s)), ptr(gamma), ptr(mean), ptr(rstd), ptr(ds), ptr(db), ptr(dgamma), ptr(dbeta), s.numel() // c, c,
+                             p_drop, seed, ptr(SEED_OFFSET), dt(s), stream())
+  return ds, db
+
+
 def softmax_fwd(x, rows, cols, ld, alpha=1.0, p_drop=0.0, seed=0):
   """In place; returns (P, P_dropped) -- the same tensor when p_drop == 0."""
   pd = torch.empty_like(x) if p_drop > 0.0 else None
   lib.tfpp_softmax_fwd(ptr(x), ptr(pd), rows, cols, ld, alpha, p_drop, seed, ptr(SEED_OFFSET), dt(x), stream())
   return x, (pd if pd is not None else x)
+
+
+def small_attn_supported(tq, tk, d, dtype):
+  return dtype == torch.float32 and bool(lib.raw('tfpp_small_attn_supported')(tq, tk, d))
+
+
+def small_attn_fwd(q, k, v, o, p_save, *, B, nh, tq, tk, d, ld_q, ld_kv, ld_o, scale, p_drop=0.0, seed=0):
+  """Attention core of the fp32 planning decoder as one launch (csrc/head_kernels.hip)."""
+  if lib.profiler is not None:
+    lib.profiler.tag('small_attn_fwd<f32>', 4.0 * B * nh * tq * tk * d)
+  lib.tfpp_small_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(p_save), B, nh, tq, tk, d, ld_q, ld_kv, ld_o, scale, p_drop, seed, ptr(SEED_OFFSET), stream())
+  return o
+
+
+def small_attn_bwd(q, k, v, p_save, d_o, dq, dk, dv, *, B, nh, tq, tk, d, ld_q, ld_kv, ld_o, scale, p_drop=0.0, seed=0):
+  if lib.profiler is not None:
+    lib.profiler.tag('small_attn_bwd<f32>', 10.0 * B * nh * tq * tk * d)
+  lib.tfpp_small_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(p_save), ptr(_chk(d_o)), ptr(dq), ptr(dk), ptr(dv), B, nh, tq, tk, d, ld_q, ld_kv, ld_o, scale,
+                          p_drop, seed, ptr(SEED_OFFSET), stream())
 
 
 def softmax_bwd(p, dp, rows, cols, ld, alpha=1.0, p_drop=0.0, seed=0):
@@ -887,13 +932,19 @@ def gru_fwd(gi, h0, w_hh, b_hh, w_dec, b_dec):
   return out, save
 
 
-def gru_bwd(dout, save, h0, w_hh, b_hh, w_dec, dw_hh, db_hh, dw_dec, db_dec):
+def gru_bwd(dout, save, h0, w_hh, b_hh, w_dec, dw_hh, db_hh, dw_dec, db_dec, defer=False):
+  """defer=True: the parameter gradients are left as per-sample partial images; returns (dgi, dh0, partial, reduce) and the caller runs
+  ``reduce()`` on whatever stream it likes once ``partial`` is complete there."""
   b, t, _, h = save.shape
   dgi = torch.empty((b, t, 3 * h), device=save.device, dtype=torch.float32)
   dh0 = torch.empty((b, h), device=save.device, dtype=torch.float32)
-  lib.tfpp_gru_bwd(ptr(_chk(dout)), ptr(save), ptr(h0), ptr(w_hh), ptr(b_hh), ptr(w_dec), ptr(dgi), ptr(dh0), ptr(dw_hh), ptr(db_hh),
-                   ptr(dw_dec), ptr(db_dec), b, t, h, stream())
-  return dgi, dh0
+  part = torch.empty(int(lib.raw('tfpp_gru_bwd_partial_floats')(b, h)), device=save.device, dtype=torch.float32)
+  dst = (None,) * 4 if defer else (dw_hh, db_hh, dw_dec, db_dec)
+  lib.tfpp_gru_bwd(ptr(_chk(dout)), ptr(save), ptr(h0), ptr(w_hh), ptr(b_hh), ptr(w_dec), ptr(dgi), ptr(dh0), ptr(part), *(ptr(x) for x in dst),
+                   b, t, h, stream())
+  if not defer:
+    return dgi, dh0
+  return dgi, dh0, part, lambda: lib.tfpp_gru_bwd_reduce(ptr(part), ptr(dw_hh), ptr(db_hh), ptr(dw_dec), ptr(db_dec), b, h, stream())
 
 
 def ce_loss(pred, label, loss_out, ws, *, rows, C, ld, HW, class_weight=None, vis_mask=None, pix_weight=None, pw_bstride=0,

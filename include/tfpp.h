@@ -408,6 +408,17 @@ int tfpp_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
                        float eps, int dtype, void* stream);
 int tfpp_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                        float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
+/* layernorm_param_grad: the dgamma / dbeta part of layernorm_bwd alone (the engine runs it on the weight-gradient lane).
+ * add_layernorm_fwd: sum = a + dropout(b) and y = LayerNorm(sum) in one launch -- the post-norm residual step of
+ *   nn.TransformerDecoderLayer (model.py:137-143); dropout mask of tfpp_add_dropout (seed, flat element index).
+ * add_layernorm_bwd: d_sum = LayerNorm backward (= gradient of a) and d_b = d_sum * the same mask, one launch. */
+int tfpp_layernorm_param_grad(const void* dy, const void* x, const float* mean, const float* rstd, float* dgamma, float* dbeta, int64_t rows,
+                              int C, int dtype, void* stream);
+int tfpp_add_layernorm_fwd(const void* a, const void* b, void* sum, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                           int64_t rows, int C, float eps, float p_drop, uint64_t seed, const uint64_t* seed_offset, int dtype, void* stream);
+int tfpp_add_layernorm_bwd(const void* dy, const void* sum, const float* gamma, const float* mean, const float* rstd, void* d_sum, void* d_b,
+                           float* dgamma, float* dbeta, int64_t rows, int C, float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                           int dtype, void* stream);
 int tfpp_softmax_fwd(void* x, void* pd, int64_t rows, int cols, int64_t ld, float alpha, float p_drop, uint64_t seed, const uint64_t* seed_offset, int dtype,
                      void* stream);
 int tfpp_softmax_bwd(const void* p, void* dp_inout, int64_t rows, int cols, int64_t ld, float alpha, float p_drop, uint64_t seed, const uint64_t* seed_offset,
@@ -439,13 +450,35 @@ int tfpp_debug_ln_buffer(float* buf);
 int tfpp_stamp(uint64_t* slot, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Attention core of the fp32 planning decoder (nn.MultiheadAttention inside nn.TransformerDecoderLayer, model.py:137-146,352: 11 / 8
+ * queries against themselves or 65 memory tokens, 8 heads of 32): softmax(scale * q k^T) -> dropout -> @ v as ONE launch, one workgroup
+ * per (sample, head), instead of batched GEMM -> softmax -> batched GEMM (and ONE launch instead of five in backward).  tq <= 16,
+ * tk <= 96, d <= 32 (tfpp_small_attn_supported).  q / k / v / o and their gradients: element (b, t, h, e) at base + (b*T + t)*ld + h*d + e.
+ * p_save [B*nh*tq][tk]: the probabilities before dropout, written by forward, read by backward.  Dropout masks: hash, seed and element
+ * index of tfpp_softmax_fwd (row * tk + key), so both paths draw the same masks. */
+int tfpp_small_attn_supported(int tq, int tk, int d);
+int tfpp_small_attn_fwd(const float* q, const float* k, const float* v, float* o, float* p_save, int B, int nh, int tq, int tk, int d,
+                        int64_t ld_q, int64_t ld_kv, int64_t ld_o, float scale, float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                        void* stream);
+int tfpp_small_attn_bwd(const float* q, const float* k, const float* v, const float* p_save, const float* d_o, float* dq, float* dk,
+                        float* dv, int B, int nh, int tq, int tk, int d, int64_t ld_q, int64_t ld_kv, int64_t ld_o, float scale,
+                        float p_drop, uint64_t seed, const uint64_t* seed_offset, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * GRU waypoint / checkpoint decoder (model.py:857-867): h0 = enc(target_point); nn.GRU(256->64) over T steps;
  * Linear 64->2; cumsum over time.  gi = x W_ih^T + b_ih comes from tfpp_conv_gemm; these kernels run the
  * recurrence and its BPTT, fp32.  save: [B,T,4,H] = (r,z,n,h). */
 int tfpp_gru_fwd(const float* gi, const float* h0, const float* w_hh, const float* b_hh, const float* w_dec, const float* b_dec,
                  float* save, float* out, int B, int T, int H, void* stream);
+/* Backward: one workgroup per sample writes dgi / dh0 and ONE partial image of the parameter gradients into partial[b]
+ * (tfpp_gru_bwd_partial_floats(B, H) floats in all; no atomics); tfpp_gru_bwd_reduce adds the B images to the gradient
+ * destinations in sample order.  With dw_hh .. db_dec given tfpp_gru_bwd launches the reduce itself on the same stream; with all
+ * four null the caller runs it later (the engine: on the weight-gradient lane). */
 int tfpp_gru_bwd(const float* dout, const float* save, const float* h0, const float* w_hh, const float* b_hh, const float* w_dec,
-                 float* dgi, float* dh0, float* dw_hh, float* db_hh, float* dw_dec, float* db_dec, int B, int T, int H, void* stream);
+                 float* dgi, float* dh0, float* partial, float* dw_hh, float* db_hh, float* dw_dec, float* db_dec, int B, int T, int H,
+                 void* stream);
+int tfpp_gru_bwd_reduce(const float* partial, float* dw_hh, float* db_hh, float* dw_dec, float* db_dec, int B, int H, void* stream);
+int tfpp_gru_bwd_partial_floats(int B, int H); /* returns the count (not an error code) */
 
 /* ---------------------------------------------------------------------------------------------------------
  * Losses (model.py:394-445, center_net.py:77-123, transfuser_utils.py:341-364).  Each call adds the (unweighted)

@@ -97,7 +97,7 @@ def _trainer_schedule_worker(rank, world, port, out):
   events = []
   tr = Trainer.__new__(Trainer)
   tr.model = types.SimpleNamespace(train=lambda: None)
-  tr.pg, tr.world, tr.step_count, tr.exchange, tr._lazy_state = None, world, 0, True, False
+  tr.pg, tr.world, tr.step_count, tr.exchange, tr._lazy_state, tr.early_opt_in_step = None, world, 0, True, False, False
   tr.eng = types.SimpleNamespace(flat_grad=torch.zeros(n), early_offset=off, invalidate=lambda: None)
   mine = torch.arange(n, dtype=torch.float32) * (rank + 1)
 
@@ -112,7 +112,8 @@ def _trainer_schedule_worker(rank, world, port, out):
     tr.eng.flat_grad[:off] = mine[:off]
     events.append('segment2')
 
-  def optimizer(step, grad_scale=None):
+  def optimizer(step, grad_scale=None, upto=None):
+    assert upto is None
     events.append('optimizer')
     tr.seen = tr.eng.flat_grad.clone()
     tr.scale = 1.0 / tr.world if grad_scale is None else grad_scale

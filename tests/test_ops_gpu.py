@@ -588,6 +588,35 @@ def test_layernorm(ops, dtype, C):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('p_drop', [0.0, 0.1])
+def test_add_dropout_layernorm_fused_equals_the_two_launches(ops, dtype, p_drop):
+  """tfpp_add_layernorm_fwd / _bwd (post-norm residual step of the planning decoder) against tfpp_add_dropout -> tfpp_layernorm_fwd and
+  tfpp_layernorm_bwd -> tfpp_add_dropout on the same seed: same masks, so everything is compared exactly where the arithmetic is the same
+  and to rounding otherwise; tfpp_layernorm_param_grad against the parameter gradients tfpp_layernorm_bwd produces."""
+  rows, C, seed = 132, 256, 31337
+  a, b = dev(rnd(rows, C, dtype=dtype, seed=75) * 2.0, dtype), dev(rnd(rows, C, dtype=dtype, seed=76), dtype)
+  g, be = dev(rnd(C, seed=77, lo=0.5, hi=1.5)), dev(rnd(C, seed=78))
+  s2 = ops.add_dropout(a, b, p_drop, seed)
+  y2, mean2, rstd2 = ops.layernorm_fwd(s2, g, be)
+  y, s, mean, rstd = ops.add_layernorm_fwd(a, b, g, be, 1e-5, p_drop, seed)
+  assert torch.equal(s, s2)
+  if p_drop > 0:
+    kept = float(((s.float() - a.float()).abs() > 0).float().mean())
+    assert abs(kept - 0.9) < 0.03, kept
+  assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2) and torch.equal(y, y2)
+  dy = dev(rnd(rows, C, dtype=dtype, seed=79), dtype)
+  dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+  ds2 = ops.layernorm_bwd(dy, s2, g, mean2, rstd2, dg2, db2)
+  dh2 = ops.add_dropout(None, ds2, p_drop, seed) if p_drop > 0 else ds2
+  ds, dh = ops.add_layernorm_bwd(dy, s, g, mean, rstd, None, None, p_drop, seed)
+  assert torch.equal(ds, ds2) and torch.equal(dh, dh2)
+  dg, db = torch.full((C,), 0.5, device=DEV), torch.full((C,), 0.5, device=DEV)
+  ops.layernorm_param_grad(dy, s, mean, rstd, dg, db)
+  check('ln_param_grad.dgamma', dg - 0.5, dg2.cpu(), torch.float32, scale=3.0)   # (atomic accumulation order: equal to rounding)
+  check('ln_param_grad.dbeta', db - 0.5, db2.cpu(), torch.float32, scale=3.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('cols', [320, 65, 11])
 def test_softmax_and_dropout(ops, dtype, cols):
   rows, alpha = 150, 0.37
@@ -667,13 +696,20 @@ def test_gru(ops):
   check('gru.fwd', pred, want, torch.float32, scale=5.0)
   dout = rnd(B, T, 2, seed=103)
   want.backward(dout)
-  gr = [torch.zeros_like(d(t)) for t in (gru.weight_hh_l0, gru.bias_hh_l0, dec.weight, dec.bias)]
+  gr = [torch.full_like(d(t), 0.25) for t in (gru.weight_hh_l0, gru.bias_hh_l0, dec.weight, dec.bias)]   # the destinations are accumulated into
   dgi, dh0 = ops.gru_bwd(d(dout), save, d(h0), d(gru.weight_hh_l0), d(gru.bias_hh_l0), d(dec.weight), *gr)
   check('gru.dh0', dh0, h0.grad, torch.float32, scale=10.0)
-  check('gru.dw_hh', gr[0], gru.weight_hh_l0.grad, torch.float32, scale=10.0)
-  check('gru.db_hh', gr[1], gru.bias_hh_l0.grad, torch.float32, scale=10.0)
-  check('gru.dw_dec', gr[2], dec.weight.grad, torch.float32, scale=10.0)
-  check('gru.db_dec', gr[3], dec.bias.grad, torch.float32, scale=10.0)
+  check('gru.dw_hh', gr[0] - 0.25, gru.weight_hh_l0.grad, torch.float32, scale=10.0)
+  check('gru.db_hh', gr[1] - 0.25, gru.bias_hh_l0.grad, torch.float32, scale=10.0)
+  check('gru.dw_dec', gr[2] - 0.25, dec.weight.grad, torch.float32, scale=10.0)
+  check('gru.db_dec', gr[3] - 0.25, dec.bias.grad, torch.float32, scale=10.0)
+  # deferred form (the engine's: the sum of the per-sample partial images runs later, on the weight-gradient lane): bit-identical, twice
+  for _ in range(2):
+    gr2 = [torch.full_like(g, 0.25) for g in gr]
+    dgi2, dh02, part, reduce = ops.gru_bwd(d(dout), save, d(h0), d(gru.weight_hh_l0), d(gru.bias_hh_l0), d(dec.weight), *gr2, defer=True)
+    assert all(float((g - 0.25).abs().max()) == 0.0 for g in gr2)   # nothing written before reduce()
+    reduce()
+    assert torch.equal(dgi2, dgi) and torch.equal(dh02, dh0) and all(torch.equal(a, b) for a, b in zip(gr, gr2))
   check('gru.dgi->dx', dgi.cpu() @ gru.weight_ih_l0.detach(), xr.grad, torch.float32, scale=10.0)
   check('gru.dgi->db_ih', dgi.cpu().sum((0, 1)), gru.bias_ih_l0.grad, torch.float32, scale=10.0)
 
@@ -873,6 +909,82 @@ def test_fused_attention_dropout_matches_the_unfused_path(ops):
   got = dqkv.float().cpu().view(B, T, 3, nh, dp)
   for i, (name, ref) in enumerate((('dq', qr.grad), ('dk', kr.grad), ('dv', vr.grad))):
     check(f'attn_dropout.{name}', got[:, :, i].permute(0, 2, 1, 3), ref, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize('shape', [(12, 11, 11, True), (12, 11, 65, False), (3, 8, 65, False), (2, 16, 96, False), (1, 1, 1, True)],
+                         ids=['self11', 'cross11x65', 'wp8x65', 'max16x96', 'one'])
+@pytest.mark.parametrize('p_drop', [0.0, 0.1])
+def test_small_attention_of_the_planning_decoder(ops, shape, p_drop):
+  """tfpp_small_attn_fwd / _bwd (one launch each) against torch autograd in fp64 on the CPU, and -- with dropout -- against the
+  bgemm -> softmax(+dropout) -> bgemm path they replace (identical masks: same hash, seed and element index).  The operands are the
+  strided views the engine passes: self-attention reads q | k | v out of one [B*T, 3*dm] matrix, cross-attention q out of [B*tq, dm] and
+  k | v out of [B*tk, 2*dm]."""
+  B, tq, tk, self_attn = shape
+  nh, d = 8, 32
+  dm = nh * d
+  scale, seed = 1.0 / math.sqrt(d), 977
+  if self_attn:
+    qkv = rnd(B * tq, 3 * dm, seed=11)
+    qkv_d = dev(qkv)
+    qd, kd, vd = qkv_d.view(-1)[0:], qkv_d.view(-1)[dm:], qkv_d.view(-1)[2 * dm:]
+    ld_q = ld_kv = 3 * dm
+    q, k, v = (qkv[:, i * dm:(i + 1) * dm].reshape(B, tq, nh, d).permute(0, 2, 1, 3) for i in range(3))
+  else:
+    qq, kv = rnd(B * tq, dm, seed=12), rnd(B * tk, 2 * dm, seed=13)
+    qq_d, kv_d = dev(qq), dev(kv)
+    qd, kd, vd = qq_d.view(-1), kv_d.view(-1)[0:], kv_d.view(-1)[dm:]
+    ld_q, ld_kv = dm, 2 * dm
+    q = qq.reshape(B, tq, nh, d).permute(0, 2, 1, 3)
+    k, v = (kv[:, i * dm:(i + 1) * dm].reshape(B, tk, nh, d).permute(0, 2, 1, 3) for i in range(2))
+  assert ops.small_attn_supported(tq, tk, d, torch.float32)
+  geo = dict(B=B, nh=nh, tq=tq, tk=tk, d=d, ld_q=ld_q, ld_kv=ld_kv, ld_o=dm, scale=scale)
+  O = torch.full((B, tq, dm), 7.0, device=DEV)
+  P = torch.full((B, nh, tq, tk), 7.0, device=DEV)
+  ops.small_attn_fwd(qd, kd, vd, O, P, p_drop=p_drop, seed=seed, **geo)
+  qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+  Pw = F.softmax(qr @ kr.transpose(-1, -2) * scale, -1)
+  check('small_attn.p', P, Pw.detach().float(), torch.float32)
+  M = torch.ones(B, nh, tq, tk, dtype=torch.float64)
+  if p_drop > 0:  # the masks of the path it replaces
+    S = torch.empty((B, nh, tq, tk), device=DEV)
+    ops.bgemm(qd, kd, S, M=tq, N=tk, K=d, lda=ld_q, ldb=ld_kv, ldc=tk, batch0=B, batch1=nh, a_bs=(tq * ld_q, d), b_bs=(tk * ld_kv, d), c_bs=(nh * tq * tk, tq * tk))
+    P2, Pd2 = ops.softmax_fwd(S, B * nh * tq, tk, tk, alpha=scale, p_drop=p_drop, seed=seed)
+    O2 = torch.empty_like(O)
+    ops.bgemm(Pd2, vd, O2, M=tq, N=d, K=tk, lda=tk, ldb=ld_kv, ldc=dm, batch0=B, batch1=nh, a_bs=(nh * tq * tk, tq * tk), b_bs=(tk * ld_kv, d),
+              c_bs=(tq * dm, d), b_km=True)
+    check('small_attn.fwd_vs_unfused', O, O2.cpu(), torch.float32)
+    M = (Pd2 != 0).double().cpu() / (1.0 - p_drop)
+    if B * nh * tq * tk > 2000:
+      assert abs(float((Pd2 != 0).float().mean()) - 0.9) < 0.03
+  want = ((Pw * M) @ vr).permute(0, 2, 1, 3).reshape(B, tq, dm)
+  check('small_attn.fwd', O, want.detach().float(), torch.float32)
+  dO = rnd(B, tq, dm, seed=14)
+  want.backward(dO.double())
+  if self_attn:
+    dqkv = torch.full_like(qkv_d, 5.0)
+    dq, dk, dv = dqkv.view(-1)[0:], dqkv.view(-1)[dm:], dqkv.view(-1)[2 * dm:]
+  else:
+    dqq, dkv = torch.full_like(qq_d, 5.0), torch.full_like(kv_d, 5.0)
+    dq, dk, dv = dqq.view(-1), dkv.view(-1)[0:], dkv.view(-1)[dm:]
+  ops.small_attn_bwd(qd, kd, vd, P, dev(dO), dq, dk, dv, p_drop=p_drop, seed=seed, **geo)
+  if self_attn:
+    got = dqkv.cpu().view(B, tq, 3, nh, d)
+    gq, gk, gv = (got[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+  else:
+    gq = dqq.cpu().view(B, tq, nh, d).permute(0, 2, 1, 3)
+    gk, gv = (dkv.cpu().view(B, tk, 2, nh, d)[:, :, i].permute(0, 2, 1, 3) for i in range(2))
+  for name, g, ref in (('dq', gq, qr.grad), ('dk', gk, kr.grad), ('dv', gv, vr.grad)):
+    check(f'small_attn.{name}', g, ref.float(), torch.float32, scale=3.0)
+
+
+def test_small_attention_rejects_what_it_does_not_cover(ops):
+  assert not ops.small_attn_supported(17, 65, 32, torch.float32)
+  assert not ops.small_attn_supported(11, 97, 32, torch.float32)
+  assert not ops.small_attn_supported(11, 65, 33, torch.float32)
+  assert not ops.small_attn_supported(11, 65, 32, torch.bfloat16)
+  x = torch.zeros(64 * 1024, device=DEV)
+  with pytest.raises(Exception):
+    ops.small_attn_fwd(x, x, x, x, x, B=1, nh=8, tq=17, tk=65, d=32, ld_q=256, ld_kv=512, ld_o=256, scale=1.0)
 
 
 def test_fused_attention_rejects_what_it_does_not_cover(ops):
