@@ -148,6 +148,7 @@ class Tape:
     self._rest = []
     self.split_index = None
     self.first = None     # (a, b): nodes recorded in [a, b) are walked FIRST in backward (Tape.hoist)
+    self.on_finish = None  # callback: the whole backward pass (both segments) has been issued
     self.on_mark = None   # callback: a single-segment backward has just walked every node recorded after mark() (the early gradients are issued)
     self.finalizers = []  # run once at the end of backward (joins side streams)
     self.uses = {}        # key -> number of recorded nodes that consume the tensor (forward)
@@ -376,6 +377,8 @@ class Tape:
     ops.stamp('bwd lane0 all lanes joined')
 
   def _finish(self):
+    if self.on_finish is not None:
+      self.on_finish()
     if self._multi:
       _release(self.lanes.held)
       self.lanes.held = []
@@ -452,6 +455,7 @@ class SideLane:
     self.streams, self.used, self.batches = [], set(), 0
     self.after_mark, self.mark_passed = None, False  # hook the trainer arms per step / set by Tape.on_mark
     self.lanes = None  # Lanes of the engine: a batch may hold closures from both encoder-branch streams
+    self.wplan = ops.WgradReducePlan()  # the slice sums of a batch's pixel-split weight gradients as one launch at the batch end
     self.keep = []
     self.pending = []
     self.checks = []
@@ -508,8 +512,13 @@ class SideLane:
           self.stream.wait_stream(st)
       with torch.cuda.stream(self.stream):
         ops.stamp(f'side lane9 batch of {len(self.pending)} begins')
-        for fn in self.pending:
-          fn()
+        ops.WGRAD_PLAN = self.wplan  # the slice sums of this batch's weight gradients: one launch at its end (ops.WgradReducePlan)
+        try:
+          for fn in self.pending:
+            fn()
+          self.wplan.flush()
+        finally:
+          ops.WGRAD_PLAN = None
         ops.stamp('side lane9 batch ends')
         if self.after_mark is not None and self.mark_passed:
           # (the trainer's optimizer launch for the early-finishing slice of the arena: behind this batch on its stream, and behind the batches
@@ -1516,6 +1525,9 @@ class Engine:
     bb = m.backbone
     out = {}
     self._bn_of, self._bn_pre = {}, {}
+    if self.tape is not None:
+      self.side.wplan.begin_pass()
+      self.tape.on_finish = self.side.wplan.end_pass
     if ops.NODE_HASH['on'] and self.tape is not None:
       ops.node_hash_begin(dev)
       LN_KEEP['armed'] = True

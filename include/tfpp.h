@@ -122,6 +122,13 @@ typedef struct {
   int64_t ws_floats;
 } tfpp_wgrad_params;
 int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stream);
+/* The second stage (slice sum) of MANY tfpp_conv_wgrad calls in one launch: the caller issues the first stages with
+ * tfpp_conv_wgrad_stage(p, dtype, 1, ...) giving every call its OWN workspace region and an explicit `splits`, keeps a device copy of
+ * those parameter blocks (descs_dev[n]) and the running sum blk_prefix_dev[n + 1] of ceil(G*n_g*R*S*ks_g / 32) workgroups per call, and
+ * sums any contiguous range of calls [i0, i1) with base = blk_prefix[i0], blocks = blk_prefix[i1] - blk_prefix[i0].  Per element the same
+ * arithmetic whatever the batching. */
+int tfpp_wgrad_reduce_multi(const tfpp_wgrad_params* descs_dev, const int64_t* blk_prefix_dev, int n, int64_t base, int64_t blocks,
+                            void* stream);
 /* Preferred workspace of one call in bytes (the library never allocates): the size at which the dispatcher's plan is not
  * limited by the workspace.  op 0: split-K slices of tfpp_conv_gemm (params = tfpp_conv_params, field splitk_ws); op 1: pixel slices of
  * tfpp_conv_wgrad (params = tfpp_wgrad_params, field ws); op 2 / 3: BatchNorm / column-sum scratch for C = *(const int*)params channels.

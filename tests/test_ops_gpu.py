@@ -141,6 +141,70 @@ def test_conv_fwd_dgrad_wgrad(ops, case, dtype):
   _conv_case(ops, case, dtype)
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_batched_slice_sums_equal_the_per_call_second_stage(ops, dtype):
+  """ops.WgradReducePlan (the weight-gradient lane's batching of the slice sums): pass 0 is recorded and runs every call the ordinary way;
+  passes 1-3 issue the first stages into their own workspace regions and ONE tfpp_wgrad_reduce_multi per batch -- in batches of different
+  sizes.  Same gradients (to summation-order rounding against pass 0, bit-identical among the batched passes whatever the batching), gradient
+  destinations accumulated into, and a call sequence that differs from the record falls back to the ordinary path."""
+  cases = [  # B, H, W, Cin, Cout, k, stride, G
+      (4, 32, 64, 72, 72, 1, 1, 1), (2, 24, 40, 72, 72, 3, 1, 3), (2, 16, 64, 216, 216, 1, 1, 1), (2, 18, 20, 48, 48, 3, 2, 2),
+      (2, 12, 40, 32, 32, 3, 1, 1), (300, 1, 1, 72, 72, 1, 1, 1), (1, 8, 80, 1512, 1512, 1, 1, 1), (3, 16, 16, 64, 256, 1, 1, 1)]
+  probs = []
+  for i, (B, H, W, Cin, Cout, k, st, G) in enumerate(cases):
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+    x = dev(rnd(B, H, W, Cin, dtype=dtype, seed=300 + i), dtype)
+    dy = dev(rnd(B, Ho, Wo, Cout, dtype=dtype, seed=400 + i), dtype)
+    dw = torch.zeros((Cout, Cin // G, k, k), device=DEV, dtype=torch.float32)
+    probs.append((dy, x, dw, dict(B=B, Hs=H, Ws=W, Cs=Cin, Hd=Ho, Wd=Wo, Cd=Cout, R=k, S=k, stride=st, pad=pad, G=G)))
+  plans = [ops.conv_wgrad_plan(dy, x, dw, **geo) for dy, x, dw, geo in probs]
+  assert sum(1 for pl in plans if pl[2]) >= 5 and len({pl[0] for pl in plans}) >= 2, plans  # several kernels, most with a second stage
+  plan = ops.WgradReducePlan()
+  plan.enabled, plan.every = True, 0   # (off by default in the engine: measured neutral to slower, see ops.WgradReducePlan)
+
+  def run_pass(batches, fill, order=None):
+    plan.begin_pass()
+    for _, _, dw, _ in probs:
+      dw.fill_(fill)
+    todo = list(order if order is not None else range(len(probs)))
+    for nb in batches:
+      ops.WGRAD_PLAN = plan
+      try:
+        for j in todo[:nb]:
+          dy, x, dw, geo = probs[j]
+          ops.conv_wgrad(dy, x, dw, **geo)
+        plan.flush()
+      finally:
+        ops.WGRAD_PLAN = None
+      todo = todo[nb:]
+    plan.end_pass()
+    torch.cuda.synchronize()
+    return [dw.clone() for _, _, dw, _ in probs]
+
+  ref = run_pass([len(probs)], 0.0)            # recorded, ordinary path; end_pass turns the record into the plan
+  assert plan.ready and len(plan.entries) == len(probs) and plan.stats['batched'] == 0
+  got1 = run_pass([len(probs)], 0.0)           # one batch
+  assert plan.cursor == len(probs) and plan.stats['batched'] == plan.stats['reduce_entries']
+  got2 = run_pass([3, 1, 4], 0.0)              # three batches
+  got3 = run_pass([1] * len(probs), 0.5)       # one call per batch, destinations pre-filled
+  for a, b1, b2, b3 in zip(ref, got1, got2, got3):
+    scale = float(a.abs().max())
+    assert float((a - b1).abs().max()) <= 2e-5 * scale + 1e-6
+    assert torch.equal(b1, b2)
+    assert float((b3 - 0.5 - b1).abs().max()) <= 2e-6 * scale + 1e-6
+  # another call sequence than the recorded one: ordinary path for the rest of the pass, then the plan is learned again
+  got4 = run_pass([len(probs)], 0.0, order=[1, 0] + list(range(2, len(probs))))
+  assert plan.broken
+  for a, b in zip(ref, got4):
+    assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-6
+  run_pass([len(probs)], 0.0)
+  assert plan.ready and not plan.broken and len(plan.entries) == len(probs) and plan.stats['builds'] == 2
+  got5 = run_pass([4, 4], 0.0)
+  for b1, b5 in zip(got1, got5):
+    assert torch.equal(b1, b5)
+
+
 # The shapes the benchmark (BASELINE config 3: bs = 12, bf16) actually runs, with the kernel variants it runs them on.
 # tfpp_conv_gemm_variant: 202 = 16-wave 256x128 LDS-DMA ring (K >= 1024, >= 128 tiles), 200 = 8-wave 128x128 (>= 256 tiles), 201 = 64x128,
 # 2 = LDS-staged 64x64 ...

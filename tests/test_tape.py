@@ -141,3 +141,20 @@ def test_take_pending_consumes_an_unshared_gradient(cpu_ops):
   t.backward([(y1, torch.ones(3)), (y2, torch.ones(3))])
   assert torch.equal(seen['pend'], torch.full((3,), 3.0)) and torch.equal(seen['dx'], torch.full((3,), 5.0))
   assert cpu_ops['axpy'] == 0 and cpu_ops['add'] == 0  # no separate accumulation pass
+
+
+def test_relane_changes_only_the_lane_backward_runs_a_node_on(cpu_ops):
+  """Tape.relane (engine: backward of LiDAR stage 1 runs on lane 0): the nodes keep outputs, inputs and closure; on one stream (CPU) the
+  gradients are those of the unchanged tape."""
+  x = torch.arange(6, dtype=torch.float32).view(2, 3) / 7
+  tape = E.Tape()
+  z, got = _toy(tape, x)
+  before = [(o, i, f) for o, i, f, _ in tape.nodes]
+  tape.nodes = [(o, i, f, 1) for o, i, f, _ in tape.nodes]     # as if recorded on a branch lane
+  tape.relane(1, 3, 0)
+  assert [n[3] for n in tape.nodes] == [1, 0, 0, 1, 1]
+  assert all(a[0] is b[0] and a[1] is b[1] and a[2] is b[2] for a, b in zip(before, tape.nodes))
+  tape.relane(3, 99, 0)                                        # a range past the end is clipped
+  assert [n[3] for n in tape.nodes] == [1, 0, 0, 0, 0]
+  tape.backward([(z, torch.ones_like(z))])
+  torch.testing.assert_close(got['x'], _want(x))
