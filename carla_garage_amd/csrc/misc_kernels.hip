@@ -408,11 +408,15 @@ extern "C" int tfpp_sum_f32(const float* x, float* out, int64_t n, void* stream)
 // AdamW with amsgrad (torch.optim.AdamW semantics, train.py:529-531) over a flat fp32 arena
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void adamw_amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                     float* __restrict__ vmax, long n, float lr, float beta1, float beta2, float eps, float wd, float bc1,
-                                     float bc2_sqrt, float grad_scale) {
+                                     float* __restrict__ vmax, long n, float lr, float beta1, float beta2, float eps, float wd_all, float bc1,
+                                     float bc2_sqrt, float grad_scale, const unsigned* __restrict__ no_decay) {
+  // no_decay (nullable): one bit per group of 4 consecutive elements of the arena (every parameter starts on a multiple of 4): set = this
+  // parameter is in the weight_decay = 0 group of create_optimizer_groups (model.py:556-632: biases, norms, embeddings, queries)
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * blockDim.x * 4;
   for (; i < n; i += stride) {
+    const long q = i >> 2;
+    const float wd = (no_decay && ((no_decay[q >> 5] >> (q & 31)) & 1u)) ? 0.f : wd_all;
     if (i + 3 < n) {
       float4 pp = *reinterpret_cast<float4*>(p + i), gg = *reinterpret_cast<const float4*>(g + i), mm = *reinterpret_cast<float4*>(m + i),
              vv = *reinterpret_cast<float4*>(v + i), xx = *reinterpret_cast<float4*>(vmax + i);
@@ -442,8 +446,24 @@ __global__ void adamw_amsgrad_kernel(float* __restrict__ p, const float* __restr
   }
 }
 
+static int launch_adamw(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, const unsigned* no_decay, void* stream);
+
 extern "C" int tfpp_adamw_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1, float beta2,
                                   float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  return launch_adamw(p, g, m, v, vmax, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, stream);
+}
+
+// Two parameter groups (team_code/train.py:522-523, use_optim_groups): elements whose bit in no_decay_bits (one bit per 4 elements, p must be the
+// start of the arena the bits were built for) is set take weight_decay = 0, the others `weight_decay`.
+extern "C" int tfpp_adamw_amsgrad_groups(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1, float beta2,
+                                         float eps, float weight_decay, int step, float grad_scale, const uint32_t* no_decay_bits, void* stream) {
+  if (!no_decay_bits) return TFPP_EINVAL;
+  return launch_adamw(p, g, m, v, vmax, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, no_decay_bits, stream);
+}
+
+static int launch_adamw(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, const unsigned* no_decay, void* stream) {
   if (!p || !g || !m || !v || !vmax || step < 1) return TFPP_EINVAL;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) return TFPP_EINVAL;
   const float bc1 = 1.f - powf(beta1, (float)step);
@@ -452,7 +472,7 @@ extern "C" int tfpp_adamw_amsgrad(float* p, const float* g, float* m, float* v, 
   if (blocks > 16384) blocks = 16384;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_amsgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, (long)n, lr, beta1, beta2,
-                     eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+                     eps, weight_decay, bc1, bc2_sqrt, grad_scale, no_decay);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

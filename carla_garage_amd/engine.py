@@ -406,7 +406,9 @@ _LN_CHECK = os.environ.get('TFPP_DEBUG_LN_CHECK', '0') == '1'
 _SPLIT_PACK = os.environ.get('TFPP_SPLIT_PACK', '1') != '0'  # weight repacking in two launches, the second beside the first layers of forward
 # planning-head Linears on the small-problem batched-GEMM kernel: 0 = never (conv_gemm + split-K / conv_wgrad), 1 = forward, data and weight
 # gradient, 2 = weight gradients only (A/B switch)
-_SIDE_STREAMS = max(1, int(os.environ.get('TFPP_SIDE_STREAMS', '2')))  # streams the weight-gradient lane alternates between, batch by batch
+# streams the weight-gradient lane alternates between, batch by batch; measured on the bs = 12 captured step (A/B/A/B, one box): 2: 24.38 / 24.43,
+# 3: 24.03 / 24.02, 4 (every batch of the default three forks on its own stream): 23.76 / 23.99 ms/step
+_SIDE_STREAMS = max(1, int(os.environ.get('TFPP_SIDE_STREAMS', '4')))
 _HEAD_BGEMM = int(os.environ.get('TFPP_HEAD_BGEMM', '0'))  # measured (same box): 0: 26.85, 1: 27.28, 2: 26.95 ms/step
 
 

@@ -1085,9 +1085,30 @@ def reg_loss(pred, target, loss_out, *, B, C, HW, ld, kind, elem_weight=None, wC
                     ptr(loss_out), ptr(dpred), B, C, HW, ld, kind, dt(pred), stream())
 
 
-def adamw_amsgrad(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+def adamw_amsgrad(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, no_decay_bits=None):
+  """no_decay_bits (int32 device tensor from no_decay_bitmask; p must start at the arena's first element): the weight_decay = 0 group of
+  create_optimizer_groups."""
+  if no_decay_bits is not None:
+    lib.tfpp_adamw_amsgrad_groups(ptr(p), ptr(g), ptr(m), ptr(v), ptr(vmax), p.numel(), lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                                  ptr(no_decay_bits), stream())
+    return
   lib.tfpp_adamw_amsgrad(ptr(p), ptr(g), ptr(m), ptr(v), ptr(vmax), p.numel(), lr, beta1, beta2, eps, weight_decay, step, grad_scale,
                          stream())
+
+
+def no_decay_bitmask(slices, no_decay_ids, total):
+  """Host side of tfpp_adamw_amsgrad_groups: slices = [(offset, numel, id(param))] of an arena of ``total`` elements whose parameters all start
+  on multiples of 4; returns the int32 words (numpy) with one bit per group of 4 elements, set for the parameters in ``no_decay_ids`` (their
+  padding elements included)."""
+  import numpy as np
+  groups = (total + 3) // 4
+  bits = np.zeros((groups + 31) // 32 * 32, dtype=bool)
+  for off, n, pid in slices:
+    assert off % 4 == 0
+    if pid in no_decay_ids:
+      bits[off // 4:(off + n + 3) // 4] = True
+  words = np.packbits(bits.reshape(-1, 32), axis=1, bitorder='little').view('<u4').reshape(-1)
+  return words.astype(np.uint32).view(np.int32)
 
 
 def adamw_amsgrad_dev(p, g, m, v, vmax, hyper):

@@ -51,10 +51,14 @@ class FlatAdamW(torch.optim.Optimizer):
       plan = self._plan = self._arenas()
     arenas, loose = plan
     for tr, members in arenas.items():
-      groups = {id(g): g for g, _ in members}
-      if len(groups) != 1:
-        raise NotImplementedError('FlatAdamW: the parameters of one model must share one parameter group (use_optim_groups=0, team_code/config.py:263)')
-      group = next(iter(groups.values()))
+      groups = [g for g in self.param_groups if any(getattr(p, '_tfpp_arena', (None,))[0] is tr for p in g['params'])]
+      group = groups[0]
+      if len(groups) > 1:
+        # use_optim_groups (train.py:522-523): the groups of create_optimizer_groups -- one hyper-parameter set, weight decay per group
+        for g in groups[1:]:
+          if (float(g['lr']), tuple(g['betas']), float(g['eps'])) != (float(group['lr']), tuple(group['betas']), float(group['eps'])):
+            raise NotImplementedError('FlatAdamW: the parameter groups of one model share lr / betas / eps (they differ in weight_decay only)')
+      tr.set_groups([g['params'] for g in groups], [g['weight_decay'] for g in groups])
       if len(members) != len(tr._slices_cached()):
         raise ValueError('FlatAdamW: every trainable parameter of the model must be optimised by the same optimizer (the fused kernel updates the whole arena)')
       if self._pending_state is not None:
@@ -72,7 +76,7 @@ class FlatAdamW(torch.optim.Optimizer):
           ops.zero_(slot)  # (torch skips such a parameter; the fused kernel decays it -- every parameter of this model receives a gradient)
         elif g.data_ptr() != slot.data_ptr():
           ops.copy_rows(g.detach().float().contiguous(), slot, 1, slot.numel(), 0, 0, 0, 0)
-      tr.lr, tr.betas, tr.eps, tr.weight_decay = float(group['lr']), tuple(group['betas']), float(group['eps']), float(group['weight_decay'])
+      tr.lr, tr.betas, tr.eps = float(group['lr']), tuple(group['betas']), float(group['eps'])  # (the weight decay(s): set_groups above)
       tr.step_count += 1
       tr._optimizer(tr.step_count, grad_scale=1.0)
     for group, p in loose:
@@ -91,28 +95,34 @@ class FlatAdamW(torch.optim.Optimizer):
   # ---------------------------------------------------------------------------------------------- checkpoint / resume
   def state_dict(self):
     arenas, loose = self._arenas()
-    if len(arenas) == 1 and not loose and len(self.param_groups) == 1:
+    if len(arenas) == 1 and not loose:
       tr = next(iter(arenas))
       g = self.param_groups[0]
-      tr.lr, tr.betas, tr.eps, tr.weight_decay = float(g['lr']), tuple(g['betas']), float(g['eps']), float(g['weight_decay'])
-      sd = tr.state_dict()  # torch.optim.AdamW's layout, keyed by the position in model.parameters() (trainer.py)
-      for k, v in g.items():  # keys the LR schedulers add to the group (initial_lr, ...)
-        if k != 'params' and k not in sd['param_groups'][0]:
-          sd['param_groups'][0][k] = v
+      tr.lr, tr.betas, tr.eps = float(g['lr']), tuple(g['betas']), float(g['eps'])
+      tr.set_groups([x['params'] for x in self.param_groups], [x['weight_decay'] for x in self.param_groups])
+      sd = tr.state_dict()  # torch.optim.AdamW's layout: positions in model.parameters() (one group) / group after group (trainer.py)
+      for x, out in zip(self.param_groups, sd['param_groups']):
+        for k, v in x.items():  # keys the LR schedulers add to the group (initial_lr, ...)
+          if k != 'params' and k not in out:
+            out[k] = v
       return sd
     if not arenas and self._pending_state is not None:
       return self._pending_state
     if not arenas:  # before the first training step: no state yet
       return {'state': {}, 'param_groups': [{**{k: v for k, v in g.items() if k != 'params'}, 'params': list(range(len(g['params'])))} for g in self.param_groups]}
-    raise NotImplementedError('FlatAdamW.state_dict: one model, one parameter group')
+    raise NotImplementedError('FlatAdamW.state_dict: the parameters of one model')
 
   def load_state_dict(self, state_dict):
     arenas, _ = self._arenas()
-    g = state_dict['param_groups'][0]
-    for k, v in g.items():
-      if k != 'params':
-        self.param_groups[0][k] = v
+    if len(state_dict['param_groups']) != len(self.param_groups):
+      raise ValueError(f"loaded state dict has {len(state_dict['param_groups'])} parameter groups, the optimizer {len(self.param_groups)}")
+    for g, mine in zip(state_dict['param_groups'], self.param_groups):
+      for k, v in g.items():
+        if k != 'params':
+          mine[k] = v
     if len(arenas) == 1:
-      next(iter(arenas)).load_state_dict(state_dict)
+      tr = next(iter(arenas))
+      tr.set_groups([x['params'] for x in self.param_groups], [x['weight_decay'] for x in self.param_groups])
+      tr.load_state_dict(state_dict)
     else:
       self._pending_state = state_dict  # applied by the first step(), when the arenas exist

@@ -25,8 +25,6 @@ class Trainer:
     """lazy_state: allocate the three optimizer-state arenas on the first optimizer launch (the drop-in path of dropin.py owns a Trainer
     for its flat arenas and gradient exchange; the 1.4 GB of AdamW state is only needed when the fused optimizer is the one stepping)."""
     self.model = model
-    if getattr(model.config, 'use_optim_groups', False) and not lazy_state:
-      raise NotImplementedError('MI355X trainer: one AdamW parameter group (team_code/config.py:263 default use_optim_groups=False)')
     prev = model.__dict__.get('_trainer')
     if prev is not None and prev is not self:
       prev.detached = True  # the parameters move into THIS trainer's arena: the previous owner's arena is stale from here on
@@ -45,6 +43,13 @@ class Trainer:
     self.loss_names = active_losses(model.config)
     self.loss_weights = normalized_loss_weights(model.config)
     self._flatten()
+    # parameter groups (team_code/train.py:522-523): None = one group; else the ordered parameter lists of the groups and their weight decays --
+    # the fused kernel supports ONE non-zero decay plus a weight_decay = 0 group (create_optimizer_groups, model.py:556-632) through a bit per
+    # 4 arena elements
+    self.groups, self.no_decay_bits = None, None
+    if getattr(model.config, 'use_optim_groups', False) and not lazy_state:
+      gr = model.create_optimizer_groups(weight_decay)
+      self.set_groups([g['params'] for g in gr], [g['weight_decay'] for g in gr])
     self.seed_offset = ops.zeros(1, torch.int64, self.eng.device)  # advanced once per step (fresh dropout masks under replay)
     ops.set_seed_offset(self.seed_offset)
     # optimizer scalars in device memory (tfpp_adamw_amsgrad_dev): lets the update of the early-finishing slice of the arena run INSIDE the step
@@ -116,7 +121,7 @@ class Trainer:
     eng._seed_ctr = 0  # the per-call part of the seeds is a function of the call site only
     eng.tape = Tape(eng.lanes)
     self.early_opt_in_step = False
-    if _EARLY_OPT and not split and not self.overlap_enabled() and eng.side.enabled and self._hyper_host is not None:
+    if _EARLY_OPT and not split and not self.overlap_enabled() and eng.side.enabled and self._hyper_host is not None and self.no_decay_bits is None:
       # single GPU: nothing has to be exchanged first, so the two thirds of the parameters whose gradients are final once backward has passed
       # Tape.mark() are updated on the weight-gradient lane while the stages 3..1 are still being differentiated
       eng.tape.on_mark = self._arm_early_optimizer
@@ -160,6 +165,39 @@ class Trainer:
       h[i] = v
     self.hyper.copy_(h, non_blocking=True)
 
+  def set_groups(self, param_lists, weight_decays):
+    """The optimizer's parameter groups in order (lists of parameters, frozen ones included as torch numbers them) and their weight decays:
+    at most one non-zero value.  One group (or equal decays) = the plain kernel."""
+    wds = [float(w) for w in weight_decays]
+    nz = sorted({w for w in wds if w != 0.0})
+    if len(nz) > 1:
+      raise NotImplementedError(f'fused AdamW: one non-zero weight decay plus a weight_decay = 0 group (got {sorted(set(wds))})')
+    key = (tuple(tuple(id(p) for p in pl) for pl in param_lists), tuple(wds))
+    if getattr(self, '_groups_key', None) == key:
+      return
+    self._groups_key = key
+    if len(param_lists) == 1 or len(set(wds)) == 1:
+      self.groups, self.no_decay_bits = (None if len(param_lists) == 1 else [list(pl) for pl in param_lists]), None
+      self.group_decays = wds
+      self.weight_decay = wds[0]
+      return
+    self.groups, self.group_decays = [list(pl) for pl in param_lists], wds
+    self.weight_decay = nz[0] if nz else 0.0
+    no_decay = {id(p) for pl, w in zip(param_lists, wds) if w == 0.0 for p in pl}
+    words = ops.no_decay_bitmask([(off, p.numel(), id(p)) for _, off, p in self._slices_cached()], no_decay, int(self.flat_param.numel()))
+    self.no_decay_bits = torch.from_numpy(words.copy()).to(self.eng.device)
+
+  def _group_index(self):
+    """{id(param): position in the optimizer's numbering} (torch numbers the parameters group after group); None = model.parameters() order."""
+    if self.groups is None:
+      return None
+    out, i = {}, 0
+    for pl in self.groups:
+      for p in pl:
+        out[id(p)] = i
+        i += 1
+    return out
+
   def _optimizer(self, step, grad_scale=None, upto=None):
     """grad_scale: None = 1 / world (the arena holds the SUM over the ranks); the drop-in path passes 1.0 (already averaged).
     upto: only the first ``upto`` elements of the arena (the rest was updated inside the step, _early_optimizer)."""
@@ -167,7 +205,8 @@ class Trainer:
     self.eng.invalidate()
     sl = slice(None) if upto is None else slice(0, upto)
     ops.adamw_amsgrad(self.flat_param[sl], self.eng.flat_grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.max_exp_avg_sq[sl], self.lr, self.betas[0],
-                      self.betas[1], self.eps, self.weight_decay, step, grad_scale=1.0 / self.world if grad_scale is None else grad_scale)
+                      self.betas[1], self.eps, self.weight_decay, step, grad_scale=1.0 / self.world if grad_scale is None else grad_scale,
+                      no_decay_bits=self.no_decay_bits)
 
   def train_step(self, batch):
     """batch: dict with rgb, lidar_bev, target_point, ego_vel, command and the *_label tensors (reference layouts).
@@ -224,9 +263,12 @@ class Trainer:
     n_params = len(list(self.model.parameters()))
     state = {}
     self._alloc_state()
+    gidx = self._group_index()
     if self.step_count > 0:
       for i, off, p in self._arena_slices():
         n = p.numel()
+        if gidx is not None:
+          i = gidx[id(p)]
         state[i] = {'step': torch.tensor(float(self.step_count)),
                     'exp_avg': self.exp_avg[off:off + n].view(p.shape).clone(),
                     'exp_avg_sq': self.exp_avg_sq[off:off + n].view(p.shape).clone(),
@@ -234,17 +276,34 @@ class Trainer:
     group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.weight_decay, 'amsgrad': True,
              'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
              'params': list(range(n_params))}
+    if gidx is not None:  # torch's layout for several groups: consecutive indices group after group
+      groups, i = [], 0
+      for pl, wd in zip(self.groups, self.group_decays):
+        groups.append({**group, 'weight_decay': wd, 'params': list(range(i, i + len(pl)))})
+        i += len(pl)
+      return {'state': state, 'param_groups': groups}
     return {'state': state, 'param_groups': [group]}
 
   def load_state_dict(self, sd):
     """Resume from ``state_dict()`` or from an optimizer_%04d.pth the reference wrote (train.py:533-534)."""
     g = sd['param_groups'][0]
-    if len(sd['param_groups']) != 1 or not g.get('amsgrad', False):
-      raise ValueError('expected the single amsgrad AdamW parameter group of team_code/train.py:529-531')
-    self.lr, self.betas, self.eps, self.weight_decay = float(g['lr']), tuple(g['betas']), float(g['eps']), float(g['weight_decay'])
+    n_groups = 1 if self.groups is None else len(self.groups)
+    if len(sd['param_groups']) != n_groups or not g.get('amsgrad', False):
+      raise ValueError(f'expected {n_groups} amsgrad AdamW parameter group(s) (team_code/train.py:522-531), got {len(sd["param_groups"])}')
+    self.lr, self.betas, self.eps = float(g['lr']), tuple(g['betas']), float(g['eps'])
+    if self.groups is None:
+      self.weight_decay = float(g['weight_decay'])
+    else:
+      if [len(x['params']) for x in sd['param_groups']] != [len(pl) for pl in self.groups]:
+        raise ValueError('parameter groups of the checkpoint do not match the optimizer\'s')
+      self._groups_key = None
+      self.set_groups(self.groups, [float(x['weight_decay']) for x in sd['param_groups']])
     self._alloc_state()
     steps = set()
+    gidx = self._group_index()
     for i, off, p in self._arena_slices():
+      if gidx is not None:
+        i = gidx[id(p)]
       st = sd['state'].get(i)
       n = p.numel()
       for name, arena in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq), ('max_exp_avg_sq', self.max_exp_avg_sq)):

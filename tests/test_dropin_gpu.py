@@ -129,6 +129,47 @@ def test_train_py_loop_with_torch_adamw_matches_the_trainer():
   _check_params(step.tr.flat_param, want_param, 4, lr)
 
 
+def test_optimizer_groups_fused_optimizer_matches_torch_adamw_with_the_same_groups():
+  """use_optim_groups (train.py:522-523): ``create_optimizer_groups`` hands the optimizer a decay and a no-decay group.  FlatAdamW runs them as
+  one launch with a bit per 4 arena elements; torch.optim.AdamW on the same groups (arena-backed parameters) is the reference.  A large weight
+  decay makes a wrong group assignment visible; the state_dict has torch's two-group layout and survives a reload."""
+  from carla_garage_amd.losses import normalized_loss_weights
+  from carla_garage_amd.optim import FlatAdamW
+  lr, wd, steps = 1e-4, 5.0, 3   # (a weight decay large enough that a parameter in the wrong group moves by 1.5e-3 |w|, far above AdamW's +-lr noise)
+  batches = _batches(steps)
+  res = {}
+  for kind in ('torch', 'fused'):
+    m = _model()
+    groups = m.create_optimizer_groups(wd)
+    assert [g['weight_decay'] for g in groups] == [wd, 0.0]
+    opt = (torch.optim.AdamW if kind == 'torch' else FlatAdamW)(groups, lr=lr, amsgrad=True)
+    p0 = {n: p.detach().clone() for n, p in m.named_parameters()}
+    losses = train_py_loop(m, opt, batches, normalized_loss_weights(m.config))
+    res[kind] = (m, opt, p0, losses)
+  (mt, _, p0, lt), (mf, of, _, lf) = res['torch'], res['fused']
+  np.testing.assert_allclose(lf, lt, rtol=2e-3)
+  worst = 0.0
+  for (n, pt), (_, pf) in zip(mt.named_parameters(), mf.named_parameters()):
+    if not pt.requires_grad:
+      continue
+    w0 = p0[n].double()
+    assert float((pt - pf).abs().max()) <= 2.2 * steps * lr + 1e-6, n   # element-wise: opposite-sign AdamW steps at most
+    if pt.numel() >= 64 and float(w0.abs().sum()) > 0:
+      # relative shrink of the tensor, fused minus torch: 0 when both decay (or both do not); +-lr wd steps = 1.5e-3 for a wrong group
+      r = float(((pf - pt).double() * torch.sign(w0)).sum() / w0.abs().sum())
+      worst = max(worst, abs(r))
+  assert worst < 2e-4, worst
+  sd = of.state_dict()
+  assert len(sd['param_groups']) == 2 and [g['weight_decay'] for g in sd['param_groups']] == [wd, 0.0]
+  assert sum(len(g['params']) for g in sd['param_groups']) == len(list(mf.parameters()))
+  assert sd['param_groups'][1]['params'][0] == len(sd['param_groups'][0]['params'])
+  of2 = FlatAdamW(mf.create_optimizer_groups(wd), lr=lr, amsgrad=True)
+  of2.load_state_dict(sd)
+  sd2 = of2.state_dict()
+  k = min(sd['state'])
+  assert torch.equal(sd2['state'][k]['exp_avg'], sd['state'][k]['exp_avg']) and float(sd2['state'][k]['step']) == float(steps)
+
+
 def test_gradients_are_arena_views_accumulate_and_match_the_engine():
   from carla_garage_amd.losses import normalized_loss_weights
   m = _model()

@@ -64,3 +64,20 @@ def test_convert_features_to_bb_metric_conversion_matches_reference(pair, monkey
   assert len(got) == len(want) > 10
   for a, b in zip(got, want):
     np.testing.assert_array_equal(a, b)
+
+
+def test_no_decay_bitmask_marks_whole_parameters_and_their_padding():
+  """ops.no_decay_bitmask (host side of tfpp_adamw_amsgrad_groups): one bit per group of 4 arena elements, little-endian inside 32-bit words."""
+  import numpy as np
+  from carla_garage_amd import ops
+  slices = [(0, 6, 'a'), (8, 4, 'b'), (12, 130, 'c'), (144, 3, 'd'), (148, 1000, 'e')]
+  total = 148 + 1000
+  words = ops.no_decay_bitmask(slices, {'b', 'd', 'e'}, total)
+  assert words.dtype == np.int32 and words.size == ((total + 3) // 4 + 31) // 32
+  bits = np.unpackbits(words.view(np.uint8), bitorder='little')
+  want = np.zeros_like(bits)
+  for off, n, name in slices:
+    if name in ('b', 'd', 'e'):
+      want[off // 4:(off + n + 3) // 4] = 1
+  assert np.array_equal(bits, want)
+  assert not ops.no_decay_bitmask(slices, set(), total).any()

@@ -866,6 +866,40 @@ def test_adamw_amsgrad(ops):
   check('adamw', p.cpu() - p0, pt.detach() - p0, torch.float32, scale=5.0)
 
 
+def test_adamw_amsgrad_two_parameter_groups(ops):
+  """tfpp_adamw_amsgrad_groups against torch.optim.AdamW with the two groups of create_optimizer_groups (train.py:522-523): parameters of the
+  weight_decay = 0 group are marked by one bit per 4 arena elements (ops.no_decay_bitmask)."""
+  sizes = [10, 4, 133, 7, 64, 2]            # parameters, each padded to a multiple of 4 in the arena
+  no_decay = {1, 3, 5}
+  offs, off = [], 0
+  for n in sizes:
+    offs.append(off)
+    off += (n + 3) // 4 * 4
+  total = off
+  p0, g = rnd(total, seed=123), rnd(total, seed=124)
+  params = [torch.nn.Parameter(p0[o:o + n].clone()) for o, n in zip(offs, sizes)]
+  opt = torch.optim.AdamW([{'params': [q for i, q in enumerate(params) if i not in no_decay], 'weight_decay': 0.05},
+                           {'params': [q for i, q in enumerate(params) if i in no_decay], 'weight_decay': 0.0}], lr=1e-2, amsgrad=True)
+  bits = torch.from_numpy(ops.no_decay_bitmask([(o, n, i) for i, (o, n) in enumerate(zip(offs, sizes))], no_decay, total).copy()).to(DEV)
+  p, m, v, vm = dev(p0.clone()), torch.zeros(total, device=DEV), torch.zeros(total, device=DEV), torch.zeros(total, device=DEV)
+  for step in range(1, 5):
+    for q, o, n in zip(params, offs, sizes):
+      q.grad = g[o:o + n].clone() * step
+    opt.step()
+    ops.adamw_amsgrad(p, dev(g * step), m, v, vm, 1e-2, 0.9, 0.999, 1e-8, 0.05, step, grad_scale=1.0, no_decay_bits=bits)
+  got = p.cpu()
+  for i, (q, o, n) in enumerate(zip(params, offs, sizes)):
+    check(f'adamw_groups.p{i}', got[o:o + n] - p0[o:o + n], q.detach() - p0[o:o + n], torch.float32, scale=5.0)
+  # the decayed and the undecayed update of the same gradient differ by far more than the tolerance (the mask matters)
+  plain = dev(p0.clone())
+  ops.adamw_amsgrad(plain, dev(g), torch.zeros_like(m), torch.zeros_like(m), torch.zeros_like(m), 1e-2, 0.9, 0.999, 1e-8, 0.05, 1)
+  masked = dev(p0.clone())
+  ops.adamw_amsgrad(masked, dev(g), torch.zeros_like(m), torch.zeros_like(m), torch.zeros_like(m), 1e-2, 0.9, 0.999, 1e-8, 0.05, 1, no_decay_bits=bits)
+  d = (plain - masked).cpu()
+  for i, (o, n) in enumerate(zip(offs, sizes)):
+    assert (float(d[o:o + n].abs().max()) > 1e-6) == (i in no_decay), i
+
+
 def test_bn1d_scalar(ops):
   x = rnd(12, 1, seed=131) * 4 + 3
   rm, rv = torch.tensor([2.5]), torch.tensor([6.0])
