@@ -153,12 +153,13 @@ def test_optimizer_groups_fused_optimizer_matches_torch_adamw_with_the_same_grou
     if not pt.requires_grad:
       continue
     w0 = p0[n].double()
-    assert float((pt - pf).abs().max()) <= 2.2 * steps * lr + 1e-6, n   # element-wise: opposite-sign AdamW steps at most
-    if pt.numel() >= 64 and float(w0.abs().sum()) > 0:
-      # relative shrink of the tensor, fused minus torch: 0 when both decay (or both do not); +-lr wd steps = 1.5e-3 for a wrong group
+    assert float((pt - pf).detach().abs().max()) <= 2.2 * steps * lr + 1e-6, n   # element-wise: opposite-sign AdamW steps at most
+    if pt.numel() >= 64 and float(w0.abs().mean()) >= 0.02:
+      # relative shrink of the tensor, fused minus torch: 0 when both decay (or both do not) up to the sign-flip noise of AdamW on near-zero
+      # gradients (measured worst 4.6e-4 over ALL tensors, tiny-weight ones included); +-lr wd steps = 1.5e-3 for a parameter in the wrong group
       r = float(((pf - pt).double() * torch.sign(w0)).sum() / w0.abs().sum())
       worst = max(worst, abs(r))
-  assert worst < 2e-4, worst
+  assert worst < 7e-4, worst
   sd = of.state_dict()
   assert len(sd['param_groups']) == 2 and [g['weight_decay'] for g in sd['param_groups']] == [wd, 0.0]
   assert sum(len(g['params']) for g in sd['param_groups']) == len(list(mf.parameters()))
