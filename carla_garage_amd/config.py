@@ -47,6 +47,8 @@ class GlobalConfig:
     self.use_speed_weights = True
     self.use_label_smoothing = False
     self.label_smoothing_alpha = 0.1
+    self.use_optim_groups = False  # config.py:263: decay / no-decay parameter groups (Trainer.set_groups, optim.FlatAdamW)
+    self.weight_decay = 0.01       # config.py:264
     self.use_bev_semantic = True
     self.use_depth = True
     self.use_semantic = True
