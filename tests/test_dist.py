@@ -97,7 +97,7 @@ def _trainer_schedule_worker(rank, world, port, out):
   events = []
   tr = Trainer.__new__(Trainer)
   tr.model = types.SimpleNamespace(train=lambda: None)
-  tr.pg, tr.world, tr.step_count, tr.exchange, tr._lazy_state, tr.early_opt_in_step = None, world, 0, True, False, False
+  tr.pg, tr.world, tr.step_count, tr.exchange, tr._lazy_state, tr.early_opt_in_step, tr.no_decay_bits = None, world, 0, True, False, False, None
   tr.eng = types.SimpleNamespace(flat_grad=torch.zeros(n), early_offset=off, invalidate=lambda: None)
   mine = torch.arange(n, dtype=torch.float32) * (rank + 1)
 
@@ -112,10 +112,15 @@ def _trainer_schedule_worker(rank, world, port, out):
     tr.eng.flat_grad[:off] = mine[:off]
     events.append('segment2')
 
-  def optimizer(step, grad_scale=None, upto=None):
-    assert upto is None
-    events.append('optimizer')
-    tr.seen = tr.eng.flat_grad.clone()
+  def optimizer(step, grad_scale=None, upto=None, lo=0):
+    # finish_step: the early slice [off:] is updated while the late slice travels, then the late slice [:off]
+    assert (lo, upto) in ((off, None), (0, off))
+    events.append('optimizer_early' if lo else 'optimizer_late')
+    if lo:
+      tr.seen = torch.zeros(n)
+      tr.seen[lo:] = tr.eng.flat_grad[lo:]     # what this launch consumed: must already be the sum over the ranks
+    else:
+      tr.seen[:upto] = tr.eng.flat_grad[:upto]
     tr.scale = 1.0 / tr.world if grad_scale is None else grad_scale
 
   tr._step_part1, tr._step_part2, tr._optimizer = part1, part2, optimizer
@@ -123,14 +128,18 @@ def _trainer_schedule_worker(rank, world, port, out):
 
   class Handle:
 
-    def __init__(self, work):
-      self.work = work
+    def __init__(self, work, name='early_waited'):
+      self.work, self.name = work, name
 
     def wait(self):
-      events.append('early_waited')
+      events.append(self.name)
       self.work.wait()
 
   def rec_async(t, group=None, avg=False):
+    if t.data_ptr() == tr.eng.flat_grad.data_ptr():
+      assert t.numel() == off                                                             # exactly the head slice (late-finishing gradients)
+      events.append('late_issued')
+      return Handle(real_async(t, group, avg=avg), 'late_waited')
     assert t.data_ptr() == tr.eng.flat_grad[off:].data_ptr() and t.numel() == n - off   # exactly the tail slice of the arena
     events.append('early_issued')
     return Handle(real_async(t, group, avg=avg))
@@ -158,6 +167,7 @@ def test_trainer_bucket_schedule_two_ranks(tmp_path):
   want = torch.arange(5003, dtype=torch.float32) * 3.0  # rank 0 contributes 1x, rank 1 contributes 2x
   for r in range(world):
     d = torch.load(tmp_path / f'sched{r}.pt')
-    assert d['events'] == ['segment1', 'early_issued', 'segment2', 'head_reduced', 'early_waited', 'optimizer'], d['events']
+    # the early slice travels behind the second backward segment, the late slice behind the optimizer launch of the early slice
+    assert d['events'] == ['segment1', 'early_issued', 'segment2', 'late_issued', 'early_waited', 'optimizer_early', 'late_waited', 'optimizer_late'], d['events']
     assert torch.equal(d['seen'], want) and d['scale'] == 0.5
     assert torch.equal(d['avg'], want / 2)
