@@ -49,6 +49,7 @@ class FlatAdamW(torch.optim.Optimizer):
     plan = getattr(self, '_plan', None)
     if plan is None or any(tr.detached for tr in plan[0]):
       plan = self._plan = self._arenas()
+      self._tr_wds = {}
       self._tr_groups = {}  # trainer -> the parameter groups that hold its parameters, in the optimizer's order (cached: 1332 lookups otherwise)
     arenas, loose = plan
     for tr, members in arenas.items():
@@ -62,7 +63,10 @@ class FlatAdamW(torch.optim.Optimizer):
         for g in groups[1:]:
           if (float(g['lr']), tuple(g['betas']), float(g['eps'])) != (float(group['lr']), tuple(group['betas']), float(group['eps'])):
             raise NotImplementedError('FlatAdamW: the parameter groups of one model share lr / betas / eps (they differ in weight_decay only)')
-      tr.set_groups([g['params'] for g in groups], [g['weight_decay'] for g in groups])
+      wds = tuple(float(g['weight_decay']) for g in groups)
+      if self._tr_wds.get(tr) != wds:  # (first step, or a scheduler / the caller changed a weight decay)
+        tr.set_groups([g['params'] for g in groups], wds)
+        self._tr_wds[tr] = wds
       if len(members) != len(tr._slices_cached()):
         raise ValueError('FlatAdamW: every trainable parameter of the model must be optimised by the same optimizer (the fused kernel updates the whole arena)')
       if self._pending_state is not None:
