@@ -340,6 +340,15 @@ def dropin_step_time(model, cfg, batch, steps, warmup, optimizer, log, ddp=False
 XGMI_LINK_GBS = 153.0  # per direction and link; 7 links per GPU, one to every other GPU of the node (MI355X_MICROARCH.md)
 
 
+def _flush_c_stdio():
+  """fflush(NULL): output written through C stdio by the native libraries (RCCL's version banner) leaves the process now."""
+  try:
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+  except Exception:  # pylint: disable=broad-except
+    pass
+
+
 def exchange_model(arena_bytes, late_bytes, world):
   """What the gradient exchange should cost on one 8 x MI355X node, to check the first real multi-GPU run against: S bytes all-reduced over N
   ranks move 2 S (N-1)/N bytes out of every GPU; a direct (one-shot reduce-scatter + all-gather over the full xGMI mesh) algorithm spreads them
@@ -624,8 +633,10 @@ def main():
     lidar_hist = lidar_histogram_latency(cfg, device, log)
     swin_fwd = video_swin_forward(device, log, train=rccl_ranks is None)
   if rccl_ranks is not None:
+    _flush_c_stdio()  # (RCCL prints a version banner through C stdio: buffered on a pipe, it would otherwise appear at exit, AFTER the JSON line)
     dist.barrier()
 
+  line = None
   if rank == 0:
     ms = 1e3 * elapsed / args.steps
     value = args.batch_size * world * args.steps / elapsed
@@ -662,10 +673,15 @@ def main():
         line['roofline_fusion_linears'] = roof_fusion
     if world == 1 and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline()
-    print(json.dumps(line), flush=True)
   torch.cuda.synchronize()  # nothing in flight when the graphs and the arenas are torn down
   if rccl_ranks is not None:
     dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0 and world > 1:
+      time.sleep(0.5)  # (the other ranks' last buffered output reaches the launcher's pipe first)
+  if line is not None:
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)  # the ONE JSON line is the last thing this job writes to stdout
 
 
 if __name__ == '__main__':
