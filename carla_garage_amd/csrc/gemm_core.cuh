@@ -256,3 +256,45 @@ __device__ __forceinline__ void epi_pass_bf16(const tfpp_conv_params& p, const f
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip is rewritten by the next pass
 }
+
+// Second half of epi_pass_bf16 on its own (the strip already holds 16 rows x 16 FN columns of fp32 results): used by kernels whose
+// accumulator layout is not the 16x16 one (gemm_pp.hip, 32x32x16 MFMA).  Same lane -> (row, 8-channel chunk) map, same arithmetic.
+template <int FN>
+__device__ __forceinline__ void epi_finish_bf16(const tfpp_conv_params& p, const float* strip, int lane, long m_pass, int rows_valid,
+                                                int n_base, int g) {
+  constexpr int PITCH = EpiStrip<FN>::PITCH, CH = FN * 2, NCHUNK = 16 * CH;
+#pragma unroll
+  for (int c = 0; c < (NCHUNK + 63) / 64; ++c) {
+    const int q = lane + c * 64;
+    const int row = q / CH, c8 = q - row * CH, n = n_base + c8 * 8;
+    if (q < NCHUNK && row < rows_valid && n < p.n_g) {
+      const float4 lo = *reinterpret_cast<const float4*>(strip + row * PITCH + c8 * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(strip + row * PITCH + c8 * 8 + 4);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const int ch = g * p.n_g + n;
+      const long m = m_pass + row;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+      if (p.scale) {
+        const float4 s0 = *reinterpret_cast<const float4*>(p.scale + ch), s1 = *reinterpret_cast<const float4*>(p.scale + ch + 4);
+        v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w; v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
+      }
+      if (p.shift) {
+        const float4 s0 = *reinterpret_cast<const float4*>(p.shift + ch), s1 = *reinterpret_cast<const float4*>(p.shift + ch + 4);
+        v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w; v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
+      }
+      if (p.res) {
+        float rv[8];
+        load_vec<bf16_t>(reinterpret_cast<const bf16_t*>(p.res) + (size_t)m * p.res_ld + ch, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+      if (p.act != ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
+      }
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.dst) + (size_t)m * p.dst_ld + ch) = pack16<bf16_t>(v);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip is rewritten by the next pass
+}

@@ -325,6 +325,7 @@ static bool use_glds_impl() {
 extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
   if (conv_halo_supported(*p, dtype)) return conv_halo_variant(*p);
+  if (conv_pp_supported(*p, dtype)) return conv_pp_variant(*p);
   if (use_glds_impl() && conv_glds_supported(*p, dtype)) return conv_glds_variant(*p);
   return conv_variant_for(*p, dtype);
 }
@@ -332,6 +333,7 @@ extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype) {
 static int conv_splits_for(const tfpp_conv_params& p, int dtype) {
   const long M = (long)p.B * p.Hd * p.Wd;
   if (conv_halo_supported(p, dtype)) return 1;
+  if (conv_pp_supported(p, dtype)) return conv_pp_splits(p);
   if (use_glds_impl() && conv_glds_supported(p, dtype)) {
     const int var = conv_glds_variant(p), bm = conv_glds_bm(var);
     if (var == 202) return 1;  // >= 128 workgroups of 16 waves with >= 16 stages each: splitting K only adds the second pass
@@ -366,6 +368,7 @@ extern "C" int tfpp_conv_gemm_stats_rows(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
   const long M = (long)p->B * p->Hd * p->Wd;
   if (conv_halo_supported(*p, dtype)) return conv_halo_mtiles(*p);
+  if (conv_pp_supported(*p, dtype)) return cdiv(M, conv_pp_bm(conv_pp_variant(*p)));
   if (use_glds_impl() && conv_glds_supported(*p, dtype)) return cdiv(M, conv_glds_bm(conv_glds_variant(*p)));
   return cdiv(M, kConvBm[conv_variant_for(*p, dtype)]);
 }
@@ -382,7 +385,8 @@ template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStr
   tfpp_conv_params q = p;
   q.splitk = conv_splits_for(p, ElemTraits<T>::DT);
   int rc;
-  if (use_glds_impl() && conv_glds_supported(p, ElemTraits<T>::DT)) rc = conv_gemm_glds(q, st);
+  if (conv_pp_supported(p, ElemTraits<T>::DT)) rc = conv_gemm_pp(q, st);
+  else if (use_glds_impl() && conv_glds_supported(p, ElemTraits<T>::DT)) rc = conv_gemm_glds(q, st);
   else {
     switch (conv_variant_for(p, ElemTraits<T>::DT)) {
       case 4:

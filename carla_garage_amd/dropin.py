@@ -127,12 +127,23 @@ class DropinStep:
     return self.model.__dict__.get('_ddp_seen', False) and tdist.exchange_enabled(self.tr.pg)
 
   def _grad_views(self):
-    """[(parameter, cached view of its slice of the gradient arena)] for every arena parameter except the anchor (autograd delivers that one)."""
+    """[(parameter, cached view of its slice of the gradient arena)] for every parameter whose gradient the engine writes: the module's own
+    parameters except the anchor (autograd delivers that one)."""
     if self._views is None or self._views[0] is not self.eng.flat_grad:
       self.eng.alloc_grads(zero=False)
       anchor = self.anchor
-      self._views = (self.eng.flat_grad, [(p, self.eng.grads[n]) for n, p in self.model.named_parameters() if p.requires_grad and p is not anchor])
+      own = self.model.__dict__['_own_param_names']
+      named = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad and p is not anchor]
+      self._views = (self.eng.flat_grad, [(p, self.eng.grads[n]) for n, p in named if n in own],
+                     [(p, self.eng.grads[n]) for n, p in named if n not in own])
     return self._views[1]
+
+  def _foreign_views(self):
+    """[(parameter, its slot in the gradient arena)] for trainable parameters the caller registered on the module (train.py:479-482: the learnable
+    loss weights): autograd -- and DistributedDataParallel, which manages them -- deliver their gradients in ``.grad``; FlatAdamW copies them
+    into the slot before the fused update, torch.optim.AdamW reads ``.grad`` as always."""
+    self._grad_views()
+    return self._views[2]
 
   def _grad_state(self):
     """'fresh': every .grad is None (zero_grad(set_to_none=True), train.py:910) -> the arena is zeroed and .grad set to its views;

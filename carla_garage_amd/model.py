@@ -125,6 +125,10 @@ class LidarCenterNet(nn.Module):
 
     self.__dict__['engine'] = None  # created lazily, not a sub-module
     self.__dict__['_param_list'] = None
+    # the parameters this class created: their gradients are produced by the engine into the flat arena.  Anything registered on the module
+    # later (team_code/train.py:479-482 adds the learnable loss weights 'weight_<loss>' with --learn_multi_task_weights) receives its gradient
+    # from plain autograd and stays under DistributedDataParallel's management (_ddp_params_and_buffers_to_ignore below)
+    self.__dict__['_own_param_names'] = frozenset(n for n, _ in self.named_parameters())
 
   # ------------------------------------------------------------------------------------------------ plumbing
   def sine_table(self, h, w):
@@ -141,19 +145,23 @@ class LidarCenterNet(nn.Module):
     keeps DDP's per-iteration bookkeeping intact); every other gradient is written into the flat arena and exchanged by dropin.py."""
     a = self.__dict__.get('_anchor')
     if a is None or not a.requires_grad:
-      cand = [self.extra_sensor_pos_embed] + list(self.parameters())
+      own = self.__dict__['_own_param_names']
+      cand = [self.extra_sensor_pos_embed] + [p for n, p in self.named_parameters() if n in own]
       a = next((p for p in cand if p.requires_grad), None)
       self.__dict__['_anchor'] = a
     return a
 
   @property
   def _ddp_params_and_buffers_to_ignore(self):
-    """Read by DistributedDataParallel.__init__ (train.py:516-520 wraps the module unchanged): everything except the anchor parameter is
-    exchanged by this package (one all-reduce of the flat gradient arena, overlapped with the second backward segment) instead of by
-    DDP's 25 MB buckets -- 1332 per-parameter hook calls and three copies of the 481 MB of gradients per step otherwise."""
+    """Read by DistributedDataParallel.__init__ (train.py:516-520 wraps the module unchanged): every parameter of this class except the
+    anchor is exchanged by this package (one all-reduce of the flat gradient arena, overlapped with the second backward segment) instead
+    of by DDP's 25 MB buckets -- 1332 per-parameter hook calls and three copies of the 481 MB of gradients per step otherwise.  Parameters
+    the caller registered on the module afterwards (the learnable loss weights of train.py:479-482) are NOT listed: autograd produces their
+    gradients and DDP averages them over the ranks like those of any other module."""
     self.__dict__['_ddp_seen'] = True
     anchor = self._dropin_anchor()
-    names = [n for n, p in self.named_parameters() if p is not anchor]
+    own = self.__dict__['_own_param_names']
+    names = [n for n, p in self.named_parameters() if p is not anchor and n in own]
     # DDP spells a parameter of the ROOT module f"{module_name}.{param_name}" with an empty module name, i.e. with a leading dot
     return names + ['.' + n for n in names if '.' not in n]
 

@@ -75,7 +75,7 @@ class FlatAdamW(torch.optim.Optimizer):
       # gradients that autograd / DDP delivered outside the arena (the anchor parameter, anything the caller assigned to .grad): copy them in
       step = tr.model.__dict__.get('_dropin_step')
       pairs = ([(p, tr.eng.g(p)) for _, p in members] if step is None or step.tr is not tr else
-               step._grad_views() + [(step.anchor, tr.eng.g(step.anchor))])  # (cached views: the identity test below is 0.2 ms for 1332 parameters)
+               step._grad_views() + step._foreign_views() + [(step.anchor, tr.eng.g(step.anchor))])  # (cached views: the identity test below is 0.2 ms for 1332 parameters)
       for p, slot in pairs:
         g = p.grad
         if g is slot:
