@@ -580,7 +580,13 @@ def main():
     # dominant kernel flips run to run: both are always on the line), plus the north-star kernels by name (fusion-transformer linears)
     hb = [(f, x) for f, x in agg.items() if x['flops'] > 0 and x['bytes'] > 0 and x['flops'] / x['bytes'] < ridge]
     roof_hbm = roof_of(*max(hb, key=lambda fa: fa[1]['ms'])) if hb else None
-    roof_fusion = roof_of('conv_gemm<bf16,glds256x128>', agg['conv_gemm<bf16,glds256x128>']) if 'conv_gemm<bf16,glds256x128>' in agg else None
+    # north-star kernels by name: the ping-pong GEMM family (csrc/gemm_pp.hip: fusion-transformer linears + the stage-4 1x1 data gradients),
+    # all tile configurations together; on a build without it, the ring kernel that ran them before
+    pp = [x for f, x in agg.items() if f.startswith('conv_gemm<bf16,pp')]
+    if pp:
+      roof_fusion = roof_of('conv_gemm<bf16,pp>', {k: sum(x[k] for x in pp) for k in ('calls', 'ms', 'flops', 'bytes')})
+    elif 'conv_gemm<bf16,glds256x128>' in agg:
+      roof_fusion = roof_of('conv_gemm<bf16,glds256x128>', agg['conv_gemm<bf16,glds256x128>'])
     if args.kernel_table:
       for f, x in sorted(agg.items(), key=lambda fa: -fa[1]['ms']):
         tf = x['flops'] / (x['ms'] * 1e-3) / 1e12 if x['flops'] else 0.0

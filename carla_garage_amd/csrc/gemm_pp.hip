@@ -38,14 +38,21 @@ typedef const __attribute__((address_space(1))) void pp_gbl_void_t;
 typedef unsigned int pp_u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-__device__ __attribute__((aligned(16))) unsigned int tfpp_pp_zero_page[4] = {0u, 0u, 0u, 0u};
+struct PPMap { int tm, tn, xm, xn, dbg; };  // dbg: ablation bits, only in builds with -DTFPP_PP_DBG (TFPP_BUILD_FLAGS): 1 no steady-state DMA, 2 no fragment reads, 4 no MFMAs, 8 no stores
 
-struct PPMap { int tm, tn, xm, xn, dbg; };  // dbg: ablation bits (tools/gemm_pp_micro.py): 1 no steady-state DMA, 2 no fragment reads, 4 no MFMAs, 8 no stores
-
-template <int OFF> __device__ __forceinline__ uint4 pp_ds_read(unsigned addr) {  // OFF: 16-bit immediate byte offset
+template <int OFF> __device__ __forceinline__ pp_u32x4_t pp_ds_read(unsigned addr) {  // OFF: 16-bit immediate byte offset
   pp_u32x4_t v;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return make_uint4(v[0], v[1], v[2], v[3]);
+  return v;
+}
+// MFMAs as inline assembly with the accumulator tied to the destination: with the builtins the register allocator renames the accumulators
+// across the unrolled phases (D != C), which doubles their live ranges -- 242 VGPRs instead of 150 for the 128x256 tile, scratch spills for
+// 256x256.  Operands come straight from ds_read_b128 returns (no VALU write in front), every accumulator is touched once per 8+ MFMAs.
+__device__ __forceinline__ void pp_mfma16(f32x4_t& acc, const pp_u32x4_t& a, const pp_u32x4_t& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pp_mfma32(f32x16_t& acc, const pp_u32x4_t& a, const pp_u32x4_t& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
 template <typename F, int... I> __device__ __forceinline__ void pp_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -60,14 +67,16 @@ template <int N> __device__ __forceinline__ void pp_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, bool MF32>
+// SR: rows of an A slab per wave = rows one phase multiplies (32: 16 / 12 / 8 MFMAs 16x16x32 per phase at BN = 256 / 192 / 128; 64: twice that --
+// a barrier round trip costs ~100+ cycles whatever the phase does, longer phases amortise it, at 32 more VGPRs of A fragments).
+template <int BM, int BN, bool MF32, int SR = 32>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(tfpp_conv_params p, PPMap map) {
-  constexpr int WM = BM / 2, WN = BN / 4, NPH = WM / 32, NB = BN / 64, NA = BM / 64, LPW = NB + NA;
+  constexpr int WM = BM / 2, WN = BN / 4, NPH = WM / SR, PPS = SR / 32, NB = BN / 64, NA = BM / 64, LPW = NB + NA;
   constexpr int KT_BYTES = (BM + BN) * 128, A_OFF = BN * 128;
   constexpr int FN = WN / 16, FN32 = WN / 32, NKS = MF32 ? 4 : 2;
-  constexpr int LATE = NPH == 4 ? 2 : 1;  // A loads of K tile t + 1 issued in phase 0 of tile t
-  static_assert(NPH == 4 || NPH == 2, "BM = 256 or 128");
-  static_assert(NA == NPH && WN % 16 == 0 && (!MF32 || WN % 32 == 0), "tile shape");
+  constexpr int LATE = (NPH == 4 ? 2 : 1) * PPS;  // A loads of K tile t + 1 issued in phase 0 of tile t
+  static_assert(NPH == 4 || NPH == 2, "two or four phases per K tile");
+  static_assert(NA == NPH * PPS && (PPS == 1 || PPS == 2) && WN % 16 == 0 && (!MF32 || WN % 32 == 0), "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,9 +113,12 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(tfpp_conv_params p, P
   nkt = __builtin_amdgcn_readfirstlane(nkt);
   const bool ktail = (kt_beg + nkt) * 64 > K;  // the last K tile of this workgroup reaches past K
 
-  // ---- LDS-DMA bookkeeping: every piece of this lane fetches logical chunk kc of its row (the swizzle depends on the piece's parity only)
+  // ---- LDS-DMA bookkeeping: every piece of this lane fetches logical chunk kc of its row (the swizzle depends on the piece's parity only).
+  // buffer_load ... lds through one descriptor per operand: address = base + voffset (per lane, fixed per piece) + soffset (uniform: the K tile);
+  // no per-load vector arithmetic.  Chunks beyond K in the last tile take an out-of-range voffset: the load returns zeros (both operands:
+  // NaN * 0 must not happen).
   const int kc = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
-  const bool tz = ktail && ((kt_beg + nkt - 1) * 64 + kc * 8 >= K);  // this lane's chunk of the LAST tile lies beyond K: zero page
+  const bool tz = ktail && ((kt_beg + nkt - 1) * 64 + kc * 8 >= K);  // this lane's chunk of the LAST tile lies beyond K
   unsigned b_vo[NB], a_vo[NA];
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
@@ -115,34 +127,29 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(tfpp_conv_params p, P
     b_vo[k] = (unsigned)n * (unsigned)K * 2u + (unsigned)kc * 16u;
   }
 #pragma unroll
-  for (int k = 0; k < NA; ++k) {
-    const int trow = (wave >> 2) * WM + k * 32 + (wave & 3) * 8 + (lane >> 3);  // LDS A row (wave + 8k) * 8 + (lane >> 3), slab-major
+  for (int k = 0; k < NA; ++k) {  // piece q = k % PPS of slab k / PPS: rows of THIS wave's group (the A image is private to a group)
+    const int trow = (wave >> 2) * WM + (k / PPS) * SR + ((k % PPS) * 4 + (wave & 3)) * 8 + (lane >> 3);
     const int m = bm0 + trow < M ? bm0 + trow : M - 1;
     a_vo[k] = (unsigned)m * (unsigned)p.src_ld * 2u + (unsigned)kc * 16u;
   }
-  const char* a_base = reinterpret_cast<const char*>(p.src) + (size_t)kt_beg * 128;  // uniform
-  const char* b_base = reinterpret_cast<const char*>(p.w) + (size_t)kt_beg * 128;
-  const char* zero = reinterpret_cast<const char*>(tfpp_pp_zero_page);
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (unsigned)((size_t)M * p.src_ld * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (unsigned)((size_t)p.n_g * K * 2), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;  // the launcher checked that both operands are smaller than 2 GB
   const unsigned wave_u = (unsigned)wave;
-  // one load: piece k of K tile tt (index within this workgroup's K range) into buffer buf; `last` (wave-uniform): tt is the tile with the K
-  // tail, whose chunks beyond K come from the zero page (both operands: NaN * 0 must not happen)
-  auto issue_b = [&](int k, int tt, unsigned buf, bool last) {
-    const char* base = b_base + (size_t)tt * 128;  // uniform
-    pp_lds_void_t* dst = (pp_lds_void_t*)(size_t)(lds_base + buf * KT_BYTES + (wave_u + 8u * k) * 1024u);
-    if (!last) __builtin_amdgcn_global_load_lds((pp_gbl_void_t*)(base + b_vo[k]), dst, 16, 0, 0);
-    else {
-      asm volatile("; K tail" ::: "memory");  // keeps the two paths apart: merged, every load of the steady state pays the address select
-      __builtin_amdgcn_global_load_lds((pp_gbl_void_t*)(tz ? zero : base + b_vo[k]), dst, 16, 0, 0);
-    }
+  // one load: piece k of K tile tt (index within this workgroup's K range) into buffer buf; TAIL (compile time): apply the K-tail mask
+  auto issue_b = [&](auto TAIL_, int k, int tt, unsigned buf) {
+    constexpr bool TAIL = decltype(TAIL_)::value;
+    const unsigned vo = (TAIL && tz) ? OOB : b_vo[k];
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (pp_lds_void_t*)(size_t)(lds_base + buf * KT_BYTES + (wave_u + 8u * k) * 1024u), 16, (int)vo,
+                                             (kt_beg + tt) * 128, 0, 0);
   };
-  auto issue_a = [&](int k, int tt, unsigned buf, bool last) {
-    const char* base = a_base + (size_t)tt * 128;
-    pp_lds_void_t* dst = (pp_lds_void_t*)(size_t)(lds_base + buf * KT_BYTES + A_OFF + (wave_u + 8u * k) * 1024u);
-    if (!last) __builtin_amdgcn_global_load_lds((pp_gbl_void_t*)(base + a_vo[k]), dst, 16, 0, 0);
-    else {
-      asm volatile("; K tail" ::: "memory");
-      __builtin_amdgcn_global_load_lds((pp_gbl_void_t*)(tz ? zero : base + a_vo[k]), dst, 16, 0, 0);
-    }
+  auto issue_a = [&](auto TAIL_, int k, int tt, unsigned buf) {
+    constexpr bool TAIL = decltype(TAIL_)::value;
+    const unsigned vo = (TAIL && tz) ? OOB : a_vo[k];
+    // LDS piece (8 rows) of the slab-major image: slab * (2 SR / 8) + group * (SR / 8) + q * 4 + (wave & 3); its parity is that of the wave
+    const unsigned piece = (unsigned)(k / PPS) * (2 * SR / 8) + (wave_u >> 2) * (SR / 8) + (unsigned)(k % PPS) * 4u + (wave_u & 3u);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (pp_lds_void_t*)(size_t)(lds_base + buf * KT_BYTES + A_OFF + piece * 1024u), 16, (int)vo,
+                                             (kt_beg + tt) * 128, 0, 0);
   };
 
   // ---- fragment read bases (per K step; the swizzle term depends on the lane only: all row offsets are multiples of 16 / 32)
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(tfpp_conv_params p, P
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const unsigned phys = (unsigned)((ks * 4 + kg) ^ s) * 16u;
-      a_rd[0][ks] = lds_base + A_OFF + (unsigned)(wm * 32 + r16) * 128u + phys;
+      a_rd[0][ks] = lds_base + A_OFF + (unsigned)(wm * SR + r16) * 128u + phys;
       b_rd[0][ks] = lds_base + (unsigned)(wn * WN + r16) * 128u + phys;
       a_rd[1][ks] = a_rd[0][ks] + KT_BYTES;
       b_rd[1][ks] = b_rd[0][ks] + KT_BYTES;
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(tfpp_conv_params p, P
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const unsigned phys = (unsigned)((ks * 2 + kg) ^ s) * 16u;
-      a_rd[0][ks] = lds_base + A_OFF + (unsigned)(wm * 32 + r32) * 128u + phys;
+      a_rd[0][ks] = lds_base + A_OFF + (unsigned)(wm * SR + r32) * 128u + phys;
       b_rd[0][ks] = lds_base + (unsigned)(wn * WN + r32) * 128u + phys;
       a_rd[1][ks] = a_rd[0][ks] + KT_BYTES;
       b_rd[1][ks] = b_rd[0][ks] + KT_BYTES;
@@ -170,124 +177,143 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(tfpp_conv_params p, P
   }
 
   // ---- accumulators and fragments (16x16x32: acc[slab * 2 + i][j]; 32x32x16: acc32[slab][j])
-  f32x4_t acc[MF32 ? 1 : 2 * NPH][MF32 ? 1 : FN];
-  f32x16_t acc32[MF32 ? NPH : 1][MF32 ? FN32 : 1];
+  constexpr int FAI = MF32 ? SR / 32 : SR / 16;  // A fragments per slab and K step
+  f32x4_t acc[MF32 ? 1 : WM / 16][MF32 ? 1 : FN];
+  f32x16_t acc32[MF32 ? WM / 32 : 1][MF32 ? FN32 : 1];
   if constexpr (!MF32) {
 #pragma unroll
-    for (int i = 0; i < 2 * NPH; ++i)
+    for (int i = 0; i < WM / 16; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   } else {
 #pragma unroll
-    for (int i = 0; i < NPH; ++i)
+    for (int i = 0; i < WM / 32; ++i)
 #pragma unroll
       for (int j = 0; j < FN32; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
   }
-  Frag<bf16_t> fa[NKS][MF32 ? 1 : 2], fb[NKS][MF32 ? FN32 : FN];
+  pp_u32x4_t fa[2][NKS][FAI], fb[NKS][MF32 ? FN32 : FN];  // fa[s]: slab s & 1 (read one phase ahead, beside the MFMAs of the slab before)
+#ifdef TFPP_PP_DBG
   const int dbg = map.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
   if (dbg & 2) {  // timing experiments without fragment reads multiply zeros
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
-      for (int i = 0; i < (MF32 ? 1 : 2); ++i) fa[ks][i].v = make_uint4(0, 0, 0, 0);
+      for (int i = 0; i < FAI; ++i) { fa[0][ks][i] = pp_u32x4_t{0, 0, 0, 0}; fa[1][ks][i] = pp_u32x4_t{0, 0, 0, 0}; }
 #pragma unroll
-      for (int j = 0; j < (MF32 ? FN32 : FN); ++j) fb[ks][j].v = make_uint4(0, 0, 0, 0);
+      for (int j = 0; j < (MF32 ? FN32 : FN); ++j) fb[ks][j] = pp_u32x4_t{0, 0, 0, 0};
     }
   }
+  // A fragments of slab SLAB in buffer RB -> fa[SLAB & 1]
+  auto read_a = [&](auto RB_, auto SLAB_) {
+    constexpr int RB = decltype(RB_)::value, SLAB = decltype(SLAB_)::value, D = SLAB & 1;
+    if (dbg & 2) return;
+    pp_static_for<NKS>([&](auto KS_) {
+      constexpr int KS = decltype(KS_)::value;
+      pp_static_for<FAI>([&](auto I_) {
+        constexpr int I = decltype(I_)::value;
+        fa[D][KS][I] = pp_ds_read<(SLAB * 2 * SR + I * (MF32 ? 32 : 16)) * 128>(a_rd[RB][KS]);
+      });
+    });
+  };
+  auto read_b = [&](auto RB_) {
+    constexpr int RB = decltype(RB_)::value;
+    if (dbg & 2) return;
+    pp_static_for<NKS>([&](auto KS_) {
+      constexpr int KS = decltype(KS_)::value;
+      pp_static_for<(MF32 ? FN32 : FN)>([&](auto J_) {
+        constexpr int J = decltype(J_)::value;
+        fb[KS][J] = pp_ds_read<J * (MF32 ? 32 : 16) * 128>(b_rd[RB][KS]);
+      });
+    });
+  };
 
-  // one K tile: t = index within this workgroup's K range, in LDS buffer BUF; mode 0: tiles t + 1 and t + 2 exist, 1: t + 1 is the last, 2: t is
-  auto tile = [&](auto BUF_, int t, int mode) {
+  // One K tile: t = index within this workgroup's K range, in LDS buffer BUF.  ONE copy of the MFMA code per buffer: the end of the K range
+  // (no more tiles to fetch, K-tail mask on the loads of the last tile, draining waits) is handled by wave-uniform flags and branches around the
+  // loads only -- per-mode copies of the body made the register allocator copy all accumulators at every join (+90 VGPRs, scratch spills).
+  // FAST (compile time): the caller guarantees t + 2 < nkt - 1 -- the steady-state copy has no scalar control flow at all.
+  auto tile = [&](auto BUF_, auto FAST_, int t) {
     constexpr int BUF = decltype(BUF_)::value;
+    constexpr bool FAST = decltype(FAST_)::value;
+    const bool have1 = FAST || t + 1 < nkt, have2 = FAST || t + 2 < nkt;          // K tiles t + 1 / t + 2 exist
+    const bool tail1 = !FAST && ktail && t + 1 == nkt - 1, tail2 = !FAST && ktail && t + 2 == nkt - 1;  // ... and are the tile with the K tail
     pp_static_for<NPH>([&](auto P_) {
       constexpr int P = decltype(P_)::value;
-      // ================= L phase: fragment reads
-      if (dbg & 2) {
-      } else if constexpr (!MF32) {
-        if constexpr (P == 0) {
-          pp_static_for<2>([&](auto KS_) {
-            constexpr int KS = decltype(KS_)::value;
-            pp_static_for<FN>([&](auto J_) {
-              constexpr int J = decltype(J_)::value;
-              fb[KS][J].v = pp_ds_read<J * 16 * 128>(b_rd[BUF][KS]);
-            });
-          });
-        }
-        pp_static_for<2>([&](auto KS_) {
-          constexpr int KS = decltype(KS_)::value;
-          fa[KS][0].v = pp_ds_read<(P * 64) * 128>(a_rd[BUF][KS]);
-          fa[KS][1].v = pp_ds_read<(P * 64 + 16) * 128>(a_rd[BUF][KS]);
-        });
-      } else {
-        if constexpr (P == 0) {
-          pp_static_for<4>([&](auto KS_) {
-            constexpr int KS = decltype(KS_)::value;
-            pp_static_for<FN32>([&](auto J_) {
-              constexpr int J = decltype(J_)::value;
-              fb[KS][J].v = pp_ds_read<J * 32 * 128>(b_rd[BUF][KS]);
-            });
-          });
-        }
-        pp_static_for<4>([&](auto KS_) {
-          constexpr int KS = decltype(KS_)::value;
-          fa[KS][0].v = pp_ds_read<(P * 64) * 128>(a_rd[BUF][KS]);
-        });
-      }
-      // ================= L phase: LDS-DMA of the pieces whose previous contents were read one phase ago
-      if constexpr (P == 0) {  // late A slabs of K tile t + 1 (other buffer; their slots were read in the last phase(s) of tile t - 1)
-        if (mode != 2 && !(dbg & 1)) {
-          const bool last = ktail && (t + 1 == nkt - 1);
+      // ================= L phase: B fragments of this tile; LDS-DMA of the pieces whose previous contents were read one phase ago
+      if constexpr (P == 0) read_b(std::integral_constant<int, BUF>{});
+      if (!(dbg & 1)) {
+        if constexpr (P == 0) {  // late A slabs of K tile t + 1 (other buffer; their slots were read in the last phase(s) of tile t - 1)
+          if (have1) {
+            if (!tail1) {
 #pragma unroll
-          for (int k = NA - LATE; k < NA; ++k) issue_a(k, t + 1, BUF ^ 1, last);
-        }
-      } else if (mode == 0 && !(dbg & 1)) {  // K tile t + 2 into this buffer
-        const bool last = ktail && (t + 2 == nkt - 1);
-        if constexpr (NPH == 4) {
-          if constexpr (P == 1) {
+              for (int k = NA - LATE; k < NA; ++k) issue_a(std::false_type{}, k, t + 1, BUF ^ 1);
+            } else {
+              asm volatile("; K tail" ::: "memory");  // (keeps the two paths apart: merged, every steady-state load would pay the select)
 #pragma unroll
-            for (int k = 0; k < (NB < 2 ? NB : 2); ++k) issue_b(k, t + 2, BUF, last);
-          } else if constexpr (P == 2) {
-#pragma unroll
-            for (int k = 2; k < NB; ++k) issue_b(k, t + 2, BUF, last);
-          } else {
-            issue_a(0, t + 2, BUF, last);
-            issue_a(1, t + 2, BUF, last);
+              for (int k = NA - LATE; k < NA; ++k) issue_a(std::true_type{}, k, t + 1, BUF ^ 1);
+            }
           }
-        } else {
+        } else if (have2) {  // K tile t + 2 into this buffer
+          auto sched = [&](auto TL) {
+            if constexpr (NPH == 4) {  // (PPS == 1)
+              if constexpr (P == 1) {
 #pragma unroll
-          for (int k = 0; k < NB; ++k) issue_b(k, t + 2, BUF, last);
-          issue_a(0, t + 2, BUF, last);
+                for (int k = 0; k < (NB < 2 ? NB : 2); ++k) issue_b(TL, k, t + 2, BUF);
+              } else if constexpr (P == 2) {
+#pragma unroll
+                for (int k = 2; k < NB; ++k) issue_b(TL, k, t + 2, BUF);
+              } else {
+                issue_a(TL, 0, t + 2, BUF);
+                issue_a(TL, 1, t + 2, BUF);
+              }
+            } else {  // two phases: all of B and slab 0 of A
+#pragma unroll
+              for (int k = 0; k < NB; ++k) issue_b(TL, k, t + 2, BUF);
+#pragma unroll
+              for (int k = 0; k < PPS; ++k) issue_a(TL, k, t + 2, BUF);
+            }
+          };
+          if (!tail2) sched(std::false_type{});
+          else {
+            asm volatile("; K tail" ::: "memory");
+            sched(std::true_type{});
+          }
         }
       }
-      // ================= L phase: everything older than one K tile of loads has landed (see the header); my reads have returned
-      if (mode == 0) pp_wait_vmcnt<LPW>();
-      else if (mode == 1) {
-        constexpr int NB1 = NB < 2 ? NB : 2;
-        constexpr int W = NPH == 4 ? (P == 0 ? LPW : P == 1 ? LPW - NB1 : P == 2 ? LPW - NB : LPW - NB - 2) : (P == 0 ? LPW : 1);
-        pp_wait_vmcnt<W>();
-      } else if (P == 0) pp_wait_vmcnt<0>();
+      // ================= L phase: everything older than one K tile of loads has landed (see the header); at the end of the K range, where
+      // fewer loads are in flight, simply everything.  My fragment reads have returned.
+      if (have2) pp_wait_vmcnt<LPW>();
+      else pp_wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      // ================= C phase
+      // ================= C phase: A fragments of the NEXT slab (the next tile's slab 0 in the last phase; past the end of the K range that is
+      // a read of stale LDS bytes nobody uses), then the MFMAs of this one
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (P + 1 < NPH) read_a(std::integral_constant<int, BUF>{}, std::integral_constant<int, P + 1>{});
+      else read_a(std::integral_constant<int, BUF ^ 1>{}, std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int CUR = P & 1;
       if (dbg & 4) {
       } else if constexpr (!MF32) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < FAI; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) frag_mma(fa[ks][i], fb[ks][j], acc[P * 2 + i][j]);
+            for (int j = 0; j < FN; ++j) pp_mfma16(acc[P * FAI + i][j], fa[CUR][ks][i], fb[ks][j]);
       } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-          for (int j = 0; j < FN32; ++j)
-            acc32[P][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[ks][0].v), __builtin_bit_cast(bf16x8_t, fb[ks][j].v),
-                                                                  acc32[P][j], 0, 0, 0);
+          for (int i = 0; i < FAI; ++i)
+#pragma unroll
+            for (int j = 0; j < FN32; ++j) pp_mfma32(acc32[P * FAI + i][j], fa[CUR][ks][i], fb[ks][j]);
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -297,52 +323,73 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(tfpp_conv_params p, P
   };
 
   if (nkt > 0) {
+    using std::integral_constant;
+    using T = std::true_type;
+    using F = std::false_type;
     // ---- prologue: K tile 0 completely, K tile 1 without its late A slabs (phase 0 of tile 0 issues those)
     {
-      const bool last0 = ktail && nkt == 1, last1 = ktail && nkt == 2;
+      if (nkt == 1) {
 #pragma unroll
-      for (int k = 0; k < NB; ++k) issue_b(k, 0, 0, last0);
+        for (int k = 0; k < NB; ++k) issue_b(T{}, k, 0, 0);
 #pragma unroll
-      for (int k = 0; k < NA; ++k) issue_a(k, 0, 0, last0);
-      if (nkt > 1) {
-#pragma unroll
-        for (int k = 0; k < NB; ++k) issue_b(k, 1, 1, last1);
-#pragma unroll
-        for (int k = 0; k < NA - LATE; ++k) issue_a(k, 1, 1, last1);
-        pp_wait_vmcnt<LPW - LATE>();
-      } else {
+        for (int k = 0; k < NA; ++k) issue_a(T{}, k, 0, 0);
         pp_wait_vmcnt<0>();
+      } else {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) issue_b(F{}, k, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NA; ++k) issue_a(F{}, k, 0, 0);
+        if (nkt == 2) {
+#pragma unroll
+          for (int k = 0; k < NB; ++k) issue_b(T{}, k, 1, 1);
+#pragma unroll
+          for (int k = 0; k < NA - LATE; ++k) issue_a(T{}, k, 1, 1);
+        } else {
+#pragma unroll
+          for (int k = 0; k < NB; ++k) issue_b(F{}, k, 1, 1);
+#pragma unroll
+          for (int k = 0; k < NA - LATE; ++k) issue_a(F{}, k, 1, 1);
+        }
+        pp_wait_vmcnt<LPW - LATE>();
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      read_a(integral_constant<int, 0>{}, integral_constant<int, 0>{});  // slab 0 of tile 0 (retired by the lgkmcnt(0) of the first L phase)
     }
     if (wm == 1) {  // group 1 runs one interval behind group 0
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
+    int t = 0;
 #pragma unroll 1
-    for (int t = 0; t < nkt; t += 2) {
-      const int r0 = nkt - 1 - t;  // tiles after t
-      tile(std::integral_constant<int, 0>{}, t, r0 >= 2 ? 0 : (r0 == 1 ? 1 : 2));
-      if (r0 >= 1) tile(std::integral_constant<int, 1>{}, t + 1, r0 >= 3 ? 0 : (r0 == 2 ? 1 : 2));
+    for (; t + 4 < nkt; t += 2) {  // steady state: neither tile touches the end of the K range
+      tile(integral_constant<int, 0>{}, T{}, t);
+      tile(integral_constant<int, 1>{}, T{}, t + 1);
+    }
+#pragma unroll 1
+    for (; t < nkt; t += 2) {  // the last 1 .. 4 tiles
+      tile(integral_constant<int, 0>{}, F{}, t);
+      if (t + 1 < nkt) tile(integral_constant<int, 1>{}, F{}, t + 1);
     }
     if (wm == 0) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
+    // the MFMAs are opaque to the compiler's hazard recogniser: results of the last ones are read by vector instructions below
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   }
 
   if (dbg & 8) {  // no stores: keep the accumulators alive behind a condition no data satisfies
     float sum = 0.f;
     if constexpr (!MF32) {
 #pragma unroll
-      for (int i = 0; i < 2 * NPH; ++i)
+      for (int i = 0; i < WM / 16; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     } else {
 #pragma unroll
-      for (int i = 0; i < NPH; ++i)
+      for (int i = 0; i < WM / 32; ++i)
 #pragma unroll
         for (int j = 0; j < FN32; ++j)
 #pragma unroll
@@ -356,7 +403,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(tfpp_conv_params p, P
     float* __restrict__ wsp = p.splitk_ws + (size_t)split * M * p.n_g;
     if constexpr (!MF32) {
 #pragma unroll
-      for (int i = 0; i < 2 * NPH; ++i)
+      for (int i = 0; i < WM / 16; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = bm0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
@@ -369,7 +416,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(tfpp_conv_params p, P
         }
     } else {
 #pragma unroll
-      for (int i = 0; i < NPH; ++i)
+      for (int i = 0; i < WM / 32; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = bm0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -389,15 +436,15 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(tfpp_conv_params p, P
   float* strip = reinterpret_cast<float*>(smem) + wave * EpiStrip<FN>::FLOATS;
   if constexpr (!MF32) {
 #pragma unroll
-    for (int i = 0; i < 2 * NPH; ++i) {
+    for (int i = 0; i < WM / 16; ++i) {
       const int m_pass = bm0 + wm * WM + i * 16;
-      epi_pass_bf16<FN, 2 * NPH, false>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, 0);
+      epi_pass_bf16<FN, WM / 16, false>(p, acc[i], strip, lane, m_pass, M - m_pass, bn0 + wn * WN, 0);
     }
   } else {
     constexpr int PITCH = EpiStrip<FN>::PITCH;
     const int c32 = lane & 31, hi = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < NPH; ++i)
+    for (int i = 0; i < WM / 32; ++i)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -414,11 +461,16 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(tfpp_conv_params p, P
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-// configurations: index -> (BM, BN, 32x32x16 MFMA)
-struct PPCfg { int bm, bn, mf32; };
-static const PPCfg kPPCfg[] = {{256, 256, 0}, {256, 256, 1}, {256, 192, 0}, {256, 128, 0}, {256, 128, 1},
-                               {128, 256, 0}, {128, 256, 1}, {128, 192, 0}, {128, 128, 0}, {128, 128, 1}};
+// configurations: index -> (BM, BN, 32x32x16 MFMA, slab rows).  Measured on MI355X (tools/gemm_pp_micro.py, profiles/r04_gemm_pp_micro.txt):
+// 256x192 wins where it fills two rounds of the chip (3840x6048x1512: 480 tiles), 128x192 (two workgroups per CU) nearly everywhere else,
+// 128x128 for narrow N with a long K; 256x256, the 32x32x16 core and 64-row slabs never win on this model's shapes -- a tile costs
+// ~11-13 us besides its K loop (dispatch, first-tile latency, 96-128 KB of output per CU written in one burst), which 24 K tiles do not
+// amortise -- they stay selectable through tfpp_gemm_pp_config for the record.
+struct PPCfg { int bm, bn, mf32, sr; };
+static const PPCfg kPPCfg[] = {{256, 256, 0, 32}, {256, 256, 1, 32}, {256, 192, 0, 32}, {256, 128, 0, 32}, {128, 256, 0, 32},
+                               {128, 192, 0, 32}, {128, 128, 0, 32}, {256, 192, 0, 64}};
 static constexpr int kPPNumCfg = (int)(sizeof(kPPCfg) / sizeof(kPPCfg[0]));
+enum { PP_256x192 = 2, PP_128x192 = 5, PP_128x128 = 6 };
 
 // tuning hook (tfpp_gemm_pp_config): 0 = automatic choice, -1 = kernel off, 1 + i + 100 * splits = configuration i with `splits` K slices (0: automatic)
 static int g_pp_force = [] { const char* e = std::getenv("TFPP_GEMM_PP"); return e ? std::atoi(e) : 0; }();
@@ -436,20 +488,25 @@ bool conv_pp_supported(const tfpp_conv_params& p, int dtype) {
   if (!pointwise || p.stats_partial || p.bns_partial || p.dst_nchw || p.dst_f32) return false;
   if (((p.n_g | (int)p.dst_ld | p.ks_g | (int)p.src_ld) & 7) || ((uintptr_t)p.dst & 15) || ((uintptr_t)p.src & 15) || ((uintptr_t)p.w & 15)) return false;
   if (p.res && ((((int)p.res_ld) & 7) || ((uintptr_t)p.res & 15))) return false;
-  if (M * (long)p.src_ld * 2 >= (1l << 32) || (long)p.n_g * p.ks_g * 2 >= (1l << 32)) return false;  // 32-bit DMA offsets
+  if (M * (long)p.src_ld * 2 >= (1l << 31) || (long)p.n_g * p.ks_g * 2 >= (1l << 31)) return false;  // buffer descriptors: 32-bit offsets, 0x80000000 = out of range
   if (g_pp_force > 0) return M >= 128 && p.n_g >= 128 && p.ks_g >= 64;
-  return M >= 2048 && p.n_g >= 1024 && p.ks_g >= 1024;  // the fusion-transformer / stage-4 shapes
+  // measured against the LDS-DMA ring kernels: +10 .. +22 % on the n_embd = 1512 / 576 fusion linears and the stage-4 1x1 convolutions,
+  // equal on 12288x576x576 (stage 3) -- narrow N needs a long K
+  if (M < 2048 || p.ks_g < 512 || p.n_g < 512) return false;
+  return p.n_g >= 1024 || p.ks_g >= 1024;
 }
 
-// number of launch rounds (in units of one 256-CU round of this tile shape, weighted by the tile's work) for a plan
-static double pp_cost(long M, long N, long K, const PPCfg& c, int splits) {
-  const long tiles = (long)cdiv(M, c.bm) * cdiv(N, c.bn) * splits;
-  const long rounds = (tiles + 255) / 256;
-  const double kt = (double)cdiv(cdiv(K, 64), splits);
-  // per tile: K loop (one unit per 64 x 256 x 256 MACs; smaller tiles feed the matrix pipe less efficiently) + prologue / epilogue
-  const double eff = (c.bm == 256 ? 1.0 : 0.85) * (c.bn == 256 ? 1.0 : c.bn == 192 ? 0.97 : 0.88);
-  const double per_tile = kt * (c.bm / 256.0) * (c.bn / 256.0) / eff + 2.5 * (c.bm / 256.0) * (c.bn / 256.0) + 1.0 + (splits > 1 ? 1.5 : 0.0);
-  return rounds * per_tile;
+// time model of one launch in us (fit of the micro-benchmark: a tile costs a + b per K tile; 256-row tiles run one workgroup per CU, i.e. in
+// rounds of 256, the 128-row tiles two per CU, which behaves like ~290 slots without round quantisation)
+static double pp_cost(long M, long N, long K, int cfg) {
+  const PPCfg& c = kPPCfg[cfg];
+  const double tiles = (double)cdiv(M, c.bm) * cdiv(N, c.bn), nkt = (double)cdiv(K, 64);
+  if (cfg == PP_256x192) {
+    const double rounds = (double)((long)(tiles + 255) / 256);
+    return rounds * (12.8 + 0.81 * nkt) * (rounds >= 2 ? 1.14 : 1.0);
+  }
+  const double w = tiles / 290.0;
+  return (w < 1.0 ? 1.0 : w) * (10.8 + 0.596 * nkt);
 }
 
 // plan: configuration index and K slices
@@ -463,25 +520,16 @@ static void pp_plan(const tfpp_conv_params& p, int* cfg_out, int* splits_out) {
     *cfg_out = c; *splits_out = s;
     return;
   }
-  static const int mf32_env = [] { const char* e = std::getenv("TFPP_GEMM_PP_MF32"); return e ? std::atoi(e) : 1; }();
-  double best = 1e30;
-  int bc = 0, bs = 1;
-  for (int c = 0; c < kPPNumCfg; ++c) {
-    if (kPPCfg[c].mf32 != (mf32_env && kPPCfg[c].bn != 192 ? 1 : 0)) continue;
-    for (int s = 1; s <= 4; ++s) {
-      if (s > 1 && (!p.splitk_ws || (long)s * M * N > p.splitk_ws_floats || N % 4 || cdiv(K, 64) / s < 8)) break;
-      const double cost = pp_cost(M, N, K, kPPCfg[c], s);
-      if (cost < best) { best = cost; bc = c; bs = s; }
-    }
-  }
-  *cfg_out = bc; *splits_out = bs;
+  *splits_out = 1;  // (split-K measured slower on every shape of the model: the fp32 slices cost more than the idle CUs)
+  if (N < 1024) { *cfg_out = PP_128x128; return; }
+  *cfg_out = pp_cost(M, N, K, PP_256x192) < 0.95 * pp_cost(M, N, K, PP_128x192) ? PP_256x192 : PP_128x192;  // (the model is a fit: ties go to the smaller tile)
 }
 
 int conv_pp_variant(const tfpp_conv_params& p) { int c, s; pp_plan(p, &c, &s); return 210 + c; }
 int conv_pp_splits(const tfpp_conv_params& p) { int c, s; pp_plan(p, &c, &s); return s; }
 int conv_pp_bm(int variant) { return kPPCfg[variant - 210].bm; }
 
-template <int BM, int BN, bool MF32> static int launch_pp(const tfpp_conv_params& p, hipStream_t st) {
+template <int BM, int BN, bool MF32, int SR = 32> static int launch_pp(const tfpp_conv_params& p, hipStream_t st) {
   const long M = (long)p.B * p.Hd * p.Wd;
   PPMap map;
   map.tm = cdiv(M, BM); map.tn = cdiv(p.n_g, BN); map.dbg = g_pp_dbg;
@@ -501,10 +549,10 @@ template <int BM, int BN, bool MF32> static int launch_pp(const tfpp_conv_params
   const size_t lds = (size_t)2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BM, BN, MF32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BM, BN, MF32, SR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_gemm_pp_kernel<BM, BN, MF32>), grid, dim3(512), lds, st, p, map);
+  hipLaunchKernelGGL((conv_gemm_pp_kernel<BM, BN, MF32, SR>), grid, dim3(512), lds, st, p, map);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -517,11 +565,9 @@ int conv_gemm_pp(const tfpp_conv_params& p, hipStream_t st) {
     case 1: return launch_pp<256, 256, true>(p, st);
     case 2: return launch_pp<256, 192, false>(p, st);
     case 3: return launch_pp<256, 128, false>(p, st);
-    case 4: return launch_pp<256, 128, true>(p, st);
-    case 5: return launch_pp<128, 256, false>(p, st);
-    case 6: return launch_pp<128, 256, true>(p, st);
-    case 7: return launch_pp<128, 192, false>(p, st);
-    case 8: return launch_pp<128, 128, false>(p, st);
-    default: return launch_pp<128, 128, true>(p, st);
+    case 4: return launch_pp<128, 256, false>(p, st);
+    case 5: return launch_pp<128, 192, false>(p, st);
+    case 6: return launch_pp<128, 128, false>(p, st);
+    default: return launch_pp<256, 192, false, 64>(p, st);
   }
 }

@@ -131,6 +131,8 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
     var = lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p), dt(src))
     if var >= 300:
       tile = f'halo8x32x{(var - 300) * 16}'
+    elif var >= 210:  # ping-pong GEMM (csrc/gemm_pp.hip)
+      tile = 'pp' + ('256x256', '256x256m32', '256x192', '256x128', '128x256', '128x192', '128x128', '256x192s64')[var - 210]
     elif var >= 200:
       tile = ('glds128x128', 'glds64x128', 'glds256x128')[var - 200]
     else:

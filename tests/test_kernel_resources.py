@@ -14,8 +14,9 @@ spec = importlib.util.spec_from_file_location('kernel_resources', os.path.join(R
 kr = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(kr)
 
-HOT = ['gemm_glds.hip', 'gemm_wgrad_glds.hip', 'conv3x3_halo.hip', 'wgrad3x3_halo.hip', 'gemm_kernels.hip', 'attention_kernels.hip', 'norm_kernels.hip',
-       'pointwise_kernels.hip', 'swin_kernels.hip', 'bev_kernels.hip', 'lidar_kernels.hip', 'misc_kernels.hip']  # every source: none of the 318 kernels spills
+import sys  # noqa: E402
+sys.path.insert(0, ROOT)
+from carla_garage_amd._lib import SOURCES as HOT  # noqa: E402  every compiled source (a new file is covered the day it joins the build)
 
 
 @pytest.mark.skipif(shutil.which('hipcc') is None, reason='needs hipcc')
@@ -28,6 +29,8 @@ def test_hot_kernels_use_no_scratch_and_keep_their_occupancy(fname):
     assert scratch == 0, (names[name], scratch)
     if 'conv_gemm_glds_kernel<128, 128, 2, 2, 4, 2, false, true>' in names[name] or 'conv_gemm_glds_kernel<256, 128, 3, 4, 4, 2, false, true>' in names[name]:
       assert total <= 128, (names[name], total)  # two 8-wave workgroups / one 16-wave workgroup per CU
+    if 'conv_gemm_pp_kernel<128, 192' in names[name] or 'conv_gemm_pp_kernel<128, 128' in names[name]:
+      assert total <= 128 and lds == 0, (names[name], total, lds)  # ping-pong GEMM, 128-row tiles: two workgroups per CU (80 / 64 KB of dynamic LDS each)
 
 
 @pytest.mark.skipif(shutil.which('hipcc') is None, reason='needs hipcc')
