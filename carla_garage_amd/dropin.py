@@ -27,7 +27,7 @@ import torch.distributed as dist
 from . import dist as tdist
 from . import ops
 from .engine import F32, Tape
-from .graph import CAPTURE_MODE, capture_stream
+from .graph import capture, capture_stream
 from .losses import active_losses, fused_losses
 
 GRAPH_AFTER = int(os.environ.get('TFPP_DROPIN_GRAPH_AFTER', '2'))  # eager steps of one input signature before it is captured; < 0: never
@@ -193,7 +193,7 @@ class DropinStep:
       torch.cuda.synchronize()
       plan.F = torch.cuda.CUDAGraph()
       st = capture_stream(self.eng.device)
-      with torch.cuda.graph(plan.F, stream=st, capture_error_mode=CAPTURE_MODE):
+      with capture(plan.F, st):
         plan.fwd = self._fwd_body(plan.static_in)
       plan.pool = plan.F.pool()
       plan.F.replay()
@@ -226,7 +226,7 @@ class DropinStep:
         torch.cuda.synchronize()
         plan.L = torch.cuda.CUDAGraph()
         st = capture_stream(self.eng.device)
-        with torch.cuda.graph(plan.L, pool=plan.pool, stream=st, capture_error_mode=CAPTURE_MODE):
+        with capture(plan.L, st, pool=plan.pool):
           _, plan.vals, plan.loss_seeds = fused_losses(model, plan.fwd['internal'], plan.static_labels, None, True)
       else:
         if set(labels) != set(plan.static_labels):
@@ -271,11 +271,11 @@ class DropinStep:
         st = capture_stream(eng.device)
         plan.B1 = torch.cuda.CUDAGraph()
         tape = fwd['tape']
-        with torch.cuda.graph(plan.B1, pool=plan.pool, stream=st, capture_error_mode=CAPTURE_MODE):
+        with capture(plan.B1, st, pool=plan.pool):
           self._bwd_part1(tape, self._scaled_seeds(plan.loss_seeds), split)
         if split:
           plan.B2 = torch.cuda.CUDAGraph()
-          with torch.cuda.graph(plan.B2, pool=plan.pool, stream=st, capture_error_mode=CAPTURE_MODE):
+          with capture(plan.B2, st, pool=plan.pool):
             tape.backward_resume()
         plan.split = split
       elif plan.split != split:

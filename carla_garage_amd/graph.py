@@ -12,6 +12,29 @@ import torch
 # unsafe calls made by the capturing thread itself.
 CAPTURE_MODE = 'thread_local'
 
+import contextlib
+import gc
+
+
+@contextlib.contextmanager
+def capture(graph, stream, pool=None):
+  """``torch.cuda.graph`` with Python's cyclic garbage collector switched off for the duration of the capture.  The engine creates tens of
+  thousands of Python objects while a 3000-launch step is captured; a collection triggered in the middle may finalise a CUDAGraph / stream /
+  event of an earlier owner (previous model, previous test), whose destructor calls into the HIP runtime from inside the open capture and
+  aborts the process (round 4: `Fatal Python error: Aborted ... Garbage-collecting` in a capture of the drop-in step).  Everything
+  collectable is collected before the capture starts instead."""
+  gc.collect()
+  was = gc.isenabled()
+  gc.disable()
+  try:
+    kw = {} if pool is None else {'pool': pool}
+    with torch.cuda.graph(graph, stream=stream, capture_error_mode=CAPTURE_MODE, **kw):
+      yield
+  finally:
+    if was:
+      gc.enable()
+
+
 _CAPTURE_STREAMS = {}
 import os as _os
 _HIGH_PRIORITY_LANES = _os.environ.get('TFPP_LANE_PRIORITY', '0') == '1'  # main lanes on high-priority streams, the weight-gradient lane on a normal one (A/B switch)
@@ -44,7 +67,7 @@ class GraphedForward:
     torch.cuda.synchronize()
     self.graph = torch.cuda.CUDAGraph()
     st = capture_stream(self.static_in[0].device)
-    with torch.inference_mode(), torch.cuda.graph(self.graph, stream=st, capture_error_mode=CAPTURE_MODE):
+    with torch.inference_mode(), capture(self.graph, st):
       self.static_out = model(*self.static_in)
     torch.cuda.synchronize()
 
@@ -80,13 +103,13 @@ class GraphedTrainStep:
       self.graph.enable_debug_mode()
     st = capture_stream(trainer.eng.device)
     if self.split:
-      with torch.cuda.graph(self.graph, stream=st, capture_error_mode=CAPTURE_MODE):
+      with capture(self.graph, st):
         self.vals = trainer._step_part1(self.static_batch)
       self.graph2 = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(self.graph2, pool=self.graph.pool(), stream=st, capture_error_mode=CAPTURE_MODE):
+      with capture(self.graph2, st, pool=self.graph.pool()):
         trainer._step_part2()
     else:
-      with torch.cuda.graph(self.graph, stream=st, capture_error_mode=CAPTURE_MODE):
+      with capture(self.graph, st):
         self.vals = trainer._step_body(self.static_batch)
     if dot:
       self.graph.debug_dump(dot)
