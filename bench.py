@@ -349,19 +349,21 @@ def _flush_c_stdio():
     pass
 
 
-def exchange_model(arena_bytes, late_bytes, world):
+def exchange_model(bucket_bytes, world):
   """What the gradient exchange should cost on one 8 x MI355X node, to check the first real multi-GPU run against: S bytes all-reduced over N
   ranks move 2 S (N-1)/N bytes out of every GPU; a direct (one-shot reduce-scatter + all-gather over the full xGMI mesh) algorithm spreads them
-  over the N-1 links, a ring is bound by one link.  'exposed' = the late slice (stems .. fusion stage 3, reduced after backward); the early slice
-  (heads + stage 4, two thirds of the arena) travels while the second backward segment computes."""
+  over the N-1 links, a ring is bound by one link.  The arena is exchanged bucket by bucket in the order backward completes them
+  (carla_garage_amd/buckets.py), each all-reduce starting behind its bucket's completion signal while the rest of backward runs: what cannot
+  hide is the LAST bucket (stage 1 + stems: the smallest parameters of the network), which is complete only when backward ends."""
   n = max(world, 2)
   per_gpu = lambda b: 2.0 * b * (n - 1) / n
   ms = lambda b, links: round(per_gpu(b) / (links * XGMI_LINK_GBS * 1e9) * 1e3, 3)
-  return {'ranks_modelled': n, 'arena_bytes': arena_bytes, 'late_slice_bytes': late_bytes,
-          'whole_arena_ms': {'direct': ms(arena_bytes, n - 1), 'ring': ms(arena_bytes, 1)},
-          'exposed_late_slice_ms': {'direct': ms(late_bytes, n - 1), 'ring': ms(late_bytes, 1)},
-          'note': f'{XGMI_LINK_GBS:.0f} GB/s per xGMI link and direction, {n - 1} links used by the direct algorithm; plus the mid-backward join of the lanes '
-                  '(1.7 ms measured on one GPU with TFPP_SPLIT_STEP=1)'}
+  total = sum(bucket_bytes)
+  return {'ranks_modelled': n, 'arena_bytes': total, 'bucket_bytes': list(bucket_bytes),
+          'whole_arena_ms': {'direct': ms(total, n - 1), 'ring': ms(total, 1)},
+          'exposed_last_bucket_ms': {'direct': ms(bucket_bytes[-1], n - 1), 'ring': ms(bucket_bytes[-1], 1)},
+          'note': f'{XGMI_LINK_GBS:.0f} GB/s per xGMI link and direction, {n - 1} links used by the direct algorithm; one captured graph, no join of the '
+                  'lanes before the end of backward'}
 
 
 def pmc_traffic(family):
@@ -440,7 +442,7 @@ def main():
   rccl_ranks = None
   if world > 1 or args.force_collectives:
     # one process per GPU, RCCL over xGMI (backend 'nccl' is RCCL on ROCm).  --force-collectives builds the group even for one
-    # rank, so a 1-GPU box executes the whole exchange path (two-graph step + all-reduce between the replays)
+    # rank, so a 1-GPU box executes the whole exchange path (one graph, in-graph completion signals, one all-reduce per gradient bucket)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29511')
     if args.force_collectives:
@@ -534,8 +536,10 @@ def main():
       comm = {'rccl_ranks': rccl_ranks, 'ms_per_step_without_exchange': round(local_ms, 3),
               'exposed_comm_ms_per_step': round(1e3 * elapsed / args.steps - local_ms, 3),
               'allreduce_bytes_per_step': int(trainer.eng.flat_grad.numel()) * 4,
-              'overlap': 'two hipGraph segments, all-reduce of the early-finishing 2/3 of the arena between the replays',
-              'predicted': exchange_model(int(trainer.eng.flat_grad.numel()) * 4, int(trainer.eng.early_offset) * 4, world)}
+              'overlap': 'one hipGraph; one all-reduce per gradient bucket (completion order of backward), each behind its own in-graph completion signal',
+              'buckets': len(trainer.eng.buckets.ranges()), 'early_signals_per_step': len(gstep.program[1]) if graphed else len(trainer.program[1]),
+              'signal_wait_timeouts': trainer.eng.buckets.timed_out(),
+              'predicted': exchange_model([4 * (hi - lo) for lo, hi in trainer.eng.buckets.ranges()], world)}
       log(f'gradient exchange: {comm}')
     finally:
       trainer.exchange = True
@@ -548,6 +552,7 @@ def main():
     for _ in range(nprof):  # local steps (no gradient exchange): only this rank profiles, so it must not enter a collective
       trainer.step_count += 1
       trainer._step_body(batch)
+      trainer.eng.buckets.executed(trainer.program)  # (the pass raised its completion signals: keep the host's counters in step)
       trainer._optimizer(trainer.step_count)
     lib.profiler = None
     agg = prof.summary()

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(PKG_DIR, 'libtfpp_hip.so')
 SOURCES = ['gemm_kernels.hip', 'gemm_glds.hip', 'gemm_pp.hip', 'gemm_wgrad_glds.hip', 'attention_kernels.hip', 'conv3x3_halo.hip', 'wgrad3x3_halo.hip', 'pointwise_kernels.hip', 'norm_kernels.hip', 'misc_kernels.hip', 'lidar_kernels.hip', 'swin_kernels.hip', 'bev_kernels.hip', 'head_kernels.hip']
 
 F32, BF16 = 0, 1
+ABI_VERSION = 2  # include/tfpp.h TFPP_ABI_VERSION
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU, ACT_TANH = 0, 1, 2, 3, 4
 EINVAL = -1000
 
@@ -58,7 +59,7 @@ class PackDesc(ctypes.Structure):
               ('blk_start', i64), ('kind', i32), ('dtype', i32), ('a', i32 * 8)]
 
 
-_CTYPE = {'int': i32, 'int32_t': i32, 'int64_t': i64, 'uint64_t': ctypes.c_uint64, 'float': f32, 'double': ctypes.c_double}
+_CTYPE = {'int': i32, 'int32_t': i32, 'int64_t': i64, 'uint64_t': ctypes.c_uint64, 'uint32_t': ctypes.c_uint32, 'float': f32, 'double': ctypes.c_double}
 
 
 def declared_functions(header=HEADER):
@@ -219,8 +220,8 @@ class _Lib:
             ctypes.sizeof(AttnParams)]
     if n != 5 or list(sizes[:5]) != mine:
       raise TfppError(f'struct layout mismatch: library {list(sizes[:5])} vs ctypes {mine}')
-    if self._dll.tfpp_version() != 1:
-      raise TfppError('ABI version mismatch')
+    if self._dll.tfpp_version() != ABI_VERSION:
+      raise TfppError(f'ABI version mismatch: library {self._dll.tfpp_version()}, binding {ABI_VERSION} (include/tfpp.h TFPP_ABI_VERSION: bumped with every signature change)')
     got = ctypes.c_uint64(0)
     self._fns['tfpp_source_hash'](ctypes.byref(got))
     if os.environ.get('TFPP_SKIP_HASH_CHECK', '0') != '1' and int(got.value) != source_hash():

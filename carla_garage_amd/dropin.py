@@ -39,12 +39,12 @@ class _Plan:
   def __init__(self):
     self.count = 0
     self.pool = None
-    self.F = self.L = self.B1 = self.B2 = None
+    self.F = self.L = self.B1 = None
+    self.program = None       # completion signals of the gradient buckets the captured backward raises (buckets.py)
     self.static_in = self.static_labels = None
     self.fwd = None           # dict(internal, tape, outs, diff) of the captured forward
     self.vals = self.loss_seeds = None
     self.broken = False       # a capture failed or the call sequence left the supported pattern: this signature stays eager
-    self.split = False        # captured with the two-segment backward (gradient exchange between the segments)
 
 
 class _Step(torch.autograd.Function):
@@ -183,12 +183,22 @@ class DropinStep:
     plan.count += 1
     self.step_id += 1
     cur = self.cur = dict(step_id=self.step_id, plan=plan, mode='eager', fwd=None, loss=None, used=set())
+    tr = self.tr
+    if not any(pl.F is not None for pl in self.plans.values()):
+      # nothing is captured yet: the arenas may still move into the completion order the previous backward showed (trainer.py).  Only while no
+      # parameter holds a view of the old gradient arena (train.py:910 zero_grad(set_to_none=True)); after a few steps of a caller that keeps
+      # its .grad tensors the static layout is final (the exchange then starts when backward ends).
+      if not tr.layout_final and all(p.grad is None for p, _ in self._grad_views()):
+        if tr.apply_observed_layout():
+          self._views = None
+      if not tr.layout_final and plan.count > GRAPH_AFTER + 4:
+        tr.layout_final = True
     if plan.F is not None and not plan.broken:
       for dst, src in zip(plan.static_in, inputs):
         dst.copy_(src, non_blocking=True)
       plan.F.replay()
       cur['mode'], cur['fwd'] = 'graph', plan.fwd
-    elif GRAPH_AFTER >= 0 and plan.count > GRAPH_AFTER and not plan.broken and plan.count - 1 > 0:
+    elif GRAPH_AFTER >= 0 and plan.count > GRAPH_AFTER and not plan.broken and plan.count - 1 > 0 and tr.layout_final and tr.eager_steps_in_layout >= 1:
       plan.static_in = [x.detach().clone() for x in inputs]
       torch.cuda.synchronize()
       plan.F = torch.cuda.CUDAGraph()
@@ -246,9 +256,12 @@ class DropinStep:
     from .losses import _scale_by_device_scalar
     return [(pred, _scale_by_device_scalar(dpred, self.gscale[i:i + 1])) for i, (pred, dpred) in enumerate(loss_seeds) if which is None or i in which]
 
-  def _bwd_part1(self, tape, seeds, split):
-    self.eng.alloc_grads(zero=False)
-    tape.backward(seeds, stop_at_mark=split)
+  def _bwd(self, tape, seeds):
+    eng = self.eng
+    eng.alloc_grads(zero=False)
+    eng.begin_backward()
+    tape.backward(seeds)
+    eng.end_backward()
 
   def _run_backward(self, step_id, gouts):
     cur = self.cur
@@ -263,27 +276,16 @@ class DropinStep:
     ops.zero_(eng.g(self.anchor))  # the anchor's gradient travels through autograd (which accumulates it): its slot holds this backward only
     live = [j for j, g in enumerate(gouts) if g is not None]
     tokens = cur['loss'] is not None and live and all(self._is_token(gouts[j]) for j in live)
-    split = self._exchange_on()
-    early = None
     if cur['mode'] == 'graph' and tokens and set(live) == set(range(len(self.names))):
       if plan.B1 is None:
         torch.cuda.synchronize()
         st = capture_stream(eng.device)
         plan.B1 = torch.cuda.CUDAGraph()
-        tape = fwd['tape']
         with capture(plan.B1, st, pool=plan.pool):
-          self._bwd_part1(tape, self._scaled_seeds(plan.loss_seeds), split)
-        if split:
-          plan.B2 = torch.cuda.CUDAGraph()
-          with capture(plan.B2, st, pool=plan.pool):
-            tape.backward_resume()
-        plan.split = split
-      elif plan.split != split:
-        raise RuntimeError('the gradient exchange was switched on / off after the step was captured into hipGraphs')
+          self._bwd(fwd['tape'], self._scaled_seeds(plan.loss_seeds))
+        plan.program = eng.bucket_program
       plan.B1.replay()
-      if plan.B2 is not None:
-        early = tr.reduce_early(avg=True)
-        plan.B2.replay()
+      program = plan.program
     elif cur['mode'] == 'graph':
       plan.broken = True
       raise RuntimeError('this step was captured into hipGraphs (forward -> compute_loss -> backward of every loss, team_code/train.py:776-898) '
@@ -300,17 +302,17 @@ class DropinStep:
             seeds += self._scaled_seeds(cur['loss']['seeds'], {j})
           else:
             seeds.append(fwd['export_seeds'][j](g.contiguous()))
-      tape = fwd['tape']
-      self._bwd_part1(tape, seeds, split)
-      if split:
-        early = tr.reduce_early(avg=True)
-        tape.backward_resume()
-    if split:
-      if early is None:
-        tdist.all_reduce_gradients(eng.flat_grad, tr.pg, avg=True)
-      else:
-        tdist.all_reduce_gradients(eng.flat_grad[:eng.early_offset], tr.pg, avg=True)
-        early.wait()
+      self._bwd(fwd['tape'], seeds)
+      program = eng.bucket_program
+      tr.eager_steps_in_layout += 1
+    eng.buckets.executed(program)
+    if self._exchange_on():
+      # DistributedDataParallel semantics (train.py:516-520): .grad holds the MEAN over the ranks when backward returns.  One all-reduce per
+      # bucket of the arena, each behind its own completion event (they started while the replay above was still running); the caller's
+      # stream waits for all of them
+      for work in eng.buckets.exchange(eng.flat_grad, program, tr.pg, avg=True):
+        if work is not None:
+          work.wait()
     cur['fwd'] = None if cur['mode'] == 'eager' else fwd  # eager: the activations die with the tape
     views = self._grad_views()
     if state == 'fresh':

@@ -453,10 +453,13 @@ class SideLane:
     self.flush_at = {int(v) for v in fa.split(',') if v} if fa else None
     self.forks = [float(v) for v in os.environ.get('TFPP_SIDE_FORKS', '0.43,0.77,0.95').split(',') if v and float(v) > 0]
     self.total_prev = 0  # closures of the previous pass (the eager warm-up in front of a capture counts them)
+    self.last_flush_counts = []  # closure counts at the flushes of the previous pass
     self.stream = None
     self.streams, self.used, self.batches = [], set(), 0
-    self.after_mark, self.mark_passed = None, False  # hook the trainer arms per step / set by Tape.on_mark
     self.lanes = None  # Lanes of the engine: a batch may hold closures from both encoder-branch streams
+    # gradient buckets (buckets.py): batches flushed so far in this pass, "a batch is running its closures right now", the closure count
+    # at every flush of this pass, and the hook called on the batch's stream when a batch has been issued completely
+    self.flush_seq, self.in_flush, self.flush_counts, self.on_batch_end = 0, False, [], None
     self.wplan = ops.WgradReducePlan()  # the slice sums of a batch's pixel-split weight gradients as one launch at the batch end
     self.keep = []
     self.pending = []
@@ -512,24 +515,28 @@ class SideLane:
       if self.lanes is not None:
         for st in self.lanes.streams():
           self.stream.wait_stream(st)
+      seq = self.flush_seq
+      self.flush_seq += 1
+      self.flush_counts.append(self.count)
       with torch.cuda.stream(self.stream):
         ops.stamp(f'side lane9 batch of {len(self.pending)} begins')
         ops.WGRAD_PLAN = self.wplan  # the slice sums of this batch's weight gradients: one launch at its end (ops.WgradReducePlan)
+        self.in_flush = True
         try:
           for fn in self.pending:
             fn()
           self.wplan.flush()
         finally:
           ops.WGRAD_PLAN = None
+          self.in_flush = False
         ops.stamp('side lane9 batch ends')
-        if self.after_mark is not None and self.mark_passed:
-          # (the trainer's optimizer launch for the early-finishing slice of the arena: behind this batch on its stream, and behind the batches
-          # still running on the lane's other streams -- every early gradient was issued before the mark was passed)
-          hook, self.after_mark = self.after_mark, None
+        if self.on_batch_end is not None:
+          # "every gradient of bucket `seq` is final" = this batch AND the earlier ones (other streams of the lane) are done; the waits sit
+          # behind the batch's own kernels, so they delay the event, not the batch
           for st in self.used:
             if st is not self.stream:
               self.stream.wait_stream(st)
-          hook()
+          self.on_batch_end(seq)
       self.pending = []
 
   def join(self):
@@ -556,6 +563,7 @@ class SideLane:
       _release(self.keep)
       self.keep = []
       self.total_prev, self.count = self.count, 0
+      self.last_flush_counts, self.flush_counts, self.flush_seq = self.flush_counts, [], 0
 
 
 # BatchNorm-backward sums (sum g, sum g*xhat) produced by the kernel that completes the gradient instead of a separate reduction pass:
@@ -572,22 +580,45 @@ SE_FUSED = os.environ.get('TFPP_SE_FUSED', '0') == '1'
 
 EARLY_GRAD_PREFIXES = ('backbone.image_encoder.s4', 'backbone.lidar_encoder.s4', 'backbone.lidar_encoder.layers.layer3', 'backbone.lidar_encoder.norm', 'backbone.transformers.3', 'backbone.lidar_channel_to_img.3',
                        'backbone.img_channel_to_lidar.3', 'backbone.c5_conv', 'backbone.up_conv')
+BUCKET_ALIGN = 128  # elements: a bucket starts on a whole word of the optimizer's no-decay bit mask (one bit per 4 elements)
 
 
 def finishes_early(name):
-  """Parameters whose gradient is complete once backward has walked back to the end of fusion stage 3 (Tape.mark() in
-  Engine.forward): everything outside the backbone (heads, decoders, planning head) and the stage-4 part of the backbone --
-  about two thirds of the 481 MB.  They sit at the tail of the flat arenas so that slice can be all-reduced early."""
+  """Static guess used until the backward pass has been observed (Engine.end_backward): parameters outside the backbone (heads,
+  decoders, planning head) and the stage-4 part of the backbone receive their gradients first -- about two thirds of the 481 MB."""
   return (not name.startswith('backbone.')) or name.startswith(EARLY_GRAD_PREFIXES)
 
 
-def arena_order(model):
-  """[(name, param)] of the trainable parameters in flat-arena order (late-finishing gradients first) and the element offset at
-  which the early-finishing group starts.  Engine.alloc_grads and Trainer._flatten both use it."""
+def arena_layout(model):
+  """Layout of the flat parameter / gradient arenas: ([(name, param, offset)], total elements, bucket offsets [o_0 = 0, ..., o_K = total]).
+
+  Bucket b holds the parameters whose gradients are complete when the b-th batch of the weight-gradient lane has run (completion order
+  of the backward pass), so the data-parallel exchange can all-reduce bucket b while the rest of backward still computes
+  (team_code/train.py:516-520: what DistributedDataParallel does with ~20 reverse-order 25 MB buckets).  The assignment comes from an
+  observed pass (``model._grad_buckets`` = {name: bucket}, set by Trainer.apply_observed_layout); before that, the static guess of
+  finishes_early() gives two buckets.  Parameters are padded to 4 elements, buckets to BUCKET_ALIGN."""
   params = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
-  late = [(n, p) for n, p in params if not finishes_early(n)]
-  early = [(n, p) for n, p in params if finishes_early(n)]
-  return late + early, sum(ops.pad_to(p.numel(), 4) for _, p in late)
+  assign = model.__dict__.get('_grad_buckets')
+  if assign is not None and all(n in assign for n, _ in params):
+    key = lambda n: assign[n]
+  else:
+    key = lambda n: 0 if finishes_early(n) else 1
+  nb = max((key(n) for n, _ in params), default=0) + 1
+  out, offsets, off = [], [0], 0
+  for b in range(nb):
+    for n, p in params:
+      if key(n) == b:
+        out.append((n, p, off))
+        off += ops.pad_to(p.numel(), 4)
+    if b + 1 < nb:
+      off = ops.pad_to(off, BUCKET_ALIGN)
+    offsets.append(off)
+  return out, off, offsets
+
+
+def arena_order(model):
+  """[(name, param)] in arena order (kept for tools: tools/replay_diff.py)."""
+  return [(n, p) for n, p, _ in arena_layout(model)[0]]
 
 
 class ConvSpec:
@@ -631,6 +662,10 @@ class Engine:
     self.lanes = Lanes()
     self.side = SideLane()
     self.side.lanes = self.lanes
+    from .buckets import GradBuckets
+    self.buckets = GradBuckets()
+    self._glog, self._bucket_of, self._want_flushes, self.observed_buckets, self.observation_stable, self._prev_total = {}, None, None, None, False, 0
+    self.bucket_program = ((), ())
     self._build_specs()
 
   # ------------------------------------------------------------------------------------------------ set-up
@@ -876,31 +911,79 @@ class Engine:
 
   # ------------------------------------------------------------------------------------------------ gradients
   def alloc_grads(self, zero=True):
-    """(Re)create the flat gradient arena when the set of trainable parameters changed; ``zero``: start the step from a zeroed arena (every
-    gradient kernel accumulates).  The drop-in path zeroes (or keeps: gradient accumulation) the arena itself and passes zero=False."""
-    sig = tuple(id(p) for p in self.m.parameters() if p.requires_grad)
+    """(Re)create the flat gradient arena when the set of trainable parameters or the bucket assignment changed; ``zero``: start the step
+    from a zeroed arena (every gradient kernel accumulates).  The drop-in path zeroes (or keeps: gradient accumulation) the arena itself
+    and passes zero=False."""
+    sig = (tuple(id(p) for p in self.m.parameters() if p.requires_grad), id(self.m.__dict__.get('_grad_buckets')))
     if self.flat_grad is not None and sig == getattr(self, '_grad_sig', None) and self.flat_grad.device == self.device:
       if zero:
         ops.zero_(self.flat_grad)
         ops.clear_stats_rows(self.device)
       return
     self._grad_sig = sig
-    params, self.early_offset = arena_order(self.m)
-    total = sum(ops.pad_to(p.numel(), 4) for _, p in params)
-    if self.flat_grad is None or self.flat_grad.numel() != total or self.flat_grad.device != self.device:
-      self.flat_grad = torch.empty(total, device=self.device, dtype=F32)
+    layout, total, self.bucket_offsets = arena_layout(self.m)
+    self.flat_grad = torch.empty(total, device=self.device, dtype=F32)  # (always a NEW tensor: holders of views compare identities)
     self.grads = {}
-    off = 0
-    for n, p in params:
+    for n, p, off in layout:
       self.grads[n] = self.flat_grad[off:off + p.numel()].view(p.shape)
-      off += ops.pad_to(p.numel(), 4)
-    self._gid = {id(p): n for n, p in params}
+    self._gid = {id(p): n for n, p, _ in layout}
+    assign = self.m.__dict__.get('_grad_buckets')
+    self._bucket_of = dict(assign) if assign is not None and all(n in assign for n in self.grads) else None  # None: static guess, nothing is known
+    self.buckets.configure(self.bucket_offsets, self.device, observed=self._bucket_of is not None)
     ops.zero_(self.flat_grad)  # (a new arena always starts from zero)
     ops.clear_stats_rows(self.device)  # the fused BatchNorm statistics start every step from zeroed rows, whatever happened before
 
   def g(self, param):
+    """Gradient slot of ``param`` (a view of the flat arena).  Every call is a write site of the backward pass: the batch of the
+    weight-gradient lane that will have covered it is logged -- the arena is laid out by that order (arena_layout), and a write that
+    comes LATER than the parameter's bucket says (another closure order than the observed one) cancels the early events of this pass."""
     n = self._gid.get(id(param))
-    return None if n is None else self.grads[n]
+    if n is None:
+      return None
+    side = self.side
+    b = side.flush_seq - 1 if side.in_flush else side.flush_seq
+    if b > self._glog.get(n, -1):
+      self._glog[n] = b
+      if self._bucket_of is not None and b > self._bucket_of[n]:
+        self.buckets.poison(f'gradient of {n} written in batch {b}, its bucket is {self._bucket_of[n]}')
+    return self.grads[n]
+
+  def begin_backward(self):
+    """Start of a backward pass (Trainer / DropinStep call it before Tape.backward)."""
+    self._glog = {}
+    self.buckets.begin_pass()
+    self._prev_total = self.side.total_prev
+    self.side.last_flush_counts = []
+    self.side.on_batch_end = self._batch_end
+    # the closure counts at which the lane flushed in the observed pass: another flush pattern = other bucket contents
+    self._want_flushes = self.m.__dict__.get('_grad_bucket_flushes')
+
+  def _batch_end(self, seq):
+    side = self.side
+    if self._bucket_of is None:
+      return
+    want = self._want_flushes
+    if want is None or seq >= len(want) or side.flush_counts[seq] != want[seq]:
+      self.buckets.poison(f'batch {seq} of the weight-gradient lane was flushed at closure {side.flush_counts[seq]}, the observed pass flushed at {want}')
+      return
+    if seq < self.buckets.count - 1:  # (the last bucket is complete at the end of the pass: buckets.finish())
+      self.buckets.record(seq)
+
+  def end_backward(self):
+    """End of a backward pass (after Tape.backward returned: every lane joined).  Returns the observation of this pass:
+    ({name: bucket}, closure counts at the flushes) -- what Trainer.apply_observed_layout turns into the arena layout."""
+    self.bucket_program = self.buckets.finish()  # (early signals raised, early signals usable): kept by whoever replays this pass
+    self.side.on_batch_end = None
+    flushes = list(self.side.last_flush_counts)
+    obs = dict(self._glog)
+    nb = max(len(flushes), 1)
+    for n in self.grads:  # parameters nobody wrote (unused heads): with the last bucket
+      obs[n] = min(obs.get(n, nb - 1), nb - 1)
+    self.observed_buckets = (obs, flushes)
+    # the lane forks at fractions of the PREVIOUS pass's closure count: the observation describes the next pass once that count has settled
+    side = self.side
+    self.observation_stable = (not side.enabled) or (not side.forks) or side.flush_at is not None or (side.total_prev > 0 and side.total_prev == self._prev_total)
+    return self.observed_buckets
 
   # ------------------------------------------------------------------------------------------------ fused BatchNorm-backward sums
   def _bns_request(self, x, query):

@@ -80,41 +80,38 @@ class GraphedForward:
 
 
 class GraphedTrainStep:
-  """Captures the training step body (repack + forward + losses + backward) for a fixed batch layout; the gradient
-  all-reduce and the optimizer launch stay outside the graphs so RCCL is never captured.  With more than one rank the body is
-  captured as TWO graphs sharing one memory pool, split where the gradients of the heads and of fusion stage 4 are final
-  (Tape.mark): their slice of the arena is all-reduced while the second graph replays."""
+  """Captures the training step body (repack + forward + losses + backward) for a fixed batch layout as ONE hipGraph, for one rank and for
+  eight alike; the gradient all-reduces and the optimizer launches stay outside the graph so RCCL is never captured.  The captured pass
+  records an external event behind the kernels that complete each bucket of the gradient arena (buckets.py); after ``graph.replay()``
+  returns -- the replay is still running -- Trainer.finish_step() issues the all-reduce of every bucket behind its event."""
 
   def __init__(self, trainer, batch, warmup=2):
-    """NOTE: the ``warmup`` eager steps are real training steps (parameters, optimizer state and ``step_count`` advance)."""
+    """NOTE: the eager steps in front of the capture are real training steps (parameters, optimizer state and ``step_count`` advance).
+    At least one runs, more until the arenas are in their observed completion order (Trainer.apply_observed_layout: the second pass is the
+    first one with the lane's final fork points) and one step has run in that layout."""
     self.trainer = trainer
     self.static_batch = {k: v.clone() for k, v in batch.items()}
-    for _ in range(warmup):
+    steps = 0
+    ready = lambda: trainer.step_count > 0 and trainer.layout_final and trainer.eager_steps_in_layout >= 1
+    while steps < warmup or (not ready() and steps < warmup + 4):
       trainer.train_step(self.static_batch)
+      steps += 1
+      trainer.apply_observed_layout()  # (when this step produced a valid observation; the next eager step then runs in the new layout)
     if trainer.step_count == 0:
-      raise RuntimeError('GraphedTrainStep: run at least one eager train_step first (warmup >= 1): the capture must not be the call '
-                         'that sizes and allocates the scratch buffers')
+      raise RuntimeError('GraphedTrainStep: run at least one eager train_step first: the capture must not be the call that sizes and '
+                         'allocates the scratch buffers')
+    trainer.layout_final = True  # (frozen from here on: the graph holds pointers into the arenas)
     torch.cuda.synchronize()
-    self.split = trainer.overlap_enabled()
     self.graph = torch.cuda.CUDAGraph()
-    self.graph2 = None
     dot = _os.environ.get('TFPP_DEBUG_GRAPH_DOT')  # debugging aid (tools/graph_lists.py): hipGraphDebugDotPrint of the captured step
     if dot:
       self.graph.enable_debug_mode()
     st = capture_stream(trainer.eng.device)
-    if self.split:
-      with capture(self.graph, st):
-        self.vals = trainer._step_part1(self.static_batch)
-      self.graph2 = torch.cuda.CUDAGraph()
-      with capture(self.graph2, st, pool=self.graph.pool()):
-        trainer._step_part2()
-    else:
-      with capture(self.graph, st):
-        self.vals = trainer._step_body(self.static_batch)
+    with capture(self.graph, st):
+      self.vals = trainer._step_body(self.static_batch)
+    self.program = trainer.program  # the completion signals of the gradient buckets every replay raises (buckets.py)
     if dot:
       self.graph.debug_dump(dot)
-    self.early_opt_in_graph = trainer.early_opt_in_step  # the captured step updates the early slice of the arena itself (trainer._early_optimizer)
-    trainer.early_opt_in_step = False  # (the capture executed nothing)
     torch.cuda.synchronize()
 
   def __call__(self, batch=None):
@@ -125,13 +122,6 @@ class GraphedTrainStep:
         if dst.data_ptr() != src.data_ptr():
           dst.copy_(src, non_blocking=True)
     tr.step_count += 1
-    if self.early_opt_in_graph:
-      tr.upload_hyper(tr.step_count)
     self.graph.replay()
-    tr.early_opt_in_step = self.early_opt_in_graph
-    early = None
-    if self.graph2 is not None:
-      early = tr.reduce_early()
-      self.graph2.replay()
-    tr.finish_step(early)
+    tr.finish_step(self.program)
     return self.vals

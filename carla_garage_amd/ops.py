@@ -112,6 +112,8 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
     p.bns_y, p.bns_x, p.bns_mean, p.bns_invstd = ptr(bns['y']), ptr(bns['x']), ptr(bns['mean']), ptr(bns['invstd'])
     p.bns_partial, p.bns_ld, p.bns_relu = ptr(bns['partial']), Cd, int(bns['relu'])
   if plan_only:  # (kernel variant, K slices) the dispatcher would use -- tests / bench bookkeeping
+    if stats_acc is not None or stats_ws is not None:
+      p.stats_partial = 16  # never dereferenced: plan as the launch with the fused BatchNorm statistics will be planned
     return lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p), dt(src)), lib.raw('tfpp_conv_gemm_splits')(ctypes.byref(p), dt(src))
   scratch = None
   if stats_acc is not None:

@@ -3,8 +3,10 @@
 One step = repack weights -> forward (engine tape) -> fused loss+gradient kernels -> tape backward into ONE flat fp32
 gradient arena -> (RCCL all-reduce of that arena, the path's only collective: plain data parallelism,
 team_code/train.py:516-520) -> fused AdamW(amsgrad) over the flat parameter arena (team_code/train.py:529-531,908).
-The whole step is a static launch sequence, so after warm-up it can be captured into a hipGraph
-(``capture_graph=True``) and replayed without Python or launch overhead.
+The whole step is a static launch sequence, so after warm-up it is captured into ONE hipGraph (graph.GraphedTrainStep) and replayed
+without Python or launch overhead -- with one rank and with eight: the arena is laid out in the order in which backward completes the
+gradients (engine.arena_layout, observed on the first eager passes), every bucket is all-reduced behind its own completion event while
+the rest of backward runs (buckets.py), and the optimizer updates a bucket as soon as it has landed.
 """
 import os
 
@@ -13,11 +15,8 @@ import torch.distributed as dist
 
 from . import ops
 from . import dist as tdist
-from .engine import Tape, F32, arena_order
+from .engine import Tape, F32, arena_layout
 from .losses import fused_losses, normalized_loss_weights, active_losses
-
-_PIPELINED_FINISH = os.environ.get('TFPP_PIPELINED_FINISH', '1') != '0'  # N > 1: optimizer on the early slice while the late slice is all-reduced
-_EARLY_OPT = os.environ.get('TFPP_EARLY_OPTIMIZER', '0') == '1'  # single GPU: update the early-finishing slice of the arena inside the step; measured SLOWER (25.57 vs 25.05 ms/step: 0.6 ms of HBM streaming beside the latency-bound main chain), off by default
 
 
 class Trainer:
@@ -53,33 +52,67 @@ class Trainer:
       self.set_groups([g['params'] for g in gr], [g['weight_decay'] for g in gr])
     self.seed_offset = ops.zeros(1, torch.int64, self.eng.device)  # advanced once per step (fresh dropout masks under replay)
     ops.set_seed_offset(self.seed_offset)
-    # optimizer scalars in device memory (tfpp_adamw_amsgrad_dev): lets the update of the early-finishing slice of the arena run INSIDE the step
-    self.hyper = ops.zeros(8, F32, self.eng.device)
-    self._hyper_host = [torch.empty(8, dtype=F32).pin_memory() for _ in range(4)] if self.eng.device.type == 'cuda' else None
-    self._hyper_i = 0
-    self.early_opt_in_step = False  # set by the hook when the in-step launch was issued (or captured): finish_step then updates the rest only
+    self.layout_final = False  # the arenas are in the completion order of an observed backward pass (apply_observed_layout)
+    self.eager_steps_in_layout = 0  # eager steps since the arenas last moved (a capture needs one: weight-image plans, scratch sizes)
 
   # ---------------------------------------------------------------------------------------------- flat arenas
   def _flatten(self):
-    """Re-home every trainable parameter into one flat fp32 arena (same offsets as the gradient arena)."""
+    """Re-home every trainable parameter into one flat fp32 arena (same offsets as the gradient arena).  Called again when the bucket
+    assignment changes (apply_observed_layout): values and optimizer state move with their parameters."""
     eng = self.eng
+    old_state = None
+    if getattr(self, 'exp_avg', None) is not None:  # (re-homing after optimizer steps: the moments follow their parameters)
+      old_state = (dict(self._offsets), self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq)
     eng.alloc_grads()
-    dev = eng.device
-    params, _ = arena_order(self.model)  # same order as the gradient arena: late-finishing gradients first
-    self.flat_param = torch.empty_like(eng.flat_grad)
-    ops.zero_(self.flat_param)
-    off = 0
-    for _, p in params:
+    layout, total, _ = arena_layout(self.model)  # same layout as the gradient arena
+    new_param = torch.empty(total, device=eng.device, dtype=F32)
+    ops.zero_(new_param)
+    for _, p, off in layout:
       n = p.numel()
-      dst = self.flat_param[off:off + n]
+      dst = new_param[off:off + n]
       ops.copy_rows(p.detach().contiguous(), dst, 1, n, 0, 0, 0, 0)
       p.data = dst.view(p.shape)
-      off += ops.pad_to(n, 4)
-      p._tfpp_arena = (self, off - ops.pad_to(n, 4))  # lets carla_garage_amd.optim.FlatAdamW find the arena a parameter lives in
+      p._tfpp_arena = (self, off)  # lets carla_garage_amd.optim.FlatAdamW find the arena a parameter lives in
+    self.flat_param = new_param
+    self._offsets = {id(p): off for _, p, off in layout}  # where every parameter lives in THIS layout (the next re-homing reads it)
+    self._slices = None
     self.exp_avg = self.exp_avg_sq = self.max_exp_avg_sq = None
-    if not self._lazy_state:
+    if old_state is not None:
+      old_off, *old_arenas = old_state
       self._alloc_state()
-    tdist.broadcast_state(self.flat_param, list(self.model.buffers()), self.pg)  # DDP constructor broadcast, train.py:516
+      for src, dst in zip(old_arenas, (self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq)):
+        for _, p, off in layout:
+          n = p.numel()
+          ops.copy_rows(src[old_off[id(p)]:old_off[id(p)] + n], dst[off:off + n], 1, n, 0, 0, 0, 0)
+    elif not self._lazy_state:
+      self._alloc_state()
+    if getattr(self, 'groups', None) is not None and getattr(self, 'no_decay_bits', None) is not None:
+      self._groups_key = None  # the no-decay bit mask is a function of the offsets
+      self.set_groups(self.groups, self.group_decays)
+    eng.invalidate()
+    if getattr(self, '_broadcast_done', False) is False:
+      tdist.broadcast_state(self.flat_param, list(self.model.buffers()), self.pg)  # DDP constructor broadcast, train.py:516
+      self._broadcast_done = True
+
+  def apply_observed_layout(self):
+    """Lay the arenas out in the completion order the last backward pass showed (Engine.end_backward), once that pass ran with the lane's
+    final fork points (the forks sit at fractions of the PREVIOUS pass's closure count, so the second eager pass is the first valid one).
+    Returns True when the arenas moved.  Never called while a captured graph holds pointers into them: graph.GraphedTrainStep and
+    dropin.DropinStep run it on their eager warm-up steps only."""
+    eng = self.eng
+    obs = eng.observed_buckets
+    if self.layout_final or obs is None or not getattr(eng, 'observation_stable', False):
+      return False
+    assign, flushes = obs
+    self.layout_final = True
+    cur = self.model.__dict__.get('_grad_buckets')
+    if cur == assign and self.model.__dict__.get('_grad_bucket_flushes') == flushes:
+      return False
+    self.model.__dict__['_grad_buckets'] = dict(assign)
+    self.model.__dict__['_grad_bucket_flushes'] = list(flushes)
+    self._flatten()
+    self.eager_steps_in_layout = 0
+    return True
 
   def _alloc_state(self):
     if self.exp_avg is None:
@@ -104,10 +137,9 @@ class Trainer:
     return self._slices
 
   # ---------------------------------------------------------------------------------------------- one step
-  def _step_part1(self, batch, split=True):
-    """repack + forward + losses + the first backward segment (back to the end of fusion stage 3): on return the tail of the
-    gradient arena, flat_grad[eng.early_offset:], is final.  split=False runs the whole backward in one segment (no join of the
-    lanes in the middle: the single-GPU step)."""
+  def _step_body(self, batch):
+    """repack + forward + losses + backward: the part of the step that is captured into the hipGraph.  The lanes are joined once, at the
+    end; the completion events of the gradient buckets are recorded on the weight-gradient lane as the pass goes (Engine._batch_end)."""
     eng, model = self.eng, self.model
     eng.training = True
     eng.dtype = model.compute_dtype
@@ -121,50 +153,16 @@ class Trainer:
     ops.inc_u64(self.seed_offset)
     eng._seed_ctr = 0  # the per-call part of the seeds is a function of the call site only
     eng.tape = Tape(eng.lanes)
-    self.early_opt_in_step = False
-    if _EARLY_OPT and not split and not self.overlap_enabled() and eng.side.enabled and self._hyper_host is not None and self.no_decay_bits is None:
-      # single GPU: nothing has to be exchanged first, so the two thirds of the parameters whose gradients are final once backward has passed
-      # Tape.mark() are updated on the weight-gradient lane while the stages 3..1 are still being differentiated
-      eng.tape.on_mark = self._arm_early_optimizer
     t = eng.forward(batch['rgb'], batch['lidar_bev'], batch['target_point'], batch['ego_vel'], batch['command'])
     ops.stamp('step lane0 FORWARD DONE')
     _, vals, seeds = fused_losses(model, t, batch, self.loss_weights, True)
     ops.stamp('step lane0 losses done')
-    self._tape, eng.tape = eng.tape, None
-    self._tape.backward(seeds, stop_at_mark=split)
+    tape, eng.tape = eng.tape, None
+    eng.begin_backward()
+    tape.backward(seeds)
+    eng.end_backward()
+    self.program = eng.bucket_program  # the completion signals this pass raises (a graph that replays it raises the same ones)
     return vals
-
-  def _step_part2(self):
-    """the rest of backward (stems .. fusion stage 3)"""
-    self._tape.backward_resume()
-    self._tape = None
-
-  def _step_body(self, batch):
-    vals = self._step_part1(batch, split=False)
-    self._tape = None
-    self.eng.side.after_mark, self.eng.side.mark_passed = None, False
-    return vals
-
-  def _arm_early_optimizer(self):
-    side = self.eng.side
-    side.mark_passed, side.after_mark = True, self._early_optimizer
-
-  def _early_optimizer(self):
-    off = self.eng.early_offset
-    self._alloc_state()
-    ops.adamw_amsgrad_dev(self.flat_param[off:], self.eng.flat_grad[off:], self.exp_avg[off:], self.exp_avg_sq[off:], self.max_exp_avg_sq[off:], self.hyper)
-    self.early_opt_in_step = True
-
-  def upload_hyper(self, step):
-    """The optimizer scalars of update number ``step`` -> device (asynchronous copy from a pinned buffer; before the step that contains the launch)."""
-    if self._hyper_host is None:
-      return
-    h = self._hyper_host[self._hyper_i % len(self._hyper_host)]
-    self._hyper_i += 1
-    bc1, bc2s = ops.adamw_bias_corrections(self.betas[0], self.betas[1], step)
-    for i, v in enumerate((self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, 1.0 / self.world, bc1, bc2s)):
-      h[i] = v
-    self.hyper.copy_(h, non_blocking=True)
 
   def set_groups(self, param_lists, weight_decays):
     """The optimizer's parameter groups in order (lists of parameters, frozen ones included as torch numbers them) and their weight decays:
@@ -201,14 +199,13 @@ class Trainer:
 
   def _optimizer(self, step, grad_scale=None, upto=None, lo=0):
     """grad_scale: None = 1 / world (the arena holds the SUM over the ranks); the drop-in path passes 1.0 (already averaged).
-    upto / lo: only the elements lo .. upto-1 of the arena (the early-finishing slice is updated on its own: inside the step by
-    _early_optimizer, or by finish_step while the late slice is still being all-reduced)."""
+    upto / lo: only the elements lo .. upto-1 of the arena (finish_step updates bucket after bucket as the all-reduces land)."""
     self._alloc_state()
     self.eng.invalidate()
     sl = slice(lo, upto)
     bits = self.no_decay_bits
     if bits is not None and lo:
-      assert lo % 128 == 0  # one 32-bit word of the mask covers 128 elements (finish_step only splits at such an offset)
+      assert lo % 128 == 0  # one 32-bit word of the mask covers 128 elements (buckets start on such an offset: engine.BUCKET_ALIGN)
       bits = bits[lo // 128:]
     ops.adamw_amsgrad(self.flat_param[sl], self.eng.flat_grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.max_exp_avg_sq[sl], self.lr, self.betas[0],
                       self.betas[1], self.eps, self.weight_decay, step, grad_scale=1.0 / self.world if grad_scale is None else grad_scale,
@@ -218,60 +215,39 @@ class Trainer:
     """batch: dict with rgb, lidar_bev, target_point, ego_vel, command and the *_label tensors (reference layouts).
     Returns the vector of unweighted losses (device tensor, order = self.loss_names)."""
     self.model.train()
+    self.apply_observed_layout()  # (eager steps only: a captured step never comes through here)
     self.step_count += 1
-    if not self.overlap_enabled():
-      self.upload_hyper(self.step_count)
-      vals = self._step_body(batch)
-      self.finish_step()
-      return vals
-    vals = self._step_part1(batch)
-    early = self.reduce_early()  # N > 1: the finished two thirds of the gradients travel while the rest is computed
-    self._step_part2()
-    self.finish_step(early)
+    vals = self._step_body(batch)
+    self.finish_step(self.program)
+    self.eager_steps_in_layout += 1
     return vals
 
-  def overlap_enabled(self):
-    return (self.exchange and tdist.exchange_enabled(self.pg)) or os.environ.get('TFPP_SPLIT_STEP', '0') == '1'
+  def exchange_enabled(self):
+    return self.exchange and tdist.exchange_enabled(self.pg)
 
-  def reduce_early(self, avg=False):
-    """Asynchronous all-reduce of flat_grad[early_offset:] (RCCL runs it on its own stream, ordered after what this stream has
-    issued so far).  Returns the handle finish_step() waits on, or None when there is nothing to overlap."""
-    if not self.exchange:
-      return None
-    return tdist.all_reduce_async(self.eng.flat_grad[self.eng.early_offset:], self.pg, avg=avg)
-
-  def finish_step(self, early=None):
-    """rest of the gradient exchange + optimizer (kept outside any captured graph)."""
-    if not self.exchange:
-      pass
-    elif early is None:
-      tdist.all_reduce_gradients(self.eng.flat_grad, self.pg)
-    else:
-      off = self.eng.early_offset
-      late = tdist.all_reduce_async(self.eng.flat_grad[:off], self.pg) if _PIPELINED_FINISH else None
-      if late is None:
-        tdist.all_reduce_gradients(self.eng.flat_grad[:off], self.pg)
-      early.wait()
-      if late is not None:
-        # the late third of the arena (stems .. fusion stage 3) is the only part of the exchange nothing computes beside: the optimizer
-        # updates the early two thirds (already reduced) while it travels -- 0.58 ms of the 0.87 ms launch hide 0.26 (direct) .. 1.8 ms (ring)
-        split = not self.early_opt_in_step and (self.no_decay_bits is None or off % 128 == 0)
-        if split:
-          self._optimizer(self.step_count, lo=off)
-        late.wait()
-        self._optimizer(self.step_count, upto=off if (split or self.early_opt_in_step) else None)
-        return
-    self._optimizer(self.step_count, upto=self.eng.early_offset if self.early_opt_in_step else None)
+  def finish_step(self, program):
+    """Gradient exchange + optimizer (outside any captured graph: RCCL is never captured).  ``program``: the completion signals of the pass
+    that was just issued (Trainer.program after an eager pass, GraphedTrainStep.program for a replay).  One asynchronous all-reduce per
+    bucket of the arena, each ordered behind the signal that says "this bucket is complete" -- they start while backward (the graph replay
+    in flight) is still running -- and one optimizer launch per bucket as soon as it has landed; without an exchange, one launch over the
+    whole arena."""
+    buckets = self.eng.buckets
+    buckets.executed(program)
+    works = buckets.exchange(self.eng.flat_grad, program, self.pg) if self.exchange else []
+    if not works:
+      self._optimizer(self.step_count)
+      return
+    for (lo, hi), work in zip(self.eng.buckets.ranges(), works):
+      if work is None:
+        continue
+      work.wait()
+      self._optimizer(self.step_count, lo=lo, upto=hi)
 
   # ---------------------------------------------------------------------------------------------- checkpoint / resume
   def _arena_slices(self):
     """[(index in model.parameters() order, arena offset, parameter)] of the trainable parameters."""
     index = {id(p): i for i, p in enumerate(self.model.parameters())}
-    out, off = [], 0
-    for _, p in arena_order(self.model)[0]:
-      out.append((index[id(p)], off, p))
-      off += ops.pad_to(p.numel(), 4)
-    return out
+    return [(index[id(p)], off, p) for _, p, off in arena_layout(self.model)[0]]
 
   def state_dict(self):
     """The optimizer state in the layout ``torch.optim.AdamW(model.parameters(), lr, amsgrad=True).state_dict()`` has in the

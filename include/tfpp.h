@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TFPP_ABI_VERSION 1
+#define TFPP_ABI_VERSION 2
 #define TFPP_EINVAL (-1000)
 #define TFPP_F32 0
 #define TFPP_BF16 1
@@ -439,6 +439,13 @@ int tfpp_add_dropout(const void* a, const void* b, void* y, int64_t n, float p_d
 /* dropout masks are a pure function of (seed + *seed_offset, element index); seed_offset (nullable) is a device counter that
  * tfpp_inc_u64 advances once per training step so that a replayed hipGraph draws fresh masks. */
 int tfpp_inc_u64(uint64_t* p, void* stream);
+/* Completion signal from a kernel node inside a captured hipGraph to a stream outside of it (data-parallel gradient exchange,
+ * team_code/train.py:516-520: the all-reduce of a gradient bucket starts while backward is still running).  sig: a zero-initialised 64-bit
+ * counter in device memory.  tfpp_signal_add: *sig += 1 (device-scope atomic) behind everything issued so far on `stream`.
+ * tfpp_signal_wait: the work issued on `stream` after this call starts once *sig >= value; gives up after timeout_ms and then adds 1 to
+ * *timeouts (nullable). */
+int tfpp_signal_add(uint64_t* sig, void* stream);
+int tfpp_signal_wait(uint64_t* sig, uint64_t value, int timeout_ms, uint32_t* timeouts, void* stream);
 int tfpp_add_bcast(const void* x, const float* bcast, void* y, int64_t n, int64_t period, int dtype, void* stream);
 int tfpp_act_bwd(const void* dy, const void* y, void* dx, int64_t n, int act, int dtype, void* stream);
 int tfpp_axpy(const void* x, void* y, int64_t n, float a, int dtype, void* stream);

@@ -1,7 +1,7 @@
 """Worker of tests/test_dist_gpu.py: runs in its own process with a ONE-rank 'nccl' (= RCCL) process group and
-TFPP_FORCE_COLLECTIVES=1, so the whole data-parallel step of team_code/train.py:516-520,898 -- two backward segments, the
-asynchronous all-reduce of the early-finishing slice between them, the all-reduce of the rest, the optimizer waiting on both,
-and the same thing as two hipGraphs with the RCCL call between the replays -- executes on a 1-GPU box.  Prints one JSON line."""
+TFPP_FORCE_COLLECTIVES=1, so the whole data-parallel step of team_code/train.py:516-520,898 -- one backward pass that raises a completion
+signal per gradient bucket, one asynchronous RCCL all-reduce per bucket behind its signal, the optimizer bucket by bucket as they land,
+and the same thing with the pass replayed from ONE hipGraph -- executes on a 1-GPU box.  Prints one JSON line."""
 import json
 import os
 import sys
@@ -49,39 +49,47 @@ def main():
     m.config.embd_pdrop = m.config.resid_pdrop = m.config.attn_pdrop = 0.0
     return m
 
-  # reference: the local single-segment step (no collective)
+  by_name = lambda tr: np.concatenate([tr.eng.grads[n].detach().double().cpu().numpy().ravel() for n, p in tr.model.named_parameters() if p.requires_grad])
+  params = lambda tr: np.concatenate([p.detach().double().cpu().numpy().ravel() for p in tr.model.parameters()])
+
+  # reference: the local step (no collective)
   tr0 = Trainer(fresh(), lr=1e-5)
   tr0.exchange = False
-  assert not tr0.overlap_enabled()
+  assert not tr0.exchange_enabled()
   v0 = tr0.train_step(batch).float().cpu().numpy()
-  g0 = tr0.eng.flat_grad.detach().double().cpu().numpy()
-  p0 = tr0.flat_param.detach().double().cpu().numpy()
+  g0, p0 = by_name(tr0), params(tr0)
   n0 = dict(calls)
 
-  # eager step with the exchange: two segments + async all-reduce in between + all-reduce of the head
+  # eager step with the exchange: one all-reduce per bucket of the arena
   tr1 = Trainer(fresh(), lr=1e-5)
-  assert tr1.overlap_enabled() and tr1.world == 1
+  assert tr1.exchange_enabled() and tr1.world == 1
   v1 = tr1.train_step(batch).float().cpu().numpy()
   torch.cuda.synchronize()
-  g1 = tr1.eng.flat_grad.detach().double().cpu().numpy()
-  p1 = tr1.flat_param.detach().double().cpu().numpy()
+  g1, p1 = by_name(tr1), params(tr1)
   n1 = dict(calls)
+  buckets_static = len(tr1.eng.buckets.ranges())
 
-  # the same as two hipGraphs with the RCCL calls between / after the replays (second step of tr1 vs second local step of tr0)
+  # steps 2-3: the arenas move into the observed completion order; step 4 replayed from ONE hipGraph with the RCCL calls after the replay
+  # call returns (they wait for the in-graph completion signals) -- against the fourth local step of tr0
+  for _ in range(2):
+    tr0.train_step(batch)
+    tr1.train_step(batch)
   v0b = tr0.train_step(batch).float().cpu().numpy()
-  g0b = tr0.eng.flat_grad.detach().double().cpu().numpy()
+  g0b = by_name(tr0)
   gs = GraphedTrainStep(tr1, batch, warmup=0)
-  assert gs.split and gs.graph2 is not None
+  assert tr1.step_count == 3 and tr1.layout_final
   before = dict(calls)
   v2 = gs(batch).float().cpu().numpy()
   torch.cuda.synchronize()
-  g2 = tr1.eng.flat_grad.detach().double().cpu().numpy()
+  g2 = by_name(tr1)
   after = dict(calls)
   rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
   out = {'world': dist.get_world_size(), 'backend': dist.get_backend(),
          'calls_local': n0['all_reduce'], 'calls_eager_step': n1['all_reduce'] - n0['all_reduce'], 'async_eager_step': n1['async'] - n0['async'],
          'bytes_eager_step': n1['bytes'] - n0['bytes'], 'arena_bytes': int(tr1.eng.flat_grad.numel()) * 4,
          'calls_graph_step': after['all_reduce'] - before['all_reduce'], 'async_graph_step': after['async'] - before['async'],
+         'bytes_graph_step': after['bytes'] - before['bytes'], 'buckets_static': buckets_static, 'buckets_observed': len(tr1.eng.buckets.ranges()),
+         'early_signals': len(gs.program[1]), 'poisoned': tr1.eng.buckets.poisoned, 'wait_timeouts': tr1.eng.buckets.timed_out(),
          'loss_eager': float(np.max(np.abs(v1 - v0) / np.abs(v0))), 'grad_eager': rel(g1, g0), 'param_eager': rel(p1, p0),
          'loss_graph': float(np.max(np.abs(v2 - v0b) / np.abs(v0b))), 'grad_graph': rel(g2, g0b)}
   print('RESULT ' + json.dumps(out), flush=True)

@@ -24,7 +24,7 @@ def main():
   from carla_garage_amd.optim import FlatAdamW
   torch.cuda.set_device(0)
   lr = 1e-4
-  batches = T._batches(4)
+  batches = T._batches(5)
   os.environ['TFPP_FORCE_COLLECTIVES'] = '0'
   want, want_param, _ = T._trainer_reference(batches, lr)   # before the process group exists: a purely local Trainer
   os.environ['TFPP_FORCE_COLLECTIVES'] = '1'
@@ -43,19 +43,22 @@ def main():
   managed = [n for n, p in m.named_parameters() if p.requires_grad and n not in ddp.parameters_to_ignore and '.' + n not in ddp.parameters_to_ignore]
   opt = FlatAdamW(ddp.parameters(), lr=lr, amsgrad=True)
   w = normalized_loss_weights(m.config)
-  got, per_step, per_bytes = [], [], []
+  got, per_step, per_bytes, arena_at = [], [], [], []
   for b in batches:
     n0, b0 = calls['n'], calls['bytes']
     got += T.train_py_loop(m, opt, [b], w, wrapper=ddp)
     torch.cuda.synchronize()
     per_step.append(calls['n'] - n0)
     per_bytes.append(calls['bytes'] - b0)
+    arena_at.append(int(m.__dict__['_dropin_step'].eng.flat_grad.numel()) * 4)
   step = m.__dict__['_dropin_step']
   plan = next(iter(step.plans.values()))
+  got_param = T._params_by_name(m)
   out = {'ddp_params': len(managed), 'ignored': len(ddp.parameters_to_ignore), 'trainable': len([p for p in m.parameters() if p.requires_grad]),
-         'calls_per_step': per_step, 'arena_bytes_per_step': per_bytes, 'arena_bytes': int(step.eng.flat_grad.numel()) * 4,
-         'graph_steps': plan.count - 2 if plan.B2 is not None else 0, 'lr': lr,
-         'loss_rel': [abs(a - b) / abs(b) for a, b in zip(got, want)], 'param_abs': T._check_params(step.tr.flat_param, want_param, 4, lr)[1], 'param_rel': T._check_params(step.tr.flat_param, want_param, 4, lr)[0]}
+         'calls_per_step': per_step, 'arena_bytes_per_step': per_bytes, 'arena_bytes_at_step': arena_at, 'arena_bytes': int(step.eng.flat_grad.numel()) * 4,
+         'buckets': len(step.eng.buckets.ranges()), 'early_signals': len(plan.program[1]) if plan.program else -1, 'wait_timeouts': step.eng.buckets.timed_out(),
+         'graph_steps': plan.count - 3 if plan.B1 is not None else 0, 'lr': lr,
+         'loss_rel': [abs(a - b) / abs(b) for a, b in zip(got, want)], 'param_abs': T._check_params(got_param, want_param, 5, lr)[1], 'param_rel': T._check_params(got_param, want_param, 5, lr)[0]}
   print('RESULT ' + json.dumps(out), flush=True)
   torch.cuda.synchronize()
   dist.destroy_process_group()

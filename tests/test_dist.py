@@ -85,78 +85,72 @@ def test_single_process_is_a_no_op():
 
 
 def _trainer_schedule_worker(rank, world, port, out):
-  """Drives Trainer.train_step ITSELF (trainer.py: _step_part1 -> reduce_early -> _step_part2 -> finish_step) with the GPU parts stubbed: the
-  backward segments only write this rank's gradients into the two slices of the arena.  What is tested is the bucket schedule: the early
-  slice [early_offset:] is all-reduced asynchronously BETWEEN the segments, the head [:early_offset] after the second one, the optimizer runs
-  after both have completed and sees the SUM over the ranks (the 1/world average is the optimizer's grad_scale)."""
+  """Drives Trainer.train_step ITSELF (trainer.py: _step_body -> finish_step -> GradBuckets.exchange) with the GPU parts stubbed: the step body
+  only writes this rank's gradients into the arena.  What is tested is the bucket schedule: ONE step body (no second segment), then one
+  asynchronous all-reduce per bucket of the arena in completion order, the optimizer launched on a bucket right after THAT bucket's
+  collective has completed (never before), every bucket exactly once, and the optimizer sees the SUM over the ranks (the 1/world average is
+  its grad_scale)."""
   import types
+  from carla_garage_amd.buckets import GradBuckets
   from carla_garage_amd.trainer import Trainer
   os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
   tdist.init_from_env('gloo')
-  n, off = 5003, 1801
+  offsets = [0, 1792, 3072, 4224, 5003]  # four buckets (bucket starts are multiples of 128 elements, engine.BUCKET_ALIGN)
+  n = offsets[-1]
   events = []
   tr = Trainer.__new__(Trainer)
-  tr.model = types.SimpleNamespace(train=lambda: None)
-  tr.pg, tr.world, tr.step_count, tr.exchange, tr._lazy_state, tr.early_opt_in_step, tr.no_decay_bits = None, world, 0, True, False, False, None
-  tr.eng = types.SimpleNamespace(flat_grad=torch.zeros(n), early_offset=off, invalidate=lambda: None)
+  tr.model = types.SimpleNamespace(train=lambda: None, __dict__={})
+  tr.pg, tr.world, tr.step_count, tr.exchange, tr._lazy_state, tr.no_decay_bits = None, world, 0, True, False, None
+  tr.layout_final, tr.eager_steps_in_layout = True, 0
+  buckets = GradBuckets()
+  buckets.configure(offsets, 'cpu', observed=True)
+  tr.eng = types.SimpleNamespace(flat_grad=torch.zeros(n), invalidate=lambda: None, buckets=buckets, observed_buckets=None)
   mine = torch.arange(n, dtype=torch.float32) * (rank + 1)
 
-  def part1(batch, split=True):
-    assert split
-    tr.eng.flat_grad[off:] = mine[off:]           # the heads / stage-4 gradients are final after the first backward segment ...
-    events.append('segment1')
+  def body(batch):
+    tr.eng.flat_grad[:] = mine
+    events.append('step_body')
+    tr.program = ((0, 1, 2), (0, 1, 2))  # three buckets raise an early completion signal, the last one is complete at the end of the pass
     return torch.zeros(3)
 
-  def part2():
-    assert 'early_issued' in events                # ... and are already travelling when the second segment starts
-    tr.eng.flat_grad[:off] = mine[:off]
-    events.append('segment2')
+  tr.seen = torch.zeros(n)
 
   def optimizer(step, grad_scale=None, upto=None, lo=0):
-    # finish_step: the early slice [off:] is updated while the late slice travels, then the late slice [:off]
-    assert (lo, upto) in ((off, None), (0, off))
-    events.append('optimizer_early' if lo else 'optimizer_late')
-    if lo:
-      tr.seen = torch.zeros(n)
-      tr.seen[lo:] = tr.eng.flat_grad[lo:]     # what this launch consumed: must already be the sum over the ranks
-    else:
-      tr.seen[:upto] = tr.eng.flat_grad[:upto]
+    b = offsets.index(lo)
+    assert upto == offsets[b + 1]
+    assert f'waited{b}' in events, (b, events)       # the optimizer never touches a bucket whose collective it has not waited for
+    events.append(f'optimizer{b}')
+    tr.seen[lo:upto] = tr.eng.flat_grad[lo:upto]     # what this launch consumed: must already be the sum over the ranks
     tr.scale = 1.0 / tr.world if grad_scale is None else grad_scale
 
-  tr._step_part1, tr._step_part2, tr._optimizer = part1, part2, optimizer
-  real_async, real_sync = tdist.all_reduce_async, tdist.all_reduce_gradients
+  tr._step_body, tr._optimizer = body, optimizer
+  real_async = tdist.all_reduce_async
 
   class Handle:
 
-    def __init__(self, work, name='early_waited'):
-      self.work, self.name = work, name
+    def __init__(self, work, b):
+      self.work, self.b = work, b
 
     def wait(self):
-      events.append(self.name)
+      events.append(f'waited{self.b}')
       self.work.wait()
 
   def rec_async(t, group=None, avg=False):
-    if t.data_ptr() == tr.eng.flat_grad.data_ptr():
-      assert t.numel() == off                                                             # exactly the head slice (late-finishing gradients)
-      events.append('late_issued')
-      return Handle(real_async(t, group, avg=avg), 'late_waited')
-    assert t.data_ptr() == tr.eng.flat_grad[off:].data_ptr() and t.numel() == n - off   # exactly the tail slice of the arena
-    events.append('early_issued')
-    return Handle(real_async(t, group, avg=avg))
+    b = [i for i in range(len(offsets) - 1) if t.data_ptr() == tr.eng.flat_grad[offsets[i]:].data_ptr()]
+    assert len(b) == 1 and t.numel() == offsets[b[0] + 1] - offsets[b[0]]   # exactly one bucket of the arena
+    events.append(f'issued{b[0]}')
+    return Handle(real_async(t, group, avg=avg), b[0])
 
-  def rec_sync(t, group=None, chunk_elems=None, avg=False):
-    assert t.data_ptr() == tr.eng.flat_grad.data_ptr() and t.numel() == off               # exactly the head slice
-    events.append('head_reduced')
-    return real_sync(t, group, chunk_elems, avg=avg)
-
-  tdist.all_reduce_async, tdist.all_reduce_gradients = rec_async, rec_sync
-  assert tr.overlap_enabled()
+  tdist.all_reduce_async = rec_async
+  assert tr.exchange_enabled()
   tr.train_step({})
+  assert buckets.expected == [1, 1, 1, 0, 1]  # host mirror of the completion counters: the pass raised buckets 0..2 and the end marker
   # the averaged variant the drop-in path uses (dropin.py): gloo has no ReduceOp.AVG -> SUM + scale after the wait
+  tdist.all_reduce_async = real_async
   g = mine.clone()
-  h = real_async(g[off:], None, avg=True)
-  real_sync(g[:off], None, avg=True)
-  h.wait()
+  buckets.executed(tr.program)
+  for w in buckets.exchange(g, tr.program, None, avg=True):
+    w.wait()
   torch.save({'events': events, 'seen': tr.seen, 'scale': tr.scale, 'avg': g}, os.path.join(out, f'sched{rank}.pt'))
   dist.destroy_process_group()
 
@@ -167,7 +161,9 @@ def test_trainer_bucket_schedule_two_ranks(tmp_path):
   want = torch.arange(5003, dtype=torch.float32) * 3.0  # rank 0 contributes 1x, rank 1 contributes 2x
   for r in range(world):
     d = torch.load(tmp_path / f'sched{r}.pt')
-    # the early slice travels behind the second backward segment, the late slice behind the optimizer launch of the early slice
-    assert d['events'] == ['segment1', 'early_issued', 'segment2', 'late_issued', 'early_waited', 'optimizer_early', 'late_waited', 'optimizer_late'], d['events']
+    # one step body; the four all-reduces are issued back to back (each waits for its own completion signal on the device, not on the host);
+    # then bucket after bucket: wait for its collective, update it -- the optimizer of bucket b overlaps the collectives of b + 1 ..
+    assert d['events'] == ['step_body', 'issued0', 'issued1', 'issued2', 'issued3', 'waited0', 'optimizer0', 'waited1', 'optimizer1', 'waited2',
+                           'optimizer2', 'waited3', 'optimizer3'], d['events']
     assert torch.equal(d['seen'], want) and d['scale'] == 0.5
     assert torch.equal(d['avg'], want / 2)

@@ -313,7 +313,7 @@ def test_conv_fused_bn_statistics_on_the_lds_dma_kernels(ops, B, H, W, C, varian
   wp = ops.pack_conv_weight(dev(w), dtype)
   raw = torch.empty((B, H, W, C), device=DEV, dtype=dtype)
   geo = dict(B=B, Hs=H, Ws=W, Cs=C, Hd=H, Wd=W, Cd=C)
-  var, _ = ops.conv_gemm(xd, wp, raw, plan_only=True, **geo)
+  var, _ = ops.conv_gemm(xd, wp, raw, plan_only=True, stats_acc=True, **geo)
   assert var == variant
   nrows, acc = ops.conv_gemm(xd, wp, raw, stats_acc=True, **geo)
   assert nrows == (B * H * W) // bm

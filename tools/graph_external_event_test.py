@@ -1,45 +1,69 @@
 #!/usr/bin/env python
-"""Does a stream that waits on an EXTERNAL event recorded inside a captured hipGraph wait for THIS replay's record node?
+"""How can a stream that is NOT part of a captured hipGraph wait for a point INSIDE the replay in flight?
 
-The N > 1 training step keeps ONE captured graph and lets the RCCL stream start the all-reduce of a gradient bucket as soon as the bucket
-is complete, i.e. in the middle of the replay: the capture records `torch.cuda.Event(external=True)` behind the kernels that finish a
-bucket, and after `graph.replay()` a side stream calls `wait_event` on it.  That is only correct if the wait issued AFTER the launch
-orders the side stream behind the record node of the replay in flight (and not behind a record of an earlier replay, or nothing).
+The N > 1 training step keeps ONE captured graph and lets the RCCL stream start the all-reduce of a gradient bucket as soon as the bucket is
+complete, i.e. in the middle of the replay.  Three candidates, each tested the same way: the graph runs
+    spin(~2 ms) -> flag = epoch -> [sync point] -> spin(~2 ms)
+a side stream waits for the sync point and copies the flag.  Correct = the copy sees THIS replay's epoch and completes well BEFORE the graph's
+tail does (so the wait really is on the point, not on the whole graph, and not on an earlier replay).
 
-Test: the graph runs  spin(~2 ms) -> flag = epoch -> [record external event] -> spin(~2 ms);  the side stream waits on the event and
-copies the flag.  Correct: the copy sees this replay's epoch, and it completes BEFORE the graph's tail does (so the wait really is on
-the node, not on the whole graph).  Prints one line per replay and a verdict."""
+  A  torch.cuda.Event(external=True)                                   -- PyTorch refuses it on ROCm ("External events are disallowed in rocm")
+  B  hipEventRecordWithFlags(ev, stream, hipEventRecordExternal) through ctypes, hipStreamWaitEvent on the side stream
+  C  a counter in signal memory (hipExtMallocWithFlags(hipMallocSignalMemory)) incremented by a kernel node of the graph (tfpp_inc_u64),
+     hipStreamWaitValue64(side, counter, replay number, hipStreamWaitValueGte) on the side stream -- the command processor polls, no CU is held
+
+Prints one line per replay and a verdict per candidate (carla_garage_amd/buckets.py uses C)."""
+import ctypes
+import os
 import sys
 import time
 
-import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
 
 
-def main():
+def hip():
+  for name in ('libamdhip64.so', '/opt/rocm/lib/libamdhip64.so'):
+    try:
+      return ctypes.CDLL(name)
+    except OSError:
+      continue
+  raise RuntimeError('libamdhip64.so not found')
+
+
+def run(name, record, wait, replays=8):
   dev = torch.device('cuda')
   flag = torch.zeros(1, device=dev, dtype=torch.int64)
   epoch = torch.zeros(1, device=dev, dtype=torch.int64)
   seen = torch.zeros(1, device=dev, dtype=torch.int64)
   side = torch.cuda.Stream(dev)
-  ev = torch.cuda.Event(external=True)
-  spin = int(2e-3 * 2.0e9)  # ~2 ms at ~2 GHz
+  spin = int(2e-3 * 2.0e9)
   torch.cuda._sleep(1000)
   torch.cuda.synchronize()
   g = torch.cuda.CUDAGraph()
   cap = torch.cuda.Stream(dev)
-  with torch.cuda.graph(g, stream=cap):
-    torch.cuda._sleep(spin)
-    flag.copy_(epoch)
-    ev.record(torch.cuda.current_stream())
-    torch.cuda._sleep(spin)
+  try:
+    with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
+      torch.cuda._sleep(spin)
+      flag.copy_(epoch)
+      record(torch.cuda.current_stream())
+      torch.cuda._sleep(spin)
+  except Exception as e:  # pylint: disable=broad-except
+    print(f'{name}: capture failed: {type(e).__name__}: {e}', flush=True)
+    return False
   ok = True
-  for it in range(1, 9):
+  for it in range(1, replays + 1):
     epoch.fill_(it)
     seen.zero_()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     g.replay()
-    side.wait_event(ev)
+    try:
+      wait(side, it)
+    except Exception as e:  # pylint: disable=broad-except
+      print(f'{name}: wait failed: {type(e).__name__}: {e}', flush=True)
+      torch.cuda.synchronize()
+      return False
     with torch.cuda.stream(side):
       seen.copy_(flag)
       done_side = torch.cuda.Event()
@@ -51,9 +75,83 @@ def main():
     v = int(seen.item())
     good = (v == it) and (t_side < 0.8 * t_all)
     ok &= good
-    print(f'replay {it}: side stream saw epoch {v} after {t_side * 1e3:.2f} ms, graph finished after {t_all * 1e3:.2f} ms -> {"ok" if good else "WRONG"}', flush=True)
-  print('EXTERNAL_EVENT_IN_GRAPH', 'OK' if ok else 'BROKEN', flush=True)
-  sys.exit(0 if ok else 1)
+    print(f'{name} replay {it}: side stream saw epoch {v} after {t_side * 1e3:.2f} ms, graph finished after {t_all * 1e3:.2f} ms -> {"ok" if good else "WRONG"}', flush=True)
+  print(f'{name}:', 'OK' if ok else 'BROKEN', flush=True)
+  return ok
+
+
+def main():
+  H = hip()
+  results = {}
+  # ---- A: PyTorch's own external event
+  try:
+    evA = torch.cuda.Event(external=True)
+    results['A torch external event'] = run('A', lambda st: evA.record(st), lambda side, it: side.wait_event(evA))
+  except Exception as e:  # pylint: disable=broad-except
+    print(f'A: {type(e).__name__}: {e}', flush=True)
+    results['A torch external event'] = False
+  # ---- B: raw HIP external event
+  evB = ctypes.c_void_p()
+  rc = H.hipEventCreateWithFlags(ctypes.byref(evB), ctypes.c_uint(0x0))  # default flags
+  if rc == 0:
+    def recB(st):
+      r = H.hipEventRecordWithFlags(evB, ctypes.c_void_p(st.cuda_stream), ctypes.c_uint(0x1))  # hipEventRecordExternal
+      if r != 0:
+        raise RuntimeError(f'hipEventRecordWithFlags -> {r}')
+
+    def waitB(side, it):
+      r = H.hipStreamWaitEvent(ctypes.c_void_p(side.cuda_stream), evB, ctypes.c_uint(0))
+      if r != 0:
+        raise RuntimeError(f'hipStreamWaitEvent -> {r}')
+    results['B raw hip external event'] = run('B', recB, waitB)
+  else:
+    print(f'B: hipEventCreateWithFlags -> {rc}', flush=True)
+    results['B raw hip external event'] = False
+  # ---- C: counter in signal memory + hipStreamWaitValue64
+  attr = ctypes.c_int(0)
+  H.hipDeviceGetAttribute(ctypes.byref(attr), ctypes.c_int(0), ctypes.c_int(0))  # (attribute ids differ between releases: informative only)
+  sig = ctypes.c_void_p()
+  rc = H.hipExtMallocWithFlags(ctypes.byref(sig), ctypes.c_size_t(8), ctypes.c_uint(0x2))  # hipMallocSignalMemory (8 bytes exactly)
+  if rc != 0:
+    print(f'C: hipExtMallocWithFlags(8, hipMallocSignalMemory) -> {rc}; trying plain device memory', flush=True)
+    rc = H.hipMalloc(ctypes.byref(sig), ctypes.c_size_t(64))
+  if rc == 0:
+    H.hipMemset(sig, 0, ctypes.c_size_t(8))
+    from carla_garage_amd import _lib
+    inc = _lib.lib.raw('tfpp_inc_u64')
+    H.hipStreamWaitValue64.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint, ctypes.c_uint64]
+
+    def recC(st):
+      r = inc(sig.value, st.cuda_stream)
+      if r != 0:
+        raise RuntimeError(f'tfpp_inc_u64 -> {r}')
+
+    def waitC(side, it):
+      r = H.hipStreamWaitValue64(ctypes.c_void_p(side.cuda_stream), sig, ctypes.c_uint64(it), ctypes.c_uint(0), ctypes.c_uint64(0xFFFFFFFFFFFFFFFF))
+      if r != 0:
+        raise RuntimeError(f'hipStreamWaitValue64 -> {r}')
+    results['C signal counter + hipStreamWaitValue64'] = run('C', recC, waitC)
+  else:
+    print(f'C: hipExtMallocWithFlags(hipMallocSignalMemory) -> {rc}', flush=True)
+    results['C signal counter + hipStreamWaitValue64'] = False
+  # ---- D: the library's own device-side signal (carla_garage_amd/buckets.py): tfpp_signal_add node + tfpp_signal_wait polling kernel
+  from carla_garage_amd import _lib as L2
+  from carla_garage_amd import ops
+  sigD = ops.zeros(1, torch.int64, torch.device('cuda'))
+  tmo = ops.zeros(1, torch.int32, torch.device('cuda'))
+  addD, waitD = L2.lib.raw('tfpp_signal_add'), L2.lib.raw('tfpp_signal_wait')
+
+  def recD(st):
+    if addD(sigD.data_ptr(), st.cuda_stream) != 0:
+      raise RuntimeError('tfpp_signal_add failed')
+
+  def wD(side, it):
+    if waitD(sigD.data_ptr(), it, 2000, tmo.data_ptr(), side.cuda_stream) != 0:
+      raise RuntimeError('tfpp_signal_wait failed')
+  results['D device counter + polling kernel (tfpp_signal_*)'] = run('D', recD, wD) and int(tmo.item()) == 0
+  for k, v in results.items():
+    print('RESULT', k, 'OK' if v else 'not usable', flush=True)
+  sys.exit(0)
 
 
 if __name__ == '__main__':
