@@ -368,7 +368,7 @@ extern "C" int tfpp_conv_gemm_stats_rows(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
   const long M = (long)p->B * p->Hd * p->Wd;
   if (conv_halo_supported(*p, dtype)) return conv_halo_mtiles(*p);
-  if (conv_pp_supported(*p, dtype)) return cdiv(M, conv_pp_bm(conv_pp_variant(*p)));
+  // (the ping-pong GEMM of gemm_pp.hip has no statistics epilogue: a launch that asks for them runs on the ring kernels)
   if (use_glds_impl() && conv_glds_supported(*p, dtype)) return cdiv(M, conv_glds_bm(conv_glds_variant(*p)));
   return cdiv(M, kConvBm[conv_variant_for(*p, dtype)]);
 }

@@ -67,7 +67,7 @@ def main():
   torch.cuda.synchronize()
   g1, p1 = by_name(tr1), params(tr1)
   n1 = dict(calls)
-  buckets_static = len(tr1.eng.buckets.ranges())
+  buckets_static, arena_static = len(tr1.eng.buckets.ranges()), int(tr1.eng.flat_grad.numel()) * 4
 
   # steps 2-3: the arenas move into the observed completion order; step 4 replayed from ONE hipGraph with the RCCL calls after the replay
   # call returns (they wait for the in-graph completion signals) -- against the fourth local step of tr0
@@ -86,7 +86,7 @@ def main():
   rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
   out = {'world': dist.get_world_size(), 'backend': dist.get_backend(),
          'calls_local': n0['all_reduce'], 'calls_eager_step': n1['all_reduce'] - n0['all_reduce'], 'async_eager_step': n1['async'] - n0['async'],
-         'bytes_eager_step': n1['bytes'] - n0['bytes'], 'arena_bytes': int(tr1.eng.flat_grad.numel()) * 4,
+         'bytes_eager_step': n1['bytes'] - n0['bytes'], 'arena_bytes': arena_static, 'arena_bytes_observed': int(tr1.eng.flat_grad.numel()) * 4,
          'calls_graph_step': after['all_reduce'] - before['all_reduce'], 'async_graph_step': after['async'] - before['async'],
          'bytes_graph_step': after['bytes'] - before['bytes'], 'buckets_static': buckets_static, 'buckets_observed': len(tr1.eng.buckets.ranges()),
          'early_signals': len(gs.program[1]), 'poisoned': tr1.eng.buckets.poisoned, 'wait_timeouts': tr1.eng.buckets.timed_out(),
