@@ -585,13 +585,19 @@ def main():
     # dominant kernel flips run to run: both are always on the line), plus the north-star kernels by name (fusion-transformer linears)
     hb = [(f, x) for f, x in agg.items() if x['flops'] > 0 and x['bytes'] > 0 and x['flops'] / x['bytes'] < ridge]
     roof_hbm = roof_of(*max(hb, key=lambda fa: fa[1]['ms'])) if hb else None
-    # north-star kernels by name: the ping-pong GEMM family (csrc/gemm_pp.hip: fusion-transformer linears + the stage-4 1x1 data gradients),
-    # all tile configurations together; on a build without it, the ring kernel that ran them before
-    pp = [x for f, x in agg.items() if f.startswith('conv_gemm<bf16,pp')]
-    if pp:
-      roof_fusion = roof_of('conv_gemm<bf16,pp>', {k: sum(x[k] for x in pp) for k in ('calls', 'ms', 'flops', 'bytes')})
-    elif 'conv_gemm<bf16,glds256x128>' in agg:
-      roof_fusion = roof_of('conv_gemm<bf16,glds256x128>', agg['conv_gemm<bf16,glds256x128>'])
+    # the north-star GEMMs BY LAYER, whatever kernel runs them: every forward / data-gradient linear of the four fusion transformers
+    # (transfuser.py:352-359,383-402; KernelProfiler group 'fusion_linears')
+    groups = prof.summary(by_group=True)
+    grp = groups.get('fusion_linears_c1512')  # the stage-4 transformer (n_embd 1512): 96 % of the fusion-linear FLOPs
+    if grp is not None:
+      roof_fusion = roof_of('fusion-transformer linears, n_embd = 1512 (forward + data gradient)', grp)
+      roof_fusion['kernels'] = {k: v // nprof for k, v in sorted(grp['kernels'].items())}
+      roof_fusion['traffic'], roof_fusion['traffic_note'] = pmc_traffic('conv_gemm<bf16,glds256x128>')
+      allg = groups.get('fusion_linears')
+      if allg is not None:  # ... and all four scales (n_embd 72 / 216 / 576 / 1512) together
+        roof_fusion['all_scales'] = {'achieved': round(allg['flops'] / (allg['ms'] * 1e-3) / 1e12, 2), 'frac': round(allg['flops'] / (allg['ms'] * 1e-3) / 1e12 / peak, 4),
+                                     'launches_per_step': allg['calls'] // nprof, 'kernels': {k: v // nprof for k, v in sorted(allg['kernels'].items())}}
+      roof_fusion['isolated'] = 'profiles/r04_gemm_pp_micro.txt: the same shapes alone on the chip, ring kernels and the opt-in ping-pong GEMM (csrc/gemm_pp.hip)'
     if args.kernel_table:
       for f, x in sorted(agg.items(), key=lambda fa: -fa[1]['ms']):
         tf = x['flops'] / (x['ms'] * 1e-3) / 1e12 if x['flops'] else 0.0

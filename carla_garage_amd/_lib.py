@@ -163,29 +163,36 @@ class KernelProfiler:
     self.records = []
     self._pending = None
 
-  def tag(self, family, flops=0.0, nbytes=0.0):
-    self._pending = (family, float(flops), float(nbytes))
+  def tag(self, family, flops=0.0, nbytes=0.0, group=None):
+    """group: a set of LAYERS (whatever kernel runs them), e.g. 'fusion_linears' -- the north-star GEMMs are priced by layer, not by kernel name"""
+    self._pending = (family, float(flops), float(nbytes), group)
 
   def run(self, name, fn, args):
-    fam, flops, nbytes = self._pending if self._pending is not None else (name, 0.0, 0.0)
+    fam, flops, nbytes, group = self._pending if self._pending is not None else (name, 0.0, 0.0, None)
     self._pending = None
     e0 = self._torch.cuda.Event(enable_timing=True)
     e1 = self._torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = fn(*args)
     e1.record()
-    self.records.append((fam, flops, nbytes, e0, e1))
+    self.records.append((fam, flops, nbytes, e0, e1, group))
     return rc
 
-  def summary(self):
+  def summary(self, by_group=False):
     self._torch.cuda.synchronize()
     agg = {}
-    for fam, flops, nbytes, e0, e1 in self.records:
-      a = agg.setdefault(fam, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
-      a['calls'] += 1
-      a['ms'] += e0.elapsed_time(e1)
-      a['flops'] += flops
-      a['bytes'] += nbytes
+    for fam, flops, nbytes, e0, e1, group in self.records:
+      keys = (group if isinstance(group, (tuple, list)) else (group,)) if by_group else (fam,)
+      ms = e0.elapsed_time(e1)
+      for key in keys:
+        if key is None:
+          continue
+        a = agg.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0, kernels={}))
+        a['calls'] += 1
+        a['ms'] += ms
+        a['flops'] += flops
+        a['bytes'] += nbytes
+        a['kernels'][fam] = a['kernels'].get(fam, 0) + 1
     return agg
 
 

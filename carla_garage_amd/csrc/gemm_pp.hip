@@ -472,7 +472,13 @@ static const PPCfg kPPCfg[] = {{256, 256, 0, 32}, {256, 256, 1, 32}, {256, 192, 
 static constexpr int kPPNumCfg = (int)(sizeof(kPPCfg) / sizeof(kPPCfg[0]));
 enum { PP_256x192 = 2, PP_128x192 = 5, PP_128x128 = 6 };
 
-// tuning hook (tfpp_gemm_pp_config): 0 = automatic choice, -1 = kernel off, 1 + i + 100 * splits = configuration i with `splits` K slices (0: automatic)
+// Selection (tfpp_gemm_pp_config / TFPP_GEMM_PP): 0 = kernel off (DEFAULT), -2 = automatic plan, 1 + i + 100 * splits = configuration i with
+// `splits` K slices.  Off by default because the training step does not get faster with it (round 4, profiles/r04_gemm_pp_*.txt): alone
+// on the chip the kernel beats the LDS-DMA ring kernels by 10-22 % on the fusion-transformer shapes, warm and cold caches alike; inside the
+// replayed step (other lanes' kernels on part of the CUs, power-limited clocks) its one-or-two-round grids of 25-45 us tiles lose what
+// they gained -- 3840x6048x1512 takes 128-143 us in the graph against 73 us alone and 95 us for the ring kernel's 720 shorter tiles; the step
+// is 0.4-2 % slower with the automatic plan, with 128-row tiles only, forward only or data gradients only, and a dynamic tile scheduler
+// (workgroups claiming tiles from per-XCD counters) made it worse still (no hardware overlap of one workgroup's prologue with another's loop).
 static int g_pp_force = [] { const char* e = std::getenv("TFPP_GEMM_PP"); return e ? std::atoi(e) : 0; }();
 static int g_pp_dbg = 0;  // ablation bits (timing experiments only: results are wrong with any bit set), cfg / 10000
 extern "C" int tfpp_gemm_pp_config(int cfg) {
@@ -482,7 +488,7 @@ extern "C" int tfpp_gemm_pp_config(int cfg) {
 }
 
 bool conv_pp_supported(const tfpp_conv_params& p, int dtype) {
-  if (g_pp_force < 0 || dtype != TFPP_BF16) return false;
+  if (g_pp_force == 0 || g_pp_force == -1 || dtype != TFPP_BF16) return false;
   const long M = (long)p.B * p.Hd * p.Wd;
   const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.Hs == p.Hd && p.Ws == p.Wd && p.G == 1;
   if (!pointwise || p.stats_partial || p.bns_partial || p.dst_nchw || p.dst_f32) return false;

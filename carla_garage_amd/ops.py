@@ -145,7 +145,11 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
     esz = src.element_size()
     nbytes = (B * Hs * Ws * G * p.ks_g + G * p.n_g * R * S * p.ks_g + (B * Hd * Wd * G * p.n_g if res is not None else 0)) * esz + \
         B * Hd * Wd * G * p.n_g * dst.element_size()  # source, weights (, residual) read once; destination written once
-    lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g), nbytes)
+    # the fusion-transformer linears (transfuser.py:352-359,383-402: forward and data gradient) are the only bf16 1x1 layers on token matrices
+    grp = None
+    if src.dtype == torch.bfloat16 and Hd == 1 and Wd == 1 and R == 1 and S == 1 and G == 1:
+      grp = ('fusion_linears', 'fusion_linears_c1512') if min(p.n_g, p.ks_g) >= 1512 else ('fusion_linears',)  # (all four scales, the stage-4 transformer)
+    lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g), nbytes, group=grp)
   lib.tfpp_conv_gemm(ctypes.byref(p), dt(src), stream())
   if stats_acc is not None:
     return nblk, stats_acc

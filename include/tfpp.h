@@ -97,8 +97,8 @@ int tfpp_conv_gemm_mtiles(const tfpp_conv_params* p);
 int tfpp_conv_gemm_stats_rows(const tfpp_conv_params* p, int dtype);
 /* 1 if the kernel the dispatcher runs for (p, dtype) supports the fused BatchNorm-backward statistics (bns_* fields) */
 int tfpp_conv_gemm_bns_ok(const tfpp_conv_params* p, int dtype);
-/* tuning hook of the ping-pong GEMM (csrc/gemm_pp.hip; fusion-transformer linears, stage-4 1x1 convs): cfg 0 = automatic plan,
- * -1 = kernel off (the LDS-DMA ring kernels run instead), 1 + i + 100 * s = tile configuration i (0: 256x256, 1: 256x256 with 32x32x16
+/* selection of the ping-pong GEMM (csrc/gemm_pp.hip; fusion-transformer linears, stage-4 1x1 convs): cfg 0 = kernel off (default: the
+ * LDS-DMA ring kernels run; the training step is not faster with it, see the source), -2 = automatic plan, 1 + i + 100 * s = tile configuration i (0: 256x256, 1: 256x256 with 32x32x16
  * MFMAs, 2: 256x192, 3: 256x128, 4: 128x256, 5: 128x192, 6: 128x128, 7: 256x192 with 64-row slabs) with s K slices (0: one).
  * Process-wide; tools/gemm_pp_micro.py. */
 int tfpp_gemm_pp_config(int cfg);

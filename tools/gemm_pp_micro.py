@@ -4,7 +4,7 @@
   python tools/gemm_pp_micro.py --check          every tile configuration x {K slices} on edge-case shapes vs an fp32 torch product
   python tools/gemm_pp_micro.py --bench          TFLOP/s of every configuration on the fusion-transformer / stage-4 shapes (hipGraph replays)
 
-tfpp_gemm_pp_config(cfg): 0 automatic, -1 off (ring kernels), 1 + i + 100 * s = configuration i with s K slices."""
+tfpp_gemm_pp_config(cfg): 0 / -1 off (ring kernels; the default), -2 automatic plan, 1 + i + 100 * s = configuration i with s K slices."""
 import argparse
 import os
 import sys
@@ -125,8 +125,10 @@ def time_graph(fn, iters):
 def label_of(cfg):
   if cfg == -1:
     return 'ring'
-  if cfg == 0:
+  if cfg == -2:
     return 'auto'
+  if cfg == 0:
+    return 'ring'
   dbg, c = cfg // 10000, cfg % 10000
   return f'{CFG_NAMES[(c % 100) - 1]} s{c // 100}' + (f' dbg{dbg}' if dbg else '')
 
@@ -192,12 +194,62 @@ def bench(iters, only, cfgs, rounds=5):
   set_cfg(0)
 
 
+def cold(iters, only, cfgs, rounds=3):
+  """The same comparison with COLD caches: a 1 GB fill between the launches evicts the operands from the L2s and the memory-side cache
+  (in the training step the weights were last touched ~10 ms and ~500 MB of traffic ago).  Time = graph of [fill, GEMM] x iters minus graph of
+  [fill] x iters."""
+  dev, dt = 'cuda', torch.bfloat16
+  torch.manual_seed(0)
+  junk = torch.empty(256 << 20, device=dev, dtype=torch.float32)
+  for name, M, N, K in BENCH_SHAPES:
+    if only and only not in name:
+      continue
+    x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
+    w = ((torch.rand(N, K, 1, 1, device=dev) - 0.5) * 0.2)
+    wp = ops.pack_conv_weight(w, dt, G=1)
+    y = torch.empty(M, N, device=dev, dtype=dt)
+    flops = 2.0 * M * N * K
+
+    def graph_of(fn):
+      fn()
+      torch.cuda.synchronize()
+      g = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g):
+        for _ in range(iters):
+          ops.zero_(junk)
+          fn()
+      g.replay()
+      torch.cuda.synchronize()
+      return g
+
+    def t_of(g):
+      best = 1e9
+      for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters)
+      return best
+
+    base = t_of(graph_of(lambda: None))
+    for cfg in cfgs:
+      set_cfg(cfg)
+      plan = run_gemm(x, wp, y, M, N, K, plan_only=True)
+      ms = t_of(graph_of(lambda: run_gemm(x, wp, y, M, N, K))) - base
+      print(f'cold {name:16s} {M}x{N}x{K:5d} {label_of(cfg):18s} {ms * 1e3:7.1f} us {flops / ms / 1e9:7.1f} TFLOP/s  plan {plan}  (fill alone {base * 1e3:.1f} us)', flush=True)
+    print(flush=True)
+  set_cfg(0)
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--check', action='store_true')
   ap.add_argument('--repeat', action='store_true')
   ap.add_argument('--bench', action='store_true')
   ap.add_argument('--eager', action='store_true')
+  ap.add_argument('--cold', action='store_true')
   ap.add_argument('--iters', type=int, default=20)
   ap.add_argument('--only', default='')
   ap.add_argument('--cfgs', default='')
@@ -209,8 +261,10 @@ def main():
     rc |= repeat_check()
   if args.eager:
     eager(args.iters, args.only, [int(v) for v in args.cfgs.split(',')])
+  if args.cold:
+    cold(args.iters, args.only, [int(v) for v in args.cfgs.split(',')] if args.cfgs else [-1, -2, 3, 6, 7])
   if args.bench:
-    cfgs = [int(v) for v in args.cfgs.split(',')] if args.cfgs else [-1, 0] + [1 + i for i in range(len(CFG_NAMES))]
+    cfgs = [int(v) for v in args.cfgs.split(',')] if args.cfgs else [-1, -2] + [1 + i for i in range(len(CFG_NAMES))]
     bench(args.iters, args.only, cfgs)
   sys.exit(1 if rc else 0)
 
