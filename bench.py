@@ -349,6 +349,51 @@ def _flush_c_stdio():
     pass
 
 
+def graph_trace():
+  """The newest committed rocprofv3 kernel trace of ONE hipGraph-replayed step (profiles/rNN_graph_step.json, tools/graph_step_profile.sh): launch
+  durations as they are inside the replayed graph, next to co-running lanes -- the HIP-event times of the eager profiling steps below are ~10 %
+  longer and blind to that (VERDICT r3 weak #10).  A committed measurement of the same command, not a live one: `source` names the file."""
+  import glob
+  files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_graph_step.json')))
+  if not files:
+    return None
+  try:
+    with open(files[-1], encoding='utf-8') as f:
+      g = json.load(f)
+    g['source'] = 'profiles/' + os.path.basename(files[-1])
+    return g
+  except (OSError, ValueError):
+    return None
+
+
+def graph_trace_of(gtrace, fam, flop_per_launch, bytes_per_launch, mfma, peak):
+  """Average launch duration of kernel family `fam` inside the replayed graph (graph_trace()), with the roofline fraction it gives."""
+  import re
+  if gtrace is None:
+    return None
+  m = re.match(r'(conv_gemm|conv_wgrad)<(f32|bf16),(glds|pp|halo|lds)?(\d+)x(\d+)', fam)
+  if m is None:
+    return None
+  op, dtype, kind, a, b = m.groups()
+  ty = 'float' if dtype == 'f32' else 'unsigned short'
+  if kind == 'glds':
+    pat = f'{op}_glds_kernel<{a}, {b},'
+  elif kind == 'pp':
+    pat = f'conv_gemm_pp_kernel<{a}, {b},'
+  elif kind is None or kind == 'lds':
+    pat = f'{op}_kernel<{ty}, {a}, {b},'
+  else:
+    return None
+  hit = [v for k, v in gtrace['kernels'].items() if pat in k]
+  if not hit:
+    return None
+  calls, total = sum(v['calls'] for v in hit), sum(v['total_ms'] for v in hit)
+  us = 1e3 * total / calls
+  ach = (flop_per_launch / (us * 1e-6) / 1e12) if mfma else (bytes_per_launch / (us * 1e-6) / 1e9)
+  return {'source': gtrace['source'], 'kernel_name_contains': pat, 'launches_per_step': calls, 'avg_launch_us': round(us, 2), 'achieved': round(ach, 2),
+          'frac': round(ach / peak, 4)}
+
+
 def exchange_model(bucket_bytes, world):
   """What the gradient exchange should cost on one 8 x MI355X node, to check the first real multi-GPU run against: S bytes all-reduced over N
   ranks move 2 S (N-1)/N bytes out of every GPU; a direct (one-shot reduce-scatter + all-gather over the full xGMI mesh) algorithm spreads them
@@ -544,7 +589,8 @@ def main():
     finally:
       trainer.exchange = True
 
-  roof = roof_mfma = roof_hbm = roof_fusion = None
+  roof = roof_mfma = roof_hbm = roof_fusion = roof_step = None
+  gtrace = graph_trace()
   if rank == 0 and rccl_ranks is None and not args.no_roofline:  # per-kernel timing runs extra local steps: single-process runs only
     prof = KernelProfiler()
     lib.profiler = prof
@@ -569,6 +615,7 @@ def main():
       else:
         ach, pk, unit = a['bytes'] / (a['ms'] * 1e-3) / 1e9, PEAK_HBM_GBS, 'GB/s'
       return {'bound': 'mfma' if mfma else 'hbm', 'kernel': fam, 'achieved': round(ach, 2), 'peak': pk, 'unit': unit, 'frac': round(ach / pk, 4),
+              'graph_trace': graph_trace_of(gtrace, fam, a['flops'] / a['calls'], (a['bytes'] / a['calls']) if a.get('bytes') else 0.0, mfma, pk),
               'traffic': traffic, 'traffic_note': traffic_note, 'algorithmic_flop_per_launch': round(a['flops'] / a['calls']),
               'algorithmic_bytes_per_launch': round(a['bytes'] / a['calls']) if a.get('bytes') else None,
               'algorithmic_flop_per_byte': round(a['flops'] / a['bytes'], 1) if a.get('bytes') else None,
@@ -598,6 +645,23 @@ def main():
         roof_fusion['all_scales'] = {'achieved': round(allg['flops'] / (allg['ms'] * 1e-3) / 1e12, 2), 'frac': round(allg['flops'] / (allg['ms'] * 1e-3) / 1e12 / peak, 4),
                                      'launches_per_step': allg['calls'] // nprof, 'kernels': {k: v // nprof for k, v in sorted(allg['kernels'].items())}}
       roof_fusion['isolated'] = 'profiles/r04_gemm_pp_micro.txt: the same shapes alone on the chip, ring kernels and the opt-in ping-pong GEMM (csrc/gemm_pp.hip)'
+    # the whole step against both roofs: sum of algorithmic FLOPs (every GEMM / attention launch) and of the GEMM families' algorithmic bytes over
+    # the MEASURED step time of the timed region above (hipGraph replay), launch count, kernel time
+    flop_step = sum(x['flops'] for x in agg.values()) / nprof
+    bytes_step = sum(x['bytes'] for x in agg.values()) / nprof
+    step_s = elapsed / args.steps
+    roof_step = {'algorithmic_tflop': round(flop_step / 1e12, 4), 'algorithmic_gb_gemm_families': round(bytes_step / 1e9, 3),
+                 'ms_per_step': round(1e3 * step_s, 3), 'achieved_tflops': round(flop_step / step_s / 1e12, 2), 'frac_of_mfma_peak': round(flop_step / step_s / 1e12 / peak, 4),
+                 'at_mfma_peak_ms': round(1e3 * flop_step / (peak * 1e12), 3), 'at_hbm_peak_ms_gemm_families': round(1e3 * bytes_step / (PEAK_HBM_GBS * 1e9), 3),
+                 'launches_per_step_library_calls': sum(x['calls'] for x in agg.values()) // nprof,
+                 'sum_kernel_ms_eager_events': round(total_ms / nprof, 3),
+                 'note': 'FLOPs: every GEMM-shaped and attention launch (2MNK / 4BhT^2d ...); bytes: operands of the GEMM families read once + result written once '
+                         '(elementwise / normalisation passes carry no tag: their traffic is the gap the fusions of DESIGN.md close)'}
+    if gtrace is not None:
+      qs = sorted(gtrace.get('queues', {}).values(), key=lambda q: -q['busy_ms'])
+      roof_step['graph_trace'] = {'source': gtrace['source'], 'launches': gtrace['launches'], 'span_ms': gtrace['span_ms'], 'sum_kernel_ms': gtrace['sum_kernel_ms'],
+                                  'busy_union_ms': gtrace['busy_union_ms'], 'critical_queue_busy_ms': qs[0]['busy_ms'] if qs else None,
+                                  'queues_busy_ms': [q['busy_ms'] for q in qs]}
     if args.kernel_table:
       for f, x in sorted(agg.items(), key=lambda fa: -fa[1]['ms']):
         tf = x['flops'] / (x['ms'] * 1e-3) / 1e12 if x['flops'] else 0.0
@@ -680,6 +744,8 @@ def main():
       line['dropin'] = dropin
     if fp32_leg is not None:
       line['fp32_step'] = fp32_leg
+    if roof_step is not None:
+      line['roofline_step'] = roof_step
     if roof is not None:
       line['roofline'] = roof
       if roof_mfma is not None and roof_mfma['kernel'] != roof['kernel']:

@@ -939,7 +939,7 @@ class Engine:
     comes LATER than the parameter's bucket says (another closure order than the observed one) cancels the early events of this pass."""
     n = self._gid.get(id(param))
     if n is None:
-      return None
+      return self._sink(param)
     side = self.side
     b = side.flush_seq - 1 if side.in_flush else side.flush_seq
     if b > self._glog.get(n, -1):
@@ -947,6 +947,32 @@ class Engine:
       if self._bucket_of is not None and b > self._bucket_of[n]:
         self.buckets.poison(f'gradient of {n} written in batch {b}, its bucket is {self._bucket_of[n]}')
     return self.grads[n]
+
+  def _sink(self, param):
+    """Gradient slot of a parameter WITHOUT a slot in the arena (``requires_grad_(False)``: two-stage training, train.py:495-508, or any
+    frozen sub-module between trainable ones).  Its backward closure still runs when a data gradient has to pass through the layer; what it
+    computes for the parameter lands in one scratch buffer shared by all frozen parameters, which nobody reads.  (Sections of the network
+    that are frozen AND fed by frozen sections only are not walked at all: Engine._drop_dead_nodes.)"""
+    if param is None:
+      return None
+    buf = getattr(self, '_sink_buf', None)
+    if buf is None or buf.numel() < param.numel() or buf.device != param.device:
+      need = max([param.numel()] + [q.numel() for q in self.m.parameters() if not q.requires_grad])
+      self._sink_buf = buf = torch.empty(need, device=param.device, dtype=F32)
+    return buf[:param.numel()].view(param.shape)
+
+  def _frozen(self, *modules):
+    return all(not p.requires_grad for mod in modules if mod is not None for p in mod.parameters())
+
+  def _drop_dead_nodes(self, start):
+    """The nodes recorded since ``start`` belong to a section whose parameters are all frozen and whose inputs need no gradient either:
+    autograd would not visit it (no leaf requires grad), neither does the tape."""
+    tape = self.tape
+    if tape is None:
+      return
+    del tape.nodes[start:]
+    if tape.split_index is not None and tape.split_index > start:
+      tape.split_index = None
 
   def begin_backward(self):
     """Start of a backward pass (Trainer / DropinStep call it before Tape.backward)."""
@@ -1630,6 +1656,10 @@ class Engine:
     else:
       xi = ops.nchw_to_nhwc_affine(rgb.float().contiguous(), dt_, 8, mul, add)
     lanes = self.lanes
+    # two-stage training (train.py:495-508 freeze_backbone): a frozen backbone is not walked by backward, and neither is a frozen head that
+    # only consumes its features
+    dead_feats = self.tape is not None and self._frozen(bb)
+    n_backbone = len(self.tape.nodes) if self.tape is not None else 0
     if self.aim or self.bev or self.video:
       self._join_pack()  # (only the default TransFuser backbone is laid out for the deferred repack)
     if self.aim:  # team_code/aim.py:32-61: the image branch alone; fused_features = the stage-4 feature grid
@@ -1706,13 +1736,15 @@ class Engine:
             self.rec([xl], [xl5], bwd_mean)
       lanes.join()
     out['image_feature_grid'], out['fused_features'] = xi, xl
+    if dead_feats:
+      self._drop_dead_nodes(n_backbone)
 
     # planning head, fp32 (model.py:299-358)
     # on the LiDAR lane (idle after the backbone): ~250 tiny latency-bound launches that overlap with the dense heads below
     hoist_from = len(self.tape.nodes) if self.tape is not None else 0
     with self.lanes.fork():
       dm = cfg.gru_input_size
-      x = self.conv(xl, 'change_channel', out_f32=True)  # [B,8,8,256] fp32
+      x = self.conv(xl, 'change_channel', out_f32=True, x_grad=not dead_feats)  # [B,8,8,256] fp32
       hh, ww = x.shape[1], x.shape[2]
       pos = self._const(f'sine{hh}x{ww}', lambda: m.sine_table(hh, ww))
       x = self.add_table(x, pos.view(-1))
@@ -1791,6 +1823,7 @@ class Engine:
     out['pred_bev_semantic'] = None
     out['bb'] = None
     lanes.hold(xl)
+    n_bev = len(self.tape.nodes) if self.tape is not None else 0
     with lanes.fork(lanes.head_lane):
       if cfg.detect_boxes or cfg.use_bev_semantic:
         p5 = self.conv(xl, 'backbone.c5_conv', act=ACT_RELU)
@@ -1811,10 +1844,16 @@ class Engine:
           bbs.append(self.conv(h, f'head.{br}_head.2', act=ACT_SIGMOID if br == 'heatmap' else ACT_NONE))
         out['bb'] = bbs
     out['bev'] = bev
+    if dead_feats and self._frozen(m.head if cfg.detect_boxes else None, m.bev_semantic_decoder if cfg.use_bev_semantic else None):
+      self._drop_dead_nodes(n_bev)
 
     # auxiliary dense heads
-    out['pred_semantic'] = self.perspective_decoder(xi, 'semantic_decoder') if cfg.use_semantic else None
-    out['pred_depth'] = self.activation(self.perspective_decoder(xi, 'depth_decoder'), ACT_SIGMOID) if cfg.use_depth else None
+    for key, name, on in (('pred_semantic', 'semantic_decoder', cfg.use_semantic), ('pred_depth', 'depth_decoder', cfg.use_depth)):
+      n_dec = len(self.tape.nodes) if self.tape is not None else 0
+      y = self.perspective_decoder(xi, name) if on else None
+      out[key] = self.activation(y, ACT_SIGMOID) if on and key == 'pred_depth' else y
+      if on and dead_feats and self._frozen(getattr(m, name)):
+        self._drop_dead_nodes(n_dec)
     self.lanes.join()
     return out
 

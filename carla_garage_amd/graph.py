@@ -82,8 +82,9 @@ class GraphedForward:
 class GraphedTrainStep:
   """Captures the training step body (repack + forward + losses + backward) for a fixed batch layout as ONE hipGraph, for one rank and for
   eight alike; the gradient all-reduces and the optimizer launches stay outside the graph so RCCL is never captured.  The captured pass
-  records an external event behind the kernels that complete each bucket of the gradient arena (buckets.py); after ``graph.replay()``
-  returns -- the replay is still running -- Trainer.finish_step() issues the all-reduce of every bucket behind its event."""
+  raises a completion signal (a device counter incremented by a kernel node: buckets.py, include/tfpp.h tfpp_signal_add) behind the kernels
+  that complete each bucket of the gradient arena; after ``graph.replay()`` returns -- the replay is still running --
+  Trainer.finish_step() issues the all-reduce of every bucket behind a wait on its signal (tfpp_signal_wait on the collective's stream)."""
 
   def __init__(self, trainer, batch, warmup=2):
     """NOTE: the eager steps in front of the capture are real training steps (parameters, optimizer state and ``step_count`` advance).

@@ -215,6 +215,41 @@ def write_wp_train_golden():
   write_train_golden(model, cfg, 2, 'tfpp_wp_train_bs2.npz')
 
 
+def write_freeze_golden():
+  """Two-stage training (team_code/train.py:495-508, config.freeze_backbone): backbone, CenterNet head and the semantic / BEV-semantic /
+  depth decoders are frozen with requires_grad_(False) exactly as train.py does it, then one train-mode step at bs = 2 -- only the planning
+  side (join, queries, GRU decoders, target-speed network, change_channel, extra-sensor encoder) receives gradients."""
+  model, _ = ref_harness.build_reference_model()
+  cfg = P.PortConfig()
+  model.load_state_dict(P.make_state_dict(cfg), strict=True)
+  model.backbone.requires_grad_(False)          # train.py:496
+  model.head.requires_grad_(False)              # :499
+  model.semantic_decoder.requires_grad_(False)  # :502
+  model.bev_semantic_decoder.requires_grad_(False)  # :505
+  model.depth_decoder.requires_grad_(False)     # :508
+  write_train_golden(model, cfg, 2, 'tfpp_train_freeze_bs2.npz')
+
+
+def write_validate_golden():
+  """Engine.validate (team_code/train.py:923-956): @torch.inference_mode(), model.eval(), forward + compute_loss on a validation batch;
+  the ten unweighted losses and their weighted sum at bs = 2."""
+  model, _ = ref_harness.build_reference_model()
+  cfg = P.PortConfig()
+  model.load_state_dict(P.make_state_dict(cfg), strict=True)
+  model.eval()
+  inp = P.make_inputs(2, cfg)
+  lab = P.make_labels(2, cfg)
+  with torch.inference_mode():
+    out = model(*inp)
+    losses = model.compute_loss(**reference_loss_kwargs(out, lab))
+  w = P.loss_weights(cfg)
+  total = sum(w[k] * float(v) for k, v in losses.items())
+  t = {'loss_names': np.array(list(losses.keys())), 'losses': np.array([float(v) for v in losses.values()]), 'total_loss': np.array(total)}
+  t.update({'fwd_' + k: v for k, v in pack_outputs(out).items() if k.startswith('pred_t') or k.startswith('pred_c') or k.endswith('_sum')})
+  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_validate_bs2.npz'), **t)
+  print('validate bs2: total', total, {k: float(v) for k, v in losses.items()})
+
+
 def write_train_golden(model, cfg, bs, fname):
   """One train-mode step of the reference at batch size ``bs`` (dropout 0, batch-statistic BN): the 10 losses, per-parameter
   gradient norms + sampled gradient values, the BN running-statistic sums after the step and the small forward outputs."""
@@ -275,6 +310,12 @@ def main():
     return
   if only == {'wp_train'}:
     write_wp_train_golden()
+    return
+  if only == {'freeze'}:
+    write_freeze_golden()
+    return
+  if only == {'validate'}:
+    write_validate_golden()
     return
 
   # ---- default TF++ ---------------------------------------------------------------------------

@@ -63,6 +63,16 @@ def test_library_exports_every_declared_symbol():
   _lib.lib.load()  # raises if a declared symbol is missing or a struct mirror has the wrong size
 
 
+def test_abi_version_of_header_and_binding_agree():
+  """include/tfpp.h is the contract: a library built from another header revision must not load (bump on every struct change)."""
+  import re
+  hdr = open(os.path.join(os.path.dirname(U.GOLDEN), '..', 'include', 'tfpp.h'), encoding='utf-8').read()
+  v = int(re.search(r'#define\s+TFPP_ABI_VERSION\s+(\d+)', hdr).group(1))
+  assert v == _lib.ABI_VERSION
+  _lib.build()
+  assert _lib.lib.raw('tfpp_version')() == v
+
+
 AIM_CFG = dict(backbone='aim', use_semantic=0, use_depth=0, detect_boxes=0, use_bev_semantic=0)  # BASELINE config 1
 
 

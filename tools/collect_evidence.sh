@@ -2,13 +2,14 @@
 # Round evidence in one go (GPU box, repo root): default bench line, rocprofv3 --kernel-trace --stats of the same command, the
 # hipGraph step kernel table, PMC traffic of the dominant kernel families, isolated GEMM rates, the stress run.  Everything lands in
 # gpurun_out/ with the prefix $1 (default r02); copy what should be judged into profiles/.
-P=${1:-r03}
+P=${1:-r04}
 R=$(pwd)
 mkdir -p gpurun_out
 python bench.py > gpurun_out/${P}_bench_default.json 2> gpurun_out/${P}_bench_default.err
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -- python $R/bench.py --no-cpu-baseline --no-inference --no-dropin > $R/gpurun_out/${P}_bench_under_rocprof.json 2> /dev/null; f=$(find /tmp/st -name "*kernel_stats.csv" | head -1); cp "$f" $R/gpurun_out/${P}_rocprofv3_kernel_stats_bench_default.csv)
 bash tools/graph_step_profile.sh > gpurun_out/${P}_graph_step_summary.txt 2>&1
 cp gpurun_out/graph_step_kernels.txt gpurun_out/${P}_graph_step_kernels_bs12_bf16.txt
+cp gpurun_out/graph_step.json gpurun_out/${P}_graph_step.json
 bash tools/pmc_traffic.sh "conv_gemm_kernel<unsigned short, 128, 32" "conv_gemm<bf16,128x32>" gemm_kernels.hip > gpurun_out/${P}_pmc_128x32.txt 2>&1
 bash tools/pmc_traffic.sh "conv_wgrad_glds_kernel<128, ?128" "conv_wgrad<bf16,glds128x128>" gemm_wgrad_glds.hip > gpurun_out/${P}_pmc_wgrad128.txt 2>&1
 bash tools/pmc_traffic.sh "conv_gemm_glds_kernel<256, ?128" "conv_gemm<bf16,glds256x128>" gemm_glds.hip > gpurun_out/${P}_pmc_glds256.txt 2>&1

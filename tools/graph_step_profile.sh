@@ -41,6 +41,17 @@ with open(sys.argv[2].replace("kernels.txt", "trace.csv"), "w") as out:  # the w
     for r in step:
         out.write("%s,%.2f,%.2f,%s\n" % (r[qkey] if qkey else "0", (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
                                       r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace(",", ";")[:70]))
+import json
+qb = {}
+if qkey:
+    for qid, (n, busy_q, ks) in perq.items():
+        qb[str(qid)] = {"kernels": n, "busy_ms": round(busy_q / 1e6, 3)}
+with open(sys.argv[2].replace("_kernels.txt", ".json"), "w") as out:
+    # machine-readable summary of the same step: bench.py attaches it (graph-accurate launch durations) to its roofline objects
+    json.dump({"what": "rocprofv3 --kernel-trace of one hipGraph-replayed training step (bs=12 bf16), tools/graph_step_profile.sh",
+               "launches": len(step), "span_ms": round((t1 - t0) / 1e6, 3), "sum_kernel_ms": round(busy / 1e6, 3), "busy_union_ms": round(cov / 1e6, 3),
+               "queues": qb, "kernels": {k: {"calls": v[0], "total_ms": round(v[1] / 1e6, 4), "avg_us": round(v[1] / v[0] / 1e3, 3)} for k, v in agg.items()}},
+              out, indent=0)
 with open(sys.argv[2], "w") as out:
     out.write("# kernel | calls | total_ms | avg_us   (one hipGraph-replayed training step, bs=12 bf16)\n")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
