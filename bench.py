@@ -547,8 +547,6 @@ def main():
   sync()
   elapsed = time.perf_counter() - t0
   log(f'{args.steps} timed steps: {1e3 * elapsed / args.steps:.1f} ms/step')
-  if trainer.eng.side.wplan.enabled:
-    log(f'weight-gradient slice sums batched (TFPP_WGRAD_BATCH_REDUCE=1): {trainer.eng.side.wplan.stats}')
   tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
   if rccl_ranks is not None:
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

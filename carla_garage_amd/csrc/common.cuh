@@ -184,3 +184,29 @@ template <int NV> __device__ __forceinline__ void col_block_reduce(float (&acc)[
     n = h;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Grid-wide sums in a FIXED order without a second launch ("last ticket adds up"): every workgroup publishes its partial(s), draws a
+// ticket, and the workgroup that draws the last one adds all partials in index order.  WHO adds varies from run to run, the order of the
+// additions does not, so the result is bit-reproducible -- unlike fp32 atomicAdd, whose order is the order of arrival.
+// MI355X has one L2 per XCD and they are not coherent with each other inside a kernel: partials are written and read with agent-scope
+// atomic stores / loads (write-through to / fetched from the memory side), and a wave waits for its publishes (s_waitcnt vmcnt(0)) before
+// the workgroup's ticket is drawn, so a drawn ticket implies published partials.  Tickets live in caller-provided scratch that is zero
+// before the first use; the last workgroup puts its ticket back to zero (tfpp_gridsum_scratch_floats, include/tfpp.h).
+// ---------------------------------------------------------------------------------------------------------------
+#define TFPP_GRIDSUM_TICKETS 64  /* first floats of the scratch: ticket counters; partials start behind them */
+__device__ __forceinline__ void grid_publish(float* slot, float v) { __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float grid_fetch(const float* slot) { return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// true (for every thread of the workgroup) in the workgroup that drew the last of `total` tickets
+__device__ __forceinline__ bool grid_last_ticket(unsigned* ticket, unsigned total) {
+  __shared__ unsigned s_last_ticket;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's publishes have completed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last_ticket = (t == total - 1u) ? 1u : 0u;
+    if (s_last_ticket) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return s_last_ticket != 0u;
+}

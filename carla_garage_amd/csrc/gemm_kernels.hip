@@ -561,64 +561,6 @@ template <int SLOTS> __global__ void wgrad_reduce_kernel(tfpp_wgrad_params p) {
   p.dw[(size_t)row * p.dw_ld + col] += s;
 }
 
-// The second stage of MANY weight gradients in one launch (round 3: 213 slice sums per step, each a 5-10 us launch on the in-order
-// weight-gradient lane, which bounds the step).  descs[n]: the parameter blocks of the calls whose first stage has been issued (device copy, ws
-// pointing at each call's OWN slice region); blk_prefix[n + 1]: running sum of ceil(slice / 32) workgroups per call; this launch covers the
-// workgroups base .. base + gridDim.x - 1.  A workgroup = 8 slice slots x 32 consecutive (row, kk) elements; same arithmetic per element as
-// wgrad_reduce_kernel (slot partial sums in slice order, then slots in order), so the result does not depend on how calls are batched.
-__global__ void __launch_bounds__(256)
-wgrad_reduce_multi_kernel(const tfpp_wgrad_params* __restrict__ descs, const long long* __restrict__ blk_prefix, int n, long long base) {
-  constexpr int SLOTS = 8, EL = 32;
-  const long long gb = base + blockIdx.x;
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {  // the last call whose first workgroup is <= gb
-    const int mid = (lo + hi + 1) >> 1;
-    if (blk_prefix[mid] <= gb) lo = mid; else hi = mid - 1;
-  }
-  const tfpp_wgrad_params& p = descs[lo];
-  const int RS = p.R * p.S, ks_g = p.ks_g, KK = RS * ks_g, rows = p.G * p.n_g, splits = p.splits;
-  const float* __restrict__ ws = p.ws;
-  const int el = threadIdx.x % EL, slot = threadIdx.x / EL;
-  const long i = (long)(gb - blk_prefix[lo]) * EL + el;
-  const size_t slice = (size_t)rows * KK;
-  float s = 0.f;
-  if (i < (long)slice) {
-    const float* __restrict__ wsp = ws + i;
-#pragma unroll 4
-    for (int k = slot; k < splits; k += SLOTS) s += wsp[(size_t)k * slice];
-  }
-  __shared__ float sm[SLOTS][EL + 1];
-  sm[slot][el] = s;
-  __syncthreads();
-  if (slot != 0 || i >= (long)slice) return;
-#pragma unroll
-  for (int k = 1; k < SLOTS; ++k) s += sm[k][el];
-  const int r = (int)(i / KK), kk = (int)(i - (long)r * KK);
-  int row = r;
-  if (p.row_map) row = p.row_map[r];
-  if (row < 0) return;
-  long col;
-  if (p.col_map) {
-    col = p.col_map[kk];
-    if (col < 0) return;
-  } else {
-    const int rs = kk / ks_g, c = kk - rs * ks_g;
-    if (c >= p.c_real) return;
-    col = (long)c * RS + rs;
-  }
-  p.dw[(size_t)row * p.dw_ld + col] += s;
-}
-
-extern "C" int tfpp_wgrad_reduce_multi(const tfpp_wgrad_params* descs_dev, const int64_t* blk_prefix_dev, int n, int64_t base, int64_t blocks,
-                                       void* stream) {
-  if (!descs_dev || !blk_prefix_dev || n < 1 || base < 0 || blocks < 0 || blocks > 0x7fffffffLL) return TFPP_EINVAL;
-  if (blocks == 0) return 0;
-  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, (const long long*)blk_prefix_dev, n,
-                     (long long)base);
-  TFPP_CHECK_LAUNCH();
-  return 0;
-}
-
 template <typename T, int BM, int BN, int WM, int WN>
 static int launch_wgrad(const tfpp_wgrad_params& p, hipStream_t st) {
   constexpr int BKT = sizeof(T) == 2 ? 64 : 32;

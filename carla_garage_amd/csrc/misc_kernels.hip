@@ -225,9 +225,17 @@ __device__ __forceinline__ long long ce_label(const long long* __restrict__ labe
   return l;
 }
 
-// pass 1 of cross entropy: ws[0] += sum_i class_weight[label_i] over non-ignored rows
+// The last workgroup of a loss kernel: sum of the gridDim.x published partials in index order (thread t adds t, t + 256, ...; then the fixed
+// tree of block_sum_256).  Valid in thread 0.
+__device__ __forceinline__ float grid_sum_partials(const float* __restrict__ partials, float* sm) {
+  float s = 0.f;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) s += grid_fetch(partials + i);
+  return block_sum_256(s, sm);
+}
+
+// pass 1 of cross entropy: ws[0] = sum_i class_weight[label_i] over non-ignored rows (fixed-order grid sum: common.cuh)
 __global__ void ce_norm_kernel(const long long* __restrict__ label, const float* __restrict__ cw, const float* __restrict__ vis, long HW,
-                               float* __restrict__ ws, long rows) {
+                               float* __restrict__ ws, long rows, float* __restrict__ scratch) {
   __shared__ float sm[4];
   float s = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
@@ -235,7 +243,10 @@ __global__ void ce_norm_kernel(const long long* __restrict__ label, const float*
     if (l >= 0) s += cw ? cw[l] : 1.f;
   }
   s = block_sum_256(s, sm);
-  if (threadIdx.x == 0) atomicAdd(ws, s);
+  if (threadIdx.x == 0) grid_publish(scratch + TFPP_GRIDSUM_TICKETS + blockIdx.x, s);
+  if (!grid_last_ticket(reinterpret_cast<unsigned*>(scratch), gridDim.x)) return;
+  s = grid_sum_partials(scratch + TFPP_GRIDSUM_TICKETS, sm);
+  if (threadIdx.x == 0) ws[0] = s;
 }
 
 // pass 2: loss and gradient.  denominator: pix_weight mode -> (*denom + eps)   else ws[0] (weighted mean)
@@ -243,7 +254,8 @@ template <typename T>
 __global__ void ce_loss_kernel(const T* __restrict__ pred, const long long* __restrict__ label, const float* __restrict__ cw,
                                const float* __restrict__ vis, const float* __restrict__ pix_weight, long pw_bstride, long HW,
                                const float* __restrict__ denom, float denom_eps, const float* __restrict__ ws, float weight,
-                               float* __restrict__ loss_out, T* __restrict__ dpred, long rows, int C, int ld, float smoothing) {
+                               float* __restrict__ loss_out, T* __restrict__ dpred, long rows, int C, int ld, float smoothing,
+                               float* __restrict__ scratch) {
   __shared__ float sm[4];
   // label smoothing (nn.CrossEntropyLoss(weight, label_smoothing), model.py:252-265): per row (1 - a) w[y] nll(y) + a / C sum_c w[c] nll(c),
   // normalised like the unsmoothed loss by sum_i w[y_i]
@@ -298,27 +310,27 @@ __global__ void ce_loss_kernel(const T* __restrict__ pred, const long long* __re
     }
   }
   acc = block_sum_256(acc, sm);
-  if (threadIdx.x == 0) atomicAdd(loss_out, acc * inv);
+  if (threadIdx.x == 0) grid_publish(scratch + TFPP_GRIDSUM_TICKETS + blockIdx.x, acc);
+  if (!grid_last_ticket(reinterpret_cast<unsigned*>(scratch), gridDim.x)) return;
+  acc = grid_sum_partials(scratch + TFPP_GRIDSUM_TICKETS, sm);
+  if (threadIdx.x == 0) loss_out[0] += acc * inv;  // (one writer: the losses accumulate into their slot)
 }
 
 extern "C" int tfpp_ce_loss(const void* pred, const int64_t* label, const float* class_weight, const float* vis_mask, const float* pix_weight,
                             int64_t pw_bstride, int64_t HW, const float* denom, float denom_eps, float weight, float* loss_out, void* dpred,
-                            float* ws, int64_t rows, int C, int ld, float smoothing, int dtype, void* stream) {
-  if (!pred || !label || !loss_out || !ws || C > 16 || ld > 16 || ld < C || HW < 1 || (pix_weight && !denom)) return TFPP_EINVAL;
+                            float* ws, float* scratch, int64_t rows, int C, int ld, float smoothing, int dtype, void* stream) {
+  if (!pred || !label || !loss_out || !ws || !scratch || C > 16 || ld > 16 || ld < C || HW < 1 || (pix_weight && !denom)) return TFPP_EINVAL;
   if (smoothing < 0.f || smoothing >= 1.f || (smoothing > 0.f && pix_weight)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   long blocks = (rows + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  if (!pix_weight) {
-    const int e = tfpp_fill_async(ws, 0, sizeof(float), st);
-    if (e != 0) return e;
-    hipLaunchKernelGGL(ce_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const long long*)label, class_weight, vis_mask, (long)HW, ws, (long)rows);
-  }
+  if (!pix_weight)
+    hipLaunchKernelGGL(ce_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const long long*)label, class_weight, vis_mask, (long)HW, ws, (long)rows, scratch);
   if (dtype == TFPP_F32)
-    hipLaunchKernelGGL(ce_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (float*)dpred, (long)rows, C, ld, smoothing);
+    hipLaunchKernelGGL(ce_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (float*)dpred, (long)rows, C, ld, smoothing, scratch);
   else
-    hipLaunchKernelGGL(ce_loss_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (bf16_t*)dpred, (long)rows, C, ld, smoothing);
+    hipLaunchKernelGGL(ce_loss_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (bf16_t*)dpred, (long)rows, C, ld, smoothing, scratch);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -330,7 +342,7 @@ extern "C" int tfpp_ce_loss(const void* pred, const int64_t* label, const float*
 template <typename T>
 __global__ void reg_loss_kernel(const T* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ ew, int wC, int w_bcast,
                                 const float* __restrict__ denom, float denom_eps, float denom_mul, float weight, float* __restrict__ loss_out,
-                                T* __restrict__ dpred, int B, int C, long HW, long ld, int kind) {
+                                T* __restrict__ dpred, int B, int C, long HW, long ld, int kind, float* __restrict__ scratch) {
   __shared__ float sm[4];
   const long n = (long)B * HW * ld;
   const float den = denom ? (denom[0] + denom_eps) * denom_mul : (float)((double)B * C * HW);
@@ -369,22 +381,25 @@ __global__ void reg_loss_kernel(const T* __restrict__ pred, const float* __restr
     if (dpred) dpred[i] = ElemTraits<T>::from_f(g * weight * inv);
   }
   acc = block_sum_256(acc, sm);
-  if (threadIdx.x == 0) atomicAdd(loss_out, acc * inv);
+  if (threadIdx.x == 0) grid_publish(scratch + TFPP_GRIDSUM_TICKETS + blockIdx.x, acc);
+  if (!grid_last_ticket(reinterpret_cast<unsigned*>(scratch), gridDim.x)) return;
+  acc = grid_sum_partials(scratch + TFPP_GRIDSUM_TICKETS, sm);
+  if (threadIdx.x == 0) loss_out[0] += acc * inv;  // (one writer: the losses accumulate into their slot)
 }
 
 extern "C" int tfpp_reg_loss(const void* pred, const float* target, const float* elem_weight, int wC, int w_bcast, const float* denom,
-                             float denom_eps, float denom_mul, float weight, float* loss_out, void* dpred, int B, int C, int64_t HW, int64_t ld,
-                             int kind, int dtype, void* stream) {
-  if (!pred || !target || !loss_out || ld < C) return TFPP_EINVAL;
+                             float denom_eps, float denom_mul, float weight, float* loss_out, void* dpred, float* scratch, int B, int C, int64_t HW,
+                             int64_t ld, int kind, int dtype, void* stream) {
+  if (!pred || !target || !loss_out || !scratch || ld < C) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long n = (long)B * HW * ld;
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   if (dtype == TFPP_F32)
-    hipLaunchKernelGGL(reg_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)pred, target, elem_weight, wC, w_bcast, denom, denom_eps, denom_mul, weight, loss_out, (float*)dpred, B, C, (long)HW, (long)ld, kind);
+    hipLaunchKernelGGL(reg_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)pred, target, elem_weight, wC, w_bcast, denom, denom_eps, denom_mul, weight, loss_out, (float*)dpred, B, C, (long)HW, (long)ld, kind, scratch);
   else
-    hipLaunchKernelGGL(reg_loss_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)pred, target, elem_weight, wC, w_bcast, denom, denom_eps, denom_mul, weight, loss_out, (bf16_t*)dpred, B, C, (long)HW, (long)ld, kind);
+    hipLaunchKernelGGL(reg_loss_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)pred, target, elem_weight, wC, w_bcast, denom, denom_eps, denom_mul, weight, loss_out, (bf16_t*)dpred, B, C, (long)HW, (long)ld, kind, scratch);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -534,6 +549,10 @@ extern "C" int tfpp_adamw_bias_corrections(float beta1, float beta2, int step, f
   *bc2_sqrt_out = sqrtf(1.f - powf(beta2, (float)step));
   return 0;
 }
+
+// scratch of the fixed-order grid sums (common.cuh): 64 ticket counters + the partials of the largest user (LayerNorm parameter gradients:
+// 64 row blocks x 2 x C <= 3072; the loss kernels publish <= 4096 partials).  Zero before the first use; one buffer per stream.
+extern "C" int tfpp_gridsum_scratch_floats(void) { return TFPP_GRIDSUM_TICKETS + 64 * 2 * 3072; }
 
 extern "C" int tfpp_version(void) { return TFPP_ABI_VERSION; }
 

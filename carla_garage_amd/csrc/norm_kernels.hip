@@ -653,7 +653,7 @@ extern "C" int tfpp_layernorm_fwd(const void* x, const float* gamma, const float
 template <typename T, int LN_MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                      const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx, long rows, int C,
-                                     int rows_per_wave, float* __restrict__ dbg, T* __restrict__ dx2, float p, float inv_keep,
+                                     int rows_per_wave, T* __restrict__ dx2, float p, float inv_keep,
                                      unsigned long long seed, const unsigned long long* __restrict__ seed_off) {
   // dx2 (nullable): dx times the dropout mask of (seed, row * C + c) -- the gradient of b in  LayerNorm(a + dropout(b))
   if (dx2 && seed_off) seed += *seed_off * 0x9E3779B97F4A7C15ull;
@@ -686,14 +686,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
     c1 = wave_sum(c1) / (float)C;
     c2 = wave_sum(c2) / (float)C;
-    const unsigned long long disagree = dbg ? __ballot(__float_as_uint(c1) != __builtin_amdgcn_readfirstlane(__float_as_uint(c1))) : 0ull;
-    if (dbg && lane == 0) {  // debugging aid (tfpp_debug_ln_buffer): the row scalars, the wave's MODE register and where it ran
-      unsigned mode, hwid;
-      mode = (unsigned)__builtin_popcountll(disagree);  // lanes whose butterfly result differs from lane 0's
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-      float* o = dbg + row * 6;
-      o[0] = c1; o[1] = c2; o[2] = mu; o[3] = rs; o[4] = __uint_as_float(mode); o[5] = __uint_as_float(hwid);
-    }
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
       const int cv = lane + k * 64;
@@ -714,11 +706,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 }
 
 // parameter gradients of LayerNorm as a column reduction: dgamma[c] += sum_r dy*xhat, dbeta[c] += sum_r dy.
-// grid (ceil(C/64), S); block = 64 channels x 4 row slots; <= S atomics per address.
+// grid (ceil(C/64), S); block = 64 channels x 4 row slots.  The S row blocks of a channel block publish their partial sums and the one that
+// draws the last ticket adds them in row-block order (fixed-order grid sum, common.cuh): bit-reproducible, one launch.
 template <typename T>
 __global__ void layernorm_param_grad_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
                                             const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                            long rows, int C, long rows_per_block) {
+                                            long rows, int C, long rows_per_block, float* __restrict__ scratch) {
   const int cl = threadIdx.x & 63, slot = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   const long r0 = (long)blockIdx.y * rows_per_block;
@@ -736,35 +729,38 @@ __global__ void layernorm_param_grad_kernel(const T* __restrict__ dy, const T* _
   sm[0][slot][cl] = sg;
   sm[1][slot][cl] = sb;
   __syncthreads();
+  // partials: [gridDim.y][2][C] behind the tickets; ticket blockIdx.x counts the row blocks of this channel block
+  float* part = scratch + TFPP_GRIDSUM_TICKETS;
   if (slot == 0 && c < C) {
-    if (dgamma) atomicAdd(dgamma + c, sm[0][0][cl] + sm[0][1][cl] + sm[0][2][cl] + sm[0][3][cl]);
-    if (dbeta) atomicAdd(dbeta + c, sm[1][0][cl] + sm[1][1][cl] + sm[1][2][cl] + sm[1][3][cl]);
+    grid_publish(part + ((size_t)blockIdx.y * 2 + 0) * C + c, sm[0][0][cl] + sm[0][1][cl] + sm[0][2][cl] + sm[0][3][cl]);
+    grid_publish(part + ((size_t)blockIdx.y * 2 + 1) * C + c, sm[1][0][cl] + sm[1][1][cl] + sm[1][2][cl] + sm[1][3][cl]);
+  }
+  if (!grid_last_ticket(reinterpret_cast<unsigned*>(scratch) + blockIdx.x, gridDim.y)) return;
+  if (slot < 2 && c < C) {  // wave 0: dgamma, wave 1: dbeta
+    float t = 0.f;
+    for (unsigned k = 0; k < gridDim.y; ++k) t += grid_fetch(part + ((size_t)k * 2 + slot) * C + c);
+    float* dst = slot == 0 ? dgamma : dbeta;
+    if (dst) dst[c] += t;
   }
 }
 
-// debugging aid: the NEXT tfpp_layernorm_bwd launch writes {c1, c2, mean, rstd, MODE register, HW_ID} per row into buf ([rows][6] floats)
-static float* g_ln_debug = nullptr;
-extern "C" int tfpp_debug_ln_buffer(float* buf) {
-  g_ln_debug = buf;
-  return 0;
-}
-
 static int launch_layernorm_param_grad(const void* dy, const void* x, const float* mean, const float* rstd, float* dgamma, float* dbeta, int64_t rows,
-                                       int C, int dtype, hipStream_t st) {
+                                       int C, int dtype, float* scratch, hipStream_t st) {
+  if (!scratch || C > 3072) return TFPP_EINVAL;
   long S = rows / 16;
   if (S > 64) S = 64;
   if (S < 1) S = 1;
   const long rpb = (rows + S - 1) / S;
   dim3 g2((unsigned)((C + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
-  if (dtype == TFPP_F32) hipLaunchKernelGGL(layernorm_param_grad_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, (const float*)x, mean, rstd, dgamma, dbeta, (long)rows, C, rpb);
-  else hipLaunchKernelGGL(layernorm_param_grad_kernel<bf16_t>, g2, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, dgamma, dbeta, (long)rows, C, rpb);
+  if (dtype == TFPP_F32) hipLaunchKernelGGL(layernorm_param_grad_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, (const float*)x, mean, rstd, dgamma, dbeta, (long)rows, C, rpb, scratch);
+  else hipLaunchKernelGGL(layernorm_param_grad_kernel<bf16_t>, g2, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, dgamma, dbeta, (long)rows, C, rpb, scratch);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
 
 static int launch_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, void* dx2, float p_drop,
-                                uint64_t seed, const uint64_t* seed_offset, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || p_drop < 0.f || p_drop >= 1.f) return TFPP_EINVAL;
+                                uint64_t seed, const uint64_t* seed_offset, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int dtype, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || p_drop < 0.f || p_drop >= 1.f || ((dgamma || dbeta) && !scratch)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int VEC = dtype == TFPP_F32 ? 4 : 8;
   if (C % VEC || C / VEC > 64 * 6) return TFPP_EINVAL;
@@ -772,36 +768,34 @@ static int launch_layernorm_bwd(const void* dy, const void* x, const float* gamm
   const int rpw = 1;  // dx: one wave per row, no atomics (parameter gradients come from the column-reduction kernel)
   const long waves = (rows + rpw - 1) / rpw;
   dim3 grid((unsigned)((waves + 3) / 4));
-  float* dbg = g_ln_debug;  // armed for one launch
-  g_ln_debug = nullptr;
   const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-#define LN_BWD(TT, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, MV>), grid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, gamma, mean, rstd, (TT*)dx, (long)rows, C, rpw, dbg, (TT*)dx2, p_drop, inv_keep, (unsigned long long)seed, (const unsigned long long*)seed_offset)
+#define LN_BWD(TT, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, MV>), grid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, gamma, mean, rstd, (TT*)dx, (long)rows, C, rpw, (TT*)dx2, p_drop, inv_keep, (unsigned long long)seed, (const unsigned long long*)seed_offset)
 #define LN_BWD_T(TT) do { if (nv <= 1) LN_BWD(TT, 1); else if (nv <= 2) LN_BWD(TT, 2); else if (nv <= 3) LN_BWD(TT, 3); else if (nv <= 4) LN_BWD(TT, 4); else LN_BWD(TT, 6); } while (0)
   if (dtype == TFPP_F32) LN_BWD_T(float); else LN_BWD_T(bf16_t);
   TFPP_CHECK_LAUNCH();
-  if (dgamma || dbeta) return launch_layernorm_param_grad(dy, x, mean, rstd, dgamma, dbeta, rows, C, dtype, st);
+  if (dgamma || dbeta) return launch_layernorm_param_grad(dy, x, mean, rstd, dgamma, dbeta, rows, C, dtype, scratch, st);
   return 0;
 }
 
 extern "C" int tfpp_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
-                                  float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream) {
-  return launch_layernorm_bwd(dy, x, gamma, mean, rstd, dx, nullptr, 0.f, 0, nullptr, dgamma, dbeta, rows, C, dtype, stream);
+                                  float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int dtype, void* stream) {
+  return launch_layernorm_bwd(dy, x, gamma, mean, rstd, dx, nullptr, 0.f, 0, nullptr, dgamma, dbeta, scratch, rows, C, dtype, stream);
 }
 
 // backward of tfpp_add_layernorm_fwd: d_sum (the gradient of a) and d_b = d_sum * dropout mask in one launch; parameter gradients as above
 extern "C" int tfpp_add_layernorm_bwd(const void* dy, const void* sum, const float* gamma, const float* mean, const float* rstd, void* d_sum, void* d_b,
-                                      float* dgamma, float* dbeta, int64_t rows, int C, float p_drop, uint64_t seed, const uint64_t* seed_offset,
-                                      int dtype, void* stream) {
+                                      float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, float p_drop, uint64_t seed,
+                                      const uint64_t* seed_offset, int dtype, void* stream) {
   if (!d_b) return TFPP_EINVAL;
-  return launch_layernorm_bwd(dy, sum, gamma, mean, rstd, d_sum, d_b, p_drop, seed, seed_offset, dgamma, dbeta, rows, C, dtype, stream);
+  return launch_layernorm_bwd(dy, sum, gamma, mean, rstd, d_sum, d_b, p_drop, seed, seed_offset, dgamma, dbeta, scratch, rows, C, dtype, stream);
 }
 
 // the parameter gradients alone (dgamma[c] += sum_r dy * xhat, dbeta[c] += sum_r dy): they only feed the optimizer, so the engine runs them
 // on the weight-gradient lane and keeps the dx kernel alone on the dY chain
-extern "C" int tfpp_layernorm_param_grad(const void* dy, const void* x, const float* mean, const float* rstd, float* dgamma, float* dbeta, int64_t rows,
-                                         int C, int dtype, void* stream) {
+extern "C" int tfpp_layernorm_param_grad(const void* dy, const void* x, const float* mean, const float* rstd, float* dgamma, float* dbeta, float* scratch,
+                                         int64_t rows, int C, int dtype, void* stream) {
   if (!dy || !x || !mean || !rstd || (!dgamma && !dbeta)) return TFPP_EINVAL;
-  return launch_layernorm_param_grad(dy, x, mean, rstd, dgamma, dbeta, rows, C, dtype, (hipStream_t)stream);
+  return launch_layernorm_param_grad(dy, x, mean, rstd, dgamma, dbeta, rows, C, dtype, scratch, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

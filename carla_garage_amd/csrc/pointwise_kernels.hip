@@ -1011,184 +1011,6 @@ extern "C" int tfpp_se_gate_bwd(const float* dgate, const float* gate, const flo
   return 0;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Squeeze-excite gate in ONE launch per direction after the pooling pass (round 2: the gate was col_final -> hidden -> gate, three
-// dependent launches of a few microseconds of work each, 42 times per step on the critical chain; likewise the backward).  One workgroup
-// per sample: the pooled vector and the hidden activations live in LDS; every matrix row is read by a wave with consecutive lanes on
-// consecutive elements.  Used while the two matrices fit comfortably in L2 (C * RD <= SE_FUSED_MAX; stage 4 keeps the separate kernels).
-constexpr int SE_NT = 1024;
-constexpr long SE_FUSED_MAX = 131072;
-
-__global__ __launch_bounds__(SE_NT) void se_fwd_fused_kernel(const float* __restrict__ partial, int nb, float mulv, const float* __restrict__ w1,
-                                                             const float* __restrict__ b1, const float* __restrict__ w2,
-                                                             const float* __restrict__ b2, float* __restrict__ pool_out,
-                                                             float* __restrict__ hidden_out, float* __restrict__ gate_out, int C, int RD) {
-  extern __shared__ float se_sh[];  // pool[C] | hidden[RD]
-  float* pool = se_sh;
-  float* hid = se_sh + C;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int NW = SE_NT / 64;
-  for (int c = tid; c < C; c += SE_NT) {  // second stage of the pooling reduction (col_final_kernel's job), same partial layout
-    const float* p = partial + (size_t)b * nb * C + c;
-    float s = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < nb; ++k) s += p[(size_t)k * C];
-    s *= mulv;
-    pool[c] = s;
-    pool_out[(size_t)b * C + c] = s;
-  }
-  __syncthreads();
-  for (int j = wave; j < RD; j += NW) {  // hidden = relu(W1 pool + b1)
-    const float* wr = w1 + (size_t)j * C;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += wr[c] * pool[c];
-    s = wave_sum(s);
-    if (lane == 0) {
-      s += b1[j];
-      s = s > 0.f ? s : 0.f;
-      hid[j] = s;
-      hidden_out[(size_t)b * RD + j] = s;
-    }
-  }
-  __syncthreads();
-  for (int c = wave; c < C; c += NW) {  // gate = sigmoid(W2 hidden + b2)
-    const float* wr = w2 + (size_t)c * RD;
-    float s = 0.f;
-    for (int j = lane; j < RD; j += 64) s += wr[j] * hid[j];
-    s = wave_sum(s);
-    if (lane == 0) gate_out[(size_t)b * C + c] = 1.f / (1.f + __expf(-(s + b2[c])));
-  }
-}
-
-extern "C" int tfpp_se_fused_supported(int C, int RD) { return (long)C * RD <= SE_FUSED_MAX && (C + RD) * 4 <= 60000; }
-
-extern "C" int tfpp_se_fwd_fused(const void* x, float* scratch, const float* w1, const float* b1, const float* w2, const float* b2, float* pool,
-                                 float* hidden, float* gate, int B, int HW, int C, int RD, int dtype, void* stream) {
-  if (!x || !scratch || !w1 || !b1 || !w2 || !b2 || !pool || !hidden || !gate || !tfpp_se_fused_supported(C, RD)) return TFPP_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const int VEC = dtype == TFPP_F32 ? 4 : 8;
-  if (C % VEC) return TFPP_EINVAL;
-  const ColLayout l = col_layout(C / VEC);
-  int nb = col_blocks_x(HW, l, 8, 4096, B);
-  if (nb > HW_MAX_PARTIALS) nb = HW_MAX_PARTIALS;
-  dim3 grid((unsigned)nb, (unsigned)l.ny, (unsigned)B);
-  if (dtype == TFPP_F32) hipLaunchKernelGGL((hw_reduce_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, (const float*)nullptr, scratch, HW, C / VEC, l.sw, l.rp);
-  else hipLaunchKernelGGL((hw_reduce_kernel<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, scratch, HW, C / VEC, l.sw, l.rp);
-  hipLaunchKernelGGL(se_fwd_fused_kernel, dim3((unsigned)B), dim3(SE_NT), (size_t)(C + RD) * sizeof(float), st, scratch, nb, 1.f / (float)HW, w1, b1, w2, b2,
-                     pool, hidden, gate, C, RD);
-  TFPP_CHECK_LAUNCH();
-  return 0;
-}
-
-// backward: dgate[c] = sum over HW of dy*x (second stage here), gd = dgate g (1 - g), dz1[j] = (hidden[j] > 0) sum_c gd[c] W2[c][j],
-// dpool[c] = sum_j dz1[j] W1[j][c].  gd and dz1 are written out for the parameter-gradient kernel, which is off the critical chain.
-__global__ __launch_bounds__(SE_NT) void se_bwd_fused_kernel(const float* __restrict__ partial, int nb, const float* __restrict__ gate,
-                                                             const float* __restrict__ hidden, const float* __restrict__ w1,
-                                                             const float* __restrict__ w2, float* __restrict__ gd_out, float* __restrict__ dz1_out,
-                                                             float* __restrict__ dpool, int C, int RD) {
-  extern __shared__ float se_sh[];  // gd[C] | dz1[RD] | part[NG][RD]
-  float* gd = se_sh;
-  float* dz = se_sh + C;
-  float* part = dz + RD;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  for (int c = tid; c < C; c += SE_NT) {
-    const float* p = partial + (size_t)b * nb * C + c;
-    float s = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < nb; ++k) s += p[(size_t)k * C];
-    const float g = gate[(size_t)b * C + c];
-    s = s * g * (1.f - g);
-    gd[c] = s;
-    gd_out[(size_t)b * C + c] = s;
-  }
-  __syncthreads();
-  // dz1: thread (cg, j) walks channels cg, cg + NG, ...: consecutive threads read consecutive j of one W2 row (coalesced); fixed-order sum over cg
-  const int NG = SE_NT / RD > 0 ? (SE_NT / RD < 16 ? SE_NT / RD : 16) : 1;
-  {
-    const int cg = tid / RD, j = tid - cg * RD;
-    if (cg < NG) {
-      float s = 0.f;
-      for (int c = cg; c < C; c += NG) s += gd[c] * w2[(size_t)c * RD + j];
-      part[cg * RD + j] = s;
-    }
-  }
-  __syncthreads();
-  for (int j = tid; j < RD; j += SE_NT) {
-    float s = 0.f;
-    for (int k = 0; k < NG; ++k) s += part[k * RD + j];
-    s = hidden[(size_t)b * RD + j] > 0.f ? s : 0.f;
-    dz[j] = s;
-    dz1_out[(size_t)b * RD + j] = s;
-  }
-  __syncthreads();
-  for (int c = tid; c < C; c += SE_NT) {
-    float s = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < RD; ++j) s += dz[j] * w1[(size_t)j * C + c];
-    dpool[(size_t)b * C + c] = s;
-  }
-}
-
-extern "C" int tfpp_se_bwd_fused(const void* dy, const void* x, float* scratch, const float* gate, const float* hidden, const float* w1,
-                                 const float* w2, float* gd, float* dz1, float* dpool, int B, int HW, int C, int RD, int dtype, void* stream) {
-  if (!dy || !x || !scratch || !gate || !hidden || !w1 || !w2 || !gd || !dz1 || !dpool || !tfpp_se_fused_supported(C, RD) || RD > SE_NT)
-    return TFPP_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const int VEC = dtype == TFPP_F32 ? 4 : 8;
-  if (C % VEC) return TFPP_EINVAL;
-  const ColLayout l = col_layout(C / VEC);
-  int nb = col_blocks_x(HW, l, 4, 4096, B);
-  if (nb > HW_MAX_PARTIALS) nb = HW_MAX_PARTIALS;
-  dim3 grid((unsigned)nb, (unsigned)l.ny, (unsigned)B);
-  if (dtype == TFPP_F32) hipLaunchKernelGGL((hw_reduce_kernel<float, true>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, scratch, HW, C / VEC, l.sw, l.rp);
-  else hipLaunchKernelGGL((hw_reduce_kernel<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, scratch, HW, C / VEC, l.sw, l.rp);
-  const int ng = SE_NT / RD > 0 ? (SE_NT / RD < 16 ? SE_NT / RD : 16) : 1;
-  hipLaunchKernelGGL(se_bwd_fused_kernel, dim3((unsigned)B), dim3(SE_NT), (size_t)(C + RD + (size_t)ng * RD) * sizeof(float), st, scratch, nb, gate, hidden,
-                     w1, w2, gd, dz1, dpool, C, RD);
-  TFPP_CHECK_LAUNCH();
-  return 0;
-}
-
-// parameter gradients of the gate MLP from gd / dz1 (single writer per element, no atomics): dw2[c][j] += sum_b gd[b,c] hidden[b,j],
-// db2[c] += sum_b gd[b,c], dw1[j][c] += sum_b dz1[b,j] pool[b,c], db1[j] += sum_b dz1[b,j].  Weight-gradient lane.
-__global__ void se_param_grads2_kernel(const float* __restrict__ gd, const float* __restrict__ dz1, const float* __restrict__ hidden,
-                                       const float* __restrict__ pool, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
-                                       float* __restrict__ db2, int B, int C, int RD) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned n1 = (unsigned)C * RD;
-  if (i < n1) {
-    const unsigned c = i / RD, j = i - c * RD;
-    float s = 0.f, sb = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float g = gd[(size_t)b * C + c];
-      s += g * hidden[(size_t)b * RD + j];
-      sb += g;
-    }
-    dw2[i] += s;
-    if (j == 0) db2[c] += sb;
-  } else if (i < 2 * n1) {
-    const unsigned k = i - n1;
-    const unsigned j = k / C, c = k - j * C;
-    float s = 0.f, sb = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float d = dz1[(size_t)b * RD + j];
-      s += d * pool[(size_t)b * C + c];
-      sb += d;
-    }
-    dw1[k] += s;
-    if (c == 0) db1[j] += sb;
-  }
-}
-
-extern "C" int tfpp_se_param_grads(const float* gd, const float* dz1, const float* hidden, const float* pool, float* dw1, float* db1, float* dw2,
-                                   float* db2, int B, int C, int RD, void* stream) {
-  if (!gd || !dz1 || !hidden || !pool || !dw1 || !db1 || !dw2 || !db2 || 2l * C * RD >= (1l << 31)) return TFPP_EINVAL;
-  const int nblk = (int)((2l * C * RD + 255) / 256);
-  hipLaunchKernelGGL(se_param_grads2_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, gd, dz1, hidden, pool, dw1, db1, dw2, db2, B, C, RD);
-  TFPP_CHECK_LAUNCH();
-  return 0;
-}
-
 // dx = dy * gate[b,c] + dpool[b,c] / HW
 template <typename T>
 __global__ void se_bwd_apply_kernel(const T* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dpool,

@@ -49,13 +49,11 @@ class Lanes:
   perspective decoders); lane 1 carries the LiDAR branch between the fusion points (a quarter of the pixels: small, latency-bound
   launches that overlap with the image branch) and afterwards the fp32 planning head.  Every tape node carries the lane it was
   recorded on, so backward mirrors the split.  Captured into the hipGraphs as parallel branches.  TFPP_BRANCH_STREAMS=0 keeps
-  everything on one stream.  The class handles any number of lanes; a third one for the BEV pyramid + CenterNet / BEV-semantic
-  heads (TFPP_HEAD_LANE=1) works eagerly but hipStreamEndCapture of ROCm 7.0 segfaults on the resulting four-stream capture
-  (round 2, gpurun_out/r02_crash.log), so it is off by default and those layers stay on lane 0."""
+  everything on one stream.  (A third lane for the BEV pyramid + CenterNet / BEV-semantic heads worked eagerly, but hipStreamEndCapture of
+  ROCm 7.x segfaults on the resulting four-stream capture -- rounds 2 and 4 -- so those layers stay on lane 0.)"""
 
   def __init__(self):
     self.enabled = os.environ.get('TFPP_BRANCH_STREAMS', '1') != '0'
-    self.head_lane = 2 if (self.enabled and os.environ.get('TFPP_HEAD_LANE', '0') == '1') else 0
     self.main = None
     self.branches = {}    # lane -> torch.cuda.Stream (created on first use, kept for the life of the engine)
     self.active = set()   # lanes forked since the last join
@@ -91,7 +89,7 @@ class Lanes:
       return self.main
     st = self.branches.get(k)
     if st is None:
-      st = self.branches[k] = torch.cuda.Stream(self.main.device, priority=-1 if os.environ.get('TFPP_LANE_PRIORITY', '0') == '1' else 0)
+      st = self.branches[k] = torch.cuda.Stream(self.main.device)
     return st
 
   def touch(self, k, ev=None):
@@ -145,11 +143,8 @@ class Tape:
     self.frozen = {}      # id(tensor) -> tensor: handed to another stream, must not be accumulated into in place
     self._graveyard = []
     self._grads = None    # pending gradients while backward() runs (take_pending)
-    self._rest = []
-    self.split_index = None
     self.first = None     # (a, b): nodes recorded in [a, b) are walked FIRST in backward (Tape.hoist)
-    self.on_finish = None  # callback: the whole backward pass (both segments) has been issued
-    self.on_mark = None   # callback: a single-segment backward has just walked every node recorded after mark() (the early gradients are issued)
+    self.on_finish = None  # callback: the whole backward pass has been issued
     self.finalizers = []  # run once at the end of backward (joins side streams)
     self.uses = {}        # key -> number of recorded nodes that consume the tensor (forward)
     self.contrib = {}     # key -> gradient contributions received so far (backward)
@@ -200,20 +195,14 @@ class Tape:
     ~2.7 ms of tiny launches on its own lane whose result the BEV pyramid and fusion stage 4 wait for, so it has to start with the pass."""
     self.first = (a, b)
 
-  def mark(self):
-    """Split point for a two-segment backward: nodes recorded after this call form the first segment."""
-    self.split_index = len(self.nodes)
-
   def relane(self, a, b, lane):
     """Backward runs the nodes recorded as a..b-1 on ``lane`` instead of the lane their forward ran on."""
     for i in range(a, min(b, len(self.nodes))):
       outs, ins, fn, _ = self.nodes[i]
       self.nodes[i] = (outs, ins, fn, lane)
 
-  def backward(self, seeds, stop_at_mark=False):
-    """seeds: list of (tensor, grad).  With ``stop_at_mark`` only the nodes recorded after ``mark()`` are processed (the lanes are
-    joined, so every gradient those nodes produce is complete) and ``backward_resume()`` runs the rest -- the trainer all-reduces
-    the finished part of the gradient arena while the second segment computes."""
+  def backward(self, seeds):
+    """seeds: list of (tensor, grad).  One pass over the recorded nodes in reverse order (the hoisted block first), the lanes joined at the end."""
     self._grads, self._refs, self._glane, self._lane = {}, {}, {}, 0
     self._gevent = {}  # key -> event recorded on the producing lane right after the gradient was written (see _wait)
     self.contrib = {}
@@ -224,40 +213,18 @@ class Tape:
     Tape.current = self
     for t, g in seeds:
       self._acc(t, g, 0)
-    split = self.split_index if (stop_at_mark and self.split_index is not None) else 0
     todo, self.nodes = self.nodes, []
-    if self.first is not None and split <= self.first[0] < self.first[1] <= len(todo):
+    if self.first is not None and 0 <= self.first[0] < self.first[1] <= len(todo):
       a, b = self.first
       todo = todo[:a] + todo[b:] + todo[a:b]  # (_run walks the list backwards)
-    self._rest = todo[:split]
-    self._mark_pos = self.split_index if (split == 0 and self.split_index and self.on_mark is not None) else None
-    self._run(todo[split:])
-    self._join()
-    if not self._rest:
-      self._finish()
-
-  def backward_resume(self):
-    """Second segment after ``backward(..., stop_at_mark=True)``."""
-    if self._grads is None:
-      return
-    if self.lanes is not None and self._multi:
-      held, self.lanes.held = self.lanes.held, []  # keep-alives of the first segment survive until the end of the second
-      self.lanes.begin(self.lanes.main.device)  # lane 0 = the stream current now (the same capture stream in a hipGraph)
-      self.lanes.held = held
-      # a branch lane is forked from lane 0 (Lanes.touch) before its first node of this segment runs: the segment may be the start
-      # of a new hipGraph capture, and a stream that has not yet waited on the capturing stream is not part of the capture (its
-      # kernels would run eagerly and be missing from the replay), even if the gradient it consumes was produced on that lane itself
-    Tape.current = self
-    self._gevent = {}  # events of the first segment belong to another capture; every lane was joined at its end (coarse waits suffice here)
-    rest, self._rest = self._rest, []
-    self._run(rest)
+    self._run(todo)
     self._join()
     self._finish()
 
   def _sync(self, to_lane, from_lane):
     if self._multi and to_lane != from_lane:
       self.lanes.touch(to_lane)
-      self.lanes.touch(from_lane)  # a producer lane idle since the last join (second backward segment) joins this pass / capture first
+      self.lanes.touch(from_lane)  # a producer lane idle since the last join joins this pass / capture first
       self.lanes.stream(to_lane).wait_stream(self.lanes.stream(from_lane))
 
   def _wait(self, to_lane, k, from_lane):
@@ -268,7 +235,7 @@ class Tape:
     tools/lane_timeline.py: lane 0 stalled 2.0 + 2.4 + 1.4 ms at the fusion points, lane 1 sat idle for 3.7 + 2.8 ms)."""
     if not self._multi or to_lane == from_lane:
       return
-    ev = self._gevent.get(k) if _FINE_EVENTS else None
+    ev = self._gevent.get(k)
     if ev is None:
       self._sync(to_lane, from_lane)
       return
@@ -276,7 +243,7 @@ class Tape:
     self.lanes.stream(to_lane).wait_event(ev)
 
   def _mark_written(self, k, lane):
-    if self._multi and _FINE_EVENTS:
+    if self._multi:
       ev = torch.cuda.Event()
       ev.record(self.lanes.stream(lane))
       self._gevent[k] = ev
@@ -312,12 +279,8 @@ class Tape:
 
   def _run(self, nodes):
     grads, refs, glane, lanes, multi = self._grads, self._refs, self._glane, self.lanes, self._multi
-    mark_pos = getattr(self, '_mark_pos', None)
     for pos in range(len(nodes) - 1, -1, -1):
       outs, ins, fn, lane = nodes[pos]
-      if mark_pos is not None and pos == mark_pos - 1:  # everything recorded after mark() has been walked: the early gradients are all issued
-        self._mark_pos = mark_pos = None
-        self.on_mark()
       if not multi:
         lane = 0
       gouts, src = [], []
@@ -340,7 +303,7 @@ class Tape:
           self._wait(lane, k, sl)
           self._gevent.pop(k, None)
         if multi and lane != 0:
-          lanes.touch(lane)  # (a lane whose first node of this pass consumes only its own gradients: second backward segment)
+          lanes.touch(lane)  # (a lane whose first node of this pass consumes only its own gradients)
         if multi and src_lanes - {lane}:
           lanes.hold(*[g for g in gouts if g is not None])
         if ops.STAMPS['on']:
@@ -366,7 +329,7 @@ class Tape:
       lanes.cur = 0
 
   def _join(self):
-    """End of a segment: flush + join the weight-gradient lane, join the encoder lanes."""
+    """End of the pass: flush + join the weight-gradient lane, join the encoder lanes."""
     ops.stamp('bwd lane0 MAIN CHAIN DONE (before the joins)')
     for fin in self.finalizers:
       fin()
@@ -402,26 +365,15 @@ def _fn_label(fn):
   return lab
 
 
-_LN_CHECK = os.environ.get('TFPP_DEBUG_LN_CHECK', '0') == '1'
-_SPLIT_PACK = os.environ.get('TFPP_SPLIT_PACK', '1') != '0'  # weight repacking in two launches, the second beside the first layers of forward
-# planning-head Linears on the small-problem batched-GEMM kernel: 0 = never (conv_gemm + split-K / conv_wgrad), 1 = forward, data and weight
-# gradient, 2 = weight gradients only (A/B switch)
 # streams the weight-gradient lane alternates between, batch by batch; measured on the bs = 12 captured step (A/B/A/B, one box): 2: 24.38 / 24.43,
 # 3: 24.03 / 24.02, 4 (every batch of the default three forks on its own stream): 23.76 / 23.99 ms/step
 _SIDE_STREAMS = max(1, int(os.environ.get('TFPP_SIDE_STREAMS', '4')))
-_HEAD_BGEMM = int(os.environ.get('TFPP_HEAD_BGEMM', '0'))  # measured (same box): 0: 26.85, 1: 27.28, 2: 26.95 ms/step
 
 
 def _early_weights(name):
   """Layers that run before the first fusion point of the default TransFuser backbone (everything else is packed beside them)."""
   return any(name.startswith(p) for p in ('backbone.image_encoder.stem', 'backbone.image_encoder.s1.', 'backbone.lidar_encoder.stem',
                                           'backbone.lidar_encoder.s1.', 'backbone.lidar_channel_to_img.0'))
-_TAIL_ON_MAIN = os.environ.get('TFPP_TAIL_ON_MAIN', '1') != '0'  # backward of LiDAR stage 1 on lane 0 (A/B switch)
-_LN_SIDE = os.environ.get('TFPP_LN_SIDE', '1') != '0'  # LayerNorm parameter gradients on the weight-gradient lane (A/B switch)
-_ADD_LN = os.environ.get('TFPP_ADD_LN', '1') != '0'  # post-norm residual step of the planning decoder as one launch (A/B switch)
-_SMALL_ATTN = os.environ.get('TFPP_SMALL_ATTN', '1') != '0'  # planning-decoder attention as one launch (head_kernels.hip) instead of bgemm -> softmax -> bgemm
-_FINE_EVENTS = os.environ.get('TFPP_FINE_EVENTS', '1') != '0'  # cross-lane gradient dependencies as events instead of stream-level waits (A/B switch)
-LN_KEEP = {}
 _SKIP_SIDE_WORK = os.environ.get('TFPP_DEBUG_SKIP_SIDE_WORK', '0') == '1'
 _SIDE_CHECK = os.environ.get('TFPP_DEBUG_SIDE_CHECK', '0') == '1'
 _KEEP_ALL = os.environ.get('TFPP_DEBUG_KEEP_ALL', '0') == '1'
@@ -460,7 +412,6 @@ class SideLane:
     # gradient buckets (buckets.py): batches flushed so far in this pass, "a batch is running its closures right now", the closure count
     # at every flush of this pass, and the hook called on the batch's stream when a batch has been issued completely
     self.flush_seq, self.in_flush, self.flush_counts, self.on_batch_end = 0, False, [], None
-    self.wplan = ops.WgradReducePlan()  # the slice sums of a batch's pixel-split weight gradients as one launch at the batch end
     self.keep = []
     self.pending = []
     self.checks = []
@@ -520,14 +471,11 @@ class SideLane:
       self.flush_counts.append(self.count)
       with torch.cuda.stream(self.stream):
         ops.stamp(f'side lane9 batch of {len(self.pending)} begins')
-        ops.WGRAD_PLAN = self.wplan  # the slice sums of this batch's weight gradients: one launch at its end (ops.WgradReducePlan)
         self.in_flush = True
         try:
           for fn in self.pending:
             fn()
-          self.wplan.flush()
         finally:
-          ops.WGRAD_PLAN = None
           self.in_flush = False
         ops.stamp('side lane9 batch ends')
         if self.on_batch_end is not None:
@@ -566,17 +514,10 @@ class SideLane:
       self.last_flush_counts, self.flush_counts, self.flush_seq = self.flush_counts, [], 0
 
 
-# BatchNorm-backward sums (sum g, sum g*xhat) produced by the kernel that completes the gradient instead of a separate reduction pass:
-#   0 off;  1 (default) only where the producer is the elementwise squeeze-excite backward (conv2 of every bottleneck: +0.3 ms in that
-#   kernel, -0.56 ms of tfpp_bn_bwd_reduce);  2 also in the epilogue of the data-gradient GEMMs (their own kernel instantiations) --
-#   correct (tests) and neutral at bs = 12: 32.16 vs 32.19 ms/step (round 2, same box, profiles/r02_kernel_table_fuse_bn_bwd{1,2}.txt): the
-#   reduction passes it removes are replaced by longer GEMM epilogues on the same critical chain.  The first measurement of mode 2
-#   (38.9 vs 35.8 ms) was taken while a run-time `bns` pointer kept the statistics object of EVERY bf16 conv launch in scratch memory.
-FUSE_BN_BWD = int(os.environ.get('TFPP_FUSE_BN_BWD', '1'))
-# squeeze-excite gate (and its backward) as one per-sample launch after the pooling pass instead of three, parameter gradients on the weight-gradient
-# lane.  Correct (tests) but SLOWER at bs = 12: 31.6 vs 30.0 ms/step (round 2, same box) -- twelve workgroups walking 64 partial rows and two
-# matrices serially lose more than the two saved launches per direction gain; off by default.
-SE_FUSED = os.environ.get('TFPP_SE_FUSED', '0') == '1'
+# BatchNorm-backward sums (sum g, sum g*xhat) are produced by the kernel that completes the gradient where that kernel is the elementwise
+# squeeze-excite backward (conv2 of every bottleneck); the data-gradient GEMMs can emit them as well (tfpp_conv_params.bns_*, tested at the
+# op level) but the longer epilogues cost more on the chain than the reduction passes they replace (+0.75 ms/step, profiles/r04_switch_ab.txt),
+# and a one-launch-per-sample squeeze-excite gate was 1.4 ms/step slower than the three small launches it replaced: neither is wired in.
 
 EARLY_GRAD_PREFIXES = ('backbone.image_encoder.s4', 'backbone.lidar_encoder.s4', 'backbone.lidar_encoder.layers.layer3', 'backbone.lidar_encoder.norm', 'backbone.transformers.3', 'backbone.lidar_channel_to_img.3',
                        'backbone.img_channel_to_lidar.3', 'backbone.c5_conv', 'backbone.up_conv')
@@ -808,7 +749,7 @@ class Engine:
       for k, imgs in ent['attn'].items():
         self._attn[k].update(imgs)
     self._plan, self._plan_key = ent['plan'], key
-    if defer and _SPLIT_PACK and torch.device(self.device).type == 'cuda':
+    if defer and torch.device(self.device).type == 'cuda':
       # the weight images of the stems and stage 1 now (the first ~1 ms of forward only needs those), the other ~99 % (0.4 ms of HBM streaming)
       # on their own stream beside that millisecond; Engine.forward waits for it at the first fusion point (_join_pack)
       ent['plan'].launch(0)
@@ -971,8 +912,6 @@ class Engine:
     if tape is None:
       return
     del tape.nodes[start:]
-    if tape.split_index is not None and tape.split_index > start:
-      tape.split_index = None
 
   def begin_backward(self):
     """Start of a backward pass (Trainer / DropinStep call it before Tape.backward)."""
@@ -1011,25 +950,6 @@ class Engine:
     self.observation_stable = (not side.enabled) or (not side.forks) or side.flush_at is not None or (side.total_prev > 0 and side.total_prev == self._prev_total)
     return self.observed_buckets
 
-  # ------------------------------------------------------------------------------------------------ fused BatchNorm-backward sums
-  def _bns_request(self, x, query):
-    """Called by the backward of a node that is about to produce a gradient for ``x``.  When x is the output of a train-mode
-    conv + BatchNorm (+ ReLU) layer, this gradient is the last one x receives (Tape.is_last_contribution) and the producing kernel
-    supports it (``query()`` -> (ok, rows)), returns the descriptor that makes the kernel emit that layer's BatchNorm-backward
-    sums in its epilogue (tfpp_conv_params.bns_*) -- the layer's own backward then skips the reduction pass over dy, y and x."""
-    if FUSE_BN_BWD < 2 or x.dtype != torch.bfloat16 or Tape.current is None:
-      return None
-    info = self._bn_of.get(_key(x))
-    if info is None or not Tape.current.is_last_contribution(x):
-      return None
-    ok, nrows = query()
-    if not ok:
-      return None
-    sL, rawL, relu = info
-    c = x.shape[-1]
-    return dict(y=x, x=rawL, mean=sL.save_mean, invstd=sL.save_invstd, relu=relu, nrows=nrows,
-                partial=torch.empty(nrows * 2 * c, device=x.device, dtype=F32))
-
   # ------------------------------------------------------------------------------------------------ primitives
   def rec(self, outs, ins, fn):
     if self.tape is not None:
@@ -1043,9 +963,6 @@ class Engine:
   def conv(self, x, key, act=ACT_NONE, res=None, x_grad=True, out_f32=False):
     """x: [B,H,W,Cstore] NHWC.  Returns [B,Ho,Wo,n_store]."""
     s = self.specs[key]
-    if ((_HEAD_BGEMM == 1 or (_HEAD_BGEMM == 3 and s.cin_g <= 512 and s.cout <= 1024)) and s.head and s.k == 1 and s.groups == 1 and s.bn is None and res is None and x.dtype == F32 and x.shape[-1] == s.cin_g and
-        s.n_store == s.cout and x.is_cuda):
-      return self.head_linear(x, s, key, act, x_grad)
     B, H, W, Cs = x.shape
     k, st, pd, G = s.k, s.stride, s.pad, s.groups
     Ho, Wo = (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
@@ -1104,13 +1021,7 @@ class Engine:
             dconv, dres = ops.bn_bwd(dy, y, raw, s.bn.weight.detach(), s.save_mean, s.save_invstd, None, self.g(s.bn.weight),
                                      self.g(s.bn.bias), relu_mask=(act == ACT_RELU), want_dres=res is not None)
         gsrc = dconv if dconv.dtype == x.dtype else ops.cast(dconv, x.dtype)
-        if (_HEAD_BGEMM == 2 and s.head and k == 1 and G == 1 and s.weight.requires_grad and gsrc.dtype == F32 and Cs == s.cin_g and
-            s.n_store == s.cout):
-          # planning-head Linear: dW[n][c] += sum_rows dz[row][n] * x[row][c] as ONE launch of the small-problem kernel (no pixel slices + slice sum)
-          rows_ = B * Ho * Wo
-          self.side.run(Tape.current, lambda: ops.bgemm(gsrc, x, self.g(s.weight).view(s.cout, Cs), M=s.cout, N=Cs, K=rows_, lda=s.n_store, ldb=Cs,
-                                                        ldc=Cs, a_km=True, b_km=True, beta=1.0), gsrc, x)
-        elif s.weight.requires_grad:
+        if s.weight.requires_grad:
           self.side.run(Tape.current, lambda: ops.conv_wgrad(
               gsrc, x, self.g(s.weight), B=B, Hs=H, Ws=W, Cs=Cs, Hd=Ho, Wd=Wo, Cd=s.n_store, R=k, S=k, stride=st, pad=pd, G=G,
               ks_g=Cs // G, n_g=s.n_store // G, c_real=s.cin_g, row_map=s.row_map), gsrc, x)
@@ -1118,48 +1029,13 @@ class Engine:
         if x_grad:
           dx = torch.empty((B, H, W, Cs), device=x.device, dtype=x.dtype)
           # a gradient already pending for x (the other path of a residual / FPN fan-out) is added in the GEMM epilogue
-          pend = Tape.current.take_pending(x, dx) if os.environ.get('TFPP_FUSE_GRAD_ACC', '1') != '0' else None
+          pend = Tape.current.take_pending(x, dx)
           dgeo = dict(B=B, Hs=Ho, Ws=Wo, Cs=s.n_store, Hd=H, Wd=W, Cd=Cs, R=k, S=k, stride=st, pad=pd, G=G, ks_g=s.n_store // G, n_g=Cs // G,
                       mode=1, res=pend)
-          bns = self._bns_request(x, lambda: ops.conv_gemm(gsrc, s.wt, dx, bns_query=True, **dgeo))
-          ops.conv_gemm(gsrc, s.wt, dx, bns=bns, **dgeo)
-          if bns is not None:
-            self._bn_pre[_key(x)] = (bns['partial'], bns['nrows'], dx)
+          ops.conv_gemm(gsrc, s.wt, dx, **dgeo)
         return dx, dres
 
       self.rec([y], [x, res], bwd)
-    return y
-
-  def head_linear(self, x, s, key, act, x_grad):
-    """A Linear of the fp32 planning head (<= 780 rows): forward, data gradient and weight gradient as three launches of the small-problem
-    batched-GEMM kernel (bgemm_ks_kernel: 32 x 32 tiles, K split over the waves of a workgroup) on the parameter as it lies in memory --
-    no split-K second stage, no slice sum, no transposed weight image."""
-    K, N = s.cin_g, s.cout
-    rows = x.numel() // K
-    w = s.weight.detach().view(N, K)
-    y = torch.empty(tuple(x.shape[:-1]) + (N,), device=x.device, dtype=F32)
-    ops.bgemm(x, w, y, M=rows, N=N, K=K, lda=K, ldb=K, ldc=N, bias=None if s.bias is None else s.bias.detach(), act=act)
-    if self.tape is not None:
-
-      def bwd(dy):
-        self.side.label = key
-        self.side.in_tail = False
-        dz = ops.act_bwd(dy, y, act) if act != ACT_NONE else dy
-
-        def param_grads():  # parameter gradients only: weight-gradient lane
-          if s.bias is not None and s.bias.requires_grad:
-            ops.colsum(dz, self.g(s.bias), rows, N, N)
-          if s.weight.requires_grad:  # dW[n][c] += sum_rows dz[row][n] * x[row][c]
-            ops.bgemm(dz, x, self.g(s.weight).view(N, K), M=N, N=K, K=rows, lda=N, ldb=K, ldc=K, a_km=True, b_km=True, beta=1.0)
-
-        self.side.run(Tape.current, param_grads, dz, x)
-        if not x_grad:
-          return None
-        dx = torch.empty(x.shape, device=x.device, dtype=F32)
-        ops.bgemm(dz, w, dx, M=rows, N=K, K=N, lda=N, ldb=K, ldc=K, b_km=True)
-        return dx
-
-      self.rec([y], [x], bwd)
     return y
 
   def linear(self, x, key, act=ACT_NONE, res=None, x_grad=True, out_f32=False):
@@ -1195,39 +1071,11 @@ class Engine:
     if self.tape is not None:
 
       def bwd(dy):
-        if not _LN_CHECK and _LN_SIDE:  # dx alone on the dY chain; dgamma / dbeta only feed the optimizer: weight-gradient lane
-          dx = ops.layernorm_bwd(dy, x, ln.weight.detach(), mean, rstd, None, None)
-          self.side.label = 'layernorm'
-          self.side.in_tail = False
-          self.side.run(Tape.current, lambda: ops.layernorm_param_grad(dy, x, mean, rstd, self.g(ln.weight), self.g(ln.bias)), dy, x)
-          return dx
-        if not _LN_CHECK:
-          return ops.layernorm_bwd(dy, x, ln.weight.detach(), mean, rstd, self.g(ln.weight), self.g(ln.bias))
-        # debugging aid (tools/replay_bisect.py): hash every operand before and after the kernel, and run the kernel twice
-        gam = ln.weight.detach()
-        for nme, t in (('dy', dy), ('x', x), ('mean', mean), ('rstd', rstd), ('gamma', gam)):
-          ops.node_hash(t, f'LN before {nme}')
-        keep = x.shape[-1] == 1512 and x.dtype == torch.bfloat16 and LN_KEEP.get('armed', True)
-        if keep:
-          for nme in ('dbg1', 'dbg2'):
-            if nme not in LN_KEEP:
-              LN_KEEP[nme] = ops.zeros((x.numel() // x.shape[-1], 6), F32, x.device)
-          ops.lib.tfpp_debug_ln_buffer(ops.ptr(LN_KEEP['dbg1']))
-        dx = ops.layernorm_bwd(dy, x, gam, mean, rstd, self.g(ln.weight), self.g(ln.bias))
-        ops.node_hash(dx, 'LN dx first run')
-        for nme, t in (('dy', dy), ('x', x), ('mean', mean), ('rstd', rstd), ('gamma', gam)):
-          ops.node_hash(t, f'LN after {nme}')
-        if keep:
-          ops.lib.tfpp_debug_ln_buffer(ops.ptr(LN_KEEP['dbg2']))
-        dx2 = ops.layernorm_bwd(dy, x, gam, mean, rstd, None, None)
-        ops.node_hash(dx2, 'LN dx second run')
-        ops.node_hash(dx, 'LN dx first run, hashed again')
-        if x.shape[-1] == 1512 and x.dtype == torch.bfloat16 and LN_KEEP.get('armed', True):  # first C = 1512 LayerNorm of the backward pass: keep both results
-          LN_KEEP['armed'] = False
-          for nme, t in (('dx1', dx), ('dx2', dx2), ('dy', dy)):
-            if nme not in LN_KEEP:
-              LN_KEEP[nme] = torch.empty_like(t)  # (allocated by the eager warm-up step, i.e. outside the capture)
-            ops.copy_rows(t, LN_KEEP[nme], 1, t.numel(), 0, 0, 0, 0)
+        # dx alone on the dY chain; dgamma / dbeta only feed the optimizer: weight-gradient lane
+        dx = ops.layernorm_bwd(dy, x, ln.weight.detach(), mean, rstd, None, None)
+        self.side.label = 'layernorm'
+        self.side.in_tail = False
+        self.side.run(Tape.current, lambda: ops.layernorm_param_grad(dy, x, mean, rstd, self.g(ln.weight), self.g(ln.bias)), dy, x)
         return dx
 
       self.rec([y], [x], bwd)
@@ -1236,8 +1084,6 @@ class Engine:
   def add_layernorm(self, a, b, p_drop, ln):
     """LayerNorm(a + dropout(b)) where the sum has no other consumer (post-norm decoder layers): one launch forward, one on the dY chain in
     backward (+ the parameter gradients on the weight-gradient lane) instead of two and three."""
-    if not _ADD_LN:
-      return self.layernorm(self.add(a, b, p_drop), ln)
     p = p_drop if self.training else 0.0
     seed = self.next_seed() if p > 0 else 0
     y, s, mean, rstd = ops.add_layernorm_fwd(a, b, ln.weight.detach(), ln.bias.detach(), ln.eps, p, seed, save=self.tape is not None)
@@ -1306,7 +1152,7 @@ class Engine:
       lse = torch.empty(B * nh * tq, device=dev, dtype=F32) if self.tape is not None else None
       ops.attn_fwd(q, k, v, O, lse, p_drop=p, seed=seed, **geo)
       return O, ('fused', lse, O), None, (p, seed)
-    if _SMALL_ATTN and ops.small_attn_supported(tq, tk, d, dt_):  # the planning decoder: one launch per attention (csrc/head_kernels.hip)
+    if ops.small_attn_supported(tq, tk, d, dt_):  # the planning decoder: one launch per attention (csrc/head_kernels.hip)
       O = torch.empty((B, tq, out_ld), device=dev, dtype=dt_)
       P = torch.empty((B, nh, tq, tk), device=dev, dtype=dt_)
       ops.small_attn_fwd(q, k, v, O, P, B=B, nh=nh, tq=tq, tk=tk, d=d, ld_q=ld_q, ld_kv=ld_kv, ld_o=out_ld, scale=scale, p_drop=p, seed=seed)
@@ -1359,26 +1205,16 @@ class Engine:
     B, H, W, C = x.shape
     w1, b1 = se.fc1.weight.detach().view(se.fc1.weight.shape[0], C), se.fc1.bias.detach()
     w2, b2 = se.fc2.weight.detach().view(C, -1), se.fc2.bias.detach()
-    fused = SE_FUSED and ops.se_fused_supported(C, w1.shape[0])  # one launch per direction after the pooling pass (stages 1-3)
-    if fused:
-      pool, hidden, gate = ops.se_fwd_fused(x, w1, b1, w2, b2)
-    else:
-      pool = ops.mean_hw(x)
-      hidden, gate = ops.se_gate_fwd(pool, w1, b1, w2, b2)
+    pool = ops.mean_hw(x)
+    hidden, gate = ops.se_gate_fwd(pool, w1, b1, w2, b2)
     y = ops.affine_act(x, gate=gate, rows_per_batch=H * W)
     if self.tape is not None:
 
       def bwd(dy):
-        if fused:
-          gd, dz1, dpool = ops.se_bwd_fused(dy, x, gate, hidden, w1, w2)
-          # the gate MLP's parameter gradients only feed the optimizer: weight-gradient lane
-          self.side.run(Tape.current, lambda: ops.se_param_grads(gd, dz1, hidden, pool, self.g(se.fc1.weight), self.g(se.fc1.bias),
-                                                                 self.g(se.fc2.weight), self.g(se.fc2.bias)), gd, dz1, hidden, pool)
-        else:
-          dgate = ops.se_dgate(dy, x)
-          dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
-                                  self.g(se.fc2.weight), self.g(se.fc2.bias))
-        info = self._bn_of.get(_key(x)) if (FUSE_BN_BWD >= 1 and x.dtype == torch.bfloat16) else None
+        dgate = ops.se_dgate(dy, x)
+        dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
+                                self.g(se.fc2.weight), self.g(se.fc2.bias))
+        info = self._bn_of.get(_key(x)) if x.dtype == torch.bfloat16 else None
         if info is not None and info[2] and Tape.current.is_last_contribution(x):
           # x = relu(BN(raw)) of conv2: this IS its complete gradient -> emit the BatchNorm-backward sums in the same pass
           sL, rawL, _ = info
@@ -1532,19 +1368,13 @@ class Engine:
       n = r1 - r0
 
       def gw(dz, xin):
-        if _HEAD_BGEMM in (1, 2):  # dW[r0:r1][c] += sum_rows dz[row][n] * x[row][c]
-          ops.bgemm(dz, xin, self.g(w)[r0:r1], M=n, N=dm, K=rows, lda=n, ldb=dm, ldc=dm, a_km=True, b_km=True, beta=1.0)
-        else:
-          ops.conv_wgrad(dz, xin, self.g(w)[r0:r1], B=rows, Hs=1, Ws=1, Cs=dm, Hd=1, Wd=1, Cd=n, c_real=dm, dw_ld=dm)
+        ops.conv_wgrad(dz, xin, self.g(w)[r0:r1], B=rows, Hs=1, Ws=1, Cs=dm, Hd=1, Wd=1, Cd=n, c_real=dm, dw_ld=dm)
 
       def gb(dz):
         ops.colsum(dz, self.g(b)[r0:r1], rows, n, n)
 
       y = torch.empty((rows, n), device=inp.device, dtype=F32)
-      if _HEAD_BGEMM in (1, 3):
-        ops.bgemm(inp, wd[r0:r1], y, M=rows, N=n, K=dm, lda=dm, ldb=dm, ldc=n, bias=bd[r0:r1])
-      else:
-        ops.conv_gemm(inp, wd[r0:r1], y, B=rows, Hs=1, Ws=1, Cs=dm, Hd=1, Wd=1, Cd=n, shift=bd[r0:r1])
+      ops.conv_gemm(inp, wd[r0:r1], y, B=rows, Hs=1, Ws=1, Cs=dm, Hd=1, Wd=1, Cd=n, shift=bd[r0:r1])
       if self.tape is not None:
 
         def bwd(dy):
@@ -1636,12 +1466,8 @@ class Engine:
     bb = m.backbone
     out = {}
     self._bn_of, self._bn_pre = {}, {}
-    if self.tape is not None:
-      self.side.wplan.begin_pass()
-      self.tape.on_finish = self.side.wplan.end_pass
     if ops.NODE_HASH['on'] and self.tape is not None:
       ops.node_hash_begin(dev)
-      LN_KEEP['armed'] = True
     if self.tape is not None:
       self.tape.on_accumulate = lambda key: self._bn_pre.pop(key, None)  # a "complete" gradient got another addend: sums are stale
     self.lanes.begin(dev)
@@ -1666,13 +1492,9 @@ class Engine:
       xi = self.conv(xi, 'backbone.image_encoder.stem', act=ACT_RELU, x_grad=False)
       for i in range(4):
         xi = self.stage(xi, f'backbone.image_encoder.s{i + 1}', bb.image_encoder[f's{i + 1}'])
-        if i == 2 and self.tape is not None:
-          self.tape.mark()
       xl = xi
     elif self.bev:  # team_code/bev_encoder.py:146-233
       xi, xl = self.bev_runner.forward(xi, lidar_bev.float().contiguous())
-      if self.tape is not None:
-        self.tape.mark()  # every backbone.* parameter of this configuration is "late" (finishes_early): the first backward segment is the heads
     else:
       lidar_in = lidar_bev.float().contiguous()
       lanes.hold(lidar_in)
@@ -1695,7 +1517,7 @@ class Engine:
           lt = self.pool_tokens(xl, cfg.lidar_vert_anchors, cfg.lidar_horz_anchors)
           lt = self.conv(lt, f'backbone.lidar_channel_to_img.{i}')
           lt = lt.view(B, nt * lt.shape[1], lt.shape[2], lt.shape[3])  # tokens in (t, h, w) order (transfuser.py:319)
-        if i == 0 and _TAIL_ON_MAIN and self.tape is not None and not self.video:
+        if i == 0 and self.tape is not None and not self.video:
           # backward of LiDAR stage 1 on lane 0, behind image stage 1: in the captured step lane 1 does not get to run it before the
           # weight-gradient batch in flight has drained (tools/lane_timeline.py: 2.4 ms after its inputs are ready), which delays the last
           # weight-gradient batch -- the tail of the step -- by as much
@@ -1712,8 +1534,6 @@ class Engine:
           if self.video:
             xl = xl.view(B, nt, xl.shape[1], xl.shape[2], xl.shape[3])
         xi = self.upsample_add(io, xi)
-        if i == 2 and self.tape is not None:
-          self.tape.mark()  # everything recorded from here on only touches the "early" parameters (finishes_early)
       if self.video:  # transfuser.py:176-180: average the remaining time frames
         with lanes.fork():
           _, _, hh_, ww_, cc_ = xl.shape
@@ -1817,32 +1637,31 @@ class Engine:
 
     if self.tape is not None:
       self.tape.hoist(hoist_from, len(self.tape.nodes))  # backward walks the planning head first (Tape.hoist)
-    # BEV feature pyramid (transfuser.py:131-137) with the CenterNet and BEV-semantic heads: 64 x 64 maps, ~25 small launches -> lane 2,
-    # beside the planning head (lane 1) and the full-resolution perspective decoders (lane 0)
+    # BEV feature pyramid (transfuser.py:131-137) with the CenterNet and BEV-semantic heads: 64 x 64 maps, ~25 small launches on lane 0,
+    # beside the planning head (lane 1)
     bev = None
     out['pred_bev_semantic'] = None
     out['bb'] = None
     lanes.hold(xl)
     n_bev = len(self.tape.nodes) if self.tape is not None else 0
-    with lanes.fork(lanes.head_lane):
-      if cfg.detect_boxes or cfg.use_bev_semantic:
-        p5 = self.conv(xl, 'backbone.c5_conv', act=ACT_RELU)
-        p4 = self.upsample(p5, p5.shape[1] * cfg.bev_upsample_factor, p5.shape[2] * cfg.bev_upsample_factor)
-        p4 = self.conv(p4, 'backbone.up_conv5', act=ACT_RELU)
-        p3 = self.upsample(p4, cfg.lidar_resolution_height // cfg.bev_down_sample_factor,
-                           cfg.lidar_resolution_width // cfg.bev_down_sample_factor)
-        bev = self.conv(p3, 'backbone.up_conv4', act=ACT_RELU)
-      if cfg.use_bev_semantic:
-        y = self.conv(bev, 'bev_semantic_decoder.0', act=ACT_RELU)
-        y = self.conv(y, 'bev_semantic_decoder.2')
-        mask = m.valid_bev_pixels.detach().view(-1)
-        out['pred_bev_semantic'] = self.upsample(y, cfg.lidar_resolution_height, cfg.lidar_resolution_width, mul=mask)
-      if cfg.detect_boxes:
-        bbs = []
-        for br in m.head.BRANCHES:
-          h = self.conv(bev, f'head.{br}_head.0', act=ACT_RELU)
-          bbs.append(self.conv(h, f'head.{br}_head.2', act=ACT_SIGMOID if br == 'heatmap' else ACT_NONE))
-        out['bb'] = bbs
+    if cfg.detect_boxes or cfg.use_bev_semantic:
+      p5 = self.conv(xl, 'backbone.c5_conv', act=ACT_RELU)
+      p4 = self.upsample(p5, p5.shape[1] * cfg.bev_upsample_factor, p5.shape[2] * cfg.bev_upsample_factor)
+      p4 = self.conv(p4, 'backbone.up_conv5', act=ACT_RELU)
+      p3 = self.upsample(p4, cfg.lidar_resolution_height // cfg.bev_down_sample_factor,
+                         cfg.lidar_resolution_width // cfg.bev_down_sample_factor)
+      bev = self.conv(p3, 'backbone.up_conv4', act=ACT_RELU)
+    if cfg.use_bev_semantic:
+      y = self.conv(bev, 'bev_semantic_decoder.0', act=ACT_RELU)
+      y = self.conv(y, 'bev_semantic_decoder.2')
+      mask = m.valid_bev_pixels.detach().view(-1)
+      out['pred_bev_semantic'] = self.upsample(y, cfg.lidar_resolution_height, cfg.lidar_resolution_width, mul=mask)
+    if cfg.detect_boxes:
+      bbs = []
+      for br in m.head.BRANCHES:
+        h = self.conv(bev, f'head.{br}_head.0', act=ACT_RELU)
+        bbs.append(self.conv(h, f'head.{br}_head.2', act=ACT_SIGMOID if br == 'heatmap' else ACT_NONE))
+      out['bb'] = bbs
     out['bev'] = bev
     if dead_feats and self._frozen(m.head if cfg.detect_boxes else None, m.bev_semantic_decoder if cfg.use_bev_semantic else None):
       self._drop_dead_nodes(n_bev)

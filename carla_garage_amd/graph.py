@@ -36,8 +36,6 @@ def capture(graph, stream, pool=None):
 
 
 _CAPTURE_STREAMS = {}
-import os as _os
-_HIGH_PRIORITY_LANES = _os.environ.get('TFPP_LANE_PRIORITY', '0') == '1'  # main lanes on high-priority streams, the weight-gradient lane on a normal one (A/B switch)
 
 
 def capture_stream(device):
@@ -47,7 +45,7 @@ def capture_stream(device):
   device = torch.device(device)
   st = _CAPTURE_STREAMS.get(str(device))
   if st is None:
-    st = _CAPTURE_STREAMS[str(device)] = torch.cuda.Stream(device, priority=-1 if _HIGH_PRIORITY_LANES else 0)
+    st = _CAPTURE_STREAMS[str(device)] = torch.cuda.Stream(device)
   st.wait_stream(torch.cuda.current_stream(device))
   with torch.cuda.stream(st):
     ops.clone_scratch_for_current_stream(device)

@@ -186,135 +186,9 @@ def conv_wgrad_plan(dy, x, dw, **kw):
   return plan[0], plan[1], plan[2]
 
 
-class WgradReducePlan:
-  """Batches the second stage (slice sum) of the pixel-split weight gradients: the weight-gradient lane (engine.SideLane) issues a batch of
-  first stages, each into its OWN region of one persistent workspace, and then ONE tfpp_wgrad_reduce_multi launch for the whole batch instead
-  of one slice-sum launch per layer (213 per training step).
-
-  The launch sequence of a backward pass is static, so the plan is learned: the first pass runs every call the ordinary way and records it
-  (parameter block, slices the library chose); ``end_pass`` sizes the workspace, uploads the parameter blocks and the
-  workgroup prefix table ONCE (host -> device copies: never inside a hipGraph capture) and from then on calls are matched against the record
-  by position.  A call that does not match (other shapes, other gradient destination) invalidates the plan: the rest of that pass runs the
-  ordinary way and the next pass records again."""
-
-  SIG = ('dw', 'row_map', 'col_map', 'B', 'Hs', 'Ws', 'Cs', 'Hd', 'Wd', 'Cd', 'R', 'S', 'stride', 'pad', 'G', 'ks_g', 'n_g', 'c_real', 'x_ld', 'dy_ld',
-         'dw_ld')
-
-  def __init__(self):
-    # Measured (round 3, bs = 12 captured step, A/B on one box): one launch per fork 25.11 vs 24.50-24.57 ms/step -- 1.75 GB of slices are then
-    # summed out of HBM instead of the memory-side cache; one launch per 2 / 4 / 8 / 16 first stages 24.40-24.53 / 24.09-24.48 / 24.34-24.46 /
-    # 24.48-24.58 vs 24.39-24.41: no gain, the 213 small launches were never what bounds the weight-gradient lane.  Off by default.
-    self.enabled = _os.environ.get('TFPP_WGRAD_BATCH_REDUCE', '0') == '1'
-    self.entries = []      # recording pass: (signature, dtype, splits, reduce?, slice floats, parameter block)
-    self.ready = False
-    self.cursor = 0        # position in entries (ready) of the next call
-    self.batch_from = 0    # first reduce-entry index of the batch being issued
-    self.pending = 0       # reduce entries issued since the last flush
-    self.broken = False    # a call did not match: ordinary path until the next pass
-    self.ws = self.table = self.prefix = None
-    self.ridx = []         # entry index -> index among the reduce entries (-1: no second stage)
-    self.prefix_host = []
-    self.stats = dict(builds=0, batched=0, flushes=0, mismatches=0, ws_mb=0.0)
-    self.every = int(_os.environ.get('TFPP_WGRAD_REDUCE_EVERY', '0'))  # also flush after this many first stages (0: only at the end of a batch)
-
-  def _sig(self, p, dtype):
-    return tuple(getattr(p, f) or 0 for f in self.SIG) + (dtype,)
-
-  def begin_pass(self):
-    """Start of a forward + backward pass of the owning engine."""
-    if not self.enabled:
-      return
-    if self.broken or (not self.ready and not torch.cuda.is_current_stream_capturing()):
-      self.entries, self.ready = [], False  # record (again)
-    self.broken = False
-    self.cursor = self.batch_from = self.pending = 0
-
-  def end_pass(self):
-    """The whole backward pass has been issued (Tape._finish): a recorded pass becomes the plan -- one eager step is enough before a capture."""
-    if self.enabled and not self.ready and self.entries and not self.broken and not torch.cuda.is_current_stream_capturing():
-      self._build()
-
-  def _build(self):
-    red = [e for e in self.entries if e[3]]
-    if not red:
-      self.entries = []
-      return
-    dev = red[0][6]
-    total = sum(e[2] * e[4] for e in red)
-    self.ws = torch.empty(total, device=dev, dtype=torch.float32)
-    blocks, off, arr = [0], 0, (WgradParams * len(red))()
-    self.ridx, r = [], 0
-    for e in self.entries:
-      if not e[3]:
-        self.ridx.append(-1)
-        continue
-      self.ridx.append(r)
-      q = arr[r]
-      ctypes.memmove(ctypes.byref(q), ctypes.byref(e[5]), ctypes.sizeof(WgradParams))
-      q.splits, q.ws, q.ws_floats = e[2], self.ws.data_ptr() + 4 * off, e[2] * e[4]
-      q.dy = q.x = None  # (the second stage reads neither)
-      off += e[2] * e[4]
-      blocks.append(blocks[-1] + (e[4] + 31) // 32)
-      r += 1
-    self.regions = [(arr[i].ws, arr[i].ws_floats, arr[i].splits) for i in range(len(red))]
-    self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-    self.prefix_host = blocks
-    self.prefix = torch.tensor(blocks, dtype=torch.int64).to(dev)
-    self.ready = True
-    self.stats['builds'] += 1
-    self.stats['ws_mb'] = total * 4 / 2**20
-    self.stats['reduce_entries'], self.stats['entries'] = len(red), len(self.entries)
-
-  def call(self, p, dtype, dev):
-    """One conv_wgrad call on the weight-gradient lane.  Returns True if it was issued here."""
-    if not self.enabled or self.broken:
-      return False
-    if not self.ready:
-      if torch.cuda.is_current_stream_capturing():
-        return False  # (nothing is learned from a capture: its activations live in the graph's pool; the ordinary path is captured)
-      plan = (ctypes.c_int * 3)()
-      lib.raw('tfpp_conv_wgrad_stage')(ctypes.byref(p), dtype, -1, plan, stream())  # plan only
-      keep = WgradParams()
-      ctypes.memmove(ctypes.byref(keep), ctypes.byref(p), ctypes.sizeof(WgradParams))
-      self.entries.append((self._sig(p, dtype), dtype, int(plan[1]), bool(plan[2]), p.G * p.n_g * p.R * p.S * p.ks_g, keep, dev))
-      return False  # recorded; the caller runs it the ordinary way
-    i = self.cursor
-    if i >= len(self.entries) or self.entries[i][0] != self._sig(p, dtype):
-      self.broken = True  # another launch sequence than the recorded one
-      self.stats['mismatches'] += 1
-      return False
-    self.cursor += 1
-    r = self.ridx[i]
-    if r < 0:
-      return False  # no second stage: ordinary call
-    p.ws, p.ws_floats, p.splits = self.regions[r]
-    lib.tfpp_conv_wgrad_stage(ctypes.byref(p), dtype, 1, None, stream())
-    if self.pending == 0:
-      self.batch_from = r
-    self.pending += 1
-    self.stats['batched'] += 1
-    if self.every and self.pending >= self.every:
-      self.flush()  # (slices summed while they are still in the 256 MB memory-side cache)
-    return True
-
-  def flush(self):
-    """End of a batch of the weight-gradient lane (on its stream): the slice sums of every first stage issued since the last flush."""
-    if self.pending:
-      r0, r1 = self.batch_from, self.batch_from + self.pending
-      lib.tfpp_wgrad_reduce_multi(self.table.data_ptr() + r0 * ctypes.sizeof(WgradParams), self.prefix.data_ptr() + 8 * r0, r1 - r0,
-                                  self.prefix_host[r0], self.prefix_host[r1] - self.prefix_host[r0], stream())
-      self.pending = 0
-      self.stats['flushes'] += 1
-
-
-WGRAD_PLAN = None  # the plan of the weight-gradient lane whose batch is being issued (engine.SideLane.flush)
-
-
 def conv_wgrad(dy, x, dw, **kw):
   p = _wgrad_params(dy, x, dw, **kw)
   B, Hd, Wd, Hs, Ws, G, R, S, stride = p.B, p.Hd, p.Wd, p.Hs, p.Ws, p.G, p.R, p.S, p.stride
-  if WGRAD_PLAN is not None and lib.profiler is None and WGRAD_PLAN.call(p, dt(dy), dy.device):
-    return dw
   if lib.profiler is not None:  # one profiled call per kernel: first stage and slice sum are timed separately
     plan = (ctypes.c_int * 3)()
     lib.raw('tfpp_conv_wgrad_stage')(ctypes.byref(p), dt(dy), -1, plan, stream())  # plan only: no launch, not timed
@@ -518,6 +392,19 @@ def bn_scratch(c, device, min_floats=0):
 
 _STATS_ROWS = {}
 _REDUCE_SCRATCH = {}
+_GRIDSUM_SCRATCH = {}
+
+
+def gridsum_scratch(device):
+  """Ticket counters + partials of the fixed-order grid sums (include/tfpp.h tfpp_gridsum_scratch_floats): zero when handed out -- the kernels
+  leave the counters at zero -- and one buffer per stream, like the other scratch tables."""
+  key = _scratch_key(device)
+  buf = _GRIDSUM_SCRATCH.get(key)
+  if buf is None:
+    if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+      raise RuntimeError('the grid-sum scratch must be allocated before hipGraph capture: run one eager warm-up step first')
+    buf = _replace_scratch(_GRIDSUM_SCRATCH, key, zero_(torch.empty(lib.raw('tfpp_gridsum_scratch_floats')(), device=device, dtype=torch.float32)))
+  return buf
 
 
 STATS_ROWS_CAP = int(_os.environ.get('TFPP_BN_STATS_ROWS', '0'))  # 0: one row per M-tile (deterministic); n > 0: fold onto n rows
@@ -557,7 +444,7 @@ def clone_scratch_for_current_stream(device):
   exists (and the statistics rows are zeroed) before the capture begins -- nothing is allocated, zero-filled or grown inside it."""
   dev = str(torch.device(device))
   key = _scratch_key(device)
-  for table, zeroed in ((_SPLITK_WS, False), (_BN_SCRATCH, False), (_STATS_ROWS, True), (_REDUCE_SCRATCH, False)):
+  for table, zeroed in ((_SPLITK_WS, False), (_BN_SCRATCH, False), (_STATS_ROWS, True), (_REDUCE_SCRATCH, False), (_GRIDSUM_SCRATCH, True)):
     sizes = [buf.numel() for (d, _), buf in table.items() if d == dev]
     if not sizes:
       continue
@@ -683,39 +570,6 @@ def se_gate_fwd(pool, w1, b1, w2, b2):
   return hidden, gate
 
 
-def se_fused_supported(c, rd):
-  return bool(lib.raw('tfpp_se_fused_supported')(c, rd))
-
-
-def se_fwd_fused(x, w1, b1, w2, b2):
-  """pool, hidden, gate of a squeeze-excite block: the pooling pass + ONE per-sample launch (tfpp_se_fwd_fused)."""
-  b, h, w, c = x.shape
-  rd = w1.shape[0]
-  pool = torch.empty((b, c), device=x.device, dtype=torch.float32)
-  hidden = torch.empty((b, rd), device=x.device, dtype=torch.float32)
-  gate = torch.empty((b, c), device=x.device, dtype=torch.float32)
-  lib.tfpp_se_fwd_fused(ptr(_chk(x)), ptr(reduce_scratch(b, c, x.device)), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(pool), ptr(hidden), ptr(gate),
-                        b, h * w, c, rd, dt(x), stream())
-  return pool, hidden, gate
-
-
-def se_bwd_fused(dy, x, gate, hidden, w1, w2):
-  """(gd, dz1, dpool): the dy*x pooling pass + ONE per-sample launch; gd / dz1 feed se_param_grads."""
-  b, h, w, c = x.shape
-  rd = hidden.shape[1]
-  gd = torch.empty_like(gate)
-  dz1 = torch.empty_like(hidden)
-  dpool = torch.empty_like(gate)
-  lib.tfpp_se_bwd_fused(ptr(_chk(dy)), ptr(_chk(x)), ptr(reduce_scratch(b, c, x.device)), ptr(gate), ptr(hidden), ptr(w1), ptr(w2), ptr(gd), ptr(dz1),
-                        ptr(dpool), b, h * w, c, rd, dt(x), stream())
-  return gd, dz1, dpool
-
-
-def se_param_grads(gd, dz1, hidden, pool, dw1, db1, dw2, db2):
-  b, c = gd.shape
-  lib.tfpp_se_param_grads(ptr(gd), ptr(dz1), ptr(hidden), ptr(pool), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), b, c, hidden.shape[1], stream())
-
-
 def se_dgate(dy, x):
   b, h, w, c = x.shape
   out = torch.empty((b, c), device=x.device, dtype=torch.float32)
@@ -814,14 +668,16 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, save=True):
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
   c = x.shape[-1]
   dx = torch.empty_like(x)
-  lib.tfpp_layernorm_bwd(ptr(_chk(dy)), ptr(_chk(x)), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
+  scratch = gridsum_scratch(x.device) if (dgamma is not None or dbeta is not None) else None
+  lib.tfpp_layernorm_bwd(ptr(_chk(dy)), ptr(_chk(x)), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(scratch),
                          x.numel() // c, c, dt(x), stream())
   return dx
 
 
 def layernorm_param_grad(dy, x, mean, rstd, dgamma, dbeta):
   c = x.shape[-1]
-  lib.tfpp_layernorm_param_grad(ptr(_chk(dy)), ptr(_chk(x)), ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), x.numel() // c, c, dt(x), stream())
+  lib.tfpp_layernorm_param_grad(ptr(_chk(dy)), ptr(_chk(x)), ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), ptr(gridsum_scratch(x.device)),
+                                x.numel() // c, c, dt(x), stream())
 
 
 def add_layernorm_fwd(a, b, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, save=True):
@@ -840,8 +696,9 @@ def add_layernorm_bwd(dy, s, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, seed=
   """Returns (d_sum, d_b): the gradients of a and b in LayerNorm(a + dropout(b))."""
   c = s.shape[-1]
   ds, db = torch.empty_like(s), torch.empty_like(s)
-  lib.tfpp_add_layernorm_bwd(ptr(_chk(dy)), ptr(_chk(s)), ptr(gamma), ptr(mean), ptr(rstd), ptr(ds), ptr(db), ptr(dgamma), ptr(dbeta), s.numel() // c, c,
-                             p_drop, seed, ptr(SEED_OFFSET), dt(s), stream())
+  scratch = gridsum_scratch(s.device) if (dgamma is not None or dbeta is not None) else None
+  lib.tfpp_add_layernorm_bwd(ptr(_chk(dy)), ptr(_chk(s)), ptr(gamma), ptr(mean), ptr(rstd), ptr(ds), ptr(db), ptr(dgamma), ptr(dbeta), ptr(scratch),
+                             s.numel() // c, c, p_drop, seed, ptr(SEED_OFFSET), dt(s), stream())
   return ds, db
 
 
@@ -1084,13 +941,13 @@ def gru_bwd(dout, save, h0, w_hh, b_hh, w_dec, dw_hh, db_hh, dw_dec, db_dec, def
 def ce_loss(pred, label, loss_out, ws, *, rows, C, ld, HW, class_weight=None, vis_mask=None, pix_weight=None, pw_bstride=0,
             denom=None, denom_eps=0.0, weight=1.0, dpred=None, smoothing=0.0):
   lib.tfpp_ce_loss(ptr(pred), ptr(label), ptr(class_weight), ptr(vis_mask), ptr(pix_weight), pw_bstride, HW, ptr(denom), denom_eps,
-                   weight, ptr(loss_out), ptr(dpred), ptr(ws), rows, C, ld, float(smoothing), dt(pred), stream())
+                   weight, ptr(loss_out), ptr(dpred), ptr(ws), ptr(gridsum_scratch(pred.device)), rows, C, ld, float(smoothing), dt(pred), stream())
 
 
 def reg_loss(pred, target, loss_out, *, B, C, HW, ld, kind, elem_weight=None, wC=1, w_bcast=False, denom=None, denom_eps=0.0,
              denom_mul=1.0, weight=1.0, dpred=None):
   lib.tfpp_reg_loss(ptr(pred), ptr(target), ptr(elem_weight), wC, int(w_bcast), ptr(denom), denom_eps, denom_mul, weight,
-                    ptr(loss_out), ptr(dpred), B, C, HW, ld, kind, dt(pred), stream())
+                    ptr(loss_out), ptr(dpred), ptr(gridsum_scratch(pred.device)), B, C, HW, ld, kind, dt(pred), stream())
 
 
 def adamw_amsgrad(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, no_decay_bits=None):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TFPP_ABI_VERSION 2
+#define TFPP_ABI_VERSION 3
 #define TFPP_EINVAL (-1000)
 #define TFPP_F32 0
 #define TFPP_BF16 1
@@ -127,13 +127,6 @@ typedef struct {
   int64_t ws_floats;
 } tfpp_wgrad_params;
 int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stream);
-/* The second stage (slice sum) of MANY tfpp_conv_wgrad calls in one launch: the caller issues the first stages with
- * tfpp_conv_wgrad_stage(p, dtype, 1, ...) giving every call its OWN workspace region and an explicit `splits`, keeps a device copy of
- * those parameter blocks (descs_dev[n]) and the running sum blk_prefix_dev[n + 1] of ceil(G*n_g*R*S*ks_g / 32) workgroups per call, and
- * sums any contiguous range of calls [i0, i1) with base = blk_prefix[i0], blocks = blk_prefix[i1] - blk_prefix[i0].  Per element the same
- * arithmetic whatever the batching. */
-int tfpp_wgrad_reduce_multi(const tfpp_wgrad_params* descs_dev, const int64_t* blk_prefix_dev, int n, int64_t base, int64_t blocks,
-                            void* stream);
 /* Preferred workspace of one call in bytes (the library never allocates): the size at which the dispatcher's plan is not
  * limited by the workspace.  op 0: split-K slices of tfpp_conv_gemm (params = tfpp_conv_params, field splitk_ws); op 1: pixel slices of
  * tfpp_conv_wgrad (params = tfpp_wgrad_params, field ws); op 2 / 3: BatchNorm / column-sum scratch for C = *(const int*)params channels.
@@ -344,17 +337,6 @@ int tfpp_se_dgate(const void* dy, const void* x, float* dgate, float* scratch, i
 int tfpp_se_gate_bwd(const float* dgate, const float* gate, const float* hidden, const float* pool, const float* w1,
                      const float* w2, float* dz1_scratch /* [B*RD] */, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
                      int B, int C, int RD, void* stream);
-/* Squeeze-excite gate with the second stage of the pooling reduction, fc1 + ReLU and fc2 + sigmoid in ONE launch per sample after the pooling
- * pass (timm SEModule as RegNetY uses it, oracle/timm_regnet.py; replaces tfpp_mean_hw + tfpp_se_gate_fwd where tfpp_se_fused_supported(C, RD)),
- * and its backward: tfpp_se_dgate + the data half of tfpp_se_gate_bwd in one launch (gd = dgate g (1 - g) [B, C] and dz1 [B, RD] are written
- * out), the parameter gradients in tfpp_se_param_grads (single writer per element, accumulating).  scratch: tfpp_reduce_scratch_floats(B, C). */
-int tfpp_se_fused_supported(int C, int RD);
-int tfpp_se_fwd_fused(const void* x, float* scratch, const float* w1, const float* b1, const float* w2, const float* b2, float* pool,
-                      float* hidden, float* gate, int B, int HW, int C, int RD, int dtype, void* stream);
-int tfpp_se_bwd_fused(const void* dy, const void* x, float* scratch, const float* gate, const float* hidden, const float* w1, const float* w2,
-                      float* gd, float* dz1, float* dpool, int B, int HW, int C, int RD, int dtype, void* stream);
-int tfpp_se_param_grads(const float* gd, const float* dz1, const float* hidden, const float* pool, float* dw1, float* db1, float* dw2, float* db2,
-                        int B, int C, int RD, void* stream);
 int tfpp_se_bwd_apply(const void* dy, const float* gate, const float* dpool, void* dx, int B, int HW, int C, int dtype, void* stream);
 /* se_bwd_apply with the BatchNorm-backward statistics of the preceding layer fused in (conv2 of a RegNet bottleneck: dx is the
  * complete gradient of y = relu(BN(x))): also writes tfpp_se_bwd_apply_bns_rows(B, HW, C, dtype) rows [2*C] of (sum g, sum g*xhat),
@@ -418,19 +400,25 @@ int tfpp_window_bias_grad(const void* ds, const int32_t* rel_index, float* dtabl
  *   dP = dPd*mask; dS = alpha * P .* (dP - sum_j dP_j P_j).  Dropout masks are regenerated from (seed, index). */
 int tfpp_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int C,
                        float eps, int dtype, void* stream);
+/* Grid-wide sums of the kernels below (LayerNorm parameter gradients, loss sums, the cross-entropy normaliser) are added in a FIXED order by
+ * the workgroup that finishes last -- no fp32 atomics, so a training step is bit-reproducible -- through `scratch`:
+ * tfpp_gridsum_scratch_floats() floats that are ZERO before the first use (the kernels leave the ticket counters at zero) and are not shared
+ * by launches that may run concurrently (one buffer per stream). */
+int tfpp_gridsum_scratch_floats(void);
+/* layernorm_bwd: dgamma / dbeta nullable (dx only: scratch may then be NULL too) */
 int tfpp_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
-                       float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
+                       float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int dtype, void* stream);
 /* layernorm_param_grad: the dgamma / dbeta part of layernorm_bwd alone (the engine runs it on the weight-gradient lane).
  * add_layernorm_fwd: sum = a + dropout(b) and y = LayerNorm(sum) in one launch -- the post-norm residual step of
  *   nn.TransformerDecoderLayer (model.py:137-143); dropout mask of tfpp_add_dropout (seed, flat element index).
  * add_layernorm_bwd: d_sum = LayerNorm backward (= gradient of a) and d_b = d_sum * the same mask, one launch. */
-int tfpp_layernorm_param_grad(const void* dy, const void* x, const float* mean, const float* rstd, float* dgamma, float* dbeta, int64_t rows,
-                              int C, int dtype, void* stream);
+int tfpp_layernorm_param_grad(const void* dy, const void* x, const float* mean, const float* rstd, float* dgamma, float* dbeta, float* scratch,
+                              int64_t rows, int C, int dtype, void* stream);
 int tfpp_add_layernorm_fwd(const void* a, const void* b, void* sum, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                            int64_t rows, int C, float eps, float p_drop, uint64_t seed, const uint64_t* seed_offset, int dtype, void* stream);
 int tfpp_add_layernorm_bwd(const void* dy, const void* sum, const float* gamma, const float* mean, const float* rstd, void* d_sum, void* d_b,
-                           float* dgamma, float* dbeta, int64_t rows, int C, float p_drop, uint64_t seed, const uint64_t* seed_offset,
-                           int dtype, void* stream);
+                           float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, float p_drop, uint64_t seed,
+                           const uint64_t* seed_offset, int dtype, void* stream);
 int tfpp_softmax_fwd(void* x, void* pd, int64_t rows, int cols, int64_t ld, float alpha, float p_drop, uint64_t seed, const uint64_t* seed_offset, int dtype,
                      void* stream);
 int tfpp_softmax_bwd(const void* p, void* dp_inout, int64_t rows, int cols, int64_t ld, float alpha, float p_drop, uint64_t seed, const uint64_t* seed_offset,
@@ -462,9 +450,6 @@ int tfpp_fill_bytes(void* p, int value, int64_t bytes, void* stream); /* hipMems
 /* debugging aid (tools/replay_bisect.py, TFPP_DEBUG_NODE_HASH): *slot += an order-independent 64-bit hash of the 32-bit words of
  * p[0, bytes) (bytes a multiple of 4; integer adds only, so equal bytes always give equal sums whatever the block order). */
 int tfpp_hash_words(const void* p, int64_t bytes, uint64_t* slot, void* stream);
-/* debugging aid: the next tfpp_layernorm_bwd launch also writes {c1, c2, mean, rstd, bits of the wave's MODE register, bits of HW_ID} per
- * row into buf ([rows][6] floats); NULL disarms. */
-int tfpp_debug_ln_buffer(float* buf);
 /* debugging aid (tools/lane_timeline.py): *slot = wall_clock64() (100 MHz) at the time this launch runs on its stream. */
 int tfpp_stamp(uint64_t* slot, void* stream);
 
@@ -506,16 +491,17 @@ int tfpp_gru_bwd_partial_floats(int B, int H); /* returns the count (not an erro
  * ce_loss: class-weighted cross entropy, mean over non-ignored rows (label -1, or vis_mask[pix]==0: the BEV
  *   visibility trick model.py:427-429); with pix_weight the per-row loss is multiplied by
  *   pix_weight[(row/HW)*pw_bstride + row%HW] and divided by (*denom + denom_eps) instead (center_net.py:109).
+ * ws: 2 floats (the normaliser sum_rows w[y] of the unweighted-pixel form); scratch: tfpp_gridsum_scratch_floats(), see tfpp_layernorm_bwd.
  * reg_loss: kind 0 L1, 1 smooth-L1, 2 gaussian focal; logical element (b,c,pix): pred[(b*HW+pix)*ld+c],
  *   target[(b*C+c)*HW+pix], elem_weight[(b*wC+(w_bcast?0:c))*HW+pix]; denominator (*denom+denom_eps)*denom_mul or B*C*HW. */
 int tfpp_ce_loss(const void* pred, const int64_t* label, const float* class_weight, const float* vis_mask, const float* pix_weight,
                  int64_t pw_bstride, int64_t HW, const float* denom, float denom_eps, float weight, float* loss_out, void* dpred,
-                 float* ws, int64_t rows, int C, int ld, float label_smoothing, int dtype, void* stream);
+                 float* ws, float* scratch, int64_t rows, int C, int ld, float label_smoothing, int dtype, void* stream);
 /* label_smoothing a in [0, 1) (nn.CrossEntropyLoss(weight, label_smoothing=a), model.py:252-265; not with pix_weight): per row
  * (1 - a) w[y] nll(y) + a / C sum_c w[c] nll(c), normalised by sum_rows w[y]. */
 int tfpp_reg_loss(const void* pred, const float* target, const float* elem_weight, int wC, int w_bcast, const float* denom,
-                  float denom_eps, float denom_mul, float weight, float* loss_out, void* dpred, int B, int C, int64_t HW, int64_t ld,
-                  int kind, int dtype, void* stream);
+                  float denom_eps, float denom_mul, float weight, float* loss_out, void* dpred, float* scratch, int B, int C, int64_t HW,
+                  int64_t ld, int kind, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.AdamW(amsgrad=True) (train.py:529-531) over a flat fp32 arena; g is scaled by grad_scale

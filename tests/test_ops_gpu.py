@@ -141,91 +141,6 @@ def test_conv_fwd_dgrad_wgrad(ops, case, dtype):
   _conv_case(ops, case, dtype)
 
 
-@pytest.mark.parametrize('dtype', DTYPES)
-def test_batched_slice_sums_equal_the_per_call_second_stage(ops, dtype):
-  """ops.WgradReducePlan (the weight-gradient lane's batching of the slice sums): pass 0 is recorded and runs every call the ordinary way;
-  passes 1-3 issue the first stages into their own workspace regions and ONE tfpp_wgrad_reduce_multi per batch -- in batches of different
-  sizes.  Same gradients (to summation-order rounding against pass 0, bit-identical among the batched passes whatever the batching), gradient
-  destinations accumulated into, and a call sequence that differs from the record falls back to the ordinary path."""
-  cases = [  # B, H, W, Cin, Cout, k, stride, G
-      (4, 32, 64, 72, 72, 1, 1, 1), (2, 24, 40, 72, 72, 3, 1, 3), (2, 16, 64, 216, 216, 1, 1, 1), (2, 18, 20, 48, 48, 3, 2, 2),
-      (2, 12, 40, 32, 32, 3, 1, 1), (300, 1, 1, 72, 72, 1, 1, 1), (1, 8, 80, 1512, 1512, 1, 1, 1), (3, 16, 16, 64, 256, 1, 1, 1)]
-  probs = []
-  for i, (B, H, W, Cin, Cout, k, st, G) in enumerate(cases):
-    pad = k // 2
-    Ho, Wo = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
-    x = dev(rnd(B, H, W, Cin, dtype=dtype, seed=300 + i), dtype)
-    dy = dev(rnd(B, Ho, Wo, Cout, dtype=dtype, seed=400 + i), dtype)
-    dw = torch.zeros((Cout, Cin // G, k, k), device=DEV, dtype=torch.float32)
-    probs.append((dy, x, dw, dict(B=B, Hs=H, Ws=W, Cs=Cin, Hd=Ho, Wd=Wo, Cd=Cout, R=k, S=k, stride=st, pad=pad, G=G)))
-  plans = [ops.conv_wgrad_plan(dy, x, dw, **geo) for dy, x, dw, geo in probs]
-  assert sum(1 for pl in plans if pl[2]) >= 5 and len({pl[0] for pl in plans}) >= 2, plans  # several kernels, most with a second stage
-  plan = ops.WgradReducePlan()
-  plan.enabled, plan.every = True, 0   # (off by default in the engine: measured neutral to slower, see ops.WgradReducePlan)
-
-  def run_pass(batches, fill, order=None):
-    plan.begin_pass()
-    for _, _, dw, _ in probs:
-      dw.fill_(fill)
-    todo = list(order if order is not None else range(len(probs)))
-    for nb in batches:
-      ops.WGRAD_PLAN = plan
-      try:
-        for j in todo[:nb]:
-          dy, x, dw, geo = probs[j]
-          ops.conv_wgrad(dy, x, dw, **geo)
-        plan.flush()
-      finally:
-        ops.WGRAD_PLAN = None
-      todo = todo[nb:]
-    plan.end_pass()
-    torch.cuda.synchronize()
-    return [dw.clone() for _, _, dw, _ in probs]
-
-  ref = run_pass([len(probs)], 0.0)            # recorded, ordinary path; end_pass turns the record into the plan
-  assert plan.ready and len(plan.entries) == len(probs) and plan.stats['batched'] == 0
-  got1 = run_pass([len(probs)], 0.0)           # one batch
-  assert plan.cursor == len(probs) and plan.stats['batched'] == plan.stats['reduce_entries']
-  got2 = run_pass([3, 1, 4], 0.0)              # three batches
-  got3 = run_pass([1] * len(probs), 0.5)       # one call per batch, destinations pre-filled
-  for a, b1, b2, b3 in zip(ref, got1, got2, got3):
-    scale = float(a.abs().max())
-    assert float((a - b1).abs().max()) <= 2e-5 * scale + 1e-6
-    assert torch.equal(b1, b2)
-    assert float((b3 - 0.5 - b1).abs().max()) <= 2e-6 * scale + 1e-6
-  # another call sequence than the recorded one: ordinary path for the rest of the pass, then the plan is learned again
-  got4 = run_pass([len(probs)], 0.0, order=[1, 0] + list(range(2, len(probs))))
-  assert plan.broken
-  for a, b in zip(ref, got4):
-    assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-6
-  run_pass([len(probs)], 0.0)
-  assert plan.ready and not plan.broken and len(plan.entries) == len(probs) and plan.stats['builds'] == 2
-  got5 = run_pass([4, 4], 0.0)
-  for b1, b5 in zip(got1, got5):
-    assert torch.equal(b1, b5)
-
-
-# The shapes the benchmark (BASELINE config 3: bs = 12, bf16) actually runs, with the kernel variants it runs them on.
-# tfpp_conv_gemm_variant: 202 = 16-wave 256x128 LDS-DMA ring (K >= 1024, >= 128 tiles), 200 = 8-wave 128x128 (>= 256 tiles), 201 = 64x128,
-# 2 = LDS-staged 64x64 ...  (210 + i = the opt-in ping-pong GEMM of round 4: tests below)
-# weight-gradient plan {variant, slices, second stage}: see tfpp_conv_wgrad_stage.
-TRUE_SHAPES = [
-    # name, B, H, W, Cin, Cout, k, stride, groups, expected forward variant, expected dgrad variant
-    (('fusion_mlp_fc1', 3840, 1, 1, 1512, 6048, 1, 1, 1), 202, 202),   # transfuser.py:392 at C = 1512: 3840 x 6048 x 1512
-    (('fusion_mlp_fc2', 3840, 1, 1, 6048, 1512, 1, 1, 1), 202, 202),
-    (('fusion_proj', 3840, 1, 1, 1512, 1512, 1, 1, 1), 202, 202),      # attention projection / QKV slices: 3840 x 1512 x 1512
-    (('fusion576_mlp_fc1', 3840, 1, 1, 576, 2304, 1, 1, 1), 200, 201),  # the C = 576 transformer: K = 576 is too short for the 144 KB ring; dgrad: 150 tiles
-    (('s3_conv1x1', 12, 16, 64, 576, 576, 1, 1, 1), 200, 200),         # image stage-3 1x1 convs: M = 12288, M-major XCD order
-    (('s4_conv1x1', 12, 8, 32, 1512, 1512, 1, 1, 1), 202, 202),        # stage 4: M = 3072
-    (('lidar_s3_conv1x1', 12, 16, 16, 576, 576, 1, 1, 1), 201, 201),   # LiDAR branch: 64x128 tiles
-    (('s2_entry_g3x3_s2', 4, 64, 128, 72, 72, 3, 2, 3), 302, 302),     # first block of a RegNet stage: stride-2 grouped 3x3 on the halo kernel
-    (('s3_entry_g3x3_s2', 2, 32, 128, 216, 216, 3, 2, 9), 302, 302),   #   (forward: 17 x 65 input halo; data gradient: zero-stuffed dy)
-    (('s2_conv1x1', 12, 32, 128, 216, 216, 1, 1, 1), 200, 200),       # stage-2 1x1 convs: K = 216 = 3 x 64 + 24, the K tail of the 64-deep ring
-    (('lidar_s2_conv1x1', 12, 32, 32, 216, 216, 1, 1, 1), 201, 201),
-    (('s1_conv1x1', 2, 64, 256, 72, 72, 1, 1, 1), 4, 4),               # stage-1 1x1 conv: one 128x96 tile column instead of 3 x 32
-]
-
-
 @pytest.mark.parametrize('entry', TRUE_SHAPES, ids=[e[0][0] for e in TRUE_SHAPES])
 def test_conv_benchmark_shapes_on_the_benchmark_kernels(ops, entry):
   case, vf, vd = entry
@@ -622,41 +537,6 @@ def test_squeeze_excite(ops, dtype):
   check('se.dx', nchw(dx.float().cpu()), ps[0].grad, dtype, scale=3.0)
   for nme, g, p in zip(('dw1', 'db1', 'dw2', 'db2'), grads, ps[1:]):
     check('se.' + nme, g.cpu(), p.grad, dtype, scale=3.0)
-
-
-@pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(3, 10, 14, 72, 8), (12, 16, 64, 576, 144), (2, 8, 8, 216, 54), (12, 16, 16, 576, 144)], ids=lambda v: 'x'.join(map(str, v)))
-def test_squeeze_excite_fused(ops, dtype, shape):
-  """tfpp_se_fwd_fused / tfpp_se_bwd_fused / tfpp_se_param_grads (one launch per direction after the pooling pass) against torch, at the
-  RegNetY stage-1 / stage-2 / stage-3 shapes of both branches; the stage-4 shape must be refused (it keeps the separate kernels)."""
-  B, H, W, C, RD = shape
-  assert ops.se_fused_supported(C, RD) and not ops.se_fused_supported(1512, 378)
-  x = rnd(B, C, H, W, dtype=dtype, seed=51)
-  w1, b1, w2, b2 = rnd(RD, C, seed=52) * 0.3, rnd(RD, seed=53), rnd(C, RD, seed=54) * 0.5, rnd(C, seed=55)
-  ps = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
-  pool_ref = ps[0].mean((2, 3))
-  hid_ref = F.relu(F.linear(pool_ref, ps[1], ps[2]))
-  gate_ref = torch.sigmoid(F.linear(hid_ref, ps[3], ps[4]))
-  want = ps[0] * gate_ref.view(B, C, 1, 1)
-  xd = dev(nhwc(x), dtype)
-  pool, hidden, gate = ops.se_fwd_fused(xd, dev(w1), dev(b1), dev(w2), dev(b2))
-  check('sef.pool', pool.cpu(), pool_ref, dtype)
-  check('sef.hidden', hidden.cpu(), hid_ref, dtype)
-  check('sef.gate', gate.cpu(), gate_ref, dtype)
-  dy = rnd(B, C, H, W, dtype=dtype, seed=56)
-  want.backward(dy)
-  dyd = dev(nhwc(dy), dtype)
-  gd, dz1, dpool = ops.se_bwd_fused(dyd, xd, gate, hidden, dev(w1), dev(w2))
-  grads = [torch.full_like(dev(t), 0.25) for t in (w1, b1, w2, b2)]  # accumulating: a non-zero start must survive
-  ops.se_param_grads(gd, dz1, hidden, pool, *grads)
-  dx = ops.se_bwd_apply(dyd, gate, dpool)
-  check('sef.dx', nchw(dx.float().cpu()), ps[0].grad, dtype, scale=3.0)
-  for nme, g, p in zip(('dw1', 'db1', 'dw2', 'db2'), grads, ps[1:]):
-    check('sef.' + nme, g.cpu() - 0.25, p.grad, dtype, scale=3.0)
-  # and against the three-launch path on the same inputs (same arithmetic up to the order of the fixed-order sums)
-  pool2 = ops.mean_hw(xd)
-  hidden2, gate2 = ops.se_gate_fwd(pool2, dev(w1), dev(b1), dev(w2), dev(b2))
-  assert float((gate - gate2).abs().max()) < 1e-5 and float((hidden - hidden2).abs().max()) < 1e-4 * (1 + float(hidden2.abs().max()))
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -1376,6 +1256,58 @@ def test_zero_and_fill_bytes_are_kernels_with_exact_extent(ops):
   big = torch.full((50_000_019,), 1.0, device=DEV)
   ops.zero_(big[3:-4])
   assert float(big.sum()) == 7.0 and float(big[:3].sum()) == 3.0
+
+
+def test_grid_sums_are_bit_reproducible_and_streams_do_not_share_tickets(ops):
+  """The grid-wide sums of the loss kernels, the cross-entropy normaliser and the LayerNorm parameter gradients are added in a fixed order by
+  the workgroup that draws the last ticket (csrc/common.cuh): the results must be bit-identical launch after launch at the training sizes
+  (thousands of workgroups, all 8 XCDs), equal to a float64 sum to fp32 rounding, and two streams running the same kernels at once must not
+  disturb each other (each stream owns its scratch)."""
+  g = torch.Generator().manual_seed(7)
+  # LayerNorm parameter gradients, stage-4 fusion transformer size
+  rows, C = 3840, 1512
+  x = dev(torch.randn(rows, C, generator=g), torch.bfloat16)
+  dy = dev(torch.randn(rows, C, generator=g), torch.bfloat16)
+  mean = dev(torch.randn(rows, generator=g) * 0.1)
+  rstd = dev(torch.rand(rows, generator=g) + 0.5)
+  want_b = dy.double().sum(0)
+  want_g = (dy.double() * (x.double() - mean.double()[:, None]) * rstd.double()[:, None]).sum(0)
+  # cross entropy at the perspective-semantic size, L1 at the depth size
+  B, H, W, Cc, ld = 12, 256, 1024, 7, 8
+  pred = dev(torch.randn(B * H * W, ld, generator=g), torch.bfloat16)
+  lab = dev(torch.randint(0, Cc, (B * H * W,), generator=g))
+  cw = dev(torch.rand(Cc, generator=g) + 0.5)
+  dpred = torch.empty_like(pred)
+  tgt = dev(torch.rand(B, 1, H, W, generator=g))
+  pd1 = dev(torch.rand(B * H * W, 8, generator=g), torch.bfloat16)
+
+  def run():
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.layernorm_param_grad(dy, x, mean, rstd, dg, db)
+    loss, ws, l1 = torch.zeros(1, device=DEV), torch.zeros(2, device=DEV), torch.zeros(1, device=DEV)
+    ops.ce_loss(pred, lab, loss, ws, rows=B * H * W, C=Cc, ld=ld, HW=H * W, class_weight=cw, dpred=dpred)
+    ops.reg_loss(pd1, tgt, l1, B=B, C=1, HW=H * W, ld=8, kind=0)
+    return dg, db, loss, ws[:1].clone(), l1
+
+  first = run()
+  torch.cuda.synchronize()
+  assert float((first[0].double() - want_g).abs().max() / want_g.abs().max()) < 1e-5
+  assert float((first[1].double() - want_b).abs().max() / want_b.abs().max()) < 1e-5
+  wsum = float(cw.double()[lab].sum())
+  assert abs(float(first[3]) - wsum) / wsum < 1e-6
+  want_l1 = float((pd1[:, 0].float().double() - tgt.reshape(-1).double()).abs().mean())
+  assert abs(float(first[4]) - want_l1) / want_l1 < 1e-5
+  side = torch.cuda.Stream()
+  for it in range(25):
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      other = run()
+    again = run()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for a, b, c in zip(first, again, other):
+      assert torch.equal(a, b) and torch.equal(a, c), f'iteration {it}: a grid sum changed between launches'
+  report('grid_sums.bit_identical_repeats', 25, 'bf16')
 
 
 @pytest.mark.parametrize('smoothing', [0.0, 0.1])

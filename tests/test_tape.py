@@ -26,26 +26,20 @@ def cpu_ops(monkeypatch):
   return calls
 
 
-def _toy(tape, x, mark_after=None):
+def _toy(tape, x):
   """y = 3*a + b with a = 2*x, b = a*a (fan-out of a), z = y + x (fan-out of x); returns (z, grads dict filled by backward)."""
   got = {}
   a = 2 * x
   tape.record([a], [x], lambda d: 2 * d)
-  if mark_after == 'a':
-    tape.mark()
   b = a * a
   tape.record([b], [a], lambda d: 2 * a * d)
   y = 3 * a + b
   tape.record([y], [a, b], lambda d: (3 * d, d.clone()))
-  if mark_after == 'y':
-    tape.mark()
   z = y + x
   tape.record([z], [y, x], lambda d: (d, d))  # the same gradient object for two inputs
   tape.record([x], [], lambda d: got.__setitem__('x', d.clone()) or ())
   # the leaf node is recorded last but x is produced first: move it to the front so it is visited last in reverse order
   tape.nodes.insert(0, tape.nodes.pop())
-  if tape.split_index is not None:
-    tape.split_index += 1
   return z, got
 
 
@@ -65,19 +59,6 @@ def test_single_segment_backward_accumulates_fan_out(cpu_ops):
   assert torch.allclose(got['x'], _want(x))
   assert E.Tape.current is None and t.nodes == [] and t._grads is None
   assert cpu_ops['axpy'] + cpu_ops['add'] >= 2  # a and x each receive two contributions
-
-
-@pytest.mark.parametrize('where', ['a', 'y'])
-def test_two_segment_backward_equals_single_segment(cpu_ops, where):
-  x = torch.arange(1.0, 7.0)
-  t = E.Tape()
-  z, got = _toy(t, x, mark_after=where)
-  t.backward([(z, torch.ones_like(z))], stop_at_mark=True)
-  assert 'x' not in got and t._grads is not None and E.Tape.current is t  # first segment only: leaf not reached, state pending
-  t.backward_resume()
-  assert torch.allclose(got['x'], _want(x))
-  assert E.Tape.current is None and t._grads is None and t._rest == []
-  t.backward_resume()  # idempotent once finished
 
 
 def test_shared_gradient_object_is_not_mutated(cpu_ops):

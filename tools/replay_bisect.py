@@ -44,32 +44,6 @@ def main():
       firsts.append(int(d.nonzero()[0]))
       ever |= d
   n = len(labels)
-  from carla_garage_amd.engine import LN_KEEP
-  if 'dx1' in LN_KEEP:  # TFPP_DEBUG_LN_CHECK=1: the two results of the same LayerNorm-backward launch of the LAST replay, element by element
-    a, b = LN_KEEP['dx1'].reshape(-1, 1512).float().cpu(), LN_KEEP['dx2'].reshape(-1, 1512).float().cpu()
-    d = a != b
-    rows, cols = d.any(1).nonzero().flatten(), d.any(0).nonzero().flatten()
-    print(f'LN dx first vs second run (last replay): {int(d.sum())} elements differ in {len(rows)} rows / {len(cols)} columns; max |diff| {float((a - b).abs().max()):.3e} '
-          f'max |dx| {float(b.abs().max()):.3e}')
-    print('  rows:', rows[:40].tolist(), '... cols:', cols[:40].tolist())
-    if 'dbg1' in LN_KEEP:
-      d1, d2 = LN_KEEP['dbg1'].cpu(), LN_KEEP['dbg2'].cpu()
-      bits = lambda t: t.contiguous().view(torch.int32)
-      print('  per-row scalars {c1, c2, mean, rstd, MODE, HW_ID}: rows whose c1/c2/mean/rstd/MODE differ between the two launches:',
-            [int((bits(d1[:, j]) != bits(d2[:, j])).sum()) for j in range(5)])
-      print('  lanes disagreeing with lane 0 on c1, first launch:', sorted(set(bits(d1[:, 4]).tolist())), 'second launch:', sorted(set(bits(d2[:, 4]).tolist())))
-      dyh = LN_KEEP['dy'].reshape(-1, 1512).double().cpu()
-      gam = tr.model.backbone.transformers[3].ln_f.weight.detach().double().cpu()
-      for r in rows[:8].tolist():
-        print(f'  row {r}: host c1 = sum(dy * gamma) / C = {float((dyh[r] * gam).sum() / 1512):.9e}')
-        print(f'  row {r}: first c1 {float(d1[r, 0]):.9e} c2 {float(d1[r, 1]):.9e} MODE {int(bits(d1[r, 4:5])):#x} HW_ID {int(bits(d1[r, 5:6])):#x} | '
-              f'second c1 {float(d2[r, 0]):.9e} c2 {float(d2[r, 1]):.9e} MODE {int(bits(d2[r, 4:5])):#x} HW_ID {int(bits(d2[r, 5:6])):#x}')
-      same = [r for r in range(0, 3840, 480)]
-      for r in same:
-        print(f'  (row {r}: first c1 {float(d1[r, 0]):.9e} MODE {int(bits(d1[r, 4:5])):#x} HW_ID {int(bits(d1[r, 5:6])):#x} | second c1 {float(d2[r, 0]):.9e} MODE {int(bits(d2[r, 4:5])):#x})')
-    for r in rows[:3].tolist():
-      cc = d[r].nonzero().flatten()
-      print(f'  row {r}: {len(cc)} cols {cc[:24].tolist()} first {a[r, cc[:6]].tolist()} second {b[r, cc[:6]].tolist()}')
   print(f'events {n} (hashed {st["lo"]}..{min(st["hi"], n)}), side batch {tr.eng.side.batch}, replays {replays}: hash tables deviating {deviating}, '
         f'gradient arenas deviating {grad_dev}')
   if deviating:
