@@ -35,6 +35,8 @@ def capture(graph, stream, pool=None):
       gc.enable()
 
 
+import os as _os
+
 _CAPTURE_STREAMS = {}
 
 

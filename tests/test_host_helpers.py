@@ -81,73 +81,3 @@ def test_no_decay_bitmask_marks_whole_parameters_and_their_padding():
       want[off // 4:(off + n + 3) // 4] = 1
   assert np.array_equal(bits, want)
   assert not ops.no_decay_bitmask(slices, set(), total).any()
-
-
-def test_wgrad_reduce_plan_life_cycle_with_stubbed_launches(monkeypatch):
-  """ops.WgradReducePlan on the CPU: the kernel launches are replaced by recorders, the planner (tfpp_conv_wgrad_stage with stage = -1) is the
-  library's own host code.  Pass 0 is recorded and runs the ordinary call; end_pass turns the record into the plan; later passes issue first
-  stages only and ONE batched slice sum per flush over exactly the calls since the last flush; a call that does not match the record sends
-  the rest of the pass down the ordinary path and the next pass records again."""
-  import torch
-  from carla_garage_amd import ops
-  from carla_garage_amd._lib import lib
-  lib.load()
-  calls = []
-
-  class FakeLib:
-    profiler = None
-
-    def raw(self, name):
-      return lib.raw(name)
-
-    def tfpp_conv_wgrad(self, *a):
-      calls.append('full')
-
-    def tfpp_conv_wgrad_stage(self, p, dtype, stage, plan, stream):
-      assert stage == 1
-      calls.append(('stage1', p._obj.splits, p._obj.ws_floats))
-
-    def tfpp_wgrad_reduce_multi(self, table, prefix, n, base, blocks, stream):
-      calls.append(('multi', n, base, blocks))
-
-  monkeypatch.setattr(ops, 'lib', FakeLib())
-  monkeypatch.setattr(ops, 'splitk_workspace', lambda dev: torch.empty(1 << 22))
-  monkeypatch.setattr(ops, 'stream', lambda: 0)
-  monkeypatch.setattr(ops, 'ptr', lambda t: None if t is None else t.data_ptr())
-  monkeypatch.setattr(torch.cuda, 'is_current_stream_capturing', lambda: False)
-  shapes = [(4, 32, 64, 72, 72), (2, 16, 64, 216, 216), (300, 1, 1, 72, 72)]   # the last one needs no second stage (one slice)
-  probs = []
-  for B, H, W, Cin, Cout in shapes:
-    probs.append((torch.empty(B, H, W, Cout), torch.empty(B, H, W, Cin), torch.zeros(Cout, Cin, 1, 1), dict(B=B, Hs=H, Ws=W, Cs=Cin, Hd=H, Wd=W, Cd=Cout)))
-  plan = ops.WgradReducePlan()
-  plan.enabled, plan.every = True, 0
-
-  def run(order, flush_after):
-    plan.begin_pass()
-    monkeypatch.setattr(ops, 'WGRAD_PLAN', plan)
-    for n, j in enumerate(order):
-      dy, x, dw, geo = probs[j]
-      ops.conv_wgrad(dy, x, dw, **geo)
-      if n in flush_after:
-        plan.flush()
-    plan.flush()
-    monkeypatch.setattr(ops, 'WGRAD_PLAN', None)
-    plan.end_pass()
-    out = list(calls)
-    calls.clear()
-    return out
-
-  assert run([0, 1, 2], ()) == ['full', 'full', 'full'] and plan.ready and plan.stats['reduce_entries'] == 2
-  got = run([0, 1, 2], ())
-  assert [c[0] if isinstance(c, tuple) else c for c in got] == ['stage1', 'stage1', 'full', 'multi']
-  splits = [c[1] for c in got[:2]]
-  assert all(s > 1 for s in splits) and got[0][2] == splits[0] * 72 * 72 and got[1][2] == splits[1] * 216 * 216
-  blocks = [(72 * 72 + 31) // 32, (216 * 216 + 31) // 32]
-  assert got[3] == ('multi', 2, 0, sum(blocks))
-  got = run([0, 1, 2], (0,))                      # a flush after the first call: two launches, the second starts where the first ended
-  assert [c for c in got if c[0] == 'multi'] == [('multi', 1, 0, blocks[0]), ('multi', 1, blocks[0], blocks[1])]
-  got = run([1, 0, 2], ())                        # another sequence: ordinary path for the whole pass, nothing batched
-  assert got == ['full', 'full', 'full'] and plan.broken and plan.stats['mismatches'] == 1
-  assert run([1, 0, 2], ()) == ['full', 'full', 'full'] and plan.ready and not plan.broken and plan.stats['builds'] == 2   # recorded again
-  got = run([1, 0, 2], ())
-  assert got[-1] == ('multi', 2, 0, sum(blocks)) and plan.stats['builds'] == 2

@@ -141,6 +141,27 @@ def test_conv_fwd_dgrad_wgrad(ops, case, dtype):
   _conv_case(ops, case, dtype)
 
 
+# The shapes the benchmark (BASELINE config 3: bs = 12, bf16) actually runs, with the kernel variants it runs them on.
+# tfpp_conv_gemm_variant: 202 = 16-wave 256x128 LDS-DMA ring (K >= 1024, >= 128 tiles), 200 = 8-wave 128x128 (>= 256 tiles), 201 = 64x128,
+# 2 = LDS-staged 64x64 ...  (210 + i = the opt-in ping-pong GEMM of round 4: tests below)
+# weight-gradient plan {variant, slices, second stage}: see tfpp_conv_wgrad_stage.
+TRUE_SHAPES = [
+    # name, B, H, W, Cin, Cout, k, stride, groups, expected forward variant, expected dgrad variant
+    (('fusion_mlp_fc1', 3840, 1, 1, 1512, 6048, 1, 1, 1), 202, 202),   # transfuser.py:392 at C = 1512: 3840 x 6048 x 1512
+    (('fusion_mlp_fc2', 3840, 1, 1, 6048, 1512, 1, 1, 1), 202, 202),
+    (('fusion_proj', 3840, 1, 1, 1512, 1512, 1, 1, 1), 202, 202),      # attention projection / QKV slices: 3840 x 1512 x 1512
+    (('fusion576_mlp_fc1', 3840, 1, 1, 576, 2304, 1, 1, 1), 200, 201),  # the C = 576 transformer: K = 576 is too short for the 144 KB ring; dgrad: 150 tiles
+    (('s3_conv1x1', 12, 16, 64, 576, 576, 1, 1, 1), 200, 200),         # image stage-3 1x1 convs: M = 12288, M-major XCD order
+    (('s4_conv1x1', 12, 8, 32, 1512, 1512, 1, 1, 1), 202, 202),        # stage 4: M = 3072
+    (('lidar_s3_conv1x1', 12, 16, 16, 576, 576, 1, 1, 1), 201, 201),   # LiDAR branch: 64x128 tiles
+    (('s2_entry_g3x3_s2', 4, 64, 128, 72, 72, 3, 2, 3), 302, 302),     # first block of a RegNet stage: stride-2 grouped 3x3 on the halo kernel
+    (('s3_entry_g3x3_s2', 2, 32, 128, 216, 216, 3, 2, 9), 302, 302),   #   (forward: 17 x 65 input halo; data gradient: zero-stuffed dy)
+    (('s2_conv1x1', 12, 32, 128, 216, 216, 1, 1, 1), 200, 200),       # stage-2 1x1 convs: K = 216 = 3 x 64 + 24, the K tail of the 64-deep ring
+    (('lidar_s2_conv1x1', 12, 32, 32, 216, 216, 1, 1, 1), 201, 201),
+    (('s1_conv1x1', 2, 64, 256, 72, 72, 1, 1, 1), 4, 4),               # stage-1 1x1 conv: one 128x96 tile column instead of 3 x 32
+]
+
+
 @pytest.mark.parametrize('entry', TRUE_SHAPES, ids=[e[0][0] for e in TRUE_SHAPES])
 def test_conv_benchmark_shapes_on_the_benchmark_kernels(ops, entry):
   case, vf, vd = entry
