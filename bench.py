@@ -143,6 +143,34 @@ def cpu_baseline(cfg_bs=2, budget_s=25.0, hard_timeout_s=90.0):
   return last
 
 
+def bf16_vs_fp32_gradients(batch, device, log):
+  """What the benchmarked precision is: the gradients of ONE bf16 training step against the fp32 HIP step (the reference's arithmetic: use_amp = 0)
+  on identical weights, batch and dropout masks -- cosine and relative L2 distance over the whole gradient arena.  (Per-tensor statistics and
+  the 50-step loss curves: tests/test_model.py, profiles/rNN_model_parity_report.jsonl.)"""
+  from carla_garage_amd.config import GlobalConfig
+  from carla_garage_amd.model import LidarCenterNet
+  from carla_garage_amd.trainer import Trainer
+  grads = {}
+  for dt_ in ('fp32', 'bf16'):
+    torch.manual_seed(0)
+    m = LidarCenterNet(GlobalConfig(tfpp_dtype=dt_)).to(device).train()
+    tr = Trainer(m, lr=0.0)
+    tr.step_count += 1
+    tr._step_body(batch)
+    tr.eng.buckets.executed(tr.program)
+    torch.cuda.synchronize()
+    grads[dt_] = {n: g.detach().double().flatten().clone() for n, g in tr.eng.grads.items()}
+    del tr, m
+    torch.cuda.empty_cache()
+  names = sorted(grads['fp32'])
+  a = torch.cat([grads['fp32'][n] for n in names])
+  b = torch.cat([grads['bf16'][n] for n in names])
+  out = {'arena_cosine': round(float((a * b).sum() / (a.norm() * b.norm())), 5), 'arena_rel_l2': round(float((b - a).norm() / a.norm()), 4),
+         'elements': int(a.numel())}
+  log(f'bf16 vs fp32 gradients of one step: {out}')
+  return out
+
+
 def inference_latency(model, cfg, device, log, iters=20):
   """Second half of the BASELINE metric: TransFuser++ forward ms/frame at bs=1 (the 20 Hz closed-loop tick,
   sensor_agent.py:456-461), eval mode, caller-facing fp32 NCHW outputs included; eager launches and hipGraph replay."""
@@ -675,7 +703,9 @@ def main():
       dropin['samples_per_s'] = round(args.batch_size * world / (dropin['fused_optimizer']['ms_per_step'] * 1e-3), 1)
       dropin['note'] = ('module driven as team_code/train.py:776-910 drives the reference (DistributedDataParallel when ranks > 1, compute_loss, '
                         '.item() per loss, loss.backward(), optimizer.step(), zero_grad(set_to_none=True)); fused_optimizer = carla_garage_amd.optim.FlatAdamW '
-                        'in place of optim.AdamW (INTEGRATION.md), torch_adamw = the unmodified optimizer')
+                        'in place of optim.AdamW (INTEGRATION.md), torch_adamw = the unmodified optimizer.  Covered by GPU tests on this boundary: ZeroRedundancyOptimizer, '
+                        'freeze_backbone, validate(), grad clip, learnable loss weights, GradScaler (tests/test_boundary_gpu.py).  NOT supported: SyncBatchNorm '
+                        'conversion (config.sync_batch_norm = 1; the reference default is 0) raises ValueError -- BatchNorm statistics are per rank')
     except Exception as e:  # pylint: disable=broad-except
       log(f'drop-in leg failed: {type(e).__name__}: {e}')
       dropin = {'error': f'{type(e).__name__}: {e}'}
@@ -702,6 +732,7 @@ def main():
       fp32_leg = {'ms_per_step': round(ms32, 3), 'samples_per_s': round(args.batch_size / (ms32 * 1e-3), 1), 'dtype': 'fp32', 'steps': n32,
                   'final_weighted_loss': round(float(tr32.total_loss(v32)), 5)}
       log(f'fp32 step bs={args.batch_size}: {fp32_leg}')
+      fp32_leg['bf16_vs_fp32_gradients'] = bf16_vs_fp32_gradients(batch, device, log)
       del g32, tr32, m32
       torch.cuda.empty_cache()
     except Exception as e:  # pylint: disable=broad-except

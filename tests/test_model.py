@@ -73,6 +73,16 @@ def test_abi_version_of_header_and_binding_agree():
   assert _lib.lib.raw('tfpp_version')() == v
 
 
+def test_sync_batchnorm_conversion_is_refused_not_ignored(model_cpu):
+  """train.py:511-512 converts the module with nn.SyncBatchNorm.convert_sync_batchnorm when config.sync_batch_norm = 1 (default 0).  The HIP
+  BatchNorm is per rank: the converted module must refuse to run rather than silently train another model."""
+  import copy
+  m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(copy.deepcopy(model_cpu))
+  m.__dict__['engine'] = None
+  with pytest.raises(ValueError, match='SyncBatchNorm'):
+    m._engine()
+
+
 AIM_CFG = dict(backbone='aim', use_semantic=0, use_depth=0, detect_boxes=0, use_bev_semantic=0)  # BASELINE config 1
 
 
