@@ -308,6 +308,27 @@ def lidar_histogram_latency(cfg, device, log, n=60000, iters=50):
   return r
 
 
+def image_augmentation_latency(cfg, device, log, bs=12, iters=20):
+  """the colour augmentation of the loader (team_code/data.py:1141-1157, color_aug_prob = 0.5) on the uploaded
+  uint8 frames of one batch -- host sampling of the programs + the device stages (carla_garage_amd/augment.py), per batch of `bs` frames."""
+  from carla_garage_amd.augment import ImageAugmenter
+  aug = ImageAugmenter(prob=cfg.color_aug_prob if hasattr(cfg, 'color_aug_prob') else 0.5, seed=1)
+  rgb = torch.randint(0, 256, (bs, 3, cfg.camera_height if hasattr(cfg, 'camera_height') else 256, cfg.camera_width if hasattr(cfg, 'camera_width') else 1024),
+                      device=device, dtype=torch.uint8)
+  aug.apply(rgb)
+  torch.cuda.synchronize()
+  stages = 0
+  t0 = time.perf_counter()
+  for _ in range(iters):
+    aug.apply(rgb)
+    stages += int((aug.last_programs['kind'] != 0).sum(1).max())
+  torch.cuda.synchronize()
+  r = {'batch': bs, 'us_per_batch': round(1e6 * (time.perf_counter() - t0) / iters, 1), 'avg_stages': round(stages / iters, 2),
+       'note': 'host program sampling + device stages, frames resident; the reference runs imgaug per sample in the DataLoader workers'}
+  log(f'image augmentation: {r}')
+  return r
+
+
 def dropin_step_time(model, cfg, batch, steps, warmup, optimizer, log, ddp=False):
   """ms/step of the DROP-IN boundary: the module driven exactly as team_code/train.py:776-910 drives the reference's (forward with keyword
   arguments -> model.compute_loss -> weighted sum with a host read of every loss (train.py:896) -> backward -> optimizer.step ->
@@ -737,10 +758,14 @@ def main():
       torch.cuda.empty_cache()
     except Exception as e:  # pylint: disable=broad-except
       log(f'fp32 leg failed: {type(e).__name__}: {e}')
-  fwd = lidar_hist = swin_fwd = None
+  fwd = lidar_hist = swin_fwd = image_aug = None
   if rank == 0 and not args.no_inference:
     fwd = inference_latency(model, cfg, device, log)
     lidar_hist = lidar_histogram_latency(cfg, device, log)
+    try:
+      image_aug = image_augmentation_latency(cfg, device, log, bs=args.batch_size)
+    except Exception as e:  # pylint: disable=broad-except
+      log(f'image augmentation leg failed: {type(e).__name__}: {e}')
     swin_fwd = video_swin_forward(device, log, train=rccl_ranks is None)
   if rccl_ranks is not None:
     _flush_c_stdio()  # (RCCL prints a version banner through C stdio: buffered on a pipe, it would otherwise appear at exit, AFTER the JSON line)
@@ -765,6 +790,8 @@ def main():
       line['fwd_ms_per_frame'] = fwd
     if lidar_hist is not None:
       line['lidar_histogram_60k_points_us'] = lidar_hist
+    if image_aug is not None:
+      line['image_augmentation'] = image_aug
     if swin_fwd is not None:
       line['video_swin_forward_bs4'] = swin_fwd
     if comm is not None:

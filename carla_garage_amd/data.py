@@ -53,11 +53,14 @@ class DeviceBatchPrefetcher:
   widening kernels) on the copy stream; the consumer thread only waits for the slot's event on its compute stream.  A yielded batch stays
   valid until the consumer asks for the next one AND the work it enqueued meanwhile on the current stream has run."""
 
-  def __init__(self, loader, config, device='cuda', slots=2, rasterise_on_device=False):
-    """rasterise_on_device: the host batches carry ``bounding_boxes_f64`` (B, n, 8) float64 + ``num_bounding_boxes`` (B,) (collate_boxes)
+  def __init__(self, loader, config, device='cuda', slots=2, rasterise_on_device=False, augment=None):
+    """augment: a carla_garage_amd.augment.ImageAugmenter -- the colour augmentation of team_code/data.py:481-496,1141-1157 runs on the
+    uploaded uint8 frame (copy stream) instead of in the loader's workers; the loader then yields the frame as decoded (use_color_aug = 0).
+    rasterise_on_device: the host batches carry ``bounding_boxes_f64`` (B, n, 8) float64 + ``num_bounding_boxes`` (B,) (collate_boxes)
     instead of the nine CenterNet label maps, which are then drawn on the GPU by rasterise_targets right after the upload."""
     self.loader, self.cfg, self.device = loader, config, torch.device(device)
     self.rasterise = bool(rasterise_on_device and config.detect_boxes)
+    self.augment = augment
     if self.device.index is None:
       self.device = torch.device('cuda', torch.cuda.current_device())
     self.copy_stream = torch.cuda.Stream(self.device)
@@ -95,6 +98,10 @@ class DeviceBatchPrefetcher:
         pin.copy_(t)  # host-side conversion / gather into pinned memory
         d = slot['dev'][src]
         d.copy_(pin, non_blocking=True)
+        if self.augment is not None and src == 'rgb':
+          if d.dtype != torch.uint8:
+            raise ValueError('device-side augmentation works on the decoded uint8 frame: the loader must yield rgb as uint8')
+          d = self.augment.apply(d)
         if narrow:
           wide = slot['dev'][src + '/wide']
           lib.tfpp_widen(ptr(d), ptr(wide), d.numel(), _NARROW[t.dtype], _WIDE[dt], ops.stream())

@@ -209,6 +209,32 @@ int tfpp_cast(const void* in, void* out, int64_t n, int dtype_in, int dtype_out,
 /* Widening of the narrow host dtypes of an uploaded batch on the device (team_code/train.py:688-766 does ``.to(device, dtype=...)`` from pageable
  * memory): src_kind 0 = uint8, 1 = int32; dst_kind 0 = fp32, 1 = int64.  16-byte aligned buffers. */
 int tfpp_widen(const void* in, void* out, int64_t n, int src_kind, int dst_kind, void* stream);
+
+/* Colour augmentation of the uploaded uint8 camera frames (team_code/data.py:1141-1157 image_augmenter, applied per sample in
+ * CARLA_Data.__getitem__, data.py:481-496; imgaug 0.4.0 / OpenCV 4.6, requirements.txt:48,95).  The HOST samples every image's program --
+ * which of the seven operators fire (Sometimes(prob)), their order (Sequential(random_order=True)) and parameters -- into
+ * progs[B][TFPP_AUG_MAX_OPS] (kind TFPP_AUG_NONE pads short programs; device copy); one call executes stage `stage` of every image:
+ * dst = op(src) on (B, 3, H, W) uint8 planes (the loader's CHW RGB, data.py:516), src != dst.  Pixels are uint8 between stages as between
+ * imgaug augmenters.  Per-pixel random maps (noise, dropout mask, displacement field) are drawn from a counter-based generator keyed by
+ * (seed, image, stage, pixel, channel).  Operator parameters in tfpp_aug_op.a:
+ *   BLUR      a[0..2] = 1-D Gaussian weights w(0), w(1), w(2) of the 5-tap kernel (imgaug: ksize 5 for sigma <= 1.5), BORDER_REFLECT_101
+ *   NOISE     a[0] = sigma of the additive Gaussian noise;  per_channel: a noise map per channel instead of one shared map
+ *   DROPOUT   a[0] = probability of zeroing a pixel;        per_channel: per channel value
+ *   MULTIPLY  a[c] = factor (a[0] for all channels unless per_channel);   table clip(round(v m))
+ *   CONTRAST  a[c] = alpha:  clip(127 + alpha (v - 127)) truncated to uint8
+ *   GRAYSCALE a[0] = alpha:  round(alpha gray + (1 - alpha) v), gray = (4899 R + 9617 G + 1868 B + 8192) >> 14
+ *   ELASTIC   a[0] = alpha, a[1..3] = smoothing weights w(0), w(1), w(2) of the U(-1, 1) displacement field; bicubic remap, border 0
+ *   CUTOUT    a = x1, y1, x2, y2 (pixels), filled with the constant `per_channel` (128 for the camera, 0 for the LiDAR: data.py:1153,1165) */
+enum { TFPP_AUG_NONE = 0, TFPP_AUG_BLUR = 1, TFPP_AUG_NOISE = 2, TFPP_AUG_DROPOUT = 3, TFPP_AUG_MULTIPLY = 4, TFPP_AUG_CONTRAST = 5,
+       TFPP_AUG_GRAYSCALE = 6, TFPP_AUG_ELASTIC = 7, TFPP_AUG_CUTOUT = 8 };
+#define TFPP_AUG_MAX_OPS 8
+typedef struct tfpp_aug_op {
+  int kind;
+  int per_channel;
+  float a[4];
+} tfpp_aug_op;
+int tfpp_image_augment_stage(const void* src, void* dst, const tfpp_aug_op* progs_dev, int stage, int B, int H, int W, uint64_t seed,
+                             void* stream);
 /* All per-step weight images in ONE launch: a device-resident table of descriptors (kind 0/1 = tfpp_pack_conv_weight
  * forward / transposed with a = {Cout, cin_g, R, S, G, ks_pad, n_pad}; kind 2 = tfpp_pack2d with a = {rows_out, cols_out,
  * transpose_in}).  Descriptor i owns workgroups [blk_start, blk_start + tfpp_pack_desc_plan(&desc_i)). */
