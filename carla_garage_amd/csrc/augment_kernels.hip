@@ -24,6 +24,18 @@ __device__ __forceinline__ unsigned char sat_rint(float v) {  // cv2 saturate_ca
   v = rintf(v);
   return (unsigned char)(v < 0.f ? 0.f : (v > 255.f ? 255.f : v));
 }
+// products and sums rounded one by one, as numpy / OpenCV's scalar float code rounds them: hipcc contracts a * b + c into one FMA otherwise
+// (and __fmul_rn / __fadd_rn are plain operators in the HIP headers), which moves results that sit on a rounding tie
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  const float r = a * b;
+  return r;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  const float r = a + b;
+  return r;
+}
 __device__ __forceinline__ int reflect101(int i, int n) {  // cv2.BORDER_REFLECT_101: gfedcb|abcdefgh|gfedcba
   if (i < 0) i = -i;
   if (i >= n) i = 2 * n - 2 - i;
@@ -76,7 +88,7 @@ __global__ __launch_bounds__(256) void aug_stage_kernel(const unsigned char* __r
     case TFPP_AUG_CONTRAST: {  // table[v] = clip(127 + alpha (v - 127)).astype(uint8): truncation  (contrast.py adjust_contrast_linear)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        float t = __fadd_rn(127.f, __fmul_rn(op.a[op.per_channel ? c : 0], (float)s[c * HW + pix] - 127.f));  // float32 table, no FMA contraction
+        float t = add_rn(127.f, mul_rn(op.a[op.per_channel ? c : 0], (float)s[c * HW + pix] - 127.f));  // float32 table, no FMA contraction
         t = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);
         d[c * HW + pix] = (unsigned char)t;
       }
@@ -86,10 +98,10 @@ __global__ __launch_bounds__(256) void aug_stage_kernel(const unsigned char* __r
       const int r = s[pix], g = s[HW + pix], bl = s[2 * HW + pix];
       const float gray = (float)((r * 4899 + g * 9617 + bl * 1868 + 8192) >> 14);
       const float al = op.a[0];
-      const float be = 1.f - al, ga = __fmul_rn(gray, al);  // products and sum rounded separately (no FMA contraction), as in the float32 host code
-      d[pix] = sat_rint(__fadd_rn(ga, __fmul_rn((float)r, be)));
-      d[HW + pix] = sat_rint(__fadd_rn(ga, __fmul_rn((float)g, be)));
-      d[2 * HW + pix] = sat_rint(__fadd_rn(ga, __fmul_rn((float)bl, be)));
+      const float be = 1.f - al, ga = mul_rn(gray, al);  // products and sum rounded separately (no FMA contraction), as in the float32 host code
+      d[pix] = sat_rint(add_rn(ga, mul_rn((float)r, be)));
+      d[HW + pix] = sat_rint(add_rn(ga, mul_rn((float)g, be)));
+      d[2 * HW + pix] = sat_rint(add_rn(ga, mul_rn((float)bl, be)));
       break;
     }
     case TFPP_AUG_BLUR: {  // cv2.GaussianBlur 5 x 5 (imgaug picks ksize 5 for sigma <= 1.5), BORDER_REFLECT_101; a[0..2] = w(0), w(1), w(2)
