@@ -193,7 +193,7 @@ def test_elastic_transformation_displacements_and_remap():
   got_tex = _run(tex, [[(A.ELASTIC, 0, (alpha, *w25))]], seed=21)[0].astype(np.int32)
   gx = _run(ramp_x[None], [[(A.ELASTIC, 0, (alpha, *w25))]], seed=21)[0][..., 0].astype(np.float64) - ramp_x[..., 0]
   # (the recovered field is rounded to whole pixels, so this is a coarse check: most pixels move by the recovered amount +- interpolation)
-  assert np.abs(got_tex - tex[0].astype(np.int32)).mean() > 1.0 and np.abs(gx).max() <= 2
+  assert np.abs(got_tex - tex[0].astype(np.int32)).mean() > 1.0 and np.abs(gx[inner]).max() <= 2   # (at the border the remap reads the constant 0)
 
 
 @pytest.mark.gpu
@@ -215,4 +215,4 @@ def test_prefetcher_augments_the_uploaded_uint8_frame():
     assert p.dtype == torch.float32 and torch.equal(p, s)
     assert c.shape == p.shape and float(c.min()) >= 0 and float(c.max()) <= 255 and float((c - c.round()).abs().max()) == 0
     diff = (c - p).abs()
-    assert float(diff.mean()) > 1.0 and float(diff.mean()) < 60.0      # all seven operators fired: visibly another image, still the same scene
+    assert float(diff.mean()) > 1.0 and float(diff.mean()) < 100.0     # all seven operators fired on a white-noise frame (blur and the remap decorrelate it): another image, valid grey levels
