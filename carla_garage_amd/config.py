@@ -44,6 +44,7 @@ class GlobalConfig:
     self.lidar_architecture = 'regnety_032'
     self.use_controller_input_prediction = True
     self.use_focal_loss = False
+    self.focal_loss_gamma = 2.0  # team_code/config.py:213
     self.use_speed_weights = True
     self.use_label_smoothing = False
     self.label_smoothing_alpha = 0.1

@@ -255,14 +255,16 @@ __global__ void ce_loss_kernel(const T* __restrict__ pred, const long long* __re
                                const float* __restrict__ vis, const float* __restrict__ pix_weight, long pw_bstride, long HW,
                                const float* __restrict__ denom, float denom_eps, const float* __restrict__ ws, float weight,
                                float* __restrict__ loss_out, T* __restrict__ dpred, long rows, int C, int ld, float smoothing,
-                               float* __restrict__ scratch) {
+                               float focal_gamma, float* __restrict__ scratch) {
   __shared__ float sm[4];
   // label smoothing (nn.CrossEntropyLoss(weight, label_smoothing), model.py:252-265): per row (1 - a) w[y] nll(y) + a / C sum_c w[c] nll(c),
   // normalised like the unsmoothed loss by sum_i w[y_i]
   float wsum = 0.f;
   if (smoothing > 0.f)
     for (int c = 0; c < C; ++c) wsum += cw ? cw[c] : 1.f;
-  const float den = pix_weight ? (denom[0] + denom_eps) : ws[0];
+  // focal form (focal_gamma >= 0; team_code/focal_loss.py:75-103): mean over ALL rows of alpha[y] (1 - p_y)^gamma (-log p_y)
+  const bool focal = focal_gamma >= 0.f;
+  const float den = focal ? (float)rows : (pix_weight ? (denom[0] + denom_eps) : ws[0]);
   const float inv = den > 0.f ? 1.f / den : 0.f;
   float acc = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
@@ -286,6 +288,21 @@ __global__ void ce_loss_kernel(const T* __restrict__ pred, const long long* __re
       float pl = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) pl = (c == (int)l) ? v[c] * invs : pl;
+      if (focal) {
+        // f(p) = -w (1 - p)^g log p;  df/dz_c = w [g (1 - p)^(g-1) p log p - (1 - p)^g] (delta_cy - softmax_c)
+        const float lp = __logf(fmaxf(pl, 1e-38f)), om = fmaxf(1.f - pl, 0.f);
+        const float pg = focal_gamma == 0.f ? 1.f : __powf(om, focal_gamma);
+        acc += -w * pg * lp;
+        if (dpred) {
+          const float pg1 = focal_gamma == 0.f ? 0.f : focal_gamma * (focal_gamma == 1.f ? 1.f : __powf(om, focal_gamma - 1.f));
+          const float coef = weight * inv * w * (pg1 * pl * lp - pg);
+          T* d = dpred + (size_t)i * ld;
+#pragma unroll
+          for (int c = 0; c < 16; ++c)
+            if (c < ld) d[c] = ElemTraits<T>::from_f(c < C ? coef * (((c == (int)l) ? 1.f : 0.f) - v[c] * invs) : 0.f);
+        }
+        continue;
+      }
       acc += -(1.f - smoothing) * w * __logf(fmaxf(pl, 1e-38f));
       if (smoothing > 0.f) {
 #pragma unroll
@@ -318,19 +335,20 @@ __global__ void ce_loss_kernel(const T* __restrict__ pred, const long long* __re
 
 extern "C" int tfpp_ce_loss(const void* pred, const int64_t* label, const float* class_weight, const float* vis_mask, const float* pix_weight,
                             int64_t pw_bstride, int64_t HW, const float* denom, float denom_eps, float weight, float* loss_out, void* dpred,
-                            float* ws, float* scratch, int64_t rows, int C, int ld, float smoothing, int dtype, void* stream) {
+                            float* ws, float* scratch, int64_t rows, int C, int ld, float smoothing, float focal_gamma, int dtype, void* stream) {
+  if (focal_gamma >= 0.f && (pix_weight || smoothing > 0.f || vis_mask)) return TFPP_EINVAL;
   if (!pred || !label || !loss_out || !ws || !scratch || C > 16 || ld > 16 || ld < C || HW < 1 || (pix_weight && !denom)) return TFPP_EINVAL;
   if (smoothing < 0.f || smoothing >= 1.f || (smoothing > 0.f && pix_weight)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   long blocks = (rows + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  if (!pix_weight)
+  if (!pix_weight && focal_gamma < 0.f)
     hipLaunchKernelGGL(ce_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const long long*)label, class_weight, vis_mask, (long)HW, ws, (long)rows, scratch);
   if (dtype == TFPP_F32)
-    hipLaunchKernelGGL(ce_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (float*)dpred, (long)rows, C, ld, smoothing, scratch);
+    hipLaunchKernelGGL(ce_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (float*)dpred, (long)rows, C, ld, smoothing, focal_gamma, scratch);
   else
-    hipLaunchKernelGGL(ce_loss_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (bf16_t*)dpred, (long)rows, C, ld, smoothing, scratch);
+    hipLaunchKernelGGL(ce_loss_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (bf16_t*)dpred, (long)rows, C, ld, smoothing, focal_gamma, scratch);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

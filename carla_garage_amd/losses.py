@@ -62,8 +62,10 @@ def _one_loss(model, name, t, labels, slot, weight, want_grad, af_sum):
     p = t['pred_target_speed']  # [B, 8] fp32 (4 real)
     d = grad_like(p)
     ws = torch.empty(2, device=dev, dtype=F32)
-    ops.ce_loss(p, labels['target_speed_label'], slot, ws, rows=p.shape[0], C=len(cfg.target_speeds), ld=p.shape[1],
-                HW=p.shape[0], class_weight=model.loss_speed.weight, weight=weight, dpred=d, smoothing=smooth)
+    focal = bool(getattr(cfg, 'use_focal_loss', False))  # model.py:255-256: FocalLoss(alpha=speed_weights, gamma) instead of the (smoothed) cross entropy
+    ops.ce_loss(p, labels['target_speed_label'], slot, ws, rows=p.shape[0], C=len(cfg.target_speeds), ld=p.shape[1], HW=p.shape[0],
+                class_weight=model.loss_speed.nll_loss.weight if focal else model.loss_speed.weight, weight=weight, dpred=d,
+                smoothing=0.0 if focal else smooth, focal_gamma=float(model.loss_speed.gamma) if focal else -1.0)
     return p, d
   if name in ('loss_checkpoint', 'loss_wp'):
     p = t['pred_checkpoint'] if name == 'loss_checkpoint' else t['pred_wp']

@@ -118,8 +118,10 @@ class LidarCenterNet(nn.Module):
     sw = torch.tensor(config.target_speed_weights) if config.use_speed_weights else torch.ones(len(config.target_speed_weights))
     smooth = config.label_smoothing_alpha if config.use_label_smoothing else 0.0  # applied by the fused CE kernel (losses.py)
     if config.use_focal_loss:
-      raise ValueError('MI355X path: the focal target-speed loss is not implemented (reference default: off)')
-    self.loss_speed = nn.CrossEntropyLoss(weight=sw, label_smoothing=smooth)
+      # team_code/model.py:255-256 -> focal_loss.py:35-103; its only state is nll_loss.weight (the class weights), computed by tfpp_ce_loss(focal_gamma)
+      self.loss_speed = M.FocalLossWeights(sw, float(config.focal_loss_gamma))
+    else:
+      self.loss_speed = nn.CrossEntropyLoss(weight=sw, label_smoothing=smooth)
     self.loss_semantic = nn.CrossEntropyLoss(weight=torch.tensor(config.semantic_weights), label_smoothing=smooth)
     self.loss_bev_semantic = nn.CrossEntropyLoss(weight=torch.tensor(config.bev_semantic_weights), label_smoothing=smooth, ignore_index=-1)
 

@@ -18,6 +18,16 @@ def _no_forward(self, *a, **k):
   raise RuntimeError('parameter container: compute runs through carla_garage_amd.engine (HIP), not nn.Module.forward')
 
 
+class FocalLossWeights(nn.Module):
+  """Container with the state_dict schema of team_code/focal_loss.py::FocalLoss (one buffer: ``nll_loss.weight``)."""
+  forward = _no_forward
+
+  def __init__(self, alpha, gamma):
+    super().__init__()
+    self.gamma = gamma
+    self.nll_loss = nn.NLLLoss(weight=alpha, reduction='none')
+
+
 class ConvBn(nn.Module):
   """timm ConvNormAct naming: ``conv`` (no bias) + ``bn`` (team_code/model.py:586-589 relies on 'conv.' / '.bn')."""
   forward = _no_forward

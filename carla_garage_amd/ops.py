@@ -939,9 +939,10 @@ def gru_bwd(dout, save, h0, w_hh, b_hh, w_dec, dw_hh, db_hh, dw_dec, db_dec, def
 
 
 def ce_loss(pred, label, loss_out, ws, *, rows, C, ld, HW, class_weight=None, vis_mask=None, pix_weight=None, pw_bstride=0,
-            denom=None, denom_eps=0.0, weight=1.0, dpred=None, smoothing=0.0):
+            denom=None, denom_eps=0.0, weight=1.0, dpred=None, smoothing=0.0, focal_gamma=-1.0):
   lib.tfpp_ce_loss(ptr(pred), ptr(label), ptr(class_weight), ptr(vis_mask), ptr(pix_weight), pw_bstride, HW, ptr(denom), denom_eps,
-                   weight, ptr(loss_out), ptr(dpred), ptr(ws), ptr(gridsum_scratch(pred.device)), rows, C, ld, float(smoothing), dt(pred), stream())
+                   weight, ptr(loss_out), ptr(dpred), ptr(ws), ptr(gridsum_scratch(pred.device)), rows, C, ld, float(smoothing), float(focal_gamma),
+                   dt(pred), stream())
 
 
 def reg_loss(pred, target, loss_out, *, B, C, HW, ld, kind, elem_weight=None, wC=1, w_bcast=False, denom=None, denom_eps=0.0,

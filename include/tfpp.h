@@ -522,8 +522,10 @@ int tfpp_gru_bwd_partial_floats(int B, int H); /* returns the count (not an erro
  *   target[(b*C+c)*HW+pix], elem_weight[(b*wC+(w_bcast?0:c))*HW+pix]; denominator (*denom+denom_eps)*denom_mul or B*C*HW. */
 int tfpp_ce_loss(const void* pred, const int64_t* label, const float* class_weight, const float* vis_mask, const float* pix_weight,
                  int64_t pw_bstride, int64_t HW, const float* denom, float denom_eps, float weight, float* loss_out, void* dpred,
-                 float* ws, float* scratch, int64_t rows, int C, int ld, float label_smoothing, int dtype, void* stream);
-/* label_smoothing a in [0, 1) (nn.CrossEntropyLoss(weight, label_smoothing=a), model.py:252-265; not with pix_weight): per row
+                 float* ws, float* scratch, int64_t rows, int C, int ld, float label_smoothing, float focal_gamma, int dtype, void* stream);
+/* focal_gamma < 0: cross entropy as above.  focal_gamma >= 0: the focal loss of team_code/focal_loss.py:35-103 (config.use_focal_loss,
+ * model.py:255-256): mean over ALL rows of class_weight[y] (1 - p_y)^gamma (-log p_y); not with pix_weight / vis_mask / label smoothing.
+ * label_smoothing a in [0, 1) (nn.CrossEntropyLoss(weight, label_smoothing=a), model.py:252-265; not with pix_weight): per row
  * (1 - a) w[y] nll(y) + a / C sum_c w[c] nll(c), normalised by sum_rows w[y]. */
 int tfpp_reg_loss(const void* pred, const float* target, const float* elem_weight, int wC, int w_bcast, const float* denom,
                   float denom_eps, float denom_mul, float weight, float* loss_out, void* dpred, float* scratch, int B, int C, int64_t HW,

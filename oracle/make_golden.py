@@ -230,6 +230,21 @@ def write_freeze_golden():
   write_train_golden(model, cfg, 2, 'tfpp_train_freeze_bs2.npz')
 
 
+def write_focal_golden():
+  """config.use_focal_loss = 1 (team_code/model.py:255-256, focal_loss.py:35-103, gamma = config.focal_loss_gamma = 2): the target-speed
+  classification loss becomes mean_i alpha[y_i] (1 - p_i)^gamma (-log p_i); one train-mode step at bs = 2.  The state_dict carries
+  loss_speed.nll_loss.weight instead of loss_speed.weight."""
+  model, _ = ref_harness.build_reference_model(use_focal_loss=True)
+  cfg = P.PortConfig()
+  sd = P.make_state_dict(cfg)
+  sd['loss_speed.nll_loss.weight'] = sd.pop('loss_speed.weight')
+  model.load_state_dict(sd, strict=True)
+  write_train_golden(model, cfg, 2, 'tfpp_train_focal_bs2.npz')
+  g = dict(np.load(os.path.join(GOLDEN, 'tfpp_train_focal_bs2.npz'), allow_pickle=False))
+  g['state_dict_keys_loss_speed'] = np.array([k for k in model.state_dict().keys() if k.startswith('loss_speed')])
+  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_train_focal_bs2.npz'), **g)
+
+
 def write_validate_golden():
   """Engine.validate (team_code/train.py:923-956): @torch.inference_mode(), model.eval(), forward + compute_loss on a validation batch;
   the ten unweighted losses and their weighted sum at bs = 2."""
@@ -313,6 +328,9 @@ def main():
     return
   if only == {'freeze'}:
     write_freeze_golden()
+    return
+  if only == {'focal'}:
+    write_focal_golden()
     return
   if only == {'validate'}:
     write_validate_golden()

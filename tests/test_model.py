@@ -461,6 +461,22 @@ def test_train_step_bs12_fp32_vs_reference_golden():
 
 
 @pytest.mark.gpu
+def test_focal_target_speed_loss_train_step_fp32_vs_reference_golden():
+  """config.use_focal_loss = 1 (team_code/model.py:255-256, focal_loss.py): the ten losses, every gradient and the state_dict schema of the loss
+  container (loss_speed.nll_loss.weight) against one train step of the unmodified reference (oracle/make_golden.py focal)."""
+  g = U.load_golden('tfpp_train_focal_bs2.npz')
+  m = LidarCenterNet(GlobalConfig(use_focal_loss=True))
+  assert [k for k in m.state_dict().keys() if k.startswith('loss_speed')] == [str(k) for k in g['state_dict_keys_loss_speed']] == ['loss_speed.nll_loss.weight']
+  sd = P.make_state_dict(P.PortConfig())
+  sd['loss_speed.nll_loss.weight'] = sd.pop('loss_speed.weight')
+  m.load_state_dict(sd, strict=True)
+  plain = U.load_golden('tfpp_train_bs2.npz')
+  lp, lf = dict(zip(map(str, plain['loss_names']), plain['losses'])), dict(zip(map(str, g['loss_names']), g['losses']))
+  assert abs(lp['loss_target_speed'] - lf['loss_target_speed']) > 0.1 * lp['loss_target_speed']   # it IS another loss than the cross entropy
+  _check_train_step_vs_golden(2, 'tfpp_train_focal_bs2.npz', 'train_fp32_focal', model=m.cuda())
+
+
+@pytest.mark.gpu
 def test_temporal_lidar_train_step_fp32_vs_reference_golden():
   """lidar_seq_len = 6 on the default RegNet LiDAR branch (6 BEV frames as input channels): the velocity / brake CenterNet heads and
   their losses (center_net.py:29-31,119-123) -- losses, gradients and BN statistics of one train step against the unmodified reference."""

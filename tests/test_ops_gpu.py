@@ -1279,6 +1279,27 @@ def test_zero_and_fill_bytes_are_kernels_with_exact_extent(ops):
   assert float(big.sum()) == 7.0 and float(big[:3].sum()) == 3.0
 
 
+@pytest.mark.parametrize('gamma', [0.0, 1.0, 2.0, 3.5])
+def test_focal_loss_vs_torch(ops, gamma):
+  """tfpp_ce_loss(focal_gamma >= 0) against the formula of team_code/focal_loss.py:75-103 written with torch ops: mean over all rows of
+  alpha[y] (1 - p_y)^gamma (-log p_y), and its gradient."""
+  rows, C, ld = 37, 4, 8
+  pred = (rnd(rows, C, seed=301) * 4).requires_grad_(True)
+  lab = torch.randint(0, C, (rows,), generator=torch.Generator().manual_seed(5))
+  cw = rnd(C, seed=302, lo=0.5, hi=2.0)
+  log_p = F.log_softmax(pred, dim=-1)
+  log_pt = log_p[torch.arange(rows), lab]
+  want = ((1 - log_pt.exp()) ** gamma * (-cw[lab] * log_pt)).mean()
+  (0.6 * want).backward()
+  loss, ws = torch.zeros(1, device=DEV), torch.zeros(2, device=DEV)
+  dp = torch.full((rows, ld), 7.0, device=DEV)
+  ops.ce_loss(dev(F.pad(pred.detach(), (0, ld - C))), dev(lab), loss, ws, rows=rows, C=C, ld=ld, HW=rows, class_weight=dev(cw), weight=0.6, dpred=dp,
+              focal_gamma=gamma)
+  check(f'focal{gamma}.loss', loss.cpu(), want.detach().view(1), torch.float32)
+  check(f'focal{gamma}.grad', dp[:, :C].cpu(), pred.grad, torch.float32, scale=3.0)
+  assert float(dp[:, C:].abs().max()) == 0.0
+
+
 def test_grid_sums_are_bit_reproducible_and_streams_do_not_share_tickets(ops):
   """The grid-wide sums of the loss kernels, the cross-entropy normaliser and the LayerNorm parameter gradients are added in a fixed order by
   the workgroup that draws the last ticket (csrc/common.cuh): the results must be bit-identical launch after launch at the training sizes
