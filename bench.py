@@ -9,7 +9,12 @@ Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line
   roofline      the dominant kernel family (largest share of the step's kernel time): algorithmic FLOPs or bytes / HIP-event time on the
                 launch stream, against the MFMA peak when its FLOP/byte lies above the ridge (312 FLOP/B for bf16), against HBM otherwise
   roofline_mfma the same object for the dominant MFMA-bound family when that is a different one (the LDS-DMA GEMMs of the fusion transformers)
+  roofline_step the whole step: sum of algorithmic FLOPs / GEMM-operand bytes against the measured step, launches, kernel time, and the committed
+                rocprofv3 trace of one replayed graph step (profiles/rNN_graph_step.json); every roofline object carries `graph_trace` = its family's
+                average launch duration inside that replayed graph
   cpu_baseline  the CPU oracle (oracle/tfpp_port.py, "port") doing the same train step on the host cores, bounded sample
+  also: dropin (the step behind train.py's call sites), fp32_step (+ bf16-vs-fp32 gradient cosine), gradient_exchange (N > 1 / --force-collectives),
+  fwd_ms_per_frame, lidar_histogram, image_augmentation, video_swin, parity (what is pinned against what)
 """
 import argparse
 import json
@@ -810,6 +815,12 @@ def main():
         line['roofline_hbm'] = roof_hbm
       if roof_fusion is not None and roof_fusion['kernel'] != roof['kernel']:
         line['roofline_fusion_linears'] = roof_fusion
+    line['parity'] = {'fp32': 'outputs / losses 1e-3 (measured 3e-6), per-parameter gradient norms 1e-2, against goldens written by the unmodified reference '
+                              '(tests/golden, oracle/make_golden.py)',
+                      'bf16': 'statistical (fp32_step.bf16_vs_fp32_gradients; per-tensor bars and 50-step loss curves in tests/test_model.py)',
+                      'unpinned_third_party': ['timm 0.6.7 (absent: RegNetY block arithmetic pinned bit-exactly against HF transformers instead)',
+                                               'shapely (absent: rotated IoU pinned against an exact rational-arithmetic oracle)',
+                                               'imgaug 0.4.0 / opencv 4.6 (absent: operator arithmetic restated in oracle/imgaug_port.py)']}
     if world == 1 and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline()
   torch.cuda.synchronize()  # nothing in flight when the graphs and the arenas are torn down
