@@ -517,10 +517,9 @@ extern "C" int tfpp_attn_supported(const tfpp_attn_params* p, int dtype) {
 
 template <int NKS> static int launch_attn_fwd(const tfpp_attn_params& p, hipStream_t st) {
   constexpr size_t lds = 2 * K_SLICE_BYTES + V_IMG_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;
+  if (tfpp_first_use_on_this_device(&attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<NKS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   hipLaunchKernelGGL(attn_fwd_kernel<NKS>, dim3(p.T / ATT_TQ, p.B * p.nh), dim3(256), lds, st, p);
   TFPP_CHECK_LAUNCH();
@@ -547,11 +546,10 @@ extern "C" int tfpp_attn_window_fwd(const tfpp_attn_params* p, int dtype, void* 
   constexpr size_t lds = 2 * K_SLICE_BYTES + V_IMG_BYTES;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((p->T + ATT_TQ - 1) / ATT_TQ, p->B * p->nh);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;
+  if (tfpp_first_use_on_this_device(&attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   if (p->d <= 32) hipLaunchKernelGGL((attn_fwd_kernel<1, true>), grid, dim3(256), lds, st, *p);
   else hipLaunchKernelGGL((attn_fwd_kernel<2, true>), grid, dim3(256), lds, st, *p);
@@ -580,11 +578,10 @@ extern "C" int tfpp_window_bias_dense(const float* table, const int32_t* rel_ind
 
 template <int NKS> static int launch_attn_bwd(const tfpp_attn_params& p, hipStream_t st) {
   constexpr size_t lds = 2 * K_SLICE_BYTES + V_IMG_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;
+  if (tfpp_first_use_on_this_device(&attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<NKS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<NKS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   const dim3 grid(p.T / ATT_TQ, p.B * p.nh);
   hipLaunchKernelGGL(attn_bwd_dq_kernel<NKS>, grid, dim3(256), lds, st, p);   // also writes delta[]

@@ -100,6 +100,17 @@ __device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned
   return ((float)(r >> 8) * (1.0f / 16777216.0f)) < p ? 0.f : inv_keep;
 }
 
+// Per-device one-time set-up in host launchers (dynamic-LDS attributes): a process may drive more than one GPU, so the "already
+// done" flag is a bit per device ordinal, not one bool per process.
+static inline bool tfpp_first_use_on_this_device(unsigned long long* mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (*mask & bit) return false;
+  *mask |= bit;
+  return true;
+}
+
 #define TFPP_CHECK_LAUNCH()                                   \
   do {                                                        \
     hipError_t e__ = hipGetLastError();                       \

@@ -239,10 +239,9 @@ template <int FN, int CV> int launch_halo(const tfpp_conv_params& p, hipStream_t
   if (geo != 0) {
     if constexpr (FN <= 2 && (CV == 0 || CV == 3)) {  // RegNet group width 24 (unrolled staging) or the run-time loop
       if (p.bns_partial) return TFPP_EINVAL;
-      static bool attr_set = false;
-      if (!attr_set) {  // the 17 x 65 input halo of the stride-2 forward needs > 64 KB with 24 channels
+      static unsigned long long attr_mask = 0;
+      if (tfpp_first_use_on_this_device(&attr_mask)) {  // the 17 x 65 input halo of the stride-2 forward needs > 64 KB with 24 channels
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<FN, CV, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-        attr_set = true;
       }
       if (geo == 1) hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, false, 1>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
       else hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, false, 2>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);

@@ -507,15 +507,14 @@ template <int BM, int BN, int NSTAGE, int WGM, int WGN, int KS = 1> static int l
   dim3 grid(cdiv(p.n_g, BN), cdiv(M, BM), p.G * (p.splitk > 1 ? p.splitk : 1));
   const size_t lds = (size_t)NSTAGE * (BM + BN) * 64 * KS;
   constexpr bool HAS_PW = true;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;
+  if (tfpp_first_use_on_this_device(&attr_mask)) {
     constexpr bool BNS_OK = (WGM * WGN <= 8);
     const void* fns[4] = {reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, false, false>),
                           reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, BNS_OK, false>),
                           reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, false, HAS_PW>),
                           reinterpret_cast<const void*>(&conv_gemm_glds_kernel<BM, BN, NSTAGE, WGM, WGN, KS, BNS_OK, HAS_PW>)};
     for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   static const int trace = [] { const char* e = std::getenv("TFPP_GLDS_TRACE"); return (e && e[0] == '1') ? 1 : 0; }();
   // small weight panels (<= 6 MB per group, measured: 1512x1512 gains, 6048x1512 loses): M-major order (see the kernel)

@@ -553,10 +553,9 @@ template <int BM, int BN, bool MF32, int SR = 32> static int launch_pp(const tfp
   const int per = cdiv(map.tm, map.xm) * cdiv(map.tn, map.xn);
   dim3 grid(8 * per, p.splitk > 1 ? p.splitk : 1, 1);
   const size_t lds = (size_t)2 * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;
+  if (tfpp_first_use_on_this_device(&attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BM, BN, MF32, SR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_gemm_pp_kernel<BM, BN, MF32, SR>), grid, dim3(512), lds, st, p, map);
   TFPP_CHECK_LAUNCH();

@@ -408,13 +408,12 @@ template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE> int launch_wgra
   static const size_t min_lds = [] { const char* e = std::getenv("TFPP_WGRAD_MIN_LDS"); return e ? (size_t)std::atol(e) : (size_t)0; }();
   constexpr size_t need = (size_t)NSTAGE * BKP * (TM + TN) * 2;
   const size_t lds = need > min_lds ? need : min_lds;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;
+  if (tfpp_first_use_on_this_device(&attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_glds_kernel<TM, TN, WGM, WGN, BKP, NSTAGE, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_glds_kernel<TM, TN, WGM, WGN, BKP, NSTAGE, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   dim3 grid((unsigned)((long)p.G * p.splits * cdiv(p.n_g, TM) * cdiv(KK, TN)));
   // lean loop: pointwise layer whose operand byte offsets fit 32 bits (TFPP_WGRAD_PW=0: the general loop, for A/B runs)

@@ -440,10 +440,9 @@ extern "C" int tfpp_nms_rotated(const float* boxes, int n, int stride, int conf_
                                 int32_t* count, double* iou_out, void* stream) {
   if (!boxes || !keep || !count || n < 0 || n > NMS_MAX_BOXES || stride < 5 || conf_idx < 0 || conf_idx >= stride) return TFPP_EINVAL;
   const size_t lds = 2 * NMS_THREADS * sizeof(NmsPoly) + (size_t)n * 8 * sizeof(double) + (size_t)n * 3 * sizeof(int) + 64;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;
+  if (tfpp_first_use_on_this_device(&attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_rotated_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    attr_set = true;
   }
   hipLaunchKernelGGL(nms_rotated_kernel, dim3(1), dim3(NMS_THREADS), lds, (hipStream_t)stream, boxes, n, stride, conf_idx, iou_threshold, min_conf, keep, count, iou_out);
   TFPP_CHECK_LAUNCH();

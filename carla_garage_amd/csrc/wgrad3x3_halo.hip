@@ -132,10 +132,9 @@ size_t halo_lds_bytes(const tfpp_wgrad_params& p, int fnn) {
 template <int FNN, int CV> int launch(const tfpp_wgrad_params& p, int nblk, hipStream_t st) {
   const int tiles_w = cdiv(p.Wd, TW), tiles_h = cdiv(p.Hd, TH);
   const size_t lds = halo_lds_bytes(p, FNN);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;
+  if (tfpp_first_use_on_this_device(&attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_halo_kernel<FNN, CV>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-    attr_set = true;
   }
   hipLaunchKernelGGL((wgrad3x3_halo_kernel<FNN, CV>), dim3((unsigned)nblk, (unsigned)p.G), dim3(256), lds, st, p, tiles_w, tiles_h, nblk);
   TFPP_CHECK_LAUNCH();

@@ -76,17 +76,31 @@ class FlatAdamW(torch.optim.Optimizer):
       step = tr.model.__dict__.get('_dropin_step')
       pairs = ([(p, tr.eng.g(p)) for _, p in members] if step is None or step.tr is not tr else
                step._grad_views() + step._foreign_views() + [(step.anchor, tr.eng.g(step.anchor))])  # (cached views: the identity test below is 0.2 ms for 1332 parameters)
+      skipped = []
       for p, slot in pairs:
         g = p.grad
         if g is slot:
           continue
         if g is None:
-          ops.zero_(slot)  # (torch skips such a parameter; the fused kernel decays it -- every parameter of this model receives a gradient)
+          # torch.optim.AdamW skips a parameter without a gradient (no decay, no moment update): the fused kernel walks the whole arena, so the
+          # parameter and its three state slices are saved here and put back after the launch (unused heads; rare and small)
+          ops.zero_(slot)
+          skipped.append(p)
         elif g.data_ptr() != slot.data_ptr():
           ops.copy_rows(g.detach().float().contiguous(), slot, 1, slot.numel(), 0, 0, 0, 0)
       tr.lr, tr.betas, tr.eps = float(group['lr']), tuple(group['betas']), float(group['eps'])  # (the weight decay(s): set_groups above)
+      saved = []
+      if skipped:
+        tr._alloc_state()
+        base = tr.flat_param.data_ptr()
+        for p in skipped:
+          off, n = (p.data_ptr() - base) // 4, p.numel()
+          saved.append((off, n, [a[off:off + n].clone() for a in (tr.flat_param, tr.exp_avg, tr.exp_avg_sq, tr.max_exp_avg_sq)]))
       tr.step_count += 1
       tr._optimizer(tr.step_count, grad_scale=1.0)
+      for off, n, keep in saved:
+        for a, k in zip((tr.flat_param, tr.exp_avg, tr.exp_avg_sq, tr.max_exp_avg_sq), keep):
+          ops.copy_rows(k, a[off:off + n], 1, n, 0, 0, 0, 0)
     for group, p in loose:
       if p.grad is None:
         continue
@@ -102,6 +116,8 @@ class FlatAdamW(torch.optim.Optimizer):
 
   # ---------------------------------------------------------------------------------------------- checkpoint / resume
   def state_dict(self):
+    if self._pending_state is not None:  # loaded before the first step and not applied yet: that IS the state
+      return self._pending_state
     arenas, loose = self._arenas()
     if len(arenas) == 1 and not loose:
       tr = next(iter(arenas))
@@ -114,8 +130,6 @@ class FlatAdamW(torch.optim.Optimizer):
           if k != 'params' and k not in out:
             out[k] = v
       return sd
-    if not arenas and self._pending_state is not None:
-      return self._pending_state
     if not arenas:  # before the first training step: no state yet
       return {'state': {}, 'param_groups': [{**{k: v for k, v in g.items() if k != 'params'}, 'params': list(range(len(g['params'])))} for g in self.param_groups]}
     raise NotImplementedError('FlatAdamW.state_dict: the parameters of one model')

@@ -210,6 +210,45 @@ def test_amp_autocast_and_grad_scaler_leave_the_step_unchanged():
   assert float((d1 - d0).norm() / d0.norm()) < 0.05
 
 
+def test_fused_optimizer_leaves_a_parameter_without_gradient_alone_like_torch_and_keeps_a_loaded_state():
+  """torch.optim.AdamW skips a parameter whose .grad is None (no weight decay, no moment update); the fused kernel walks the whole arena, so
+  FlatAdamW restores such a parameter and its state after the launch.  And a state loaded before the first step is what
+  state_dict() returns until that step has applied it."""
+  from carla_garage_amd.losses import normalized_loss_weights
+  from carla_garage_amd.optim import FlatAdamW
+  m = TD._model()
+  opt = FlatAdamW(m.parameters(), lr=1e-2, amsgrad=True, weight_decay=0.1)
+  w = normalized_loss_weights(m.config)
+  TD.train_py_loop(m, opt, TD._batches(1), w)                       # one ordinary step: arenas and state exist
+  plist = list(m.parameters())
+  victim, other = m.target_speed_network[2].bias, m.target_speed_network[0].weight
+  vi = next(i for i, q in enumerate(plist) if q is victim)
+  b = TD._batches(2)[1]
+  pred = m(rgb=b['rgb'], lidar_bev=b['lidar_bev'], target_point=b['target_point'], ego_vel=b['ego_vel'], command=b['command'])
+  lab = {k: v for k, v in b.items() if k.endswith('_label')}
+  ls = m.compute_loss(pred_wp=pred[0], pred_target_speed=pred[1], pred_checkpoint=pred[2], pred_semantic=pred[3], pred_bev_semantic=pred[4],
+                      pred_depth=pred[5], pred_bounding_box=pred[6], pred_wp_1=pred[8], selected_path=pred[9], **lab)
+  sum(w[k] * v for k, v in ls.items()).backward()
+  victim.grad = None
+  before = (victim.detach().clone(), other.detach().clone(), {k: v.clone() for k, v in opt.state_dict()['state'][vi].items()})
+  opt.step()
+  torch.cuda.synchronize()
+  assert torch.equal(victim.detach(), before[0])                    # untouched: not even decayed
+  assert not torch.equal(other.detach(), before[1])                 # everything else stepped
+  after = opt.state_dict()['state'][vi]
+  for k in ('exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'):
+    assert torch.equal(after[k], before[2][k]), k
+  # a state loaded before the first step of a fresh optimizer is not lost by an early state_dict()
+  sd = opt.state_dict()
+  m2 = TD._model()
+  opt2 = FlatAdamW(m2.parameters(), lr=1e-2, amsgrad=True, weight_decay=0.1)
+  opt2.load_state_dict(sd)
+  got = opt2.state_dict()
+  assert got['state'].keys() == sd['state'].keys() and torch.equal(got['state'][vi]['exp_avg'], sd['state'][vi]['exp_avg'])
+  TD.train_py_loop(m2, opt2, TD._batches(1), w)                      # the first step applies it
+  assert float(opt2.state_dict()['state'][vi]['step']) == float(sd['state'][vi]['step']) + 1
+
+
 def _free_port():
   with socket.socket() as s:
     s.bind(('127.0.0.1', 0))
