@@ -32,6 +32,17 @@ def exchange_enabled(group=None):
   return dist.get_world_size(group) > 1 or os.environ.get('TFPP_FORCE_COLLECTIVES', '0') == '1'
 
 
+def assert_same_on_every_rank(value, what, device, group=None):
+  """Raises on EVERY rank when the ranks hold different values of the 63-bit integer ``value`` (one tiny MIN / MAX all-reduce pair): used for
+  things that must agree for the exchange to be meaningful -- the layout of the gradient arena is observed per rank."""
+  if not exchange_enabled(group):
+    return
+  t = torch.tensor([value, -value], dtype=torch.int64, device=device)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+  if int(t[0]) != -int(t[1]):
+    raise RuntimeError(f'carla_garage_amd: the ranks disagree on {what}: the gradient exchange would mix different parameters')
+
+
 def broadcast_state(flat_param, buffers, group=None, src=0):
   """Rank ``src``'s parameters and buffers everywhere (what the DDP constructor does, train.py:516)."""
   if not exchange_enabled(group):

@@ -11,7 +11,7 @@ reducer.  ``DropinStep`` keeps the call sites and removes the overheads:
 
 * parameters live in ONE flat fp32 arena, gradients in one flat arena (the ``Trainer`` of trainer.py, optimizer state allocated lazily);
   ``p.grad`` is set to cached views of the gradient arena (no copy), DDP only manages one small anchor parameter
-  (``LidarCenterNet._ddp_params_and_buffers_to_ignore``) and the arena is all-reduced here, overlapped with the second backward segment;
+  (``LidarCenterNet._ddp_params_and_buffers_to_ignore``) and the arena is all-reduced here bucket by bucket behind the buckets' completion signals (buckets.py), while backward still runs;
 * ``compute_loss`` returns scalars whose backward hands autograd a zero-stride token instead of a full-resolution tensor; the gradient
   of each loss w.r.t. the internal NHWC prediction is already in HBM (fused loss kernels) and is only scaled by the incoming d(total)/d(loss);
 * after ``TFPP_DROPIN_GRAPH_AFTER`` (2) eager steps of one input signature the three phases (forward / losses / backward) are captured

@@ -161,7 +161,8 @@ class LidarCenterNet(nn.Module):
   @property
   def _ddp_params_and_buffers_to_ignore(self):
     """Read by DistributedDataParallel.__init__ (train.py:516-520 wraps the module unchanged): every parameter of this class except the
-    anchor is exchanged by this package (one all-reduce of the flat gradient arena, overlapped with the second backward segment) instead
+    anchor is exchanged by this package (one all-reduce per completion-order bucket of the flat gradient arena, released by device-side
+    completion signals while backward runs: buckets.py) instead
     of by DDP's 25 MB buckets -- 1332 per-parameter hook calls and three copies of the 481 MB of gradients per step otherwise.  Parameters
     the caller registered on the module afterwards (the learnable loss weights of train.py:479-482) are NOT listed: autograd produces their
     gradients and DDP averages them over the ranks like those of any other module."""

@@ -233,6 +233,13 @@ class Trainer:
     whole arena."""
     buckets = self.eng.buckets
     buckets.executed(program)
+    offs = getattr(self, '_offsets', None)  # (None: no arena was flattened -- the schedule test drives finish_step on a stand-in)
+    if self.exchange and offs is not None and getattr(self, '_layout_agreed', None) is not offs and self.exchange_enabled():
+      # every rank observes its own backward pass: the arena layouts (bucket boundaries, parameter order) must come out the same
+      import zlib
+      sig = repr((tuple(buckets.offsets), tuple((n, off) for n, _, off in arena_layout(self.model)[0]))).encode()
+      tdist.assert_same_on_every_rank(zlib.crc32(sig) | (len(sig) << 32), 'the layout of the gradient arena', self.eng.flat_grad.device, self.pg)
+      self._layout_agreed = offs
     works = buckets.exchange(self.eng.flat_grad, program, self.pg) if self.exchange else []
     if not works:
       self._optimizer(self.step_count)

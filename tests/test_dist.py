@@ -52,6 +52,14 @@ def _worker(rank, world, port, out):
       scale = tdist.all_reduce_gradients(flat_grad, chunk_elems=4096 if step == 2 else None)
     assert scale == 1.0 / world
     flat_param, m, v, vmax = _adamw_amsgrad_ref(flat_param, flat_grad, m, v, vmax, 3e-4, 0.9, 0.999, 1e-8, 0.01, step, scale)
+  # ranks that disagree on something the exchange relies on (the arena layout is observed per rank) must ALL fail loudly, agreeing ranks pass
+  tdist.assert_same_on_every_rank(123456789, 'a value every rank computes alike', torch.device('cpu'))
+  try:
+    tdist.assert_same_on_every_rank(1000 + rank, 'the layout of the gradient arena', torch.device('cpu'))
+    raised = False
+  except RuntimeError as e:
+    raised = 'disagree on the layout' in str(e)
+  assert raised
   tmax = tdist.max_over_ranks(1.0 + rank, torch.device('cpu'))
   torch.save({'param': flat_param, 'buf': buf, 'grads': grads, 'tmax': tmax}, os.path.join(out, f'rank{rank}.pt'))
   dist.destroy_process_group()
