@@ -310,6 +310,7 @@ class DropinStep:
       # DistributedDataParallel semantics (train.py:516-520): .grad holds the MEAN over the ranks when backward returns.  One all-reduce per
       # bucket of the arena, each behind its own completion event (they started while the replay above was still running); the caller's
       # stream waits for all of them
+      tr.agree_on_layout()
       for work in eng.buckets.exchange(eng.flat_grad, program, tr.pg, avg=True):
         if work is not None:
           work.wait()

@@ -225,6 +225,17 @@ class Trainer:
   def exchange_enabled(self):
     return self.exchange and tdist.exchange_enabled(self.pg)
 
+  def agree_on_layout(self):
+    """Every rank observes its own backward pass: before the first exchange in a new arena layout the ranks compare it (bucket boundaries,
+    parameter order) and fail loudly on a mismatch instead of averaging different parameters (one tiny all-reduce per layout)."""
+    offs = getattr(self, '_offsets', None)  # (None: no arena was flattened -- the schedule test drives finish_step on a stand-in)
+    if offs is None or getattr(self, '_layout_agreed', None) is offs or not tdist.exchange_enabled(self.pg):
+      return
+    import zlib
+    sig = repr((tuple(self.eng.buckets.offsets), tuple((n, off) for n, _, off in arena_layout(self.model)[0]))).encode()
+    tdist.assert_same_on_every_rank(zlib.crc32(sig) | (len(sig) << 32), 'the layout of the gradient arena', self.eng.flat_grad.device, self.pg)
+    self._layout_agreed = offs
+
   def finish_step(self, program):
     """Gradient exchange + optimizer (outside any captured graph: RCCL is never captured).  ``program``: the completion signals of the pass
     that was just issued (Trainer.program after an eager pass, GraphedTrainStep.program for a replay).  One asynchronous all-reduce per
@@ -233,13 +244,8 @@ class Trainer:
     whole arena."""
     buckets = self.eng.buckets
     buckets.executed(program)
-    offs = getattr(self, '_offsets', None)  # (None: no arena was flattened -- the schedule test drives finish_step on a stand-in)
-    if self.exchange and offs is not None and getattr(self, '_layout_agreed', None) is not offs and self.exchange_enabled():
-      # every rank observes its own backward pass: the arena layouts (bucket boundaries, parameter order) must come out the same
-      import zlib
-      sig = repr((tuple(buckets.offsets), tuple((n, off) for n, _, off in arena_layout(self.model)[0]))).encode()
-      tdist.assert_same_on_every_rank(zlib.crc32(sig) | (len(sig) << 32), 'the layout of the gradient arena', self.eng.flat_grad.device, self.pg)
-      self._layout_agreed = offs
+    if self.exchange:
+      self.agree_on_layout()
     works = buckets.exchange(self.eng.flat_grad, program, self.pg) if self.exchange else []
     if not works:
       self._optimizer(self.step_count)
