@@ -148,7 +148,7 @@ def cpu_baseline(cfg_bs=2, budget_s=25.0, hard_timeout_s=90.0):
   return last
 
 
-def bf16_vs_fp32_gradients(batch, device, log):
+def bf16_vs_fp32_gradients(batch, device, log, state_dict=None):
   """What the benchmarked precision is: the gradients of ONE bf16 training step against the fp32 HIP step (the reference's arithmetic: use_amp = 0)
   on identical weights, batch and dropout masks -- cosine and relative L2 distance over the whole gradient arena.  (Per-tensor statistics and
   the 50-step loss curves: tests/test_model.py, profiles/rNN_model_parity_report.jsonl.)"""
@@ -159,6 +159,8 @@ def bf16_vs_fp32_gradients(batch, device, log):
   for dt_ in ('fp32', 'bf16'):
     torch.manual_seed(0)
     m = LidarCenterNet(GlobalConfig(tfpp_dtype=dt_)).to(device).train()
+    if state_dict is not None:  # the weights the timed run ended with (at initialisation the last BatchNorm of every block is zero: a shallower network)
+      m.load_state_dict(state_dict, strict=True)
     tr = Trainer(m, lr=0.0)
     tr.step_count += 1
     tr._step_body(batch)
@@ -171,7 +173,7 @@ def bf16_vs_fp32_gradients(batch, device, log):
   a = torch.cat([grads['fp32'][n] for n in names])
   b = torch.cat([grads['bf16'][n] for n in names])
   out = {'arena_cosine': round(float((a * b).sum() / (a.norm() * b.norm())), 5), 'arena_rel_l2': round(float((b - a).norm() / a.norm()), 4),
-         'elements': int(a.numel())}
+         'elements': int(a.numel()), 'weights': 'as left by the timed bf16 run' if state_dict is not None else 'initialisation'}
   log(f'bf16 vs fp32 gradients of one step: {out}')
   return out
 
@@ -758,7 +760,7 @@ def main():
       fp32_leg = {'ms_per_step': round(ms32, 3), 'samples_per_s': round(args.batch_size / (ms32 * 1e-3), 1), 'dtype': 'fp32', 'steps': n32,
                   'final_weighted_loss': round(float(tr32.total_loss(v32)), 5)}
       log(f'fp32 step bs={args.batch_size}: {fp32_leg}')
-      fp32_leg['bf16_vs_fp32_gradients'] = bf16_vs_fp32_gradients(batch, device, log)
+      fp32_leg['bf16_vs_fp32_gradients'] = bf16_vs_fp32_gradients(batch, device, log, {k: v.detach().clone() for k, v in model.state_dict().items()})
       del g32, tr32, m32
       torch.cuda.empty_cache()
     except Exception as e:  # pylint: disable=broad-except
