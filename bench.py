@@ -761,6 +761,7 @@ def main():
                   'final_weighted_loss': round(float(tr32.total_loss(v32)), 5)}
       log(f'fp32 step bs={args.batch_size}: {fp32_leg}')
       fp32_leg['bf16_vs_fp32_gradients'] = bf16_vs_fp32_gradients(batch, device, log, {k: v.detach().clone() for k, v in model.state_dict().items()})
+      fp32_leg['bf16_vs_fp32_gradients_at_init'] = bf16_vs_fp32_gradients(batch, device, log)
       del g32, tr32, m32
       torch.cuda.empty_cache()
     except Exception as e:  # pylint: disable=broad-except
