@@ -22,7 +22,6 @@ No fallback computes anything outside libtfpp_hip.so: unsupported uses raise."""
 import os
 
 import torch
-import torch.distributed as dist
 
 from . import dist as tdist
 from . import ops

@@ -8,7 +8,6 @@ without Python or launch overhead -- with one rank and with eight: the arena is 
 gradients (engine.arena_layout, observed on the first eager passes), every bucket is all-reduced behind its own completion event while
 the rest of backward runs (buckets.py), and the optimizer updates a bucket as soon as it has landed.
 """
-import os
 
 import torch
 import torch.distributed as dist
