@@ -759,10 +759,11 @@ class Engine:
       self._pack_stream.wait_stream(cur)
       with torch.cuda.stream(self._pack_stream):
         ent['plan'].launch(1)
+        self._refresh_small()  # (padded biases of the heads / decoders: first read long after the join)
       self._pack_pending = True
     else:
       ent['plan'].launch()
-    self._refresh_small()
+      self._refresh_small()
 
   def _join_pack(self):
     if self._pack_pending:
@@ -858,7 +859,13 @@ class Engine:
     sig = (tuple(id(p) for p in self.m.parameters() if p.requires_grad), id(self.m.__dict__.get('_grad_buckets')))
     if self.flat_grad is not None and sig == getattr(self, '_grad_sig', None) and self.flat_grad.device == self.device:
       if zero:
-        ops.zero_(self.flat_grad)
+        if zero == 'beside_forward' and self._pack_pending:
+          # 481 MB of memset that nothing reads before backward: on the weight-repack stream, beside the first layers of forward (joined at the
+          # first fusion point, Engine._join_pack), instead of in front of the stem on lane 0
+          with torch.cuda.stream(self._pack_stream):
+            ops.zero_(self.flat_grad)
+        else:
+          ops.zero_(self.flat_grad)
         ops.clear_stats_rows(self.device)
       return
     self._grad_sig = sig

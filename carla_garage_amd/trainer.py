@@ -148,7 +148,7 @@ class Trainer:
     ops.stamp('step lane0 START')
     eng.repack(eng.dtype, True, defer=True)
     ops.stamp('step lane0 weights repacked')
-    eng.alloc_grads()
+    eng.alloc_grads(zero='beside_forward')  # (the 481 MB memset runs on the repack stream beside the first layers: -0.05 ms, A/B x3)
     ops.inc_u64(self.seed_offset)
     eng._seed_ctr = 0  # the per-call part of the seeds is a function of the call site only
     eng.tape = Tape(eng.lanes)
