@@ -35,7 +35,7 @@ def exchange_enabled(group=None):
 def assert_same_on_every_rank(value, what, device, group=None):
   """Raises on EVERY rank when the ranks hold different values of the 63-bit integer ``value`` (one tiny MIN / MAX all-reduce pair): used for
   things that must agree for the exchange to be meaningful -- the layout of the gradient arena is observed per rank."""
-  if not exchange_enabled(group):
+  if not (dist.is_available() and dist.is_initialized()) or not exchange_enabled(group):
     return
   t = torch.tensor([value, -value], dtype=torch.int64, device=device)
   dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)

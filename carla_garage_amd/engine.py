@@ -368,6 +368,7 @@ def _fn_label(fn):
 # streams the weight-gradient lane alternates between, batch by batch; measured on the bs = 12 captured step (A/B/A/B, one box): 2: 24.38 / 24.43,
 # 3: 24.03 / 24.02, 4 (every batch of the default three forks on its own stream): 23.76 / 23.99 ms/step
 _SIDE_STREAMS = max(1, int(os.environ.get('TFPP_SIDE_STREAMS', '4')))
+_TAIL_SPLIT = int(os.environ.get('TFPP_SIDE_TAIL_SPLIT', '4'))  # streams the last batch of a pass is dealt onto (SideLane.flush)
 
 
 def _early_weights(name):
@@ -455,41 +456,50 @@ class SideLane:
     if len(self.pending) >= (self.tail_batch if self.in_tail else self.batch):
       self.flush()
 
-  def flush(self):
+  def flush(self, split=1):
+    """Issue the queued closures as one batch.  ``split`` > 1 (the LAST batch of a pass: stage-1 / stem weight gradients, issued when the main
+    chain is done and nothing else is left to run beside them) deals the closures round-robin onto that many streams of the lane: they are
+    independent launches with a few workgroups each, and on one stream they run one after the other on an otherwise idle chip."""
     if self.pending:
-      # successive batches alternate between the streams of the lane: the last batch of a pass (stage 1 / stems, issued when the main chain is
-      # done) then does not queue behind what is left of the batch before it
-      self.stream = self.streams[self.batches % len(self.streams)]
-      self.batches += 1
-      self.used.add(self.stream)
-      self.stream.wait_stream(torch.cuda.current_stream())
-      if self.lanes is not None:
-        for st in self.lanes.streams():
-          self.stream.wait_stream(st)
+      # successive batches alternate between the streams of the lane: the last batch of a pass then does not queue behind what is left of the
+      # batch before it
+      split = max(1, min(split, len(self.streams), len(self.pending)))
+      mine = [self.streams[(self.batches + j) % len(self.streams)] for j in range(split)]
+      self.stream = mine[-1]
+      self.batches += split
       seq = self.flush_seq
       self.flush_seq += 1
       self.flush_counts.append(self.count)
+      for j, st in enumerate(mine):
+        self.used.add(st)
+        st.wait_stream(torch.cuda.current_stream())
+        if self.lanes is not None:
+          for ls in self.lanes.streams():
+            st.wait_stream(ls)
+        with torch.cuda.stream(st):
+          if j == 0:
+            ops.stamp(f'side lane9 batch of {len(self.pending)} begins')
+          self.in_flush = True
+          try:
+            for fn in self.pending[j::split]:
+              fn()
+          finally:
+            self.in_flush = False
       with torch.cuda.stream(self.stream):
-        ops.stamp(f'side lane9 batch of {len(self.pending)} begins')
-        self.in_flush = True
-        try:
-          for fn in self.pending:
-            fn()
-        finally:
-          self.in_flush = False
-        ops.stamp('side lane9 batch ends')
-        if self.on_batch_end is not None:
+        if self.on_batch_end is not None or ops.STAMPS['on']:
           # "every gradient of bucket `seq` is final" = this batch AND the earlier ones (other streams of the lane) are done; the waits sit
           # behind the batch's own kernels, so they delay the event, not the batch
           for st in self.used:
             if st is not self.stream:
               self.stream.wait_stream(st)
+        ops.stamp('side lane9 batch ends')
+        if self.on_batch_end is not None:
           self.on_batch_end(seq)
       self.pending = []
 
   def join(self):
     if self.keep:
-      self.flush()
+      self.flush(split=_TAIL_SPLIT)
       for st in self.used:
         torch.cuda.current_stream().wait_stream(st)
       self.used = set()
