@@ -33,6 +33,7 @@ def test_one_rank_rccl_group_runs_the_bucketed_exchange_eager_and_behind_one_hip
     pass
   assert r['backend'] == 'nccl' and r['world'] == 1
   assert r['calls_local'] == 0                                   # the local step issues no collective
+  assert r['layout_agreements'] == 2                             # the ranks compare the arena layout once per layout (static, then observed)
   assert r['buckets_static'] == 2 and r['calls_eager_step'] == 2 and r['async_eager_step'] == 2  # before a pass has been observed: the two static buckets
   assert r['bytes_eager_step'] == r['arena_bytes']               # together exactly one pass over the 481 MB arena
   # the captured step: >= 4 buckets in completion order, every one all-reduced once, all but the last behind an in-graph completion signal
