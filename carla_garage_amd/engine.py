@@ -368,7 +368,6 @@ def _fn_label(fn):
 # streams the weight-gradient lane alternates between, batch by batch; measured on the bs = 12 captured step (A/B/A/B, one box): 2: 24.38 / 24.43,
 # 3: 24.03 / 24.02, 4 (every batch of the default three forks on its own stream): 23.76 / 23.99 ms/step
 _SIDE_STREAMS = max(1, int(os.environ.get('TFPP_SIDE_STREAMS', '4')))
-_TAIL_SPLIT = int(os.environ.get('TFPP_SIDE_TAIL_SPLIT', '4'))  # streams the last batch of a pass is dealt onto (SideLane.flush)
 
 
 def _early_weights(name):
@@ -463,7 +462,9 @@ class SideLane:
     if self.pending:
       # successive batches alternate between the streams of the lane: the last batch of a pass then does not queue behind what is left of the
       # batch before it
-      split = max(1, min(split, len(self.streams), len(self.pending)))
+      # all streams of the lane or one: dealing the batch onto SOME of them (2 or 3 of 4) runs eagerly but kills the process inside
+      # hipStreamEndCapture of ROCm 7.2 when the step is captured (round 4; the same failure as a third branch lane, see Lanes)
+      split = len(self.streams) if (split >= len(self.streams) and len(self.pending) >= len(self.streams)) else 1
       mine = [self.streams[(self.batches + j) % len(self.streams)] for j in range(split)]
       self.stream = mine[-1]
       self.batches += split
@@ -499,7 +500,7 @@ class SideLane:
 
   def join(self):
     if self.keep:
-      self.flush(split=_TAIL_SPLIT)
+      self.flush(split=len(self.streams))
       for st in self.used:
         torch.cuda.current_stream().wait_stream(st)
       self.used = set()
