@@ -233,6 +233,19 @@ __device__ __forceinline__ float grid_sum_partials(const float* __restrict__ par
   return block_sum_256(s, sm);
 }
 
+template <typename T, bool VROW> __device__ __forceinline__ void ce_store_row(T* d, const float* g, int ld) {
+  if (VROW) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+#pragma unroll
+    for (int k = 0; k < 16 / VEC; ++k)
+      if (k * VEC < ld) store_vec<T>(d + k * VEC, g + k * VEC);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < ld) d[c] = ElemTraits<T>::from_f(g[c]);
+  }
+}
+
 // pass 1 of cross entropy: ws[0] = sum_i class_weight[label_i] over non-ignored rows (fixed-order grid sum: common.cuh)
 __global__ void ce_norm_kernel(const long long* __restrict__ label, const float* __restrict__ cw, const float* __restrict__ vis, long HW,
                                float* __restrict__ ws, long rows, float* __restrict__ scratch) {
@@ -250,7 +263,9 @@ __global__ void ce_norm_kernel(const long long* __restrict__ label, const float*
 }
 
 // pass 2: loss and gradient.  denominator: pix_weight mode -> (*denom + eps)   else ws[0] (weighted mean)
-template <typename T>
+// VROW: a row (ld elements) is a whole number of aligned 16-byte vectors -> vector loads of the logits and vector stores of the gradient
+// (the full-resolution semantic map is 3.1 M rows of 8 bf16: 16 scalar loads per row made this kernel ALU / issue bound)
+template <typename T, bool VROW>
 __global__ void ce_loss_kernel(const T* __restrict__ pred, const long long* __restrict__ label, const float* __restrict__ cw,
                                const float* __restrict__ vis, const float* __restrict__ pix_weight, long pw_bstride, long HW,
                                const float* __restrict__ denom, float denom_eps, const float* __restrict__ ws, float weight,
@@ -272,8 +287,17 @@ __global__ void ce_loss_kernel(const T* __restrict__ pred, const long long* __re
     const long long l = ce_label(label, vis, i, HW);
     float v[16];
     float mx = -3.0e38f;
+    if (VROW) {
+      constexpr int VEC = ElemTraits<T>::VEC;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) { v[c] = (c < C) ? ElemTraits<T>::to_f(p[c < ld ? c : 0]) : -3.0e38f; mx = fmaxf(mx, v[c]); }
+      for (int k = 0; k < 16 / VEC; ++k)
+        if (k * VEC < ld) load_vec<T>(p + k * VEC, v + k * VEC);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { v[c] = (c < C) ? v[c] : -3.0e38f; mx = fmaxf(mx, v[c]); }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { v[c] = (c < C) ? ElemTraits<T>::to_f(p[c < ld ? c : 0]) : -3.0e38f; mx = fmaxf(mx, v[c]); }
+    }
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < 16; ++c) { v[c] = (c < C) ? __expf(v[c] - mx) : 0.f; s += v[c]; }
@@ -296,10 +320,10 @@ __global__ void ce_loss_kernel(const T* __restrict__ pred, const long long* __re
         if (dpred) {
           const float pg1 = focal_gamma == 0.f ? 0.f : focal_gamma * (focal_gamma == 1.f ? 1.f : __powf(om, focal_gamma - 1.f));
           const float coef = weight * inv * w * (pg1 * pl * lp - pg);
-          T* d = dpred + (size_t)i * ld;
+          float gout[16];
 #pragma unroll
-          for (int c = 0; c < 16; ++c)
-            if (c < ld) d[c] = ElemTraits<T>::from_f(c < C ? coef * (((c == (int)l) ? 1.f : 0.f) - v[c] * invs) : 0.f);
+          for (int c = 0; c < 16; ++c) gout[c] = c < C ? coef * (((c == (int)l) ? 1.f : 0.f) - v[c] * invs) : 0.f;
+          ce_store_row<T, VROW>(dpred + (size_t)i * ld, gout, ld);
         }
         continue;
       }
@@ -312,18 +336,17 @@ __global__ void ce_loss_kernel(const T* __restrict__ pred, const long long* __re
       }
     }
     if (dpred) {
-      T* d = dpred + (size_t)i * ld;
       const float gs = weight * inv;
       const float wp = (l >= 0) ? (1.f - smoothing) * w + smoothing / (float)C * wsum : 0.f;  // coefficient of softmax(z)_c
+      float gout[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        if (c < ld) {
-          float g = 0.f;
-          if (c < C && l >= 0)
-            g = gs * (wp * v[c] * invs - ((c == (int)l) ? (1.f - smoothing) * w : 0.f) - smoothing / (float)C * (cw ? cw[c] : 1.f));
-          d[c] = ElemTraits<T>::from_f(g);
-        }
+        float g = 0.f;
+        if (c < C && l >= 0)
+          g = gs * (wp * v[c] * invs - ((c == (int)l) ? (1.f - smoothing) * w : 0.f) - smoothing / (float)C * (cw ? cw[c] : 1.f));
+        gout[c] = g;
       }
+      ce_store_row<T, VROW>(dpred + (size_t)i * ld, gout, ld);
     }
   }
   acc = block_sum_256(acc, sm);
@@ -341,14 +364,16 @@ extern "C" int tfpp_ce_loss(const void* pred, const int64_t* label, const float*
   if (smoothing < 0.f || smoothing >= 1.f || (smoothing > 0.f && pix_weight)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   long blocks = (rows + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 1024) blocks = 1024;  // (one partial + one ticket per workgroup: 1024 x 256 threads stream at the HBM rate, 4096 tickets on one address cost more than they buy)
   if (blocks < 1) blocks = 1;
+  const int vec = dtype == TFPP_F32 ? 4 : 8;
+  const bool vrow = ld % vec == 0 && !((uintptr_t)pred & 15) && !((uintptr_t)dpred & 15);
   if (!pix_weight && focal_gamma < 0.f)
     hipLaunchKernelGGL(ce_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const long long*)label, class_weight, vis_mask, (long)HW, ws, (long)rows, scratch);
-  if (dtype == TFPP_F32)
-    hipLaunchKernelGGL(ce_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (float*)dpred, (long)rows, C, ld, smoothing, focal_gamma, scratch);
-  else
-    hipLaunchKernelGGL(ce_loss_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (bf16_t*)dpred, (long)rows, C, ld, smoothing, focal_gamma, scratch);
+#define CE_LAUNCH(TT, VR) hipLaunchKernelGGL((ce_loss_kernel<TT, VR>), dim3((unsigned)blocks), dim3(256), 0, st, (const TT*)pred, (const long long*)label, class_weight, vis_mask, pix_weight, (long)pw_bstride, (long)HW, denom, denom_eps, ws, weight, loss_out, (TT*)dpred, (long)rows, C, ld, smoothing, focal_gamma, scratch)
+  if (dtype == TFPP_F32) { if (vrow) CE_LAUNCH(float, true); else CE_LAUNCH(float, false); }
+  else { if (vrow) CE_LAUNCH(bf16_t, true); else CE_LAUNCH(bf16_t, false); }
+#undef CE_LAUNCH
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -357,46 +382,74 @@ extern "C" int tfpp_ce_loss(const void* pred, const int64_t* label, const float*
 // elem weight (NCHW with wC channels) at [(b*wC + (w_bcast?0:c))*HW + pix].
 // kind 0: L1   1: smooth-L1 (beta 1)   2: gaussian focal loss on sigmoid outputs (transfuser_utils.py:341-364)
 // loss = sum(...)/den, den = denom ? (*denom + denom_eps) * denom_mul : B*C*HW
-template <typename T>
+__device__ __forceinline__ float reg_loss_elem(int kind, float p, float t, float w, float& g) {
+  if (kind == 0) {
+    const float d = p - t;
+    g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w;
+    return fabsf(d) * w;
+  }
+  if (kind == 1) {
+    const float d = p - t, ad = fabsf(d);
+    g = (ad < 1.f ? d : (d > 0.f ? 1.f : -1.f)) * w;
+    return (ad < 1.f ? 0.5f * d * d : ad - 0.5f) * w;
+  }
+  const float eps = 1e-12f;
+  if (t == 1.f) {
+    const float om = 1.f - p, lg = __logf(p + eps);
+    g = -om * om / (p + eps) + 2.f * om * lg;
+    return -lg * om * om;
+  }
+  const float omt = 1.f - t, nw = omt * omt * omt * omt, lg = __logf(1.f - p + eps);
+  g = (p * p / (1.f - p + eps) - 2.f * p * lg) * nw;
+  return -lg * p * p * nw;
+}
+
+// One thread per pixel ROW (b, pix): the ld stored channels of a row are one or two aligned 16-byte vectors (VROW) or scalar loads; one
+// division per row instead of three 64-bit divisions per element (the full-resolution depth map is 3.1 M rows x 8 bf16).
+template <typename T, bool VROW>
 __global__ void reg_loss_kernel(const T* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ ew, int wC, int w_bcast,
                                 const float* __restrict__ denom, float denom_eps, float denom_mul, float weight, float* __restrict__ loss_out,
                                 T* __restrict__ dpred, int B, int C, long HW, long ld, int kind, float* __restrict__ scratch) {
   __shared__ float sm[4];
-  const long n = (long)B * HW * ld;
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const long nrows = (long)B * HW;
   const float den = denom ? (denom[0] + denom_eps) * denom_mul : (float)((double)B * C * HW);
   const float inv = 1.f / den;
+  const float gscale = weight * inv;
   float acc = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % ld);
-    float g = 0.f;
-    if (c < C) {
-      const long bp = i / ld;
-      const long b = bp / HW, pix = bp - b * HW;
-      const float p = ElemTraits<T>::to_f(pred[i]);
-      const float t = target[((size_t)b * C + c) * HW + pix];
-      const float w = ew ? ew[((size_t)b * wC + (w_bcast ? 0 : c)) * HW + pix] : 1.f;
-      if (kind == 0) {
-        const float d = p - t;
-        acc += fabsf(d) * w;
-        g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w;
-      } else if (kind == 1) {
-        const float d = p - t, ad = fabsf(d);
-        acc += (ad < 1.f ? 0.5f * d * d : ad - 0.5f) * w;
-        g = (ad < 1.f ? d : (d > 0.f ? 1.f : -1.f)) * w;
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (long)gridDim.x * blockDim.x) {
+    const long b = r / HW, pix = r - b * HW;
+    const T* prow = pred + (size_t)r * ld;
+    T* drow = dpred ? dpred + (size_t)r * ld : nullptr;
+    for (int c0 = 0; c0 < (int)ld; c0 += VEC) {
+      float p[VEC], g[VEC];
+      if (VROW) {
+        load_vec<T>(prow + c0, p);
       } else {
-        const float eps = 1e-12f;
-        if (t == 1.f) {
-          const float om = 1.f - p, lg = __logf(p + eps);
-          acc += -lg * om * om;
-          g = -om * om / (p + eps) + 2.f * om * lg;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) p[e] = c0 + e < (int)ld ? ElemTraits<T>::to_f(prow[c0 + e]) : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int c = c0 + e;
+        g[e] = 0.f;
+        if (c < C) {
+          const float t = target[((size_t)b * C + c) * HW + pix];
+          const float w = ew ? ew[((size_t)b * wC + (w_bcast ? 0 : c)) * HW + pix] : 1.f;
+          acc += reg_loss_elem(kind, p[e], t, w, g[e]);
+          g[e] *= gscale;
+        }
+      }
+      if (drow) {
+        if (VROW) {
+          store_vec<T>(drow + c0, g);
         } else {
-          const float omt = 1.f - t, nw = omt * omt * omt * omt, lg = __logf(1.f - p + eps);
-          acc += -lg * p * p * nw;
-          g = (p * p / (1.f - p + eps) - 2.f * p * lg) * nw;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            if (c0 + e < (int)ld) drow[c0 + e] = ElemTraits<T>::from_f(g[e]);
         }
       }
     }
-    if (dpred) dpred[i] = ElemTraits<T>::from_f(g * weight * inv);
   }
   acc = block_sum_256(acc, sm);
   if (threadIdx.x == 0) grid_publish(scratch + TFPP_GRIDSUM_TICKETS + blockIdx.x, acc);
@@ -410,14 +463,16 @@ extern "C" int tfpp_reg_loss(const void* pred, const float* target, const float*
                              int64_t ld, int kind, int dtype, void* stream) {
   if (!pred || !target || !loss_out || !scratch || ld < C) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const long n = (long)B * HW * ld;
-  long blocks = (n + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  const long nrows = (long)B * HW;
+  long blocks = (nrows + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  if (dtype == TFPP_F32)
-    hipLaunchKernelGGL(reg_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)pred, target, elem_weight, wC, w_bcast, denom, denom_eps, denom_mul, weight, loss_out, (float*)dpred, B, C, (long)HW, (long)ld, kind, scratch);
-  else
-    hipLaunchKernelGGL(reg_loss_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)pred, target, elem_weight, wC, w_bcast, denom, denom_eps, denom_mul, weight, loss_out, (bf16_t*)dpred, B, C, (long)HW, (long)ld, kind, scratch);
+  const int vec = dtype == TFPP_F32 ? 4 : 8;
+  const bool vrow = ld % vec == 0 && !((uintptr_t)pred & 15) && !((uintptr_t)dpred & 15);
+#define REG_LAUNCH(TT, VR) hipLaunchKernelGGL((reg_loss_kernel<TT, VR>), dim3((unsigned)blocks), dim3(256), 0, st, (const TT*)pred, target, elem_weight, wC, w_bcast, denom, denom_eps, denom_mul, weight, loss_out, (TT*)dpred, B, C, (long)HW, (long)ld, kind, scratch)
+  if (dtype == TFPP_F32) { if (vrow) REG_LAUNCH(float, true); else REG_LAUNCH(float, false); }
+  else { if (vrow) REG_LAUNCH(bf16_t, true); else REG_LAUNCH(bf16_t, false); }
+#undef REG_LAUNCH
   TFPP_CHECK_LAUNCH();
   return 0;
 }
