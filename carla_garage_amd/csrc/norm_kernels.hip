@@ -729,18 +729,29 @@ __global__ void layernorm_param_grad_kernel(const T* __restrict__ dy, const T* _
   sm[0][slot][cl] = sg;
   sm[1][slot][cl] = sb;
   __syncthreads();
-  // partials: [gridDim.y][2][C] behind the tickets; ticket blockIdx.x counts the row blocks of this channel block
-  float* part = scratch + TFPP_GRIDSUM_TICKETS;
+  // partials: [gridDim.y][C] pairs (dgamma, dbeta) behind the tickets -- one 8-byte agent-scope access per channel; ticket blockIdx.x counts the
+  // row blocks of this channel block.  The last block adds them with all four row slots in parallel (slot s takes row blocks s, s + 4, ...:
+  // agent-scope loads are issued one after the other, 16 instead of 64 round trips), then the four slot sums in slot order: a fixed order.
+  unsigned long long* part = reinterpret_cast<unsigned long long*>(scratch + TFPP_GRIDSUM_TICKETS);
   if (slot == 0 && c < C) {
-    grid_publish(part + ((size_t)blockIdx.y * 2 + 0) * C + c, sm[0][0][cl] + sm[0][1][cl] + sm[0][2][cl] + sm[0][3][cl]);
-    grid_publish(part + ((size_t)blockIdx.y * 2 + 1) * C + c, sm[1][0][cl] + sm[1][1][cl] + sm[1][2][cl] + sm[1][3][cl]);
+    const float tg = sm[0][0][cl] + sm[0][1][cl] + sm[0][2][cl] + sm[0][3][cl], tb = sm[1][0][cl] + sm[1][1][cl] + sm[1][2][cl] + sm[1][3][cl];
+    const unsigned long long pk = (unsigned long long)__float_as_uint(tg) | ((unsigned long long)__float_as_uint(tb) << 32);
+    __hip_atomic_store(part + (size_t)blockIdx.y * C + c, pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (!grid_last_ticket(reinterpret_cast<unsigned*>(scratch) + blockIdx.x, gridDim.y)) return;
-  if (slot < 2 && c < C) {  // wave 0: dgamma, wave 1: dbeta
-    float t = 0.f;
-    for (unsigned k = 0; k < gridDim.y; ++k) t += grid_fetch(part + ((size_t)k * 2 + slot) * C + c);
-    float* dst = slot == 0 ? dgamma : dbeta;
-    if (dst) dst[c] += t;
+  float tg = 0.f, tb = 0.f;
+  if (c < C)
+    for (unsigned k = slot; k < gridDim.y; k += 4) {
+      const unsigned long long pk = __hip_atomic_load(part + (size_t)k * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tg += __uint_as_float((unsigned)pk);
+      tb += __uint_as_float((unsigned)(pk >> 32));
+    }
+  sm[0][slot][cl] = tg;
+  sm[1][slot][cl] = tb;
+  __syncthreads();
+  if (slot == 0 && c < C) {
+    if (dgamma) dgamma[c] += sm[0][0][cl] + sm[0][1][cl] + sm[0][2][cl] + sm[0][3][cl];
+    if (dbeta) dbeta[c] += sm[1][0][cl] + sm[1][1][cl] + sm[1][2][cl] + sm[1][3][cl];
   }
 }
 
