@@ -758,6 +758,44 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, const float* __res
   float acc[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  // The column weights do not depend on the output row: computed once per thread (<= MAXR candidates: upsampling factors <= 8), not once
+  // per candidate pixel -- the index arithmetic was most of this kernel (8 launches of ~100 us on the chain at the start of backward).
+  constexpr int MAXR = 24;
+  const int nw = ow1 - ow0 + 1;
+  if (nw <= MAXR) {
+    float wwv[MAXR];
+#pragma unroll
+    for (int j = 0; j < MAXR; ++j) {
+      float ww = 0.f;
+      if (j < nw) {
+        int w0, w1; float lw;
+        bilin_coord(ow0 + j, Wi, Wo, w0, w1, lw);
+        if (w0 == wi) ww += 1.f - lw;
+        if (w1 == wi) ww += lw;
+      }
+      wwv[j] = ww;
+    }
+    for (int oh = oh0; oh <= oh1; ++oh) {
+      int h0, h1; float lh;
+      bilin_coord(oh, Hi, Ho, h0, h1, lh);
+      float wh = 0.f;
+      if (h0 == hi) wh += 1.f - lh;
+      if (h1 == hi) wh += lh;
+      if (wh == 0.f) continue;
+      const size_t rowbase = ((size_t)b * Ho + oh) * Wo + ow0;
+#pragma unroll
+      for (int j = 0; j < MAXR; ++j) {
+        if (j >= nw || wwv[j] == 0.f) continue;
+        float g[VEC];
+        load_vec<T>(dy + (rowbase + j) * dy_ld + cv * VEC, g);
+        const float wt = wh * wwv[j] * (mul ? mul[(size_t)oh * Wo + ow0 + j] : 1.f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += wt * g[e];
+      }
+    }
+    store_vec<T>(dx + (((size_t)b * Hi + hi) * Wi + wi) * dx_ld + cv * VEC, acc);
+    return;
+  }
   for (int oh = oh0; oh <= oh1; ++oh) {
     int h0, h1; float lh;
     bilin_coord(oh, Hi, Ho, h0, h1, lh);
