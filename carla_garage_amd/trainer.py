@@ -261,11 +261,19 @@ class Trainer:
     index = {id(p): i for i, p in enumerate(self.model.parameters())}
     return [(index[id(p)], off, p) for _, p, off in arena_layout(self.model)[0]]
 
+  def check_exchange_health(self):
+    """Host-side check (one device read): a completion-signal wait of the gradient exchange that gave up (buckets.WAIT_TIMEOUT_MS) means a
+    collective may have run on an incomplete bucket.  Called where the host synchronises anyway (checkpoints); raises instead of training on."""
+    n = self.eng.buckets.timed_out() if self.eng.buckets.timeouts is not None else 0
+    if n:
+      raise RuntimeError(f'carla_garage_amd: {n} completion-signal wait(s) of the gradient exchange timed out: gradients of those steps may be incomplete')
+
   def state_dict(self):
     """The optimizer state in the layout ``torch.optim.AdamW(model.parameters(), lr, amsgrad=True).state_dict()`` has in the
     reference (team_code/train.py:529-531, saved as optimizer_%04d.pth at train.py:967-976): per-parameter ``step``, ``exp_avg``,
     ``exp_avg_sq``, ``max_exp_avg_sq`` keyed by the position in ``model.parameters()`` (frozen parameters have no state), one
     parameter group.  Values are clones cut out of the flat arenas."""
+    self.check_exchange_health()
     n_params = len(list(self.model.parameters()))
     state = {}
     self._alloc_state()
