@@ -98,13 +98,11 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // combined through LDS by the rg = 0 threads in index order: independent of scheduling, bit-reproducible.  clear: re-zero what was read (the
 // conv epilogue accumulates into rows that are zero between uses, so no memset launch is needed).  Returns true in the threads that hold a
 // channel's totals.
-// CW channels per workgroup (32: 128-byte row segments; 8 for narrow layers with many rows -- 32 or 72 channels x 1536 ... 6144 M-tile rows
-// are 1 ... 3 workgroups at CW = 32, i.e. one to three CUs summing 0.4 ... 1.5 MB on the chain between a stage-1 conv and its BatchNorm apply).
-template <int NT, int CW = 32>
+template <int NT>
 __device__ __forceinline__ bool partial_cols_sum(float* __restrict__ partial, int nrows, int C, bool clear, int& c, double& s0, double& s1) {
-  constexpr int RG = NT / CW;
-  const int cl = threadIdx.x % CW, rg = threadIdx.x / CW;
-  c = (int)blockIdx.x * CW + cl;
+  constexpr int RG = NT / 32;
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  c = (int)blockIdx.x * 32 + cl;
   double a = 0.0, b = 0.0;
   if (c < C) {
     int k = rg;
@@ -134,7 +132,7 @@ __device__ __forceinline__ bool partial_cols_sum(float* __restrict__ partial, in
       if (clear) { row[c] = 0.f; row[C + c] = 0.f; }
     }
   }
-  __shared__ double sm[2][RG][CW + 1];
+  __shared__ double sm[2][RG][33];
   sm[0][rg][cl] = a;
   sm[1][rg][cl] = b;
   __syncthreads();
@@ -238,7 +236,7 @@ extern "C" int tfpp_bn_finalize(const double* ws, const float* gamma, const floa
 // The same from accumulation rows (tfpp_conv_params.stats_partial); re-zeroes the rows it consumed.  WIDE = false: one wave
 // per channel (<= 256 rows); WIDE = true: one 256-thread workgroup per channel (one row per M-tile on the large feature
 // maps: up to 1536 rows), combined through LDS in a fixed order -- the sum is independent of scheduling either way.
-template <int NT, int CW = 32>
+template <int NT>
 __global__ __launch_bounds__(NT) void bn_finalize_partials_kernel(float* __restrict__ partial, int nrows, const float* __restrict__ gamma,
                                             const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv,
                                             long long* __restrict__ nbt, float* __restrict__ scale, float* __restrict__ shift,
@@ -247,7 +245,7 @@ __global__ __launch_bounds__(NT) void bn_finalize_partials_kernel(float* __restr
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   int c;
   double s0, s1;
-  if (!partial_cols_sum<NT, CW>(partial, nrows, C, clear != 0, c, s0, s1)) return;
+  if (!partial_cols_sum<NT>(partial, nrows, C, clear != 0, c, s0, s1)) return;
   const double n = (double)rows;
   const double m = s0 / n;
   double var = s1 / n - m * m;
@@ -269,11 +267,7 @@ extern "C" int tfpp_bn_finalize_partials(float* partial, int nrows, int clear, c
                                          float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
                                          float* save_invstd, int64_t rows, int C, float momentum, float eps, void* stream) {
   if (!partial || nrows < 1 || !scale || !shift) return TFPP_EINVAL;
-  if (nrows > 128 && C <= 256)
-    hipLaunchKernelGGL((bn_finalize_partials_kernel<1024, 8>), dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, nrows, gamma, beta,
-                       running_mean, running_var, (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd, (long)rows, C,
-                       momentum, eps, clear);
-  else if (nrows > 128)
+  if (nrows > 128)
     hipLaunchKernelGGL(bn_finalize_partials_kernel<1024>, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial, nrows, gamma, beta,
                        running_mean, running_var, (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd, (long)rows, C,
                        momentum, eps, clear);
