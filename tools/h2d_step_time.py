@@ -54,6 +54,11 @@ def main(bs=12, steps=30, nhost=4):
   timed(DeviceBatchPrefetcher(many[:3], cfg))
   res['prefetcher_ms'] = timed(DeviceBatchPrefetcher(many, cfg))
   res['resident_ms'] = timed(None for _ in many)
+  # ... and with the loader's colour augmentation on the device (carla_garage_amd/augment.py: programs sampled on the host, stages on the copy stream)
+  from carla_garage_amd.augment import ImageAugmenter
+  aug = ImageAugmenter(prob=0.5, seed=1)
+  timed(DeviceBatchPrefetcher(many[:3], cfg, augment=aug))
+  res['prefetcher_with_augmentation_ms'] = timed(DeviceBatchPrefetcher(many, cfg, augment=aug))
   # diagnostics: the upload path alone (no step), and the step fed by the prefetcher but replaying on its resident copy
   torch.cuda.synchronize()
   t0 = time.perf_counter()
