@@ -403,7 +403,7 @@ class SideLane:
     self.count = 0
     fa = os.environ.get('TFPP_SIDE_FLUSH_AT', '')
     self.flush_at = {int(v) for v in fa.split(',') if v} if fa else None
-    self.forks = [float(v) for v in os.environ.get('TFPP_SIDE_FORKS', '0.43,0.77,0.95').split(',') if v and float(v) > 0]
+    self.forks = [float(v) for v in os.environ.get('TFPP_SIDE_FORKS', '0.46,0.80,0.95').split(',') if v and float(v) > 0]
     self.total_prev = 0  # closures of the previous pass (the eager warm-up in front of a capture counts them)
     self.last_flush_counts = []  # closure counts at the flushes of the previous pass
     self.stream = None
@@ -441,7 +441,8 @@ class SideLane:
     self.count += 1
     if self.flush_at is None and self.forks and self.total_prev:
       # fork points as fractions of the pass (the previous pass of this engine counted its closures): round 3 swept them on the bs = 12 step
-      # (334 closures): TWO forks, in the middle of fusion transformer 3's backward (0.43) and when stage 3 of both encoders is done (0.77),
+      # (334 closures then; 374 in round 4, re-swept: 0.46 / 0.80 / 0.95 = closures 172 / 299 / 355, -0.17 ms against 0.43 / 0.77, profiles/r04_fork_sweep.txt):
+      # TWO forks, in the middle of fusion transformer 3's backward (0.43) and when stage 3 of both encoders is done (0.77),
       # give 26.0 ms/step; any third fork costs ~2 ms, one fork ~2.5 ms, moving the second one 8 closures earlier 1.4 ms (tools/sweep_flush.sh)
       if self.count in {max(1, int(round(f * self.total_prev))) for f in self.forks}:
         self.flush()
