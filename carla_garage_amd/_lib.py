@@ -215,6 +215,10 @@ class _Lib:
     if not os.path.exists(LIB_PATH):
       raise TfppError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                       '(there is no PyTorch/CPU fallback for the HIP path)')
+    # torch first: its wheel carries its own libamdhip64, and the library must bind to THAT copy of the HIP runtime (same SONAME: the loader
+    # reuses what is already mapped).  Loaded before torch, libtfpp_hip.so pulls in /opt/rocm's copy, the process ends up with two runtimes and
+    # every launch of this library fails with hipErrorNoDevice once torch has opened the device (seen with build() and smoke() in one process).
+    import torch  # noqa: F401
     self._dll = ctypes.CDLL(LIB_PATH)
     for name, argtypes in declared_functions().items():
       fn = getattr(self._dll, name)  # AttributeError if the library does not export a declared symbol
