@@ -1300,6 +1300,18 @@ def test_focal_loss_vs_torch(ops, gamma):
   assert float(dp[:, C:].abs().max()) == 0.0
 
 
+def test_library_loaded_before_torch_touches_the_gpu_still_launches():
+  """__graft_entry__.build() loads libtfpp_hip.so (to check its exports) and smoke() may follow in the same process: the library has to bind
+  to the HIP runtime torch uses, whatever was loaded first (two runtimes in one process = hipErrorNoDevice on every launch)."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  code = ('from carla_garage_amd import _lib\n_lib.lib.load()\nimport torch\nfrom carla_garage_amd import ops\n'
+          'x = torch.ones(1024, device="cuda")\nops.zero_(x)\ntorch.cuda.synchronize()\nassert float(x.abs().sum()) == 0.0\nprint("ok")')
+  r = subprocess.run([sys.executable, '-c', code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, check=False)
+  assert r.returncode == 0 and r.stdout.decode().strip().endswith('ok'), r.stdout.decode()[-2000:]
+
+
 def test_grid_sums_are_bit_reproducible_and_streams_do_not_share_tickets(ops):
   """The grid-wide sums of the loss kernels, the cross-entropy normaliser and the LayerNorm parameter gradients are added in a fixed order by
   the workgroup that draws the last ticket (csrc/common.cuh): the results must be bit-identical launch after launch at the training sizes
