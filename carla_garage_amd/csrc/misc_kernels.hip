@@ -565,66 +565,8 @@ static int launch_adamw(float* p, const float* g, float* m, float* v, float* vma
   return 0;
 }
 
-// The same update with the step-dependent scalars in DEVICE memory: hyper = {lr, beta1, beta2, eps, weight_decay, grad_scale, bc1, bc2_sqrt}
-// (bc1 = 1 - beta1^step, bc2_sqrt = sqrt(1 - beta2^step), computed by the host exactly as tfpp_adamw_amsgrad computes them).  A launch with
-// constant arguments can sit INSIDE a captured step: the trainer updates the early-finishing two thirds of the parameters on the
-// weight-gradient lane while the rest of backward still runs, and uploads `hyper` before every replay.
-__global__ void adamw_amsgrad_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                         float* __restrict__ vmax, long n, const float* __restrict__ hyper) {
-  const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], wd = hyper[4], grad_scale = hyper[5], bc1 = hyper[6], bc2_sqrt = hyper[7];
-  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  const long stride = (long)gridDim.x * blockDim.x * 4;
-  for (; i < n; i += stride) {
-    if (i + 3 < n) {
-      float4 pp = *reinterpret_cast<float4*>(p + i), gg = *reinterpret_cast<const float4*>(g + i), mm = *reinterpret_cast<float4*>(m + i),
-             vv = *reinterpret_cast<float4*>(v + i), xx = *reinterpret_cast<float4*>(vmax + i);
-      float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x; float* xa = &xx.x;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float gr = ga[e] * grad_scale;
-        pa[e] *= (1.f - lr * wd);
-        ma[e] = beta1 * ma[e] + (1.f - beta1) * gr;
-        va[e] = beta2 * va[e] + (1.f - beta2) * gr * gr;
-        xa[e] = fmaxf(xa[e], va[e]);
-        pa[e] -= (lr / bc1) * ma[e] / (sqrtf(xa[e]) / bc2_sqrt + eps);
-      }
-      *reinterpret_cast<float4*>(p + i) = pp; *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv;
-      *reinterpret_cast<float4*>(vmax + i) = xx;
-    } else {
-      for (long j = i; j < n; ++j) {
-        const float gr = g[j] * grad_scale;
-        float pj = p[j] * (1.f - lr * wd);
-        const float mj = beta1 * m[j] + (1.f - beta1) * gr;
-        const float vj = beta2 * v[j] + (1.f - beta2) * gr * gr;
-        const float xj = fmaxf(vmax[j], vj);
-        pj -= (lr / bc1) * mj / (sqrtf(xj) / bc2_sqrt + eps);
-        p[j] = pj; m[j] = mj; v[j] = vj; vmax[j] = xj;
-      }
-    }
-  }
-}
-
-extern "C" int tfpp_adamw_amsgrad_dev(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, const float* hyper, void* stream) {
-  if (!p || !g || !m || !v || !vmax || !hyper) return TFPP_EINVAL;
-  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) return TFPP_EINVAL;
-  long blocks = (n / 4 + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adamw_amsgrad_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, (long)n, hyper);
-  TFPP_CHECK_LAUNCH();
-  return 0;
-}
-
-// the step-dependent scalars of tfpp_adamw_amsgrad, as it computes them (for the `hyper` vector of tfpp_adamw_amsgrad_dev)
-extern "C" int tfpp_adamw_bias_corrections(float beta1, float beta2, int step, float* bc1_out, float* bc2_sqrt_out) {
-  if (!bc1_out || !bc2_sqrt_out || step < 1) return TFPP_EINVAL;
-  *bc1_out = 1.f - powf(beta1, (float)step);
-  *bc2_sqrt_out = sqrtf(1.f - powf(beta2, (float)step));
-  return 0;
-}
-
 // scratch of the fixed-order grid sums (common.cuh): 64 ticket counters + the partials of the largest user (LayerNorm parameter gradients:
-// 64 row blocks x 2 x C <= 3072; the loss kernels publish <= 4096 partials).  Zero before the first use; one buffer per stream.
+// 64 row blocks x 2 x C <= 3072; the loss kernels publish <= 1024 partials).  Zero before the first use; one buffer per stream.
 extern "C" int tfpp_gridsum_scratch_floats(void) { return TFPP_GRIDSUM_TICKETS + 64 * 2 * 3072; }
 
 extern "C" int tfpp_version(void) { return TFPP_ABI_VERSION; }

@@ -339,11 +339,6 @@ def cast(x, dtype):
   return out
 
 
-def cast_into(x, out):
-  lib.tfpp_cast(ptr(_chk(x)), ptr(out), x.numel(), dt(x), dt(out), stream())
-  return out
-
-
 # ------------------------------------------------------------------------------------------------ layout
 def nchw_to_nhwc_affine(x, dtype, cpad, mul=None, add=None):
   b, c, h, w = x.shape
@@ -975,13 +970,3 @@ def no_decay_bitmask(slices, no_decay_ids, total):
       bits[off // 4:(off + n + 3) // 4] = True
   words = np.packbits(bits.reshape(-1, 32), axis=1, bitorder='little').view('<u4').reshape(-1)
   return words.astype(np.uint32).view(np.int32)
-
-
-def adamw_amsgrad_dev(p, g, m, v, vmax, hyper):
-  lib.tfpp_adamw_amsgrad_dev(ptr(p), ptr(g), ptr(m), ptr(v), ptr(vmax), p.numel(), ptr(hyper), stream())
-
-
-def adamw_bias_corrections(beta1, beta2, step):
-  a, b = ctypes.c_float(0), ctypes.c_float(0)
-  lib.tfpp_adamw_bias_corrections(float(beta1), float(beta2), int(step), ctypes.byref(a), ctypes.byref(b))
-  return a.value, b.value

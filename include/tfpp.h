@@ -540,11 +540,6 @@ int tfpp_adamw_amsgrad(float* p, const float* g, float* m, float* v, float* vmax
  * one bit per 4 consecutive elements of the arena starting at p (every parameter starts on a multiple of 4); set = weight_decay 0. */
 int tfpp_adamw_amsgrad_groups(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1, float beta2,
                               float eps, float weight_decay, int step, float grad_scale, const uint32_t* no_decay_bits, void* stream);
-/* the same update with {lr, beta1, beta2, eps, weight_decay, grad_scale, 1 - beta1^step, sqrt(1 - beta2^step)} read from DEVICE memory, so that
- * the launch can be part of a captured step (the early-finishing slice of the arena is updated while backward still runs); the host fills
- * the last two entries with tfpp_adamw_bias_corrections (host function, no launch). */
-int tfpp_adamw_amsgrad_dev(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, const float* hyper, void* stream);
-int tfpp_adamw_bias_corrections(float beta1, float beta2, int step, float* bc1_out, float* bc2_sqrt_out);
 
 #ifdef __cplusplus
 }
