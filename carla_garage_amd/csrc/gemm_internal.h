@@ -30,3 +30,31 @@ int conv_wgrad_glds(const tfpp_wgrad_params& p, int tile, hipStream_t st);
 // 3x3 / stride 1 weight gradient with LDS-staged halo tiles (wgrad3x3_halo.hip), bf16, n_g, ks_g <= 64: slices per group (0 = n/a)
 int wgrad_halo_slices(const tfpp_wgrad_params& p, int dtype);
 int conv_wgrad_halo(const tfpp_wgrad_params& p, int nblk, hipStream_t st);
+
+// Grouped pointwise weight gradients (gemm_wgrad_glds.hip conv_wgrad_glds_group_kernel, gemm_kernels.hip wgrad_reduce_group_kernel): the
+// descriptor table of one launch, passed BY VALUE as the kernel argument (<= 4 KB), so that a captured hipGraph node carries it and no
+// device-side table has to be kept consistent with the replays.  One item = one layer: dW[n_g][KK] += dY[P][n_g]^T X[P][KK].
+struct tfpp_wgrad_item {
+  const void* dy; const void* x; float* dw; float* ws; const int* row_map; const int* col_map;
+  int P, n_g, KK, c_real, splits, dy_ld, x_ld, dw_ld;
+  int wg_start, wgs;  // workgroup range [wg_start, wg_start + wgs) of the launch (wg_start: a multiple of 8 = whole XCD rounds)
+};
+#define TFPP_WGRAD_GROUP_MAX 42
+struct tfpp_wgrad_group {
+  int n, total;  // items, workgroups (padded ranges included)
+  tfpp_wgrad_item it[TFPP_WGRAD_GROUP_MAX];
+};
+static_assert(sizeof(tfpp_wgrad_group) <= 4096, "kernel arguments are limited to 4 KB");
+#if defined(__HIPCC__)
+__device__ __forceinline__ tfpp_wgrad_params tfpp_wgrad_item_params(const tfpp_wgrad_item& it) {
+  tfpp_wgrad_params p;
+  p.dy = it.dy; p.x = it.x; p.dw = it.dw; p.row_map = it.row_map; p.col_map = it.col_map;
+  p.B = it.P; p.Hs = 1; p.Ws = 1; p.Cs = it.KK; p.Hd = 1; p.Wd = 1; p.Cd = it.n_g; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
+  p.G = 1; p.ks_g = it.KK; p.n_g = it.n_g; p.c_real = it.c_real; p.splits = it.splits;
+  p.x_ld = it.x_ld; p.dy_ld = it.dy_ld; p.dw_ld = it.dw_ld; p.ws = it.ws; p.ws_floats = 0;
+  return p;
+}
+#endif
+// host side of the grouped launch: items are pointwise bf16 layers the LDS-DMA kernel supports (wgrad_glds_group_ok); tile = 64 | 128
+bool wgrad_glds_group_ok(const tfpp_wgrad_params& p, int dtype);
+int conv_wgrad_glds_group(const tfpp_wgrad_group& grp, int tile, int grid_cap, hipStream_t st);

@@ -2,6 +2,8 @@
 // See gemm_core.cuh for the fragment / LDS layouts and include/tfpp.h for the semantics of each entry point.
 #include "gemm_core.cuh"
 #include "gemm_internal.h"
+#include <algorithm>
+#include <vector>
 #include <cstdlib>
 #include <cstring>
 
@@ -290,13 +292,16 @@ template <typename T> static int launch_splitk_epilogue(const tfpp_conv_params& 
 }
 
 // K slices for a problem that yields `tiles` output tiles with K stages of depth bk: only when the grid would leave most
-// of the chip idle (<= 192 workgroups) and every slice keeps >= 2 K stages.
+// of the chip idle (<= 192 workgroups) and every slice keeps >= TFPP_SPLITK_MIN_STAGES K stages (default 2).  Round 5 measured 12 stages per
+// slice (140 fewer splitk_epilogue launches of the 792 in the bs = 1 forward): 3.95 -> 4.37 ms bf16, 5.95 -> 7.9 ms fp32, training step
+// +0.6 ms -- the second launch costs less than the serial K loop of a few workgroups (profiles/r05_ab_se_splitk.txt).
 static int conv_splits(const tfpp_conv_params& p, long tiles, int bk) {
+  static const int min_stages = [] { const char* e = std::getenv("TFPP_SPLITK_MIN_STAGES"); const int v = e ? std::atoi(e) : 2; return v < 2 ? 2 : v; }();
   if (!p.splitk_ws || p.stats_partial || p.bns_partial || tiles > 192) return 1;
   const int K = p.R * p.S * p.ks_g, ntot = p.G * p.n_g;
   if (ntot % 4) return 1;
   long sp = (512 + tiles - 1) / tiles;
-  if (sp > K / (2 * bk)) sp = K / (2 * bk);
+  if (sp > K / (min_stages * bk)) sp = K / (min_stages * bk);
   if (sp > 32) sp = 32;
   const long per_slice = (long)p.B * p.Hd * p.Wd * ntot;
   while (sp > 1 && sp * per_slice > p.splitk_ws_floats) --sp;
@@ -527,11 +532,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_
 // dw[row][col] += sum_s ws[s][row][kk]  (second stage of the pixel-split weight gradient).  A workgroup is SLOTS slice
 // slots x (256 / SLOTS) consecutive (row, kk) elements: many slices of a small gradient (stage-1 layers: 384 slices of
 // 72 x 72) are summed by 16 slots in parallel, few slices of a large one by 4.
-template <int SLOTS> __global__ void wgrad_reduce_kernel(tfpp_wgrad_params p) {
+template <int SLOTS> __device__ __forceinline__ void wgrad_reduce_body(const tfpp_wgrad_params& p, const long block) {
   constexpr int EL = 256 / SLOTS;
   const int KK = p.R * p.S * p.ks_g, rows = p.G * p.n_g;
   const int el = threadIdx.x % EL, slot = threadIdx.x / EL;
-  const long i = (long)blockIdx.x * EL + el;
+  const long i = block * EL + el;
   const size_t slice = (size_t)rows * KK;
   float s = 0.f;
   if (i < (long)slice) {
@@ -559,6 +564,20 @@ template <int SLOTS> __global__ void wgrad_reduce_kernel(tfpp_wgrad_params p) {
     col = (long)c * (p.R * p.S) + rs;
   }
   p.dw[(size_t)row * p.dw_ld + col] += s;
+}
+template <int SLOTS> __global__ void wgrad_reduce_kernel(tfpp_wgrad_params p) { wgrad_reduce_body<SLOTS>(p, (long)blockIdx.x); }
+
+// slice sums of every pixel-split layer of a grouped weight-gradient launch in ONE grid (wg_start / wgs of the items now count the
+// workgroups of this kernel: ceil(n_g * KK / 64) per layer)
+__global__ void wgrad_reduce_group_kernel(const tfpp_wgrad_group grp) {
+  const int id = (int)blockIdx.x;
+  int k = 0;
+  for (int i = 1; i < grp.n; ++i) k = (id >= grp.it[i].wg_start) ? i : k;
+  k = __builtin_amdgcn_readfirstlane(k);
+  const int local = id - grp.it[k].wg_start;
+  if (local >= grp.it[k].wgs) return;
+  const tfpp_wgrad_params p = tfpp_wgrad_item_params(grp.it[k]);
+  wgrad_reduce_body<4>(p, (long)local);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -649,6 +668,114 @@ extern "C" int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stre
   if (dtype == TFPP_F32) return dispatch_wgrad<float>(*p, 0, nullptr, st);
   if (dtype == TFPP_BF16) return dispatch_wgrad<bf16_t>(*p, 0, nullptr, st);
   return TFPP_EINVAL;
+}
+
+// ---- many weight gradients in one call (round 5) --------------------------------------------------------------------------------------
+// The weight-gradient lane of the training step hands over a whole batch of independent layers (engine.SideLane.flush).  Pointwise bf16
+// layers the LDS-DMA kernel covers are launched as grouped grids (conv_wgrad_glds_group_kernel: one grid per <= 42 layers of a tile
+// class, descriptor table in the kernel arguments); everything else runs through the single-layer dispatcher, in the order given.
+// Pixel splits are chosen for the GROUP: the grid as a whole has to fill the chip, not every layer on its own -- the stage-3 / stage-4 /
+// fusion-transformer layers then need no split at all (their tile is added straight into dW: no slices, no second pass), layers with
+// few tiles and many pixels (stages 1-2) keep slices + ONE grouped slice-sum launch (deterministic order, no atomics).
+// Two layers of a batch that write the same dW (a parameter used twice) never share a group: the later one takes the single-layer path.
+namespace {
+struct GroupBuild {
+  int tile, bkp;
+  std::vector<tfpp_wgrad_params> items;
+};
+}  // namespace
+
+static int emit_wgrad_group(const std::vector<tfpp_wgrad_params>& its, int tile, int bkp, int grid_cap, hipStream_t st) {
+  // target: ~4 workgroups per CU-slot over the whole group, every workgroup >= 512 pixels of reduction
+  static const int target = [] { const char* e = std::getenv("TFPP_WGRAD_GROUP_TARGET"); const int v = e ? std::atoi(e) : 0; return v; }();
+  const long want_wgs = target > 0 ? target : (tile == 128 ? 1024 : 3072);
+  size_t pos = 0;
+  while (pos < its.size()) {
+    const size_t n = std::min(its.size() - pos, (size_t)TFPP_WGRAD_GROUP_MAX);
+    // work of this chunk in (tile x stage) units
+    double work = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const tfpp_wgrad_params& q = its[pos + i];
+      const long P = (long)q.B * q.Hd * q.Wd;
+      work += (double)cdiv(q.n_g, tile) * cdiv(q.ks_g, tile) * (double)cdiv(P, bkp);
+    }
+    const double min_grain = 512.0 / bkp;
+    double grain = work / (double)want_wgs;
+    if (grain < min_grain) grain = min_grain;
+    tfpp_wgrad_group grp, red;
+    grp.n = red.n = 0;
+    grp.total = red.total = 0;
+    float* ws = its[pos].ws;
+    long ws_left = ws ? its[pos].ws_floats : 0, ws_off = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const tfpp_wgrad_params& q = its[pos + i];
+      const long P = (long)q.B * q.Hd * q.Wd, stages = cdiv(P, bkp), slice = (long)q.n_g * q.ks_g;
+      long sp = (long)(stages / grain + 0.5);
+      if (sp < 1) sp = 1;
+      if (sp > 64) sp = 64;
+      if (sp >= 8) sp = sp / 8 * 8;
+      if (sp > 1 && sp * slice > ws_left - ws_off) sp = (ws_left - ws_off) / slice >= 2 ? (ws_left - ws_off) / slice : 1;
+      tfpp_wgrad_item& it = grp.it[grp.n++];
+      it.dy = q.dy; it.x = q.x; it.dw = q.dw; it.row_map = q.row_map; it.col_map = q.col_map;
+      it.P = (int)P; it.n_g = q.n_g; it.KK = q.ks_g; it.c_real = q.c_real; it.splits = (int)sp;
+      it.dy_ld = (int)q.dy_ld; it.x_ld = (int)q.x_ld; it.dw_ld = (int)q.dw_ld;
+      it.ws = sp > 1 ? ws + ws_off : nullptr;
+      it.wg_start = grp.total;
+      it.wgs = (int)sp * cdiv(q.n_g, tile) * cdiv(q.ks_g, tile);
+      grp.total += (it.wgs + 7) / 8 * 8;
+      if (sp > 1) {
+        ws_off += sp * slice;
+        tfpp_wgrad_item& r = red.it[red.n++];
+        r = it;
+        r.wg_start = red.total;
+        r.wgs = (int)((slice + 63) / 64);
+        red.total += r.wgs;
+      }
+    }
+    int rc = conv_wgrad_glds_group(grp, tile, grid_cap, st);
+    if (rc != 0) return rc;
+    if (red.n > 0) {
+      hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)red.total), dim3(256), 0, st, red);
+      TFPP_CHECK_LAUNCH();
+    }
+    pos += n;
+  }
+  return 0;
+}
+
+extern "C" int tfpp_conv_wgrad_batch(const tfpp_wgrad_params* items, int n, int dtype, void* stream) {
+  if (!items || n < 0 || (dtype != TFPP_F32 && dtype != TFPP_BF16)) return TFPP_EINVAL;
+  static const int grid_cap = [] { const char* e = std::getenv("TFPP_WGRAD_GROUP_WGS"); return e ? std::atoi(e) : 0; }();
+  hipStream_t st = (hipStream_t)stream;
+  GroupBuild g64{64, 32, {}}, g128{128, 64, {}};
+  std::vector<const float*> seen;
+  for (int i = 0; i < n; ++i) {
+    tfpp_wgrad_params q = items[i];
+    if (!q.dy || !q.x || !q.dw) return TFPP_EINVAL;
+    bool grouped = false;
+    if (dtype == TFPP_BF16 && wgrad_glds_group_ok(q, dtype) && std::find(seen.begin(), seen.end(), q.dw) == seen.end()) {
+      WgradPlan pl;
+      tfpp_wgrad_params t = q;
+      if (plan_wgrad<bf16_t>(t, pl) == 0 && (pl.variant == 2 || pl.variant == 4)) {
+        (pl.variant == 4 ? g128 : g64).items.push_back(q);
+        grouped = true;
+      }
+    }
+    seen.push_back(q.dw);
+    if (grouped) continue;
+    const int rc = dtype == TFPP_F32 ? dispatch_wgrad<float>(q, 0, nullptr, st) : dispatch_wgrad<bf16_t>(q, 0, nullptr, st);
+    if (rc != 0) return rc;
+  }
+  for (GroupBuild* g : {&g128, &g64}) {
+    if (g->items.empty()) continue;
+    // longest pixel reductions first: the workgroups that run longest are dispatched first
+    std::stable_sort(g->items.begin(), g->items.end(), [](const tfpp_wgrad_params& a, const tfpp_wgrad_params& b) {
+      return (long)a.B * a.Hd * a.Wd > (long)b.B * b.Hd * b.Wd;
+    });
+    const int rc = emit_wgrad_group(g->items, g->tile, g->bkp, grid_cap, st);
+    if (rc != 0) return rc;
+  }
+  return 0;
 }
 
 // Workspace the dispatcher would like for one call (the library never allocates, the caller passes workspace in):

@@ -45,8 +45,10 @@ template <> __device__ __forceinline__ int swz<128>(int p) { return 2 * (p & 3) 
 // offsets against the uniform operand bases, out-of-tile channels clamped into the row instead of redirected to the zero page (they only
 // feed gradient rows / columns that are never stored), the zero page only for the pixel tail of the last stage.  The general loop
 // spends ~110 non-MFMA instructions per 16 MFMAs (run-time pointwise / tap branches, 64-bit pointer selects).
-template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE, bool PW = false>
-__global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wgrad_params p) {
+// One workgroup's share of one weight gradient: workgroup `wg_id` of the tfpp_conv_wgrad launch geometry of p (G * splits * tiles
+// workgroups).  Called once per workgroup by conv_wgrad_glds_kernel and in a loop by the grouped kernel below.
+template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE, bool PW>
+__device__ __forceinline__ void wgrad_glds_tile(const tfpp_wgrad_params& p, const int wg_id) {
   typedef bf16_t T;
   constexpr int NT = WGM * WGN * 64, NWAVES = WGM * WGN;
   constexpr int WM = TM / WGM, WN = TN / WGN, FM = WM / 16, FN = WN / 16, KS = BKP / 32;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wg
   const int tiles_m = (p.n_g + TM - 1) / TM, tiles_n = (KK + TN - 1) / TN, ntiles = tiles_m * tiles_n;
   int g, split, tile_m, tile_n;
   {
-    const int id = blockIdx.x, per_g = p.splits * ntiles;
+    const int id = wg_id, per_g = p.splits * ntiles;
     g = id / per_g;
     const int r = id - g * per_g;
     int tile;
@@ -401,6 +403,34 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wg
     }
 }
 
+template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE, bool PW = false>
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_kernel(tfpp_wgrad_params p) {
+  wgrad_glds_tile<TM, TN, WGM, WGN, BKP, NSTAGE, PW>(p, (int)blockIdx.x);
+}
+
+// Grouped launch (round 5): the pointwise weight gradients of MANY layers in one grid.  A flush of the weight-gradient lane used to be
+// ~100 launches of this kernel plus ~100 slice sums, each a few dozen workgroups, one after the other on a stream: neither the chip nor
+// the stream was ever full.  Here the workgroups of all layers of a batch form one grid (the descriptor table travels in the kernel
+// arguments, so a captured hipGraph node carries it), the pixel reduction of a layer is split only as far as the WHOLE grid needs it,
+// and a grid smaller than the work list (persistent workgroups, gridDim.x < grp.total) caps the CUs the lane takes from the dY chain.
+template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE>
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_group_kernel(const tfpp_wgrad_group grp) {
+  for (int id = (int)blockIdx.x; id < grp.total; id += (int)gridDim.x) {
+    int k = 0;
+    for (int i = 1; i < grp.n; ++i) k = (id >= grp.it[i].wg_start) ? i : k;  // wave-uniform (kernel arguments, blockIdx)
+    k = __builtin_amdgcn_readfirstlane(k);
+    const int local = id - grp.it[k].wg_start;
+    if (local < grp.it[k].wgs) {  // (the workgroup ranges are padded to whole XCD rounds)
+      const tfpp_wgrad_params p = tfpp_wgrad_item_params(grp.it[k]);
+      wgrad_glds_tile<TM, TN, WGM, WGN, BKP, NSTAGE, true>(p, local);
+    }
+    if (id + (int)gridDim.x < grp.total) {  // another tile follows: every wave is done with the LDS ring before its first DMA, and the
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // epilogue's loads / stores no longer count against the ring's vmcnt arithmetic
+      __syncthreads();
+    }
+  }
+}
+
 template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE> int launch_wgrad_glds(const tfpp_wgrad_params& p, hipStream_t st) {
   const int KK = p.R * p.S * p.ks_g;
   // TFPP_WGRAD_MIN_LDS (bytes): occupancy limiter for A/B runs -- weight gradients run beside the latency-bound dY chain of the other
@@ -455,4 +485,34 @@ int conv_wgrad_glds(const tfpp_wgrad_params& p, int tile, hipStream_t st) {
   }
   if (cfg == 2) return launch_wgrad_glds<64, 64, 2, 2, 64, 3>(p, st);  // 64-pixel stages
   return launch_wgrad_glds<64, 64, 2, 2, 32, 4>(p, st);
+}
+
+// ---- grouped launch (host side) --------------------------------------------------------------------------------------------------
+// A layer can join a group when the lean pointwise loop covers it: 1x1 / stride 1 / one group, 32-bit operand byte offsets.
+bool wgrad_glds_group_ok(const tfpp_wgrad_params& p, int dtype) {
+  static const int on = [] { const char* e = std::getenv("TFPP_WGRAD_GROUP"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (!on || !wgrad_glds_supported(p, dtype)) return false;
+  const long P = (long)p.B * p.Hd * p.Wd;
+  return p.G == 1 && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.Hs == p.Hd && p.Ws == p.Wd && p.n_g > 32 && p.ks_g > 32 &&
+         P < (1l << 30) && (P + 128) * (long)p.dy_ld * 2 < (1l << 32) && (P + 128) * (long)p.x_ld * 2 < (1l << 32) && p.dw_ld < (1l << 31);
+}
+
+template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE> static int launch_wgrad_glds_group(const tfpp_wgrad_group& grp, int grid_cap, hipStream_t st) {
+  constexpr size_t lds = (size_t)NSTAGE * BKP * (TM + TN) * 2;
+  static unsigned long long attr_mask = 0;
+  if (tfpp_first_use_on_this_device(&attr_mask))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_glds_group_kernel<TM, TN, WGM, WGN, BKP, NSTAGE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  int grid = grp.total;
+  if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+  hipLaunchKernelGGL((conv_wgrad_glds_group_kernel<TM, TN, WGM, WGN, BKP, NSTAGE>), dim3((unsigned)grid), dim3(WGM * WGN * 64), lds, st, grp);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+int conv_wgrad_glds_group(const tfpp_wgrad_group& grp, int tile, int grid_cap, hipStream_t st) {
+  if (grp.n < 1 || grp.total < 1) return 0;
+  // 128 x 128: the 2 x 32 KB ring (two workgroups per CU, or one beside a forward / data-gradient GEMM of the dY chain)
+  if (tile == 128) return launch_wgrad_glds_group<128, 128, 2, 4, 64, 2>(grp, grid_cap, st);
+  return launch_wgrad_glds_group<64, 64, 2, 2, 32, 4>(grp, grid_cap, st);
 }
