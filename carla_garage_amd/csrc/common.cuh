@@ -208,6 +208,50 @@ template <int NV> __device__ __forceinline__ void col_block_reduce(float (&acc)[
 #define TFPP_GRIDSUM_TICKETS 64  /* first floats of the scratch: ticket counters; partials start behind them */
 __device__ __forceinline__ void grid_publish(float* slot, float v) { __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float grid_fetch(const float* slot) { return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Sum of n (<= 16) published partials base[k * stride], k = 0 .. n-1, added in index order.  __hip_atomic_load compiles to one
+// `global_load_dword ... sc1` followed by s_waitcnt vmcnt(0) EACH: n dependent round trips to the memory side (~1 us apiece -- a 43-partial sum
+// over 3 channel passes took 130 us in the first fused squeeze-excite kernel, profiles/r05_ab_se_splitk.txt).  Here the same sc1 loads are issued
+// back to back and waited for once: one round trip.
+__device__ __forceinline__ float grid_fetch_sum16(const float* base, long stride, int n) {
+  float v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float* q = base + (long)(k < n ? k : 0) * stride;  // (slots beyond n re-read partial 0: a valid address; their value is not added)
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[k]) : "v"(q) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]),
+                 "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+               :
+               : "memory");
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (k < n) t += v[k];
+  return t;
+}
+// the same for published (float, float) pairs packed into 64-bit words: lo and hi sums of base[k * stride], k < n <= 16, in index order
+__device__ __forceinline__ void grid_fetch_pair_sum16(const unsigned long long* base, long stride, int n, float& lo, float& hi) {
+  unsigned long long v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const unsigned long long* q = base + (long)(k < n ? k : 0) * stride;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[k]) : "v"(q) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]),
+                 "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+               :
+               : "memory");
+  lo = 0.f;
+  hi = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (k < n) {
+      lo += __uint_as_float((unsigned)v[k]);
+      hi += __uint_as_float((unsigned)(v[k] >> 32));
+    }
+}
 // true (for every thread of the workgroup) in the workgroup that drew the last of `total` tickets
 __device__ __forceinline__ bool grid_last_ticket(unsigned* ticket, unsigned total) {
   __shared__ unsigned s_last_ticket;

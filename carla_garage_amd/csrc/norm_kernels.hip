@@ -740,12 +740,8 @@ __global__ void layernorm_param_grad_kernel(const T* __restrict__ dy, const T* _
   }
   if (!grid_last_ticket(reinterpret_cast<unsigned*>(scratch) + blockIdx.x, gridDim.y)) return;
   float tg = 0.f, tb = 0.f;
-  if (c < C)
-    for (unsigned k = slot; k < gridDim.y; k += 4) {
-      const unsigned long long pk = __hip_atomic_load(part + (size_t)k * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      tg += __uint_as_float((unsigned)pk);
-      tb += __uint_as_float((unsigned)(pk >> 32));
-    }
+  if (c < C && slot < (int)gridDim.y)  // gridDim.y <= 64: at most 16 row blocks per slot, fetched in ONE round trip (common.cuh grid_fetch_pair_sum16)
+    grid_fetch_pair_sum16(part + (size_t)slot * C + c, 4l * C, ((int)gridDim.y - slot + 3) / 4, tg, tb);
   sm[0][slot][cl] = tg;
   sm[1][slot][cl] = tb;
   __syncthreads();
