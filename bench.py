@@ -163,8 +163,8 @@ def bf16_vs_fp32_gradients(batch, device, log, state_dict=None):
       m.load_state_dict(state_dict, strict=True)
     tr = Trainer(m, lr=0.0)
     tr.step_count += 1
+    tr.eng.buckets.begin_issue()
     tr._step_body(batch)
-    tr.eng.buckets.executed(tr.program)
     torch.cuda.synchronize()
     grads[dt_] = {n: g.detach().double().flatten().clone() for n, g in tr.eng.grads.items()}
     del tr, m
@@ -651,8 +651,8 @@ def main():
     nprof = 2
     for _ in range(nprof):  # local steps (no gradient exchange): only this rank profiles, so it must not enter a collective
       trainer.step_count += 1
+      trainer.eng.buckets.begin_issue()  # (serial number for the completion signals this pass raises)
       trainer._step_body(batch)
-      trainer.eng.buckets.executed(trainer.program)  # (the pass raised its completion signals: keep the host's counters in step)
       trainer._optimizer(trainer.step_count)
     lib.profiler = None
     agg = prof.summary()

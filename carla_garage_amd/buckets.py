@@ -11,9 +11,13 @@ inside a capture, hipMallocSignalMemory / hipStreamWaitValue64 are not available
 ``tfpp_signal_add`` is a one-thread kernel node behind the bucket's last kernels, ``tfpp_signal_wait`` a one-wave kernel on the collective's
 stream that polls it (include/tfpp.h).  The same mechanism runs in eager steps, so the eager tests exercise what the graph replays.
 
-Host bookkeeping: every executed pass (eager pass or graph replay) raises the same signals as the pass that was RECORDED -- its "program",
-the tuple of buckets with an early signal, returned by finish() and kept by whoever owns the graph -- so `executed(program)` advances the
-expected counter values once per executed pass, whether or not an exchange follows.
+Host bookkeeping (round 5: self-describing signals): a signal does not count passes, it CARRIES the serial number of the pass that
+raised it.  ``begin_issue()`` -- called by whoever issues a pass, in front of the eager pass or of the graph replay, never inside a capture --
+advances the host serial and writes it into a device word on the compute stream (``tfpp_set_u64``); the in-graph nodes raise their signal to
+that word's value (``tfpp_signal_set``: max), and the exchange waits for "signal >= serial of THIS pass".  A pass nobody book-kept (a bare
+``graph.replay()``, an eager pass that died half-way) re-raises an old serial, so a later wait can only be satisfied late -- a reported
+time-out -- never early on gradients that are still being written.  A wait that times out is reported at the NEXT step on every rank: the
+time-out word is MAX-all-reduced behind the step's collectives and copied to pinned host memory (``raise_if_timed_out``).
 
 Correctness never depends on the observation being right: Engine.g() and the lane's flush hook cancel ("poison") the early signals of a
 pass whose write order differs from the observed one; every bucket is then released by the signal raised at the END of the pass."""
@@ -21,7 +25,11 @@ import torch
 
 from . import dist as tdist
 
-WAIT_TIMEOUT_MS = 2000  # a wait that sees nothing for this long gives up (and counts in `timeouts`): a stuck stream must not hang the GPU
+import os
+
+# a wait that sees nothing for this long gives up (and counts in `timeouts`): a stuck stream must not hang the GPU.  Far above any plausible
+# step (a profiled / pre-empted / PMC-serialised step can take seconds: 2 s, the round-4 value, was within reach of those)
+WAIT_TIMEOUT_MS = int(os.environ.get('TFPP_SIGNAL_TIMEOUT_MS', '20000'))
 
 
 class GradBuckets:
@@ -33,7 +41,10 @@ class GradBuckets:
     self.comm = None           # stream the collectives are issued from (RCCL's own stream waits for it, not for the compute stream)
     self.sig = None            # int64 [K + 1] device counters: one per bucket + the end-of-pass marker
     self.timeouts = None       # int32 [1]: waits that gave up
-    self.expected = []         # host mirror of the counters: executed passes that raised each signal
+    self.serial = 0            # serial number of the pass issued last (begin_issue); the signals of a pass carry its serial
+    self.serial_dev = None     # int64 [1] device word: the serial of the pass that is executing (written in front of it on the compute stream)
+    self._flag_dev = self._flag_host = self._flag_event = None  # time-out word on its way to the host (raise_if_timed_out)
+    self._flag_pending, self._flag_seen, self._flag_skipped = False, 0, 0
     self._early = set()        # buckets with an early signal in the pass being recorded
     self.poisoned = None       # reason the early signals of this pass are not used
     self.stats = {'early_signals': 0, 'poisoned_passes': 0, 'exchanges': 0, 'waits': 0}
@@ -50,7 +61,9 @@ class GradBuckets:
       self.sig = ops.zeros(self.count + 1, torch.int64, self.device)
       if self.timeouts is None:
         self.timeouts = ops.zeros(1, torch.int32, self.device)
-    self.expected = [0] * (self.count + 1)
+      if self.serial_dev is None:
+        self.serial_dev = ops.zeros(1, torch.int64, self.device)
+        self.serial = 0
     self._early = set()
 
   def ranges(self):
@@ -61,9 +74,19 @@ class GradBuckets:
     self._early = set()
     self.poisoned = None
 
+  def begin_issue(self):
+    """A pass is about to be issued on the current stream (eager pass or graph replay): give it the next serial number and put that number
+    where its signal nodes will read it.  NEVER inside a capture (the number would be frozen into the graph)."""
+    self.serial += 1
+    if self.serial_dev is not None:
+      from . import ops
+      assert not torch.cuda.is_current_stream_capturing(), 'GradBuckets.begin_issue() belongs in front of the capture / replay, not inside'
+      ops.lib.tfpp_set_u64(self.serial_dev.data_ptr(), self.serial, torch.cuda.current_stream(self.device).cuda_stream)
+    return self.serial
+
   def _raise(self, idx):
     from . import ops
-    ops.lib.tfpp_signal_add(self.sig.data_ptr() + 8 * idx, torch.cuda.current_stream(self.device).cuda_stream)
+    ops.lib.tfpp_signal_set(self.sig.data_ptr() + 8 * idx, self.serial_dev.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
 
   def record(self, b):
     """Bucket b is complete behind everything issued so far on the CURRENT stream."""
@@ -90,11 +113,7 @@ class GradBuckets:
     return (raised, usable)
 
   def executed(self, program):
-    """A pass with this program has been issued (eager pass, or a replay of the graph it was captured into)."""
-    raised, _ = program
-    for b in raised:
-      self.expected[b] += 1
-    self.expected[self.count] += 1
+    """Kept for callers of the round-4 interface: the signals carry the serial of their pass (begin_issue), nothing is counted any more."""
 
   # ------------------------------------------------------------------------------------------------ exchange
   def exchange(self, flat_grad, program, group=None, avg=False):
@@ -103,6 +122,7 @@ class GradBuckets:
     stream behind that bucket's collective), [] when no collective is issued."""
     if not tdist.exchange_enabled(group):
       return []
+    self.raise_if_timed_out()  # (a wait of an EARLIER step that gave up: stop here, on every rank, before more gradients are averaged)
     self.stats['exchanges'] += 1
     _, usable = program
     works = []
@@ -118,14 +138,53 @@ class GradBuckets:
       if cuda:
         idx = b if b in usable else self.count
         if idx != self.count or not waited_end:  # (the stream is ordered: one wait on the end marker covers every later bucket)
-          ops.lib.tfpp_signal_wait(self.sig.data_ptr() + 8 * idx, self.expected[idx], WAIT_TIMEOUT_MS, self.timeouts.data_ptr(), self.comm.cuda_stream)
+          ops.lib.tfpp_signal_wait(self.sig.data_ptr() + 8 * idx, self.serial, WAIT_TIMEOUT_MS, self.timeouts.data_ptr(), self.comm.cuda_stream)
           self.stats['waits'] += 1
           waited_end |= idx == self.count
         with torch.cuda.stream(self.comm):
           works.append(tdist.all_reduce_async(flat_grad[lo:hi], group, avg=avg))
       else:
         works.append(tdist.all_reduce_async(flat_grad[lo:hi], group, avg=avg))
+    if cuda:
+      self._post_health_flag(group)
     return works
+
+  # ------------------------------------------------------------------------------------------------ health of the exchange
+  def _post_health_flag(self, group):
+    """Behind this step's collectives on the exchange stream: MAX over the ranks of the time-out word, copied to pinned host memory.  The
+    host looks at it at the next step without waiting for the device (raise_if_timed_out)."""
+    import torch.distributed as dist
+    if self._flag_pending:  # the previous flag has not been looked at yet (its event is still pending): keep it, post none on top
+      return
+    if self._flag_dev is None:
+      self._flag_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+      self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+      self._flag_event = torch.cuda.Event()
+    with torch.cuda.stream(self.comm):
+      self._flag_dev.copy_(self.timeouts, non_blocking=True)
+      if tdist.world_size(group) > 1:
+        dist.all_reduce(self._flag_dev, op=dist.ReduceOp.MAX, group=group)  # (every rank stops together)
+      self._flag_host.copy_(self._flag_dev, non_blocking=True)
+      self._flag_event.record(self.comm)
+    self._flag_pending = True
+
+  def raise_if_timed_out(self, block=False):
+    """Raises when a completion-signal wait of an earlier step gave up: its all-reduce may have run on an incomplete bucket and the partial
+    sums were averaged into every rank's gradients.  Cheap: reads a pinned host word the exchange stream filled behind the previous step's
+    collectives; it does not wait for the device unless that word has been pending for more than two steps (or ``block``)."""
+    if not self._flag_pending:
+      return
+    if not self._flag_event.query():
+      self._flag_skipped += 1
+      if not block and self._flag_skipped <= 2:
+        return
+      self._flag_event.synchronize()
+    self._flag_pending, self._flag_skipped = False, 0
+    n = int(self._flag_host[0])
+    if n > self._flag_seen:
+      new, self._flag_seen = n - self._flag_seen, n
+      raise RuntimeError(f'carla_garage_amd: {new} completion-signal wait(s) of the gradient exchange gave up after {WAIT_TIMEOUT_MS} ms (on this or another '
+                         'rank): an all-reduce may have run on an incomplete gradient bucket; the gradients of that step are not trustworthy')
 
   def timed_out(self):
     """Number of signal waits that gave up since start-up (host synchronisation: tests / end of a run)."""

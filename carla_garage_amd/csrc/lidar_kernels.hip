@@ -63,6 +63,75 @@ extern "C" int tfpp_lidar_histogram(const float* points, int64_t n, int point_st
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The loader's LiDAR path on the device: CARLA_Data.align (team_code/data.py:840-871: two
+// transfuser_utils.algin_lidar calls, transfuser_utils.py:116-130 -- ego motion, then the augmentation shift / rotation) followed by
+// lidar_to_histogram_features (data.py:873-906) for EVERY frame of a batch in one launch chain.  The loader workers spend ~4 ms per
+// frame in numpy on it; here the raw float64 sweeps (laspy .xyz, data.py:365) are uploaded as they are.
+// Arithmetic is the reference's, in float64: (p - t) elementwise, then the 3 x 3 rotation as numpy's matmul evaluates it -- an FMA chain
+// over k in ascending order: acc = r0 * d0 (rounded), acc = fma(r1, d1, acc), acc = fma(r2, d2, acc) (checked against numpy bit for bit,
+// oracle/lidar_port.align) -- with cos / sin taken on the host (numpy), so no transcendental is evaluated here.  xf: 10 doubles per frame
+// = (t1x, t1y, t1z, cos1, sin1, t2x, t2y, t2z, cos2, sin2).  Points are concatenated; offsets[f] .. offsets[f + 1] belong to frame f.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lidar_algin(double& x, double& y, double& z, const double* __restrict__ t, double c, double s) {
+#pragma clang fp contract(off)
+  const double d0 = x - t[0], d1 = y - t[1], d2 = z - t[2];
+  // rows of rotation_matrix.T = [[c, s, 0], [-s, c, 0], [0, 0, 1]]
+  x = __builtin_fma(0.0, d2, __builtin_fma(s, d1, c * d0));
+  y = __builtin_fma(0.0, d2, __builtin_fma(c, d1, (-s) * d0));
+  z = __builtin_fma(1.0, d2, __builtin_fma(0.0, d1, 0.0 * d0));
+}
+
+__global__ void lidar_align_scatter_kernel(const double* __restrict__ pts, const long long* __restrict__ offsets, const double* __restrict__ xf,
+                                           int frames, const double* __restrict__ xe, int nx, const double* __restrict__ ye, int ny,
+                                           int* __restrict__ counts, double max_height, double split, int use_ground_plane,
+                                           double* __restrict__ aligned_out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= offsets[frames]) return;
+  int lo = 0, hi = frames;  // offsets[lo] <= i < offsets[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (i >= offsets[mid]) lo = mid;
+    else hi = mid;
+  }
+  const int f = lo;
+  double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+  const double* q = xf + 10 * f;
+  lidar_algin(x, y, z, q, q[3], q[4]);       // into the coordinate system of the current frame (data.py:863)
+  lidar_algin(x, y, z, q + 5, q[8], q[9]);   // augmentation shift / rotation (data.py:865-868)
+  if (aligned_out) {
+    aligned_out[3 * i] = x; aligned_out[3 * i + 1] = y; aligned_out[3 * i + 2] = z;
+  }
+  if (!(z < max_height)) return;   // data.py:895, in float64 here (the aligned cloud is float64)
+  const bool above = z > split;
+  if (!above && !use_ground_plane) return;
+  const int ix = lidar_bin(xe, nx, x);
+  if (ix < 0) return;
+  const int iy = lidar_bin(ye, ny, y);
+  if (iy < 0) return;
+  const int C = use_ground_plane ? 2 : 1, c = use_ground_plane ? (above ? 1 : 0) : 0;
+  atomicAdd(counts + (((size_t)f * C + c) * ny + iy) * nx + ix, 1);
+}
+
+extern "C" int tfpp_lidar_align_histogram(const double* points, const int64_t* offsets, int64_t total_points, const double* xforms, int frames,
+                                          const double* xedges, int nx, const double* yedges, int ny, int32_t* counts, float* out,
+                                          double max_height, double split_height, int use_ground_plane, int hist_max, double* aligned_out,
+                                          void* stream) {
+  if ((total_points > 0 && !points) || !offsets || !xforms || frames < 1 || !xedges || !yedges || !counts || !out || nx < 1 || ny < 1 || hist_max < 1 ||
+      total_points < 0)
+    return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)frames * (use_ground_plane ? 2 : 1) * nx * ny;
+  const int e = tfpp_fill_async(counts, 0, (size_t)total * sizeof(int), st);
+  if (e != 0) return e;
+  if (total_points > 0)
+    hipLaunchKernelGGL(lidar_align_scatter_kernel, dim3((unsigned)((total_points + 255) / 256)), dim3(256), 0, st, points, (const long long*)offsets, xforms,
+                       frames, xedges, nx, yedges, ny, counts, max_height, split_height, use_ground_plane, aligned_out);
+  hipLaunchKernelGGL(lidar_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, out, total, hist_max);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // CenterNet heat-map decode: LidarCenterNetHead.decode_heatmap (team_code/center_net.py:172-237) with
 // get_local_maximum / get_topk_from_heatmap / transpose_and_gather_feat (team_code/gaussian_target.py:186-264) in one launch.
 // One 1024-thread workgroup per sample: every thread keeps its share of the ncls*H*W candidates (3x3 local maxima keep their score,

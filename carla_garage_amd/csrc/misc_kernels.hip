@@ -659,6 +659,25 @@ extern "C" int tfpp_signal_add(uint64_t* sig, void* stream) {
   TFPP_CHECK_LAUNCH();
   return 0;
 }
+// Self-describing form (round 5): the signal does not COUNT passes, it carries the serial number of the pass that raised it.
+// tfpp_set_u64 writes the host's serial of the pass about to be issued into a device word on the compute stream (outside any captured
+// graph: stream-ordered in front of the replay); the in-graph node tfpp_signal_set raises sig to max(sig, *serial_word); the wait looks
+// for sig >= the serial the host gave THIS pass.  A pass the host never book-kept (a bare graph.replay(), an aborted eager pass) re-raises
+// an old serial: a later wait can be satisfied late (time-out, reported), never early on gradients still being written.
+__global__ void set_u64_kernel(unsigned long long* p, unsigned long long v) { *p = v; }
+__global__ void signal_set_kernel(unsigned long long* sig, const unsigned long long* serial) { atomicMax(sig, *serial); }
+extern "C" int tfpp_set_u64(uint64_t* p, uint64_t v, void* stream) {
+  if (!p) return TFPP_EINVAL;
+  hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)p, (unsigned long long)v);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tfpp_signal_set(uint64_t* sig, const uint64_t* serial, void* stream) {
+  if (!sig || !serial) return TFPP_EINVAL;
+  hipLaunchKernelGGL(signal_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)sig, (const unsigned long long*)serial);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int tfpp_signal_wait(uint64_t* sig, uint64_t value, int timeout_ms, uint32_t* timeouts, void* stream) {
   if (!sig || timeout_ms < 1) return TFPP_EINVAL;
   hipLaunchKernelGGL(signal_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)sig, (unsigned long long)value,

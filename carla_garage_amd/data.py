@@ -53,19 +53,27 @@ class DeviceBatchPrefetcher:
   widening kernels) on the copy stream; the consumer thread only waits for the slot's event on its compute stream.  A yielded batch stays
   valid until the consumer asks for the next one AND the work it enqueued meanwhile on the current stream has run."""
 
-  def __init__(self, loader, config, device='cuda', slots=2, rasterise_on_device=False, augment=None):
+  def __init__(self, loader, config, device='cuda', slots=2, rasterise_on_device=False, augment=None, lidar_on_device=False):
     """augment: a carla_garage_amd.augment.ImageAugmenter -- the colour augmentation of team_code/data.py:481-496,1141-1157 runs on the
     uploaded uint8 frame (copy stream) instead of in the loader's workers; the loader then yields the frame as decoded (use_color_aug = 0).
     rasterise_on_device: the host batches carry ``bounding_boxes_f64`` (B, n, 8) float64 + ``num_bounding_boxes`` (B,) (collate_boxes)
-    instead of the nine CenterNet label maps, which are then drawn on the GPU by rasterise_targets right after the upload."""
+    instead of the nine CenterNet label maps, which are then drawn on the GPU by rasterise_targets right after the upload.
+    lidar_on_device (round 5): the host batches carry the RAW sweeps -- ``lidar_sweeps``: a list of B x T float64 (N_i, 3) arrays in
+    (sample, time frame) order, as laspy's .xyz yields them (data.py:365), and ``lidar_align``: (B x T, 10) float64 from
+    carla_garage_amd.lidar.align_params (collate_lidar below builds both) -- instead of the BEV images ``lidar`` / ``temporal_lidar``;
+    CARLA_Data.align + lidar_to_histogram_features (data.py:524-560,840-906: ~4 ms of numpy per frame in the loader's workers) then run on
+    the copy stream (tfpp_lidar_align_histogram), bit-exactly."""
     self.loader, self.cfg, self.device = loader, config, torch.device(device)
     self.rasterise = bool(rasterise_on_device and config.detect_boxes)
     self.augment = augment
+    self.lidar_on_device = bool(lidar_on_device)
+    self._hist = None
     if self.device.index is None:
       self.device = torch.device('cuda', torch.cuda.current_device())
     self.copy_stream = torch.cuda.Stream(self.device)
     self.slots = [dict(pin={}, dev={}, ready=torch.cuda.Event(), used=False) for _ in range(slots)]
-    self.keys = [(src, dst, dt) for src, dst, dt, need in KEYMAP if need(config) and not (self.rasterise and dst in TARGET_KEYS)]
+    self.keys = [(src, dst, dt) for src, dst, dt, need in KEYMAP if need(config) and not (self.rasterise and dst in TARGET_KEYS) and
+                 not (self.lidar_on_device and dst == 'lidar_bev')]
     if self.rasterise:
       self.keys += [('bounding_boxes_f64', 'bounding_boxes_f64', torch.float64), ('num_bounding_boxes', 'num_bounding_boxes', torch.int32)]
 
@@ -107,6 +115,8 @@ class DeviceBatchPrefetcher:
           lib.tfpp_widen(ptr(d), ptr(wide), d.numel(), _NARROW[t.dtype], _WIDE[dt], ops.stream())
           d = wide
         out[dst] = d
+      if self.lidar_on_device:
+        out['lidar_bev'] = self._lidar_bev(slot, host_batch)
       if self.rasterise:
         boxes, counts = out.pop('bounding_boxes_f64'), out.pop('num_bounding_boxes')
         tg = slot['dev'].get('/targets')
@@ -117,6 +127,44 @@ class DeviceBatchPrefetcher:
       slot['ready'].record(self.copy_stream)
     slot['used'] = True
     return out
+
+  def _lidar_bev(self, slot, host_batch):
+    """Raw sweeps of the batch -> pinned staging -> device -> aligned BEV histograms (B, T * C, H, W), all on the copy stream."""
+    from .lidar import LidarBatchHistogram
+    import numpy as np
+    if self._hist is None:
+      self._hist = LidarBatchHistogram(self.cfg, self.device)
+    sweeps, xf = host_batch['lidar_sweeps'], torch.as_tensor(host_batch['lidar_align'], dtype=torch.float64).reshape(-1, 10)
+    frames = len(sweeps)
+    T = max(1, int(self.cfg.lidar_seq_len))
+    if frames % T or xf.shape[0] != frames:
+      raise ValueError(f'lidar_sweeps: {frames} sweeps / {xf.shape[0]} parameter rows for lidar_seq_len = {T}')
+    sizes = [int(np.asarray(s).reshape(-1, 3).shape[0]) for s in sweeps]
+    total = sum(sizes)
+    cap = slot['pin'].get('/lidar_cap', 0)
+    if total > cap or slot['pin'].get('/lidar_frames') != frames:
+      cap = max(total + total // 4, 1024)
+      slot['pin'].update({'/lidar_cap': cap, '/lidar_frames': frames, '/lidar_pts': torch.empty((cap, 3), dtype=torch.float64, pin_memory=True),
+                          '/lidar_off': torch.empty(frames + 1, dtype=torch.int64, pin_memory=True), '/lidar_xf': torch.empty((frames, 10), dtype=torch.float64, pin_memory=True)})
+      slot['dev'].update({'/lidar_pts': torch.empty((cap, 3), dtype=torch.float64, device=self.device), '/lidar_off': torch.empty(frames + 1, dtype=torch.int64, device=self.device),
+                          '/lidar_xf': torch.empty((frames, 10), dtype=torch.float64, device=self.device), '/lidar_bev': None})
+    pin, dev = slot['pin'], slot['dev']
+    pts_np, off_np = pin['/lidar_pts'].numpy(), pin['/lidar_off'].numpy()
+    o = 0
+    for i, (s_, n) in enumerate(zip(sweeps, sizes)):
+      off_np[i] = o
+      if n:
+        pts_np[o:o + n] = np.asarray(s_, dtype=np.float64).reshape(-1, 3)
+      o += n
+    off_np[frames] = o
+    pin['/lidar_xf'].copy_(xf)
+    dev['/lidar_pts'][:max(total, 1)].copy_(pin['/lidar_pts'][:max(total, 1)], non_blocking=True)
+    dev['/lidar_off'].copy_(pin['/lidar_off'], non_blocking=True)
+    dev['/lidar_xf'].copy_(pin['/lidar_xf'], non_blocking=True)
+    gp = bool(self.cfg.use_ground_plane)
+    dev['/lidar_bev'] = self._hist.from_device(dev['/lidar_pts'], dev['/lidar_off'], dev['/lidar_xf'], frames, gp, out=dev['/lidar_bev'], total_points=total)
+    bev = dev['/lidar_bev']
+    return bev.view(frames // T, T * bev.shape[1], bev.shape[2], bev.shape[3])  # (b, t) frame order = the channel concatenation of data.py:536,558
 
   def _stager(self, free_q, ready_q, stop):
     try:
@@ -225,3 +273,21 @@ def to_reference_batch(batch, config, rgb_uint8=True):
       t = t.reshape(-1)
     out[src] = t
   return out
+
+
+def collate_lidar(samples, config):
+  """Host-side collation for lidar_on_device: ``samples`` = one dict per dataset item carrying ``lidar_sweeps`` (the T = lidar_seq_len raw float64
+  sweeps of the item, oldest first, as laspy's .xyz returns them -- team_code/data.py:365) and ``lidar_align`` ((T, 10) float64, one
+  carla_garage_amd.lidar.align_params(measurements_i, target, y_augmentation, yaw_augmentation) row per sweep with the target frame of
+  data.py:524-553) next to the other CARLA_Data keys.  Returns the batch dict DeviceBatchPrefetcher(lidar_on_device=True) takes: every other
+  key stacked as torch's default collate stacks it, the sweeps as a flat list in (sample, time) order, the parameters as (B x T, 10)."""
+  import numpy as np
+  from torch.utils.data import default_collate
+  rest = [{k: v for k, v in s.items() if k not in ('lidar_sweeps', 'lidar_align', 'lidar', 'temporal_lidar')} for s in samples]
+  batch = default_collate(rest) if rest and rest[0] else {}
+  batch['lidar_sweeps'] = [np.asarray(sw, dtype=np.float64).reshape(-1, 3) for s in samples for sw in s['lidar_sweeps']]
+  batch['lidar_align'] = torch.from_numpy(np.concatenate([np.asarray(s['lidar_align'], dtype=np.float64).reshape(-1, 10) for s in samples], axis=0))
+  T = max(1, int(config.lidar_seq_len))
+  if len(batch['lidar_sweeps']) != len(samples) * T:
+    raise ValueError(f'collate_lidar: expected {T} sweeps per sample (lidar_seq_len)')
+  return batch

@@ -283,6 +283,7 @@ class DropinStep:
         with capture(plan.B1, st, pool=plan.pool):
           self._bwd(fwd['tape'], self._scaled_seeds(plan.loss_seeds))
         plan.program = eng.bucket_program
+      eng.buckets.begin_issue()  # serial number of this pass's completion signals (buckets.py): in front of the replay, outside the capture
       plan.B1.replay()
       program = plan.program
     elif cur['mode'] == 'graph':
@@ -301,11 +302,12 @@ class DropinStep:
             seeds += self._scaled_seeds(cur['loss']['seeds'], {j})
           else:
             seeds.append(fwd['export_seeds'][j](g.contiguous()))
+      eng.buckets.begin_issue()
       self._bwd(fwd['tape'], seeds)
       program = eng.bucket_program
       tr.eager_steps_in_layout += 1
-    eng.buckets.executed(program)
     if self._exchange_on():
+      eng.buckets.raise_if_timed_out()  # a signal wait of an earlier step gave up (on any rank): raise here, not at a checkpoint the caller may never write
       # DistributedDataParallel semantics (train.py:516-520): .grad holds the MEAN over the ranks when backward returns.  One all-reduce per
       # bucket of the arena, each behind its own completion event (they started while the replay above was still running); the caller's
       # stream waits for all of them

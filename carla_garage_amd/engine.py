@@ -482,10 +482,15 @@ class SideLane:
           if j == 0:
             ops.stamp(f'side lane9 batch of {len(self.pending)} begins')
           self.in_flush = True
+          # the closures of a batch are independent layers: their pointwise weight gradients are collected and launched as grouped
+          # grids (ops.wgrad_batch_end -> tfpp_conv_wgrad_batch) instead of two small launches per layer one after the other
+          collecting = ops.wgrad_batch_begin()
           try:
             for fn in self.pending[j::split]:
               fn()
           finally:
+            if collecting:
+              ops.wgrad_batch_end()
             self.in_flush = False
       with torch.cuda.stream(self.stream):
         if self.on_batch_end is not None or ops.STAMPS['on']:
@@ -1065,13 +1070,15 @@ class Engine:
                   x_grad=x_grad, out_f32=out_f32)
     return y.view(*shp[:-1], y.shape[-1])
 
-  def raw_linear(self, x, w, bias, wt, gw, gb, n, k, act=ACT_NONE, row_map=None, col_map=None, n_real=None):
+  def raw_linear(self, x, w, bias, wt, gw, gb, n, k, act=ACT_NONE, row_map=None, col_map=None, n_real=None, res=None):
     """Linear with explicitly supplied packed images (fusion QKV / proj, decoder in_proj slices).
-    x: [rows, k];  w: [n, k];  wt: [k, n] (for the data gradient);  gw/gb: gradient destinations (callables)."""
+    x: [rows, k];  w: [n, k];  wt: [k, n] (for the data gradient);  gw/gb: gradient destinations (callables);
+    res: [rows, n] added in the GEMM epilogue (the residual stream of a transformer block when no dropout sits in between)."""
     rows = x.numel() // k
     y = torch.empty((rows, n), device=x.device, dtype=x.dtype)
     geo = dict(B=rows, Hs=1, Ws=1, Cs=k, Hd=1, Wd=1, Cd=n)
-    ops.conv_gemm(x, w, y, act=act, shift=bias, **geo)
+    assert res is None or act == ACT_NONE
+    ops.conv_gemm(x, w, y, act=act, shift=bias, res=res, **geo)
     if self.tape is not None:
 
       def bwd(dy):
@@ -1080,9 +1087,9 @@ class Engine:
         self.side.run(Tape.current, lambda: (gw(dz, x), gb(dz) if gb is not None else None), dz, x)
         dx = torch.empty((rows, k), device=x.device, dtype=x.dtype)
         ops.conv_gemm(dz, wt, dx, B=rows, Hs=1, Ws=1, Cs=n, Hd=1, Wd=1, Cd=k, mode=1)
-        return dx
+        return (dx, dz) if res is not None else dx
 
-      self.rec([y], [x], bwd)
+      self.rec([y], [x, res] if res is not None else [x], bwd)
     return y
 
   def layernorm(self, x, ln):
@@ -1224,15 +1231,26 @@ class Engine:
     B, H, W, C = x.shape
     w1, b1 = se.fc1.weight.detach().view(se.fc1.weight.shape[0], C), se.fc1.bias.detach()
     w2, b2 = se.fc2.weight.detach().view(C, -1), se.fc2.bias.detach()
-    pool = ops.mean_hw(x)
-    hidden, gate = ops.se_gate_fwd(pool, w1, b1, w2, b2)
+    fused = ops.se_fused_supported(B, w1.shape[0], C)  # one launch for squeeze + fc1 + fc2 (and their backward) instead of four
+    if fused:
+      pool, hidden, gate = ops.se_squeeze_gate(x, w1, b1, w2, b2)
+    else:
+      pool = ops.mean_hw(x)
+      hidden, gate = ops.se_gate_fwd(pool, w1, b1, w2, b2)
     y = ops.affine_act(x, gate=gate, rows_per_batch=H * W)
     if self.tape is not None:
 
       def bwd(dy):
-        dgate = ops.se_dgate(dy, x)
-        dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
-                                self.g(se.fc2.weight), self.g(se.fc2.bias))
+        if fused:
+          dgate, dz1, dpool = ops.se_bwd_squeeze(dy, x, gate, hidden, w1, w2)
+          # the parameter gradients of the gate MLP only feed the optimizer: weight-gradient lane
+          self.side.label = 'squeeze_excite'
+          self.side.run(Tape.current, lambda: ops.se_param_grads(dgate, gate, hidden, pool, dz1, self.g(se.fc1.weight), self.g(se.fc1.bias),
+                                                                self.g(se.fc2.weight), self.g(se.fc2.bias)), dgate, dz1)
+        else:
+          dgate = ops.se_dgate(dy, x)
+          dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
+                                  self.g(se.fc2.weight), self.g(se.fc2.bias))
         info = self._bn_of.get(_key(x)) if x.dtype == torch.bfloat16 else None
         if info is not None and info[2] and Tape.current.is_last_contribution(x):
           # x = relu(BN(raw)) of conv2: this IS its complete gradient -> emit the BatchNorm-backward sums in the same pass
@@ -1365,11 +1383,16 @@ class Engine:
     def gb_proj(dz):
       ops.colsum(dz, self.g(blk.attn.proj.bias), B * T, C, C)
 
+    # residual adds: with dropout between the linear and the sum (training) a separate add_dropout launch; without one (the 20 Hz inference
+    # tick, resid_pdrop = 0) the sum is the residual operand of the GEMM epilogue -- two launches fewer per block on a launch-bound chain
+    fuse_res = not (self.training and cfg.resid_pdrop > 0)
     y = self.raw_linear(O.view(B * T, nh * dp), st['wproj'], blk.attn.proj.bias.detach(), st.get('wproj_t'), gw_proj, gb_proj, C,
-                        nh * dp)
-    x = self.add(x, y.view(B, T, C), cfg.resid_pdrop)
+                        nh * dp, res=x.view(B * T, C) if fuse_res else None)
+    x = y.view(B, T, C) if fuse_res else self.add(x, y.view(B, T, C), cfg.resid_pdrop)
     h = self.layernorm(x, blk.ln2)
     h = self.linear(h, key + '.mlp.0', act=ACT_RELU)
+    if fuse_res:
+      return self.linear(h, key + '.mlp.2', res=x)
     h = self.linear(h, key + '.mlp.2')
     return self.add(x, h, cfg.resid_pdrop)
 

@@ -123,6 +123,7 @@ class GraphedTrainStep:
         if dst.data_ptr() != src.data_ptr():
           dst.copy_(src, non_blocking=True)
     tr.step_count += 1
+    tr.eng.buckets.begin_issue()  # the serial number the replay's completion signals will carry (buckets.py): in front of the replay
     self.graph.replay()
     tr.finish_step(self.program)
     return self.vals

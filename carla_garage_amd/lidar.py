@@ -52,6 +52,80 @@ class LidarHistogram:
     return out
 
 
+def normalize_angle(x):
+  """team_code/transfuser_utils.py:19-23"""
+  x = x % (2 * np.pi)
+  if x > np.pi:
+    x -= 2 * np.pi
+  return x
+
+
+def align_params(measurements_0, measurements_1, y_augmentation=0.0, yaw_augmentation=0):
+  """Host side of CARLA_Data.align (team_code/data.py:840-871): the ten float64 numbers per frame tfpp_lidar_align_histogram takes --
+  (pos_diff, cos / sin of rot_diff) of the ego-motion transform (data.py:853-863) and (pos_diff_aug, cos / sin of rot_diff_aug) of the
+  augmentation (data.py:865-868), computed with the reference's own numpy operations (a handful of scalars per frame; the N x 3 work -- the
+  two algin_lidar calls of transfuser_utils.py:116-130 and the histogram -- runs on the device)."""
+  pos_1 = np.array([measurements_1['pos_global'][0], measurements_1['pos_global'][1], 0.0])
+  pos_0 = np.array([measurements_0['pos_global'][0], measurements_0['pos_global'][1], 0.0])
+  pos_diff = pos_1 - pos_0
+  rot_diff = normalize_angle(measurements_1['theta'] - measurements_0['theta'])
+  rotation_matrix = np.array([[np.cos(measurements_1['theta']), -np.sin(measurements_1['theta']), 0.0],
+                              [np.sin(measurements_1['theta']), np.cos(measurements_1['theta']), 0.0], [0.0, 0.0, 1.0]])
+  pos_diff = rotation_matrix.T @ pos_diff
+  rot_diff_aug = np.deg2rad(yaw_augmentation)
+  return np.array([pos_diff[0], pos_diff[1], pos_diff[2], np.cos(rot_diff), np.sin(rot_diff), 0.0, y_augmentation, 0.0, np.cos(rot_diff_aug),
+                   np.sin(rot_diff_aug)], dtype=np.float64)
+
+
+class LidarBatchHistogram(LidarHistogram):
+  """The loader's LiDAR path for a whole batch on the device: raw float64 sweeps + per-frame align
+  parameters -> (frames, C, H, W) BEV images, i.e. CARLA_Data.align + lidar_to_histogram_features (team_code/data.py:524-560,840-906) of
+  every sample and time frame in one call of tfpp_lidar_align_histogram.
+
+    hist = LidarBatchHistogram(config)
+    bev = hist.from_device(points, offsets, xforms, frames, use_ground_plane)     # device tensors (the prefetcher's copy stream)
+    bev = hist(sweeps, params, use_ground_plane)                                   # lists of (N_i, 3) float64 arrays / (10,) arrays"""
+
+  def __init__(self, config, device='cuda'):
+    super().__init__(config, device)
+    self.max_height64 = float(config.max_height_lidar)  # the aligned cloud is float64: the height tests of data.py:895-897 are float64 ones here
+    self.split64 = float(config.lidar_split_height)
+
+  def from_device(self, points, offsets, xforms, frames, use_ground_plane=False, out=None, total_points=None, aligned_out=None):
+    ch = 2 if use_ground_plane else 1
+    if out is None:
+      out = torch.empty((frames, ch, self.ny, self.nx), device=self.device, dtype=torch.float32)
+    lib.load()
+    st = ops.stream()
+    key = (st, frames * ch)
+    counts = self._counts.get(key)
+    if counts is None:
+      counts = self._counts[key] = torch.empty(frames * ch * self.nx * self.ny, device=self.device, dtype=torch.int32)
+    n = int(points.shape[0]) if total_points is None else int(total_points)
+    lib.tfpp_lidar_align_histogram(ops.ptr(points) if points.numel() else None, ops.ptr(offsets), n, ops.ptr(xforms), frames, ops.ptr(self.xe), self.nx,
+                                   ops.ptr(self.ye), self.ny, ops.ptr(counts), ops.ptr(out), self.max_height64, self.split64, int(use_ground_plane),
+                                   self.hist_max, ops.ptr(aligned_out), st)
+    return out
+
+  def __call__(self, sweeps, params, use_ground_plane=False, aligned_out=False):
+    pts, off, xf = pack_sweeps(sweeps, params)
+    pts, off, xf = pts.to(self.device), off.to(self.device), xf.to(self.device)
+    al = torch.empty_like(pts) if aligned_out else None
+    out = self.from_device(pts, off, xf, len(sweeps), use_ground_plane, aligned_out=al)
+    return (out, al) if aligned_out else out
+
+
+def pack_sweeps(sweeps, params):
+  """Host-side collation of the raw LiDAR path: a list of (N_i, 3) float64 sweeps and their (10,) align parameters ->
+  (points (sum N_i, 3) float64, offsets (frames + 1,) int64, xforms (frames, 10) float64) CPU tensors."""
+  arrs = [np.ascontiguousarray(np.asarray(s, dtype=np.float64).reshape(-1, 3)) for s in sweeps]
+  off = np.zeros(len(arrs) + 1, np.int64)
+  off[1:] = np.cumsum([a.shape[0] for a in arrs])
+  pts = np.concatenate(arrs, axis=0) if arrs else np.zeros((0, 3), np.float64)
+  xf = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float64).reshape(10) for p in params]))
+  return torch.from_numpy(pts), torch.from_numpy(off), torch.from_numpy(xf)
+
+
 _CACHE = {}
 
 

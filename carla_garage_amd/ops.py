@@ -186,8 +186,42 @@ def conv_wgrad_plan(dy, x, dw, **kw):
   return plan[0], plan[1], plan[2]
 
 
+WGRAD_BATCH = None  # list of (params, tensors kept alive) while a batch of the weight-gradient lane is being collected
+WGRAD_GROUP = _os.environ.get('TFPP_WGRAD_GROUP', '1') != '0'
+
+
+def wgrad_batch_begin():
+  """From here to wgrad_batch_end() the bf16 conv_wgrad calls of the CURRENT stream are collected instead of launched (the closures of one
+  flush of engine.SideLane: independent layers), then handed to tfpp_conv_wgrad_batch in one call -- grouped grids instead of ~200 launches."""
+  global WGRAD_BATCH
+  if WGRAD_GROUP and WGRAD_BATCH is None:
+    WGRAD_BATCH = []
+    return True
+  return False
+
+
+def wgrad_batch_end():
+  global WGRAD_BATCH
+  batch, WGRAD_BATCH = WGRAD_BATCH, None
+  if not batch:
+    return
+  arr = (WgradParams * len(batch))()
+  flops = nbytes = 0.0
+  for i, (p, _) in enumerate(batch):
+    ctypes.memmove(ctypes.byref(arr, i * ctypes.sizeof(WgradParams)), ctypes.byref(p), ctypes.sizeof(WgradParams))
+    kk = p.R * p.S * p.ks_g
+    flops += 2.0 * p.B * p.Hd * p.Wd * p.G * p.n_g * kk
+    nbytes += (p.B * p.Hd * p.Wd * p.G * p.n_g + p.B * p.Hs * p.Ws * p.G * p.ks_g) * 2 + 2 * p.G * p.n_g * kk * 4
+  if lib.profiler is not None:
+    lib.profiler.tag('conv_wgrad<bf16,batch>', flops, nbytes)
+  lib.tfpp_conv_wgrad_batch(arr, len(batch), BF16, stream())
+
+
 def conv_wgrad(dy, x, dw, **kw):
   p = _wgrad_params(dy, x, dw, **kw)
+  if WGRAD_BATCH is not None and dy.dtype == torch.bfloat16:
+    WGRAD_BATCH.append((p, (dy, x, dw, kw.get('row_map'), kw.get('col_map'))))
+    return dw
   B, Hd, Wd, Hs, Ws, G, R, S, stride = p.B, p.Hd, p.Wd, p.Hs, p.Ws, p.G, p.R, p.S, p.stride
   if lib.profiler is not None:  # one profiled call per kernel: first stage and slice sum are timed separately
     plan = (ctypes.c_int * 3)()
@@ -580,6 +614,48 @@ def se_gate_bwd(dgate, gate, hidden, pool, w1, w2, dw1, db1, dw2, db2):
   lib.tfpp_se_gate_bwd(ptr(dgate), ptr(gate), ptr(hidden), ptr(pool), ptr(w1), ptr(w2), ptr(scratch), ptr(dpool), ptr(dw1), ptr(db1),
                        ptr(dw2), ptr(db2), b, c, rd, stream())
   return dpool
+
+
+SE_FUSED = _os.environ.get('TFPP_SE_FUSED', '1') != '0'  # 0: the unfused launch chain (A/B runs, op-level comparison tests)
+
+
+SE_FUSED_MAX_MACS = int(_os.environ.get('TFPP_SE_FUSED_MAX_MACS', '4096'))
+
+
+def se_fused_supported(b, rd, c=0):
+  """The tail of the fused kernels runs fc1 / fc2 of a sample on ONE workgroup, i.e. as a chain of dependent load round trips on one CU.
+  Measured alone on the chip (tools/se_micro.py, profiles/r05_se_micro.txt; forward, us fused / unfused): stage 1 (72 x 8) 20 / 29, stage 2
+  (216 x 54) 30 / 30, stage 3 (576 x 144) 66 / 30, stage 4 (1512 x 378) 231 / 30 -- and in the step: fused up to stage 3 = +2.7 ms / step,
+  +0.85 ms on the bs = 1 forward (profiles/r05_ab_se2.txt).  The default therefore fuses stage 1 only (C x RD <= 4096)."""
+  return SE_FUSED and b <= 64 and rd <= 384 and c * rd <= SE_FUSED_MAX_MACS
+
+
+def se_squeeze_gate(x, w1, b1, w2, b2):
+  """pool, hidden, gate of one squeeze-excite block in ONE launch (tfpp_se_squeeze_gate)."""
+  b, h, w, c = x.shape
+  rd = w1.shape[0]
+  pool = torch.empty((b, c), device=x.device, dtype=torch.float32)
+  hidden = torch.empty((b, rd), device=x.device, dtype=torch.float32)
+  gate = torch.empty((b, c), device=x.device, dtype=torch.float32)
+  lib.tfpp_se_squeeze_gate(ptr(_chk(x)), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(pool), ptr(hidden), ptr(gate), ptr(reduce_scratch(b, c, x.device)),
+                           ptr(gridsum_scratch(x.device)), b, h * w, c, rd, dt(x), stream())
+  return pool, hidden, gate
+
+
+def se_bwd_squeeze(dy, x, gate, hidden, w1, w2):
+  """dgate, dz1, dpool of one squeeze-excite block in ONE launch (tfpp_se_bwd_squeeze)."""
+  b, h, w, c = x.shape
+  rd = hidden.shape[1]
+  dgate, dpool = torch.empty_like(gate), torch.empty_like(gate)
+  dz1 = torch.empty_like(hidden)
+  lib.tfpp_se_bwd_squeeze(ptr(_chk(dy)), ptr(_chk(x)), ptr(gate), ptr(hidden), ptr(w1), ptr(w2), ptr(dgate), ptr(dz1), ptr(dpool),
+                          ptr(reduce_scratch(b, c, x.device)), ptr(gridsum_scratch(x.device)), b, h * w, c, rd, dt(x), stream())
+  return dgate, dz1, dpool
+
+
+def se_param_grads(dgate, gate, hidden, pool, dz1, dw1, db1, dw2, db2):
+  b, c = gate.shape
+  lib.tfpp_se_param_grads(ptr(dgate), ptr(gate), ptr(hidden), ptr(pool), ptr(dz1), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), b, c, hidden.shape[1], stream())
 
 
 def se_bwd_apply(dy, gate, dpool):

@@ -216,6 +216,7 @@ class Trainer:
     self.model.train()
     self.apply_observed_layout()  # (eager steps only: a captured step never comes through here)
     self.step_count += 1
+    self.eng.buckets.begin_issue()  # (serial number of this pass for its completion signals: in front of the pass, never inside a capture)
     vals = self._step_body(batch)
     self.finish_step(self.program)
     self.eager_steps_in_layout += 1
@@ -242,8 +243,8 @@ class Trainer:
     in flight) is still running -- and one optimizer launch per bucket as soon as it has landed; without an exchange, one launch over the
     whole arena."""
     buckets = self.eng.buckets
-    buckets.executed(program)
     if self.exchange:
+      buckets.raise_if_timed_out()  # a signal wait of an EARLIER step gave up (on any rank): stop before this step's gradients are averaged in
       self.agree_on_layout()
     works = buckets.exchange(self.eng.flat_grad, program, self.pg) if self.exchange else []
     if not works:
@@ -263,7 +264,9 @@ class Trainer:
 
   def check_exchange_health(self):
     """Host-side check (one device read): a completion-signal wait of the gradient exchange that gave up (buckets.WAIT_TIMEOUT_MS) means a
-    collective may have run on an incomplete bucket.  Called where the host synchronises anyway (checkpoints); raises instead of training on."""
+    collective may have run on an incomplete bucket.  Every step already looks at the previous step's time-out word without synchronising
+    (GradBuckets.raise_if_timed_out in finish_step / DropinStep._run_backward); this is the blocking variant for checkpoints."""
+    self.eng.buckets.raise_if_timed_out(block=True)
     n = self.eng.buckets.timed_out() if self.eng.buckets.timeouts is not None else 0
     if n:
       raise RuntimeError(f'carla_garage_amd: {n} completion-signal wait(s) of the gradient exchange timed out: gradients of those steps may be incomplete')

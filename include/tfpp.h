@@ -127,6 +127,13 @@ typedef struct {
   int64_t ws_floats;
 } tfpp_wgrad_params;
 int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stream);
+/* n independent weight gradients in one call (the batches of the training step's weight-gradient lane; the reference computes them one
+ * autograd node at a time, train.py:898 loss.backward()).  Pointwise bf16 layers run as GROUPED grids -- the workgroups of up to 42 layers
+ * in one launch, the descriptor table in the kernel arguments, pixel splits chosen for the group (most layers then add their tile straight
+ * into dw; the rest share one slice-sum launch; no atomics) -- everything else through tfpp_conv_wgrad, in the order given.  All items use
+ * items[i].ws as the slice workspace (the same buffer for every item of a call).  Results equal n tfpp_conv_wgrad calls up to the order of
+ * the fp32 pixel sums.  TFPP_WGRAD_GROUP=0 disables grouping, TFPP_WGRAD_GROUP_WGS=n caps the grid (persistent workgroups). */
+int tfpp_conv_wgrad_batch(const tfpp_wgrad_params* items, int n, int dtype, void* stream);
 /* Preferred workspace of one call in bytes (the library never allocates): the size at which the dispatcher's plan is not
  * limited by the workspace.  op 0: split-K slices of tfpp_conv_gemm (params = tfpp_conv_params, field splitk_ws); op 1: pixel slices of
  * tfpp_conv_wgrad (params = tfpp_wgrad_params, field ws); op 2 / 3: BatchNorm / column-sum scratch for C = *(const int*)params channels.
@@ -261,6 +268,17 @@ int tfpp_lidar_histogram(const float* points, int64_t n, int point_stride, const
                          int32_t* counts, float* out, float max_height, float split_height, int use_ground_plane, int hist_max,
                          void* stream);
 
+/* The loader's LiDAR path for a whole batch: CARLA_Data.align (team_code/data.py:840-871 = two
+ * transfuser_utils.algin_lidar calls, transfuser_utils.py:116-130) + lidar_to_histogram_features (data.py:873-906) per frame, called per
+ * sample and time frame from CARLA_Data.__getitem__ (data.py:524-560).  points: the raw float64 sweeps (laspy .xyz) of all frames
+ * concatenated, (total_points, 3); offsets: int64 [frames + 1] (device); xforms: float64 [frames][10] = (t1, cos1, sin1, t2, cos2, sin2),
+ * the two translations and the cos / sin of the two yaw angles as the host computes them (carla_garage_amd.lidar.align_params follows
+ * data.py:853-868); out: float32 (frames, C, ny, nx); counts: int32 scratch of the same element count; aligned_out (nullable): the
+ * aligned float64 points (tests).  float64 arithmetic in numpy's evaluation order: histograms equal the reference's bit for bit. */
+int tfpp_lidar_align_histogram(const double* points, const int64_t* offsets, int64_t total_points, const double* xforms, int frames,
+                               const double* xedges, int nx, const double* yedges, int ny, int32_t* counts, float* out, double max_height,
+                               double split_height, int use_ground_plane, int hist_max, double* aligned_out, void* stream);
+
 /* CenterNet heat-map decode, the step right after forward() when boxes are requested (replaces
  * LidarCenterNetHead.decode_heatmap, team_code/center_net.py:172-237, incl. gaussian_target.py:186-264): 3x3 local maxima of
  * heat (B, ncls, H, W), top-k in descending score order (equal scores: lower flat index first), gathered wh / offset /
@@ -364,6 +382,20 @@ int tfpp_se_gate_bwd(const float* dgate, const float* gate, const float* hidden,
                      const float* w2, float* dz1_scratch /* [B*RD] */, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
                      int B, int C, int RD, void* stream);
 int tfpp_se_bwd_apply(const void* dy, const float* gate, const float* dpool, void* dx, int B, int HW, int C, int dtype, void* stream);
+/* Fused squeeze-excite (round 5): one launch per pass instead of four.  The row-block workgroups of a sample publish their partial sums
+ * and draw a ticket per sample; the workgroup that draws the last one finishes the squeeze and runs fc1 / fc2 (forward) or their data
+ * gradients (backward) for its sample.  Same arithmetic as tfpp_mean_hw + tfpp_se_gate_fwd and tfpp_se_dgate + tfpp_se_gate_bwd up to the
+ * order of the fp32 dot products (timm SEModule; called per bottleneck from transfuser.py:207-220 through timm's RegNet stages).
+ * partial_scratch: tfpp_reduce_scratch_floats(B, C) floats; ticket_scratch: a tfpp_gridsum_scratch_floats() buffer (zero before the first
+ * use, left at zero; not shared between concurrent streams).  B <= 64, RD <= 384, else TFPP_EINVAL (callers fall back to the unfused calls).
+ * tfpp_se_param_grads: the parameter gradients alone (dw1 += dz1^T pool, db1, dw2 += gd^T hidden, db2), off the dY chain. */
+int tfpp_se_squeeze_gate(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, float* pool, float* hidden,
+                         float* gate, float* partial_scratch, float* ticket_scratch, int B, int HW, int C, int RD, int dtype, void* stream);
+int tfpp_se_bwd_squeeze(const void* dy, const void* x, const float* gate, const float* hidden, const float* w1, const float* w2,
+                        float* dgate, float* dz1, float* dpool, float* partial_scratch, float* ticket_scratch, int B, int HW, int C, int RD,
+                        int dtype, void* stream);
+int tfpp_se_param_grads(const float* dgate, const float* gate, const float* hidden, const float* pool, const float* dz1, float* dw1,
+                        float* db1, float* dw2, float* db2, int B, int C, int RD, void* stream);
 /* se_bwd_apply with the BatchNorm-backward statistics of the preceding layer fused in (conv2 of a RegNet bottleneck: dx is the
  * complete gradient of y = relu(BN(x))): also writes tfpp_se_bwd_apply_bns_rows(B, HW, C, dtype) rows [2*C] of (sum g, sum g*xhat),
  * g = dx * (y > 0), for tfpp_bn_bwd_apply_rows. */
@@ -459,6 +491,12 @@ int tfpp_inc_u64(uint64_t* p, void* stream);
  * tfpp_signal_wait: the work issued on `stream` after this call starts once *sig >= value; gives up after timeout_ms and then adds 1 to
  * *timeouts (nullable). */
 int tfpp_signal_add(uint64_t* sig, void* stream);
+/* Self-describing signals (round 5): tfpp_set_u64 stores v into *p on `stream` (the host's serial number of the pass it is about to issue,
+ * written in front of the pass / the graph replay); tfpp_signal_set raises *sig to max(*sig, *serial) behind everything issued so far on
+ * `stream` (a kernel node inside the captured step); the exchange then waits with tfpp_signal_wait(sig, serial of that pass).  A pass the
+ * host did not book-keep re-raises an old serial and can never satisfy a later wait early. */
+int tfpp_set_u64(uint64_t* p, uint64_t v, void* stream);
+int tfpp_signal_set(uint64_t* sig, const uint64_t* serial, void* stream);
 int tfpp_signal_wait(uint64_t* sig, uint64_t value, int timeout_ms, uint32_t* timeouts, void* stream);
 int tfpp_add_bcast(const void* x, const float* bcast, void* y, int64_t n, int64_t period, int dtype, void* stream);
 int tfpp_act_bwd(const void* dy, const void* y, void* dx, int64_t n, int act, int dtype, void* stream);

@@ -75,3 +75,58 @@ def make_cloud(n, seed=0, edge_cases=True):
                   [2.0, 2.0, 100.0], [2.0, 2.0, np.nextafter(np.float32(100.0), np.float32(0))], [5.125, -7.375, -2.0]], dtype=np.float32)
     xyz = np.concatenate([xyz, e], axis=0)
   return np.ascontiguousarray(xyz.astype(np.float32))
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# The loader's per-frame LiDAR path: CARLA_Data.align + lidar_to_histogram_features as
+# CARLA_Data.__getitem__ chains them (team_code/data.py:524-560), restated in numpy.
+# ----------------------------------------------------------------------------------------------------------------------------------
+def normalize_angle(x):
+  """team_code/transfuser_utils.py:19-23"""
+  x = x % (2 * np.pi)
+  if x > np.pi:
+    x -= 2 * np.pi
+  return x
+
+
+def algin_lidar(lidar, translation, yaw):
+  """team_code/transfuser_utils.py:116-130 (sic): rotation inverse to translation and yaw."""
+  rotation_matrix = np.array([[np.cos(yaw), -np.sin(yaw), 0.0], [np.sin(yaw), np.cos(yaw), 0.0], [0.0, 0.0, 1.0]])
+  return (rotation_matrix.T @ (lidar - translation).T).T
+
+
+def align_params(measurements_0, measurements_1, y_augmentation=0.0, yaw_augmentation=0):
+  """The two (translation, yaw) pairs CARLA_Data.align derives (team_code/data.py:853-868) from the measurements of the sweep's frame and
+  of the target frame and from the augmentation: returns (pos_diff (3,), rot_diff, pos_diff_aug (3,), rot_diff_aug)."""
+  pos_1 = np.array([measurements_1['pos_global'][0], measurements_1['pos_global'][1], 0.0])
+  pos_0 = np.array([measurements_0['pos_global'][0], measurements_0['pos_global'][1], 0.0])
+  pos_diff = pos_1 - pos_0
+  rot_diff = normalize_angle(measurements_1['theta'] - measurements_0['theta'])
+  rotation_matrix = np.array([[np.cos(measurements_1['theta']), -np.sin(measurements_1['theta']), 0.0],
+                              [np.sin(measurements_1['theta']), np.cos(measurements_1['theta']), 0.0], [0.0, 0.0, 1.0]])
+  pos_diff = rotation_matrix.T @ pos_diff
+  return pos_diff, rot_diff, np.array([0.0, y_augmentation, 0.0]), np.deg2rad(yaw_augmentation)
+
+
+def align(lidar_0, measurements_0, measurements_1, y_augmentation=0.0, yaw_augmentation=0):
+  """team_code/data.py:840-871"""
+  pos_diff, rot_diff, pos_diff_aug, rot_diff_aug = align_params(measurements_0, measurements_1, y_augmentation, yaw_augmentation)
+  return algin_lidar(algin_lidar(lidar_0, pos_diff, rot_diff), pos_diff_aug, rot_diff_aug)
+
+
+def make_sweep_f64(n, seed):
+  """A deterministic float64 sweep as laspy's .xyz yields it (team_code/data.py:365): make_cloud's geometry on a 1 mm lattice (the .laz scale),
+  no hand-placed edge points (after a rotation they are ordinary points)."""
+  c = make_cloud(n, seed, edge_cases=False).astype(np.float64)
+  return np.round(c * 1000.0) / 1000.0
+
+
+def make_measurements(seed, frames):
+  """`frames` consecutive ego poses (pos_global, theta) of a car driving a gentle curve at ~8 m/s, 20 Hz frames 0.05 s apart."""
+  th0 = float(detrand.uniform(f'meas.th.{seed}', (1,), -3.0, 3.0)[0])
+  x, y, out = 100.0 + seed, -50.0 + 2 * seed, []
+  for i in range(frames):
+    th = th0 + 0.01 * i
+    x, y = x + 0.4 * np.cos(th), y + 0.4 * np.sin(th)
+    out.append({'pos_global': [float(x), float(y)], 'theta': float(th)})
+  return out

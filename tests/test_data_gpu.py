@@ -132,3 +132,42 @@ def test_prefetcher_rasterises_targets_on_device():
       assert float(got['avg_factor_label'][j]) == float(avg)
     n += 1
   assert n == 4
+
+
+@pytest.mark.parametrize('seq', [1, 6])
+def test_prefetcher_aligns_and_bins_the_raw_lidar_sweeps_on_device(seq):
+  """the host batches carry what CARLA_Data.__getitem__ has BEFORE its numpy LiDAR work -- the raw float64
+  sweeps and the ego poses (here through carla_garage_amd.lidar.align_params + data.collate_lidar, per-sample dicts as a Dataset yields them) --
+  and the prefetcher produces `lidar_bev` on the copy stream.  Must equal, bit for bit, what the loader would have stacked: the oracle's
+  CARLA_Data.align + lidar_to_histogram_features per sample and time frame (pinned on the reference's own output by tests/test_lidar.py),
+  concatenated over time as data.py:536,558 concatenates them; the other keys take the usual path."""
+  import numpy as np
+  from oracle import lidar_port as L
+  from carla_garage_amd.config import GlobalConfig
+  from carla_garage_amd.data import DeviceBatchPrefetcher, collate_lidar
+  from carla_garage_amd.lidar import align_params
+  cfg = GlobalConfig(lidar_seq_len=seq) if seq > 1 else GlobalConfig()
+  bs, nb = 3, 3
+  host, want = [], []
+  for i, h in enumerate(_host_batches(cfg, nb, bs=bs)):
+    samples, bev = [], []
+    for j in range(bs):
+      meas = L.make_measurements(10 * i + j, seq)
+      y_aug, yaw_aug = 0.3 * j - 0.2, 4.0 * i - 3.0
+      sweeps = [L.make_sweep_f64(3000 + 500 * j + 100 * t, 1000 * i + 10 * j + t) for t in range(seq)]
+      if i == 1 and j == 2:
+        sweeps[0] = np.zeros((0, 3))  # an empty sweep in the middle of a batch
+      samples.append({'lidar_sweeps': sweeps, 'lidar_align': np.stack([align_params(meas[t], meas[seq - 1], y_aug, yaw_aug) for t in range(seq)]),
+                      **{k: v[j] for k, v in h.items() if k not in ('lidar', 'temporal_lidar')}})
+      bev.append(np.concatenate([L.lidar_to_histogram_features(L.align(sweeps[t], meas[t], meas[seq - 1], y_aug, yaw_aug), cfg.use_ground_plane)
+                                 for t in range(seq)], axis=0))
+    host.append(collate_lidar(samples, cfg))
+    want.append(np.stack(bev))
+  n = 0
+  for b, w, h in zip(DeviceBatchPrefetcher(host, cfg, lidar_on_device=True), want, host):
+    assert b['lidar_bev'].shape == w.shape and b['lidar_bev'].dtype == torch.float32
+    assert np.array_equal(b['lidar_bev'].cpu().numpy(), w), f'batch {n}'
+    assert torch.equal(b['rgb'], h['rgb'].to('cuda', torch.float32))
+    torch.cuda._sleep(10_000_000)
+    n += 1
+  assert n == nb

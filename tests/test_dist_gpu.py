@@ -46,6 +46,51 @@ def test_one_rank_rccl_group_runs_the_bucketed_exchange_eager_and_behind_one_hip
   assert r['loss_graph'] < 1e-2 and r['grad_graph'] < 1e-1, r
 
 
+def _two_ranks(mode):
+  port = _free_port()
+  procs = []
+  for rank in range(2):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), TFPP_FORCE_COLLECTIVES='0')
+    procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dist_two_ranks_worker.py'), mode], env=env, stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT))
+  res = []
+  for p in procs:
+    try:
+      text = p.communicate(timeout=900)[0].decode()
+    except subprocess.TimeoutExpired:
+      for q in procs:
+        q.kill()
+      raise
+    assert p.returncode == 0, text[-3000:]
+    res.append(json.loads([l for l in text.splitlines() if l.startswith('RESULT ')][-1][len('RESULT '):]))
+  try:
+    with open(os.path.join(ROOT, 'gpurun_out', 'model_report.jsonl'), 'a', encoding='utf-8') as f:
+      f.write(json.dumps({'test': 'two_ranks_one_gpu_' + mode, 'errs': res}) + '\n')
+  except OSError:
+    pass
+  return res
+
+
+def test_two_ranks_one_gpu_trainer_gradient_sum_layout_agreement_and_bit_equal_replicas():
+  """VERDICT r4 item 6b: the REAL Trainer with two ranks (two processes sharing this box's GPU, 'gloo' on device tensors), different batches per
+  rank (train.py:544-553).  The exchanged arena is the sum of the two local gradients; each rank observes its own backward pass and the layouts
+  agree; after three eager steps and two replays of the captured step the replicas are bit-equal and no completion-signal wait gave up."""
+  for r in _two_ranks('trainer'):
+    assert r['world'] == 2 and r['backend'] == 'gloo'
+    assert r['grad_sum_rel'] < 1e-5 and r['ranks_see_the_same_sum'], r         # (gloo sums on the host in fp32: not the kernels' order)
+    assert r['layout_final_after_eager'] and r['layouts_equal'] and r['buckets'] >= 3 and r['poisoned'] is None, r
+    assert r['steps'] == 5 and r['wait_timeouts'] == 0 and r['params_finite'] and r['replicas_bit_equal'], r
+    assert r['losses_differ_between_ranks'], r                               # the ranks really trained on different batches
+
+
+def test_two_ranks_one_gpu_dropin_module_under_distributed_data_parallel():
+  """The drop-in module wrapped by torch's DistributedDataParallel as train.py:516-520 wraps the reference's, two ranks on one GPU ('gloo'),
+  different batches, five steps of the restated train.py loop (the last two replayed from hipGraphs): replicas bit-equal, no wait gave up."""
+  for r in _two_ranks('dropin'):
+    assert r['world'] == 2 and r['graph_steps'] >= 2 and r['buckets'] >= 3, r
+    assert r['wait_timeouts'] == 0 and r['params_finite'] and r['replicas_bit_equal'] and r['losses_differ_between_ranks'], r
+
+
 def test_bench_refuses_to_report_more_gpus_than_it_runs_on():
   """VERDICT r1 weak #11: `python bench.py --gpus 2` without a launcher used to run one rank and print n_gpus: 1."""
   import torch

@@ -560,6 +560,45 @@ def test_train_step_bs12_bf16_vs_fp32_hip_and_golden():
 
 
 @pytest.mark.gpu
+def test_bf16_step_is_no_worse_than_the_autocast_reference():
+  """Pins the benchmarked precision against a bf16 REFERENCE: tests/golden/tfpp_bf16_autocast_bs12.npz holds what the
+  unmodified reference does to its own gradients when train.py:885's autocast runs in bfloat16 (oracle/make_golden_bf16.py: CPU autocast,
+  deterministic test weights, the bs = 12 batch, dropout 0).  The HIP bf16 step -- against the HIP fp32 step on the same weights and batch,
+  same formulas (oracle/grad_stats.py) -- must be no worse on any statistic, and its losses no further from the reference's fp32 losses
+  than twice the autocast reference's own distance."""
+  from oracle.grad_stats import STAT_KEYS, gradient_stats
+  g = U.load_golden('tfpp_bf16_autocast_bs12.npz')
+  want = dict(zip([str(k) for k in g['stat_names']], [float(v) for v in g['stats_autocast_vs_fp32']]))
+  m32 = _model('fp32').train()
+  _, v32, e32 = _engine_train_step(m32, 12)
+  ref = {n: e32.grads[n].detach().clone() for n in e32.grads}
+  del m32, e32
+  torch.cuda.empty_cache()
+  m16 = _model('bf16').train()
+  names, v16, e16 = _engine_train_step(m16, 12)
+  got = gradient_stats(ref, {n: e16.grads[n].detach() for n in ref})
+  l_ref = dict(zip([str(x) for x in g['loss_names']], g['losses_fp32']))
+  l_ac = dict(zip([str(x) for x in g['loss_names']], g['losses_autocast']))
+  l_hip = dict(zip(names, v16))
+  loss_dev = {n: (abs(float(l_hip[n]) - l_ref[n]) / abs(l_ref[n]), abs(l_ac[n] - l_ref[n]) / abs(l_ref[n])) for n in names}
+  # the HIP bf16 gradients against the autocast reference's gradients directly: two bf16 roundings of the same fp32 quantity
+  an = dict(zip([str(x) for x in g['grad_names']], g['autocast_grad_norms']))
+  fn = dict(zip([str(x) for x in g['grad_names']], g['fp32_grad_norms']))
+  big = max(fn.values())
+  direct = sorted(abs(float(e16.grads[n].double().norm()) - an[n]) / an[n] for n in ref if n in an and fn[n] >= 1e-3 * big)
+  _report('bf16_vs_autocast_reference', {'hip_bf16_vs_hip_fp32': got, 'reference_autocast_vs_reference_fp32': want,
+                                         'losses_rel_dev_hip_and_autocast': {n: [float(a), float(b)] for n, (a, b) in loss_dev.items()},
+                                         'hip_bf16_norms_vs_autocast_norms': {'median': direct[len(direct) // 2], 'p90': direct[int(0.9 * len(direct))], 'max': direct[-1]}})
+  slack = 1.02
+  assert got['arena_cosine'] >= 1.0 - (1.0 - want['arena_cosine']) * slack, (got, want)
+  for k in STAT_KEYS[1:]:
+    assert got[k] <= want[k] * slack, (k, got, want)
+  assert got['tensors'] >= 500
+  for n, (a, b) in loss_dev.items():
+    assert a <= 2.0 * b + 1e-3, (n, a, b)
+
+
+@pytest.mark.gpu
 def test_bf16_trains_like_fp32_over_50_steps():
   """Does the benchmarked precision TRAIN like fp32?  50 optimizer steps (AdamW-amsgrad, lr 1e-4, four different batches of 4 cycled, dropout
   off), a bf16 Trainer beside an fp32 Trainer from identical weights: the weighted training loss of both falls from ~96 to ~1.5 and the bf16
@@ -718,16 +757,20 @@ def test_dropin_autograd_path_matches_engine_path():
   np.testing.assert_allclose(float(total), float(g['total_loss']), rtol=1e-3)
   params = dict(m.named_parameters())
   worst = worst_el = 0.0
+  over = {}
   for name, (norm, gmax), samples in zip(g['grad_names'], g['grad_norms'], g['grad_samples']):
     if gmax < 1e-5:
       continue
     mine = params[str(name)].grad.detach().flatten()
-    worst = max(worst, abs(mine.double().norm().item() - norm) / norm)
+    e = abs(mine.double().norm().item() - norm) / norm
+    worst = max(worst, e)
+    if e > (GRAD_NORM_TOL_SE_FC1 if '.se.fc' in str(name) else GRAD_NORM_TOL):  # (the bars of _check_train_step_vs_golden: squeeze-excite layers 2e-2)
+      over[str(name)] = e
     idx = U.sample_idx(mine.numel())
     got = mine[torch.from_numpy(idx).to(mine.device)].float().cpu().numpy()
     worst_el = max(worst_el, float(np.max(np.abs(got - samples[:len(idx)]) / (norm / np.sqrt(mine.numel()) + np.abs(samples[:len(idx)])))))
   _report('dropin', {'worst_grad_norm': worst, 'worst_grad_elem': worst_el})
-  assert worst <= GRAD_NORM_TOL and worst_el <= GRAD_ELEM_TOL
+  assert not over and worst_el <= GRAD_ELEM_TOL, (over, worst_el)
   # predictions that are not the last forward's outputs (here: one clone) take compute_loss's general path (converted to the internal
   # layout) and give the same losses (tests/test_dropin_gpu.py covers gradients, accumulation, DDP and the hipGraph replays)
   with torch.no_grad():
@@ -801,6 +844,62 @@ def test_streams_and_hipgraph_do_not_change_the_training_step():
   _report('streams', errs)
   for name, e in errs.items():
     assert e['loss1'] < 1e-4 and e['grad1'] < 2e-2 and e['loss4'] < 1e-2 and e['grad4'] < 1e-1, (name, e)
+
+
+@pytest.mark.gpu
+def test_completion_signals_carry_their_pass_and_a_timeout_raises_at_the_next_step(monkeypatch):
+  """ADVICE r4 (two mediums) on carla_garage_amd/buckets.py.  (1) A signal carries the serial number of the pass that raised it: a pass the
+  host never book-kept (a bare graph.replay(), an eager pass that died) re-raises an OLD serial and cannot release the next exchange early --
+  the wait stays pending until the book-kept pass raises its own.  (2) A wait that gives up is reported at the NEXT exchange (the time-out
+  word travels to pinned host memory behind the step's collectives) -- in Trainer.finish_step and DropinStep._run_backward, not only at a
+  checkpoint."""
+  import time
+  from carla_garage_amd import buckets as B
+  from carla_garage_amd import dist as tdist
+  monkeypatch.setattr(tdist, 'exchange_enabled', lambda group=None: True)
+  monkeypatch.setattr(tdist, 'world_size', lambda group=None: 1)
+
+  class Done:
+
+    def wait(self):
+      pass
+
+  monkeypatch.setattr(tdist, 'all_reduce_async', lambda t, group=None, avg=False: Done())
+  flat = torch.zeros(256, device='cuda')
+  # ---- (1) stale serials never release a later wait
+  bk = B.GradBuckets()
+  bk.configure([0, 128, 256], 'cuda', observed=True)
+  bk.begin_issue()
+  bk.begin_pass()
+  prog = bk.finish()                      # pass 1 raises the end marker with serial 1
+  bk.exchange(flat, prog)
+  torch.cuda.synchronize()
+  bk.begin_pass()
+  bk.finish()                             # a pass nobody book-kept: re-raises serial 1
+  bk.begin_issue()                        # pass 2 is "issued" but its signal nodes have not run yet
+  bk.exchange(flat, prog)                 # waits for serial 2 on the exchange stream
+  time.sleep(0.2)
+  assert not bk.comm.query(), 'the wait for pass 2 was released by the stale signal of an un-book-kept pass'
+  bk.begin_pass()
+  bk.finish()                             # now pass 2 raises its end marker
+  torch.cuda.synchronize()
+  assert bk.comm.query() and bk.timed_out() == 0
+  bk.raise_if_timed_out(block=True)
+  # ---- (2) a wait that gives up raises at the next exchange
+  monkeypatch.setattr(B, 'WAIT_TIMEOUT_MS', 50)
+  bk2 = B.GradBuckets()
+  bk2.configure([0, 128, 256], 'cuda', observed=True)
+  bk2.begin_issue()
+  bk2.exchange(flat, ((), ()))            # nothing ever raises serial 1: the wait gives up after 50 ms, the "all-reduce" runs on whatever is there
+  torch.cuda.synchronize()
+  assert bk2.timed_out() == 1
+  bk2.begin_issue()
+  bk2.begin_pass()
+  prog2 = bk2.finish()
+  with pytest.raises(RuntimeError, match='completion-signal wait'):
+    bk2.exchange(flat, prog2)
+  bk2.exchange(flat, prog2)               # reported once; training code that catches it can go on
+  torch.cuda.synchronize()
 
 
 @pytest.mark.gpu

@@ -141,6 +141,55 @@ def test_conv_fwd_dgrad_wgrad(ops, case, dtype):
   _conv_case(ops, case, dtype)
 
 
+def test_weight_gradients_of_a_batch_as_grouped_launches(ops):
+  """tfpp_conv_wgrad_batch (round 5): the bf16 weight gradients of a whole flush of the weight-gradient lane in one call.  Layers of the
+  fusion-transformer / RegNet stage 2-4 / LiDAR-branch shapes (both tile classes, with and without a pixel split), a 3x3 layer and a narrow
+  layer (single-layer path inside the same call), a parameter used TWICE (the second use must not share the group) and a layer that
+  accumulates onto a non-zero gradient: every result equals the plain tfpp_conv_wgrad call and the fp32 reference."""
+  dtype = torch.bfloat16
+  layers = [  # P (pixels), Cin, Cout, k
+      (3840, 1512, 1512, 1), (3072, 576, 576, 1), (3072, 576, 576, 1), (12288, 576, 576, 1), (49152, 216, 216, 1), (12288, 216, 216, 1),
+      (3840, 576, 2304, 1), (3840, 2304, 576, 1), (768, 1512, 1512, 1), (30000, 72, 216, 1), (4096, 64, 64, 3), (5000, 72, 24, 1), (777, 216, 576, 1),
+  ]
+  items = []
+  for i, (P, cin, cout, k) in enumerate(layers):
+    H, W = (64, P // 64) if k == 3 else (1, 1)
+    B = 1 if k == 3 else P
+    x = (rnd(B, H, W, cin, dtype=dtype, seed=900 + i) * 0.5)
+    dy = (rnd(B, H, W, cout, dtype=dtype, seed=950 + i) * 0.5)
+    geo = dict(B=B, Hs=H, Ws=W, Cs=cin, Hd=H, Wd=W, Cd=cout, R=k, S=k, stride=1, pad=k // 2)
+    xd, dyd = dev(x, dtype), dev(dy, dtype)
+    if k == 1:
+      want = dy.reshape(-1, cout).double().t() @ x.reshape(-1, cin).double()
+      want = want.view(cout, cin, 1, 1)
+    else:
+      xr = x.permute(0, 3, 1, 2).double().requires_grad_(False)
+      wr = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+      F.conv2d(xr, wr, padding=k // 2).backward(dy.permute(0, 3, 1, 2).double())
+      want = wr.grad
+    items.append(dict(x=xd, dy=dyd, geo=geo, want=want.float(), shape=(cout, cin, k, k)))
+  # plain calls
+  single = []
+  for it in items:
+    dw = torch.zeros(it['shape'], device=DEV, dtype=torch.float32)
+    ops.conv_wgrad(it['dy'], it['x'], dw, **it['geo'])
+    single.append(dw)
+  # one batch: every layer, layer 1 a second time into the SAME gradient (2 x), layer 3 onto a gradient that already holds ones
+  grads = [torch.zeros(it['shape'], device=DEV, dtype=torch.float32) for it in items]
+  grads[3].fill_(1.0)
+  assert ops.wgrad_batch_begin()
+  for it, dw in zip(items, grads):
+    ops.conv_wgrad(it['dy'], it['x'], dw, **it['geo'])
+  ops.conv_wgrad(items[1]['dy'], items[1]['x'], grads[1], **items[1]['geo'])
+  assert torch.count_nonzero(grads[0]).item() == 0, 'collected calls must not launch before the batch ends'
+  ops.wgrad_batch_end()
+  torch.cuda.synchronize()
+  for i, (it, dw, dws) in enumerate(zip(items, grads, single)):
+    mult, off = (2.0 if i == 1 else 1.0), (1.0 if i == 3 else 0.0)
+    check(f'wgrad_batch.{i}.vs_reference', dw.cpu(), it['want'] * mult + off, dtype)
+    check(f'wgrad_batch.{i}.vs_single_call', dw.cpu(), dws.cpu() * mult + off, torch.float32, scale=5.0)
+
+
 # The shapes the benchmark (BASELINE config 3: bs = 12, bf16) actually runs, with the kernel variants it runs them on.
 # tfpp_conv_gemm_variant: 202 = 16-wave 256x128 LDS-DMA ring (K >= 1024, >= 128 tiles), 200 = 8-wave 128x128 (>= 256 tiles), 201 = 64x128,
 # 2 = LDS-staged 64x64 ...  (210 + i = the opt-in ping-pong GEMM of round 4: tests below)
@@ -558,6 +607,49 @@ def test_squeeze_excite(ops, dtype):
   check('se.dx', nchw(dx.float().cpu()), ps[0].grad, dtype, scale=3.0)
   for nme, g, p in zip(('dw1', 'db1', 'dw2', 'db2'), grads, ps[1:]):
     check('se.' + nme, g.cpu(), p.grad, dtype, scale=3.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(3, 10, 14, 72, 18), (12, 16, 64, 576, 144), (1, 8, 32, 1512, 378), (2, 64, 64, 72, 8)])
+def test_squeeze_excite_fused_one_launch_per_pass(ops, dtype, shape):
+  """tfpp_se_squeeze_gate / tfpp_se_bwd_squeeze / tfpp_se_param_grads (round 5) against torch AND against the unfused launch chain on the
+  RegNet shapes (bs = 12 stage 3, bs = 1 stage 4 of the inference tick, the 8-unit gate of stage 1); twice in a row: the tickets return to zero."""
+  B, H, W, C, RD = shape
+  x = rnd(B, C, H, W, dtype=dtype, seed=61)
+  w1, b1, w2, b2 = rnd(RD, C, seed=62) * (3.0 / C**0.5), rnd(RD, seed=63), rnd(C, RD, seed=64) * (3.0 / RD**0.5), rnd(C, seed=65)
+  ps = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+  s = ps[0].mean((2, 3))
+  hid_ref = F.relu(F.linear(s, ps[1], ps[2]))
+  gate_ref = torch.sigmoid(F.linear(hid_ref, ps[3], ps[4]))
+  want = ps[0] * gate_ref.view(B, C, 1, 1)
+  dy = rnd(B, C, H, W, dtype=dtype, seed=66)
+  want.backward(dy)
+  xd, dyd = dev(nhwc(x), dtype), dev(nhwc(dy), dtype)
+  wd = [dev(t) for t in (w1, b1, w2, b2)]
+  assert ops.se_fused_supported(B, RD) and ops.se_fused_supported(B, RD, C) == (C * RD <= ops.SE_FUSED_MAX_MACS)
+  for rep in range(2):
+    pool, hidden, gate = ops.se_squeeze_gate(xd, *wd)
+    check(f'se_fused.pool.{rep}', pool.cpu(), s, dtype)
+    check(f'se_fused.hidden.{rep}', hidden.cpu(), hid_ref, dtype)
+    check(f'se_fused.gate.{rep}', gate.cpu(), gate_ref, dtype)
+    dgate, dz1, dpool = ops.se_bwd_squeeze(dyd, xd, gate, hidden, wd[0], wd[2])
+    grads = [torch.zeros_like(t) for t in wd]
+    ops.se_param_grads(dgate, gate, hidden, pool, dz1, *grads)
+    dx = ops.se_bwd_apply(dyd, gate, dpool)
+    check(f'se_fused.dx.{rep}', nchw(dx.float().cpu()), ps[0].grad, dtype, scale=3.0)
+    for nme, g, p in zip(('dw1', 'db1', 'dw2', 'db2'), grads, ps[1:]):
+      check(f'se_fused.{nme}.{rep}', g.cpu(), p.grad, dtype, scale=3.0)
+  # the unfused chain on the same device tensors: same values up to the order of the fp32 dot products
+  pool_u = ops.mean_hw(xd)
+  hidden_u, gate_u = ops.se_gate_fwd(pool_u, *wd)
+  check('se_fused.gate_vs_unfused', gate.cpu(), gate_u.cpu(), torch.float32, scale=0.5)
+  dgate_u = ops.se_dgate(dyd, xd)
+  grads_u = [torch.zeros_like(t) for t in wd]
+  dpool_u = ops.se_gate_bwd(dgate_u, gate_u, hidden_u, pool_u, wd[0], wd[2], *grads_u)
+  check('se_fused.dgate_vs_unfused', dgate.cpu(), dgate_u.cpu(), torch.float32, scale=0.5)
+  check('se_fused.dpool_vs_unfused', dpool.cpu(), dpool_u.cpu(), torch.float32, scale=5.0)
+  torch.cuda.synchronize()
+  assert int(ops.gridsum_scratch(xd.device)[:64].view(torch.int32).abs().sum()) == 0, 'ticket counters must return to zero'
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
