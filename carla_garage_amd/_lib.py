@@ -14,7 +14,7 @@ ROOT = os.path.dirname(PKG_DIR)
 HEADER = os.path.join(ROOT, 'include', 'tfpp.h')
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libtfpp_hip.so')
-SOURCES = ['gemm_kernels.hip', 'gemm_glds.hip', 'gemm_pp.hip', 'gemm_wgrad_glds.hip', 'attention_kernels.hip', 'conv3x3_halo.hip', 'wgrad3x3_halo.hip', 'pointwise_kernels.hip', 'norm_kernels.hip', 'misc_kernels.hip', 'lidar_kernels.hip', 'swin_kernels.hip', 'bev_kernels.hip', 'head_kernels.hip', 'augment_kernels.hip']
+SOURCES = ['gemm_kernels.hip', 'gemm_glds.hip', 'gemm_wgrad_glds.hip', 'attention_kernels.hip', 'conv3x3_halo.hip', 'wgrad3x3_halo.hip', 'pointwise_kernels.hip', 'norm_kernels.hip', 'misc_kernels.hip', 'lidar_kernels.hip', 'swin_kernels.hip', 'bev_kernels.hip', 'head_kernels.hip', 'augment_kernels.hip']
 
 F32, BF16 = 0, 1
 ABI_VERSION = 3  # include/tfpp.h TFPP_ABI_VERSION

@@ -258,7 +258,7 @@ __device__ __forceinline__ void epi_pass_bf16(const tfpp_conv_params& p, const f
 }
 
 // Second half of epi_pass_bf16 on its own (the strip already holds 16 rows x 16 FN columns of fp32 results): used by kernels whose
-// accumulator layout is not the 16x16 one (gemm_pp.hip, 32x32x16 MFMA).  Same lane -> (row, 8-channel chunk) map, same arithmetic.
+// accumulator layout is not the 16x16 one (32x32x16 MFMA tiles).  Same lane -> (row, 8-channel chunk) map, same arithmetic.
 template <int FN>
 __device__ __forceinline__ void epi_finish_bf16(const tfpp_conv_params& p, const float* strip, int lane, long m_pass, int rows_valid,
                                                 int n_base, int g) {

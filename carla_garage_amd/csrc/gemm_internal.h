@@ -9,13 +9,6 @@ int conv_glds_variant(const tfpp_conv_params& p);
 int conv_glds_bm(int variant);  // rows per M-tile
 int conv_gemm_glds(const tfpp_conv_params& p, hipStream_t st);
 
-// ping-pong LDS-DMA GEMM (gemm_pp.hip), bf16 pointwise layers with large M, N, K; variant codes 210 + configuration index
-bool conv_pp_supported(const tfpp_conv_params& p, int dtype);
-int conv_pp_variant(const tfpp_conv_params& p);
-int conv_pp_splits(const tfpp_conv_params& p);
-int conv_pp_bm(int variant);
-int conv_gemm_pp(const tfpp_conv_params& p, hipStream_t st);
-
 // 3x3 / stride 1 / pad 1 with the input tile staged once in LDS (conv3x3_halo.hip), bf16, n_g <= 64; variant codes 300 + FN
 bool conv_halo_supported(const tfpp_conv_params& p, int dtype);
 int conv_halo_variant(const tfpp_conv_params& p);

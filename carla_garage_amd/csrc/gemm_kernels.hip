@@ -330,7 +330,6 @@ static bool use_glds_impl() {
 extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
   if (conv_halo_supported(*p, dtype)) return conv_halo_variant(*p);
-  if (conv_pp_supported(*p, dtype)) return conv_pp_variant(*p);
   if (use_glds_impl() && conv_glds_supported(*p, dtype)) return conv_glds_variant(*p);
   return conv_variant_for(*p, dtype);
 }
@@ -338,7 +337,6 @@ extern "C" int tfpp_conv_gemm_variant(const tfpp_conv_params* p, int dtype) {
 static int conv_splits_for(const tfpp_conv_params& p, int dtype) {
   const long M = (long)p.B * p.Hd * p.Wd;
   if (conv_halo_supported(p, dtype)) return 1;
-  if (conv_pp_supported(p, dtype)) return conv_pp_splits(p);
   if (use_glds_impl() && conv_glds_supported(p, dtype)) {
     const int var = conv_glds_variant(p), bm = conv_glds_bm(var);
     if (var == 202) return 1;  // >= 128 workgroups of 16 waves with >= 16 stages each: splitting K only adds the second pass
@@ -373,7 +371,6 @@ extern "C" int tfpp_conv_gemm_stats_rows(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
   const long M = (long)p->B * p->Hd * p->Wd;
   if (conv_halo_supported(*p, dtype)) return conv_halo_mtiles(*p);
-  // (the ping-pong GEMM of gemm_pp.hip has no statistics epilogue: a launch that asks for them runs on the ring kernels)
   if (use_glds_impl() && conv_glds_supported(*p, dtype)) return cdiv(M, conv_glds_bm(conv_glds_variant(*p)));
   return cdiv(M, kConvBm[conv_variant_for(*p, dtype)]);
 }
@@ -390,8 +387,7 @@ template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStr
   tfpp_conv_params q = p;
   q.splitk = conv_splits_for(p, ElemTraits<T>::DT);
   int rc;
-  if (conv_pp_supported(p, ElemTraits<T>::DT)) rc = conv_gemm_pp(q, st);
-  else if (use_glds_impl() && conv_glds_supported(p, ElemTraits<T>::DT)) rc = conv_gemm_glds(q, st);
+  if (use_glds_impl() && conv_glds_supported(p, ElemTraits<T>::DT)) rc = conv_gemm_glds(q, st);
   else {
     switch (conv_variant_for(p, ElemTraits<T>::DT)) {
       case 4:
@@ -688,7 +684,8 @@ struct GroupBuild {
 static int emit_wgrad_group(const std::vector<tfpp_wgrad_params>& its, int tile, int bkp, int grid_cap, hipStream_t st) {
   // target: ~4 workgroups per CU-slot over the whole group, every workgroup >= 512 pixels of reduction
   static const int target = [] { const char* e = std::getenv("TFPP_WGRAD_GROUP_TARGET"); const int v = e ? std::atoi(e) : 0; return v; }();
-  const long want_wgs = target > 0 ? target : (tile == 128 ? 1024 : 3072);
+  // (swept on the bs = 12 step, profiles/r05_ab_wgrad_group_target.txt: 256: +0.4 ms, 512: +0.05, 2048: -0.03, 6144: +0.1 against the ungrouped lane)
+  const long want_wgs = target > 0 ? target : 2048;
   size_t pos = 0;
   while (pos < its.size()) {
     const size_t n = std::min(its.size() - pos, (size_t)TFPP_WGRAD_GROUP_MAX);

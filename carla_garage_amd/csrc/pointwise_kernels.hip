@@ -907,191 +907,10 @@ __global__ void hw_reduce_kernel(const T* __restrict__ x, const T* __restrict__ 
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Fused squeeze-excite (round 5).  The unfused chain is hw_reduce -> col_final -> se_hidden -> se_gate (forward) and hw_reduce<DOT> ->
-// col_final -> se_dz1 -> se_param_grads (backward): four dependent launches of a few microseconds each on a chain whose cost is the
-// launch count (42 blocks per pass; at bs = 1 the forward is 792 launches of ~4 us).  Here the row-block workgroups of a sample publish
-// their partial sums and draw a ticket per sample (fixed-order grid sum, common.cuh); the workgroup that draws the last one finishes the
-// squeeze and runs the two tiny fully-connected layers for its sample out of LDS: one launch.  The weights are read by one workgroup
-// per sample (<= 0.7 MB up to stage 3, 4.6 MB in stage 4: 2 of 42 blocks).
-//   forward : pool = mean_hw(x); hidden = relu(W1 pool + b1); gate = sigmoid(W2 hidden + b2)
-//   backward: dgate = sum_hw dy * x; gd = dgate * g * (1 - g); dz1 = (hidden > 0) * W2^T gd; dpool = W1^T dz1
-//             (the parameter gradients need all samples: se_param_grads_kernel, on the weight-gradient lane)
-// ---------------------------------------------------------------------------------------------------------------
-#define SE_FUSED_MAX_RD 384
-// acc[r] = sum_c W[(row0 + r) * ld + c] * vec[c] for R rows at once, one wave: lanes walk the row in V-float vectors (coalesced), the R
-// row loads of a step are independent and issued together.  One workgroup runs these dot products for a whole sample, so what bounds
-// them is the number of DEPENDENT load round trips (~0.2 us each), not bytes: the first version (one row at a time, scalar loads:
-// 650 trips for stage 3) took 140 us where the unfused launches -- the same loads spread over hundreds of workgroups -- take 12.
-template <int R, int V>
-__device__ __forceinline__ void wave_rows_dot(const float* __restrict__ W, long ld, int n, const float* vec, int row0, int nrows, int lane,
-                                              float (&acc)[R]) {
-#pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = 0.f;
-  const int nv = n / V;  // n % V == 0
-#pragma unroll 2
-  for (int ch = lane; ch < nv; ch += 64) {
-    float x[V], w[R][V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) x[e] = vec[ch * V + e];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int row = row0 + r < nrows ? row0 + r : nrows - 1;
-      const float* q = W + (long)row * ld + ch * V;
-      if constexpr (V == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(q);
-        w[r][0] = t.x; w[r][1] = t.y; w[r][2] = t.z; w[r][3] = t.w;
-      } else if constexpr (V == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(q);
-        w[r][0] = t.x; w[r][1] = t.y;
-      } else {
-        w[r][0] = *q;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int e = 0; e < V; ++e) acc[r] += w[r][e] * x[e];
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-}
-template <typename T>
-__global__ __launch_bounds__(256) void se_squeeze_gate_kernel(const T* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                              const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ pool,
-                                                              float* __restrict__ hidden, float* __restrict__ gate, float* __restrict__ partial,
-                                                              unsigned* __restrict__ tickets, int HW, int CV, int sw, int rp, int RD) {
-  constexpr int VEC = ElemTraits<T>::VEC;
-  int rr, cv;
-  const bool active = col_thread(sw, rp, CV, rr, cv);
-  const int b = blockIdx.z, C = CV * VEC;
-  float acc[VEC];
-  hw_accumulate<T, false>(x, nullptr, b, HW, CV, rp, rr, cv, active, acc);
-  __shared__ float sm[VEC * 256];
-  col_block_reduce<VEC>(acc, sw, rp, rr, sm);
-  if (active && rr == 0) {
-    float* o = partial + ((size_t)b * gridDim.x + blockIdx.x) * C + cv * VEC;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) grid_publish(o + e, acc[e]);
-  }
-  if (!grid_last_ticket(tickets + b, gridDim.x * gridDim.y)) return;
-  extern __shared__ float se_dyn[];  // pool [C], hidden [RD]
-  float* s_pool = se_dyn;
-  float* s_hid = se_dyn + C;
-  const float inv = 1.f / (float)HW;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float t0 = grid_fetch_sum16(partial + (size_t)b * gridDim.x * C + c, C, (int)gridDim.x);  // row-block order: fixed; gridDim.x <= 16
-    const float t = t0 * inv;
-    s_pool[c] = t;
-    pool[(size_t)b * C + c] = t;
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {  // hidden units: 8 rows of W1 per wave and step, float4 loads (C % 4 == 0)
-    constexpr int R = 8;
-    for (int j0 = wave * R; j0 < RD; j0 += 4 * R) {
-      float t[R];
-      wave_rows_dot<R, 4>(w1, C, C, s_pool, j0, RD, lane, t);
-      if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-          if (j0 + r < RD) {
-            float u = t[r] + b1[j0 + r];
-            u = u > 0.f ? u : 0.f;
-            s_hid[j0 + r] = u;
-            hidden[(size_t)b * RD + j0 + r] = u;
-          }
-      }
-    }
-  }
-  __syncthreads();
-  {  // gate: 8 rows of W2 per wave and step (16 rows cost 238 VGPRs: two waves per SIMD for the squeeze phase of every workgroup); the rows
-    // are RD floats long: 16-, 8- or 4-byte vectors as RD allows (8, 54, 144, 378)
-    constexpr int R = 8;
-    for (int c0 = wave * R; c0 < C; c0 += 4 * R) {
-      float t[R];
-      if ((RD & 3) == 0) wave_rows_dot<R, 4>(w2, RD, RD, s_hid, c0, C, lane, t);
-      else if ((RD & 1) == 0) wave_rows_dot<R, 2>(w2, RD, RD, s_hid, c0, C, lane, t);
-      else wave_rows_dot<R, 1>(w2, RD, RD, s_hid, c0, C, lane, t);
-      if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-          if (c0 + r < C) gate[(size_t)b * C + c0 + r] = 1.f / (1.f + __expf(-(t[r] + b2[c0 + r])));
-      }
-    }
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void se_bwd_squeeze_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gate,
-                                                             const float* __restrict__ hidden, const float* __restrict__ w1, const float* __restrict__ w2,
-                                                             float* __restrict__ dgate, float* __restrict__ dz1, float* __restrict__ dpool,
-                                                             float* __restrict__ partial, unsigned* __restrict__ tickets, int HW, int CV, int sw, int rp,
-                                                             int RD) {
-  constexpr int VEC = ElemTraits<T>::VEC;
-  int rr, cv;
-  const bool active = col_thread(sw, rp, CV, rr, cv);
-  const int b = blockIdx.z, C = CV * VEC;
-  float acc[VEC];
-  hw_accumulate<T, true>(dy, x, b, HW, CV, rp, rr, cv, active, acc);
-  __shared__ float sm[VEC * 256];
-  col_block_reduce<VEC>(acc, sw, rp, rr, sm);
-  if (active && rr == 0) {
-    float* o = partial + ((size_t)b * gridDim.x + blockIdx.x) * C + cv * VEC;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) grid_publish(o + e, acc[e]);
-  }
-  if (!grid_last_ticket(tickets + b, gridDim.x * gridDim.y)) return;
-  extern __shared__ float se_dyn[];  // gd [C], dz1 [RD], wave partials [4][RDP]
-  const int RDP = (RD + 63) & ~63;
-  float* s_gd = se_dyn;
-  float* s_dz = se_dyn + C;
-  float* s_red = s_dz + RDP;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float t = grid_fetch_sum16(partial + (size_t)b * gridDim.x * C + c, C, (int)gridDim.x);
-    dgate[(size_t)b * C + c] = t;
-    const float g = gate[(size_t)b * C + c];
-    s_gd[c] = t * g * (1.f - g);
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {  // dz1[j] = (hidden[j] > 0) * sum_c gd[c] * W2[c][j]: wave w walks channels w, w + 4, ..., lanes over j (coalesced rows of W2)
-    constexpr int QMAX = SE_FUSED_MAX_RD / 64;
-    float a[QMAX];
-#pragma unroll
-    for (int q = 0; q < QMAX; ++q) a[q] = 0.f;
-#pragma unroll 8
-    for (int c = wave; c < C; c += 4) {  // (independent loads: unrolled so that eight rows of W2 are in flight per wave)
-      const float g = s_gd[c];
-      const float* wr = w2 + (size_t)c * RD;
-#pragma unroll
-      for (int q = 0; q < QMAX; ++q) {
-        const int j = lane + q * 64;
-        if (j < RD) a[q] += g * wr[j];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < QMAX; ++q) {
-      const int j = lane + q * 64;
-      if (j < RDP) s_red[wave * RDP + j] = a[q];
-    }
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < RD; j += 256) {
-    float t = s_red[j] + s_red[RDP + j] + s_red[2 * RDP + j] + s_red[3 * RDP + j];
-    t = hidden[(size_t)b * RD + j] > 0.f ? t : 0.f;
-    s_dz[j] = t;
-    dz1[(size_t)b * RD + j] = t;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {  // dpool[c] = sum_j dz1[j] * W1[j][c]: thread per channel (coalesced rows of W1)
-    float t = 0.f;
-#pragma unroll 16
-    for (int j = 0; j < RD; ++j) t += s_dz[j] * w1[(size_t)j * C + c];
-    dpool[(size_t)b * C + c] = t;
-  }
-}
-
+// (Round 5 measured a fused squeeze-excite -- squeeze + fc1 + fc2 in ONE launch, the workgroup that draws the last ticket of a sample runs the two
+// tiny fully-connected layers -- and removed it again: alone on the chip it wins only for stage 1 (20 vs 29 us), stage 3 takes 66 us and stage 4
+// 231 us against 30 us for the four launches below (a chain of dependent load round trips on ONE CU, profiles/r05_se_micro.txt); in the step
+// even the stage-1-only variant cost +0.7 ms and the bs = 1 forward did not move (profiles/r05_ab_se_*.txt).)
 template <typename T>
 static int launch_hw_reduce(const void* x, const void* y, float* out, float* scratch, int B, int HW, int C, float mulv, hipStream_t st) {
   constexpr int VEC = ElemTraits<T>::VEC;
@@ -1239,64 +1058,6 @@ extern "C" int tfpp_se_gate_bwd(const float* dgate, const float* gate, const flo
   const int nblk_dw = (int)((2l * C * RD + 255) / 256);
   hipLaunchKernelGGL(se_param_grads_kernel, dim3((unsigned)(nblk_dw + B * ((C + 15) / 16))), dim3(256), 0, st, dgate, gate, hidden, pool, w1,
                      dz1_scratch, dpool, dw1, db1, dw2, db2, B, C, RD, nblk_dw);
-  TFPP_CHECK_LAUNCH();
-  return 0;
-}
-
-// Fused squeeze-excite entry points (kernels above).  partial: tfpp_reduce_scratch_floats(B, C) floats; tickets: the first B words of a
-// tfpp_gridsum_scratch_floats() buffer (zero before the first use, left at zero).  B <= TFPP_GRIDSUM_TICKETS, RD <= SE_FUSED_MAX_RD.
-template <typename T>
-static int launch_se_fused(bool bwd, const void* a, const void* x, const float* gate_in, const float* hidden_in, const float* w1, const float* b1,
-                           const float* w2, const float* b2, float* o0, float* o1, float* o2, float* partial, float* tickets, int B, int HW, int C,
-                           int RD, hipStream_t st) {
-  constexpr int VEC = ElemTraits<T>::VEC;
-  if (C % VEC || B < 1 || B > TFPP_GRIDSUM_TICKETS || RD < 1 || RD > SE_FUSED_MAX_RD || (C & 3)) return TFPP_EINVAL;
-  if ((((uintptr_t)w1) & 15) || (((uintptr_t)w2) & (RD % 4 == 0 ? 15 : RD % 2 == 0 ? 7 : 3))) return TFPP_EINVAL;  // vector loads of the weight rows
-  const ColLayout l = col_layout(C / VEC);
-  int nb = col_blocks_x(HW, l, bwd ? 4 : 8, 4096, B);
-  if (nb > 16) nb = 16;  // one batch of sc1 loads per channel in the tail (grid_fetch_sum16)
-  dim3 grid((unsigned)nb, (unsigned)l.ny, (unsigned)B);
-  const int RDP = (RD + 63) & ~63;
-  if (!bwd) {
-    hipLaunchKernelGGL((se_squeeze_gate_kernel<T>), grid, dim3(256), (size_t)(C + RD) * sizeof(float), st, (const T*)x, w1, b1, w2, b2, o0, o1, o2, partial,
-                       reinterpret_cast<unsigned*>(tickets), HW, C / VEC, l.sw, l.rp, RD);
-  } else {
-    hipLaunchKernelGGL((se_bwd_squeeze_kernel<T>), grid, dim3(256), (size_t)(C + 5 * RDP) * sizeof(float), st, (const T*)a, (const T*)x, gate_in, hidden_in,
-                       w1, w2, o0, o1, o2, partial, reinterpret_cast<unsigned*>(tickets), HW, C / VEC, l.sw, l.rp, RD);
-  }
-  TFPP_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int tfpp_se_squeeze_gate(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, float* pool, float* hidden,
-                                    float* gate, float* partial_scratch, float* ticket_scratch, int B, int HW, int C, int RD, int dtype, void* stream) {
-  if (!x || !w1 || !b1 || !w2 || !b2 || !pool || !hidden || !gate || !partial_scratch || !ticket_scratch) return TFPP_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == TFPP_F32) return launch_se_fused<float>(false, nullptr, x, nullptr, nullptr, w1, b1, w2, b2, pool, hidden, gate, partial_scratch, ticket_scratch, B, HW, C, RD, st);
-  if (dtype == TFPP_BF16) return launch_se_fused<bf16_t>(false, nullptr, x, nullptr, nullptr, w1, b1, w2, b2, pool, hidden, gate, partial_scratch, ticket_scratch, B, HW, C, RD, st);
-  return TFPP_EINVAL;
-}
-
-extern "C" int tfpp_se_bwd_squeeze(const void* dy, const void* x, const float* gate, const float* hidden, const float* w1, const float* w2,
-                                   float* dgate, float* dz1, float* dpool, float* partial_scratch, float* ticket_scratch, int B, int HW, int C, int RD,
-                                   int dtype, void* stream) {
-  if (!dy || !x || !gate || !hidden || !w1 || !w2 || !dgate || !dz1 || !dpool || !partial_scratch || !ticket_scratch) return TFPP_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == TFPP_F32) return launch_se_fused<float>(true, dy, x, gate, hidden, w1, nullptr, w2, nullptr, dgate, dz1, dpool, partial_scratch, ticket_scratch, B, HW, C, RD, st);
-  if (dtype == TFPP_BF16) return launch_se_fused<bf16_t>(true, dy, x, gate, hidden, w1, nullptr, w2, nullptr, dgate, dz1, dpool, partial_scratch, ticket_scratch, B, HW, C, RD, st);
-  return TFPP_EINVAL;
-}
-
-// parameter gradients of the gate MLP alone (dz1 comes from tfpp_se_bwd_squeeze): dw2 += gd^T hidden, db2 += sum_b gd, dw1 += dz1^T pool,
-// db1 += sum_b dz1.  They feed only the optimizer: the engine issues this launch on the weight-gradient lane.
-extern "C" int tfpp_se_param_grads(const float* dgate, const float* gate, const float* hidden, const float* pool, const float* dz1, float* dw1,
-                                   float* db1, float* dw2, float* db2, int B, int C, int RD, void* stream) {
-  if (!dgate || !gate || !hidden || !pool || !dz1 || !dw1 || !db1 || !dw2 || !db2) return TFPP_EINVAL;
-  if (2l * C * RD >= (1l << 31)) return TFPP_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const int nblk_dw = (int)((2l * C * RD + 255) / 256);
-  hipLaunchKernelGGL(se_param_grads_kernel, dim3((unsigned)nblk_dw), dim3(256), 0, st, dgate, gate, hidden, pool, (const float*)nullptr, dz1,
-                     (float*)nullptr, dw1, db1, dw2, db2, B, C, RD, nblk_dw);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

@@ -1231,26 +1231,15 @@ class Engine:
     B, H, W, C = x.shape
     w1, b1 = se.fc1.weight.detach().view(se.fc1.weight.shape[0], C), se.fc1.bias.detach()
     w2, b2 = se.fc2.weight.detach().view(C, -1), se.fc2.bias.detach()
-    fused = ops.se_fused_supported(B, w1.shape[0], C)  # one launch for squeeze + fc1 + fc2 (and their backward) instead of four
-    if fused:
-      pool, hidden, gate = ops.se_squeeze_gate(x, w1, b1, w2, b2)
-    else:
-      pool = ops.mean_hw(x)
-      hidden, gate = ops.se_gate_fwd(pool, w1, b1, w2, b2)
+    pool = ops.mean_hw(x)
+    hidden, gate = ops.se_gate_fwd(pool, w1, b1, w2, b2)
     y = ops.affine_act(x, gate=gate, rows_per_batch=H * W)
     if self.tape is not None:
 
       def bwd(dy):
-        if fused:
-          dgate, dz1, dpool = ops.se_bwd_squeeze(dy, x, gate, hidden, w1, w2)
-          # the parameter gradients of the gate MLP only feed the optimizer: weight-gradient lane
-          self.side.label = 'squeeze_excite'
-          self.side.run(Tape.current, lambda: ops.se_param_grads(dgate, gate, hidden, pool, dz1, self.g(se.fc1.weight), self.g(se.fc1.bias),
-                                                                self.g(se.fc2.weight), self.g(se.fc2.bias)), dgate, dz1)
-        else:
-          dgate = ops.se_dgate(dy, x)
-          dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
-                                  self.g(se.fc2.weight), self.g(se.fc2.bias))
+        dgate = ops.se_dgate(dy, x)
+        dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
+                                self.g(se.fc2.weight), self.g(se.fc2.bias))
         info = self._bn_of.get(_key(x)) if x.dtype == torch.bfloat16 else None
         if info is not None and info[2] and Tape.current.is_last_contribution(x):
           # x = relu(BN(raw)) of conv2: this IS its complete gradient -> emit the BatchNorm-backward sums in the same pass

@@ -133,8 +133,6 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
     var = lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p), dt(src))
     if var >= 300:
       tile = f'halo8x32x{(var - 300) * 16}'
-    elif var >= 210:  # ping-pong GEMM (csrc/gemm_pp.hip)
-      tile = 'pp' + ('256x256', '256x256m32', '256x192', '256x128', '128x256', '128x192', '128x128', '256x192s64')[var - 210]
     elif var >= 200:
       tile = ('glds128x128', 'glds64x128', 'glds256x128')[var - 200]
     else:
@@ -614,48 +612,6 @@ def se_gate_bwd(dgate, gate, hidden, pool, w1, w2, dw1, db1, dw2, db2):
   lib.tfpp_se_gate_bwd(ptr(dgate), ptr(gate), ptr(hidden), ptr(pool), ptr(w1), ptr(w2), ptr(scratch), ptr(dpool), ptr(dw1), ptr(db1),
                        ptr(dw2), ptr(db2), b, c, rd, stream())
   return dpool
-
-
-SE_FUSED = _os.environ.get('TFPP_SE_FUSED', '1') != '0'  # 0: the unfused launch chain (A/B runs, op-level comparison tests)
-
-
-SE_FUSED_MAX_MACS = int(_os.environ.get('TFPP_SE_FUSED_MAX_MACS', '4096'))
-
-
-def se_fused_supported(b, rd, c=0):
-  """The tail of the fused kernels runs fc1 / fc2 of a sample on ONE workgroup, i.e. as a chain of dependent load round trips on one CU.
-  Measured alone on the chip (tools/se_micro.py, profiles/r05_se_micro.txt; forward, us fused / unfused): stage 1 (72 x 8) 20 / 29, stage 2
-  (216 x 54) 30 / 30, stage 3 (576 x 144) 66 / 30, stage 4 (1512 x 378) 231 / 30 -- and in the step: fused up to stage 3 = +2.7 ms / step,
-  +0.85 ms on the bs = 1 forward (profiles/r05_ab_se2.txt).  The default therefore fuses stage 1 only (C x RD <= 4096)."""
-  return SE_FUSED and b <= 64 and rd <= 384 and c * rd <= SE_FUSED_MAX_MACS
-
-
-def se_squeeze_gate(x, w1, b1, w2, b2):
-  """pool, hidden, gate of one squeeze-excite block in ONE launch (tfpp_se_squeeze_gate)."""
-  b, h, w, c = x.shape
-  rd = w1.shape[0]
-  pool = torch.empty((b, c), device=x.device, dtype=torch.float32)
-  hidden = torch.empty((b, rd), device=x.device, dtype=torch.float32)
-  gate = torch.empty((b, c), device=x.device, dtype=torch.float32)
-  lib.tfpp_se_squeeze_gate(ptr(_chk(x)), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(pool), ptr(hidden), ptr(gate), ptr(reduce_scratch(b, c, x.device)),
-                           ptr(gridsum_scratch(x.device)), b, h * w, c, rd, dt(x), stream())
-  return pool, hidden, gate
-
-
-def se_bwd_squeeze(dy, x, gate, hidden, w1, w2):
-  """dgate, dz1, dpool of one squeeze-excite block in ONE launch (tfpp_se_bwd_squeeze)."""
-  b, h, w, c = x.shape
-  rd = hidden.shape[1]
-  dgate, dpool = torch.empty_like(gate), torch.empty_like(gate)
-  dz1 = torch.empty_like(hidden)
-  lib.tfpp_se_bwd_squeeze(ptr(_chk(dy)), ptr(_chk(x)), ptr(gate), ptr(hidden), ptr(w1), ptr(w2), ptr(dgate), ptr(dz1), ptr(dpool),
-                          ptr(reduce_scratch(b, c, x.device)), ptr(gridsum_scratch(x.device)), b, h * w, c, rd, dt(x), stream())
-  return dgate, dz1, dpool
-
-
-def se_param_grads(dgate, gate, hidden, pool, dz1, dw1, db1, dw2, db2):
-  b, c = gate.shape
-  lib.tfpp_se_param_grads(ptr(dgate), ptr(gate), ptr(hidden), ptr(pool), ptr(dz1), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), b, c, hidden.shape[1], stream())
 
 
 def se_bwd_apply(dy, gate, dpool):

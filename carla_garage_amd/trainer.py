@@ -100,7 +100,19 @@ class Trainer:
     dropin.DropinStep run it on their eager warm-up steps only."""
     eng = self.eng
     obs = eng.observed_buckets
-    if self.layout_final or obs is None or not getattr(eng, 'observation_stable', False):
+    if self.layout_final:
+      return False
+    if self.exchange and tdist.exchange_enabled(self.pg) and self.world > 1:
+      # Agreed by construction (ADVICE r4): every rank adopts RANK 0's observation -- one small object broadcast per eager warm-up step until
+      # rank 0 has a stable one -- so all ranks re-home on the same step with the same layout; agree_on_layout() stays as an assertion.
+      # (Each rank acting on its OWN observation could re-home on different steps: one rank would then issue the layout check's int64
+      # all-reduce while another issues a gradient bucket's float all-reduce.)
+      box = [obs if (obs is not None and getattr(eng, 'observation_stable', False)) else None]
+      dist.broadcast_object_list(box, src=0, group=self.pg)
+      obs = box[0]
+      if obs is None:
+        return False
+    elif obs is None or not getattr(eng, 'observation_stable', False):
       return False
     assign, flushes = obs
     self.layout_final = True

@@ -97,11 +97,6 @@ int tfpp_conv_gemm_mtiles(const tfpp_conv_params* p);
 int tfpp_conv_gemm_stats_rows(const tfpp_conv_params* p, int dtype);
 /* 1 if the kernel the dispatcher runs for (p, dtype) supports the fused BatchNorm-backward statistics (bns_* fields) */
 int tfpp_conv_gemm_bns_ok(const tfpp_conv_params* p, int dtype);
-/* selection of the ping-pong GEMM (csrc/gemm_pp.hip; fusion-transformer linears, stage-4 1x1 convs): cfg 0 = kernel off (default: the
- * LDS-DMA ring kernels run; the training step is not faster with it, see the source), -2 = automatic plan, 1 + i + 100 * s = tile configuration i (0: 256x256, 1: 256x256 with 32x32x16
- * MFMAs, 2: 256x192, 3: 256x128, 4: 128x256, 5: 128x192, 6: 128x128, 7: 256x192 with 64-row slabs) with s K slices (0: one).
- * Process-wide; tools/gemm_pp_micro.py. */
-int tfpp_gemm_pp_config(int cfg);
 /* debugging aid (TFPP_GLDS_TRACE=1): per-workgroup phase timestamps of the last LDS-DMA GEMM launch; returns slots per workgroup */
 int tfpp_debug_glds_trace(uint64_t* out, int n_blocks);
 
@@ -382,20 +377,6 @@ int tfpp_se_gate_bwd(const float* dgate, const float* gate, const float* hidden,
                      const float* w2, float* dz1_scratch /* [B*RD] */, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
                      int B, int C, int RD, void* stream);
 int tfpp_se_bwd_apply(const void* dy, const float* gate, const float* dpool, void* dx, int B, int HW, int C, int dtype, void* stream);
-/* Fused squeeze-excite (round 5): one launch per pass instead of four.  The row-block workgroups of a sample publish their partial sums
- * and draw a ticket per sample; the workgroup that draws the last one finishes the squeeze and runs fc1 / fc2 (forward) or their data
- * gradients (backward) for its sample.  Same arithmetic as tfpp_mean_hw + tfpp_se_gate_fwd and tfpp_se_dgate + tfpp_se_gate_bwd up to the
- * order of the fp32 dot products (timm SEModule; called per bottleneck from transfuser.py:207-220 through timm's RegNet stages).
- * partial_scratch: tfpp_reduce_scratch_floats(B, C) floats; ticket_scratch: a tfpp_gridsum_scratch_floats() buffer (zero before the first
- * use, left at zero; not shared between concurrent streams).  B <= 64, RD <= 384, else TFPP_EINVAL (callers fall back to the unfused calls).
- * tfpp_se_param_grads: the parameter gradients alone (dw1 += dz1^T pool, db1, dw2 += gd^T hidden, db2), off the dY chain. */
-int tfpp_se_squeeze_gate(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, float* pool, float* hidden,
-                         float* gate, float* partial_scratch, float* ticket_scratch, int B, int HW, int C, int RD, int dtype, void* stream);
-int tfpp_se_bwd_squeeze(const void* dy, const void* x, const float* gate, const float* hidden, const float* w1, const float* w2,
-                        float* dgate, float* dz1, float* dpool, float* partial_scratch, float* ticket_scratch, int B, int HW, int C, int RD,
-                        int dtype, void* stream);
-int tfpp_se_param_grads(const float* dgate, const float* gate, const float* hidden, const float* pool, const float* dz1, float* dw1,
-                        float* db1, float* dw2, float* db2, int B, int C, int RD, void* stream);
 /* se_bwd_apply with the BatchNorm-backward statistics of the preceding layer fused in (conv2 of a RegNet bottleneck: dx is the
  * complete gradient of y = relu(BN(x))): also writes tfpp_se_bwd_apply_bns_rows(B, HW, C, dtype) rows [2*C] of (sum g, sum g*xhat),
  * g = dx * (y > 0), for tfpp_bn_bwd_apply_rows. */

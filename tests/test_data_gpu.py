@@ -151,6 +151,9 @@ def test_prefetcher_aligns_and_bins_the_raw_lidar_sweeps_on_device(seq):
   host, want = [], []
   for i, h in enumerate(_host_batches(cfg, nb, bs=bs)):
     samples, bev = [], []
+    if seq > 1:  # the temporal CenterNet labels of a multi-frame configuration (data.py:725-728), absent from the single-frame synthetic batch
+      h['velocity'] = torch.zeros(bs, 1, 64, 64)
+      h['brake_target'] = torch.zeros(bs, 64, 64, dtype=torch.int32)
     for j in range(bs):
       meas = L.make_measurements(10 * i + j, seq)
       y_aug, yaw_aug = 0.3 * j - 0.2, 4.0 * i - 3.0

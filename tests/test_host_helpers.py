@@ -84,8 +84,8 @@ def test_no_decay_bitmask_marks_whole_parameters_and_their_padding():
 
 
 def test_the_product_never_imports_the_oracle():
-  """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() (carla_garage_amd/smoke.py, the checker of one small invocation) and
-  bench.py's cpu_baseline / bit-exactness legs may import it.  Static check over the package sources + a dynamic one: importing every product
+  """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() (tools/smoke_check.py, the checker of one small invocation) and
+  bench.py's cpu_baseline / bit-exactness legs may import it; no file of the package is exempt.  Static check over the package sources + a dynamic one: importing every product
   module leaves no `oracle` module behind."""
   import glob
   import os
@@ -95,12 +95,10 @@ def test_the_product_never_imports_the_oracle():
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   offenders = []
   for f in glob.glob(os.path.join(root, 'carla_garage_amd', '*.py')):
-    if os.path.basename(f) == 'smoke.py':
-      continue
     if re.search(r'^\s*(from|import)\s+oracle\b', open(f, encoding='utf-8').read(), re.M):
       offenders.append(f)
   assert not offenders, offenders
-  mods = sorted(os.path.basename(f)[:-3] for f in glob.glob(os.path.join(root, 'carla_garage_amd', '*.py')) if os.path.basename(f) not in ('smoke.py', '__init__.py'))
+  mods = sorted(os.path.basename(f)[:-3] for f in glob.glob(os.path.join(root, 'carla_garage_amd', '*.py')) if os.path.basename(f) != '__init__.py')
   code = 'import sys, importlib\n' + ''.join(f'importlib.import_module("carla_garage_amd.{m}")\n' for m in mods) + \
       'bad = [k for k in sys.modules if k == "oracle" or k.startswith("oracle.")]\nassert not bad, bad\nprint("ok")'
   r = subprocess.run([sys.executable, '-c', code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, check=False)

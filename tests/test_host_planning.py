@@ -66,21 +66,6 @@ def test_conv_kernel_selection(L):
   assert variant(L, conv(3840, 1, 1, 1512, 6048)) == 202        # fusion MLP: K >= 1024 and >= 128 tiles of 256x128 (16 waves)
   assert variant(L, conv(3840, 1, 1, 576, 2304)) == 200         # K = 576: too short for the 144 KB ring
   assert variant(L, conv(12, 8, 32, 1512, 1512)) == 202         # image stage-4 1x1 conv
-  # the opt-in ping-pong GEMM (round 4, csrc/gemm_pp.hip; tfpp_gemm_pp_config(-2) = its automatic plan): 212 = 256x192 tiles, 215 = 128x192,
-  # 216 = 128x128 -- the plan measured with the kernel alone on the chip (tools/gemm_pp_micro.py)
-  cfg = L.raw('tfpp_gemm_pp_config')
-  try:
-    assert cfg(-2) == 0
-    assert variant(L, conv(3840, 1, 1, 1512, 6048)) == 212        # fusion MLP fc1: 480 tiles of 256x192 = two rounds of the chip
-    assert variant(L, conv(3840, 1, 1, 6048, 1512)) == 215        # fc2 (and fc1's data gradient): 240 tiles of 128x192, 95 K tiles each
-    assert variant(L, conv(3840, 1, 1, 1512, 4608)) == 215        # fused QKV
-    assert variant(L, conv(3840, 1, 1, 576, 2304)) == 215         # the C = 576 transformer
-    assert variant(L, conv(3840, 1, 1, 2304, 576)) == 216         # narrow N, long K: 128x128
-    assert variant(L, conv(12, 8, 32, 1512, 1512)) == 215         # image stage-4 1x1 conv (data gradient; the forward fuses BatchNorm statistics:)
-    assert variant(L, conv(12, 8, 32, 1512, 1512, stats=True)) == 202  # ... 16-wave 256x128 LDS-DMA ring
-    assert variant(L, conv(3840, 1, 1, 576, 576)) == 201          # N and K short: the ring kernels stay (equal on 12288x576x576)
-  finally:
-    cfg(0)
   assert variant(L, conv(12, 16, 64, 576, 576), F32) in (2, 3)  # fp32 never takes the bf16-only kernels
   assert variant(L, conv(12, 32, 128, 216, 216)) == 200           # stage-2 1x1 conv: K = 216 >= 200 runs the 64-deep LDS-DMA ring (K tail through the zero page)
   assert variant(L, conv(12, 64, 256, 72, 144)) in (0, 1, 2, 3, 4)  # K = 72 < 200: LDS-staged

@@ -192,7 +192,7 @@ def test_weight_gradients_of_a_batch_as_grouped_launches(ops):
 
 # The shapes the benchmark (BASELINE config 3: bs = 12, bf16) actually runs, with the kernel variants it runs them on.
 # tfpp_conv_gemm_variant: 202 = 16-wave 256x128 LDS-DMA ring (K >= 1024, >= 128 tiles), 200 = 8-wave 128x128 (>= 256 tiles), 201 = 64x128,
-# 2 = LDS-staged 64x64 ...  (210 + i = the opt-in ping-pong GEMM of round 4: tests below)
+# 2 = LDS-staged 64x64 ...
 # weight-gradient plan {variant, slices, second stage}: see tfpp_conv_wgrad_stage.
 TRUE_SHAPES = [
     # name, B, H, W, Cin, Cout, k, stride, groups, expected forward variant, expected dgrad variant
@@ -222,66 +222,6 @@ def test_conv_benchmark_shapes_on_the_benchmark_kernels(ops, entry):
     assert var in WGRAD_GLDS_VARIANTS, plans
   if case[0] in WGRAD_EXPECT:
     assert (var, slices > 1, second) == WGRAD_EXPECT[case[0]], plans
-
-
-PP_CONFIGS = ['256x256', '256x256/32x32x16', '256x192', '256x128', '128x256', '128x192', '128x128', '256x192/slab64']
-
-
-@pytest.mark.parametrize('ci', range(len(PP_CONFIGS)), ids=PP_CONFIGS)
-def test_ping_pong_gemm_every_tile_configuration(ops, ci):
-  """csrc/gemm_pp.hip through tfpp_conv_gemm with the configuration forced (tfpp_gemm_pp_config): ragged M / N, K tails (K % 64 != 0, zero
-  fill through out-of-range buffer offsets), 1 / 2 / 3 / many K tiles (every end-of-range path of the two-buffer ring), K slices with the
-  split-K second stage, the fused epilogue (alpha, scale, shift, residual, ReLU) -- against an fp32 product of the same bf16 operands."""
-  from carla_garage_amd import _lib
-  cfg = _lib.lib.raw('tfpp_gemm_pp_config')
-  dt = torch.bfloat16
-  try:
-    for (M, N, K) in [(256, 256, 64), (256, 192, 128), (300, 200, 72), (384, 256, 192), (512, 384, 1512), (777, 1000, 520), (3840, 1512, 1512)]:
-      x = (torch.rand(M, K, device=DEV) - 0.5).to(dt)
-      w = (torch.rand(N, K, 1, 1, device=DEV) - 0.5) * 0.2
-      wp = ops.pack_conv_weight(w, dt, G=1)
-      scale, shift = torch.rand(N, device=DEV) + 0.5, torch.rand(N, device=DEV) - 0.5
-      res = (torch.rand(M, N, device=DEV) - 0.5).to(dt)
-      ref0 = x.float() @ w.view(N, K).to(dt).float().t()
-      geo = dict(B=M, Hs=1, Ws=1, Cs=K, Hd=1, Wd=1, Cd=N)
-      for sp in (0, 2):
-        assert cfg(1 + ci + 100 * sp) == 0
-        var, _ = ops.conv_gemm(x, wp, torch.empty((M, N), device=DEV, dtype=dt), plan_only=True, **geo)
-        assert var == 210 + ci
-        y = torch.full((M, N), float('nan'), device=DEV, dtype=dt)
-        ops.conv_gemm(x, wp, y, **geo)
-        y2 = torch.full((M, N), float('nan'), device=DEV, dtype=dt)
-        ops.conv_gemm(x, wp, y2, scale=scale, shift=shift, res=res, act=ops.ACT_RELU, alpha=0.5, **geo)
-        torch.cuda.synchronize()
-        tol = 0.02 * max(1.0, float(ref0.abs().max()))
-        assert bool(torch.isfinite(y.float()).all()) and float((y.float() - ref0).abs().max()) <= tol, (M, N, K, sp)
-        ref2 = torch.relu(0.5 * ref0 * scale + shift + res.float())
-        assert bool(torch.isfinite(y2.float()).all()) and float((y2.float() - ref2).abs().max()) <= tol, (M, N, K, sp, 'epilogue')
-        report(f'pp_gemm.{PP_CONFIGS[ci]}.{M}x{N}x{K}.s{sp}', float((y.float() - ref0).abs().max()) / max(1.0, float(ref0.abs().max())), 'max abs err / max |ref|')
-  finally:
-    cfg(0)
-
-
-def test_ping_pong_gemm_replays_bit_identically(ops):
-  """race screen of the LDS ring (counted vmcnt / barrier hazards show up as rare differing tiles): 30 launches of the two plans the model uses."""
-  from carla_garage_amd import _lib
-  cfg = _lib.lib.raw('tfpp_gemm_pp_config')
-  dt = torch.bfloat16
-  try:
-    assert cfg(-2) == 0  # the automatic plan (the kernel is off by default: the training step is not faster with it, csrc/gemm_pp.hip)
-    for (M, N, K, variant) in [(3840, 6048, 1512, 212), (3840, 1512, 6048, 215)]:
-      x = (torch.rand(M, K, device=DEV) - 0.5).to(dt)
-      wp = ops.pack_conv_weight((torch.rand(N, K, 1, 1, device=DEV) - 0.5) * 0.2, dt, G=1)
-      geo = dict(B=M, Hs=1, Ws=1, Cs=K, Hd=1, Wd=1, Cd=N)
-      y0 = torch.empty((M, N), device=DEV, dtype=dt)
-      assert ops.conv_gemm(x, wp, y0, plan_only=True, **geo)[0] == variant
-      ops.conv_gemm(x, wp, y0, **geo)
-      for _ in range(30):
-        y = torch.empty((M, N), device=DEV, dtype=dt)
-        ops.conv_gemm(x, wp, y, **geo)
-        assert torch.equal(y, y0)
-  finally:
-    cfg(0)
 
 
 WGRAD_GLDS_VARIANTS = (2, 4)  # 2: 64x64 tiles, 4: 128x128 tiles (8 waves)
@@ -607,49 +547,6 @@ def test_squeeze_excite(ops, dtype):
   check('se.dx', nchw(dx.float().cpu()), ps[0].grad, dtype, scale=3.0)
   for nme, g, p in zip(('dw1', 'db1', 'dw2', 'db2'), grads, ps[1:]):
     check('se.' + nme, g.cpu(), p.grad, dtype, scale=3.0)
-
-
-@pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(3, 10, 14, 72, 18), (12, 16, 64, 576, 144), (1, 8, 32, 1512, 378), (2, 64, 64, 72, 8)])
-def test_squeeze_excite_fused_one_launch_per_pass(ops, dtype, shape):
-  """tfpp_se_squeeze_gate / tfpp_se_bwd_squeeze / tfpp_se_param_grads (round 5) against torch AND against the unfused launch chain on the
-  RegNet shapes (bs = 12 stage 3, bs = 1 stage 4 of the inference tick, the 8-unit gate of stage 1); twice in a row: the tickets return to zero."""
-  B, H, W, C, RD = shape
-  x = rnd(B, C, H, W, dtype=dtype, seed=61)
-  w1, b1, w2, b2 = rnd(RD, C, seed=62) * (3.0 / C**0.5), rnd(RD, seed=63), rnd(C, RD, seed=64) * (3.0 / RD**0.5), rnd(C, seed=65)
-  ps = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
-  s = ps[0].mean((2, 3))
-  hid_ref = F.relu(F.linear(s, ps[1], ps[2]))
-  gate_ref = torch.sigmoid(F.linear(hid_ref, ps[3], ps[4]))
-  want = ps[0] * gate_ref.view(B, C, 1, 1)
-  dy = rnd(B, C, H, W, dtype=dtype, seed=66)
-  want.backward(dy)
-  xd, dyd = dev(nhwc(x), dtype), dev(nhwc(dy), dtype)
-  wd = [dev(t) for t in (w1, b1, w2, b2)]
-  assert ops.se_fused_supported(B, RD) and ops.se_fused_supported(B, RD, C) == (C * RD <= ops.SE_FUSED_MAX_MACS)
-  for rep in range(2):
-    pool, hidden, gate = ops.se_squeeze_gate(xd, *wd)
-    check(f'se_fused.pool.{rep}', pool.cpu(), s, dtype)
-    check(f'se_fused.hidden.{rep}', hidden.cpu(), hid_ref, dtype)
-    check(f'se_fused.gate.{rep}', gate.cpu(), gate_ref, dtype)
-    dgate, dz1, dpool = ops.se_bwd_squeeze(dyd, xd, gate, hidden, wd[0], wd[2])
-    grads = [torch.zeros_like(t) for t in wd]
-    ops.se_param_grads(dgate, gate, hidden, pool, dz1, *grads)
-    dx = ops.se_bwd_apply(dyd, gate, dpool)
-    check(f'se_fused.dx.{rep}', nchw(dx.float().cpu()), ps[0].grad, dtype, scale=3.0)
-    for nme, g, p in zip(('dw1', 'db1', 'dw2', 'db2'), grads, ps[1:]):
-      check(f'se_fused.{nme}.{rep}', g.cpu(), p.grad, dtype, scale=3.0)
-  # the unfused chain on the same device tensors: same values up to the order of the fp32 dot products
-  pool_u = ops.mean_hw(xd)
-  hidden_u, gate_u = ops.se_gate_fwd(pool_u, *wd)
-  check('se_fused.gate_vs_unfused', gate.cpu(), gate_u.cpu(), torch.float32, scale=0.5)
-  dgate_u = ops.se_dgate(dyd, xd)
-  grads_u = [torch.zeros_like(t) for t in wd]
-  dpool_u = ops.se_gate_bwd(dgate_u, gate_u, hidden_u, pool_u, wd[0], wd[2], *grads_u)
-  check('se_fused.dgate_vs_unfused', dgate.cpu(), dgate_u.cpu(), torch.float32, scale=0.5)
-  check('se_fused.dpool_vs_unfused', dpool.cpu(), dpool_u.cpu(), torch.float32, scale=5.0)
-  torch.cuda.synchronize()
-  assert int(ops.gridsum_scratch(xd.device)[:64].view(torch.int32).abs().sum()) == 0, 'ticket counters must return to zero'
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

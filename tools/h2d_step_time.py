@@ -59,6 +59,34 @@ def main(bs=12, steps=30, nhost=4):
   aug = ImageAugmenter(prob=0.5, seed=1)
   timed(DeviceBatchPrefetcher(many[:3], cfg, augment=aug))
   res['prefetcher_with_augmentation_ms'] = timed(DeviceBatchPrefetcher(many, cfg, augment=aug))
+  # ... and with the loader's LiDAR path on the device (round 5): the host batches carry the raw float64 sweeps (60 k points per
+  # sample) + align parameters instead of the BEV image; CARLA_Data.align + lidar_to_histogram_features run on the copy stream.  Beside it: what
+  # that work costs the loader's workers per batch in numpy (the oracle's restatement of data.py:840-906, one core)
+  import numpy as np
+  from oracle import lidar_port as LP
+  from carla_garage_amd.data import collate_lidar
+  from carla_garage_amd.lidar import align_params
+  meas = LP.make_measurements(1, 1)
+  sweeps = [LP.make_sweep_f64(60000, 500 + j) for j in range(bs)]
+  par = [align_params(meas[0], meas[0], 0.3, 5.0) for _ in range(bs)]
+  lid_host = []
+  for hb in host:
+    samples = [{'lidar_sweeps': [sweeps[j]], 'lidar_align': par[j][None]} for j in range(bs)]
+    b2 = collate_lidar(samples, cfg)
+    b2.update({k: v for k, v in hb.items() if k not in ('lidar', 'temporal_lidar')})
+    lid_host.append(b2)
+  many_l = [lid_host[i % nhost] for i in range(steps)]
+  timed(DeviceBatchPrefetcher(many_l[:3], cfg, lidar_on_device=True))
+  res['prefetcher_with_lidar_on_device_ms'] = timed(DeviceBatchPrefetcher(many_l, cfg, lidar_on_device=True))
+  res['lidar_raw_bytes_per_batch'] = int(sum(s_.nbytes for s_ in sweeps))
+  t0 = time.perf_counter()
+  for j in range(bs):
+    LP.lidar_to_histogram_features(LP.align(sweeps[j], meas[0], meas[0], 0.3, 5.0), False)
+  res['host_numpy_align_histogram_ms_per_batch_one_core'] = (time.perf_counter() - t0) * 1e3
+  t0 = time.perf_counter()
+  for _ in range(5):
+    collate_lidar([{'lidar_sweeps': [sweeps[j]], 'lidar_align': par[j][None]} for j in range(bs)], cfg)
+  res['host_collate_raw_sweeps_ms_per_batch'] = (time.perf_counter() - t0) / 5 * 1e3
   # diagnostics: the upload path alone (no step), and the step fed by the prefetcher but replaying on its resident copy
   torch.cuda.synchronize()
   t0 = time.perf_counter()

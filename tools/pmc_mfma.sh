@@ -13,6 +13,9 @@ timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACT
   python $REPO/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-inference --no-roofline --no-dropin > $REPO/gpurun_out/pmc_mfma_A.log 2>&1 || echo "pass A failed"
 timeout 400 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d /tmp/pmcB -- \
   python $REPO/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-inference --no-roofline --no-dropin > $REPO/gpurun_out/pmc_mfma_B.log 2>&1 || echo "pass B failed"
+rm -rf /tmp/pmcC
+timeout 400 rocprofv3 --pmc MfmaUtil --kernel-include-regex "conv_gemm|conv_wgrad|conv3x3_halo|wgrad3x3|attn_|bgemm" --output-format csv -d /tmp/pmcC -- \
+  python $REPO/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-inference --no-roofline --no-dropin > $REPO/gpurun_out/pmc_mfma_C.log 2>&1 || echo "pass C failed"
 python - "$REPO" <<'PY'
 import csv, glob, json, sys, collections, re
 repo = sys.argv[1]
@@ -27,13 +30,17 @@ def load(d):
             if key not in seen:
                 seen.add(key); n[k] += 1
     return out, n
-A, nA = load('/tmp/pmcA'); B, nB = load('/tmp/pmcB')
+A, nA = load('/tmp/pmcA'); B, nB = load('/tmp/pmcB'); Cc, nC = load('/tmp/pmcC')
 rows = {}
 for k in A:
     a = A[k]; busy = a.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0); gui = a.get('GRBM_GUI_ACTIVE', 0.0); sq = a.get('SQ_BUSY_CYCLES', 0.0)
     if busy <= 0: continue
     b = B.get(k, {})
+    util = Cc.get(k, {}).get('MfmaUtil')
     rows[k] = {'dispatches': nA[k], 'mfma_busy_cycles': busy, 'grbm_gui_active': gui, 'sq_busy_cycles': sq,
+               # rocprofv3's derived metric (reduce(SQ_VALU_MFMA_BUSY_CYCLES,sum) / (reduce(GRBM_GUI_ACTIVE,max) * SIMD_NUM) * 100), mean over the dispatches
+               'MfmaUtil_pct': round(util / nC[k], 2) if util is not None and nC.get(k) else None,
+               # the same ratio from the raw counters of pass A, where the CSV sums GRBM_GUI_ACTIVE over the 8 XCDs (hence x 8 against MfmaUtil)
                'mfma_util_pct_of_all_simds': round(100.0 * busy / (gui * SIMDS), 2) if gui else None,
                'mfma_flops_bf16': b.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0.0) * 512, 'mfma_flops_f32': b.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0.0) * 512}
 tot_busy = sum(r['mfma_busy_cycles'] for r in rows.values()); tot_gui = sum(r['grbm_gui_active'] for r in rows.values())
@@ -44,9 +51,9 @@ res = {'what': 'rocprofv3 --pmc, two eager training steps bs=12 bf16 (counters s
        'kernels': dict(sorted(rows.items(), key=lambda kv: -kv[1]['mfma_busy_cycles']))}
 json.dump(res, open(repo + '/gpurun_out/pmc_mfma.json', 'w'), indent=1)
 with open(repo + '/gpurun_out/pmc_mfma.txt', 'w') as f:
-    f.write('# kernel | dispatches | MfmaUtil %% (MFMA busy / (GUI active x 1024 SIMDs)) | bf16 MFMA GFLOP | fp32 MFMA GFLOP\n')
+    f.write('# kernel | dispatches | MfmaUtil %% (rocprofv3 derived metric, mean over dispatches) | raw busy/(gui_sum x 1024) %% | bf16 MFMA GFLOP | fp32 MFMA GFLOP\n')
     for k, r in res['kernels'].items():
-        f.write('%-92s %5d %7s %10.2f %10.2f\n' % (k, r['dispatches'], r['mfma_util_pct_of_all_simds'], r['mfma_flops_bf16'] / 1e9, r['mfma_flops_f32'] / 1e9))
+        f.write('%-92s %5d %7s %7s %10.2f %10.2f\n' % (k, r['dispatches'], r['MfmaUtil_pct'], r['mfma_util_pct_of_all_simds'], r['mfma_flops_bf16'] / 1e9, r['mfma_flops_f32'] / 1e9))
     f.write('# all kernels with MFMA work: MfmaUtil %s %%\n' % res['all_mfma_kernels']['mfma_util_pct'])
 print(open(repo + '/gpurun_out/pmc_mfma.txt').read()[:3000])
 PY

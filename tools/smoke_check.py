@@ -1,4 +1,7 @@
-"""One small invocation of the hot path on cuda:0 checked against the CPU oracle (used by __graft_entry__.smoke())."""
+"""One small invocation of the hot path on cuda:0 checked against the CPU oracle (used by __graft_entry__.smoke()).
+
+Lives in tools/, not in the product package: it imports the oracle (the checker), and carla_garage_amd/ is oracle-free by construction
+(tests/test_host_helpers.py::test_the_product_never_imports_the_oracle has no exception list)."""
 import torch
 
 
@@ -35,4 +38,13 @@ def run(verbose=True):
   assert np.array_equal(hist, L.lidar_to_histogram_features(cloud, True)), 'LiDAR histogram differs from the CPU oracle'
   if verbose:
     print('smoke lidar_histogram      bit-exact')
+  # the loader's LiDAR path (section 8(f) item 4): align + histogram of two raw float64 sweeps in one call
+  from carla_garage_amd.lidar import LidarBatchHistogram, align_params
+  meas = L.make_measurements(3, 2)
+  sweeps = [L.make_sweep_f64(5000, 31 + t) for t in range(2)]
+  bev = LidarBatchHistogram(cfg, dev)(sweeps, [align_params(meas[t], meas[1], 0.4, -6.0) for t in range(2)], False).cpu().numpy()
+  for t in range(2):
+    assert np.array_equal(bev[t], L.lidar_to_histogram_features(L.align(sweeps[t], meas[t], meas[1], 0.4, -6.0), False)), 'aligned LiDAR histogram differs from the CPU oracle'
+  if verbose:
+    print('smoke lidar_align+histogram bit-exact')
   return worst
