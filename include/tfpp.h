@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TFPP_ABI_VERSION 3
+#define TFPP_ABI_VERSION 4
 #define TFPP_EINVAL (-1000)
 #define TFPP_F32 0
 #define TFPP_BF16 1

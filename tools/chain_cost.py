@@ -23,7 +23,7 @@ GROUPS = {
     'residual_dropout+layernorm': ['tfpp_add_dropout', 'tfpp_layernorm_fwd', 'tfpp_layernorm_bwd'],
     'colsum': ['tfpp_colsum'],
     'act_bwd': ['tfpp_act_bwd'],
-    'wgrad': ['tfpp_conv_wgrad', 'tfpp_conv_wgrad_stage'],
+    'wgrad': ['tfpp_conv_wgrad', 'tfpp_conv_wgrad_stage', 'tfpp_conv_wgrad_batch'],
     'attention': ['tfpp_attn_fwd', 'tfpp_attn_bwd'],
     'bilinear': ['tfpp_bilinear_fwd', 'tfpp_bilinear_bwd'],
     'optimizer+repack': ['tfpp_adamw_amsgrad', 'tfpp_pack_multi'],

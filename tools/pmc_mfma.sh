@@ -44,9 +44,11 @@ for k in A:
                'mfma_util_pct_of_all_simds': round(100.0 * busy / (gui * SIMDS), 2) if gui else None,
                'mfma_flops_bf16': b.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0.0) * 512, 'mfma_flops_f32': b.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0.0) * 512}
 tot_busy = sum(r['mfma_busy_cycles'] for r in rows.values()); tot_gui = sum(r['grbm_gui_active'] for r in rows.values())
+wnum = sum(r['MfmaUtil_pct'] * r['grbm_gui_active'] for r in rows.values() if r['MfmaUtil_pct'] is not None)
+wden = sum(r['grbm_gui_active'] for r in rows.values() if r['MfmaUtil_pct'] is not None)
 res = {'what': 'rocprofv3 --pmc, two eager training steps bs=12 bf16 (counters serialise the kernels: per-kernel values are for a kernel ALONE on the chip)',
        'formula': 'MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs) (rocprofv3 derived metric MfmaUtil); flops = SQ_INSTS_VALU_MFMA_MOPS_* x 512',
-       'all_mfma_kernels': {'mfma_util_pct': round(100.0 * tot_busy / (tot_gui * SIMDS), 2) if tot_gui else None,
+       'all_mfma_kernels': {'MfmaUtil_pct_time_weighted': round(wnum / wden, 2) if wden else None,
                             'mfma_flops_bf16': sum(r['mfma_flops_bf16'] for r in rows.values()), 'mfma_flops_f32': sum(r['mfma_flops_f32'] for r in rows.values())},
        'kernels': dict(sorted(rows.items(), key=lambda kv: -kv[1]['mfma_busy_cycles']))}
 json.dump(res, open(repo + '/gpurun_out/pmc_mfma.json', 'w'), indent=1)
@@ -54,6 +56,6 @@ with open(repo + '/gpurun_out/pmc_mfma.txt', 'w') as f:
     f.write('# kernel | dispatches | MfmaUtil %% (rocprofv3 derived metric, mean over dispatches) | raw busy/(gui_sum x 1024) %% | bf16 MFMA GFLOP | fp32 MFMA GFLOP\n')
     for k, r in res['kernels'].items():
         f.write('%-92s %5d %7s %7s %10.2f %10.2f\n' % (k, r['dispatches'], r['MfmaUtil_pct'], r['mfma_util_pct_of_all_simds'], r['mfma_flops_bf16'] / 1e9, r['mfma_flops_f32'] / 1e9))
-    f.write('# all kernels with MFMA work: MfmaUtil %s %%\n' % res['all_mfma_kernels']['mfma_util_pct'])
+    f.write('# all kernels with MFMA work, weighted by GPU-active cycles: MfmaUtil %s %%\n' % res['all_mfma_kernels']['MfmaUtil_pct_time_weighted'])
 print(open(repo + '/gpurun_out/pmc_mfma.txt').read()[:3000])
 PY
