@@ -819,8 +819,8 @@ def main():
       dropin['note'] = ('module driven as team_code/train.py:776-910 drives the reference (DistributedDataParallel when ranks > 1, compute_loss, '
                         '.item() per loss, loss.backward(), optimizer.step(), zero_grad(set_to_none=True)); fused_optimizer = carla_garage_amd.optim.FlatAdamW '
                         'in place of optim.AdamW (INTEGRATION.md), torch_adamw = the unmodified optimizer.  Covered by GPU tests on this boundary: ZeroRedundancyOptimizer, '
-                        'freeze_backbone, validate(), grad clip, learnable loss weights, GradScaler (tests/test_boundary_gpu.py).  NOT supported: SyncBatchNorm '
-                        'conversion (config.sync_batch_norm = 1; the reference default is 0) raises ValueError -- BatchNorm statistics are per rank')
+                        'freeze_backbone, validate(), grad clip, learnable loss weights, GradScaler (tests/test_boundary_gpu.py); SyncBatchNorm conversion (config.sync_batch_norm = 1; '
+                        'the reference default is 0) runs eagerly with the statistics all-reduced over the ranks (tests/test_dist_gpu.py, two ranks on one GPU)')
     except Exception as e:  # pylint: disable=broad-except
       log(f'drop-in leg failed: {type(e).__name__}: {e}')
       dropin = {'error': f'{type(e).__name__}: {e}'}

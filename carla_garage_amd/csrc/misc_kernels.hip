@@ -659,6 +659,18 @@ extern "C" int tfpp_signal_add(uint64_t* sig, void* stream) {
   TFPP_CHECK_LAUNCH();
   return 0;
 }
+// double -> float of a small vector (SyncBatchNorm: the per-channel sums travel between the ranks in double, tfpp_bn_bwd_apply_rows takes float rows)
+__global__ void f64_to_f32_kernel(const double* __restrict__ x, float* __restrict__ y, long n, double scale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (float)(x[i] * scale);
+}
+extern "C" int tfpp_f64_to_f32(const double* x, float* y, int64_t n, double scale, void* stream) {
+  if ((n > 0 && (!x || !y)) || n < 0) return TFPP_EINVAL;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, scale);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
 // Self-describing form (round 5): the signal does not COUNT passes, it carries the serial number of the pass that raised it.
 // tfpp_set_u64 writes the host's serial of the pass about to be issued into a device word on the compute stream (outside any captured
 // graph: stream-ordered in front of the replay); the in-graph node tfpp_signal_set raises sig to max(sig, *serial_word); the wait looks

@@ -197,7 +197,7 @@ class DropinStep:
         dst.copy_(src, non_blocking=True)
       plan.F.replay()
       cur['mode'], cur['fwd'] = 'graph', plan.fwd
-    elif GRAPH_AFTER >= 0 and plan.count > GRAPH_AFTER and not plan.broken and plan.count - 1 > 0 and tr.layout_final and tr.eager_steps_in_layout >= 1:
+    elif GRAPH_AFTER >= 0 and not self.eng.sync_bn and plan.count > GRAPH_AFTER and not plan.broken and plan.count - 1 > 0 and tr.layout_final and tr.eager_steps_in_layout >= 1:
       plan.static_in = [x.detach().clone() for x in inputs]
       torch.cuda.synchronize()
       plan.F = torch.cuda.CUDAGraph()

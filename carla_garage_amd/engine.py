@@ -624,6 +624,12 @@ class Engine:
     self.buckets = GradBuckets()
     self._glog, self._bucket_of, self._want_flushes, self.observed_buckets, self.observation_stable, self._prev_total = {}, None, None, None, False, 0
     self.bucket_program = ((), ())
+    # SyncBatchNorm (train.py:511-512: nn.SyncBatchNorm.convert_sync_batchnorm(model) when config.sync_batch_norm = 1): BatchNorm statistics
+    # over the batches of all ranks -- collectives inside the pass, so such a step is never captured into a hipGraph
+    sbn = [mod for mod in model.modules() if isinstance(mod, torch.nn.SyncBatchNorm)]
+    self.sync_bn = bool(sbn)
+    self.sync_group = sbn[0].process_group if sbn else None
+    self.sync_world = 1
     self._build_specs()
 
   # ------------------------------------------------------------------------------------------------ set-up
@@ -1008,9 +1014,13 @@ class Engine:
     else:
       raw = torch.empty((B, Ho, Wo, s.n_store), device=x.device, dtype=odt)
       nrows, acc = ops.conv_gemm(x, s.wp, raw, stats_acc=True, **geo)  # BN statistics fused into the epilogue
-      ops.bn_finalize_partials(acc, nrows, s.bn.weight.detach(), s.bn.bias.detach(), s.bn.running_mean, s.bn.running_var,
-                               s.bn.num_batches_tracked, s.scale, s.shift, s.save_mean, s.save_invstd, B * Ho * Wo,
-                               s.bn.momentum, s.bn.eps)
+      if self.sync_bn and self.sync_world > 1:  # train.py:511-512: statistics over the batches of all ranks (one all-reduce of 2C doubles per layer)
+        ops.bn_sync_finalize(acc, nrows, s.bn.weight.detach(), s.bn.bias.detach(), s.bn.running_mean, s.bn.running_var, s.bn.num_batches_tracked,
+                             s.scale, s.shift, s.save_mean, s.save_invstd, B * Ho * Wo, self.sync_world, self.sync_group, s.ws, s.bn.momentum, s.bn.eps)
+      else:
+        ops.bn_finalize_partials(acc, nrows, s.bn.weight.detach(), s.bn.bias.detach(), s.bn.running_mean, s.bn.running_var,
+                                 s.bn.num_batches_tracked, s.scale, s.shift, s.save_mean, s.save_invstd, B * Ho * Wo,
+                                 s.bn.momentum, s.bn.eps)
       y = ops.affine_act(raw, scale=s.scale, shift=s.shift, res=res, act=act)
       if self.tape is not None and act in (ACT_NONE, ACT_RELU):
         self._bn_of[_key(y)] = (s, raw, act == ACT_RELU)  # lets the producer of d(y) fuse this layer's BatchNorm-backward sums
@@ -1038,7 +1048,10 @@ class Engine:
           dconv = dz
         elif bn_train:
           pre = self._bn_pre.pop(_key(y), None)
-          if pre is not None and pre[2] is dy:  # the kernel that wrote dy already reduced sum g / sum g*xhat per tile (one pass saved)
+          if self.sync_bn and self.sync_world > 1:
+            dconv, dres = ops.bn_bwd_sync(dy, y, raw, s.bn.weight.detach(), s.save_mean, s.save_invstd, self.g(s.bn.weight), self.g(s.bn.bias),
+                                          relu_mask=(act == ACT_RELU), world=self.sync_world, group=self.sync_group, want_dres=res is not None)
+          elif pre is not None and pre[2] is dy:  # the kernel that wrote dy already reduced sum g / sum g*xhat per tile (one pass saved)
             dconv, dres = ops.bn_bwd_rows(dy, y, raw, s.bn.weight.detach(), s.save_mean, s.save_invstd, pre[0], pre[1], self.g(s.bn.weight),
                                           self.g(s.bn.bias), relu_mask=(act == ACT_RELU), want_dres=res is not None)
           else:
@@ -1241,7 +1254,7 @@ class Engine:
         dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
                                 self.g(se.fc2.weight), self.g(se.fc2.bias))
         info = self._bn_of.get(_key(x)) if x.dtype == torch.bfloat16 else None
-        if info is not None and info[2] and Tape.current.is_last_contribution(x):
+        if info is not None and info[2] and Tape.current.is_last_contribution(x) and not (self.sync_bn and self.sync_world > 1):
           # x = relu(BN(raw)) of conv2: this IS its complete gradient -> emit the BatchNorm-backward sums in the same pass
           sL, rawL, _ = info
           dx, partial, nrows = ops.se_bwd_apply_bns(dy, gate, dpool, x, rawL, sL.save_mean, sL.save_invstd)
@@ -1497,6 +1510,12 @@ class Engine:
     bb = m.backbone
     out = {}
     self._bn_of, self._bn_pre = {}, {}
+    if self.sync_bn:
+      import torch.distributed as dist
+      self.sync_world = dist.get_world_size(self.sync_group) if (dist.is_available() and dist.is_initialized()) else 1
+      if self.training and self.sync_world > 1 and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('carla_garage_amd: a SyncBatchNorm training step puts collectives inside the pass and cannot be captured into a hipGraph '
+                           '(use Trainer.train_step / the eager drop-in step: TFPP_DROPIN_GRAPH_AFTER=-1)')
     if ops.NODE_HASH['on'] and self.tape is not None:
       ops.node_hash_begin(dev)
     if self.tape is not None:
@@ -1599,9 +1618,21 @@ class Engine:
       hh, ww = x.shape[1], x.shape[2]
       pos = self._const(f'sine{hh}x{ww}', lambda: m.sine_table(hh, ww))
       x = self.add_table(x, pos.view(-1))
-      vel = ops.bn1d_scalar(ego_vel.float().contiguous(), m.velocity_normalization.running_mean, m.velocity_normalization.running_var,
-                            m.velocity_normalization.num_batches_tracked, self.training and m.velocity_normalization.training,
-                            m.velocity_normalization.momentum, m.velocity_normalization.eps)
+      vn = m.velocity_normalization
+      ev = ego_vel.float().contiguous()
+      if self.sync_bn and self.training and vn.training and self.sync_world > 1:
+        # the BatchNorm1d on the ego speed is converted too: normalise with the statistics of every rank's speeds (gather, normalise the
+        # gathered vector -- identical on every rank, as are the running statistics it updates -- keep the own slice)
+        import torch.distributed as dist
+        parts = [torch.empty_like(ev) for _ in range(self.sync_world)]
+        dist.all_gather(parts, ev, group=self.sync_group)
+        allv = torch.empty((self.sync_world * B, 1), device=dev, dtype=F32)
+        for k, pt in enumerate(parts):
+          ops.copy_rows(pt, allv, 1, B, 0, 0, 0, k * B)
+        r = dist.get_rank(self.sync_group)
+        vel = ops.bn1d_scalar(allv, vn.running_mean, vn.running_var, vn.num_batches_tracked, True, vn.momentum, vn.eps)[r * B:(r + 1) * B].contiguous()
+      else:
+        vel = ops.bn1d_scalar(ev, vn.running_mean, vn.running_var, vn.num_batches_tracked, self.training and vn.training, vn.momentum, vn.eps)
       es_in = ops.zeros((B, 8), F32, dev)
       ops.copy_rows(vel, es_in, B, 1, 1, 0, 8, 0)
       ops.copy_rows(command.float().contiguous(), es_in, B, 6, 6, 0, 8, 1)

@@ -91,6 +91,9 @@ class GraphedTrainStep:
     At least one runs, more until the arenas are in their observed completion order (Trainer.apply_observed_layout: the second pass is the
     first one with the lane's final fork points) and one step has run in that layout."""
     self.trainer = trainer
+    if trainer.eng.sync_bn and trainer.world > 1:
+      raise RuntimeError('GraphedTrainStep: a SyncBatchNorm step (train.py:511-512) all-reduces BatchNorm statistics inside the pass and cannot be captured; '
+                         'use Trainer.train_step')
     self.static_batch = {k: v.clone() for k, v in batch.items()}
     steps = 0
     ready = lambda: trainer.step_count > 0 and trainer.layout_final and trainer.eager_steps_in_layout >= 1

@@ -138,11 +138,8 @@ class LidarCenterNet(nn.Module):
 
   def _engine(self):
     if self.__dict__['engine'] is None:
-      if any(isinstance(mod, nn.SyncBatchNorm) for mod in self.modules()):
-        # train.py:511-512 (config.sync_batch_norm = 1, off by default): the HIP BatchNorm computes its statistics over THIS rank's batch;
-        # running on silently with per-rank statistics would be another model than the one the caller asked for
-        raise ValueError('carla_garage_amd: SyncBatchNorm is not implemented on the MI355X path (BatchNorm statistics are per rank); '
-                         'keep config.sync_batch_norm = 0 (the reference default)')
+      # train.py:511-512 (config.sync_batch_norm = 1, off by default): a module converted by nn.SyncBatchNorm.convert_sync_batchnorm computes its
+      # BatchNorm statistics over the batches of all ranks (Engine.sync_bn: one all-reduce of 2C doubles per layer and pass, eager steps only)
       self.__dict__['engine'] = Engine(self)
       self.__dict__['_param_list'] = list(self.parameters())
     return self.__dict__['engine']

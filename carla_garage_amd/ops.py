@@ -547,6 +547,48 @@ def bn_bwd_rows(dy, y, x, gamma, save_mean, save_invstd, partial, nrows, dgamma,
   return dx, dres
 
 
+# ---- SyncBatchNorm (team_code/train.py:511-512, config.sync_batch_norm = 1): statistics over the batches of ALL ranks.  The per-channel sums
+# (2C doubles per layer and pass) are all-reduced between the kernels; everything else is the per-rank path.  Collectives inside the pass:
+# such a step runs eagerly (graph.py / dropin.py refuse to capture it).
+def bn_sync_finalize(acc, nrows, gamma, beta, rm, rv, nbt, scale, shift, save_mean, save_invstd, rows, world, group, ws, momentum=0.1, eps=1e-5):
+  """bn_finalize_partials with the sums of every rank: rows = this rank's B*H*W (equal on all ranks, as DistributedSampler makes them)."""
+  import torch.distributed as dist
+  c = scale.numel()
+  lib.tfpp_bn_reduce_final(ptr(acc), ptr(ws), nrows, 2 * c, stream())
+  lib.tfpp_zero(ptr(acc), nrows * 2 * c * 4, stream())  # (the rows start every layer from zero: bn_finalize_partials(clear=True) does this in the per-rank path)
+  dist.all_reduce(ws, op=dist.ReduceOp.SUM, group=group)
+  lib.tfpp_bn_finalize(ptr(ws), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nbt), ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd), rows * world, c,
+                       momentum, eps, stream())
+
+
+def bn_bwd_sync(dy, y, x, gamma, save_mean, save_invstd, dgamma, dbeta, relu_mask, world, group, want_dres=False):
+  """bn_bwd with sum g / sum g*xhat over ALL ranks in dx (torch SyncBatchNorm's backward) and this rank's own sums in dgamma / dbeta
+  (DistributedDataParallel averages the parameter gradients afterwards, as for every other parameter)."""
+  import torch.distributed as dist
+  c = x.shape[-1]
+  rows = x.numel() // c
+  scratch = bn_scratch(c, x.device)
+  ws = torch.empty(2 * c, device=x.device, dtype=torch.float64)
+  lib.tfpp_bn_bwd_reduce(ptr(_chk(dy)), ptr(y), ptr(_chk(x)), ptr(save_mean), ptr(save_invstd), ptr(scratch), ptr(ws), rows, c, int(relu_mask), dt(x), stream())
+  local = torch.empty(2 * c, device=x.device, dtype=torch.float32)
+  lib.tfpp_f64_to_f32(ptr(ws), ptr(local), 2 * c, 1.0, stream())
+  dist.all_reduce(ws, op=dist.ReduceOp.SUM, group=group)
+  glob = torch.empty(2 * c, device=x.device, dtype=torch.float32)
+  # the coefficients of dx depend on sum / count only: the sums over all ranks divided by `world`, with this rank's row count (which the
+  # kernel also uses as the extent of the tensor it walks)
+  lib.tfpp_f64_to_f32(ptr(ws), ptr(glob), 2 * c, 1.0 / world, stream())
+  coef = torch.empty(3 * c, device=x.device, dtype=torch.float32)
+  dx = torch.empty_like(x)
+  dres = torch.empty_like(x) if want_dres else None
+  lib.tfpp_bn_bwd_apply_rows(ptr(dy), ptr(y), ptr(x), ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(glob), 1, ptr(coef), ptr(dx), ptr(dres), None, None,
+                             rows, c, int(relu_mask), dt(x), stream())
+  if dbeta is not None:
+    copy_rows(local, dbeta, 1, c, 0, 0, 0, 0, accumulate=True)
+  if dgamma is not None:
+    copy_rows(local[c:], dgamma, 1, c, 0, 0, 0, 0, accumulate=True)
+  return dx, dres
+
+
 def instance_norm_fwd(x, act=ACT_NONE, eps=1e-5):
   """nn.InstanceNorm2d (affine=False, no running statistics) on NHWC x, optionally fused with ReLU: BatchNorm arithmetic on each sample's
   rows (team_code/bev_encoder.py:120,262-267).  Returns (y, saved mean [B,C], saved invstd [B,C])."""

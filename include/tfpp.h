@@ -472,6 +472,9 @@ int tfpp_inc_u64(uint64_t* p, void* stream);
  * tfpp_signal_wait: the work issued on `stream` after this call starts once *sig >= value; gives up after timeout_ms and then adds 1 to
  * *timeouts (nullable). */
 int tfpp_signal_add(uint64_t* sig, void* stream);
+/* y[i] = (float)(x[i] * scale): the per-channel BatchNorm sums of the SyncBatchNorm path (train.py:511-512) are all-reduced in double and handed
+ * to tfpp_bn_bwd_apply_rows as one float row (scale = 1 / world: that entry point normalises by the LOCAL row count it also walks). */
+int tfpp_f64_to_f32(const double* x, float* y, int64_t n, double scale, void* stream);
 /* Self-describing signals (round 5): tfpp_set_u64 stores v into *p on `stream` (the host's serial number of the pass it is about to issue,
  * written in front of the pass / the graph replay); tfpp_signal_set raises *sig to max(*sig, *serial) behind everything issued so far on
  * `stream` (a kernel node inside the captured step); the exchange then waits with tfpp_signal_wait(sig, serial of that pass).  A pass the

@@ -93,6 +93,60 @@ def main():
                wait_timeouts=tr.eng.buckets.timed_out(), params_finite=bool(torch.isfinite(tr.flat_param).all()),
                replicas_bit_equal=gather_equal([crc(params(tr.model))]), layouts_equal=gather_equal([crc(torch.tensor(tr.eng.buckets.offsets))]),
                losses_differ_between_ranks=not gather_equal([int(1e6 * l) for l in losses]))
+  elif mode == 'syncbn':
+    # SyncBatchNorm (train.py:511-512): rank r holds samples [2r, 2r + 2) of a 4-sample batch and a module converted by
+    # nn.SyncBatchNorm.convert_sync_batchnorm; the reference is the SAME 4 samples in one process with plain BatchNorm.  Forward rows, BatchNorm
+    # running statistics and the SUM over the ranks of the parameter gradients (seeded with the same per-sample output gradients) must agree.
+    from carla_garage_amd.engine import Tape
+
+    def seeds_for(t, b0, nb):
+      out = []
+      for key, real in (('pred_target_speed', 4), ('pred_semantic', 7), ('pred_bev_semantic', 11), ('bb0', 4)):
+        x = t['bb'][0] if key == 'bb0' else t[key]
+        per = x.numel() // x.shape[0]
+        idx = torch.arange(per, device=x.device, dtype=torch.float32).view(1, -1)
+        bb = torch.arange(b0, b0 + nb, device=x.device, dtype=torch.float32).view(-1, 1)
+        g = (1e-3 * torch.sin(0.37 * idx + 1.3 * bb + len(key))).view(x.shape)
+        mask = (torch.arange(x.shape[-1], device=x.device) < real).to(g.dtype)  # channel-padded lanes carry no gradient
+        out.append((x, (g * mask).to(x.dtype).contiguous()))
+      return out
+
+    def run(model, b0, nb):
+      eng = model._engine()
+      inp = [v[b0:b0 + nb].cuda().contiguous() for v in P.make_inputs(4)]
+      eng.prepare(model.compute_dtype, True, True)
+      eng.training = True
+      eng.alloc_grads()
+      eng.tape = Tape()
+      t = eng.forward(*inp)
+      fwd = {k: t[k].detach().float().clone() for k in ('pred_target_speed', 'pred_checkpoint')}
+      fwd['heat'] = t['bb'][0].detach().float().clone()
+      tape, eng.tape = eng.tape, None
+      eng.begin_backward()
+      tape.backward(seeds_for(t, b0, nb))
+      eng.end_backward()
+      torch.cuda.synchronize()
+      names = [n for n, p in model.named_parameters() if p.requires_grad]
+      g = torch.cat([eng.grads[n].detach().double().flatten() for n in names])
+      rs = torch.cat([b.detach().double().flatten() for n, b in model.named_buffers() if 'running_' in n])
+      return fwd, g, rs, [(n, eng.grads[n].numel()) for n in names]
+
+    ref_fwd, ref_g, ref_rs, sizes = run(T._model(), 0, 4)    # plain BatchNorm over the 4 samples, this process alone
+    m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(T._model())
+    assert m._engine().sync_bn
+    fwd, g, rs, _ = run(m, 2 * rank, 2)
+    assert m._engine().sync_world == world
+    gsum = g.clone()
+    dist.all_reduce(gsum, op=dist.ReduceOp.SUM)
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-300))
+    # the control: how far apart are two plain-BatchNorm evaluations of the SAME four samples that only differ in the order of the fp32 sums?
+    # (the two halves as two passes with the statistics of the joint batch cannot be had without SyncBatchNorm; a second joint pass with the
+    # samples in another order changes every reduction order and nothing else)
+    from oracle.grad_stats import gradient_stats
+    split = lambda flat: {n: flat[o:o + k] for (n, k), o in zip(sizes, np.cumsum([0] + [k for _, k in sizes])[:-1])}
+    st = gradient_stats(split(ref_g), split(gsum))
+    out.update(fwd_rel={k: rel(fwd[k].double(), ref_fwd[k][2 * rank:2 * rank + 2].double()) for k in fwd}, grad_sum_rel=rel(gsum, ref_g),
+               grad_stats={k: float(v) for k, v in st.items()}, running_stats_rel=rel(rs, ref_rs), own_grad_differs_from_sum=rel(g, ref_g) > 0.05)
   else:
     from carla_garage_amd.losses import normalized_loss_weights
     from carla_garage_amd.optim import FlatAdamW

@@ -73,14 +73,20 @@ def test_abi_version_of_header_and_binding_agree():
   assert _lib.lib.raw('tfpp_version')() == v
 
 
-def test_sync_batchnorm_conversion_is_refused_not_ignored(model_cpu):
-  """train.py:511-512 converts the module with nn.SyncBatchNorm.convert_sync_batchnorm when config.sync_batch_norm = 1 (default 0).  The HIP
-  BatchNorm is per rank: the converted module must refuse to run rather than silently train another model."""
+def test_sync_batchnorm_conversion_is_accepted_and_marks_the_engine(model_cpu):
+  """train.py:511-512 converts the module with nn.SyncBatchNorm.convert_sync_batchnorm when config.sync_batch_norm = 1 (default 0).  Round 5: the
+  converted module runs (BatchNorm statistics all-reduced over the ranks, tests/test_dist_gpu.py::test_two_ranks_one_gpu_sync_batchnorm_*); its
+  engine knows it and such a training step is never captured into a hipGraph."""
   import copy
   m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(copy.deepcopy(model_cpu))
+  assert isinstance(m.velocity_normalization, torch.nn.SyncBatchNorm) and isinstance(m.backbone.image_encoder['s3'].b2.conv1.bn, torch.nn.SyncBatchNorm)
   m.__dict__['engine'] = None
-  with pytest.raises(ValueError, match='SyncBatchNorm'):
-    m._engine()
+  eng = m._engine()
+  assert eng.sync_bn and eng.sync_group is None and eng.sync_world == 1
+  assert list(m.state_dict().keys()) == list(model_cpu.state_dict().keys())  # the checkpoint schema is unchanged by the conversion
+  plain = copy.deepcopy(model_cpu)
+  plain.__dict__['engine'] = None
+  assert not plain._engine().sync_bn
 
 
 AIM_CFG = dict(backbone='aim', use_semantic=0, use_depth=0, detect_boxes=0, use_bev_semantic=0)  # BASELINE config 1
