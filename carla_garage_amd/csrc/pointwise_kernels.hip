@@ -1,6 +1,7 @@
 // HBM-bound kernels: weight packing, layout changes, pooling / bilinear resampling, elementwise ops, squeeze-excite.
 // All activations are NHWC; every kernel moves 16-byte vectors per lane along the channel dimension.
 #include "common.cuh"
+#include <cstdlib>
 #include "../../include/tfpp.h"
 
 #define PW_THREADS 256
@@ -956,17 +957,21 @@ __global__ void se_hidden_kernel(const float* __restrict__ pool, const float* __
   }
 }
 
+// gate[b,c] = sigmoid(b2[c] + sum_j W2[c][j] hidden[b][j]): one WAVE per (b, c), lanes over j -- the rows of W2 are RD contiguous floats, read as
+// whole 256-byte segments.  (Rounds 1-4 ran one THREAD per channel: every lane walked its own row, RD strided loads of one cache line each --
+// 8 us for a 576 x 144 matrix-vector product at bs = 1.  A/B in one call, profiles/r05_ab_se_gate.txt: bs = 1 forward 3.95 -> 3.87 ms bf16,
+// 5.95 -> 5.86 ms fp32, training step unchanged.)
 __global__ void se_gate_kernel(const float* __restrict__ hidden, const float* __restrict__ w2, const float* __restrict__ b2,
                                float* __restrict__ gate, int C, int RD) {
-  extern __shared__ float sh[];  // hidden[b, :RD]
-  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int j = threadIdx.x; j < RD; j += blockDim.x) sh[j] = hidden[(size_t)b * RD + j];
-  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.y, c = (int)blockIdx.x * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6);
   if (c >= C) return;
-  float s = b2[c];
   const float* wr = w2 + (size_t)c * RD;
-  for (int j = 0; j < RD; ++j) s += wr[j] * sh[j];
-  gate[(size_t)b * C + c] = 1.f / (1.f + __expf(-s));
+  const float* h = hidden + (size_t)b * RD;
+  float s = 0.f;
+  for (int j = lane; j < RD; j += 64) s += wr[j] * h[j];
+  s = wave_sum(s);
+  if (lane == 0) gate[(size_t)b * C + c] = 1.f / (1.f + __expf(-(s + b2[c])));
 }
 
 extern "C" int tfpp_se_gate_fwd(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2, float* hidden,
@@ -974,7 +979,7 @@ extern "C" int tfpp_se_gate_fwd(const float* pool, const float* w1, const float*
   if (!pool || !w1 || !w2 || !hidden || !gate) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(se_hidden_kernel, dim3((B * RD + 3) / 4), dim3(256), 0, st, pool, w1, b1, hidden, B, C, RD);
-  hipLaunchKernelGGL(se_gate_kernel, dim3((C + 255) / 256, B), dim3(256), (size_t)RD * sizeof(float), st, hidden, w2, b2, gate, C, RD);
+  hipLaunchKernelGGL(se_gate_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, hidden, w2, b2, gate, C, RD);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
