@@ -912,6 +912,62 @@ __global__ void hw_reduce_kernel(const T* __restrict__ x, const T* __restrict__ 
 // tiny fully-connected layers -- and removed it again: alone on the chip it wins only for stage 1 (20 vs 29 us), stage 3 takes 66 us and stage 4
 // 231 us against 30 us for the four launches below (a chain of dependent load round trips on ONE CU, profiles/r05_se_micro.txt); in the step
 // even the stage-1-only variant cost +0.7 ms and the bs = 1 forward did not move (profiles/r05_ab_se_*.txt).)
+// hw_reduce + col_final in ONE launch (round 5): the (<= 16) row-block workgroups of a sample publish their partial sums and draw a ticket per
+// sample; the workgroup that draws the last one adds the partials in row-block order -- all of them fetched in one round trip
+// (grid_fetch_sum16) -- scales and writes out[b][c].  Fixed order: bit-reproducible.  Saves the second launch (5 us + the gap in front of it) of
+// every squeeze (forward) and every dgate reduction (backward) of the 42 squeeze-excite blocks.
+template <typename T, bool DOT>
+__global__ __launch_bounds__(256) void hw_reduce_ticket_kernel(const T* __restrict__ x, const T* __restrict__ y, float* __restrict__ partial,
+                                                               float* __restrict__ out, unsigned* __restrict__ tickets, int HW, int CV, int sw, int rp,
+                                                               float mul) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  int rr, cv;
+  const bool active = col_thread(sw, rp, CV, rr, cv);
+  const int b = blockIdx.z, C = CV * VEC;
+  float acc[VEC];
+  hw_accumulate<T, DOT>(x, y, b, HW, CV, rp, rr, cv, active, acc);
+  __shared__ float sm[VEC * 256];
+  col_block_reduce<VEC>(acc, sw, rp, rr, sm);
+  if (active && rr == 0) {
+    float* o = partial + ((size_t)b * gridDim.x + blockIdx.x) * C + cv * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) grid_publish(o + e, acc[e]);
+  }
+  if (!grid_last_ticket(tickets + b, gridDim.x * gridDim.y)) return;
+  for (int c = threadIdx.x; c < C; c += 256)
+    out[(size_t)b * C + c] = grid_fetch_sum16(partial + (size_t)b * gridDim.x * C + c, C, (int)gridDim.x) * mul;
+}
+
+template <typename T>
+static int launch_hw_reduce_ticket(const void* x, const void* y, float* out, float* scratch, float* tickets, int B, int HW, int C, float mulv, hipStream_t st) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  if (C % VEC || B < 1 || B > TFPP_GRIDSUM_TICKETS) return TFPP_EINVAL;
+  const ColLayout l = col_layout(C / VEC);
+  int nb = col_blocks_x(HW, l, y ? 4 : 8, 4096, B);
+  if (nb > 16) nb = 16;  // one batch of agent-scope loads per channel in the tail
+  dim3 grid((unsigned)nb, (unsigned)l.ny, (unsigned)B);
+  if (y) hipLaunchKernelGGL((hw_reduce_ticket_kernel<T, true>), grid, dim3(256), 0, st, (const T*)x, (const T*)y, scratch, out, reinterpret_cast<unsigned*>(tickets), HW, C / VEC, l.sw, l.rp, mulv);
+  else hipLaunchKernelGGL((hw_reduce_ticket_kernel<T, false>), grid, dim3(256), 0, st, (const T*)x, (const T*)y, scratch, out, reinterpret_cast<unsigned*>(tickets), HW, C / VEC, l.sw, l.rp, mulv);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// one-launch forms of tfpp_mean_hw / tfpp_se_dgate: ticket_scratch = a tfpp_gridsum_scratch_floats() buffer (zero before the first use, left at
+// zero, one per stream); B <= 64, else TFPP_EINVAL (callers use the two-launch forms)
+extern "C" int tfpp_mean_hw_ticket(const void* x, float* out, float* scratch, float* ticket_scratch, int B, int HW, int C, int dtype, void* stream) {
+  if (!x || !out || !scratch || !ticket_scratch) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == TFPP_F32 ? launch_hw_reduce_ticket<float>(x, nullptr, out, scratch, ticket_scratch, B, HW, C, 1.f / (float)HW, st)
+                           : launch_hw_reduce_ticket<bf16_t>(x, nullptr, out, scratch, ticket_scratch, B, HW, C, 1.f / (float)HW, st);
+}
+extern "C" int tfpp_se_dgate_ticket(const void* dy, const void* x, float* dgate, float* scratch, float* ticket_scratch, int B, int HW, int C, int dtype,
+                                    void* stream) {
+  if (!dy || !x || !dgate || !scratch || !ticket_scratch) return TFPP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == TFPP_F32 ? launch_hw_reduce_ticket<float>(dy, x, dgate, scratch, ticket_scratch, B, HW, C, 1.f, st)
+                           : launch_hw_reduce_ticket<bf16_t>(dy, x, dgate, scratch, ticket_scratch, B, HW, C, 1.f, st);
+}
+
 template <typename T>
 static int launch_hw_reduce(const void* x, const void* y, float* out, float* scratch, int B, int HW, int C, float mulv, hipStream_t st) {
   constexpr int VEC = ElemTraits<T>::VEC;

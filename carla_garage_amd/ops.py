@@ -623,9 +623,15 @@ def bn1d_scalar(x, rm, rv, nbt, training, momentum=0.1, eps=1e-5):
 
 
 # ------------------------------------------------------------------------------------------------ squeeze-excite
+HW_TICKET = _os.environ.get('TFPP_HW_TICKET', '1') != '0'  # 0: the two-launch reductions (A/B runs, comparison tests)
+
+
 def mean_hw(x):
   b, h, w, c = x.shape
   out = torch.empty((b, c), device=x.device, dtype=torch.float32)
+  if HW_TICKET and b <= 64:  # one launch: the last workgroup of a sample adds the partial sums (tfpp_mean_hw_ticket)
+    lib.tfpp_mean_hw_ticket(ptr(_chk(x)), ptr(out), ptr(reduce_scratch(b, c, x.device)), ptr(gridsum_scratch(x.device)), b, h * w, c, dt(x), stream())
+    return out
   lib.tfpp_mean_hw(ptr(_chk(x)), ptr(out), ptr(reduce_scratch(b, c, x.device)), b, h * w, c, dt(x), stream())
   return out
 
@@ -642,6 +648,9 @@ def se_gate_fwd(pool, w1, b1, w2, b2):
 def se_dgate(dy, x):
   b, h, w, c = x.shape
   out = torch.empty((b, c), device=x.device, dtype=torch.float32)
+  if HW_TICKET and b <= 64:
+    lib.tfpp_se_dgate_ticket(ptr(_chk(dy)), ptr(_chk(x)), ptr(out), ptr(reduce_scratch(b, c, x.device)), ptr(gridsum_scratch(x.device)), b, h * w, c, dt(x), stream())
+    return out
   lib.tfpp_se_dgate(ptr(_chk(dy)), ptr(_chk(x)), ptr(out), ptr(reduce_scratch(b, c, x.device)), b, h * w, c, dt(x), stream())
   return out
 

@@ -370,6 +370,11 @@ int tfpp_bn1d_scalar(const float* x, float* y, float* running_mean, float* runni
  * two-stage (plain stores + a small second kernel), deterministic, no atomics or memsets. */
 int tfpp_reduce_scratch_floats(int B, int C);
 int tfpp_mean_hw(const void* x, float* out, float* scratch, int B, int HW, int C, int dtype, void* stream);
+/* tfpp_mean_hw / tfpp_se_dgate in ONE launch (round 5): the row-block workgroups of a sample publish their partial sums, the workgroup that draws the
+ * sample's last ticket adds them in a fixed order and writes the result.  ticket_scratch: a tfpp_gridsum_scratch_floats() buffer (zero before the
+ * first use, left at zero, not shared between concurrent streams); B <= 64, else TFPP_EINVAL. */
+int tfpp_mean_hw_ticket(const void* x, float* out, float* scratch, float* ticket_scratch, int B, int HW, int C, int dtype, void* stream);
+int tfpp_se_dgate_ticket(const void* dy, const void* x, float* dgate, float* scratch, float* ticket_scratch, int B, int HW, int C, int dtype, void* stream);
 int tfpp_se_gate_fwd(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2, float* hidden,
                      float* gate, int B, int C, int RD, void* stream);
 int tfpp_se_dgate(const void* dy, const void* x, float* dgate, float* scratch, int B, int HW, int C, int dtype, void* stream);
