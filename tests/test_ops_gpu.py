@@ -190,6 +190,18 @@ def test_weight_gradients_of_a_batch_as_grouped_launches(ops):
     check(f'wgrad_batch.{i}.vs_single_call', dw.cpu(), dws.cpu() * mult + off, torch.float32, scale=5.0)
 
 
+def test_weight_gradients_of_a_batch_with_persistent_workgroups_and_without_grouping():
+  """The two knobs of the grouped launch are read once per process: the same batch test in fresh processes with a grid cap (persistent
+  workgroups walking the tile list: TFPP_WGRAD_GROUP_WGS=24 -- fewer workgroups than tiles, not a multiple of the tile counts), with few large
+  workgroups per layer (no pixel split anywhere) and with many pixel slices walked by a capped grid."""
+  import subprocess
+  import sys
+  for env in ({'TFPP_WGRAD_GROUP_WGS': '24'}, {'TFPP_WGRAD_GROUP_TARGET': '200'}, {'TFPP_WGRAD_GROUP_TARGET': '20000', 'TFPP_WGRAD_GROUP_WGS': '64'}):
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', 'test_weight_gradients_of_a_batch_as_grouped_launches'],
+                       env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, check=False)
+    assert r.returncode == 0, (env, r.stdout.decode()[-2000:])
+
+
 # The shapes the benchmark (BASELINE config 3: bs = 12, bf16) actually runs, with the kernel variants it runs them on.
 # tfpp_conv_gemm_variant: 202 = 16-wave 256x128 LDS-DMA ring (K >= 1024, >= 128 tiles), 200 = 8-wave 128x128 (>= 256 tiles), 201 = 64x128,
 # 2 = LDS-staged 64x64 ...
