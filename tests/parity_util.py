@@ -72,3 +72,32 @@ def compare_packed(got, want, tol=REL_TOL_FP32, keys=None):
 
 def sample_idx(n):
   return np.unique(np.linspace(0, n - 1, GRAD_SAMPLES).astype(np.int64))
+
+
+def full_outputs(out):
+  """{name: full-resolution numpy array} of every tensor of the 10-tuple (no striding, no reduction)."""
+  d = {}
+  for i, name in ((0, 'pred_wp'), (1, 'pred_target_speed'), (2, 'pred_checkpoint'), (3, 'pred_semantic'), (4, 'pred_bev_semantic'), (5, 'pred_depth')):
+    if out[i] is not None:
+      d[name] = to_np(out[i])
+  if out[6] is not None:
+    for i, name in enumerate(('heatmap', 'wh', 'offset', 'yaw_class', 'yaw_res', 'velocity', 'brake')):
+      if i < len(out[6]) and out[6][i] is not None:
+        d['bb_' + name] = to_np(out[6][i])
+  return d
+
+
+def assert_every_element_close(got_out, want_out, tol, what):
+  """|got - want| <= tol * max|want| at EVERY element of every output tensor (the dense maps at full resolution: 1.8 M / 0.7 M / 0.26 M values):
+  a single wrong pixel anywhere fails, which the strided samples + row sums of pack_outputs cannot promise."""
+  got, want = full_outputs(got_out), full_outputs(want_out)
+  assert set(got) == set(want), (sorted(got), sorted(want))
+  errs = {}
+  for k, w in want.items():
+    g = got[k]
+    assert g.shape == w.shape, f'{what} {k}: {g.shape} vs {w.shape}'
+    d = np.abs(g.astype(np.float64) - w.astype(np.float64))
+    scale = float(np.abs(w).max()) + 1e-30
+    errs[k] = float(d.max() / scale)
+    assert errs[k] <= tol, f'{what} {k}: worst element off by {errs[k]:.3e} of the tensor scale at index {np.unravel_index(int(d.argmax()), d.shape)}'
+  return errs

@@ -209,6 +209,24 @@ def test_eval_forward_fp32_vs_reference_golden_and_oracle():
 
 
 @pytest.mark.gpu
+def test_eval_forward_fp32_every_pixel_vs_oracle():
+  """the golden comparison samples the dense maps (every 8th / 4th pixel + row sums).  Here EVERY element of every output --
+  1.8 M semantic logits, 0.7 M BEV logits, 0.26 M depths, the five CenterNet maps, the planning outputs -- against the CPU oracle's full-resolution
+  forward on the same inputs, for two different input seeds; tests/test_oracle.py::test_port_vs_live_reference holds the oracle to the unmodified
+  reference at every element (2e-5), so a single wrong pixel anywhere on the HIP path fails."""
+  m = _model().eval()
+  worst = {}
+  for seed in (1234, 7):
+    inp = P.make_inputs(1, seed=seed)
+    with torch.inference_mode():
+      out = m(*[x.cuda() for x in inp])
+      want = P.forward(P.make_state_dict(), P.PortConfig(), *inp)
+    for k, e in U.assert_every_element_close(out, want, U.REL_TOL_FP32, f'HIP vs oracle (seed {seed})').items():
+      worst[k] = max(worst.get(k, 0.0), e)
+  _report('eval_fp32_every_pixel', worst)
+
+
+@pytest.mark.gpu
 def test_eval_forward_bf16_close_to_fp32_reference():
   """bf16 storage (training precision): the reference never validated reduced precision (config.py:245-246); the
   tolerance here is 5e-2 relative on the same golden vectors."""

@@ -109,6 +109,9 @@ def test_port_vs_live_reference(cfg, sd):
     ref = model(*inp)
     out = P.forward(sd, cfg, *inp)
   U.compare_packed(U.pack_outputs(out), U.pack_outputs(ref), tol=2e-5)
+  # ... and EVERY element of every output (the packed form samples the dense maps on a stride grid + row sums).  The GPU test
+  # tests/test_model.py::test_eval_forward_fp32_every_pixel_vs_oracle closes the chain: HIP == port at every pixel, port == reference at every pixel.
+  U.assert_every_element_close(out, ref, 2e-5, 'port vs live reference')
   # the reference's decoder layers run ReLU, not the GELU its source passes (PortConfig.decoder_activation)
   assert all(l.activation is torch.nn.functional.relu for l in model.join.layers)
   torch.testing.assert_close(P.visibility_mask(cfg), model.valid_bev_pixels.data)
