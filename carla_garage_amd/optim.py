@@ -23,6 +23,7 @@ class FlatAdamW(torch.optim.Optimizer):
       raise ValueError('FlatAdamW implements AdamW with amsgrad=True (team_code/train.py:529-531)')
     super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=True))
     self._loose = {}            # id(param) -> (m, v, vmax, steps) for parameters outside any arena
+    self._updated = set()       # id(param) of arena parameters that have received a gradient at least once (the others carry no state, as in torch)
     self._pending_state = None  # load_state_dict before the arenas exist (train.py:533-534 resumes before the first forward)
 
   # ---------------------------------------------------------------------------------------------- arenas
@@ -71,6 +72,7 @@ class FlatAdamW(torch.optim.Optimizer):
         raise ValueError('FlatAdamW: every trainable parameter of the model must be optimised by the same optimizer (the fused kernel updates the whole arena)')
       if self._pending_state is not None:
         tr.load_state_dict(self._pending_state)
+        self._mark_loaded(tr, self._pending_state)
         self._pending_state = None
       # gradients that autograd / DDP delivered outside the arena (the anchor parameter, anything the caller assigned to .grad): copy them in
       step = tr.model.__dict__.get('_dropin_step')
@@ -80,13 +82,16 @@ class FlatAdamW(torch.optim.Optimizer):
       for p, slot in pairs:
         g = p.grad
         if g is slot:
+          self._updated.add(id(p))
           continue
         if g is None:
           # torch.optim.AdamW skips a parameter without a gradient (no decay, no moment update): the fused kernel walks the whole arena, so the
           # parameter and its three state slices are saved here and put back after the launch (unused heads; rare and small)
           ops.zero_(slot)
           skipped.append(p)
-        elif g.data_ptr() != slot.data_ptr():
+          continue
+        self._updated.add(id(p))
+        if g.data_ptr() != slot.data_ptr():
           ops.copy_rows(g.detach().float().contiguous(), slot, 1, slot.numel(), 0, 0, 0, 0)
       tr.lr, tr.betas, tr.eps = float(group['lr']), tuple(group['betas']), float(group['eps'])  # (the weight decay(s): set_groups above)
       saved = []
@@ -114,6 +119,12 @@ class FlatAdamW(torch.optim.Optimizer):
                         group['betas'][1], float(group['eps']), float(group['weight_decay']), st[3], grad_scale=1.0)
     return loss
 
+  def _mark_loaded(self, tr, state_dict):
+    """Parameters that carry state in a loaded checkpoint count as updated (their state must survive the next state_dict())."""
+    index = tr._group_index() or {id(p): i for i, p in enumerate(tr.model.parameters())}
+    have = set(state_dict.get('state', {}).keys())
+    self._updated |= {pid for pid, i in index.items() if i in have}
+
   # ---------------------------------------------------------------------------------------------- checkpoint / resume
   def state_dict(self):
     if self._pending_state is not None:  # loaded before the first step and not applied yet: that IS the state (ADVICE r3)
@@ -125,6 +136,13 @@ class FlatAdamW(torch.optim.Optimizer):
       tr.lr, tr.betas, tr.eps = float(g['lr']), tuple(g['betas']), float(g['eps'])
       tr.set_groups([x['params'] for x in self.param_groups], [x['weight_decay'] for x in self.param_groups])
       sd = tr.state_dict()  # torch.optim.AdamW's layout: positions in model.parameters() (one group) / group after group (trainer.py)
+      # a parameter that never received a gradient (an unused head) has NO state in torch.optim.AdamW: drop the entry the arena-wide kernel
+      # implies, so that a checkpoint loads into the reference's optimizer exactly as one written by it would
+      if self._updated:
+        index = tr._group_index() or {id(p): i for i, p in enumerate(tr.model.parameters())}  # (the numbering Trainer.state_dict used)
+        never = {index[id(p)] for _, p in arenas[tr] if id(p) not in self._updated and id(p) in index}
+        for i in never:
+          sd['state'].pop(i, None)
       for x, out in zip(self.param_groups, sd['param_groups']):
         for k, v in x.items():  # keys the LR schedulers add to the group (initial_lr, ...)
           if k != 'params' and k not in out:
@@ -146,5 +164,6 @@ class FlatAdamW(torch.optim.Optimizer):
       tr = next(iter(arenas))
       tr.set_groups([x['params'] for x in self.param_groups], [x['weight_decay'] for x in self.param_groups])
       tr.load_state_dict(state_dict)
+      self._mark_loaded(tr, state_dict)
     else:
       self._pending_state = state_dict  # applied by the first step(), when the arenas exist

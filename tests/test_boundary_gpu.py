@@ -249,6 +249,33 @@ def test_fused_optimizer_leaves_a_parameter_without_gradient_alone_like_torch_an
   assert float(opt2.state_dict()['state'][vi]['step']) == float(sd['state'][vi]['step']) + 1
 
 
+def test_fused_optimizer_keeps_no_state_for_a_parameter_that_never_had_a_gradient():
+  """torch.optim.AdamW creates state for a parameter when it first sees a gradient for it; a parameter that never had one (an
+  unused head) has none, and a checkpoint written by FlatAdamW must look the same so that the reference's optimizer loads it unchanged."""
+  from carla_garage_amd.losses import normalized_loss_weights
+  from carla_garage_amd.optim import FlatAdamW
+  m = TD._model()
+  opt = FlatAdamW(m.parameters(), lr=1e-3, amsgrad=True)
+  w = normalized_loss_weights(m.config)
+  plist = list(m.parameters())
+  victim, other = m.target_speed_network[2].bias, m.target_speed_network[0].weight
+  vi, oi = (next(i for i, q in enumerate(plist) if q is t) for t in (victim, other))
+  for b in TD._batches(2):
+    pred = m(rgb=b['rgb'], lidar_bev=b['lidar_bev'], target_point=b['target_point'], ego_vel=b['ego_vel'], command=b['command'])
+    lab = {k: v for k, v in b.items() if k.endswith('_label')}
+    ls = m.compute_loss(pred_wp=pred[0], pred_target_speed=pred[1], pred_checkpoint=pred[2], pred_semantic=pred[3], pred_bev_semantic=pred[4],
+                        pred_depth=pred[5], pred_bounding_box=pred[6], pred_wp_1=pred[8], selected_path=pred[9], **lab)
+    sum(w[k] * v for k, v in ls.items()).backward()
+    victim.grad = None
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+  sd = opt.state_dict()
+  assert vi not in sd['state'] and oi in sd['state'] and float(sd['state'][oi]['step']) == 2.0
+  ref = torch.optim.AdamW([p for p in plist], lr=1e-3, amsgrad=True)
+  ref.load_state_dict(sd)  # the reference's optimizer takes the checkpoint as it is
+  assert len(ref.state_dict()['state']) == len(sd['state'])
+
+
 def _free_port():
   with socket.socket() as s:
     s.bind(('127.0.0.1', 0))

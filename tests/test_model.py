@@ -541,7 +541,7 @@ BF16_ELEM_FRACTION_BEYOND_HALF = 0.13
 def test_train_step_bs12_bf16_vs_fp32_hip_and_golden():
   """The benchmarked precision: the bf16 step at bs = 12 against the reference's fp32 losses and against the fp32 HIP step's gradients --
   losses, the whole gradient arena (cosine / relative L2), the distribution of per-tensor norm errors and sampled ELEMENTS (see the
-  constants above).  tests/test_model.py::test_bf16_trains_like_fp32_over_50_steps is the end-to-end counterpart."""
+  constants above).  tests/test_model.py::test_bf16_trains_like_fp32_over_200_steps_... is the end-to-end counterpart."""
   g = U.load_golden('tfpp_train_bs12.npz')
   m32 = _model('fp32').train()
   _, v32, e32 = _engine_train_step(m32, 12)
@@ -623,11 +623,16 @@ def test_bf16_step_is_no_worse_than_the_autocast_reference():
 
 
 @pytest.mark.gpu
-def test_bf16_trains_like_fp32_over_50_steps():
-  """Does the benchmarked precision TRAIN like fp32?  50 optimizer steps (AdamW-amsgrad, lr 1e-4, four different batches of 4 cycled, dropout
-  off), a bf16 Trainer beside an fp32 Trainer from identical weights: the weighted training loss of both falls from ~96 to ~1.5 and the bf16
-  curve stays within a few percent of the fp32 one (measured: max 2.5 %, mean 0.54 %, tools/bf16_evidence.py)."""
+def test_bf16_trains_like_fp32_over_200_steps_and_drifts_no_further_than_the_autocast_reference():
+  """Does the benchmarked precision TRAIN like fp32?  200 optimizer steps (AdamW-amsgrad, lr 1e-4, four different batches of 4 cycled, dropout
+  off), a bf16 Trainer beside an fp32 Trainer from identical weights.  The bar is not an absolute number but the drift of a bf16 REFERENCE:
+  tests/golden/tfpp_bf16_autocast_curve.npz holds the same 200 steps of the oracle port in fp32 and under torch.autocast(bfloat16)
+  (oracle/make_golden_bf16_curve.py).  Compared on curves smoothed over 8 steps (two cycles of the four batches): these statistics move by
+  +-30 % between two builds that only differ in the ORDER of fp32 sums (profiles/r05_bf16_curve.txt: smoothed max 2.9-3.8 %, mean 1.7-2.1 %
+  over 200 steps), so the raw 50-step bars of rounds 3-4 (max 4 %, mean 1 %, set from one measurement) were inside their own noise."""
   from carla_garage_amd.trainer import Trainer
+  g = U.load_golden('tfpp_bf16_autocast_curve.npz')
+  steps = int(g['steps'])
   batches = []
   for i in range(4):
     b = {k: v.cuda() for k, v in P.make_labels(4).items()}
@@ -640,15 +645,27 @@ def test_bf16_trains_like_fp32_over_50_steps():
     m = _model(dt).train()
     _zero_dropout(m)
     tr = Trainer(m, lr=1e-4)
-    curves[dt] = np.array([tr.total_loss(tr.train_step(batches[s % 4])) for s in range(50)])
+    curves[dt] = np.array([tr.total_loss(tr.train_step(batches[s % 4])) for s in range(steps)])
     del tr, m
     torch.cuda.empty_cache()
+  smooth = lambda x: np.convolve(x, np.ones(8) / 8, mode='valid')
+  dev = lambda x, ref: np.abs(smooth(x) - smooth(ref)) / np.abs(smooth(ref))
   a, b = curves['fp32'], curves['bf16']
-  dev = np.abs(a - b) / np.abs(a)
-  _report('bf16_vs_fp32_50_steps', {'fp32_first_last': [float(a[0]), float(a[-1])], 'bf16_first_last': [float(b[0]), float(b[-1])],
-                                    'max_rel_dev': float(dev.max()), 'mean_rel_dev': float(dev.mean())})
-  assert np.isfinite(b).all() and a[-1] < 0.05 * a[0] and b[-1] < 0.05 * b[0]
-  assert dev.max() <= 0.04 and dev.mean() <= 0.01, (float(dev.max()), float(dev.mean()))
+  hip, ref = dev(b, a), dev(g['autocast'], g['fp32'])
+  fp32_vs_ref = dev(a, g['fp32'])
+  rep = {'steps': steps, 'fp32_first_last8': [float(a[0]), float(a[-8:].mean())], 'bf16_first_last8': [float(b[0]), float(b[-8:].mean())],
+         'hip_bf16_vs_fp32_smoothed': {'max': float(hip.max()), 'mean': float(hip.mean())},
+         'reference_autocast_vs_fp32_smoothed': {'max': float(ref.max()), 'mean': float(ref.mean())},
+         'hip_fp32_vs_reference_fp32_smoothed': {'max': float(fp32_vs_ref.max()), 'mean': float(fp32_vs_ref.mean())},
+         'reference_last8': [float(g['fp32'][-8:].mean()), float(g['autocast'][-8:].mean())]}
+  _report('bf16_vs_fp32_200_steps', rep)
+  assert np.isfinite(b).all() and a[-8:].mean() < 0.02 * a[0] and b[-8:].mean() < 0.02 * b[0], rep   # both train: 96.5 -> below 1.9
+  assert abs(float(a[0]) - float(g['fp32'][0])) <= 1e-4 * float(a[0]), rep                            # the same first step as the oracle in fp32
+  assert fp32_vs_ref.mean() <= 0.03, rep                                                                # ... and the same fp32 curve within its own chaos
+  # the bf16 run drifts from its fp32 run no further than the reference's autocast run drifts from ITS fp32 run (smoothed: max 5.9 %, mean 3.1 %,
+  # final loss 2.7 % lower) + half a percent / one percent for the order-of-sums noise.  Measured: max 2.9-3.8 %, mean 1.7-2.1 %, final loss 1.1-1.9 % lower
+  assert hip.mean() <= ref.mean() + 0.005 and hip.max() <= ref.max() + 0.01, rep
+  assert abs(b[-8:].mean() - a[-8:].mean()) <= 0.04 * a[-8:].mean(), rep
 
 
 @pytest.mark.gpu
