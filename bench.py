@@ -147,7 +147,7 @@ def cpu_baseline(cfg_bs=12, budget_s=75.0, hard_timeout_s=150.0):
 def bf16_vs_fp32_gradients(batch, device, log, state_dict=None):
   """What the benchmarked precision is: the gradients of ONE bf16 training step against the fp32 HIP step (the reference's arithmetic: use_amp = 0)
   on identical weights, batch and dropout masks -- cosine and relative L2 distance over the whole gradient arena.  (Per-tensor statistics and
-  the 50-step loss curves: tests/test_model.py, profiles/rNN_model_parity_report.jsonl.)"""
+  the 200-step loss curves against the autocast reference: tests/test_model.py, profiles/rNN_model_parity_report.jsonl.)"""
   from carla_garage_amd.config import GlobalConfig
   from carla_garage_amd.model import LidarCenterNet
   from carla_garage_amd.trainer import Trainer
