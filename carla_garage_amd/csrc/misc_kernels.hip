@@ -477,6 +477,80 @@ extern "C" int tfpp_reg_loss(const void* pred, const float* target, const float*
   return 0;
 }
 
+// Two waypoint hypotheses, the better one per sample is trained (config.multi_wp_output, model.py:401-408): l_h[b] = mean_e |pair[b,h,e] - label[b,e]|,
+// loss = mean_b min(l_0, l_1); the arg-min (0 / 1, the first on a tie as torch.min) is the label of the path-selection logit.  One wave per
+// sample; fp32 (planning head).  dpair: d(weight * loss) / d pair, zero for the hypothesis that lost.
+#define TFPP_MULTI_WP_MAX_B 1024
+__global__ void min_l1_pair_loss_kernel(const float* __restrict__ pair, const float* __restrict__ label, float weight, float* __restrict__ loss_out,
+                                        float* __restrict__ dpair, float* __restrict__ sel_label, int B, int n) {
+  __shared__ float best[TFPP_MULTI_WP_MAX_B];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const float gs = weight / ((float)n * (float)B);
+  for (int b = w; b < B; b += nw) {
+    const float* p0 = pair + (size_t)b * 2 * n;
+    const float* p1 = p0 + n;
+    const float* l = label + (size_t)b * n;
+    float a0 = 0.f, a1 = 0.f;
+    for (int e = lane; e < n; e += 64) {
+      a0 += fabsf(p0[e] - l[e]);
+      a1 += fabsf(p1[e] - l[e]);
+    }
+    a0 = wave_sum(a0) / (float)n;
+    a1 = wave_sum(a1) / (float)n;
+    const int pick = a1 < a0 ? 1 : 0;
+    if (lane == 0) {
+      best[b] = pick ? a1 : a0;
+      sel_label[b] = (float)pick;
+    }
+    if (dpair) {
+      float* d0 = dpair + (size_t)b * 2 * n;
+      for (int e = lane; e < 2 * n; e += 64) {
+        const int h = e >= n, ee = e - h * n;
+        const float df = p0[e] - l[ee];  // (p0 + n + ee == p1 + ee)
+        d0[e] = h == pick ? (df > 0.f ? gs : (df < 0.f ? -gs : 0.f)) : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += best[b];
+    loss_out[0] += s / (float)B;
+  }
+}
+extern "C" int tfpp_min_l1_pair_loss(const float* pair, const float* label, float weight, float* loss_out, float* dpair, float* sel_label, int B,
+                                     int n, void* stream) {
+  if (!pair || !label || !loss_out || !sel_label || B < 1 || B > TFPP_MULTI_WP_MAX_B || n < 1) return TFPP_EINVAL;
+  hipLaunchKernelGGL(min_l1_pair_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pair, label, weight, loss_out, dpair, sel_label, B, n);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
+// nn.BCEWithLogitsLoss() on one logit per sample (model.py:266-267,409-411): mean_b [max(x, 0) - x y + log(1 + exp(-|x|))]; x = logit[b * ld],
+// the other ld - 1 stored channels are padding and get a zero gradient.
+__global__ void bce_logits_loss_kernel(const float* __restrict__ logit, int ld, const float* __restrict__ y, float weight, float* __restrict__ loss_out,
+                                       float* __restrict__ dlogit, int B) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float x = logit[(size_t)b * ld], t = y[b];
+    acc += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+    if (dlogit) {
+      const float sg = x >= 0.f ? 1.f / (1.f + expf(-x)) : expf(x) / (1.f + expf(x));
+      dlogit[(size_t)b * ld] = weight * (sg - t) / (float)B;
+      for (int c = 1; c < ld; ++c) dlogit[(size_t)b * ld + c] = 0.f;
+    }
+  }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) loss_out[0] += acc / (float)B;
+}
+extern "C" int tfpp_bce_logits_loss(const float* logit, int ld, const float* y, float weight, float* loss_out, float* dlogit, int B, void* stream) {
+  if (!logit || !y || !loss_out || B < 1 || ld < 1) return TFPP_EINVAL;
+  hipLaunchKernelGGL(bce_logits_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logit, ld, y, weight, loss_out, dlogit, B);
+  TFPP_CHECK_LAUNCH();
+  return 0;
+}
+
 // out[0] = sum(x[0..n))  (avg_factor.sum(), center_net.py:98)
 __global__ void sum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, long n) {
   __shared__ float sm[4];

@@ -27,7 +27,7 @@ from . import dist as tdist
 from . import ops
 from .engine import F32, Tape
 from .graph import capture, capture_stream
-from .losses import active_losses, fused_losses
+from .losses import active_losses, fused_losses, output_slots
 
 GRAPH_AFTER = int(os.environ.get('TFPP_DROPIN_GRAPH_AFTER', '2'))  # eager steps of one input signature before it is captured; < 0: never
 
@@ -83,6 +83,24 @@ class _LossNode(torch.autograd.Function):
     return step.token(ctx.shape, ctx.dtype, ctx.device), None, None, None, None
 
 
+class _PairLossNode(torch.autograd.Function):
+  """_LossNode of a loss with two caller-facing predictions (loss_wp of the multi_wp_output variant: pred_wp and pred_wp_1)."""
+
+  @staticmethod
+  def forward(ctx, caller0, caller1, value, step, index, step_id):
+    ctx.step, ctx.index, ctx.step_id = step, index, step_id
+    ctx.meta = [(c.shape, c.dtype, c.device) for c in (caller0, caller1)]
+    return value.detach()
+
+  @staticmethod
+  def backward(ctx, g):
+    step = ctx.step
+    if g is not None and ctx.step_id == step.step_id:
+      ops.copy_rows(g.detach().float().reshape(1).contiguous(), step.gscale, 1, 1, 0, 0, 0, ctx.index)
+      step.cur['used'].add(ctx.index)
+    return tuple(step.token(*m) for m in ctx.meta) + (None,) * 4
+
+
 class DropinStep:
 
   def __init__(self, model):
@@ -94,6 +112,9 @@ class DropinStep:
       tr = Trainer(model, lazy_state=True)
     self.tr, self.eng = tr, tr.eng
     self.names = active_losses(self.cfg)
+    # the caller-facing predictions of model._export, each with the loss it belongs to (one per loss, except the two hypotheses of multi_wp_output)
+    self.slots = output_slots(self.cfg)
+    self.slot_loss = [self.names.index(l) for _, l in self.slots]
     self.gscale = ops.zeros(max(16, len(self.names)), F32, self.eng.device)
     self._tokens = {}
     self._views = None
@@ -173,7 +194,7 @@ class DropinStep:
     internal = eng.forward(*inputs)
     tape, eng.tape = eng.tape, None
     outs, seeds = model._export(internal)
-    assert len(outs) == len(self.names), 'one caller-facing prediction per active loss (model._export / losses.active_losses)'
+    assert len(outs) == len(self.slots), 'the caller-facing predictions are those of losses.output_slots (model._export)'
     return dict(internal=internal, tape=tape, outs=outs, export_seeds=seeds)
 
   def _run_forward(self, inputs):
@@ -222,7 +243,7 @@ class DropinStep:
     cur = self.cur
     if cur is None or cur['loss'] is not None or not torch.is_grad_enabled():
       return False
-    got = [callers.get(n) for n in self.names]
+    got = [callers.get(k) for k, _ in self.slots]
     return all(c is not None and c.requires_grad and c.data_ptr() == p for c, p in zip(got, cur['out_ptrs']))
 
   def losses(self, callers, labels):
@@ -248,7 +269,12 @@ class DropinStep:
       _, vals, seeds = fused_losses(model, cur['fwd']['internal'], labels, None, True)
     cur['loss'] = dict(vals=vals, seeds=seeds)
     ops.zero_(self.gscale)
-    return {n: _LossNode.apply(callers[n], vals[i], self, i, cur['step_id']) for i, n in enumerate(self.names)}
+    out = {}
+    for i, n in enumerate(self.names):
+      mine = [callers[k] for k, l in self.slots if l == n]
+      node = _LossNode if len(mine) == 1 else _PairLossNode
+      out[n] = node.apply(*mine, vals[i], self, i, cur['step_id'])
+    return out
 
   # ------------------------------------------------------------------------------------------------ backward
   def _scaled_seeds(self, loss_seeds, which=None):
@@ -275,7 +301,7 @@ class DropinStep:
     ops.zero_(eng.g(self.anchor))  # the anchor's gradient travels through autograd (which accumulates it): its slot holds this backward only
     live = [j for j, g in enumerate(gouts) if g is not None]
     tokens = cur['loss'] is not None and live and all(self._is_token(gouts[j]) for j in live)
-    if cur['mode'] == 'graph' and tokens and set(live) == set(range(len(self.names))):
+    if cur['mode'] == 'graph' and tokens and set(live) == set(range(len(self.slots))):
       if plan.B1 is None:
         torch.cuda.synchronize()
         st = capture_stream(eng.device)
@@ -294,12 +320,15 @@ class DropinStep:
     else:
       seeds = []
       if tokens:
-        seeds = self._scaled_seeds(cur['loss']['seeds'], set(live))
+        seeds = self._scaled_seeds(cur['loss']['seeds'], {self.slot_loss[j] for j in live})
       else:
+        seeded = set()
         for j in live:
           g = gouts[j]
           if self._is_token(g) and cur['loss'] is not None:
-            seeds += self._scaled_seeds(cur['loss']['seeds'], {j})
+            if self.slot_loss[j] not in seeded:  # (both hypotheses of multi_wp_output carry the token of the ONE loss_wp seed)
+              seeds += self._scaled_seeds(cur['loss']['seeds'], {self.slot_loss[j]})
+              seeded.add(self.slot_loss[j])
           else:
             seeds.append(fwd['export_seeds'][j](g.contiguous()))
       eng.buckets.begin_issue()

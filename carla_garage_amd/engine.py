@@ -705,11 +705,13 @@ class Engine:
       self._spec(q + '.multihead_attn.out_proj', layer.multihead_attn.out_proj.weight, layer.multihead_attn.out_proj.bias, **h)
       self._spec(q + '.linear1', layer.linear1.weight, layer.linear1.bias, **h)
       self._spec(q + '.linear2', layer.linear2.weight, layer.linear2.bias, **h)
-    for dn in ('checkpoint_decoder', 'wp_decoder'):
+    for dn in ('checkpoint_decoder', 'wp_decoder', 'wp_decoder_1'):
       if hasattr(m, dn):
         d = getattr(m, dn)
         self._spec(dn + '.gru.ih', d.gru.weight_ih_l0, d.gru.bias_ih_l0, **h)
         self._spec(dn + '.encoder', d.encoder.weight, d.encoder.bias, cin_store=4, **h)
+    if hasattr(m, 'select_wps'):
+      self._spec('select_wps', m.select_wps.weight, m.select_wps.bias, **h)
     if hasattr(m, 'target_speed_network'):
       self._spec('target_speed_network.0', m.target_speed_network[0].weight, m.target_speed_network[0].bias, **h)
       self._spec('target_speed_network.2', m.target_speed_network[2].weight, m.target_speed_network[2].bias, **h)
@@ -1669,7 +1671,47 @@ class Engine:
         return self.decoder(q0, mem, B, nq, ntok + 1)
 
       out['pred_wp'] = out['pred_target_speed'] = out['pred_checkpoint'] = None
-      if cfg.use_wp_gru:
+      if cfg.use_wp_gru and getattr(m, 'multi_wp', False):
+        # multi_wp_output (model.py:326-331): 2 nq + 1 queries -> two GRU decoders (one hypothesis each) and the path-selection logit
+        nq = cfg.pred_len // cfg.wp_dilation
+        nqa = 2 * nq + 1
+        j = run_queries(m.wp_query, nqa)
+        g0, g1 = (torch.empty((B, nq, dm), device=dev, dtype=F32) for _ in range(2))
+        sf = torch.empty((B, dm), device=dev, dtype=F32)
+        ops.copy_rows(j, g0, B, nq * dm, nqa * dm, 0, nq * dm, 0)
+        ops.copy_rows(j, g1, B, nq * dm, nqa * dm, nq * dm, nq * dm, 0)
+        ops.copy_rows(j, sf, B, dm, nqa * dm, 2 * nq * dm, dm, 0)
+        if self.tape is not None:
+
+          def bwd_split(d0, d1, ds):
+            d = ops.zeros((B, nqa, dm), F32, dev)
+            if d0 is not None:
+              ops.copy_rows(d0, d, B, nq * dm, nq * dm, 0, nqa * dm, 0)
+            if d1 is not None:
+              ops.copy_rows(d1, d, B, nq * dm, nq * dm, 0, nqa * dm, nq * dm)
+            if ds is not None:
+              ops.copy_rows(ds, d, B, dm, dm, 0, nqa * dm, 2 * nq * dm)
+            return d
+
+          self.rec([g0, g1, sf], [j], bwd_split)
+        tp = target_point.float().contiguous()
+        w0 = self.gru_decoder(g0, tp, m.wp_decoder, 'wp_decoder', B, nq)
+        w1 = self.gru_decoder(g1, tp, m.wp_decoder_1, 'wp_decoder_1', B, nq)
+        pair = torch.empty((B, 2, nq, 2), device=dev, dtype=F32)  # both hypotheses of a sample side by side: one loss kernel, one gradient seed
+        ops.copy_rows(w0, pair, B, nq * 2, nq * 2, 0, nq * 4, 0)
+        ops.copy_rows(w1, pair, B, nq * 2, nq * 2, 0, nq * 4, nq * 2)
+        if self.tape is not None:
+
+          def bwd_pair(d):
+            d0, d1 = torch.empty_like(w0), torch.empty_like(w1)
+            ops.copy_rows(d, d0, B, nq * 2, nq * 4, 0, nq * 2, 0)
+            ops.copy_rows(d, d1, B, nq * 2, nq * 4, nq * 2, nq * 2, 0)
+            return d0, d1
+
+          self.rec([pair], [w0, w1], bwd_pair)
+        out['pred_wp_pair'] = pair
+        out['selected_path'] = self.linear(sf, 'select_wps')  # [B, 8] (1 real)
+      elif cfg.use_wp_gru:
         nq = cfg.pred_len // cfg.wp_dilation
         j = run_queries(m.wp_query, nq)
         out['pred_wp'] = self.gru_decoder(j, target_point.float().contiguous(), m.wp_decoder, 'wp_decoder', B, nq)

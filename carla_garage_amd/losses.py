@@ -10,7 +10,7 @@ import torch
 from . import ops
 from .engine import F32, EPS_F32
 
-LOSS_ORDER = ('loss_wp', 'loss_target_speed', 'loss_checkpoint', 'loss_semantic', 'loss_bev_semantic', 'loss_depth',
+LOSS_ORDER = ('loss_wp', 'loss_selection', 'loss_target_speed', 'loss_checkpoint', 'loss_semantic', 'loss_bev_semantic', 'loss_depth',
               'loss_center_heatmap', 'loss_wh', 'loss_offset', 'loss_yaw_class', 'loss_yaw_res', 'loss_velocity', 'loss_brake')
 BB_LOSSES = ('loss_center_heatmap', 'loss_wh', 'loss_offset', 'loss_yaw_class', 'loss_yaw_res', 'loss_velocity', 'loss_brake')
 
@@ -20,10 +20,18 @@ def temporal(cfg):
   return not (cfg.lidar_seq_len == 1 and cfg.seq_len == 1)
 
 
+def multi_wp(cfg):
+  """config.multi_wp_output (config.py:484, model.py:151-163): two waypoint hypotheses, the better one per sample is trained, and a logit that
+  learns which one that is (loss_selection, weight 1.0: train.py:440-441)."""
+  return bool(cfg.use_wp_gru and getattr(cfg, 'multi_wp_output', False))
+
+
 def active_losses(cfg):
   names = []
   if cfg.use_wp_gru:
     names.append('loss_wp')
+    if multi_wp(cfg):
+      names.append('loss_selection')
   if cfg.use_controller_input_prediction:
     names += ['loss_target_speed', 'loss_checkpoint']
   if cfg.use_semantic:
@@ -37,6 +45,17 @@ def active_losses(cfg):
     if temporal(cfg):
       names += ['loss_velocity', 'loss_brake']
   return names
+
+
+def output_slots(cfg):
+  """[(key, loss name)] of the caller-facing predictions in the order model._export emits them: one per active loss, except that loss_wp of
+  the multi_wp_output variant has two (pred_wp under 'loss_wp', pred_wp_1 under 'loss_wp/1')."""
+  slots = []
+  for n in active_losses(cfg):
+    slots.append((n, n))
+    if n == 'loss_wp' and multi_wp(cfg):
+      slots.append(('loss_wp/1', n))
+  return slots
 
 
 def normalized_loss_weights(cfg):
@@ -66,6 +85,17 @@ def _one_loss(model, name, t, labels, slot, weight, want_grad, af_sum):
     ops.ce_loss(p, labels['target_speed_label'], slot, ws, rows=p.shape[0], C=len(cfg.target_speeds), ld=p.shape[1], HW=p.shape[0],
                 class_weight=model.loss_speed.nll_loss.weight if focal else model.loss_speed.weight, weight=weight, dpred=d,
                 smoothing=0.0 if focal else smooth, focal_gamma=float(model.loss_speed.gamma) if focal else -1.0)
+    return p, d
+  if name == 'loss_wp' and multi_wp(cfg):
+    p = t['pred_wp_pair']  # [B, 2, n, 2] fp32
+    d = grad_like(p)
+    t['_selection_labels'] = torch.empty(p.shape[0], device=dev, dtype=F32)  # the hypothesis that won, per sample: the target of loss_selection below
+    ops.min_l1_pair_loss(p, labels['waypoint_label'].float().contiguous(), slot, t['_selection_labels'], weight=weight, dpair=d)
+    return p, d
+  if name == 'loss_selection':
+    p = t['selected_path']  # [B, 8] fp32 (1 real)
+    d = grad_like(p)
+    ops.bce_logits_loss(p, t['_selection_labels'], slot, weight=weight, dlogit=d)
     return p, d
   if name in ('loss_checkpoint', 'loss_wp'):
     p = t['pred_checkpoint'] if name == 'loss_checkpoint' else t['pred_wp']
@@ -155,6 +185,20 @@ class _LossNode(torch.autograd.Function):
     return ctx.to_caller_grad(g), None, None
 
 
+class _PairLossNode(torch.autograd.Function):
+  """_LossNode for loss_wp of the multi_wp_output variant: one scalar, two caller-facing predictions (pred_wp, pred_wp_1)."""
+
+  @staticmethod
+  def forward(ctx, caller0, caller1, value, to_caller_grads):
+    ctx.to_caller_grads = to_caller_grads
+    return value.detach()
+
+  @staticmethod
+  def backward(ctx, g):
+    g0, g1 = ctx.to_caller_grads(g)
+    return g0, g1, None, None
+
+
 def _scale_by_device_scalar(x, g):
   """x * g for a 0-d device tensor g without a host sync (broadcast g into a per-channel scale vector)."""
   ld = x.shape[-1] if x.dim() > 1 and x.shape[-1] % 4 == 0 else 4
@@ -176,7 +220,16 @@ def _internal_from_callers(model, args):
       x = x.unsqueeze(1)
     return ops.nchw_to_nhwc_pad(x, dt_, ops.pad_to(x.shape[1], pad))
 
-  if args.get('pred_wp') is not None:
+  if args.get('pred_wp') is not None and multi_wp(cfg):
+    w0, w1 = (args[k].detach().float().contiguous() for k in ('pred_wp', 'pred_wp_1'))
+    B, n = w0.shape[0], w0.shape[1] * w0.shape[2]
+    t['pred_wp_pair'] = torch.empty((B, 2) + tuple(w0.shape[1:]), device=w0.device, dtype=F32)
+    ops.copy_rows(w0, t['pred_wp_pair'], B, n, n, 0, 2 * n, 0)
+    ops.copy_rows(w1, t['pred_wp_pair'], B, n, n, 0, 2 * n, n)
+    sp = args['selected_path'].detach().float().contiguous()
+    t['selected_path'] = ops.zeros((B, 8), F32, sp.device)
+    ops.copy_rows(sp, t['selected_path'], B, 1, 1, 0, 8, 0)
+  elif args.get('pred_wp') is not None:
     t['pred_wp'] = args['pred_wp'].detach().float().contiguous()
   if args.get('pred_target_speed') is not None:
     ts = args['pred_target_speed'].detach().float().contiguous()
@@ -192,7 +245,7 @@ def _internal_from_callers(model, args):
     t['pred_depth'] = dense(args['pred_depth'], 8)
   if cfg.detect_boxes and args.get('pred_bounding_box') is not None:
     t['bb'] = [dense(b, 8) for b in args['pred_bounding_box'][:7 if temporal(cfg) else 5]]
-  t['fused_features'] = next(v for v in (t['pred_checkpoint'], t['pred_wp'], t['pred_semantic']) if v is not None)  # (device carrier for fused_losses)
+  t['fused_features'] = next(v for v in (t['pred_checkpoint'], t['pred_wp'], t.get('pred_wp_pair'), t['pred_semantic']) if v is not None)  # (device carrier for fused_losses)
   return t
 
 
@@ -208,6 +261,8 @@ def reference_form_losses(model, args):
   labels = {k: args[k] for k in label_keys if args.get(k) is not None}
   callers = {'loss_wp': args['pred_wp'], 'loss_target_speed': args['pred_target_speed'], 'loss_checkpoint': args['pred_checkpoint'],
              'loss_semantic': args['pred_semantic'], 'loss_bev_semantic': args['pred_bev_semantic'], 'loss_depth': args['pred_depth']}
+  if multi_wp(cfg):
+    callers['loss_wp/1'], callers['loss_selection'] = args['pred_wp_1'], args['selected_path']
   if cfg.detect_boxes:
     for i, n in enumerate(BB_LOSSES[:7 if temporal(cfg) else 5]):
       callers[n] = args['pred_bounding_box'][i]
@@ -228,6 +283,16 @@ def reference_form_losses(model, args):
 
       def to_caller(g, pred=pred, dpred=dpred, caller=caller, n=n):
         d = _scale_by_device_scalar(dpred, g)
+        if n == 'loss_wp' and multi_wp(cfg):  # [B, 2, n, 2] -> the gradients of pred_wp and pred_wp_1
+          B_, n_ = caller.shape[0], caller.shape[1] * caller.shape[2]
+          halves = [torch.empty(caller.shape, device=d.device, dtype=F32) for _ in range(2)]
+          for h, o in enumerate(halves):
+            ops.copy_rows(d, o, B_, n_, 2 * n_, h * n_, n_, 0)
+          return halves
+        if n == 'loss_selection':
+          o = torch.empty(caller.shape, device=d.device, dtype=F32)
+          ops.copy_rows(d, o, caller.shape[0], 1, d.shape[1], 0, 1, 0)
+          return o
         if n == 'loss_target_speed':
           o = torch.empty(caller.shape, device=d.device, dtype=F32)
           ops.copy_rows(d, o, caller.shape[0], caller.shape[1], d.shape[1], 0, caller.shape[1], 0)
@@ -237,7 +302,10 @@ def reference_form_losses(model, args):
           return ops.nhwc_to_nchw(d, c_real).view(caller.shape)
         return d.view(caller.shape)
 
-      out[n] = _LossNode.apply(caller, vals[i], to_caller)
+      if n == 'loss_wp' and multi_wp(cfg):
+        out[n] = _PairLossNode.apply(caller, callers['loss_wp/1'], vals[i], to_caller)
+      else:
+        out[n] = _LossNode.apply(caller, vals[i], to_caller)
     else:
       out[n] = vals[i].detach()
   return out

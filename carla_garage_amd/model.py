@@ -51,8 +51,8 @@ class LidarCenterNet(nn.Module):
       # the reference itself cannot build these heads on the AIM backbone (model.py:71 reads backbone.perspective_upsample_factor,
       # which team_code/aim.py does not define; there is no BEV feature grid): BASELINE config 1 switches them off
       raise ValueError('backbone="aim" needs use_semantic = use_depth = detect_boxes = use_bev_semantic = 0')
-    if not config.transformer_decoder_join or cfg_get(config, 'tp_attention', False) or cfg_get(config, 'multi_wp_output', False):
-      raise ValueError('MI355X path: only transformer_decoder_join=True, tp_attention=False, multi_wp_output=False')
+    if not config.transformer_decoder_join or cfg_get(config, 'tp_attention', False):
+      raise ValueError('MI355X path: only transformer_decoder_join=True, tp_attention=False')
     if not (config.use_wp_gru or config.use_controller_input_prediction):
       raise ValueError('MI355X path needs use_wp_gru or use_controller_input_prediction')
     self.speed_histogram = []
@@ -67,8 +67,11 @@ class LidarCenterNet(nn.Module):
       self.valid_bev_pixels_inv = nn.Parameter(1.0 - vis, requires_grad=False)
     d = config.gru_input_size
     self.extra_sensor_pos_embed = nn.Parameter(torch.zeros(1, d))
+    n_wp = config.pred_len // config.wp_dilation
+    multi = self.multi_wp = bool(config.use_wp_gru and cfg_get(config, 'multi_wp_output', False))
     if config.use_wp_gru:
-      self.wp_query = nn.Parameter(torch.zeros(1, config.pred_len // config.wp_dilation, d))
+      # multi_wp_output (model.py:151-163): two waypoint hypotheses + one path-selection token share the query tensor
+      self.wp_query = nn.Parameter(torch.zeros(1, 2 * n_wp + 1 if multi else n_wp, d))
     if config.use_controller_input_prediction:
       self.checkpoint_query = nn.Parameter(torch.zeros(1, config.predict_checkpoint_len + 1, d))
 
@@ -96,7 +99,10 @@ class LidarCenterNet(nn.Module):
     self.join = nn.TransformerDecoder(layer, num_layers=config.num_transformer_decoder_layers, norm=nn.LayerNorm(d))
     self.change_channel = nn.Conv2d(self.backbone.num_features, d, kernel_size=1)
     if config.use_wp_gru:
-      self.wp_decoder = M.GRUWaypointsPredictorInterFuser(d, config.pred_len // config.wp_dilation, config.gru_hidden_size, tp_size)
+      self.wp_decoder = M.GRUWaypointsPredictorInterFuser(d, n_wp, config.gru_hidden_size, tp_size)
+      if multi:
+        self.wp_decoder_1 = M.GRUWaypointsPredictorInterFuser(d, n_wp, config.gru_hidden_size, tp_size)
+        self.select_wps = nn.Linear(d, 1)
     if config.use_controller_input_prediction:
       self.checkpoint_decoder = M.GRUWaypointsPredictorInterFuser(d, config.predict_checkpoint_len, config.gru_hidden_size, tp_size)
     self.velocity_normalization = nn.BatchNorm1d(1, affine=False)
@@ -124,6 +130,8 @@ class LidarCenterNet(nn.Module):
       self.loss_speed = nn.CrossEntropyLoss(weight=sw, label_smoothing=smooth)
     self.loss_semantic = nn.CrossEntropyLoss(weight=torch.tensor(config.semantic_weights), label_smoothing=smooth)
     self.loss_bev_semantic = nn.CrossEntropyLoss(weight=torch.tensor(config.bev_semantic_weights), label_smoothing=smooth, ignore_index=-1)
+    if multi:
+      self.selection_loss = nn.BCEWithLogitsLoss()  # model.py:266-267 (stateless; evaluated by tfpp_bce_logits_loss)
 
     self.__dict__['engine'] = None  # created lazily, not a sub-module
     self.__dict__['_param_list'] = None
@@ -193,6 +201,30 @@ class LidarCenterNet(nn.Module):
 
     if t['pred_wp'] is not None:
       add(t['pred_wp'], lambda g, x=t['pred_wp']: (x, g))
+    if t.get('pred_wp_pair') is not None:
+      # multi_wp_output: the two hypotheses live side by side in one [B, 2, n, 2] tensor (one loss kernel, one seed); the caller gets a copy of each
+      pair = t['pred_wp_pair']
+      B, n = pair.shape[0], pair.shape[2] * pair.shape[3]
+      for h in range(2):
+        o = torch.empty((B,) + tuple(pair.shape[2:]), device=pair.device, dtype=F32)
+        ops.copy_rows(pair, o, B, n, 2 * n, h * n, n, 0)
+
+        def seed_h(g, pair=pair, B=B, n=n, h=h):
+          gp = ops.zeros(pair.shape, F32, pair.device)
+          ops.copy_rows(g.float().contiguous(), gp, B, n, n, 0, 2 * n, h * n)
+          return pair, gp
+
+        add(o, seed_h)
+      sel = t['selected_path']  # [B, 8] (1 real)
+      o = torch.empty((B, 1), device=sel.device, dtype=F32)
+      ops.copy_rows(sel, o, B, 1, sel.shape[1], 0, 1, 0)
+
+      def seed_sel(g, sel=sel, B=B):
+        gp = ops.zeros(sel.shape, F32, sel.device)
+        ops.copy_rows(g.float().contiguous(), gp, B, 1, 1, 0, sel.shape[1], 0)
+        return sel, gp
+
+      add(o, seed_sel)
     if t['pred_target_speed'] is not None:
       ts = t['pred_target_speed']
       B, n = ts.shape[0], len(cfg.target_speeds)
@@ -228,6 +260,9 @@ class LidarCenterNet(nn.Module):
     cfg = self.config
     it = iter(outs)
     pred_wp = next(it) if cfg.use_wp_gru else None
+    pred_wp_1 = selected_path = None
+    if self.multi_wp:
+      pred_wp_1, selected_path = next(it), next(it)
     pred_ts = pred_cp = None
     if cfg.use_controller_input_prediction:
       pred_ts, pred_cp = next(it), next(it)
@@ -238,7 +273,7 @@ class LidarCenterNet(nn.Module):
     if cfg.detect_boxes:
       bb = tuple(next(it) for _ in self.head.BRANCHES)
       bb = bb + (None,) * (7 - len(bb))  # velocity / brake only exist with temporal input (center_net.py:66-75)
-    return pred_wp, pred_ts, pred_cp, pred_sem, pred_bev, pred_depth, bb, None, None, None
+    return pred_wp, pred_ts, pred_cp, pred_sem, pred_bev, pred_depth, bb, None, pred_wp_1, selected_path
 
   def forward(self, rgb, lidar_bev, target_point, ego_vel, command):
     if not rgb.is_cuda:

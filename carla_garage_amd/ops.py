@@ -1029,6 +1029,17 @@ def reg_loss(pred, target, loss_out, *, B, C, HW, ld, kind, elem_weight=None, wC
                     ptr(loss_out), ptr(dpred), ptr(gridsum_scratch(pred.device)), B, C, HW, ld, kind, dt(pred), stream())
 
 
+def min_l1_pair_loss(pair, label, loss_out, sel_label, weight=1.0, dpair=None):
+  """pair [B, 2, n...] fp32, label [B, n...]: the two-hypothesis waypoint loss of config.multi_wp_output (model.py:401-408); sel_label [B] fp32 <- arg-min."""
+  b = pair.shape[0]
+  lib.tfpp_min_l1_pair_loss(ptr(_chk(pair)), ptr(_chk(label)), weight, ptr(loss_out), ptr(dpair), ptr(sel_label), b, pair.numel() // (2 * b), stream())
+
+
+def bce_logits_loss(logit, y, loss_out, weight=1.0, dlogit=None):
+  """logit [B, ld] fp32 (channel 0 real), y [B] fp32: nn.BCEWithLogitsLoss() (model.py:266-267,409-411)."""
+  lib.tfpp_bce_logits_loss(ptr(_chk(logit)), logit.shape[1], ptr(y), weight, ptr(loss_out), ptr(dlogit), logit.shape[0], stream())
+
+
 def adamw_amsgrad(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, no_decay_bits=None):
   """no_decay_bits (int32 device tensor from no_decay_bitmask; p must start at the arena's first element): the weight_decay = 0 group of
   create_optimizer_groups."""

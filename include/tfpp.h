@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TFPP_ABI_VERSION 4
+#define TFPP_ABI_VERSION 5
 #define TFPP_EINVAL (-1000)
 #define TFPP_F32 0
 #define TFPP_BF16 1
@@ -557,6 +557,14 @@ int tfpp_ce_loss(const void* pred, const int64_t* label, const float* class_weig
 int tfpp_reg_loss(const void* pred, const float* target, const float* elem_weight, int wC, int w_bcast, const float* denom,
                   float denom_eps, float denom_mul, float weight, float* loss_out, void* dpred, float* scratch, int B, int C, int64_t HW,
                   int64_t ld, int kind, int dtype, void* stream);
+
+/* config.multi_wp_output (model.py:151-163,326-331,401-411; train.py:440-441): two waypoint hypotheses and a path-selection logit.
+ * min_l1_pair_loss: pair [B, 2, n] fp32 (both hypotheses of a sample side by side), label [B, n]; *loss_out += mean_b min_h mean_e |pair - label|,
+ *   dpair (nullable) = d(weight * loss) / d pair (zero for the hypothesis that lost), sel_label[b] = 0 / 1 = the hypothesis that won (B <= 1024).
+ * bce_logits_loss: nn.BCEWithLogitsLoss() of logit[b * ld] against y[b]; *loss_out += the mean over b; dlogit [B, ld] (nullable). */
+int tfpp_min_l1_pair_loss(const float* pair, const float* label, float weight, float* loss_out, float* dpair, float* sel_label, int B, int n,
+                          void* stream);
+int tfpp_bce_logits_loss(const float* logit, int ld, const float* y, float weight, float* loss_out, float* dlogit, int B, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.AdamW(amsgrad=True) (train.py:529-531) over a flat fp32 arena; g is scaled by grad_scale

@@ -215,6 +215,43 @@ def write_wp_train_golden():
   write_train_golden(model, cfg, 2, 'tfpp_wp_train_bs2.npz')
 
 
+MULTI_WP_LABEL_SEED = 39
+
+
+def write_multi_wp_golden():
+  """config.multi_wp_output = 1 with use_wp_gru = 1 (model.py:151-163,326-331,401-411; train.py:440-441 gives loss_selection the weight 1.0):
+  wp_query (1, 17, 256), two GRU decoders, the select_wps logit; loss_wp = mean_b min over the two hypotheses, loss_selection = BCE of the logit
+  against the arg-min.  One train-mode step at bs = 4 and an eval forward at bs = 1 on the unmodified reference."""
+  import dataclasses
+  over = dict(use_wp_gru=True, use_controller_input_prediction=False, multi_wp_output=True)
+  model, _ = ref_harness.build_reference_model(**over)
+  # label_seed: the draw of the synthetic labels with which two of the four samples train hypothesis 0 and two hypothesis 1 (the default draw picks
+  # hypothesis 0 four times, which would leave one branch of the min untested)
+  cfg = dataclasses.replace(P.PortConfig(), extra={'label_seed': MULTI_WP_LABEL_SEED}, **over)
+  model.load_state_dict(P.make_state_dict(cfg), strict=True)  # (strict: the port's schema names every tensor of the variant)
+  keys = list(model.state_dict().keys())
+  model.eval()
+  inp = P.make_inputs(1, cfg)
+  with torch.inference_mode():
+    out = model(*inp)
+  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_multi_wp_eval_bs1.npz'), pred_wp=_np(out[0]), pred_wp_1=_np(out[8]), selected_path=_np(out[9]),
+                      bb_heatmap=_np(out[6][0]), state_dict_keys=np.array(keys))
+  write_train_golden(model, cfg, 4, 'tfpp_multi_wp_train_bs4.npz')
+  # which hypothesis each of the four samples trained (both should occur, or the test exercises one branch of the min only)
+  model.train()
+  disable_dropout(model)
+  g = dict(np.load(os.path.join(GOLDEN, 'tfpp_multi_wp_train_bs4.npz'), allow_pickle=False))
+  model.load_state_dict(P.make_state_dict(cfg), strict=True)
+  out = model(*P.make_inputs(4, cfg))
+  lab = P.make_labels(4, cfg)
+  per = torch.stack([torch.mean(torch.abs(w - lab['waypoint_label']), dim=(1, 2)) for w in (out[0], out[8])], dim=1)
+  g['selection_labels'] = _np(torch.argmin(per, dim=1)).astype(np.int64)
+  g['fwd_pred_wp'], g['fwd_pred_wp_1'], g['fwd_selected_path'] = _np(out[0]), _np(out[8]), _np(out[9])
+  print('multi_wp: per-hypothesis losses', _np(per), 'picked', g['selection_labels'])
+  assert 0 < int(g['selection_labels'].sum()) < 4
+  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_multi_wp_train_bs4.npz'), **g)
+
+
 def write_freeze_golden():
   """Two-stage training (team_code/train.py:495-508, config.freeze_backbone): backbone, CenterNet head and the semantic / BEV-semantic /
   depth decoders are frozen with requires_grad_(False) exactly as train.py does it, then one train-mode step at bs = 2 -- only the planning
@@ -325,6 +362,9 @@ def main():
     return
   if only == {'wp_train'}:
     write_wp_train_golden()
+    return
+  if only == {'multi_wp'}:
+    write_multi_wp_golden()
     return
   if only == {'freeze'}:
     write_freeze_golden()

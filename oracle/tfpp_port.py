@@ -80,6 +80,7 @@ class PortConfig:
   num_bb_classes: int = 4
   num_dir_bins: int = 12
   use_wp_gru: bool = False  # config.py:370
+  multi_wp_output: bool = False  # config.py:484: two waypoint hypotheses + a path-selection logit (with use_wp_gru)
   use_controller_input_prediction: bool = True  # config.py:203
   target_speed_weights: tuple = (0.866605263873406, 7.4527377240841775, 1.2281629310898465, 0.5269622904065803)
   semantic_weights: tuple = (1.0,) * 7  # config.py:163
@@ -150,7 +151,7 @@ def param_schema(cfg=None):
   add('valid_bev_pixels_inv', (1, 1, cfg.lidar_resolution_height, cfg.lidar_resolution_width), 'mask')
   add('extra_sensor_pos_embed', (1, cfg.gru_input_size), 'emb')
   if cfg.use_wp_gru:
-    add('wp_query', (1, cfg.pred_len, cfg.gru_input_size), 'emb')
+    add('wp_query', (1, 2 * cfg.pred_len + 1 if cfg.multi_wp_output else cfg.pred_len, cfg.gru_input_size), 'emb')  # model.py:151-153,165-166
   if cfg.use_controller_input_prediction:
     add('checkpoint_query', (1, cfg.predict_checkpoint_len + 1, cfg.gru_input_size), 'emb')
 
@@ -229,6 +230,9 @@ def param_schema(cfg=None):
 
   if cfg.use_wp_gru:
     gru_dec('wp_decoder')
+    if cfg.multi_wp_output:  # model.py:159-163
+      gru_dec('wp_decoder_1')
+      lin('select_wps', d, 1)
   if cfg.use_controller_input_prediction:
     gru_dec('checkpoint_decoder')
   add('velocity_normalization.running_mean', (1,), 'rm')
@@ -370,6 +374,7 @@ def make_labels(batch, cfg=None, seed=1234):
   """Synthetic training labels with the dtypes of team_code/train.py:693-766 and the CenterNet target
   conventions of team_code/data.py:722-791 (heat-map peaks are exactly 1.0)."""
   cfg = cfg or PortConfig()
+  seed = cfg.extra.get('label_seed', seed)  # (a variant's fixture may ask for another draw: oracle/make_golden.py multi_wp)
   b = batch
   hb, wb = cfg.lidar_resolution_height // cfg.bev_down_sample_factor, cfg.lidar_resolution_width // cfg.bev_down_sample_factor
   lab = {}
@@ -620,7 +625,14 @@ def forward(sd, cfg, rgb, lidar_bev, target_point, ego_vel, command, training=Fa
   mem = torch.cat((x, es.unsqueeze(2)), 2).permute(0, 2, 1)  # model.py:319,324
   if taps is not None:
     taps['memory'] = mem
-  if cfg.use_wp_gru:
+  pred_wp_1 = selected_path = None
+  if cfg.use_wp_gru and cfg.multi_wp_output:  # model.py:326-331
+    j = _decoder(sd['wp_query'].repeat(bs, 1, 1), mem, sd, cfg, training)
+    n = cfg.pred_len
+    pred_wp = _gru_decoder(j[:, :n], target_point, sd, 'wp_decoder')
+    pred_wp_1 = _gru_decoder(j[:, n:2 * n], target_point, sd, 'wp_decoder_1')
+    selected_path = _lin(j[:, 2 * n], sd, 'select_wps')
+  elif cfg.use_wp_gru:
     j = _decoder(sd['wp_query'].repeat(bs, 1, 1), mem, sd, cfg, training)
     pred_wp = _gru_decoder(j, target_point, sd, 'wp_decoder')  # model.py:333-334
   if cfg.use_controller_input_prediction:
@@ -640,7 +652,7 @@ def forward(sd, cfg, rgb, lidar_bev, target_point, ego_vel, command, training=Fa
   bb = (torch.sigmoid(_head_branch(bev, sd, 'head.heatmap_head')), _head_branch(bev, sd, 'head.wh_head'),
         _head_branch(bev, sd, 'head.offset_head'), _head_branch(bev, sd, 'head.yaw_class_head'),
         _head_branch(bev, sd, 'head.yaw_res_head'), None, None)  # center_net.py:49-75
-  return pred_wp, pred_ts, pred_cp, pred_sem, pred_bev, pred_depth, bb, None, None, None
+  return pred_wp, pred_ts, pred_cp, pred_sem, pred_bev, pred_depth, bb, None, pred_wp_1, selected_path
 
 
 # ----------------------------------------------------------------------------------------------
@@ -660,7 +672,12 @@ def compute_loss(sd, cfg, outputs, labels):
   """team_code/model.py:394-445 + team_code/center_net.py:77-123 -> dict of 0-d losses (default heads)."""
   pred_wp, pred_ts, pred_cp, pred_sem, pred_bev, pred_depth, bb = outputs[:7]
   loss = {}
-  if cfg.use_wp_gru:
+  if cfg.use_wp_gru and cfg.multi_wp_output:  # model.py:401-411
+    per = torch.stack([torch.mean(torch.abs(w - labels['waypoint_label']), dim=(1, 2)) for w in (pred_wp, outputs[8])], dim=1)
+    best, pick = torch.min(per, dim=1, keepdim=True)
+    loss['loss_wp'] = torch.mean(best)
+    loss['loss_selection'] = F.binary_cross_entropy_with_logits(outputs[9], pick.detach().float())
+  elif cfg.use_wp_gru:
     loss['loss_wp'] = torch.mean(torch.abs(pred_wp - labels['waypoint_label']))
   if cfg.use_controller_input_prediction:
     loss['loss_target_speed'] = F.cross_entropy(pred_ts, labels['target_speed_label'],
@@ -688,6 +705,7 @@ def loss_weights(cfg):
   ``detailed_loss_weights`` (config.py:223-239): unused losses zeroed, the rest divided by their sum."""
   w = {
       'loss_wp': 1.0 if cfg.use_wp_gru else 0.0,
+      'loss_selection': 1.0 if (cfg.use_wp_gru and cfg.multi_wp_output) else 0.0,  # train.py:440-441
       'loss_target_speed': 1.0 if cfg.use_controller_input_prediction else 0.0,
       'loss_checkpoint': 1.0 if cfg.use_controller_input_prediction else 0.0,
       'loss_semantic': 1.0,

@@ -525,6 +525,114 @@ def test_wp_variant_train_step_fp32_vs_reference_golden():
   _check_train_step_vs_golden(2, 'tfpp_wp_train_bs2.npz', 'train_fp32_wp', model=m.cuda(), port_cfg=cfgw)
 
 
+MULTI_WP = dict(use_wp_gru=True, use_controller_input_prediction=False, multi_wp_output=True)
+
+
+def _multi_wp_model(dtype='fp32'):
+  from oracle.make_golden import MULTI_WP_LABEL_SEED
+  cfgm = dataclasses.replace(P.PortConfig(), extra={'label_seed': MULTI_WP_LABEL_SEED}, **MULTI_WP)
+  m = LidarCenterNet(GlobalConfig(tfpp_dtype=dtype, **MULTI_WP))
+  m.load_state_dict(P.make_state_dict(cfgm), strict=True)
+  return m.cuda(), cfgm
+
+
+def test_multi_wp_variant_schema_and_loss_weights():
+  """CPU: the multi_wp_output module has the reference's state_dict (keys, order, shapes: strict load) and loss list (loss_selection right behind
+  loss_wp, both at the same normalised weight, train.py:440-441)."""
+  from carla_garage_amd.losses import active_losses, normalized_loss_weights, output_slots
+  from oracle.make_golden import MULTI_WP_LABEL_SEED
+  cfgm = dataclasses.replace(P.PortConfig(), extra={'label_seed': MULTI_WP_LABEL_SEED}, **MULTI_WP)
+  m = LidarCenterNet(GlobalConfig(**MULTI_WP))
+  g = U.load_golden('tfpp_multi_wp_eval_bs1.npz')
+  assert list(m.state_dict().keys()) == [str(k) for k in g['state_dict_keys']]
+  m.load_state_dict(P.make_state_dict(cfgm), strict=True)
+  assert 0.0 <= float(m.wp_query.min()) and tuple(m.wp_query.shape) == (1, 17, 256)
+  names = active_losses(m.config)
+  assert names[:2] == ['loss_wp', 'loss_selection'] and names == [str(x) for x in U.load_golden('tfpp_multi_wp_train_bs4.npz')['loss_names']]
+  assert [k for k, _ in output_slots(m.config)][:3] == ['loss_wp', 'loss_wp/1', 'loss_selection']
+  w = normalized_loss_weights(m.config)
+  assert w['loss_selection'] == w['loss_wp'] and abs(sum(w.values()) - 1.0) < 1e-12
+  # ... and the default configuration is untouched by the variant's code
+  assert 'loss_selection' not in active_losses(GlobalConfig()) and all(k == l for k, l in output_slots(GlobalConfig()))
+
+
+@pytest.mark.gpu
+def test_multi_wp_variant_forward():
+  """config.multi_wp_output (config.py:484; model.py:151-163,326-331): wp_query (1, 17, 256), two GRU decoders and the select_wps logit -- the
+  reference's state_dict loads strictly and pred_wp / pred_wp_1 / selected_path (tuple slots 0, 8, 9) agree with the unmodified reference."""
+  m, cfgm = _multi_wp_model()
+  g = U.load_golden('tfpp_multi_wp_eval_bs1.npz')
+  assert list(m.state_dict().keys()) == [str(k) for k in g['state_dict_keys']]
+  m.eval()
+  with torch.inference_mode():
+    out = m(*[x.cuda() for x in P.make_inputs(1, cfgm)])
+  assert tuple(out[0].shape) == (1, 8, 2) and tuple(out[8].shape) == (1, 8, 2) and tuple(out[9].shape) == (1, 1)
+  for i, k in ((0, 'pred_wp'), (8, 'pred_wp_1'), (9, 'selected_path')):
+    U.assert_close(U.to_np(out[i]), g[k], U.REL_TOL_FP32, k)
+  U.assert_close(U.to_np(out[6][0]), g['bb_heatmap'], U.REL_TOL_FP32, 'heatmap')
+  assert out[1] is None and out[2] is None and out[7] is None
+
+
+@pytest.mark.gpu
+def test_multi_wp_variant_train_step_fp32_vs_reference_golden():
+  """loss_wp = mean_b min over the two hypotheses, loss_selection = BCE of the logit against the arg-min (model.py:401-411; weight 1.0:
+  train.py:440-441): losses, per-parameter gradient norms / sampled elements and BN statistics of one step at bs = 4 against the unmodified
+  reference -- two samples train hypothesis 0, two hypothesis 1 (tests/golden/tfpp_multi_wp_train_bs4.npz, `python -m oracle.make_golden multi_wp`)."""
+  m, cfgm = _multi_wp_model()
+  g = U.load_golden('tfpp_multi_wp_train_bs4.npz')
+  assert sorted(g['selection_labels'].tolist()) == [0, 0, 1, 1]
+  names = [str(x) for x in g['grad_names']]
+  assert all(k in names for k in ('wp_decoder_1.gru.weight_hh_l0', 'select_wps.weight', 'select_wps.bias', 'wp_query'))
+  _check_train_step_vs_golden(4, 'tfpp_multi_wp_train_bs4.npz', 'train_fp32_multi_wp', model=m, port_cfg=cfgm)
+
+
+@pytest.mark.gpu
+def test_multi_wp_variant_through_the_reference_call_sequence():
+  """forward -> compute_loss(pred_wp, pred_wp_1, selected_path, ...) -> backward as team_code/train.py:776-898 drives it, five times: eager
+  steps, then the captured hipGraphs (loss_wp hands ONE token gradient to both hypotheses), every time the reference's gradients; then the
+  general path (a cloned prediction: gradients in the caller layout through autograd) with the same result."""
+  from carla_garage_amd.losses import normalized_loss_weights
+  m, cfgm = _multi_wp_model()
+  m.train()
+  _zero_dropout(m)
+  g = U.load_golden('tfpp_multi_wp_train_bs4.npz')
+  lab = {k: v.cuda() for k, v in P.make_labels(4, cfgm).items()}
+  inp = [x.cuda() for x in P.make_inputs(4, cfgm)]
+  w = normalized_loss_weights(m.config)
+  assert abs(w['loss_selection'] - w['loss_wp']) < 1e-12 and abs(sum(w.values()) - 1.0) < 1e-9
+
+  def step(tamper=None):
+    m.zero_grad(set_to_none=True)
+    out = list(m(*inp))
+    if tamper is not None:
+      out = tamper(out)
+    losses = m.compute_loss(pred_wp=out[0], pred_target_speed=out[1], pred_checkpoint=out[2], pred_semantic=out[3], pred_bev_semantic=out[4],
+                            pred_depth=out[5], pred_bounding_box=out[6], pred_wp_1=out[8], selected_path=out[9], **lab)
+    assert list(losses.keys()) == [str(x) for x in g['loss_names']]
+    total = sum(w[k] * v for k, v in losses.items())
+    total.backward()
+    np.testing.assert_allclose(np.array([float(v) for v in losses.values()]), g['losses'], rtol=1e-3)
+    np.testing.assert_allclose(float(total), float(g['total_loss']), rtol=1e-3)
+
+  modes = []
+  for i in range(5):
+    step()
+    modes.append(m._dropin().cur['mode'])
+    _param_grads_vs_golden(m, g, f'dropin_multi_wp_{i}')
+  assert modes[0] == 'eager' and modes[-1] == 'graph', modes
+
+  def clone_second(out):  # not the tensor the forward returned: compute_loss cannot use the token path
+    out[8] = out[8] * 1.0
+    return out
+
+  m, _ = _multi_wp_model()  # (a fresh module: the first one replays its captured graphs by now, and those only take token gradients)
+  m.train()
+  _zero_dropout(m)
+  step(clone_second)
+  assert m._dropin().cur['mode'] == 'eager'
+  _param_grads_vs_golden(m, g, 'dropin_multi_wp_general')
+
+
 BF16_LOSS_TOL = 5e-2  # measured worst: loss_yaw_res 3.4e-2 (a loss of ~1e-2 absolute, i.e. 3e-4 absolute error), every other loss <= 5e-3
 # Gradients of the bf16 step against the fp32 HIP step on identical weights and batch (tools/bf16_evidence.py, round 3; 568 tensors carrying
 # >= 1e-3 of the largest norm).  bf16 rounding through 100+ layers with batch-statistic BatchNorm is chaotic on the ill-conditioned tensors
@@ -779,6 +887,27 @@ def test_trainer_state_dict_round_trip_and_reference_layout():
   assert d <= 0.5 * 1e-4, d
 
 
+def _param_grads_vs_golden(m, g, tag):
+  """``p.grad`` of every parameter (what the reference's optimizer reads after loss.backward()) against the reference's gradients: per-tensor
+  norms and the sampled elements, at the bars of _check_train_step_vs_golden."""
+  params = dict(m.named_parameters())
+  worst = worst_el = 0.0
+  over = {}
+  for name, (norm, gmax), samples in zip(g['grad_names'], g['grad_norms'], g['grad_samples']):
+    if gmax < 1e-5:
+      continue
+    mine = params[str(name)].grad.detach().flatten()
+    e = abs(mine.double().norm().item() - norm) / norm
+    worst = max(worst, e)
+    if e > (GRAD_NORM_TOL_SE_FC1 if '.se.fc' in str(name) else GRAD_NORM_TOL):  # (squeeze-excite layers 2e-2)
+      over[str(name)] = e
+    idx = U.sample_idx(mine.numel())
+    got = mine[torch.from_numpy(idx).to(mine.device)].float().cpu().numpy()
+    worst_el = max(worst_el, float(np.max(np.abs(got - samples[:len(idx)]) / (norm / np.sqrt(mine.numel()) + np.abs(samples[:len(idx)])))))
+  _report(tag, {'worst_grad_norm': worst, 'worst_grad_elem': worst_el})
+  assert not over and worst_el <= GRAD_ELEM_TOL, (over, worst_el)
+
+
 @pytest.mark.gpu
 def test_dropin_autograd_path_matches_engine_path():
   """forward -> compute_loss -> loss.backward() exactly as team_code/train.py:776-898 drives the model."""
@@ -796,22 +925,7 @@ def test_dropin_autograd_path_matches_engine_path():
   total.backward()
   g = U.load_golden('tfpp_train_bs2.npz')
   np.testing.assert_allclose(float(total), float(g['total_loss']), rtol=1e-3)
-  params = dict(m.named_parameters())
-  worst = worst_el = 0.0
-  over = {}
-  for name, (norm, gmax), samples in zip(g['grad_names'], g['grad_norms'], g['grad_samples']):
-    if gmax < 1e-5:
-      continue
-    mine = params[str(name)].grad.detach().flatten()
-    e = abs(mine.double().norm().item() - norm) / norm
-    worst = max(worst, e)
-    if e > (GRAD_NORM_TOL_SE_FC1 if '.se.fc' in str(name) else GRAD_NORM_TOL):  # (the bars of _check_train_step_vs_golden: squeeze-excite layers 2e-2)
-      over[str(name)] = e
-    idx = U.sample_idx(mine.numel())
-    got = mine[torch.from_numpy(idx).to(mine.device)].float().cpu().numpy()
-    worst_el = max(worst_el, float(np.max(np.abs(got - samples[:len(idx)]) / (norm / np.sqrt(mine.numel()) + np.abs(samples[:len(idx)])))))
-  _report('dropin', {'worst_grad_norm': worst, 'worst_grad_elem': worst_el})
-  assert not over and worst_el <= GRAD_ELEM_TOL, (over, worst_el)
+  _param_grads_vs_golden(m, g, 'dropin')
   # predictions that are not the last forward's outputs (here: one clone) take compute_loss's general path (converted to the internal
   # layout) and give the same losses (tests/test_dropin_gpu.py covers gradients, accumulation, DDP and the hipGraph replays)
   with torch.no_grad():

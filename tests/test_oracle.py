@@ -59,6 +59,37 @@ def test_port_wp_variant_vs_reference_golden(cfg):
   assert out[1] is None and out[2] is None
 
 
+MULTI_WP = dict(use_wp_gru=True, use_controller_input_prediction=False, multi_wp_output=True)
+
+
+def multi_wp_port_cfg(cfg):
+  from oracle.make_golden import MULTI_WP_LABEL_SEED
+  return dataclasses.replace(cfg, extra={'label_seed': MULTI_WP_LABEL_SEED}, **MULTI_WP)
+
+
+def test_port_multi_wp_variant_vs_reference_golden(cfg):
+  """config.multi_wp_output (model.py:151-163,326-331): both waypoint hypotheses and the path-selection logit of the unmodified reference."""
+  cfgm = multi_wp_port_cfg(cfg)
+  g = U.load_golden('tfpp_multi_wp_eval_bs1.npz')
+  sd = P.make_state_dict(cfgm)
+  assert list(sd.keys()) == [str(k) for k in g['state_dict_keys']]
+  assert tuple(sd['wp_query'].shape) == (1, 17, 256) and tuple(sd['select_wps.weight'].shape) == (1, 256)
+  with torch.inference_mode():
+    out = P.forward(sd, cfgm, *P.make_inputs(1, cfgm))
+  for i, k in ((0, 'pred_wp'), (8, 'pred_wp_1'), (9, 'selected_path')):
+    U.assert_close(U.to_np(out[i]), g[k], 2e-5, k)
+  U.assert_close(U.to_np(out[6][0]), g['bb_heatmap'], 2e-5, 'heatmap')
+
+
+def test_port_multi_wp_train_step_vs_reference_golden(cfg):
+  """loss_wp = mean_b min over the hypotheses, loss_selection = BCE against the arg-min (model.py:401-411), weight 1.0 (train.py:440-441): losses and
+  every gradient of one step at bs = 4 in which two samples train hypothesis 0 and two hypothesis 1."""
+  g = U.load_golden('tfpp_multi_wp_train_bs4.npz')
+  assert sorted(g['selection_labels'].tolist()) == [0, 0, 1, 1]
+  assert [str(x) for x in g['loss_names']][:2] == ['loss_wp', 'loss_selection']
+  _port_train_step_vs_golden(multi_wp_port_cfg(cfg), 4, 'tfpp_multi_wp_train_bs4.npz')
+
+
 def _port_train_step_vs_golden(cfg, bs, fname):
   g = U.load_golden(fname)
   cfg0 = dataclasses.replace(cfg, embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0, decoder_dropout=0.0)
