@@ -17,7 +17,7 @@ import os
 import torch
 
 from . import ops
-from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 F32 = torch.float32
 EPS_F32 = float(torch.finfo(torch.float32).eps)
@@ -699,12 +699,22 @@ class Engine:
     h = dict(head=True)
     self._spec('extra_sensor_encoder.0', m.extra_sensor_encoder[0].weight, m.extra_sensor_encoder[0].bias, cin_store=8, **h)
     self._spec('extra_sensor_encoder.2', m.extra_sensor_encoder[2].weight, m.extra_sensor_encoder[2].bias, **h)
+    self.tp_attention = bool(getattr(m, 'tp_attention', False))
     for l, layer in enumerate(m.join.layers):
       q = f'join.layers.{l}'
-      self._spec(q + '.self_attn.out_proj', layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias, **h)
-      self._spec(q + '.multihead_attn.out_proj', layer.multihead_attn.out_proj.weight, layer.multihead_attn.out_proj.bias, **h)
+      if self.tp_attention:  # transfuser.py:404-443: separate key / query / value / proj linears per attention
+        for an in ('self_attn', 'multihead_attn'):
+          for ln_ in ('query', 'key', 'value', 'proj'):
+            lin = getattr(getattr(layer, an), ln_)
+            self._spec(f'{q}.{an}.{ln_}', lin.weight, lin.bias, **h)
+      else:
+        self._spec(q + '.self_attn.out_proj', layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias, **h)
+        self._spec(q + '.multihead_attn.out_proj', layer.multihead_attn.out_proj.weight, layer.multihead_attn.out_proj.bias, **h)
       self._spec(q + '.linear1', layer.linear1.weight, layer.linear1.bias, **h)
       self._spec(q + '.linear2', layer.linear2.weight, layer.linear2.bias, **h)
+    if self.tp_attention:
+      self._spec('tp_encoder.0', m.tp_encoder[0].weight, m.tp_encoder[0].bias, cin_store=4, **h)
+      self._spec('tp_encoder.2', m.tp_encoder[2].weight, m.tp_encoder[2].bias, **h)
     for dn in ('checkpoint_decoder', 'wp_decoder', 'wp_decoder_1'):
       if hasattr(m, dn):
         d = getattr(m, dn)
@@ -1478,6 +1488,47 @@ class Engine:
       x = self.add_layernorm(x, h, pd, layer.norm3)
     return self.layernorm(x, self.m.join.norm)
 
+  def attention_with_weights(self, x, src, prefix, mod, B, tq, tk, acc=None):
+    """team_code/transfuser.py:404-443 (MultiheadAttentionWithAttention): query / key / value / proj linears, dropout on the probabilities and on the
+    projected output.  ``acc`` [nh, tq, tk]: the probabilities of sample 0 (before dropout) are added to it -- the attention read-out of tp_attention."""
+    dm, nh = x.shape[-1], self.cfg.num_decoder_heads
+    d = dm // nh
+    q = self.linear(x, prefix + '.query')
+    k = self.linear(src, prefix + '.key')
+    v = self.linear(src, prefix + '.value')
+    scale = 1.0 / math.sqrt(d)
+    O, P, Pd, drop = self.attention(q.view(-1), k.view(-1), v.view(-1), B, nh, tq, tk, d, dm, dm, scale, float(mod.attn_drop.p), dm)
+    if acc is not None:
+      probs = P[1] if isinstance(P, tuple) else P  # [B, nh, tq, tk]
+      ops.copy_rows(probs, acc, 1, nh * tq * tk, 0, 0, 0, 0, accumulate=True)
+    if self.tape is not None:
+
+      def bwd_attn(dO):
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        self.attention_bwd(dO, q.view(-1), k.view(-1), v.view(-1), dq.view(-1), dk.view(-1), dv.view(-1), P, Pd, drop, B, nh, tq, tk, d, dm, dm, scale, dm)
+        return dq, dk, dv
+
+      self.rec([O], [q, k, v], bwd_attn)
+    return self.dropout(self.linear(O, prefix + '.proj'), float(mod.resid_drop.p))
+
+  def decoder_with_attention(self, query, mem, B, tq, tk, acc):
+    """team_code/transfuser.py:447-508 (TransformerDecoderWithAttention, the decoder of config.tp_attention): post-norm layers with the exact GELU in
+    the FFN (here the activation module survives the per-layer deep copy) and a final LayerNorm."""
+    pd = self._decoder_dropout()
+    x = query
+    for l, layer in enumerate(self.m.join.layers):
+      q = f'join.layers.{l}'
+      x = self.add_layernorm(x, self.attention_with_weights(x, x, q + '.self_attn', layer.self_attn, B, tq, tq), pd, layer.norm1)
+      x = self.add_layernorm(x, self.attention_with_weights(x, mem, q + '.multihead_attn', layer.multihead_attn, B, tq, tk, acc), pd, layer.norm2)
+      h1 = self.linear(x, q + '.linear1')
+      h = ops.affine_act(h1, act=ACT_GELU)
+      if self.tape is not None:
+        self.rec([h], [h1], lambda dh, h1=h1: ops.act_bwd(dh, h1, ACT_GELU))  # (the exact GELU derivative needs the pre-activation)
+      h = self.dropout(h, pd)
+      h = self.linear(h, q + '.linear2')
+      x = self.add_layernorm(x, h, pd, layer.norm3)
+    return self.layernorm(x, self.m.join.norm)
+
   def gru_decoder(self, feats, target_point, dec, name, B, T):
     """team_code/model.py:857-867."""
     dm = feats.shape[-1]
@@ -1642,19 +1693,28 @@ class Engine:
       es = self.linear(es, 'extra_sensor_encoder.2', act=ACT_RELU)
       es = self.add_table(es, m.extra_sensor_pos_embed.detach().view(-1), m.extra_sensor_pos_embed)
       ntok = hh * ww
-      mem = torch.empty((B, ntok + 1, dm), device=dev, dtype=F32)
-      ops.copy_rows(x, mem, B, ntok * dm, ntok * dm, 0, (ntok + 1) * dm, 0)
-      ops.copy_rows(es, mem, B, dm, dm, 0, (ntok + 1) * dm, ntok * dm)
+      extra = [es]
+      if self.tp_attention:  # model.py:336-339: the encoded target point is one more memory token
+        tp4 = ops.zeros((B, 4), F32, dev)
+        ops.copy_rows(target_point.float().contiguous(), tp4, B, 2, 2, 0, 4, 0)
+        tpt = self.linear(self.linear(tp4, 'tp_encoder.0', act=ACT_RELU, x_grad=False), 'tp_encoder.2')
+        extra.append(self.add_table(tpt, m.tp_pos_embed.detach().view(-1), m.tp_pos_embed))
+      nmem = ntok + len(extra)
+      mem = torch.empty((B, nmem, dm), device=dev, dtype=F32)
+      ops.copy_rows(x, mem, B, ntok * dm, ntok * dm, 0, nmem * dm, 0)
+      for i_, e_ in enumerate(extra):
+        ops.copy_rows(e_, mem, B, dm, dm, 0, nmem * dm, (ntok + i_) * dm)
       if self.tape is not None:
 
         def bwd_mem(d):
           dx_ = torch.empty_like(x)
-          des = torch.empty_like(es)
-          ops.copy_rows(d, dx_, B, ntok * dm, (ntok + 1) * dm, 0, ntok * dm, 0)
-          ops.copy_rows(d, des, B, dm, (ntok + 1) * dm, ntok * dm, dm, 0)
-          return dx_, des
+          ops.copy_rows(d, dx_, B, ntok * dm, nmem * dm, 0, ntok * dm, 0)
+          des = [torch.empty_like(e_) for e_ in extra]
+          for i_, de in enumerate(des):
+            ops.copy_rows(d, de, B, dm, nmem * dm, (ntok + i_) * dm, dm, 0)
+          return (dx_,) + tuple(des)
 
-        self.rec([mem], [x, es], bwd_mem)
+        self.rec([mem], [x] + extra, bwd_mem)
       out['memory'] = mem
 
       def run_queries(qparam, nq):
@@ -1668,7 +1728,11 @@ class Engine:
             return ()
 
           self.rec([q0], [], bwd_q)
-        return self.decoder(q0, mem, B, nq, ntok + 1)
+        if self.tp_attention:
+          out['attn_acc'] = ops.zeros((cfg.num_decoder_heads, nq, nmem), F32, dev)
+          out['attn_layers'] = len(m.join.layers)
+          return self.decoder_with_attention(q0, mem, B, nq, nmem, out['attn_acc'])
+        return self.decoder(q0, mem, B, nq, nmem)
 
       out['pred_wp'] = out['pred_target_speed'] = out['pred_checkpoint'] = None
       if cfg.use_wp_gru and getattr(m, 'multi_wp', False):

@@ -51,8 +51,13 @@ class LidarCenterNet(nn.Module):
       # the reference itself cannot build these heads on the AIM backbone (model.py:71 reads backbone.perspective_upsample_factor,
       # which team_code/aim.py does not define; there is no BEV feature grid): BASELINE config 1 switches them off
       raise ValueError('backbone="aim" needs use_semantic = use_depth = detect_boxes = use_bev_semantic = 0')
-    if not config.transformer_decoder_join or cfg_get(config, 'tp_attention', False):
-      raise ValueError('MI355X path: only transformer_decoder_join=True, tp_attention=False')
+    if not config.transformer_decoder_join:
+      raise ValueError('MI355X path: only transformer_decoder_join=True')
+    self.tp_attention = bool(cfg_get(config, 'tp_attention', False))
+    if self.tp_attention and (config.use_wp_gru or not config.use_controller_input_prediction):
+      # the reference's forward hands the (output, attention) tuple of the attention-returning decoder to wp_decoder (model.py:332-334): it only runs
+      # with the checkpoint / target-speed head
+      raise ValueError('tp_attention needs use_controller_input_prediction=1 and use_wp_gru=0 (as the reference\'s forward does, model.py:326-350)')
     if not (config.use_wp_gru or config.use_controller_input_prediction):
       raise ValueError('MI355X path needs use_wp_gru or use_controller_input_prediction')
     self.speed_histogram = []
@@ -66,6 +71,8 @@ class LidarCenterNet(nn.Module):
       self.valid_bev_pixels = nn.Parameter(vis, requires_grad=False)
       self.valid_bev_pixels_inv = nn.Parameter(1.0 - vis, requires_grad=False)
     d = config.gru_input_size
+    if self.tp_attention:
+      self.tp_pos_embed = nn.Parameter(torch.zeros(1, d))  # model.py:127 (registered before extra_sensor_pos_embed)
     self.extra_sensor_pos_embed = nn.Parameter(torch.zeros(1, d))
     n_wp = config.pred_len // config.wp_dilation
     multi = self.multi_wp = bool(config.use_wp_gru and cfg_get(config, 'multi_wp_output', False))
@@ -93,10 +100,17 @@ class LidarCenterNet(nn.Module):
       self.depth_decoder = M.PerspectiveDecoder(self.backbone.num_image_features, 1, *dec_args)
     if config.use_controller_input_prediction:
       self.target_speed_network = nn.Sequential(nn.Linear(d, d), nn.ReLU(inplace=True), nn.Linear(d, len(config.target_speeds)))
-    layer = nn.TransformerDecoderLayer(d, config.num_decoder_heads, activation=nn.GELU(), batch_first=True)
-    # NOTE: exactly as in the reference (model.py:137-143) the deep copies made by nn.TransformerDecoder lose the GELU
-    # module and run F.relu (nn.TransformerDecoderLayer.__setstate__); the HIP path computes what the reference computes.
-    self.join = nn.TransformerDecoder(layer, num_layers=config.num_transformer_decoder_layers, norm=nn.LayerNorm(d))
+    if self.tp_attention:
+      # model.py:124-134: the target point enters as one more memory token of the reference's own attention-returning decoder (transfuser.py:404-508)
+      self.tp_encoder = nn.Sequential(nn.Linear(2, 128), nn.ReLU(inplace=True), nn.Linear(128, d))
+      if d % config.num_decoder_heads:
+        raise ValueError('gru_input_size must be a multiple of num_decoder_heads')
+      self.join = M.DecoderWithAttention(d, config.num_transformer_decoder_layers, nn.LayerNorm(d))
+    else:
+      layer = nn.TransformerDecoderLayer(d, config.num_decoder_heads, activation=nn.GELU(), batch_first=True)
+      # NOTE: exactly as in the reference (model.py:137-143) the deep copies made by nn.TransformerDecoder lose the GELU
+      # module and run F.relu (nn.TransformerDecoderLayer.__setstate__); the HIP path computes what the reference computes.
+      self.join = nn.TransformerDecoder(layer, num_layers=config.num_transformer_decoder_layers, norm=nn.LayerNorm(d))
     self.change_channel = nn.Conv2d(self.backbone.num_features, d, kernel_size=1)
     if config.use_wp_gru:
       self.wp_decoder = M.GRUWaypointsPredictorInterFuser(d, n_wp, config.gru_hidden_size, tp_size)
@@ -113,6 +127,8 @@ class LidarCenterNet(nn.Module):
     if config.use_controller_input_prediction:
       nn.init.uniform_(self.checkpoint_query)
     nn.init.uniform_(self.extra_sensor_pos_embed)
+    if self.tp_attention:
+      nn.init.uniform_(self.tp_pos_embed)
 
     # host-side controllers (model.py:224-242)
     self.turn_controller = PIDController(config.turn_kp, config.turn_ki, config.turn_kd, config.turn_n)
@@ -273,7 +289,20 @@ class LidarCenterNet(nn.Module):
     if cfg.detect_boxes:
       bb = tuple(next(it) for _ in self.head.BRANCHES)
       bb = bb + (None,) * (7 - len(bb))  # velocity / brake only exist with temporal input (center_net.py:66-75)
-    return pred_wp, pred_ts, pred_cp, pred_sem, pred_bev, pred_depth, bb, None, pred_wp_1, selected_path
+    return pred_wp, pred_ts, pred_cp, pred_sem, pred_bev, pred_depth, bb, self._attention_weights(), pred_wp_1, selected_path
+
+  def _attention_weights(self):
+    """model.py:339-350 (tp_attention): [vision, speed, target point] = the cross-attention of sample 0, averaged over decoder layers, heads and the
+    checkpoint queries, summed over the pixel tokens -- three host floats, as the reference's three .item() calls produce.  In train mode these are
+    the probabilities BEFORE attention dropout (the reference averages the dropped-out ones: its expectation)."""
+    t = self.__dict__.get('_last_internal')
+    if not self.tp_attention or t is None or t.get('attn_acc') is None:
+      return None
+    acc = t['attn_acc'].detach().cpu().numpy()  # [heads, queries, keys] summed over the layers
+    a = acc.mean(axis=0) / float(t['attn_layers'])
+    ga = a[:self.config.predict_checkpoint_len].mean(axis=0)
+    npix = ga.shape[0] - 2
+    return [float(ga[:npix].sum()), float(ga[npix]), float(ga[npix + 1])]
 
   def forward(self, rgb, lidar_bev, target_point, ego_vel, command):
     if not rgb.is_cuda:

@@ -106,6 +106,47 @@ class SelfAttention(nn.Module):
     self.proj = nn.Linear(c, c)
 
 
+class AttentionWithWeights(SelfAttention):
+  """Container of team_code/transfuser.py:404-443 (MultiheadAttentionWithAttention): key / query / value / proj linears; the two dropout modules carry
+  the rates the engine reads (no parameters)."""
+
+  def __init__(self, c, pdrop):
+    super().__init__(c)
+    self.attn_drop = nn.Dropout(pdrop)
+    self.resid_drop = nn.Dropout(pdrop)
+
+
+class DecoderLayerWithAttention(nn.Module):
+  """Container of team_code/transfuser.py:447-477 (TransformerDecoderLayerWithAttention; the decoder of config.tp_attention)."""
+  forward = _no_forward
+
+  def __init__(self, d_model, dim_feedforward=2048, dropout=0.1, layer_norm_eps=1e-5):
+    super().__init__()
+    self.self_attn = AttentionWithWeights(d_model, dropout)
+    self.multihead_attn = AttentionWithWeights(d_model, dropout)
+    self.linear1 = nn.Linear(d_model, dim_feedforward)
+    self.dropout = nn.Dropout(dropout)
+    self.linear2 = nn.Linear(dim_feedforward, d_model)
+    self.norm1 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+    self.norm2 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+    self.norm3 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+    self.dropout1 = nn.Dropout(dropout)
+    self.dropout2 = nn.Dropout(dropout)
+    self.dropout3 = nn.Dropout(dropout)
+    self.activation = nn.GELU()  # a module: it survives the per-layer deep copy (transfuser.py:485), so this decoder really runs the exact GELU
+
+
+class DecoderWithAttention(nn.Module):
+  """Container of team_code/transfuser.py:479-508 (TransformerDecoderWithAttention): layers.{l}, norm."""
+  forward = _no_forward
+
+  def __init__(self, d_model, num_layers, norm):
+    super().__init__()
+    self.layers = nn.ModuleList([DecoderLayerWithAttention(d_model) for _ in range(num_layers)])
+    self.num_layers = num_layers
+    self.norm = norm
+
+
 class Block(nn.Module):
   forward = _no_forward
 

@@ -252,6 +252,40 @@ def write_multi_wp_golden():
   np.savez_compressed(os.path.join(GOLDEN, 'tfpp_multi_wp_train_bs4.npz'), **g)
 
 
+def write_tp_attention_golden():
+  """config.tp_attention = 1 (config.py:483; model.py:124-134,276-277,336-350; transfuser.py:404-508): the encoded target point as one more memory token
+  of the reference's own attention-returning decoder (separate key / query / value / proj linears, exact GELU), attention read-out in tuple slot 7.
+  Eval forward at bs = 1 and one train-mode step at bs = 2 on the unmodified reference; weights: generic_state_dict over the default ones."""
+  import dataclasses
+  model, _ = ref_harness.build_reference_model(tp_attention=True)
+  cfg = dataclasses.replace(P.PortConfig(), tp_attention=True)
+  sd = P.generic_state_dict(model.state_dict(), base=P.make_state_dict(P.PortConfig()))
+  model.load_state_dict(sd, strict=True)
+  keys = list(model.state_dict().keys())
+  model.eval()
+  with torch.inference_mode():
+    out = model(*P.make_inputs(1, cfg))
+  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_tp_attention_eval_bs1.npz'), pred_target_speed=_np(out[1]), pred_checkpoint=_np(out[2]),
+                      attention_weights=np.array(out[7], np.float64), bb_heatmap=_np(out[6][0]), state_dict_keys=np.array(keys))
+  print('tp_attention: attention weights [vision, speed, target point]', out[7])
+  write_train_golden(model, cfg, 2, 'tfpp_tp_attention_train_bs2.npz')
+  # The gradients of the first decoder layer's self-attention (its input is the query parameter, identical for every sample) are ill-conditioned in
+  # fp32: the reference's own fp32 norms sit 4e-3 off a float64 evaluation.  The float64 norms (oracle/tfpp_port.py in double precision, the same
+  # step) go into the fixture so that the fp32 HIP step can be held against the truth where two fp32 evaluations disagree.
+  cfg0 = dataclasses.replace(cfg, embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0, decoder_dropout=0.0)
+  f64 = lambda v: v.double() if v.is_floating_point() else v
+  frozen = lambda k: ('valid_bev' in k or 'running' in k or k.startswith('loss_'))
+  sd64 = {k: (f64(v).clone().requires_grad_(True) if v.is_floating_point() and not frozen(k) else f64(v).clone()) for k, v in sd.items()}
+  out = P.forward(sd64, cfg0, *[f64(x) for x in P.make_inputs(2, cfg0)], training=True)
+  total, _ = P.total_loss(sd64, cfg0, out, {k: f64(v) for k, v in P.make_labels(2, cfg0).items()})
+  total.backward()
+  g = dict(np.load(os.path.join(GOLDEN, 'tfpp_tp_attention_train_bs2.npz'), allow_pickle=False))
+  g['grad_norms_fp64'] = np.array([sd64[str(k)].grad.norm().item() for k in g['grad_names']])
+  worst = max(abs(a - b[0]) / b[0] for a, b in zip(g['grad_norms_fp64'], g['grad_norms']) if b[1] >= 1e-5)
+  print('tp_attention: reference fp32 vs float64 port, worst per-tensor gradient norm difference', worst)
+  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_tp_attention_train_bs2.npz'), **g)
+
+
 def write_freeze_golden():
   """Two-stage training (team_code/train.py:495-508, config.freeze_backbone): backbone, CenterNet head and the semantic / BEV-semantic /
   depth decoders are frozen with requires_grad_(False) exactly as train.py does it, then one train-mode step at bs = 2 -- only the planning
@@ -365,6 +399,9 @@ def main():
     return
   if only == {'multi_wp'}:
     write_multi_wp_golden()
+    return
+  if only == {'tp_attention'}:
+    write_tp_attention_golden()
     return
   if only == {'freeze'}:
     write_freeze_golden()

@@ -81,6 +81,7 @@ class PortConfig:
   num_dir_bins: int = 12
   use_wp_gru: bool = False  # config.py:370
   multi_wp_output: bool = False  # config.py:484: two waypoint hypotheses + a path-selection logit (with use_wp_gru)
+  tp_attention: bool = False  # config.py:483: target point as a memory token of the reference's own attention-returning decoder (state_dict: generic_state_dict)
   use_controller_input_prediction: bool = True  # config.py:203
   target_speed_weights: tuple = (0.866605263873406, 7.4527377240841775, 1.2281629310898465, 0.5269622904065803)
   semantic_weights: tuple = (1.0,) * 7  # config.py:163
@@ -570,6 +571,36 @@ def _decoder(query, memory, sd, cfg, training):
   return _ln(x, sd, 'join.norm')
 
 
+def _attn_with_weights(q_in, kv_in, sd, p, nh, pdrop, training):
+  """team_code/transfuser.py:404-443 (MultiheadAttentionWithAttention): separate key / query / value / proj linears, dropout on the probabilities and
+  on the projected output; returns (y, probabilities averaged over the heads)."""
+  b, t, c = q_in.shape
+  tm = kv_in.shape[1]
+  q = _lin(q_in, sd, p + '.query').view(b, t, nh, c // nh).transpose(1, 2)
+  k = _lin(kv_in, sd, p + '.key').view(b, tm, nh, c // nh).transpose(1, 2)
+  v = _lin(kv_in, sd, p + '.value').view(b, tm, nh, c // nh).transpose(1, 2)
+  att = F.dropout(F.softmax((q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(c // nh)), dim=-1), pdrop, training)
+  y = (att @ v).transpose(1, 2).contiguous().view(b, t, c)
+  return F.dropout(_lin(y, sd, p + '.proj'), pdrop, training), att.mean(dim=1)
+
+
+def _decoder_with_attention(query, memory, sd, cfg, training):
+  """team_code/transfuser.py:447-508 (TransformerDecoderLayerWithAttention x num_layers + final norm), the decoder of config.tp_attention: post-norm
+  layers, an exact GELU in the FFN (the activation module survives the deep copy here, unlike nn.TransformerDecoderLayer's), returns
+  (output, cross-attention probabilities averaged over heads and layers)."""
+  x, pd, atts = query, cfg.decoder_dropout, []
+  for l in range(cfg.num_transformer_decoder_layers):
+    p = f'join.layers.{l}'
+    a, _ = _attn_with_weights(x, x, sd, p + '.self_attn', cfg.num_decoder_heads, pd, training)
+    x = _ln(x + F.dropout(a, pd, training), sd, p + '.norm1')
+    a, att = _attn_with_weights(x, memory, sd, p + '.multihead_attn', cfg.num_decoder_heads, pd, training)
+    atts.append(att)
+    x = _ln(x + F.dropout(a, pd, training), sd, p + '.norm2')
+    h = _lin(F.dropout(F.gelu(_lin(x, sd, p + '.linear1')), pd, training), sd, p + '.linear2')
+    x = _ln(x + F.dropout(h, pd, training), sd, p + '.norm3')
+  return _ln(x, sd, 'join.norm'), torch.stack(atts).mean(dim=0)
+
+
 def _gru_decoder(x, target_point, sd, p):
   """team_code/model.py:857-867 (GRUWaypointsPredictorInterFuser.forward); torch.nn.GRU gate equations."""
   h = _lin(target_point, sd, p + '.encoder')
@@ -635,8 +666,16 @@ def forward(sd, cfg, rgb, lidar_bev, target_point, ego_vel, command, training=Fa
   elif cfg.use_wp_gru:
     j = _decoder(sd['wp_query'].repeat(bs, 1, 1), mem, sd, cfg, training)
     pred_wp = _gru_decoder(j, target_point, sd, 'wp_decoder')  # model.py:333-334
-  if cfg.use_controller_input_prediction:
+  attention_weights = None
+  if cfg.use_controller_input_prediction and cfg.tp_attention:  # model.py:336-350
+    tp_token = _lin(F.relu(_lin(target_point, sd, 'tp_encoder.0')), sd, 'tp_encoder.2') + sd['tp_pos_embed']
+    npix = mem.shape[1] - 1
+    j, att = _decoder_with_attention(sd['checkpoint_query'].repeat(bs, 1, 1), torch.cat((mem, tp_token.unsqueeze(1)), 1), sd, cfg, training)
+    ga = att[:, :cfg.predict_checkpoint_len].mean(dim=1)[0]
+    attention_weights = [ga[:npix].sum().item(), ga[npix].item(), ga[npix + 1].item()]
+  elif cfg.use_controller_input_prediction:
     j = _decoder(sd['checkpoint_query'].repeat(bs, 1, 1), mem, sd, cfg, training)  # model.py:352
+  if cfg.use_controller_input_prediction:
     if taps is not None:
       taps['joined'] = j
     n = cfg.predict_checkpoint_len
@@ -652,7 +691,7 @@ def forward(sd, cfg, rgb, lidar_bev, target_point, ego_vel, command, training=Fa
   bb = (torch.sigmoid(_head_branch(bev, sd, 'head.heatmap_head')), _head_branch(bev, sd, 'head.wh_head'),
         _head_branch(bev, sd, 'head.offset_head'), _head_branch(bev, sd, 'head.yaw_class_head'),
         _head_branch(bev, sd, 'head.yaw_res_head'), None, None)  # center_net.py:49-75
-  return pred_wp, pred_ts, pred_cp, pred_sem, pred_bev, pred_depth, bb, None, pred_wp_1, selected_path
+  return pred_wp, pred_ts, pred_cp, pred_sem, pred_bev, pred_depth, bb, attention_weights, pred_wp_1, selected_path
 
 
 # ----------------------------------------------------------------------------------------------

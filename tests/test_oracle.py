@@ -90,10 +90,38 @@ def test_port_multi_wp_train_step_vs_reference_golden(cfg):
   _port_train_step_vs_golden(multi_wp_port_cfg(cfg), 4, 'tfpp_multi_wp_train_bs4.npz')
 
 
-def _port_train_step_vs_golden(cfg, bs, fname):
+def tp_attention_state_dict():
+  """The weights the tp_attention fixtures were written with (oracle/make_golden.py tp_attention): generic_state_dict over the schema of the variant --
+  taken from this package's parameter containers here, from the reference's module there; test_port_tp_attention_* checks they name the same tensors."""
+  from carla_garage_amd.config import GlobalConfig
+  from carla_garage_amd.model import LidarCenterNet
+  return P.generic_state_dict(LidarCenterNet(GlobalConfig(tp_attention=True)).state_dict(), base=P.make_state_dict(P.PortConfig()))
+
+
+def test_port_tp_attention_variant_vs_reference_golden(cfg):
+  """config.tp_attention (model.py:124-134,336-350; transfuser.py:404-508): the attention-returning decoder with the target-point token -- predictions and
+  the [vision, speed, target point] attention read-out of the unmodified reference."""
+  cfgt = dataclasses.replace(cfg, tp_attention=True)
+  g = U.load_golden('tfpp_tp_attention_eval_bs1.npz')
+  sd = tp_attention_state_dict()
+  assert list(sd.keys()) == [str(k) for k in g['state_dict_keys']]
+  with torch.inference_mode():
+    out = P.forward(sd, cfgt, *P.make_inputs(1, cfgt))
+  U.assert_close(U.to_np(out[1]), g['pred_target_speed'], 2e-5, 'pred_target_speed')
+  U.assert_close(U.to_np(out[2]), g['pred_checkpoint'], 2e-5, 'pred_checkpoint')
+  U.assert_close(U.to_np(out[6][0]), g['bb_heatmap'], 2e-5, 'heatmap')
+  np.testing.assert_allclose(np.array(out[7]), g['attention_weights'], rtol=1e-4)
+  assert abs(sum(out[7]) - 1.0) < 1e-5  # a probability distribution over {pixels, speed token, target-point token}
+
+
+def test_port_tp_attention_train_step_vs_reference_golden(cfg):
+  _port_train_step_vs_golden(dataclasses.replace(cfg, tp_attention=True), 2, 'tfpp_tp_attention_train_bs2.npz', sd=tp_attention_state_dict())
+
+
+def _port_train_step_vs_golden(cfg, bs, fname, sd=None):
   g = U.load_golden(fname)
   cfg0 = dataclasses.replace(cfg, embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0, decoder_dropout=0.0)
-  sd = P.make_state_dict(cfg0)
+  sd = sd if sd is not None else P.make_state_dict(cfg0)
   frozen = lambda k: ('valid_bev' in k or 'running' in k or k.startswith('loss_'))
   sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not frozen(k) else v.clone())
         for k, v in sd.items()}
