@@ -19,6 +19,9 @@ from .config import cfg_get
 from .engine import Engine, F32
 
 DTYPES = {'fp32': torch.float32, 'bf16': torch.bfloat16}
+# eval-mode forwards of one input signature that run eagerly before the forward is captured into a hipGraph and replayed (< 0: never).  The 20 Hz tick of
+# sensor_agent.py:456-461 calls forward() with the same shapes every time: ~740 launches at bs = 1 cost 10 ms issued one by one and 3.8 ms as one replay.
+EVAL_GRAPH_AFTER = int(os.environ.get('TFPP_EVAL_GRAPH_AFTER', '2'))
 
 
 class PIDController:
@@ -313,14 +316,55 @@ class LidarCenterNet(nn.Module):
     if need_grad:  # the training step of team_code/train.py:776-910 (dropin.py): flat arenas, token gradients, hipGraph replay
       outs = self._dropin().forward([rgb, lidar_bev, target_point, ego_vel, command])
     else:
-      eng.prepare(self.compute_dtype, self.training, False)
-      eng.tape = None
-      internal = eng.forward(rgb, lidar_bev, target_point, ego_vel, command)
+      internal, outs = self._plain_forward([rgb, lidar_bev, target_point, ego_vel, command])
       self.__dict__['_last_internal'] = internal
-      outs, _ = self._export(internal)
     # compute_loss() evaluates the losses on the internal tensors of THIS call: remember which caller-facing tensors belong to it
     self.__dict__['_last_output_ptrs'] = {o.data_ptr() for o in outs}
     return self._assemble(list(outs))
+
+  def _plain_forward(self, inputs):
+    """The forward without a backward to follow (model.eval() under no_grad / inference_mode: sensor_agent.py:456-461, train.py:923-956 validate()).
+    Eval-mode calls of one input signature are captured into a hipGraph after EVAL_GRAPH_AFTER eager ones and replayed from then on; the caller gets
+    copies of the graph's output buffers (so results it keeps are not overwritten by the next call).  The weight images the graph reads are repacked
+    from the parameters only when those change: the check (tensor versions and addresses of every parameter and buffer, ~3 ms of host time) runs while
+    the GPU executes the replay, and a replay that turns out to have read stale images is discarded and redone eagerly."""
+    eng = self._engine()
+    dt_ = self.compute_dtype
+    after = self.__dict__.get('eval_graph_after', EVAL_GRAPH_AFTER)
+    graphable = (after >= 0 and not self.training and all(x.is_cuda for x in inputs) and not torch.cuda.is_current_stream_capturing())
+    plans = self.__dict__.setdefault('_eval_plans', {})
+    sig = (dt_,) + tuple((tuple(x.shape), x.dtype, str(x.device)) for x in inputs)
+    plan = plans.get(sig) if graphable else None
+    if plan is not None and plan.get('graph') is not None:
+      for dst, src in zip(plan['static_in'], inputs):
+        dst.copy_(src, non_blocking=True)
+      plan['graph'].replay()
+      eng.dtype, eng.training = dt_, False
+      if eng._weights_key(dt_, False) == plan['key']:  # (host work beside the replay)
+        return plan['internal'], [o.clone() for o in plan['outs']]
+      del plans[sig]  # parameters / BatchNorm statistics were written (or moved) since the capture
+      plan = None
+    eng.prepare(dt_, self.training, False)
+    eng.tape = None
+    if graphable:
+      plan = plans.setdefault(sig, dict(count=0, graph=None))
+      plan['count'] += 1
+      if plan['count'] > after and plan['count'] > 1:  # (at least one eager call of the signature: scratch buffers and constants exist)
+        from .graph import capture, capture_stream
+        plan['static_in'] = [x.detach().clone() for x in inputs]
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        st = capture_stream(eng.device)
+        with torch.no_grad(), capture(graph, st):
+          plan['internal'] = eng.forward(*plan['static_in'])
+          plan['outs'], _ = self._export(plan['internal'])
+        plan['key'] = eng._packed_key
+        plan['graph'] = graph
+        graph.replay()
+        return plan['internal'], [o.clone() for o in plan['outs']]
+    internal = eng.forward(*inputs)
+    outs, _ = self._export(internal)
+    return internal, outs
 
   # ------------------------------------------------------------------------------------------------ losses
   def compute_loss(self, pred_wp, pred_target_speed, pred_checkpoint, pred_semantic, pred_bev_semantic, pred_depth,

@@ -936,6 +936,69 @@ def test_eval_after_training_steps_uses_current_weights_and_running_statistics()
 
 
 @pytest.mark.gpu
+def test_eval_forward_calls_are_captured_and_replayed_without_changing_results():
+  """model.forward() as sensor_agent.py:456-461 calls it every tick (eval, inference_mode, the same shapes): the third call of a signature is captured
+  into a hipGraph and later calls replay it (model.py _plain_forward).  Replayed results are bit-identical to the eager ones; the caller owns what it
+  gets (a later call does not overwrite it); other inputs give other (correct) results; weights written in place, a loaded state_dict or training steps
+  in between are picked up (the replay that read stale weight images is discarded); eval_graph_after = -1 keeps every call eager."""
+  from carla_garage_amd.trainer import Trainer
+  m = _model('fp32').eval()
+  a = [x.cuda() for x in P.make_inputs(1)]
+  b = [x.cuda() for x in P.make_inputs(1, seed=7)]
+  pick = lambda o: [o[1], o[2], o[3], o[5], o[6][0], o[6][3]]
+  with torch.inference_mode():
+    first = pick(m(*a))
+    assert m._eval_plans and all(pl['graph'] is None for pl in m._eval_plans.values())
+    m(*a)
+    third = pick(m(*a))  # captured here
+    plan, = m._eval_plans.values()
+    assert plan['graph'] is not None
+    fourth = pick(m(*a))
+    for x, y, z in zip(first, third, fourth):
+      assert torch.equal(x, y) and torch.equal(x, z)
+    other = pick(m(*b))  # the same signature, other values: a replay
+    again = pick(m(*a))
+    for x, y, z, w in zip(first, fourth, other, again):
+      assert torch.equal(x, y)  # what the caller got from the fourth call survived the two calls after it
+      assert torch.equal(x, w) and not torch.equal(x, z)
+    m.eval_graph_after = -1
+    want_other = pick(m(*b))  # eager
+    del m.eval_graph_after
+    for z, w in zip(other, want_other):
+      assert torch.equal(z, w)
+    U.compare_packed(U.pack_outputs(m(*a)), U.load_golden('tfpp_eval_bs1.npz'))  # a replay against the reference's golden forward
+  # weights written in place (outside inference_mode, where in-place writes do not advance tensor._version -- the eager path's repack check relies
+  # on it just the same)
+  with torch.no_grad():
+    m.target_speed_network[2].bias.add_(0.5)
+  with torch.inference_mode():
+    moved = pick(m(*a))
+    assert next(iter(m._eval_plans.values()))['graph'] is None  # the plan was dropped, this call ran eagerly on repacked weights
+    torch.testing.assert_close(moved[0], first[0] + 0.5, rtol=0, atol=1e-5)
+    assert torch.equal(moved[4], first[4])
+    for _ in range(3):
+      m(*a)
+    assert next(iter(m._eval_plans.values()))['graph'] is not None
+  # training steps in between (the fused optimizer writes the arena through raw pointers; BatchNorm statistics move)
+  batch = {k: v.cuda() for k, v in P.make_labels(2).items()}
+  for k, v in zip(('rgb', 'lidar_bev', 'target_point', 'ego_vel', 'command'), P.make_inputs(2)):
+    batch[k] = v.cuda()
+  tr = Trainer(m, lr=1e-3)
+  for _ in range(2):
+    tr.train_step(batch)
+  m.eval()
+  with torch.inference_mode():
+    after = pick(m(*a))
+  fresh = LidarCenterNet(GlobalConfig(tfpp_dtype='fp32'))
+  fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, strict=True)
+  fresh.cuda().eval()
+  with torch.inference_mode():
+    want = pick(fresh(*a))
+  for x, w, old in zip(after, want, moved):
+    assert U.rel_err(U.to_np(x), U.to_np(w)) <= 1e-5 and U.rel_err(U.to_np(x), U.to_np(old)) > 1e-5
+
+
+@pytest.mark.gpu
 def test_trainer_state_dict_round_trip_and_reference_layout():
   """Trainer.state_dict() has the layout of the reference's optimizer_%04d.pth (torch.optim.AdamW(model.parameters(), amsgrad=True),
   team_code/train.py:529-534,967-976): torch's own AdamW loads it; save -> fresh trainer -> load -> the next step is identical."""

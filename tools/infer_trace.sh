@@ -4,7 +4,7 @@ set -e
 REPO=$(pwd); DT=${1:-bf16}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/inf
-rocprofv3 --kernel-trace --output-format csv -d /tmp/inf -- python $REPO/tools/infer_trace.py $DT 4 > $REPO/gpurun_out/infer_trace_$DT.log 2>&1
+TFPP_EVAL_GRAPH_AFTER=-1 rocprofv3 --kernel-trace --output-format csv -d /tmp/inf -- python $REPO/tools/infer_trace.py $DT 4 > $REPO/gpurun_out/infer_trace_$DT.log 2>&1
 t=$(find /tmp/inf -name "*kernel_trace.csv" | head -1)
 python - "$t" "$REPO/gpurun_out/infer_kernels_$DT.txt" <<'PY'
 import csv, sys, collections
