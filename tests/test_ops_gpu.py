@@ -1280,6 +1280,52 @@ def test_zero_and_fill_bytes_are_kernels_with_exact_extent(ops):
   assert float(big.sum()) == 7.0 and float(big[:3].sum()) == 3.0
 
 
+@pytest.mark.parametrize('B,n', [(1, 8), (4, 8), (12, 8), (37, 5), (1024, 3)])
+def test_min_l1_pair_loss_and_bce_logits_vs_torch(ops, B, n):
+  """tfpp_min_l1_pair_loss + tfpp_bce_logits_loss (config.multi_wp_output, model.py:401-411) against the reference's torch formulation with autograd:
+  mean_b min over the two hypotheses incl. the arg-min labels (an exact tie picks hypothesis 0, as torch.min does), BCE-with-logits over logits from
+  -40 to 40 (no overflow), weights folded into the gradients, losses ACCUMULATED into their slots, padding channels of the logit tensor zeroed."""
+  g = torch.Generator().manual_seed(B * 131 + n)
+  pair = (torch.randn(B, 2, n, 2, generator=g) * 3).requires_grad_(True)
+  label = torch.randn(B, n, 2, generator=g) * 3
+  with torch.no_grad():
+    pair[0, 1] = pair[0, 0]  # an exact tie
+    if B > 2:
+      pair[2, 1] = label[2] + 0.01  # hypothesis 1 clearly better
+      pair[1, 0, 0, 0] = label[1, 0, 0]  # |0|: zero sub-gradient
+  logit = torch.linspace(-40.0, 40.0, B).view(B, 1).clone().requires_grad_(True)
+  per = torch.stack([torch.mean(torch.abs(pair[:, h] - label), dim=(1, 2)) for h in range(2)], dim=1)
+  best, pick = torch.min(per, dim=1, keepdim=True)
+  l_wp = best.mean()
+  l_sel = F.binary_cross_entropy_with_logits(logit, pick.detach().float())
+  w_wp, w_sel = 0.37, 1.9
+  (w_wp * l_wp + w_sel * l_sel).backward()
+  dp = pair.detach().to(DEV).contiguous()
+  slots = torch.tensor([0.25, -1.0], device=DEV)  # the kernels add to what is there
+  dpair = torch.full_like(dp, float('nan'))
+  sel = torch.full((B,), float('nan'), device=DEV)
+  ops.min_l1_pair_loss(dp, label.to(DEV).contiguous(), slots[0:1], sel, weight=w_wp, dpair=dpair)
+  lg = torch.zeros(B, 8, device=DEV)
+  lg[:, 0] = logit.detach().to(DEV)[:, 0]
+  lg[:, 1:] = 123.0  # padding channels must not matter
+  dlg = torch.full_like(lg, float('nan'))
+  ops.bce_logits_loss(lg, sel, slots[1:2], weight=w_sel, dlogit=dlg)
+  torch.cuda.synchronize()
+  assert torch.equal(sel.cpu(), pick.view(-1).float()) and sel[0].item() == 0.0
+  close = lambda got, want: torch.testing.assert_close(got.cpu(), want.detach().view(1), rtol=2e-4, atol=2e-6)  # (the BCE of one logit at -40 is 4e-18)
+  close(slots[0:1] - 0.25, l_wp)
+  close(slots[1:2] + 1.0, l_sel)
+  check('min_l1_pair.dpair', dpair, pair.grad, torch.float32)
+  check('bce_logits.dlogit', dlg[:, :1], logit.grad, torch.float32)
+  assert torch.count_nonzero(dlg[:, 1:]).item() == 0
+  # without gradients (validate() under inference_mode)
+  slots2 = torch.zeros(2, device=DEV)
+  ops.min_l1_pair_loss(dp, label.to(DEV).contiguous(), slots2[0:1], sel)
+  ops.bce_logits_loss(lg, sel, slots2[1:2])
+  close(slots2[0:1], l_wp)
+  close(slots2[1:2], l_sel)
+
+
 @pytest.mark.parametrize('gamma', [0.0, 1.0, 2.0, 3.5])
 def test_focal_loss_vs_torch(ops, gamma):
   """tfpp_ce_loss(focal_gamma >= 0) against the formula of team_code/focal_loss.py:75-103 written with torch ops: mean over all rows of
