@@ -22,6 +22,7 @@ DTYPES = {'fp32': torch.float32, 'bf16': torch.bfloat16}
 # eval-mode forwards of one input signature that run eagerly before the forward is captured into a hipGraph and replayed (< 0: never).  The 20 Hz tick of
 # sensor_agent.py:456-461 calls forward() with the same shapes every time: ~740 launches at bs = 1 cost 10 ms issued one by one and 3.8 ms as one replay.
 EVAL_GRAPH_AFTER = int(os.environ.get('TFPP_EVAL_GRAPH_AFTER', '2'))
+EVAL_GRAPH_MAX_PLANS = 4  # captured signatures kept per module (each owns the activations of one forward); the least recently used one goes first
 
 
 class PIDController:
@@ -335,6 +336,8 @@ class LidarCenterNet(nn.Module):
     plans = self.__dict__.setdefault('_eval_plans', {})
     sig = (dt_,) + tuple((tuple(x.shape), x.dtype, str(x.device)) for x in inputs)
     plan = plans.get(sig) if graphable else None
+    if plan is not None:
+      plans[sig] = plans.pop(sig)  # (dicts keep insertion order: the most recently used signature last)
     if plan is not None and plan.get('graph') is not None:
       for dst, src in zip(plan['static_in'], inputs):
         dst.copy_(src, non_blocking=True)
@@ -360,6 +363,9 @@ class LidarCenterNet(nn.Module):
           plan['outs'], _ = self._export(plan['internal'])
         plan['key'] = eng._packed_key
         plan['graph'] = graph
+        captured = [k for k, pl in plans.items() if pl.get('graph') is not None]
+        for k in captured[:max(0, len(captured) - EVAL_GRAPH_MAX_PLANS)]:
+          del plans[k]
         graph.replay()
         return plan['internal'], [o.clone() for o in plan['outs']]
     internal = eng.forward(*inputs)

@@ -999,6 +999,26 @@ def test_eval_forward_calls_are_captured_and_replayed_without_changing_results()
 
 
 @pytest.mark.gpu
+def test_captured_eval_signatures_are_bounded(monkeypatch):
+  """Every captured signature owns the activations of one forward: the module keeps the EVAL_GRAPH_MAX_PLANS most recently used ones."""
+  import carla_garage_amd.model as MM
+  monkeypatch.setattr(MM, 'EVAL_GRAPH_MAX_PLANS', 2)
+  m = _model('bf16').eval()
+  ref = {}
+  with torch.inference_mode():
+    for bs in (1, 2, 3):
+      inp = [x.cuda() for x in P.make_inputs(bs)]
+      ref[bs] = m(*inp)[2].clone()
+      for _ in range(3):
+        got = m(*inp)[2]
+      assert torch.equal(got, ref[bs])
+    captured = [k[1][0][0] for k, pl in m._eval_plans.items() if pl.get('graph') is not None]  # batch size of the rgb input of the signature
+    assert captured == [2, 3], captured
+    inp = [x.cuda() for x in P.make_inputs(1)]  # the evicted signature runs eagerly again and is re-captured later
+    assert torch.equal(m(*inp)[2], ref[1])
+
+
+@pytest.mark.gpu
 def test_trainer_state_dict_round_trip_and_reference_layout():
   """Trainer.state_dict() has the layout of the reference's optimizer_%04d.pth (torch.optim.AdamW(model.parameters(), amsgrad=True),
   team_code/train.py:529-534,967-976): torch's own AdamW loads it; save -> fresh trainer -> load -> the next step is identical."""
