@@ -354,13 +354,16 @@ class LidarCenterNet(nn.Module):
       plan['count'] += 1
       if plan['count'] > after and plan['count'] > 1:  # (at least one eager call of the signature: scratch buffers and constants exist)
         from .graph import capture, capture_stream
-        plan['static_in'] = [x.detach().clone() for x in inputs]
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        st = capture_stream(eng.device)
-        with torch.no_grad(), capture(graph, st):
-          plan['internal'] = eng.forward(*plan['static_in'])
-          plan['outs'], _ = self._export(plan['internal'])
+        # (inference_mode(False): the graph's input buffers must be ordinary tensors -- later calls may come under no_grad instead of
+        # inference_mode, where copying into an inference tensor is an error)
+        with torch.inference_mode(False), torch.no_grad():
+          plan['static_in'] = [torch.empty_like(x).copy_(x) for x in inputs]
+          torch.cuda.synchronize()
+          graph = torch.cuda.CUDAGraph()
+          st = capture_stream(eng.device)
+          with capture(graph, st):
+            plan['internal'] = eng.forward(*plan['static_in'])
+            plan['outs'], _ = self._export(plan['internal'])
         plan['key'] = eng._packed_key
         plan['graph'] = graph
         captured = [k for k, pl in plans.items() if pl.get('graph') is not None]

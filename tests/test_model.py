@@ -957,7 +957,9 @@ def test_eval_forward_calls_are_captured_and_replayed_without_changing_results()
     for x, y, z in zip(first, third, fourth):
       assert torch.equal(x, y) and torch.equal(x, z)
     other = pick(m(*b))  # the same signature, other values: a replay
+  with torch.no_grad():  # (captured under inference_mode, replayed under no_grad: the graph's input buffers are ordinary tensors)
     again = pick(m(*a))
+  with torch.inference_mode():
     for x, y, z, w in zip(first, fourth, other, again):
       assert torch.equal(x, y)  # what the caller got from the fourth call survived the two calls after it
       assert torch.equal(x, w) and not torch.equal(x, z)
