@@ -18,6 +18,11 @@ Files written
   tfpp_aim.npz             BASELINE config 1: image-only AIM backbone, eval forward bs=1 + train step bs=2 (`... make_golden aim`)
   tfpp_wp_eval_bs1.npz     WP variant (use_wp_gru=1, use_controller_input_prediction=0): pred_wp
   tfpp_wp_train_bs2.npz    the same variant, one train-mode step at bs = 2 (`python -m oracle.make_golden wp_train`): loss_wp + gradients
+  tfpp_multi_wp_eval_bs1.npz / tfpp_multi_wp_train_bs4.npz      multi_wp_output = 1 (`... make_golden multi_wp`): pred_wp, pred_wp_1, selected_path; one
+                           train step in which two samples train hypothesis 0 and two hypothesis 1
+  tfpp_tp_attention_eval_bs1.npz / tfpp_tp_attention_train_bs2.npz   tp_attention = 1 (`... make_golden tp_attention`): predictions, the attention read-out,
+                           one train step + float64 gradient norms of the same step (CPU port in double precision)
+  (the other variants -- swin, swin_train, bev, temporal, freeze, focal, validate -- are documented at their write_* functions)
 """
 import json
 import os
