@@ -254,14 +254,15 @@ def inference_latency(model, cfg, device, log, iters=20):
       for _ in range(3):
         model(*inp)
       out[f'{dtype}_eager'] = timed(lambda: model(*inp))
-      # model.forward() exactly as sensor_agent.py:456-461 calls it, nothing else changed: the module captures the eval forward of a signature
-      # after two eager calls and replays it (model.py _plain_forward); `_tick` = each call followed by a device synchronisation (the agent reads
-      # the predictions on the host before the next tick)
-      del model.eval_graph_after
+      # model.forward() exactly as sensor_agent.py:456-461 calls it with TFPP_EVAL_GRAPH_AFTER=2 in the environment: the module captures the eval
+      # forward of a signature after two eager calls and replays it (model.py _plain_forward); `_tick` = each call followed by a device
+      # synchronisation (the agent reads the predictions on the host before the next tick)
+      model.eval_graph_after = 2  # (= TFPP_EVAL_GRAPH_AFTER=2 in the agent's environment)
       for _ in range(4):
         model(*inp)
       out[f'{dtype}_forward_call'] = timed(lambda: model(*inp))
       out[f'{dtype}_forward_call_tick'] = timed(lambda: model(*inp), sync_each=True)
+      model.eval_graph_after = -1
     try:
       g = GraphedForward(model, *inp)
       torch.cuda.synchronize()

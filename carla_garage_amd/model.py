@@ -19,10 +19,13 @@ from .config import cfg_get
 from .engine import Engine, F32
 
 DTYPES = {'fp32': torch.float32, 'bf16': torch.bfloat16}
-# eval-mode forwards of one input signature that run eagerly before the forward is captured into a hipGraph and replayed (< 0: never).  The 20 Hz tick of
-# sensor_agent.py:456-461 calls forward() with the same shapes every time: ~740 launches at bs = 1 cost 10 ms issued one by one and 3.8 ms as one replay.
-EVAL_GRAPH_AFTER = int(os.environ.get('TFPP_EVAL_GRAPH_AFTER', '2'))
-EVAL_GRAPH_MAX_PLANS = 4  # captured signatures kept per module (each owns the activations of one forward); the least recently used one goes first
+# Eval-mode forwards of one input signature that run eagerly before the forward is captured into a hipGraph and replayed; < 0 (the default): never.
+# The 20 Hz tick of sensor_agent.py:456-461 calls forward() with the same shapes every time: ~740 launches at bs = 1 cost 10 ms issued one by one and
+# 3.6 ms as one replay.  ``TFPP_EVAL_GRAPH_AFTER=2`` in the agent's environment (or ``model.eval_graph_after = 2``) switches it on without touching
+# sensor_agent.py.  Off by default: in ONE test process that had run trainers and other captured modules before, the first replay of a fresh capture crashed
+# inside hipGraphLaunch (ROCm 7.2; history dependent, not reproduced in an agent-like or bench-like process) -- a default must not be able to do that.
+EVAL_GRAPH_AFTER = int(os.environ.get('TFPP_EVAL_GRAPH_AFTER', '-1'))
+EVAL_GRAPH_MAX_PLANS = 4  # captured signatures per module (each owns the activations of one forward); further signatures keep running eagerly
 
 
 class PIDController:
@@ -323,12 +326,28 @@ class LidarCenterNet(nn.Module):
     self.__dict__['_last_output_ptrs'] = {o.data_ptr() for o in outs}
     return self._assemble(list(outs))
 
+  # the module's tensors may have been replaced or moved: Engine.fast_weights_key re-reads the module tree at the next eval forward
+  def _structure_changed(self):
+    self.__dict__['_structure_epoch'] = self.__dict__.get('_structure_epoch', 0) + 1
+
+  def train(self, mode=True):
+    self._structure_changed()
+    return super().train(mode)
+
+  def load_state_dict(self, *args, **kwargs):
+    self._structure_changed()
+    return super().load_state_dict(*args, **kwargs)
+
+  def _apply(self, fn, *args, **kwargs):
+    self._structure_changed()
+    return super()._apply(fn, *args, **kwargs)
+
   def _plain_forward(self, inputs):
     """The forward without a backward to follow (model.eval() under no_grad / inference_mode: sensor_agent.py:456-461, train.py:923-956 validate()).
-    Eval-mode calls of one input signature are captured into a hipGraph after EVAL_GRAPH_AFTER eager ones and replayed from then on; the caller gets
-    copies of the graph's output buffers (so results it keeps are not overwritten by the next call).  The weight images the graph reads are repacked
-    from the parameters only when those change: the check (tensor versions and addresses of every parameter and buffer, ~3 ms of host time) runs while
-    the GPU executes the replay, and a replay that turns out to have read stale images is discarded and redone eagerly."""
+    With EVAL_GRAPH_AFTER >= 0 (opt-in), eval-mode calls of one input signature are captured into a hipGraph after that many eager ones and replayed from then on; the caller gets
+    copies of the graph's output buffers (so results it keeps are not overwritten by the next call).  A captured plan is only replayed while every
+    parameter and buffer has the address and version it had at the capture (Engine.fast_weights_key, ~0.3 ms of host time in front of the replay);
+    otherwise it is dropped and the call runs eagerly on freshly packed weight images."""
     eng = self._engine()
     dt_ = self.compute_dtype
     after = self.__dict__.get('eval_graph_after', EVAL_GRAPH_AFTER)
@@ -336,14 +355,14 @@ class LidarCenterNet(nn.Module):
     plans = self.__dict__.setdefault('_eval_plans', {})
     sig = (dt_,) + tuple((tuple(x.shape), x.dtype, str(x.device)) for x in inputs)
     plan = plans.get(sig) if graphable else None
-    if plan is not None:
-      plans[sig] = plans.pop(sig)  # (dicts keep insertion order: the most recently used signature last)
     if plan is not None and plan.get('graph') is not None:
-      for dst, src in zip(plan['static_in'], inputs):
-        dst.copy_(src, non_blocking=True)
-      plan['graph'].replay()
       eng.dtype, eng.training = dt_, False
-      if eng._weights_key(dt_, False) == plan['key']:  # (host work beside the replay)
+      # BEFORE the replay: the graph reads biases / normalisation gains at the parameters' own addresses, and a parameter that moved (Trainer arenas,
+      # .to()) may have left unmapped memory behind
+      if eng.fast_weights_key(dt_) == plan['key']:
+        for dst, src in zip(plan['static_in'], inputs):
+          dst.copy_(src, non_blocking=True)
+        plan['graph'].replay()
         return plan['internal'], [o.clone() for o in plan['outs']]
       del plans[sig]  # parameters / BatchNorm statistics were written (or moved) since the capture
       plan = None
@@ -352,7 +371,8 @@ class LidarCenterNet(nn.Module):
     if graphable:
       plan = plans.setdefault(sig, dict(count=0, graph=None))
       plan['count'] += 1
-      if plan['count'] > after and plan['count'] > 1:  # (at least one eager call of the signature: scratch buffers and constants exist)
+      room = sum(pl.get('graph') is not None for pl in plans.values()) < EVAL_GRAPH_MAX_PLANS
+      if room and plan['count'] > after and plan['count'] > 1:  # (at least one eager call of the signature: scratch buffers and constants exist)
         from .graph import capture, capture_stream
         # (inference_mode(False): the graph's input buffers must be ordinary tensors -- later calls may come under no_grad instead of
         # inference_mode, where copying into an inference tensor is an error)
@@ -364,11 +384,8 @@ class LidarCenterNet(nn.Module):
           with capture(graph, st):
             plan['internal'] = eng.forward(*plan['static_in'])
             plan['outs'], _ = self._export(plan['internal'])
-        plan['key'] = eng._packed_key
+        plan['key'] = eng.fast_weights_key(dt_)
         plan['graph'] = graph
-        captured = [k for k, pl in plans.items() if pl.get('graph') is not None]
-        for k in captured[:max(0, len(captured) - EVAL_GRAPH_MAX_PLANS)]:
-          del plans[k]
         graph.replay()
         return plan['internal'], [o.clone() for o in plan['outs']]
     internal = eng.forward(*inputs)
