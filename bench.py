@@ -229,6 +229,59 @@ def autocast_reference(state_dict, bs, seed, log, hard_timeout_s=240.0):
       os.remove(path)
 
 
+def forward_call_worker(device_index, iters=20):
+  """Child process (an agent-like one: nothing but the module and its eval forward): model.forward() exactly as sensor_agent.py:456-461 calls it with
+  TFPP_EVAL_GRAPH_AFTER=2 in the environment -- the module captures the eval forward of a signature after two eager calls and replays it (model.py
+  _plain_forward).  `_tick` = each call followed by a device synchronisation (the agent reads the predictions on the host before the next tick)."""
+  from carla_garage_amd.config import GlobalConfig
+  from carla_garage_amd.model import LidarCenterNet
+  device = torch.device('cuda', device_index)
+  torch.cuda.set_device(device)
+  cfg = GlobalConfig(tfpp_dtype='bf16')
+  torch.manual_seed(0)
+  model = LidarCenterNet(cfg).to(device).eval()
+  model.eval_graph_after = 2  # (what TFPP_EVAL_GRAPH_AFTER=2 in the environment sets for every module; the launcher exports it as well)
+  b = synthetic_batch(1, cfg, device, 99)
+  inp = [b[k] for k in ('rgb', 'lidar_bev', 'target_point', 'ego_vel', 'command')]
+  out = {}
+  for dtype in ('bf16', 'fp32'):
+    cfg.tfpp_dtype = dtype
+    with torch.inference_mode():
+      for _ in range(5):  # two eager calls, the capture, two replays
+        model(*inp)
+      for key, sync_each in ((f'{dtype}_forward_call', False), (f'{dtype}_forward_call_tick', True)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+          model(*inp)
+          if sync_each:
+            torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        out[key] = round(1e3 * (time.perf_counter() - t0) / iters, 3)
+  out['captured_signatures'] = sum(pl.get('graph') is not None for pl in model._eval_plans.values())
+  print(json.dumps(out), flush=True)
+
+
+def forward_call_latency(device, log, hard_timeout_s=150.0):
+  """forward_call_worker in its own process on the same GPU: whatever happens there cannot take this process (and the bench line) down."""
+  import subprocess
+  try:
+    cmd = [sys.executable, os.path.abspath(__file__), '--forward-call-only', str(device.index or 0)]
+    env = dict(os.environ, TFPP_EVAL_GRAPH_AFTER='2')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+      env.pop(k, None)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=hard_timeout_s, env=env, check=False)
+    for ln in reversed(p.stdout.decode().splitlines()):
+      try:
+        return json.loads(ln)
+      except ValueError:
+        continue
+    log(f'forward-call leg: no result (rc {p.returncode}): {p.stderr.decode()[-300:]}')
+  except Exception as e:  # pylint: disable=broad-except
+    log(f'forward-call leg failed: {type(e).__name__}: {e}')
+  return {}
+
+
 def inference_latency(model, cfg, device, log, iters=20):
   """Second half of the BASELINE metric: TransFuser++ forward ms/frame at bs=1 (the 20 Hz closed-loop tick,
   sensor_agent.py:456-461), eval mode, caller-facing fp32 NCHW outputs included; eager launches and hipGraph replay."""
@@ -254,15 +307,6 @@ def inference_latency(model, cfg, device, log, iters=20):
       for _ in range(3):
         model(*inp)
       out[f'{dtype}_eager'] = timed(lambda: model(*inp))
-      # model.forward() exactly as sensor_agent.py:456-461 calls it with TFPP_EVAL_GRAPH_AFTER=2 in the environment: the module captures the eval
-      # forward of a signature after two eager calls and replays it (model.py _plain_forward); `_tick` = each call followed by a device
-      # synchronisation (the agent reads the predictions on the host before the next tick)
-      model.eval_graph_after = 2  # (= TFPP_EVAL_GRAPH_AFTER=2 in the agent's environment)
-      for _ in range(4):
-        model(*inp)
-      out[f'{dtype}_forward_call'] = timed(lambda: model(*inp))
-      out[f'{dtype}_forward_call_tick'] = timed(lambda: model(*inp), sync_each=True)
-      model.eval_graph_after = -1
     try:
       g = GraphedForward(model, *inp)
       torch.cuda.synchronize()
@@ -603,6 +647,7 @@ def main():
                   help='initialise a process group and issue the gradient all-reduces even with one rank (exercises the RCCL path on one GPU)')
   ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
   ap.add_argument('--autocast-reference-only', default=None, help=argparse.SUPPRESS)
+  ap.add_argument('--forward-call-only', default=None, help=argparse.SUPPRESS)
   ap.add_argument('--seed', type=int, default=1234, help=argparse.SUPPRESS)
   ap.add_argument('--no-bf16-reference', action='store_true', help='skip the CPU autocast-bf16 reference beside the bf16-vs-fp32 gradient statistics')
   ap.add_argument('--cpu-budget', type=float, default=25.0, help=argparse.SUPPRESS)
@@ -612,6 +657,9 @@ def main():
     return
   if args.cpu_baseline_only:
     cpu_baseline_worker(args.batch_size, args.cpu_budget)
+    return
+  if args.forward_call_only is not None:
+    forward_call_worker(int(args.forward_call_only))
     return
 
   if not torch.cuda.is_available():
@@ -890,6 +938,7 @@ def main():
   fwd = lidar_hist = swin_fwd = image_aug = None
   if rank == 0 and not args.no_inference:
     fwd = inference_latency(model, cfg, device, log)
+    fwd.update(forward_call_latency(device, log))  # the module's own capture (TFPP_EVAL_GRAPH_AFTER=2), measured in an agent-like child process
     lidar_hist = lidar_histogram_latency(cfg, device, log)
     try:
       image_aug = image_augmentation_latency(cfg, device, log, bs=args.batch_size)
