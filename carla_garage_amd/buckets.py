@@ -8,7 +8,7 @@ The exchange waits for nothing else: ONE captured graph, no second segment, no j
 The signal has to cross from a node inside a captured hipGraph to a stream outside of it.  ROCm 7.x has no host-side primitive for that
 (tools/graph_external_event_test.py: PyTorch refuses external events on ROCm, hipEventRecordWithFlags(..., hipEventRecordExternal) fails
 inside a capture, hipMallocSignalMemory / hipStreamWaitValue64 are not available on these boxes), so it is a counter in device memory:
-``tfpp_signal_add`` is a one-thread kernel node behind the bucket's last kernels, ``tfpp_signal_wait`` a one-wave kernel on the collective's
+``tfpp_signal_set`` is a one-thread kernel node behind the bucket's last kernels, ``tfpp_signal_wait`` a one-wave kernel on the collective's
 stream that polls it (include/tfpp.h).  The same mechanism runs in eager steps, so the eager tests exercise what the graph replays.
 
 Host bookkeeping (round 5: self-describing signals): a signal does not count passes, it CARRIES the serial number of the pass that
@@ -17,7 +17,9 @@ advances the host serial and writes it into a device word on the compute stream 
 that word's value (``tfpp_signal_set``: max), and the exchange waits for "signal >= serial of THIS pass".  A pass nobody book-kept (a bare
 ``graph.replay()``, an eager pass that died half-way) re-raises an old serial, so a later wait can only be satisfied late -- a reported
 time-out -- never early on gradients that are still being written.  A wait that times out is reported at the NEXT step on every rank: the
-time-out word is MAX-all-reduced behind the step's collectives and copied to pinned host memory (``raise_if_timed_out``).
+time-out word is MAX-all-reduced behind the collectives of EVERY exchange (unconditionally: whether a collective is posted must never depend
+on a rank-local ``event.query()``, or the ranks' collective sequences diverge -- ADVICE r5) and copied to one slot of a small ring of pinned
+host words; the host reads whichever slots have landed (``raise_if_timed_out``).
 
 Correctness never depends on the observation being right: Engine.g() and the lane's flush hook cancel ("poison") the early signals of a
 pass whose write order differs from the observed one; every bucket is then released by the signal raised at the END of the pass."""
@@ -30,6 +32,7 @@ import os
 # a wait that sees nothing for this long gives up (and counts in `timeouts`): a stuck stream must not hang the GPU.  Far above any plausible
 # step (a profiled / pre-empted / PMC-serialised step can take seconds: 2 s, the round-4 value, was within reach of those)
 WAIT_TIMEOUT_MS = int(os.environ.get('TFPP_SIGNAL_TIMEOUT_MS', '20000'))
+FLAG_RING = 4  # health flags in flight between the exchange stream and the host (one per exchange)
 
 
 class GradBuckets:
@@ -43,8 +46,8 @@ class GradBuckets:
     self.timeouts = None       # int32 [1]: waits that gave up
     self.serial = 0            # serial number of the pass issued last (begin_issue); the signals of a pass carry its serial
     self.serial_dev = None     # int64 [1] device word: the serial of the pass that is executing (written in front of it on the compute stream)
-    self._flag_dev = self._flag_host = self._flag_event = None  # time-out word on its way to the host (raise_if_timed_out)
-    self._flag_pending, self._flag_seen, self._flag_skipped = False, 0, 0
+    self._flags = None         # ring of FLAG_RING (device word, pinned host word, event): time-out words on their way to the host
+    self._flag_posted, self._flag_read, self._flag_seen = 0, 0, 0  # exchanges that posted a flag / flags the host has looked at / time-outs reported
     self._early = set()        # buckets with an early signal in the pass being recorded
     self.poisoned = None       # reason the early signals of this pass are not used
     self.stats = {'early_signals': 0, 'poisoned_passes': 0, 'exchanges': 0, 'waits': 0}
@@ -151,36 +154,49 @@ class GradBuckets:
 
   # ------------------------------------------------------------------------------------------------ health of the exchange
   def _post_health_flag(self, group):
-    """Behind this step's collectives on the exchange stream: MAX over the ranks of the time-out word, copied to pinned host memory.  The
-    host looks at it at the next step without waiting for the device (raise_if_timed_out)."""
+    """Behind this step's collectives on the exchange stream: MAX over the ranks of the time-out word, copied to pinned host memory.  Posted
+    by EVERY exchange on every rank -- the collective sequence is a function of the step count alone -- into slot (exchange number mod
+    FLAG_RING) of a ring; the host looks at the slots that have landed at the next step without waiting for the device (raise_if_timed_out)."""
     import torch.distributed as dist
-    if self._flag_pending:  # the previous flag has not been looked at yet (its event is still pending): keep it, post none on top
-      return
-    if self._flag_dev is None:
-      self._flag_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
-      self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-      self._flag_event = torch.cuda.Event()
+    if self._flags is None:
+      self._flags = [(torch.zeros(1, dtype=torch.int32, device=self.device), torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+                     for _ in range(FLAG_RING)]
+    if self._flag_posted - self._flag_read >= FLAG_RING:
+      # the slot about to be reused has not been read: the host is FLAG_RING exchanges ahead of the device.  Wait for that one copy (host-side
+      # only: no collective is added or dropped) and read it
+      self._read_flags(block=True, upto=self._flag_posted - FLAG_RING + 1)
+    dev, host, ev = self._flags[self._flag_posted % FLAG_RING]
     with torch.cuda.stream(self.comm):
-      self._flag_dev.copy_(self.timeouts, non_blocking=True)
+      dev.copy_(self.timeouts, non_blocking=True)
       if tdist.world_size(group) > 1:
-        dist.all_reduce(self._flag_dev, op=dist.ReduceOp.MAX, group=group)  # (every rank stops together)
-      self._flag_host.copy_(self._flag_dev, non_blocking=True)
-      self._flag_event.record(self.comm)
-    self._flag_pending = True
+        dist.all_reduce(dev, op=dist.ReduceOp.MAX, group=group)  # (every rank stops together)
+      host.copy_(dev, non_blocking=True)
+      ev.record(self.comm)
+    self._flag_posted += 1
+
+  def _read_flags(self, block, upto=None):
+    """Look at the posted flags in order, oldest first, as far as they have landed (``block``: wait for them, all or up to number ``upto``);
+    returns the largest time-out count seen."""
+    worst = 0
+    upto = self._flag_posted if upto is None else min(upto, self._flag_posted)
+    while self._flag_read < upto:
+      _, host, ev = self._flags[self._flag_read % FLAG_RING]
+      if not ev.query():
+        if not block:
+          break
+        ev.synchronize()
+      worst = max(worst, int(host[0]))
+      self._flag_read += 1
+    return worst
 
   def raise_if_timed_out(self, block=False):
     """Raises when a completion-signal wait of an earlier step gave up: its all-reduce may have run on an incomplete bucket and the partial
-    sums were averaged into every rank's gradients.  Cheap: reads a pinned host word the exchange stream filled behind the previous step's
-    collectives; it does not wait for the device unless that word has been pending for more than two steps (or ``block``)."""
-    if not self._flag_pending:
+    sums were averaged into every rank's gradients.  Cheap: reads the pinned host words the exchange stream has filled behind earlier
+    collectives; it never waits for the device unless ``block`` (checkpoints: Trainer.check_exchange_health), and it never posts or skips a
+    collective -- how often it is called per step does not matter."""
+    if self._flags is None:
       return
-    if not self._flag_event.query():
-      self._flag_skipped += 1
-      if not block and self._flag_skipped <= 2:
-        return
-      self._flag_event.synchronize()
-    self._flag_pending, self._flag_skipped = False, 0
-    n = int(self._flag_host[0])
+    n = self._read_flags(block)
     if n > self._flag_seen:
       new, self._flag_seen = n - self._flag_seen, n
       raise RuntimeError(f'carla_garage_amd: {new} completion-signal wait(s) of the gradient exchange gave up after {WAIT_TIMEOUT_MS} ms (on this or another '

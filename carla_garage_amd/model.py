@@ -453,7 +453,9 @@ class LidarCenterNet(nn.Module):
   def create_optimizer_groups(self, weight_decay):
     """model.py:556-632: decay for conv / linear / GRU input weights, none for biases, norms, embeddings, queries."""
     decay, no_decay = [], []
-    norm_types = (nn.LayerNorm, nn.BatchNorm2d, nn.BatchNorm1d)
+    # (_BatchNorm covers nn.SyncBatchNorm: train.py:511-512 converts before train.py:523 builds the groups, and the reference's name rules keep
+    # the converted layers' weights out of the decay set)
+    norm_types = (nn.LayerNorm, nn.modules.batchnorm._BatchNorm)
     owner = {}
     for mn, mod in self.named_modules():
       for pn, p in mod.named_parameters(recurse=False):

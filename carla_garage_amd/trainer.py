@@ -102,13 +102,14 @@ class Trainer:
     obs = eng.observed_buckets
     if self.layout_final:
       return False
-    if self.exchange and tdist.exchange_enabled(self.pg) and self.world > 1:
+    if self.exchange and self.world > 1:
       # Agreed by construction: every rank adopts RANK 0's observation -- one small object broadcast per eager warm-up step until
       # rank 0 has a stable one -- so all ranks re-home on the same step with the same layout; agree_on_layout() stays as an assertion.
       # (Each rank acting on its OWN observation could re-home on different steps: one rank would then issue the layout check's int64
       # all-reduce while another issues a gradient bucket's float all-reduce.)
       box = [obs if (obs is not None and getattr(eng, 'observation_stable', False)) else None]
-      dist.broadcast_object_list(box, src=0, group=self.pg)
+      # (needed whether or not THIS step exchanges -- no_sync() / accumulation steps re-home too -- and from the group's own rank 0)
+      dist.broadcast_object_list(box, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
       obs = box[0]
       if obs is None:
         return False

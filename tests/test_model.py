@@ -56,6 +56,24 @@ def test_optimizer_groups_cover_every_parameter(model_cpu):
   assert not any(k.endswith('bias') or '.bn.' in k or '.ln' in k or 'norm' in k for k in decay)
 
 
+def test_optimizer_groups_of_a_syncbatchnorm_converted_model_equal_the_unconverted_ones():
+  """train.py:511-512 converts the BatchNorm layers BEFORE train.py:523 builds the optimizer groups; nn.SyncBatchNorm is no subclass of
+  BatchNorm2d / BatchNorm1d, and the reference's name rules keep the converted layers' weights in the no-decay group."""
+  import copy
+  from carla_garage_amd.config import GlobalConfig
+  from carla_garage_amd.model import LidarCenterNet
+  torch.manual_seed(0)
+  plain = LidarCenterNet(GlobalConfig())
+  conv = torch.nn.SyncBatchNorm.convert_sync_batchnorm(copy.deepcopy(plain))
+  assert any(isinstance(mod, torch.nn.SyncBatchNorm) for mod in conv.modules())
+  for model_a, model_b in ((plain, conv),):
+    na = {id(p): k for k, p in model_a.named_parameters()}
+    nb = {id(p): k for k, p in model_b.named_parameters()}
+    for ga, gb in zip(model_a.create_optimizer_groups(0.01), model_b.create_optimizer_groups(0.01)):
+      assert ga['weight_decay'] == gb['weight_decay']
+      assert sorted(na[id(p)] for p in ga['params']) == sorted(nb[id(p)] for p in gb['params'])
+
+
 def test_library_exports_every_declared_symbol():
   _lib.build()
   decl = _lib.declared_functions()
