@@ -14,30 +14,36 @@ ROOT = os.path.dirname(PKG_DIR)
 HEADER = os.path.join(ROOT, 'include', 'tfpp.h')
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libtfpp_hip.so')
-SOURCES = ['gemm_kernels.hip', 'gemm_glds.hip', 'gemm_wgrad_glds.hip', 'attention_kernels.hip', 'conv3x3_halo.hip', 'wgrad3x3_halo.hip', 'pointwise_kernels.hip', 'norm_kernels.hip', 'misc_kernels.hip', 'lidar_kernels.hip', 'swin_kernels.hip', 'bev_kernels.hip', 'head_kernels.hip', 'augment_kernels.hip']
+SOURCES = ['gemm_kernels.hip', 'gemm_glds.hip', 'gemm_wgrad_glds.hip', 'attention_kernels.hip', 'conv3x3_halo.hip', 'wgrad3x3_halo.hip', 'pointwise_kernels.hip', 'norm_kernels.hip', 'bn_rows_kernels.hip', 'misc_kernels.hip', 'lidar_kernels.hip', 'swin_kernels.hip', 'bev_kernels.hip', 'head_kernels.hip', 'augment_kernels.hip']
 
 F32, BF16 = 0, 1
-ABI_VERSION = 5  # include/tfpp.h TFPP_ABI_VERSION
+ABI_VERSION = 6  # include/tfpp.h TFPP_ABI_VERSION
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU, ACT_TANH = 0, 1, 2, 3, 4
 EINVAL = -1000
 
 i32, i64, f32, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
 
+class BnRows(ctypes.Structure):
+  """tfpp_bn_rows: BatchNorm statistics still in the per-M-tile rows of the producing convolution (include/tfpp.h)"""
+  _fields_ = [('partial', vp), ('nrows', i32), ('C', i32), ('count', i64), ('gamma', vp), ('beta', vp), ('running_mean', vp), ('running_var', vp),
+              ('num_batches_tracked', vp), ('scale', vp), ('shift', vp), ('save_mean', vp), ('save_invstd', vp), ('momentum', f32), ('eps', f32)]
+
+
 class ConvParams(ctypes.Structure):
   _fields_ = [('src', vp), ('w', vp), ('dst', vp), ('scale', vp), ('shift', vp), ('res', vp), ('B', i32), ('Hs', i32),
               ('Ws', i32), ('Cs', i32), ('Hd', i32), ('Wd', i32), ('Cd', i32), ('R', i32), ('S', i32), ('stride', i32),
               ('pad', i32), ('G', i32), ('ks_g', i32), ('n_g', i32), ('mode', i32), ('act', i32), ('dst_nchw', i32),
-              ('alpha', f32), ('src_ld', i64), ('dst_ld', i64), ('res_ld', i64), ('dst_f32', i32), ('stats_partial', vp), ('stats_rows', i32), ('splitk_ws', vp),
+              ('alpha', f32), ('src_ld', i64), ('dst_ld', i64), ('res_ld', i64), ('dst_f32', i32), ('stats_partial', vp), ('stats_rows', i32), ('stats_store', i32), ('splitk_ws', vp),
               ('splitk_ws_floats', i64), ('splitk', i32), ('bns_y', vp), ('bns_x', vp), ('bns_mean', vp), ('bns_invstd', vp),
-              ('bns_partial', vp), ('bns_ld', i64), ('bns_relu', i32)]
+              ('bns_partial', vp), ('bns_ld', i64), ('bns_relu', i32), ('in_bn', BnRows), ('in_relu', i32)]
 
 
 class WgradParams(ctypes.Structure):
   _fields_ = [('dy', vp), ('x', vp), ('dw', vp), ('row_map', vp), ('col_map', vp), ('B', i32), ('Hs', i32), ('Ws', i32),
               ('Cs', i32), ('Hd', i32), ('Wd', i32), ('Cd', i32), ('R', i32), ('S', i32), ('stride', i32), ('pad', i32),
               ('G', i32), ('ks_g', i32), ('n_g', i32), ('c_real', i32), ('splits', i32), ('x_ld', i64), ('dy_ld', i64),
-              ('dw_ld', i64), ('ws', vp), ('ws_floats', i64)]
+              ('dw_ld', i64), ('ws', vp), ('ws_floats', i64), ('x_scale', vp), ('x_shift', vp), ('x_relu', i32)]
 
 
 class BgemmParams(ctypes.Structure):
@@ -229,8 +235,9 @@ class _Lib:
     n = self._dll.tfpp_struct_sizes(sizes, 8)
     mine = [ctypes.sizeof(ConvParams), ctypes.sizeof(WgradParams), ctypes.sizeof(BgemmParams), ctypes.sizeof(PackDesc),
             ctypes.sizeof(AttnParams)]
-    if n != 5 or list(sizes[:5]) != mine:
-      raise TfppError(f'struct layout mismatch: library {list(sizes[:5])} vs ctypes {mine}')
+    mine.append(ctypes.sizeof(BnRows))
+    if n != 6 or list(sizes[:6]) != mine:
+      raise TfppError(f'struct layout mismatch: library {list(sizes[:6])} vs ctypes {mine}')
     if self._dll.tfpp_version() != ABI_VERSION:
       raise TfppError(f'ABI version mismatch: library {self._dll.tfpp_version()}, binding {ABI_VERSION} (include/tfpp.h TFPP_ABI_VERSION: bumped with every signature change)')
     got = ctypes.c_uint64(0)

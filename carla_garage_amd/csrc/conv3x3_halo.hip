@@ -16,6 +16,7 @@
 // work is free).  The implicit GEMM ran these at 119 / 242 us (stage 1, bs = 12) against a 28 us HBM bound.
 #include "gemm_core.cuh"
 #include "gemm_internal.h"
+#include "bn_rows.cuh"
 #include <cstdlib>
 
 namespace {
@@ -24,11 +25,16 @@ template <int GEO> struct HaloGeo { static constexpr int HH = GEO == 1 ? 2 * TH 
 
 // CV = Cin_g / 8 at compile time (0: run-time loop): with CV known the staging loops are fully unrolled, so a thread issues all of
 // its ~11 global loads before the first LDS store instead of paying one memory latency per 16-byte chunk.
-template <int FN, int CV, bool BNS = false, int GEO = 0>
+// INBN (round 6): the source exists only as (raw output of the 1x1 convolution in front, BatchNorm statistics): every staged chunk becomes
+// relu(raw * scale[c] + shift[c]) on its way into LDS (out-of-image chunks stay zero: the padding is applied AFTER the activation), and when
+// in_bn.partial is set the workgroup first adds the statistics rows of its group's input channels (bn_rows.cuh) -- beside its tile loads, which
+// are already in flight.  The normalised tensor is never written (tfpp.h).
+template <int FN, int CV, bool BNS = false, int GEO = 0, bool INBN = false>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, int tiles_w, int tiles_h, int ksteps_rt) {
   typedef bf16_t T;
   constexpr int FM = 4, HH = HaloGeo<GEO>::HH, HWID = HaloGeo<GEO>::HWID;
   static_assert(!(BNS && GEO != 0), "the statistics epilogue exists for the stride-1 geometry only");
+  static_assert(!(INBN && (BNS || GEO == 2)), "normalise-on-load is a forward feature");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cin = CV ? CV * 8 : p.ks_g, cv = cin >> 3, K = 9 * cin;
@@ -48,22 +54,38 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
   const T* __restrict__ src = reinterpret_cast<const T*>(p.src) + g * cin;
   const T* __restrict__ wk = reinterpret_cast<const T*>(p.w) + (size_t)g * p.n_g * K;
   const int kc_row = kpitch >> 3;  // 16-byte chunks per LDS weight row
-  auto halo_chunk = [&](int q) {
+  auto halo_chunk = [&](int q, bool& inside) {
     const int pix = q / cv, c = q - pix * cv;
     const int hr = pix / HWID, hc = pix - hr * HWID;
     uint4 v = make_uint4(0, 0, 0, 0);
+    inside = false;
     if constexpr (GEO == 0) {
       const int h = h0 + hr - 1, w = w0 + hc - 1;
-      if (h >= 0 && h < H && w >= 0 && w < W) v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * H + h) * W + w) * p.src_ld + c * 8);
+      inside = h >= 0 && h < H && w >= 0 && w < W;
+      if (inside) v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * H + h) * W + w) * p.src_ld + c * 8);
     } else if constexpr (GEO == 1) {  // forward, stride 2: input pixel (2 h0 - 1 + hr, 2 w0 - 1 + hc) of the Hs x Ws source
       const int h = 2 * h0 + hr - 1, w = 2 * w0 + hc - 1;
-      if (h >= 0 && h < p.Hs && w >= 0 && w < p.Ws) v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.Hs + h) * p.Ws + w) * p.src_ld + c * 8);
+      inside = h >= 0 && h < p.Hs && w >= 0 && w < p.Ws;
+      if (inside) v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.Hs + h) * p.Ws + w) * p.src_ld + c * 8);
     } else {  // data gradient, stride 2: the zero-stuffed gradient Z[2a][2b] = dy[a][b]
       const int hz = h0 + hr - 1, wz = w0 + hc - 1;
-      if (hz >= 0 && wz >= 0 && !((hz | wz) & 1) && (hz >> 1) < p.Hs && (wz >> 1) < p.Ws)
-        v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.Hs + (hz >> 1)) * p.Ws + (wz >> 1)) * p.src_ld + c * 8);
+      inside = hz >= 0 && wz >= 0 && !((hz | wz) & 1) && (hz >> 1) < p.Hs && (wz >> 1) < p.Ws;
+      if (inside) v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.Hs + (hz >> 1)) * p.Ws + (wz >> 1)) * p.src_ld + c * 8);
     }
     return v;
+  };
+  // normalise-on-load: scale / shift of this group's input channels in LDS; the transform of one staged chunk
+  __shared__ float in_sc[INBN ? 64 : 1], in_sh[INBN ? 64 : 1];
+  auto in_bn_chunk = [&](uint4 v, int q) {
+    const int c8 = (q % cv) * 8;
+    float f[8];
+    unpack16<T>(v, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = f[e] * in_sc[c8 + e] + in_sh[c8 + e];
+      f[e] = p.in_relu ? (t > 0.f ? t : 0.f) : t;
+    }
+    return pack16<T>(f);
   };
   auto weight_chunk = [&](int q) {
     const int n = q / kc_row, kc = q - n * kc_row;
@@ -75,10 +97,24 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
     constexpr int HCH = HH * HWID * CV, HIT = (HCH + 255) / 256;
     constexpr int WCH = FN * 16 * (((9 * CV * 8 + 31) / 32) * 4 + 1), WIT = (WCH + 255) / 256;
     uint4 hv[HIT], wv[WIT];
+    unsigned inside_bits = 0u;
+    static_assert(HIT <= 32, "one validity bit per staged chunk");
 #pragma unroll
-    for (int it = 0; it < HIT; ++it) { const int q = tid + it * 256; hv[it] = q < HCH ? halo_chunk(q) : make_uint4(0, 0, 0, 0); }
+    for (int it = 0; it < HIT; ++it) {
+      const int q = tid + it * 256;
+      bool inside = false;
+      hv[it] = q < HCH ? halo_chunk(q, inside) : make_uint4(0, 0, 0, 0);
+      if (INBN && inside) inside_bits |= 1u << it;
+    }
 #pragma unroll
     for (int it = 0; it < WIT; ++it) { const int q = tid + it * 256; wv[it] = q < WCH ? weight_chunk(q) : make_uint4(0, 0, 0, 0); }
+    if constexpr (INBN) {  // the statistics of this group's input channels, while the tile loads are in flight
+      __shared__ double in_sm[512];
+      bn_block_scale_shift(p.in_bn, g * cin, cin, blockIdx.x == 0, blockIdx.x == 0 && blockIdx.y == 0, in_sm, in_sc, in_sh);
+#pragma unroll
+      for (int it = 0; it < HIT; ++it)
+        if (inside_bits & (1u << it)) hv[it] = in_bn_chunk(hv[it], tid + it * 256);
+    }
 #pragma unroll
     for (int it = 0; it < HIT; ++it) { const int q = tid + it * 256; if (q < HCH) *reinterpret_cast<uint4*>(halo + (size_t)q * 8) = hv[it]; }
 #pragma unroll
@@ -87,7 +123,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
       if (q < WCH) { const int n = q / kc_row, kc = q - n * kc_row; *reinterpret_cast<uint4*>(wl + (size_t)n * kpitch + kc * 8) = wv[it]; }
     }
   } else {
-    for (int q = tid; q < HH * HWID * cv; q += 256) *reinterpret_cast<uint4*>(halo + (size_t)q * 8) = halo_chunk(q);
+    if constexpr (INBN) {
+      __shared__ double in_sm[512];
+      bn_block_scale_shift(p.in_bn, g * cin, cin, blockIdx.x == 0, blockIdx.x == 0 && blockIdx.y == 0, in_sm, in_sc, in_sh);
+    }
+    for (int q = tid; q < HH * HWID * cv; q += 256) {
+      bool inside = false;
+      uint4 v = halo_chunk(q, inside);
+      if (INBN && inside) v = in_bn_chunk(v, q);
+      *reinterpret_cast<uint4*>(halo + (size_t)q * 8) = v;
+    }
     for (int q = tid; q < FN * 16 * kc_row; q += 256) {
       const int n = q / kc_row, kc = q - n * kc_row;
       *reinterpret_cast<uint4*>(wl + (size_t)n * kpitch + kc * 8) = weight_chunk(q);
@@ -157,8 +202,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
 #pragma unroll
           for (int w2 = 0; w2 < 4; ++w2) { sum += st[((0 * 4 + w2) * FN + n) * 16 + lane]; sq += st[((1 * 4 + w2) * FN + n) * 16 + lane]; }
           float* row = p.stats_partial + (size_t)(blockIdx.x % p.stats_rows) * 2 * ctot;
-          atomicAdd(row + g * p.n_g + ch, sum);
-          atomicAdd(row + ctot + g * p.n_g + ch, sq);
+          if (p.stats_store) { row[g * p.n_g + ch] = sum; row[ctot + g * p.n_g + ch] = sq; }  // one writer per cell: nothing to zero (tfpp.h)
+          else { atomicAdd(row + g * p.n_g + ch, sum); atomicAdd(row + ctot + g * p.n_g + ch, sq); }
         }
       }
     }
@@ -243,7 +288,13 @@ template <int FN, int CV> int launch_halo(const tfpp_conv_params& p, hipStream_t
       if (tfpp_first_use_on_this_device(&attr_mask)) {  // the 17 x 65 input halo of the stride-2 forward needs > 64 KB with 24 channels
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<FN, CV, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
       }
-      if (geo == 1) hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, false, 1>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
+      if (p.in_bn.scale && geo != 1) return TFPP_EINVAL;
+      if (geo == 1 && p.in_bn.scale) {
+        static unsigned long long attr_mask_bn = 0;
+        if (tfpp_first_use_on_this_device(&attr_mask_bn))
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<FN, CV, false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, false, 1, true>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
+      } else if (geo == 1) hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, false, 1>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
       else hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, false, 2>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
       TFPP_CHECK_LAUNCH();
       return 0;
@@ -251,7 +302,10 @@ template <int FN, int CV> int launch_halo(const tfpp_conv_params& p, hipStream_t
       return TFPP_EINVAL;  // conv_halo_supported does not route such shapes here
     }
   }
-  if (p.bns_partial) hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, true>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
+  if (p.in_bn.scale) {
+    if (p.bns_partial || p.mode != 0 || p.ks_g > 64) return TFPP_EINVAL;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, false, 0, true>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
+  } else if (p.bns_partial) hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, true>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
   else hipLaunchKernelGGL((conv3x3_halo_kernel<FN, CV, false>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, ksteps);
   TFPP_CHECK_LAUNCH();
   return 0;
@@ -285,6 +339,11 @@ bool conv_halo_supported(const tfpp_conv_params& p, int dtype) {
   if (p.stride != 1 || p.Hs != p.Hd || p.Ws != p.Wd) return false;
   static const int max_lds = [] { const char* e = std::getenv("TFPP_CONV_HALO_MAX_LDS"); return e ? std::atoi(e) : 65536; }();
   return halo_lds_bytes(p, fn) <= max_lds;
+}
+
+// normalise-on-load (tfpp_conv_params.in_bn): forward launches of this kernel with <= 64 input channels per group
+bool conv_halo_in_bn_ok(const tfpp_conv_params& p, int dtype) {
+  return conv_halo_supported(p, dtype) && p.mode == 0 && p.ks_g <= 64 && !p.bns_partial;
 }
 
 int conv_halo_variant(const tfpp_conv_params& p) { return 300 + (p.n_g <= 16 ? 1 : (p.n_g <= 32 ? 2 : 4)); }

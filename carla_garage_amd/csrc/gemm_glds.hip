@@ -440,8 +440,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_glds_kernel(tfpp_con
             q += st[(((1 * WGM + w2) * WGN + wn) * FN + j) * 16 + lane];
           }
           float* row = p.stats_partial + (size_t)(mtile % p.stats_rows) * 2 * ctot;
-          atomicAdd(row + g * p.n_g + n, s);
-          atomicAdd(row + ctot + g * p.n_g + n, q);
+          if (p.stats_store) { row[g * p.n_g + n] = s; row[ctot + g * p.n_g + n] = q; }  // one writer per cell: nothing to zero (tfpp.h)
+          else { atomicAdd(row + g * p.n_g + n, s); atomicAdd(row + ctot + g * p.n_g + n, q); }
         }
       }
     }

@@ -11,6 +11,7 @@ int conv_gemm_glds(const tfpp_conv_params& p, hipStream_t st);
 
 // 3x3 / stride 1 / pad 1 with the input tile staged once in LDS (conv3x3_halo.hip), bf16, n_g <= 64; variant codes 300 + FN
 bool conv_halo_supported(const tfpp_conv_params& p, int dtype);
+bool conv_halo_in_bn_ok(const tfpp_conv_params& p, int dtype);  // the source may be normalised while it is staged (tfpp_conv_params.in_bn)
 int conv_halo_variant(const tfpp_conv_params& p);
 int conv_halo_mtiles(const tfpp_conv_params& p);
 int conv_gemm_halo(const tfpp_conv_params& p, hipStream_t st);
@@ -45,6 +46,7 @@ __device__ __forceinline__ tfpp_wgrad_params tfpp_wgrad_item_params(const tfpp_w
   p.B = it.P; p.Hs = 1; p.Ws = 1; p.Cs = it.KK; p.Hd = 1; p.Wd = 1; p.Cd = it.n_g; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
   p.G = 1; p.ks_g = it.KK; p.n_g = it.n_g; p.c_real = it.c_real; p.splits = it.splits;
   p.x_ld = it.x_ld; p.dy_ld = it.dy_ld; p.dw_ld = it.dw_ld; p.ws = it.ws; p.ws_floats = 0;
+  p.x_scale = nullptr; p.x_shift = nullptr; p.x_relu = 0;
   return p;
 }
 #endif

@@ -144,8 +144,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
           for (int w2 = 0; w2 < C::WAVES_M; ++w2) { s += st[0][w2][wn][j][lane]; q += st[1][w2][wn][j][lane]; }
           // M-tiles are folded onto stats_rows accumulation rows (<= ~100 fp32 atomics per address, pre-zeroed by the caller)
           float* row = p.stats_partial + (size_t)(mtile % p.stats_rows) * 2 * ctot;
-          atomicAdd(row + g * p.n_g + n, s);
-          atomicAdd(row + ctot + g * p.n_g + n, q);
+          if (p.stats_store) { row[g * p.n_g + n] = s; row[ctot + g * p.n_g + n] = q; }  // one writer per cell: nothing to zero (tfpp.h)
+          else { atomicAdd(row + g * p.n_g + n, s); atomicAdd(row + ctot + g * p.n_g + n, q); }
         }
       }
     }
@@ -366,6 +366,11 @@ extern "C" int tfpp_conv_gemm_bns_ok(const tfpp_conv_params* p, int dtype) {
   return conv_bns_ok(q, dtype) ? 1 : 0;
 }
 
+extern "C" int tfpp_conv_gemm_in_bn_ok(const tfpp_conv_params* p, int dtype) {
+  if (!p) return TFPP_EINVAL;
+  return conv_halo_in_bn_ok(*p, dtype) ? 1 : 0;
+}
+
 // exact number of M-tiles (= distinct stats_partial rows) of the kernel the dispatcher runs for (p, dtype)
 extern "C" int tfpp_conv_gemm_stats_rows(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
@@ -383,6 +388,8 @@ template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStr
   if (M >= (1l << 31) || M * (long)p.dst_ld >= (1l << 40)) return TFPP_EINVAL;
   if (p.bns_partial && (!conv_bns_ok(p, ElemTraits<T>::DT) || !p.bns_x || !p.bns_mean || !p.bns_invstd || (p.bns_relu && !p.bns_y)))
     return TFPP_EINVAL;  // the caller asks tfpp_conv_gemm_bns_ok first
+  if (p.in_bn.scale && !conv_halo_in_bn_ok(p, ElemTraits<T>::DT)) return TFPP_EINVAL;  // the caller asks tfpp_conv_gemm_in_bn_ok first
+  if (p.stats_partial && p.stats_store && p.stats_rows != tfpp_conv_gemm_stats_rows(&p, ElemTraits<T>::DT)) return TFPP_EINVAL;
   if (conv_halo_supported(p, ElemTraits<T>::DT)) return conv_gemm_halo(p, st);
   tfpp_conv_params q = p;
   q.splitk = conv_splits_for(p, ElemTraits<T>::DT);
@@ -652,10 +659,16 @@ template <typename T> static int dispatch_wgrad(tfpp_wgrad_params p, int stage, 
   int rc = plan_wgrad<T>(p, pl);
   if (rc != 0) return rc;
   if (plan_out) { plan_out[0] = pl.variant; plan_out[1] = pl.splits; plan_out[2] = pl.reduce; }
+  if (p.x_scale && (pl.variant != 3 || !p.x_shift)) return TFPP_EINVAL;  // normalise-on-load: 3x3 halo kernel only (tfpp_conv_wgrad_x_bn_ok)
   if (stage < 0) return 0;  // plan only
   if (stage != 2) rc = run_wgrad_stage1<T>(p, pl, st);
   if (rc != 0 || stage == 1 || !pl.reduce) return rc;
   return run_wgrad_reduce(p, st);
+}
+
+extern "C" int tfpp_conv_wgrad_x_bn_ok(const tfpp_wgrad_params* p, int dtype) {
+  if (!p) return TFPP_EINVAL;
+  return (dtype == TFPP_BF16 && wgrad_halo_slices(*p, dtype) > 0) ? 1 : 0;
 }
 
 extern "C" int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stream) {

@@ -657,13 +657,14 @@ extern "C" int tfpp_source_hash(uint64_t* out) {
 }
 
 extern "C" int tfpp_struct_sizes(int* out, int n) {
-  if (!out || n < 5) return TFPP_EINVAL;
+  if (!out || n < 6) return TFPP_EINVAL;
   out[0] = (int)sizeof(tfpp_conv_params);
   out[1] = (int)sizeof(tfpp_wgrad_params);
   out[2] = (int)sizeof(tfpp_bgemm_params);
   out[3] = (int)sizeof(tfpp_pack_desc);
   out[4] = (int)sizeof(tfpp_attn_params);
-  return 5;
+  out[5] = (int)sizeof(tfpp_bn_rows);
+  return 6;
 }
 
 // order-independent 64-bit hash of a buffer (debugging aid: which tensor differs between two replays of one hipGraph?)

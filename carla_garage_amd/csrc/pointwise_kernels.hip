@@ -1050,36 +1050,48 @@ extern "C" int tfpp_se_gate_fwd(const float* pool, const float* w1, const float*
 }
 
 // backward of the gate MLP.  gd[b,c] = dgate*g*(1-g).  dz1[b,j] = (hidden>0) * sum_c gd[b,c] w2[c,j].
-// One workgroup per (sample, 64 hidden units): lane jl reads W2[c][j0 + jl] -- 64 consecutive floats of row c, one 256-byte segment -- for the
-// channels c = cg, cg + 4, ... of its group (4 groups of 64 lanes), four loads in flight; the groups are summed through LDS in a fixed order.
-// (Rounds 1-4: one wave per (b, j) with the lanes over c, i.e. 64 different cache lines per load: 7.3 us per launch in the step.)
-__global__ void se_dz1_kernel(const float* __restrict__ dgate, const float* __restrict__ gate, const float* __restrict__ hidden,
-                              const float* __restrict__ w2, float* __restrict__ dz1, int B, int C, int RD) {
+// One 1024-thread workgroup per (sample, 64 hidden units): lane jl reads W2[c][j0 + jl] -- 64 consecutive floats of row c, one 256-byte segment --
+// for the channels c = cg, cg + 16, ... of its group (16 groups of 64 lanes), twelve loads in flight; the groups are summed through LDS in a fixed
+// order.  (Rounds 1-4: one wave per (b, j) with the lanes over c, 64 different cache lines per load.  Round 5: this layout with 4 groups and 4
+// loads in flight -- a chain of 36 dependent L2 round trips for C = 576, 17.8 us per launch in the captured bs = 12 step; 16 groups x 12 in
+// flight make it 3.)
+#define SE_DZ1_GROUPS 16
+__global__ __launch_bounds__(64 * SE_DZ1_GROUPS) void se_dz1_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                                    const float* __restrict__ hidden, const float* __restrict__ w2,
+                                                                    float* __restrict__ dz1, int B, int C, int RD) {
+  constexpr int NG = SE_DZ1_GROUPS, U = 12;
   const int jl = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const int b = blockIdx.y, j = (int)blockIdx.x * 64 + jl;
   const bool ok = j < RD;
   const float* dg = dgate + (size_t)b * C;
   const float* g = gate + (size_t)b * C;
   const float* wc = w2 + (ok ? j : 0);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) s[u] = 0.f;
   int c = cg;
-  for (; c + 12 < C; c += 16) {
-    const float g0 = g[c], g1 = g[c + 4], g2 = g[c + 8], g3 = g[c + 12];
-    s0 += dg[c] * g0 * (1.f - g0) * wc[(size_t)c * RD];
-    s1 += dg[c + 4] * g1 * (1.f - g1) * wc[(size_t)(c + 4) * RD];
-    s2 += dg[c + 8] * g2 * (1.f - g2) * wc[(size_t)(c + 8) * RD];
-    s3 += dg[c + 12] * g3 * (1.f - g3) * wc[(size_t)(c + 12) * RD];
+  for (; c + (U - 1) * NG < C; c += U * NG) {
+    float wv[U], gv[U], dv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { wv[u] = wc[(size_t)(c + u * NG) * RD]; gv[u] = g[c + u * NG]; dv[u] = dg[c + u * NG]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) s[u] += dv[u] * gv[u] * (1.f - gv[u]) * wv[u];
   }
-  for (; c < C; c += 4) {
+  for (; c < C; c += NG) {
     const float g0 = g[c];
-    s0 += dg[c] * g0 * (1.f - g0) * wc[(size_t)c * RD];
+    s[0] += dg[c] * g0 * (1.f - g0) * wc[(size_t)c * RD];
   }
-  __shared__ float sm[4][64];
-  sm[cg][jl] = (s0 + s1) + (s2 + s3);
+  float t = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) t += s[u];
+  __shared__ float sm[NG][64];
+  sm[cg][jl] = t;
   __syncthreads();
   if (cg == 0 && ok) {
-    const float t = (sm[0][jl] + sm[1][jl]) + (sm[2][jl] + sm[3][jl]);
-    dz1[(size_t)b * RD + j] = hidden[(size_t)b * RD + j] > 0.f ? t : 0.f;
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) tot += sm[q][jl];
+    dz1[(size_t)b * RD + j] = hidden[(size_t)b * RD + j] > 0.f ? tot : 0.f;
   }
 }
 
@@ -1142,7 +1154,7 @@ extern "C" int tfpp_se_gate_bwd(const float* dgate, const float* gate, const flo
   if (!dgate || !gate || !hidden || !pool || !dpool || !dz1_scratch) return TFPP_EINVAL;
   if (2l * C * RD >= (1l << 31)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(se_dz1_kernel, dim3((unsigned)((RD + 63) / 64), (unsigned)B), dim3(256), 0, st, dgate, gate, hidden, w2, dz1_scratch, B, C, RD);
+  hipLaunchKernelGGL(se_dz1_kernel, dim3((unsigned)((RD + 63) / 64), (unsigned)B), dim3(64 * SE_DZ1_GROUPS), 0, st, dgate, gate, hidden, w2, dz1_scratch, B, C, RD);
   const int nblk_dw = (int)((2l * C * RD + 255) / 256);
   hipLaunchKernelGGL(se_param_grads_kernel, dim3((unsigned)(nblk_dw + B * ((C + 15) / 16))), dim3(256), 0, st, dgate, gate, hidden, pool, w1,
                      dz1_scratch, dpool, dw1, db1, dw2, db2, B, C, RD, nblk_dw);

@@ -23,7 +23,9 @@ __device__ __forceinline__ uint2 lds_tr16(const bf16_t* p) {
 
 // FNN: 16-channel fragments of dY (n_g <= 16 FNN); CV = Cin_g / 8 (compile time: the staging loops are fully unrolled, all of a
 // thread's global loads are in flight before its first LDS store); CB = 16-channel blocks of X per tap
-template <int FNN, int CV>
+// XBN (round 6): x exists only as (raw output of the 1x1 convolution in front, final BatchNorm scale / shift): every staged chunk of the halo
+// becomes relu(raw * scale[c] + shift[c]) on its way into LDS; out-of-image chunks stay zero (tfpp_wgrad_params.x_scale).
+template <int FNN, int CV, bool XBN = false>
 __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(tfpp_wgrad_params p, int tiles_w, int tiles_h, int nblk) {
   typedef bf16_t T;
   constexpr int CB = CV <= 2 ? 1 : (CV <= 4 ? 2 : 4);
@@ -48,6 +50,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(tfpp_wgrad_params p,
 
   const int m16 = lane & 15, kg = lane >> 4;
   const int ntiles = tiles_w * tiles_h * p.B;
+  __shared__ float x_sc[XBN ? 64 : 1], x_sh[XBN ? 64 : 1];
+  if constexpr (XBN) {
+    if (tid < cin) { x_sc[tid] = p.x_scale[g * cin + tid]; x_sh[tid] = p.x_shift[g * cin + tid]; }
+    __syncthreads();
+  }
   for (int t = blockIdx.x; t < ntiles; t += nblk) {
     const int tw = t % tiles_w, t2 = t / tiles_w, th = t2 % tiles_h, b = t2 / tiles_h;
     const int h0 = th * TH, w0 = tw * TW;
@@ -62,12 +69,38 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(tfpp_wgrad_params p,
       hv[it] = make_uint4(0, 0, 0, 0);
       if (q < HCH && h >= 0 && h < H && w >= 0 && w < W) hv[it] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + h) * W + w) * p.x_ld + c * 8);
     }
+    unsigned inside_bits = 0u;
+    if constexpr (XBN) {
+      static_assert(HIT <= 32, "one validity bit per staged chunk");
+#pragma unroll
+      for (int it = 0; it < HIT; ++it) {
+        const int q = tid + it * 256, pix = q / cv;
+        const int hr = pix / HWID, hc = pix - hr * HWID;
+        const int h = h0 + hr - 1, w = w0 + hc - 1;
+        if (q < HCH && h >= 0 && h < H && w >= 0 && w < W) inside_bits |= 1u << it;
+      }
+    }
 #pragma unroll
     for (int it = 0; it < DIT; ++it) {
       const int q = tid + it * 256, pix = q / (FNN * 2), c = q - pix * (FNN * 2);
       const int h = h0 + pix / TW, w = w0 + pix % TW;
       dv[it] = make_uint4(0, 0, 0, 0);
       if (c < nv && h < H && w < W) dv[it] = *reinterpret_cast<const uint4*>(dy + ((size_t)(b * H + h) * W + w) * p.dy_ld + c * 8);
+    }
+    if constexpr (XBN) {
+#pragma unroll
+      for (int it = 0; it < HIT; ++it) {
+        if (!(inside_bits & (1u << it))) continue;
+        const int c8 = ((tid + it * 256) % cv) * 8;
+        float f[8];
+        unpack16<T>(hv[it], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float tv = f[e] * x_sc[c8 + e] + x_sh[c8 + e];
+          f[e] = p.x_relu ? (tv > 0.f ? tv : 0.f) : tv;
+        }
+        hv[it] = pack16<T>(f);
+      }
     }
 #pragma unroll
     for (int it = 0; it < HIT; ++it) { const int q = tid + it * 256; if (q < HCH) *reinterpret_cast<uint4*>(halo + (size_t)q * 8) = hv[it]; }
@@ -135,8 +168,10 @@ template <int FNN, int CV> int launch(const tfpp_wgrad_params& p, int nblk, hipS
   static unsigned long long attr_mask = 0;
   if (tfpp_first_use_on_this_device(&attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_halo_kernel<FNN, CV>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_halo_kernel<FNN, CV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
   }
-  hipLaunchKernelGGL((wgrad3x3_halo_kernel<FNN, CV>), dim3((unsigned)nblk, (unsigned)p.G), dim3(256), lds, st, p, tiles_w, tiles_h, nblk);
+  if (p.x_scale) hipLaunchKernelGGL((wgrad3x3_halo_kernel<FNN, CV, true>), dim3((unsigned)nblk, (unsigned)p.G), dim3(256), lds, st, p, tiles_w, tiles_h, nblk);
+  else hipLaunchKernelGGL((wgrad3x3_halo_kernel<FNN, CV>), dim3((unsigned)nblk, (unsigned)p.G), dim3(256), lds, st, p, tiles_w, tiles_h, nblk);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

@@ -5,7 +5,7 @@ import ctypes
 
 import torch
 
-from ._lib import (lib, ConvParams, WgradParams, BgemmParams, PackDesc, AttnParams, F32, BF16, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU,
+from ._lib import (lib, ConvParams, WgradParams, BgemmParams, PackDesc, AttnParams, BnRows, F32, BF16, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU,
                    ACT_TANH)
 
 import os as _os
@@ -84,10 +84,14 @@ def splitk_workspace(device):
 
 def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=0, G=1, ks_g=None, n_g=None, mode=0,
               act=ACT_NONE, scale=None, shift=None, res=None, alpha=1.0, dst_nchw=False, src_ld=None, dst_ld=None,
-              res_ld=None, stats_ws=None, stats_acc=None, plan_only=False, bns=None, bns_query=False):
+              res_ld=None, stats_ws=None, stats_acc=None, plan_only=False, bns=None, bns_query=False, stats_rows_query=False, stats_store=None,
+              in_bn=None, in_relu=False, in_bn_query=False):
   """stats_ws (double[2*Cd]): also produce per-channel sum / sum of squares of the result (fused BatchNorm statistics).
   stats_acc (True, or zeroed fp32 accumulation rows from stats_rows_buffer()): leave the statistics in the rows for
-  bn_finalize_partials and return (number of rows used, rows buffer)."""
+  bn_finalize_partials and return (number of rows used, rows buffer).
+  stats_store (fp32 [>= rows * 2 * Cd], the layer's own buffer): one row per M-tile, STORED (nothing to zero); returns (rows, buffer) -- the
+  consumers of the normalised tensor finalize them in their prologues (tfpp_bn_rows).  stats_rows_query: only return that row count.
+  in_bn (BnRows) / in_relu: the source is (raw, BatchNorm statistics), normalised while it is staged; in_bn_query: can this launch do that?"""
   p = ConvParams()
   p.src, p.w, p.dst = ptr(src), ptr(w), ptr(dst)
   p.scale, p.shift, p.res = ptr(scale), ptr(shift), ptr(res)
@@ -104,6 +108,13 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
   p.splitk_ws, p.splitk_ws_floats, p.splitk = ptr(ws), ws.numel(), 0
   if _NO_CONV_SPLITK:  # debugging aid: no K split for forward / data-gradient GEMMs while the weight-gradient slices keep their workspace
     p.splitk_ws, p.splitk_ws_floats = None, 0
+  if stats_rows_query or in_bn_query:
+    p.stats_partial = 16  # never dereferenced: plan as the launch with the fused BatchNorm statistics will be planned
+    if in_bn_query:
+      return bool(lib.raw('tfpp_conv_gemm_in_bn_ok')(ctypes.byref(p), dt(src)))
+    return lib.raw('tfpp_conv_gemm_stats_rows')(ctypes.byref(p), dt(src))
+  if in_bn is not None:
+    p.in_bn, p.in_relu = in_bn, int(in_relu)
   if bns_query:  # (can the kernel that runs here emit the fused BatchNorm-backward statistics?, rows of bns_partial it would write)
     p.bns_ld = Cd
     p.bns_partial = 16  # never dereferenced: plan as the launch with the statistics will be planned (tile variant, no split-K)
@@ -116,7 +127,12 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
       p.stats_partial = 16  # never dereferenced: plan as the launch with the fused BatchNorm statistics will be planned
     return lib.raw('tfpp_conv_gemm_variant')(ctypes.byref(p), dt(src)), lib.raw('tfpp_conv_gemm_splits')(ctypes.byref(p), dt(src))
   scratch = None
-  if stats_acc is not None:
+  if stats_store is not None:
+    p.stats_partial = 16
+    nblk = lib.raw('tfpp_conv_gemm_stats_rows')(ctypes.byref(p), dt(src))
+    assert stats_store.numel() >= nblk * 2 * Cd and stats_store.dtype == torch.float32
+    p.stats_partial, p.stats_rows, p.stats_store = ptr(stats_store), nblk, 1
+  elif stats_acc is not None:
     nblk = lib.raw('tfpp_conv_gemm_stats_rows')(ctypes.byref(p), dt(src))
     if STATS_ROWS_CAP > 0:
       nblk = min(STATS_ROWS_CAP, nblk)
@@ -149,6 +165,8 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
       grp = ('fusion_linears', 'fusion_linears_c1512') if min(p.n_g, p.ks_g) >= 1512 else ('fusion_linears',)  # (all four scales, the stage-4 transformer)
     lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * (R * S * p.ks_g), nbytes, group=grp)
   lib.tfpp_conv_gemm(ctypes.byref(p), dt(src), stream())
+  if stats_store is not None:
+    return nblk, stats_store
   if stats_acc is not None:
     return nblk, stats_acc
   if stats_ws is not None:
@@ -157,8 +175,9 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
 
 
 def _wgrad_params(dy, x, dw, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=0, G=1, ks_g=None, n_g=None, c_real=None,
-                  row_map=None, col_map=None, x_ld=None, dy_ld=None, dw_ld=None, splits=0):
+                  row_map=None, col_map=None, x_ld=None, dy_ld=None, dw_ld=None, splits=0, x_scale=None, x_shift=None, x_relu=False):
   p = WgradParams()
+  p.x_scale, p.x_shift, p.x_relu = ptr(x_scale), ptr(x_shift), int(x_relu)
   p.dy, p.x, p.dw = ptr(dy), ptr(x), ptr(dw)
   p.row_map, p.col_map = ptr(row_map), ptr(col_map)
   p.B, p.Hs, p.Ws, p.Cs, p.Hd, p.Wd, p.Cd = B, Hs, Ws, Cs, Hd, Wd, Cd
@@ -174,6 +193,12 @@ def _wgrad_params(dy, x, dw, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, p
   ws = splitk_workspace(dy.device)
   p.ws, p.ws_floats = ptr(ws), ws.numel()
   return p
+
+
+def conv_wgrad_x_bn_ok(dy, x, dw, **kw):
+  """Can the kernel that runs this weight gradient normalise x while loading it (x_scale / x_shift / x_relu)?"""
+  p = _wgrad_params(dy, x, dw, **kw)
+  return bool(lib.raw('tfpp_conv_wgrad_x_bn_ok')(ctypes.byref(p), dt(dy)))
 
 
 def conv_wgrad_plan(dy, x, dw, **kw):
@@ -218,7 +243,7 @@ def wgrad_batch_end():
 def conv_wgrad(dy, x, dw, **kw):
   p = _wgrad_params(dy, x, dw, **kw)
   if WGRAD_BATCH is not None and dy.dtype == torch.bfloat16:
-    WGRAD_BATCH.append((p, (dy, x, dw, kw.get('row_map'), kw.get('col_map'))))
+    WGRAD_BATCH.append((p, (dy, x, dw, kw.get('row_map'), kw.get('col_map'), kw.get('x_scale'), kw.get('x_shift'))))
     return dw
   B, Hd, Wd, Hs, Ws, G, R, S, stride = p.B, p.Hd, p.Wd, p.Hs, p.Ws, p.G, p.R, p.S, p.stride
   if lib.profiler is not None:  # one profiled call per kernel: first stage and slice sum are timed separately
@@ -545,6 +570,88 @@ def bn_bwd_rows(dy, y, x, gamma, save_mean, save_invstd, partial, nrows, dgamma,
   lib.tfpp_bn_bwd_apply_rows(ptr(_chk(dy)), ptr(y), ptr(_chk(x)), ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(partial), nrows, ptr(coef),
                              ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), rows, c, int(relu_mask), dt(x), stream())
   return dx, dres
+
+
+# ---- round 6: the statistics step lives in the prologue of the pass that needs it (csrc/bn_rows_kernels.hip, tfpp_bn_rows) ----------------
+BN_ROWS_MAX = 256  # include/tfpp.h TFPP_BN_ROWS_MAX: most rows a consumer adds in its prologue
+
+
+def bn_rows(C, scale, shift, partial=None, nrows=0, count=0, gamma=None, beta=None, rm=None, rv=None, nbt=None, save_mean=None, save_invstd=None,
+            momentum=0.1, eps=1e-5):
+  """tfpp_bn_rows: partial given -> the consumer finalizes from the rows (and writes scale / shift / saved and running statistics);
+  partial None -> scale / shift are final and read.  The caller keeps the tensors alive."""
+  b = BnRows()
+  b.partial, b.nrows, b.C, b.count = ptr(partial), nrows, C, count
+  b.gamma, b.beta, b.running_mean, b.running_var, b.num_batches_tracked = ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nbt)
+  b.scale, b.shift, b.save_mean, b.save_invstd = ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd)
+  b.momentum, b.eps = (0.1 if momentum is None else momentum), eps
+  return b
+
+
+def bn_apply_rows(x, bn, res=None, gate=None, rows_per_batch=1, relu_pre=False, relu_post=False, y=None):
+  """y = [relu](([relu](x * scale + shift)) * gate + res) with the BatchNorm finalize in the prologue when bn carries rows."""
+  c = x.shape[-1]
+  if y is None:
+    y = torch.empty_like(x)
+  lib.tfpp_bn_apply_rows(ptr(_chk(x)), ctypes.byref(bn), ptr(res), ptr(gate), ptr(y), x.numel() // c, rows_per_batch, int(relu_pre), int(relu_post),
+                         dt(x), stream())
+  return y
+
+
+MASK_NONE, MASK_Y, MASK_RAW = 0, 1, 2
+
+
+def bn_bwd_reduce_rows(dy, y, x, scale, shift, save_mean, save_invstd, mask):
+  """Stage-1 sums of the BatchNorm backward in the channel-block layout: returns (partial rows [nrows][2C], nrows)."""
+  c = x.shape[-1]
+  rows = x.numel() // c
+  nrows = lib.raw('tfpp_bn_bwd_rows_count')(rows, c, dt(x))
+  partial = torch.empty(nrows * 2 * c, device=x.device, dtype=torch.float32)
+  lib.tfpp_bn_bwd_reduce_rows(ptr(_chk(dy)), ptr(y), ptr(_chk(x)), ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(partial), rows, c, mask,
+                              dt(x), stream())
+  return partial, nrows
+
+
+def bn_bwd_apply_rows2(dy, y, x, scale, shift, gamma, save_mean, save_invstd, partial, nrows, dgamma, dbeta, mask, want_dres=False):
+  """dx (and dres = masked dy) from the stage-1 rows; the coefficient step runs in the kernel's prologue (nrows <= BN_ROWS_MAX)."""
+  c = x.shape[-1]
+  rows = x.numel() // c
+  assert nrows <= BN_ROWS_MAX
+  dx = torch.empty_like(x)
+  dres = torch.empty_like(x) if want_dres else None
+  lib.tfpp_bn_bwd_apply_rows2(ptr(_chk(dy)), ptr(y), ptr(_chk(x)), ptr(scale), ptr(shift), ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(partial), nrows,
+                              ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), rows, c, mask, dt(x), stream())
+  return dx, dres
+
+
+def mean_hw_bn(x, bn):
+  """mean over HW of relu(BN(x)) for x = raw convolution output [B,H,W,C]; bn carries rows -> finalize in the prologue."""
+  b, h, w, c = x.shape
+  assert b <= 64
+  out = torch.empty((b, c), device=x.device, dtype=torch.float32)
+  lib.tfpp_mean_hw_bn(ptr(_chk(x)), ctypes.byref(bn), ptr(out), ptr(reduce_scratch(b, c, x.device)), ptr(gridsum_scratch(x.device)), b, h * w, dt(x), stream())
+  return out
+
+
+def se_dgate_bn(dy, x, scale, shift):
+  b, h, w, c = x.shape
+  assert b <= 64
+  out = torch.empty((b, c), device=x.device, dtype=torch.float32)
+  lib.tfpp_se_dgate_bn(ptr(_chk(dy)), ptr(_chk(x)), ptr(scale), ptr(shift), ptr(out), ptr(reduce_scratch(b, c, x.device)), ptr(gridsum_scratch(x.device)), b,
+                       h * w, c, dt(x), stream())
+  return out
+
+
+def se_bwd_apply_bn(dy, gate, dpool, x, scale, shift, save_mean, save_invstd):
+  """dx = dy * gate + dpool / HW and the BatchNorm-backward rows of the layer in front (mask recomputed from the raw tensor x);
+  returns (dx, partial rows, nrows)."""
+  b, h, w, c = dy.shape
+  nrows = lib.raw('tfpp_se_bwd_apply_bn_rows')(b, h * w, c, dt(dy))
+  partial = torch.empty(nrows * 2 * c, device=dy.device, dtype=torch.float32)
+  dx = torch.empty_like(dy)
+  lib.tfpp_se_bwd_apply_bn(ptr(_chk(dy)), ptr(gate), ptr(dpool), ptr(_chk(x)), ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(dx), ptr(partial),
+                           b, h * w, c, dt(dy), stream())
+  return dx, partial, nrows
 
 
 # ---- SyncBatchNorm (team_code/train.py:511-512, config.sync_batch_norm = 1): statistics over the batches of ALL ranks.  The per-channel sums

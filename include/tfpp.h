@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TFPP_ABI_VERSION 5
+#define TFPP_ABI_VERSION 6
 #define TFPP_EINVAL (-1000)
 #define TFPP_F32 0
 #define TFPP_BF16 1
@@ -37,6 +37,25 @@ int tfpp_version(void);
 int tfpp_source_hash(uint64_t* out);
 /* sizeof() of the parameter structs, in declaration order, so the ctypes mirror can be verified. */
 int tfpp_struct_sizes(int* out, int n);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Train-mode BatchNorm2d whose statistics still lie in the per-M-tile rows that the producing convolution's epilogue wrote
+ * (tfpp_conv_params.stats_partial with stats_store = 1).  Round 6: there is no finalize launch any more on the layers whose row count is
+ * small (<= TFPP_BN_ROWS_MAX) -- the FIRST kernel that consumes the normalised tensor adds the rows of the channels it touches in its
+ * prologue (in double, fixed order: bit-reproducible), beside its own first loads, and one designated workgroup per channel block writes
+ * scale / shift / the saved statistics and updates the running statistics, exactly what tfpp_bn_finalize_partials did.  Later kernels of
+ * the pass (and the backward pass) pass partial = NULL and READ scale / shift.  (timm ConvNormAct, F.batch_norm in training mode.) */
+#define TFPP_BN_ROWS_MAX 256
+typedef struct {
+  const float* partial;  /* [nrows][2*C] sums | sums of squares of the raw convolution output; NULL: scale / shift are final, read them */
+  int nrows, C;
+  int64_t count;         /* elements per channel behind the sums: B*H*W */
+  const float* gamma; const float* beta;                                   /* nullable: 1 / 0 */
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;   /* nullable; touched only when partial != NULL */
+  float* scale; float* shift;                                              /* [C] written when partial != NULL, read otherwise */
+  float* save_mean; float* save_invstd;                                    /* nullable; written when partial != NULL */
+  float momentum, eps;
+} tfpp_bn_rows;
 
 /* ---------------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / linear layer (MFMA).  Replaces F.conv2d / nn.Linear calls:
@@ -65,6 +84,9 @@ typedef struct {
   int dst_f32;          /* 1: dst is float regardless of dtype */
   float* stats_partial; /* nullable: fused BatchNorm statistics, [stats_rows][2*Cd] fp32 partial sums / sums of squares, zeroed by the caller */
   int stats_rows;       /* M-tile t accumulates into row t % stats_rows */
+  int stats_store;      /* 1 (requires stats_rows = tfpp_conv_gemm_stats_rows()): every (row, channel) cell has exactly one writer, so the
+                           epilogue STORES instead of adding -- the rows need no zeroing and stay valid until the next launch writes them
+                           (the consumers of tfpp_bn_rows.partial read them in their prologues) */
   float* splitk_ws;     /* nullable: fp32 workspace for split-K (few output tiles x long reduction: the fp32 planning head,
                            K = 9*1512 FPN convs); the dispatcher splits K over up to splitk_ws_floats / (M*Cd) workgroups per
                            tile and a second kernel sums the slices and applies the epilogue */
@@ -83,6 +105,12 @@ typedef struct {
   float* bns_partial;       /* nullable = feature off; [tfpp_conv_gemm_stats_rows()][2*Cd] */
   int64_t bns_ld;
   int bns_relu;
+  /* Round 6: the SOURCE is a tensor that exists only as (raw convolution output, BatchNorm statistics): src = raw and the loader applies
+   * v = raw * scale[c] + shift[c], ReLU if in_relu, while it stages the tile (zero padding stays zero) -- the normalised tensor is never
+   * written.  Only the register-staged 3x3 LDS-halo kernel can do this (tfpp_conv_gemm_in_bn_ok); in_bn.partial != NULL additionally runs the
+   * finalize prologue described at tfpp_bn_rows.  in_bn.scale == NULL: feature off. */
+  tfpp_bn_rows in_bn;
+  int in_relu;
 } tfpp_conv_params;
 /* number of K slices the dispatcher would use for p (1 = no split) */
 int tfpp_conv_gemm_splits(const tfpp_conv_params* p, int dtype);
@@ -97,6 +125,8 @@ int tfpp_conv_gemm_mtiles(const tfpp_conv_params* p);
 int tfpp_conv_gemm_stats_rows(const tfpp_conv_params* p, int dtype);
 /* 1 if the kernel the dispatcher runs for (p, dtype) supports the fused BatchNorm-backward statistics (bns_* fields) */
 int tfpp_conv_gemm_bns_ok(const tfpp_conv_params* p, int dtype);
+/* 1 if the kernel the dispatcher runs for (p, dtype) can normalise its source while loading it (in_bn) */
+int tfpp_conv_gemm_in_bn_ok(const tfpp_conv_params* p, int dtype);
 /* debugging aid (TFPP_GLDS_TRACE=1): per-workgroup phase timestamps of the last LDS-DMA GEMM launch; returns slots per workgroup */
 int tfpp_debug_glds_trace(uint64_t* out, int n_blocks);
 
@@ -120,8 +150,14 @@ typedef struct {
   int64_t dw_ld;        /* elements per output row of dw (c_real*R*S unless rows are wider) */
   float* ws;            /* nullable: workspace for the pixel-split slices, [splits][G*n_g][R*S*ks_g] fp32 */
   int64_t ws_floats;
+  /* Round 6: x exists only as (raw convolution output, final BatchNorm scale / shift): the loader applies x = raw * x_scale[c] + x_shift[c]
+   * (ReLU if x_relu) while staging; 3x3 LDS-halo weight-gradient kernel only (tfpp_conv_wgrad_x_bn_ok).  x_scale == NULL: feature off. */
+  const float* x_scale; const float* x_shift;
+  int x_relu;
 } tfpp_wgrad_params;
 int tfpp_conv_wgrad(const tfpp_wgrad_params* p, int dtype, void* stream);
+/* 1 if the kernel the dispatcher runs for (p, dtype) can normalise x while loading it (x_scale / x_shift / x_relu) */
+int tfpp_conv_wgrad_x_bn_ok(const tfpp_wgrad_params* p, int dtype);
 /* n independent weight gradients in one call (the batches of the training step's weight-gradient lane; the reference computes them one
  * autograd node at a time, train.py:898 loss.backward()).  Pointwise bf16 layers run as GROUPED grids -- the workgroups of up to 42 layers
  * in one launch, the descriptor table in the kernel arguments, pixel splits chosen for the group (most layers then add their tile straight
@@ -357,6 +393,36 @@ int tfpp_bn_bwd_apply(const void* dy, const void* y, const void* x, const float*
 int tfpp_bn_bwd_apply_rows(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
                            const float* save_invstd, float* partial, int nrows, float* coef, void* dx, void* dres, float* dgamma,
                            float* dbeta, int64_t rows, int C, int relu_mask, int dtype, void* stream);
+/* Round 6 (csrc/bn_rows_kernels.hip): the BatchNorm passes with the finalize / coefficient step in the PROLOGUE of the pass that needs it.
+ * Thread layout: a workgroup owns a block of ~64 channels (8-9 sixteen-byte chunks) x 28-32 row slots, so the rows of statistics it has to add
+ * are 0.25-0.5 KB wide instead of 2*C floats.
+ * bn_apply_rows:  t = x * scale[c] + shift[c];  relu_pre: t = max(t, 0);  gate (nullable, [rows / rows_per_batch][C]): t *= gate;
+ *                 res (nullable): t += res;  relu_post: t = max(t, 0);  y = t.   bn->partial != NULL: statistics from the rows (see tfpp_bn_rows).
+ *                 Replaces tfpp_bn_finalize_partials + tfpp_affine_act (+ the squeeze-excite gate pass).
+ * bn_bwd_reduce_rows: g = dy * mask;  partial[t][c] = sum g, partial[t][C + c] = sum g * (x - mean[c]) * invstd[c] over the rows of row block t;
+ *                 mask: 0 none, 1 (y > 0) from the forward output y, 2 (x * scale[c] + shift[c] > 0) recomputed from the raw tensor (y == NULL:
+ *                 the normalised tensor was never written).  Returns rows in *nrows_out (<= TFPP_BN_ROWS_MAX).
+ * bn_bwd_apply_rows2: dx = gamma*invstd*(g - s0/rows - xhat*s1/rows) with s0, s1 = the column sums of `partial` added in the prologue;
+ *                 dgamma += s1, dbeta += s0 (designated workgroups); dres = g (nullable).  Replaces tfpp_bn_bwd_apply_rows' two launches. */
+int tfpp_bn_apply_rows(const void* x, const tfpp_bn_rows* bn, const void* res, const float* gate, void* y, int64_t rows, int64_t rows_per_batch,
+                       int relu_pre, int relu_post, int dtype, void* stream);
+int tfpp_bn_bwd_rows_count(int64_t rows, int C, int dtype);
+int tfpp_bn_bwd_reduce_rows(const void* dy, const void* y, const void* x, const float* scale, const float* shift, const float* save_mean,
+                            const float* save_invstd, float* partial, int64_t rows, int C, int mask, int dtype, void* stream);
+int tfpp_bn_bwd_apply_rows2(const void* dy, const void* y, const void* x, const float* scale, const float* shift, const float* gamma,
+                            const float* save_mean, const float* save_invstd, const float* partial, int nrows, void* dx, void* dres,
+                            float* dgamma, float* dbeta, int64_t rows, int C, int mask, int dtype, void* stream);
+/* Squeeze-excite around a conv2 output that exists only as (raw, BatchNorm statistics) -- a2 = relu(BN2(raw2)) is never written:
+ * mean_hw_bn: pool[b][c] = mean over HW of relu(x*scale+shift) (bn->partial != NULL: finalize prologue); one launch (ticket per sample).
+ * se_dgate_bn: dgate[b][c] = sum over HW of dy * relu(x*scale+shift).
+ * se_bwd_apply_bn: dx = dy*gate[b,c] + dpool[b,c]/HW (the complete gradient of a2), and rows [2*C] of (sum g, sum g*xhat), g = dx (rounded)
+ *   * (x*scale+shift > 0), for tfpp_bn_bwd_apply_rows2; rows = tfpp_se_bwd_apply_bn_rows(B, HW, C, dtype). */
+int tfpp_mean_hw_bn(const void* x, const tfpp_bn_rows* bn, float* out, float* scratch, float* ticket_scratch, int B, int HW, int dtype, void* stream);
+int tfpp_se_dgate_bn(const void* dy, const void* x, const float* scale, const float* shift, float* dgate, float* scratch, float* ticket_scratch,
+                     int B, int HW, int C, int dtype, void* stream);
+int tfpp_se_bwd_apply_bn_rows(int B, int HW, int C, int dtype);
+int tfpp_se_bwd_apply_bn(const void* dy, const float* gate, const float* dpool, const void* x, const float* scale, const float* shift,
+                         const float* save_mean, const float* save_invstd, void* dx, float* partial, int B, int HW, int C, int dtype, void* stream);
 /* BatchNorm1d(1, affine=False) on the ego speed (model.py:216,311), fp32 [B]. */
 int tfpp_bn1d_scalar(const float* x, float* y, float* running_mean, float* running_var, int64_t* nbt, int B, int training,
                      float momentum, float eps, void* stream);
