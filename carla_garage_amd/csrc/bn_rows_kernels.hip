@@ -46,7 +46,7 @@ __device__ __forceinline__ bool cb_thread(int cb, int rs, int CV, int& rr, int& 
 
 // ---- forward: y = f(BN(x)) -----------------------------------------------------------------------------------------------------------------
 template <typename T, bool RES, bool GATE>
-__global__ __launch_bounds__(256) void bn_apply_rows_kernel(const T* __restrict__ x, tfpp_bn_rows bn, const T* __restrict__ res,
+__global__ __launch_bounds__(256, 4) void bn_apply_rows_kernel(const T* __restrict__ x, tfpp_bn_rows bn, const T* __restrict__ res,
                                                             const float* __restrict__ gate, T* __restrict__ y, long rows, long rows_per_batch,
                                                             int relu_pre, int relu_post, int cb, int rs, int rpt) {
   constexpr int VEC = ElemTraits<T>::VEC, U = 4;
@@ -157,28 +157,31 @@ __device__ __forceinline__ void masked_grad(const uint4& gq, const uint4& yq, co
   }
 }
 
-// Sum NV per-thread accumulators over the rs row slots of a channel-block workgroup (tid = rr * cb + cc); rr == 0 threads hold the totals.
-template <int NV> __device__ __forceinline__ void cb_block_reduce(float (&acc)[NV], int cb, int rs, int rr, float* sm) {
+// Sum NV per-thread accumulators (element e of chunk column cc at acc[e], tid = rr * cb + cc) over the rs row slots of a channel-block workgroup
+// in ONE step: every thread parks its values in LDS, then thread t < NV * cb adds the rs addends of one (value, column) pair in row-slot order
+// (fixed order: deterministic).  Returns true in those threads; `tot` is the sum of value index e = t / cb ... see the callers' mapping:
+// t -> (h = t / nch, ch = t % nch) with nch = cb * VEC, value index e = h * VEC + ch % VEC, column cc = ch / VEC.
+// (The first version was a 5-level tree with a barrier per level: ~1.5 us per workgroup for rs = 32.)  sm: NV * SM_PITCH floats.
+#define CB_SM_PITCH 257
+template <int NV, int VEC> __device__ __forceinline__ bool cb_block_sum(const float (&acc)[NV], int cb, int rs, float* sm, int& h, int& ch, float& tot) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int e = 0; e < NV; ++e) sm[e * 256 + tid] = acc[e];
+  for (int e = 0; e < NV; ++e) sm[e * CB_SM_PITCH + tid] = acc[e];
   __syncthreads();
-  for (int n = rs; n > 1;) {
-    const int h = (n + 1) >> 1;
-    if (rr + h < n) {
-#pragma unroll
-      for (int e = 0; e < NV; ++e) {
-        acc[e] += sm[e * 256 + tid + h * cb];
-        sm[e * 256 + tid] = acc[e];
-      }
-    }
-    __syncthreads();
-    n = h;
-  }
+  const int nch = cb * VEC;
+  h = tid / nch;
+  ch = tid - h * nch;
+  if (h >= NV / VEC) return false;
+  const int e = h * VEC + ch % VEC, cc = ch / VEC;
+  const float* p = sm + e * CB_SM_PITCH + cc;
+  float t0 = 0.f;
+  for (int rr = 0; rr < rs; ++rr) t0 += p[rr * cb];
+  tot = t0;
+  return true;
 }
 
 template <typename T, int MASK>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_rows_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+__global__ __launch_bounds__(256, 4) void bn_bwd_reduce_rows_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                  float* __restrict__ partial, long rows, int C, int cb, int rs, int rpt) {
@@ -224,26 +227,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_rows_kernel(const T* __rest
       }
     }
   }
-  __shared__ float sm[2 * VEC * 256];
-  cb_block_reduce<2 * VEC>(acc, cb, rs, rr, sm);
-  if (active && rr == 0) {
-    float* out = partial + (size_t)blockIdx.x * 2 * C;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      out[c0 + e] = acc[e];
-      out[C + c0 + e] = acc[VEC + e];
-    }
+  __shared__ float sm[2 * VEC * CB_SM_PITCH];
+  int h, ch;
+  float tot;
+  if (cb_block_sum<2 * VEC, VEC>(acc, cb, rs, sm, h, ch, tot)) {
+    const int c = (int)blockIdx.y * cb * VEC + ch;
+    if (c < C) partial[(size_t)blockIdx.x * 2 * C + (size_t)h * C + c] = tot;
   }
 }
 
 template <typename T, int MASK, bool DRES>
-__global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+__global__ __launch_bounds__(256, 4) void bn_bwd_apply_rows_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, const float* __restrict__ partial, int nrows,
                                                                 T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, long rows, int C, int cb, int rs, int rpt) {
-  constexpr int VEC = ElemTraits<T>::VEC, U = 4;
+  constexpr int VEC = ElemTraits<T>::VEC, U = (MASK == 1 || DRES) ? 2 : 4;  // (three operand streams / two result streams: 4 rows in flight spill)
   const int CV = C / VEC;
   __shared__ double sm[512];
   __shared__ float ka_s[96], kb_s[96], kd_s[96], sc_s[96], sh_s[96];
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const T* __restr
     const int c_base = (int)blockIdx.y * cb * VEC, nch = cb * VEC, t = threadIdx.x;
     int c;
     double s0, s1;
-    if (rows_block_sum(partial, nrows, C, c_base, nch, sm, c, s0, s1)) {
+    if (rows_block_sum<16>(partial, nrows, C, c_base, nch, sm, c, s0, s1)) {  // (16: with the three operand streams of the main loop 24 spills)
       const double n = (double)rows;
       const double gm = gamma ? (double)gamma[c] : 1.0, is = (double)invstd[c], mu = (double)mean[c];
       const double A = gm * is, Bc = -gm * is * is * s1 / n, D = -gm * is * s0 / n - Bc * mu;
@@ -370,14 +370,14 @@ int launch_bn_bwd_apply_rows(const void* dy, const void* y, const void* x, const
 // One launch: the (<= 16) row-block workgroups of a sample publish their partial sums and draw a ticket per sample, the last one adds them in
 // row-block order (common.cuh).  grid = (row blocks per sample, channel blocks, B).
 template <typename T, bool DOT>
-__global__ __launch_bounds__(256) void hw_reduce_bn_kernel(const T* __restrict__ x, const T* __restrict__ dy, tfpp_bn_rows bn,
+__global__ __launch_bounds__(256, 4) void hw_reduce_bn_kernel(const T* __restrict__ x, const T* __restrict__ dy, tfpp_bn_rows bn,
                                                            float* __restrict__ partial, float* __restrict__ out, unsigned* __restrict__ tickets,
                                                            int HW, int cb, int rs, int rpt, float mul) {
   constexpr int VEC = ElemTraits<T>::VEC, U = 4;
   const int C = bn.C, CV = C / VEC;
   __shared__ double smd[512];
   __shared__ float sc_s[96], sh_s[96];
-  __shared__ float sm[VEC * 256];
+  __shared__ float sm[VEC * CB_SM_PITCH];
   int rr, cv;
   const bool active = cb_thread(cb, rs, CV, rr, cv);
   const int c0 = cv * VEC, b = blockIdx.z;
@@ -440,11 +440,13 @@ __global__ __launch_bounds__(256) void hw_reduce_bn_kernel(const T* __restrict__
       }
     }
   }
-  cb_block_reduce<VEC>(acc, cb, rs, rr, sm);
-  if (active && rr == 0) {
-    float* o = partial + ((size_t)b * gridDim.x + blockIdx.x) * C + c0;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) grid_publish(o + e, acc[e]);
+  {
+    int h, ch;
+    float tot;
+    if (cb_block_sum<VEC, VEC>(acc, cb, rs, sm, h, ch, tot)) {
+      const int c = (int)blockIdx.y * cb * VEC + ch;
+      if (c < C) grid_publish(partial + ((size_t)b * gridDim.x + blockIdx.x) * C + c, tot);
+    }
   }
   if (!grid_last_ticket(tickets + b, gridDim.x * gridDim.y)) return;
   for (int c = threadIdx.x; c < C; c += 256)
@@ -468,11 +470,11 @@ int launch_hw_reduce_bn(const void* x, const void* dy, const tfpp_bn_rows& bn, f
 // dx = dy * gate[b,c] + dpool[b,c] / HW  (complete gradient of a2 = relu(BN2(raw2))), and one row of (sum g, sum g*xhat) per workgroup with
 // g = dx (rounded) * (raw * scale + shift > 0).  grid = (row blocks per sample, channel blocks, B); partial row = b * gridDim.x + blockIdx.x.
 template <typename T>
-__global__ __launch_bounds__(256) void se_bwd_apply_bn_kernel(const T* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dpool,
+__global__ __launch_bounds__(256, 4) void se_bwd_apply_bn_kernel(const T* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dpool,
                                                               const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd, T* __restrict__ dx,
                                                               float* __restrict__ partial, int HW, int C, int cb, int rs, int rpt) {
-  constexpr int VEC = ElemTraits<T>::VEC, U = 4;
+  constexpr int VEC = ElemTraits<T>::VEC, U = 2;  // (six per-channel parameter vectors live in registers: 4 rows in flight spill)
   const int CV = C / VEC;
   int rr, cv;
   const bool active = cb_thread(cb, rs, CV, rr, cv);
@@ -526,15 +528,12 @@ __global__ __launch_bounds__(256) void se_bwd_apply_bn_kernel(const T* __restric
       }
     }
   }
-  __shared__ float sm[2 * VEC * 256];
-  cb_block_reduce<2 * VEC>(acc, cb, rs, rr, sm);
-  if (active && rr == 0) {
-    float* out = partial + ((size_t)b * gridDim.x + blockIdx.x) * 2 * C;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      out[c0 + e] = acc[e];
-      out[C + c0 + e] = acc[VEC + e];
-    }
+  __shared__ float sm[2 * VEC * CB_SM_PITCH];
+  int h, ch;
+  float tot;
+  if (cb_block_sum<2 * VEC, VEC>(acc, cb, rs, sm, h, ch, tot)) {
+    const int c = (int)blockIdx.y * cb * VEC + ch;
+    if (c < C) partial[((size_t)b * gridDim.x + blockIdx.x) * 2 * C + (size_t)h * C + c] = tot;
   }
 }
 

@@ -96,6 +96,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
   if constexpr (CV > 0) {
     constexpr int HCH = HH * HWID * CV, HIT = (HCH + 255) / 256;
     constexpr int WCH = FN * 16 * (((9 * CV * 8 + 31) / 32) * 4 + 1), WIT = (WCH + 255) / 256;
+    if constexpr (INBN) {  // the statistics of this group's (<= 64) input channels FIRST: its registers are dead before the tile loads are
+      // issued -- one more memory round trip than overlapping the two, but the kernel keeps 4 workgroups per CU (overlapped: 196 registers, 2)
+      __shared__ double in_sm[512];
+      bn_block_scale_shift<12>(p.in_bn, g * cin, cin, blockIdx.x == 0, blockIdx.x == 0 && blockIdx.y == 0, in_sm, in_sc, in_sh);
+    }
     uint4 hv[HIT], wv[WIT];
     unsigned inside_bits = 0u;
     static_assert(HIT <= 32, "one validity bit per staged chunk");
@@ -108,9 +113,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
     }
 #pragma unroll
     for (int it = 0; it < WIT; ++it) { const int q = tid + it * 256; wv[it] = q < WCH ? weight_chunk(q) : make_uint4(0, 0, 0, 0); }
-    if constexpr (INBN) {  // the statistics of this group's input channels, while the tile loads are in flight
-      __shared__ double in_sm[512];
-      bn_block_scale_shift(p.in_bn, g * cin, cin, blockIdx.x == 0, blockIdx.x == 0 && blockIdx.y == 0, in_sm, in_sc, in_sh);
+    if constexpr (INBN) {
 #pragma unroll
       for (int it = 0; it < HIT; ++it)
         if (inside_bits & (1u << it)) hv[it] = in_bn_chunk(hv[it], tid + it * 256);
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, i
   } else {
     if constexpr (INBN) {
       __shared__ double in_sm[512];
-      bn_block_scale_shift(p.in_bn, g * cin, cin, blockIdx.x == 0, blockIdx.x == 0 && blockIdx.y == 0, in_sm, in_sc, in_sh);
+      bn_block_scale_shift<12>(p.in_bn, g * cin, cin, blockIdx.x == 0, blockIdx.x == 0 && blockIdx.y == 0, in_sm, in_sc, in_sh);
     }
     for (int q = tid; q < HH * HWID * cv; q += 256) {
       bool inside = false;

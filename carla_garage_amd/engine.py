@@ -27,6 +27,40 @@ def _key(t):
   return (t.data_ptr(), t.numel())
 
 
+# Round 6: train-mode BatchNorm without finalize / coefficient launches, conv1 / conv2 outputs of a bottleneck never normalised in memory
+# (csrc/bn_rows_kernels.hip).  TFPP_BN_ROWS=0: the launch sequence of rounds 1-5 (A/B runs, comparison tests).
+BN_ROWS = os.environ.get('TFPP_BN_ROWS', '1') != '0'
+
+
+class BnView:
+  """y = [relu](BatchNorm(raw)) that exists only as the raw convolution output plus the layer's statistics: its consumers (the 3x3 LDS-halo
+  convolution and its weight gradient, the squeeze-excite passes) apply it while they load ``raw``; anything else calls
+  Engine.materialize().  On the tape it stands for the virtual tensor y under the storage key of ``raw``.  ``final`` turns True once a
+  consumer has run the finalize prologue (spec.scale / shift / save_mean / save_invstd are valid from then on)."""
+  __slots__ = ('raw', 'spec', 'relu', 'rows', 'nrows', 'count', 'final')
+
+  def __init__(self, raw, spec, relu, rows, nrows, count, final):
+    self.raw, self.spec, self.relu, self.rows, self.nrows, self.count, self.final = raw, spec, relu, rows, nrows, count, final
+
+  def data_ptr(self):
+    return self.raw.data_ptr()
+
+  def numel(self):
+    return self.raw.numel()
+
+  @property
+  def shape(self):
+    return self.raw.shape
+
+  @property
+  def dtype(self):
+    return self.raw.dtype
+
+  @property
+  def device(self):
+    return self.raw.device
+
+
 DEBUG_POISON = os.environ.get('TFPP_DEBUG_POISON', '0') == '1'
 # Engine.fast_weights_key: calls between two walks of the module tree (1: every call, +2 ms of host time per eval forward).  Only a tensor OBJECT
 # replaced by attribute assignment on a sub-module (``conv.weight = nn.Parameter(...)``) can go unnoticed in between; in-place writes, load_state_dict,
@@ -600,6 +634,8 @@ class ConvSpec:
     self.scale = self.shift = None  # folded BN (eval)
     self.row_map = None
     self.packed_for = None
+    self.stat_rows = None   # fp32 [nrows][2 * n_store]: this layer's BatchNorm statistics rows, STORED by the conv epilogue (round 6)
+    self.plan_cache = {}    # geometry -> (statistics rows of the kernel that runs it, can it normalise its source on load?)
 
 
 class Engine:
@@ -1020,33 +1056,104 @@ class Engine:
         ops.stamp(f'fwd lane{self.lanes.cur} {_fn_label(fn)}')
       if ops.NODE_HASH['on']:
         for j, o in enumerate(outs):
-          ops.node_hash(o, f'fwd lane{self.lanes.cur} {_fn_label(fn)} out{j}')
+          ops.node_hash(o.raw if isinstance(o, BnView) else o, f'fwd lane{self.lanes.cur} {_fn_label(fn)} out{j}')
 
-  def conv(self, x, key, act=ACT_NONE, res=None, x_grad=True, out_f32=False):
-    """x: [B,H,W,Cstore] NHWC.  Returns [B,Ho,Wo,n_store]."""
+  # ---- round 6: BatchNorm(train) layers whose statistics live in per-layer rows until a consumer needs them --------------------------------
+  def _bn_desc(self, v, finalize=True):
+    """tfpp_bn_rows of a BnView for the next kernel that reads it: the first consumer gets the rows (finalize prologue: it also writes scale /
+    shift / saved statistics and updates the running statistics), every later one reads scale / shift."""
+    sp = v.spec
+    if finalize and not v.final:
+      v.final = True
+      bn = sp.bn
+      return ops.bn_rows(sp.n_store, sp.scale, sp.shift, partial=v.rows, nrows=v.nrows, count=v.count, gamma=bn.weight.detach(), beta=bn.bias.detach(),
+                         rm=bn.running_mean, rv=bn.running_var, nbt=bn.num_batches_tracked, save_mean=sp.save_mean, save_invstd=sp.save_invstd,
+                         momentum=bn.momentum, eps=bn.eps)
+    assert v.final, 'a BatchNorm view is read before any consumer finalized its statistics'
+    return ops.bn_rows(sp.n_store, sp.scale, sp.shift)
+
+  def materialize(self, v):
+    """The normalised tensor of a BnView in memory, for consumers that cannot apply it while loading (LDS-DMA GEMMs, strided 3x3 weight
+    gradients, maps narrower than a halo tile)."""
+    if not isinstance(v, BnView):
+      return v
+    y = ops.bn_apply_rows(v.raw, self._bn_desc(v), relu_pre=v.relu)
+    if self.tape is not None:
+      self.rec([y], [v], lambda dy: dy)  # (the producer's backward takes d(y) and rebuilds the ReLU mask from raw)
+    return y
+
+  def _conv_plan(self, s, xt, geo, want_grad):
+    """(statistics rows of the kernel that runs this layer, can that kernel -- and the layer's weight-gradient kernel -- normalise the source
+    while loading it?) -- cached per geometry."""
+    k = (tuple(xt.shape), xt.dtype, want_grad)
+    plan = s.plan_cache.get(k)
+    if plan is None:
+      nrows = ops.conv_gemm(xt, s.wp, None, stats_rows_query=True, **geo) if s.bn is not None else 0
+      on_load = xt.dtype == torch.bfloat16 and ops.conv_gemm(xt, s.wp, None, in_bn_query=True, **geo)
+      if on_load and want_grad:
+        on_load = ops.conv_wgrad_x_bn_ok(xt, xt, s.scale if s.scale is not None else torch.empty(1, device=xt.device), B=geo['B'], Hs=geo['Hs'], Ws=geo['Ws'],
+                                         Cs=geo['Cs'], Hd=geo['Hd'], Wd=geo['Wd'], Cd=geo['Cd'], R=geo['R'], S=geo['S'], stride=geo['stride'], pad=geo['pad'],
+                                         G=geo['G'], ks_g=geo['ks_g'], n_g=geo['n_g'], c_real=s.cin_g)
+      plan = s.plan_cache[k] = (nrows, bool(on_load))
+    return plan
+
+  def conv(self, x, key, act=ACT_NONE, res=None, x_grad=True, out_f32=False, lazy=False):
+    """x: [B,H,W,Cstore] NHWC, or a BnView (the un-normalised output of the BatchNorm layer in front).  Returns [B,Ho,Wo,n_store]; with
+    ``lazy`` a train-mode BatchNorm layer returns a BnView instead of writing the normalised tensor (the caller's next operator consumes it)."""
     s = self.specs[key]
-    B, H, W, Cs = x.shape
+    xv = x if isinstance(x, BnView) else None
+    xt = xv.raw if xv is not None else x
+    B, H, W, Cs = xt.shape
     k, st, pd, G = s.k, s.stride, s.pad, s.groups
     Ho, Wo = (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
-    odt = F32 if (out_f32 or s.head) else x.dtype
+    odt = F32 if (out_f32 or s.head) else xt.dtype
     geo = dict(B=B, Hs=H, Ws=W, Cs=Cs, Hd=Ho, Wd=Wo, Cd=s.n_store, R=k, S=k, stride=st, pad=pd, G=G, ks_g=Cs // G,
                n_g=s.n_store // G)
     bn_train = s.bn is not None and self.training and s.bn.training
+    sync = self.sync_bn and self.sync_world > 1
+    want_grad = self.tape is not None and s.weight.requires_grad
+    if xv is not None and not self._conv_plan(s, xt, geo, want_grad)[1]:
+      x, xv = self.materialize(xv), None
+      xt = x
+    in_kw = dict(in_bn=self._bn_desc(xv), in_relu=xv.relu) if xv is not None else {}
+    rows_path = bn_train and BN_ROWS and not sync and act in (ACT_NONE, ACT_RELU) and odt == xt.dtype and s.n_store == s.cout
+    view = None
     if s.bn is None:
-      y = torch.empty((B, Ho, Wo, s.n_store), device=x.device, dtype=odt)
-      ops.conv_gemm(x, s.wp, y, act=act, shift=s.bias_pad, res=res, **geo)
+      y = torch.empty((B, Ho, Wo, s.n_store), device=xt.device, dtype=odt)
+      ops.conv_gemm(xt, s.wp, y, act=act, shift=s.bias_pad, res=res, **in_kw, **geo)
       raw = None
     elif not bn_train:
       if self.tape is not None:
         raise NotImplementedError('gradients through eval-mode BatchNorm are not implemented on the HIP path (round 1); '
                                   'call model.train() or run under torch.no_grad()')
-      y = torch.empty((B, Ho, Wo, s.n_store), device=x.device, dtype=odt)
-      ops.conv_gemm(x, s.wp, y, act=act, scale=s.scale, shift=s.shift, res=res, **geo)
+      y = torch.empty((B, Ho, Wo, s.n_store), device=xt.device, dtype=odt)
+      ops.conv_gemm(xt, s.wp, y, act=act, scale=s.scale, shift=s.shift, res=res, **in_kw, **geo)
       raw = None
+    elif rows_path:
+      # conv (statistics rows in the epilogue) and nothing else: the finalize step runs in the prologue of whoever reads the result first
+      raw = torch.empty((B, Ho, Wo, s.n_store), device=xt.device, dtype=odt)
+      nrows = self._conv_plan(s, xt, geo, want_grad)[0]
+      if nrows <= ops.BN_ROWS_MAX:
+        if s.stat_rows is None or s.stat_rows.numel() < nrows * 2 * s.n_store or s.stat_rows.device != xt.device:
+          if xt.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('BatchNorm statistics rows must be allocated before hipGraph capture: run one eager warm-up step first')
+          s.stat_rows = torch.empty(nrows * 2 * s.n_store, device=xt.device, dtype=F32)
+        ops.conv_gemm(xt, s.wp, raw, stats_store=s.stat_rows, **in_kw, **geo)
+        view = BnView(raw, s, act == ACT_RELU, s.stat_rows, nrows, B * Ho * Wo, False)
+      else:  # large feature maps (stage 1, the stems): too many rows for a prologue -- the finalize launch of rounds 1-5
+        nrows, acc = ops.conv_gemm(xt, s.wp, raw, stats_acc=True, **in_kw, **geo)
+        ops.bn_finalize_partials(acc, nrows, s.bn.weight.detach(), s.bn.bias.detach(), s.bn.running_mean, s.bn.running_var,
+                                 s.bn.num_batches_tracked, s.scale, s.shift, s.save_mean, s.save_invstd, B * Ho * Wo,
+                                 s.bn.momentum, s.bn.eps)
+        view = BnView(raw, s, act == ACT_RELU, None, 0, B * Ho * Wo, True)
+      if lazy and res is None:
+        y = view
+      else:
+        y = ops.bn_apply_rows(raw, self._bn_desc(view), res=res, relu_pre=(act == ACT_RELU and res is None), relu_post=(act == ACT_RELU and res is not None))
     else:
-      raw = torch.empty((B, Ho, Wo, s.n_store), device=x.device, dtype=odt)
-      nrows, acc = ops.conv_gemm(x, s.wp, raw, stats_acc=True, **geo)  # BN statistics fused into the epilogue
-      if self.sync_bn and self.sync_world > 1:  # train.py:511-512: statistics over the batches of all ranks (one all-reduce of 2C doubles per layer)
+      raw = torch.empty((B, Ho, Wo, s.n_store), device=xt.device, dtype=odt)
+      nrows, acc = ops.conv_gemm(xt, s.wp, raw, stats_acc=True, **in_kw, **geo)  # BN statistics fused into the epilogue
+      if sync:  # train.py:511-512: statistics over the batches of all ranks (one all-reduce of 2C doubles per layer)
         ops.bn_sync_finalize(acc, nrows, s.bn.weight.detach(), s.bn.bias.detach(), s.bn.running_mean, s.bn.running_var, s.bn.num_batches_tracked,
                              s.scale, s.shift, s.save_mean, s.save_invstd, B * Ho * Wo, self.sync_world, self.sync_group, s.ws, s.bn.momentum, s.bn.eps)
       else:
@@ -1057,6 +1164,8 @@ class Engine:
       if self.tape is not None and act in (ACT_NONE, ACT_RELU):
         self._bn_of[_key(y)] = (s, raw, act == ACT_RELU)  # lets the producer of d(y) fuse this layer's BatchNorm-backward sums
     if self.tape is not None:
+      xin = xv if xv is not None else x  # what the tape knows the input as
+      wg_kw = dict(x_scale=xv.spec.scale, x_shift=xv.spec.shift, x_relu=xv.relu) if xv is not None else {}
 
       def bwd(dy):
         self.side.label = key
@@ -1070,7 +1179,7 @@ class Engine:
               if s.n_store == s.cout:
                 ops.colsum(dz, self.g(s.bias), B * Ho * Wo, s.cout, s.n_store)
               else:
-                tmp = ops.zeros(s.n_store, F32, x.device)
+                tmp = ops.zeros(s.n_store, F32, xt.device)
                 ops.colsum(dz, tmp, B * Ho * Wo, s.n_store, s.n_store)
                 ops.copy_rows(tmp, self.g(s.bias), 1, s.cout, 0, 0, 0, 0, accumulate=True)
 
@@ -1078,9 +1187,22 @@ class Engine:
             if _SIDE_CHECK:
               self.side.outs.append((key, dz, self.g(s.bias), s.cout))
           dconv = dz
+        elif view is not None:
+          # reduce (unless the kernel that completed dy already emitted the sums) -> apply with the coefficient step in its prologue.  The ReLU
+          # mask comes from the forward output where one exists in memory with a residual folded in, otherwise it is rebuilt from raw
+          pre = self._bn_pre.pop(_key(y), None)
+          relu = act == ACT_RELU
+          mask = ops.MASK_NONE if not relu else (ops.MASK_Y if res is not None else ops.MASK_RAW)
+          yk = y if mask == ops.MASK_Y else None
+          if pre is not None and pre[2] is dy:
+            partial, nrows_b = pre[0], pre[1]
+          else:
+            partial, nrows_b = ops.bn_bwd_reduce_rows(dy, yk, raw, s.scale, s.shift, s.save_mean, s.save_invstd, mask)
+          dconv, dres = ops.bn_bwd_apply_rows2(dy, yk, raw, s.scale, s.shift, s.bn.weight.detach(), s.save_mean, s.save_invstd, partial, nrows_b,
+                                               self.g(s.bn.weight), self.g(s.bn.bias), mask, want_dres=res is not None)
         elif bn_train:
           pre = self._bn_pre.pop(_key(y), None)
-          if self.sync_bn and self.sync_world > 1:
+          if sync:
             dconv, dres = ops.bn_bwd_sync(dy, y, raw, s.bn.weight.detach(), s.save_mean, s.save_invstd, self.g(s.bn.weight), self.g(s.bn.bias),
                                           relu_mask=(act == ACT_RELU), world=self.sync_world, group=self.sync_group, want_dres=res is not None)
           elif pre is not None and pre[2] is dy:  # the kernel that wrote dy already reduced sum g / sum g*xhat per tile (one pass saved)
@@ -1089,22 +1211,22 @@ class Engine:
           else:
             dconv, dres = ops.bn_bwd(dy, y, raw, s.bn.weight.detach(), s.save_mean, s.save_invstd, None, self.g(s.bn.weight),
                                      self.g(s.bn.bias), relu_mask=(act == ACT_RELU), want_dres=res is not None)
-        gsrc = dconv if dconv.dtype == x.dtype else ops.cast(dconv, x.dtype)
+        gsrc = dconv if dconv.dtype == xt.dtype else ops.cast(dconv, xt.dtype)
         if s.weight.requires_grad:
           self.side.run(Tape.current, lambda: ops.conv_wgrad(
-              gsrc, x, self.g(s.weight), B=B, Hs=H, Ws=W, Cs=Cs, Hd=Ho, Wd=Wo, Cd=s.n_store, R=k, S=k, stride=st, pad=pd, G=G,
-              ks_g=Cs // G, n_g=s.n_store // G, c_real=s.cin_g, row_map=s.row_map), gsrc, x)
+              gsrc, xt, self.g(s.weight), B=B, Hs=H, Ws=W, Cs=Cs, Hd=Ho, Wd=Wo, Cd=s.n_store, R=k, S=k, stride=st, pad=pd, G=G,
+              ks_g=Cs // G, n_g=s.n_store // G, c_real=s.cin_g, row_map=s.row_map, **wg_kw), gsrc, xt)
         dx = None
         if x_grad:
-          dx = torch.empty((B, H, W, Cs), device=x.device, dtype=x.dtype)
+          dx = torch.empty((B, H, W, Cs), device=xt.device, dtype=xt.dtype)
           # a gradient already pending for x (the other path of a residual / FPN fan-out) is added in the GEMM epilogue
-          pend = Tape.current.take_pending(x, dx)
+          pend = Tape.current.take_pending(xin, dx)
           dgeo = dict(B=B, Hs=Ho, Ws=Wo, Cs=s.n_store, Hd=H, Wd=W, Cd=Cs, R=k, S=k, stride=st, pad=pd, G=G, ks_g=s.n_store // G, n_g=Cs // G,
                       mode=1, res=pend)
           ops.conv_gemm(gsrc, s.wt, dx, **dgeo)
         return dx, dres
 
-      self.rec([y], [x, res], bwd)
+      self.rec([y], [xin, res], bwd)
     return y
 
   def linear(self, x, key, act=ACT_NONE, res=None, x_grad=True, out_f32=False):
@@ -1265,10 +1387,12 @@ class Engine:
 
   # ------------------------------------------------------------------------------------------------ RegNet
   def bottleneck(self, x, key, blk):
-    """RegNet-Y block (timm Bottleneck)."""
+    """RegNet-Y block (timm Bottleneck).  Round 6: conv1 and conv2 hand their consumers the raw convolution output plus
+    the BatchNorm statistics (BnView): conv2 normalises conv1's output while staging its halo tiles, the squeeze-excite passes normalise
+    conv2's; the only normalised tensors written are the gated input of conv3 and the block output."""
     sc = self.conv(x, key + '.downsample') if blk.downsample is not None else x
-    y = self.conv(x, key + '.conv1', act=ACT_RELU)
-    y = self.conv(y, key + '.conv2', act=ACT_RELU)
+    y = self.conv(x, key + '.conv1', act=ACT_RELU, lazy=True)
+    y = self.conv(y, key + '.conv2', act=ACT_RELU, lazy=True)
     y = self.squeeze_excite(y, blk.se)
     return self.conv(y, key + '.conv3', act=ACT_RELU, res=sc)
 
@@ -1276,6 +1400,27 @@ class Engine:
     B, H, W, C = x.shape
     w1, b1 = se.fc1.weight.detach().view(se.fc1.weight.shape[0], C), se.fc1.bias.detach()
     w2, b2 = se.fc2.weight.detach().view(C, -1), se.fc2.bias.detach()
+    if isinstance(x, BnView) and (not x.relu or B > 64):
+      x = self.materialize(x)
+    if isinstance(x, BnView):
+      # x = relu(BN2(raw2)) exists only as (raw2, statistics): squeeze from raw2 (finalize prologue), then ONE pass writes the gated tensor
+      raw, sL = x.raw, x.spec
+      pool = ops.mean_hw_bn(raw, self._bn_desc(x))
+      hidden, gate = ops.se_gate_fwd(pool, w1, b1, w2, b2)
+      y = ops.bn_apply_rows(raw, self._bn_desc(x), gate=gate, rows_per_batch=H * W, relu_pre=True)
+      if self.tape is not None:
+
+        def bwd_view(dy):
+          dgate = ops.se_dgate_bn(dy, raw, sL.scale, sL.shift)
+          dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
+                                  self.g(se.fc2.weight), self.g(se.fc2.bias))
+          # dx is the complete gradient of relu(BN2(raw2)) (its only consumer is this block): the BatchNorm-backward sums come with it
+          dx, partial, nrows = ops.se_bwd_apply_bn(dy, gate, dpool, raw, sL.scale, sL.shift, sL.save_mean, sL.save_invstd)
+          self._bn_pre[_key(x)] = (partial, nrows, dx)
+          return dx
+
+        self.rec([y], [x], bwd_view)
+      return y
     pool = ops.mean_hw(x)
     hidden, gate = ops.se_gate_fwd(pool, w1, b1, w2, b2)
     y = ops.affine_act(x, gate=gate, rows_per_batch=H * W)

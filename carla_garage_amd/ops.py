@@ -103,7 +103,7 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
   p.src_ld = src_ld if src_ld is not None else Cs
   p.dst_ld = dst_ld if dst_ld is not None else Cd
   p.res_ld = res_ld if res_ld is not None else p.dst_ld
-  p.dst_f32 = int(dst.dtype == torch.float32 and src.dtype != torch.float32)
+  p.dst_f32 = int(dst is not None and dst.dtype == torch.float32 and src.dtype != torch.float32)  # (dst None: geometry queries)
   ws = splitk_workspace(src.device)
   p.splitk_ws, p.splitk_ws_floats, p.splitk = ptr(ws), ws.numel(), 0
   if _NO_CONV_SPLITK:  # debugging aid: no K split for forward / data-gradient GEMMs while the weight-gradient slices keep their workspace
@@ -240,8 +240,13 @@ def wgrad_batch_end():
   lib.tfpp_conv_wgrad_batch(arr, len(batch), BF16, stream())
 
 
+_DBG_SKIP = set(_os.environ.get('TFPP_DEBUG_SKIP_OPS', '').split(','))  # timing experiments only (results are wrong): which side-lane work costs what?
+
+
 def conv_wgrad(dy, x, dw, **kw):
   p = _wgrad_params(dy, x, dw, **kw)
+  if _DBG_SKIP and (('wgrad_f32' in _DBG_SKIP and dy.dtype == torch.float32) or ('wgrad_narrow' in _DBG_SKIP and dy.dtype != torch.float32 and (p.n_g <= 32 or p.R * p.S * p.ks_g <= 32) and p.R == 1) or ('wgrad_3x3' in _DBG_SKIP and p.R == 3) or ('wgrad_all' in _DBG_SKIP)):
+    return dw
   if WGRAD_BATCH is not None and dy.dtype == torch.bfloat16:
     WGRAD_BATCH.append((p, (dy, x, dw, kw.get('row_map'), kw.get('col_map'), kw.get('x_scale'), kw.get('x_shift'))))
     return dw
@@ -860,6 +865,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
 
 
 def layernorm_param_grad(dy, x, mean, rstd, dgamma, dbeta):
+  if 'ln_param' in _DBG_SKIP:
+    return
   c = x.shape[-1]
   lib.tfpp_layernorm_param_grad(ptr(_chk(dy)), ptr(_chk(x)), ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), ptr(gridsum_scratch(x.device)),
                                 x.numel() // c, c, dt(x), stream())
@@ -1025,6 +1032,8 @@ def mul_pixmask(x, m, hw, out=None):
 
 
 def colsum(x, out, rows, c, ld=None):
+  if 'colsum' in _DBG_SKIP:
+    return out
   lib.tfpp_colsum(ptr(x), ptr(out), ptr(reduce_scratch(1, c, x.device)), rows, c, ld or c, dt(x), stream())
   return out
 
