@@ -366,11 +366,11 @@ int launch_bn_bwd_apply_rows(const void* dy, const void* y, const void* x, const
 }
 
 // ---- squeeze-excite passes around a tensor that exists only as (raw, statistics) -----------------------------------------------------------
-// pool (DOT = false): out[b][c] = mul * sum_hw relu(x * scale + shift);  dgate (DOT = true): out[b][c] = sum_hw dy * relu(x * scale + shift).
+// pool: out[b][c] = mul * sum_hw relu(x * scale + shift)  (the squeeze of a conv2 output that is never normalised in memory).
 // One launch: the (<= 16) row-block workgroups of a sample publish their partial sums and draw a ticket per sample, the last one adds them in
 // row-block order (common.cuh).  grid = (row blocks per sample, channel blocks, B).
-template <typename T, bool DOT>
-__global__ __launch_bounds__(256, 4) void hw_reduce_bn_kernel(const T* __restrict__ x, const T* __restrict__ dy, tfpp_bn_rows bn,
+template <typename T>
+__global__ __launch_bounds__(256, 4) void hw_reduce_bn_kernel(const T* __restrict__ x, tfpp_bn_rows bn,
                                                            float* __restrict__ partial, float* __restrict__ out, unsigned* __restrict__ tickets,
                                                            int HW, int cb, int rs, int rpt, float mul) {
   constexpr int VEC = ElemTraits<T>::VEC, U = 4;
@@ -383,16 +383,12 @@ __global__ __launch_bounds__(256, 4) void hw_reduce_bn_kernel(const T* __restric
   const int c0 = cv * VEC, b = blockIdx.z;
   const long r0 = (long)blockIdx.x * rs * rpt + rr;
   const T* xb = x + (size_t)b * HW * C;
-  const T* gb = DOT ? dy + (size_t)b * HW * C : nullptr;
-  uint4 xq[U], gq[U];
+  uint4 xq[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const long r = r0 + (long)u * rs;
-    xq[u] = gq[u] = make_uint4(0, 0, 0, 0);
-    if (active && u < rpt && r < HW) {
-      xq[u] = *reinterpret_cast<const uint4*>(xb + (size_t)r * C + c0);
-      if (DOT) gq[u] = *reinterpret_cast<const uint4*>(gb + (size_t)r * C + c0);
-    }
+    xq[u] = make_uint4(0, 0, 0, 0);
+    if (active && u < rpt && r < HW) xq[u] = *reinterpret_cast<const uint4*>(xb + (size_t)r * C + c0);
   }
   bn_block_scale_shift(bn, (int)blockIdx.y * cb * VEC, cb * VEC, blockIdx.x == 0 && b == 0, blockIdx.x == 0 && blockIdx.y == 0 && b == 0, smd, sc_s,
                        sh_s);
@@ -404,39 +400,30 @@ __global__ __launch_bounds__(256, 4) void hw_reduce_bn_kernel(const T* __restric
     const int cl = ((int)threadIdx.x - rr * cb) * VEC;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { sc[e] = sc_s[cl + e]; sh[e] = sh_s[cl + e]; }
-    auto body = [&](const uint4& x4, const uint4& g4) {
-      float v[VEC], g[VEC];
+    auto body = [&](const uint4& x4) {
+      float v[VEC];
       unpack16<T>(x4, v);
-      if (DOT) unpack16<T>(g4, g);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        float t = v[e] * sc[e] + sh[e];
-        t = t > 0.f ? t : 0.f;
-        if (DOT) {  // (the forward pass multiplied the UNROUNDED activation by the gate: a2 = round(relu(t) * gate))
-          acc[e] += g[e] * t;
-        } else {
-          acc[e] += t;
-        }
+        const float t = v[e] * sc[e] + sh[e];
+        acc[e] += t > 0.f ? t : 0.f;
       }
     };
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long r = r0 + (long)u * rs;
-      if (u < rpt && r < HW) body(xq[u], gq[u]);
+      if (u < rpt && r < HW) body(xq[u]);
     }
     for (int i = U; i < rpt; i += U) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long r = r0 + (long)(i + u) * rs;
-        if (i + u < rpt && r < HW) {
-          xq[u] = *reinterpret_cast<const uint4*>(xb + (size_t)r * C + c0);
-          if (DOT) gq[u] = *reinterpret_cast<const uint4*>(gb + (size_t)r * C + c0);
-        }
+        if (i + u < rpt && r < HW) xq[u] = *reinterpret_cast<const uint4*>(xb + (size_t)r * C + c0);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long r = r0 + (long)(i + u) * rs;
-        if (i + u < rpt && r < HW) body(xq[u], gq[u]);
+        if (i + u < rpt && r < HW) body(xq[u]);
       }
     }
   }
@@ -454,15 +441,14 @@ __global__ __launch_bounds__(256, 4) void hw_reduce_bn_kernel(const T* __restric
 }
 
 template <typename T>
-int launch_hw_reduce_bn(const void* x, const void* dy, const tfpp_bn_rows& bn, float* out, float* scratch, float* tickets, int B, int HW, float mulv,
+int launch_hw_reduce_bn(const void* x, const tfpp_bn_rows& bn, float* out, float* scratch, float* tickets, int B, int HW, float mulv,
                         hipStream_t st) {
   constexpr int VEC = ElemTraits<T>::VEC;
   if (bn.C % VEC || B < 1 || B > TFPP_GRIDSUM_TICKETS) return TFPP_EINVAL;
   const CbLayout l = cb_layout(bn.C / VEC);
   const int rpt = cb_rows_per_thread(HW, l.rs, 4, 16);  // <= 16 row blocks per sample: one batch of agent-scope loads per channel in the tail
   dim3 grid((unsigned)((HW + l.rs * rpt - 1) / (l.rs * rpt)), (unsigned)l.ncb, (unsigned)B);
-  if (dy) hipLaunchKernelGGL((hw_reduce_bn_kernel<T, true>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, bn, scratch, out, reinterpret_cast<unsigned*>(tickets), HW, l.cb, l.rs, rpt, mulv);
-  else hipLaunchKernelGGL((hw_reduce_bn_kernel<T, false>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, bn, scratch, out, reinterpret_cast<unsigned*>(tickets), HW, l.cb, l.rs, rpt, mulv);
+  hipLaunchKernelGGL((hw_reduce_bn_kernel<T>), grid, dim3(256), 0, st, (const T*)x, bn, scratch, out, reinterpret_cast<unsigned*>(tickets), HW, l.cb, l.rs, rpt, mulv);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -590,20 +576,8 @@ extern "C" int tfpp_mean_hw_bn(const void* x, const tfpp_bn_rows* bn, float* out
   if (!x || !bn || !out || !scratch || !ticket_scratch || !bn->scale || !bn->shift || HW < 1) return TFPP_EINVAL;
   if (bn->partial && (bn->nrows < 1 || bn->count < 1)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  return dtype == TFPP_F32 ? launch_hw_reduce_bn<float>(x, nullptr, *bn, out, scratch, ticket_scratch, B, HW, 1.f / (float)HW, st)
-                           : launch_hw_reduce_bn<bf16_t>(x, nullptr, *bn, out, scratch, ticket_scratch, B, HW, 1.f / (float)HW, st);
-}
-
-extern "C" int tfpp_se_dgate_bn(const void* dy, const void* x, const float* scale, const float* shift, float* dgate, float* scratch,
-                                float* ticket_scratch, int B, int HW, int C, int dtype, void* stream) {
-  if (!dy || !x || !scale || !shift || !dgate || !scratch || !ticket_scratch || HW < 1) return TFPP_EINVAL;
-  tfpp_bn_rows bn = {};
-  bn.C = C;
-  bn.scale = const_cast<float*>(scale);
-  bn.shift = const_cast<float*>(shift);
-  hipStream_t st = (hipStream_t)stream;
-  return dtype == TFPP_F32 ? launch_hw_reduce_bn<float>(x, dy, bn, dgate, scratch, ticket_scratch, B, HW, 1.f, st)
-                           : launch_hw_reduce_bn<bf16_t>(x, dy, bn, dgate, scratch, ticket_scratch, B, HW, 1.f, st);
+  return dtype == TFPP_F32 ? launch_hw_reduce_bn<float>(x, *bn, out, scratch, ticket_scratch, B, HW, 1.f / (float)HW, st)
+                           : launch_hw_reduce_bn<bf16_t>(x, *bn, out, scratch, ticket_scratch, B, HW, 1.f / (float)HW, st);
 }
 
 extern "C" int tfpp_se_bwd_apply_bn_rows(int B, int HW, int C, int dtype) {

@@ -1058,7 +1058,7 @@ extern "C" int tfpp_se_gate_fwd(const float* pool, const float* w1, const float*
 #define SE_DZ1_GROUPS 16
 __global__ __launch_bounds__(64 * SE_DZ1_GROUPS) void se_dz1_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
                                                                     const float* __restrict__ hidden, const float* __restrict__ w2,
-                                                                    float* __restrict__ dz1, int B, int C, int RD) {
+                                                                    float* __restrict__ dz1, int B, int C, int RD, int premul) {
   constexpr int NG = SE_DZ1_GROUPS, U = 12;
   const int jl = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const int b = blockIdx.y, j = (int)blockIdx.x * 64 + jl;
@@ -1075,11 +1075,11 @@ __global__ __launch_bounds__(64 * SE_DZ1_GROUPS) void se_dz1_kernel(const float*
 #pragma unroll
     for (int u = 0; u < U; ++u) { wv[u] = wc[(size_t)(c + u * NG) * RD]; gv[u] = g[c + u * NG]; dv[u] = dg[c + u * NG]; }
 #pragma unroll
-    for (int u = 0; u < U; ++u) s[u] += dv[u] * gv[u] * (1.f - gv[u]) * wv[u];
+    for (int u = 0; u < U; ++u) s[u] += dv[u] * (premul ? 1.f : gv[u]) * (1.f - gv[u]) * wv[u];
   }
   for (; c < C; c += NG) {
     const float g0 = g[c];
-    s[0] += dg[c] * g0 * (1.f - g0) * wc[(size_t)c * RD];
+    s[0] += dg[c] * (premul ? 1.f : g0) * (1.f - g0) * wc[(size_t)c * RD];
   }
   float t = 0.f;
 #pragma unroll
@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(64 * SE_DZ1_GROUPS) void se_dz1_kernel(const float*
 __global__ void se_param_grads_kernel(const float* __restrict__ dgate, const float* __restrict__ gate, const float* __restrict__ hidden,
                                       const float* __restrict__ pool, const float* __restrict__ w1, const float* __restrict__ dz1,
                                       float* __restrict__ dpool, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
-                                      float* __restrict__ db2, int B, int C, int RD, int nblk_dw) {
+                                      float* __restrict__ db2, int B, int C, int RD, int nblk_dw, int premul) {
   if ((int)blockIdx.x >= nblk_dw) {
     const int ctiles = (C + 15) / 16;
     const int t = blockIdx.x - nblk_dw, b = t / ctiles, c = (t - b * ctiles) * 16 + (threadIdx.x & 15), js = threadIdx.x >> 4;
@@ -1128,7 +1128,7 @@ __global__ void se_param_grads_kernel(const float* __restrict__ dgate, const flo
     float s = 0.f, sb = 0.f;
     for (int b = 0; b < B; ++b) {
       const float g = gate[(size_t)b * C + c];
-      const float gd = dgate[(size_t)b * C + c] * g * (1.f - g);
+      const float gd = dgate[(size_t)b * C + c] * (premul ? 1.f : g) * (1.f - g);
       s += gd * hidden[(size_t)b * RD + j];
       sb += gd;
     }
@@ -1148,18 +1148,30 @@ __global__ void se_param_grads_kernel(const float* __restrict__ dgate, const flo
   }
 }
 
-extern "C" int tfpp_se_gate_bwd(const float* dgate, const float* gate, const float* hidden, const float* pool, const float* w1,
-                                const float* w2, float* dz1_scratch, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int B,
-                                int C, int RD, void* stream) {
+static int se_gate_bwd_impl(const float* dgate, const float* gate, const float* hidden, const float* pool, const float* w1,
+                           const float* w2, float* dz1_scratch, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int B,
+                           int C, int RD, int premul, void* stream) {
   if (!dgate || !gate || !hidden || !pool || !dpool || !dz1_scratch) return TFPP_EINVAL;
   if (2l * C * RD >= (1l << 31)) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(se_dz1_kernel, dim3((unsigned)((RD + 63) / 64), (unsigned)B), dim3(64 * SE_DZ1_GROUPS), 0, st, dgate, gate, hidden, w2, dz1_scratch, B, C, RD);
+  hipLaunchKernelGGL(se_dz1_kernel, dim3((unsigned)((RD + 63) / 64), (unsigned)B), dim3(64 * SE_DZ1_GROUPS), 0, st, dgate, gate, hidden, w2, dz1_scratch, B, C, RD, premul);
   const int nblk_dw = (int)((2l * C * RD + 255) / 256);
   hipLaunchKernelGGL(se_param_grads_kernel, dim3((unsigned)(nblk_dw + B * ((C + 15) / 16))), dim3(256), 0, st, dgate, gate, hidden, pool, w1,
-                     dz1_scratch, dpool, dw1, db1, dw2, db2, B, C, RD, nblk_dw);
+                     dz1_scratch, dpool, dw1, db1, dw2, db2, B, C, RD, nblk_dw, premul);
   TFPP_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int tfpp_se_gate_bwd(const float* dgate, const float* gate, const float* hidden, const float* pool, const float* w1,
+                                const float* w2, float* dz1_scratch, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int B,
+                                int C, int RD, void* stream) {
+  return se_gate_bwd_impl(dgate, gate, hidden, pool, w1, w2, dz1_scratch, dpool, dw1, db1, dw2, db2, B, C, RD, 0, stream);
+}
+// the same with dgate_g = dgate * gate handed in (= sum_hw dy * y for the GATED tensor y the forward pass wrote: tfpp.h)
+extern "C" int tfpp_se_gate_bwd_premul(const float* dgate_g, const float* gate, const float* hidden, const float* pool, const float* w1,
+                                       const float* w2, float* dz1_scratch, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int B,
+                                       int C, int RD, void* stream) {
+  return se_gate_bwd_impl(dgate_g, gate, hidden, pool, w1, w2, dz1_scratch, dpool, dw1, db1, dw2, db2, B, C, RD, 1, stream);
 }
 
 // dx = dy * gate[b,c] + dpool[b,c] / HW

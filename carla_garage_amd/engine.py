@@ -1411,9 +1411,11 @@ class Engine:
       if self.tape is not None:
 
         def bwd_view(dy):
-          dgate = ops.se_dgate_bn(dy, raw, sL.scale, sL.shift)
-          dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
-                                  self.g(se.fc2.weight), self.g(se.fc2.bias))
+          # dgate * gate = sum_hw dy * y with the gated tensor y as conv3 read it (the gate's gradient is a residual of cancelling sums: it
+          # has to be taken on the values the forward pass used, roundings included -- tfpp.h tfpp_se_gate_bwd_premul)
+          dgate_g = ops.se_dgate(dy, y)
+          dpool = ops.se_gate_bwd(dgate_g, gate, hidden, pool, w1, w2, self.g(se.fc1.weight), self.g(se.fc1.bias),
+                                  self.g(se.fc2.weight), self.g(se.fc2.bias), premul=True)
           # dx is the complete gradient of relu(BN2(raw2)) (its only consumer is this block): the BatchNorm-backward sums come with it
           dx, partial, nrows = ops.se_bwd_apply_bn(dy, gate, dpool, raw, sL.scale, sL.shift, sL.save_mean, sL.save_invstd)
           self._bn_pre[_key(x)] = (partial, nrows, dx)

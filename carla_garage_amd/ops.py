@@ -638,15 +638,6 @@ def mean_hw_bn(x, bn):
   return out
 
 
-def se_dgate_bn(dy, x, scale, shift):
-  b, h, w, c = x.shape
-  assert b <= 64
-  out = torch.empty((b, c), device=x.device, dtype=torch.float32)
-  lib.tfpp_se_dgate_bn(ptr(_chk(dy)), ptr(_chk(x)), ptr(scale), ptr(shift), ptr(out), ptr(reduce_scratch(b, c, x.device)), ptr(gridsum_scratch(x.device)), b,
-                       h * w, c, dt(x), stream())
-  return out
-
-
 def se_bwd_apply_bn(dy, gate, dpool, x, scale, shift, save_mean, save_invstd):
   """dx = dy * gate + dpool / HW and the BatchNorm-backward rows of the layer in front (mask recomputed from the raw tensor x);
   returns (dx, partial rows, nrows)."""
@@ -767,13 +758,14 @@ def se_dgate(dy, x):
   return out
 
 
-def se_gate_bwd(dgate, gate, hidden, pool, w1, w2, dw1, db1, dw2, db2):
+def se_gate_bwd(dgate, gate, hidden, pool, w1, w2, dw1, db1, dw2, db2, premul=False):
+  """premul: ``dgate`` is dgate * gate = sum_hw dy * (gated tensor) (tfpp_se_gate_bwd_premul)"""
   b, c = gate.shape
   rd = hidden.shape[1]
   dpool = torch.empty_like(gate)
   scratch = torch.empty_like(hidden)
-  lib.tfpp_se_gate_bwd(ptr(dgate), ptr(gate), ptr(hidden), ptr(pool), ptr(w1), ptr(w2), ptr(scratch), ptr(dpool), ptr(dw1), ptr(db1),
-                       ptr(dw2), ptr(db2), b, c, rd, stream())
+  fn = lib.tfpp_se_gate_bwd_premul if premul else lib.tfpp_se_gate_bwd
+  fn(ptr(dgate), ptr(gate), ptr(hidden), ptr(pool), ptr(w1), ptr(w2), ptr(scratch), ptr(dpool), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), b, c, rd, stream())
   return dpool
 
 

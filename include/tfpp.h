@@ -414,12 +414,9 @@ int tfpp_bn_bwd_apply_rows2(const void* dy, const void* y, const void* x, const 
                             float* dgamma, float* dbeta, int64_t rows, int C, int mask, int dtype, void* stream);
 /* Squeeze-excite around a conv2 output that exists only as (raw, BatchNorm statistics) -- a2 = relu(BN2(raw2)) is never written:
  * mean_hw_bn: pool[b][c] = mean over HW of relu(x*scale+shift) (bn->partial != NULL: finalize prologue); one launch (ticket per sample).
- * se_dgate_bn: dgate[b][c] = sum over HW of dy * relu(x*scale+shift).
  * se_bwd_apply_bn: dx = dy*gate[b,c] + dpool[b,c]/HW (the complete gradient of a2), and rows [2*C] of (sum g, sum g*xhat), g = dx (rounded)
  *   * (x*scale+shift > 0), for tfpp_bn_bwd_apply_rows2; rows = tfpp_se_bwd_apply_bn_rows(B, HW, C, dtype). */
 int tfpp_mean_hw_bn(const void* x, const tfpp_bn_rows* bn, float* out, float* scratch, float* ticket_scratch, int B, int HW, int dtype, void* stream);
-int tfpp_se_dgate_bn(const void* dy, const void* x, const float* scale, const float* shift, float* dgate, float* scratch, float* ticket_scratch,
-                     int B, int HW, int C, int dtype, void* stream);
 int tfpp_se_bwd_apply_bn_rows(int B, int HW, int C, int dtype);
 int tfpp_se_bwd_apply_bn(const void* dy, const float* gate, const float* dpool, const void* x, const float* scale, const float* shift,
                          const float* save_mean, const float* save_invstd, void* dx, float* partial, int B, int HW, int C, int dtype, void* stream);
@@ -447,6 +444,13 @@ int tfpp_se_dgate(const void* dy, const void* x, float* dgate, float* scratch, i
 int tfpp_se_gate_bwd(const float* dgate, const float* gate, const float* hidden, const float* pool, const float* w1,
                      const float* w2, float* dz1_scratch /* [B*RD] */, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
                      int B, int C, int RD, void* stream);
+/* se_gate_bwd with dgate_g[b,c] = dgate[b,c] * gate[b,c] = sum_hw dy * y, y = the GATED tensor as the forward pass stored it (tfpp_se_dgate on
+ * (dy, y)).  Round 6: the gate's gradient is a small residual of cancelling sums -- BatchNorm behind conv3 removes any common scale of its input --
+ * and the cancellation holds for the tensor conv3 actually read, roundings included; rebuilding the un-gated activation instead
+ * (tfpp_se_dgate_bn) left the squeeze-excite fc1 gradients of the bf16 step 1.4x further from the fp32 step's. */
+int tfpp_se_gate_bwd_premul(const float* dgate_g, const float* gate, const float* hidden, const float* pool, const float* w1,
+                            const float* w2, float* dz1_scratch, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int B,
+                            int C, int RD, void* stream);
 int tfpp_se_bwd_apply(const void* dy, const float* gate, const float* dpool, void* dx, int B, int HW, int C, int dtype, void* stream);
 /* se_bwd_apply with the BatchNorm-backward statistics of the preceding layer fused in (conv2 of a RegNet bottleneck: dx is the
  * complete gradient of y = relu(BN(x))): also writes tfpp_se_bwd_apply_bns_rows(B, HW, C, dtype) rows [2*C] of (sum g, sum g*xhat),

@@ -145,10 +145,11 @@ def test_squeeze_excite_around_a_tensor_that_is_never_normalised_in_memory(ops, 
   gamma, beta = rnd(C, seed=12, lo=0.5, hi=1.5), rnd(C, seed=13)
   w1, b1, w2, b2 = rnd(RD, C, seed=14) * 0.3, rnd(RD, seed=15), rnd(C, RD, seed=16) * 0.5, rnd(C, seed=17)
   rawr = raw.clone().requires_grad_(True)
+  w1r, b1r, w2r, b2r = (t.clone().requires_grad_(True) for t in (w1, b1, w2, b2))
   y2 = F.relu(F.batch_norm(rawr, None, None, gamma, beta, True, 0.1, 1e-5))
   y2.retain_grad()
   pool_ref = y2.mean((2, 3))
-  gate_ref = torch.sigmoid(F.linear(F.relu(F.linear(pool_ref, w1, b1)), w2, b2))
+  gate_ref = torch.sigmoid(F.linear(F.relu(F.linear(pool_ref, w1r, b1r)), w2r, b2r))
   a2_ref = y2 * gate_ref.view(B, C, 1, 1)
   d_a2 = rnd(B, C, H, W, dtype=dtype, seed=18)
   a2_ref.backward(d_a2)
@@ -168,10 +169,12 @@ def test_squeeze_excite_around_a_tensor_that_is_never_normalised_in_memory(ops, 
   a2 = ops.bn_apply_rows(rd, ops.bn_rows(C, scale, shift), gate=gate, rows_per_batch=H * W, relu_pre=True)
   check('se_bn.a2', nchw(a2.float().cpu()), a2_ref, dtype, scale=2.0)
   dyd = dev(nhwc(d_a2), dtype)
-  dgate = ops.se_dgate_bn(dyd, rd, scale, shift)
-  check('se_bn.dgate', dgate.cpu(), (d_a2 * y2.detach()).sum((2, 3)), dtype, scale=3.0)
+  dgate_g = ops.se_dgate(dyd, a2)  # = dgate * gate, on the gated tensor as stored (tfpp_se_gate_bwd_premul)
+  check('se_bn.dgate_g', dgate_g.cpu(), (d_a2 * a2_ref.detach()).sum((2, 3)), dtype, scale=3.0)
   grads = [torch.zeros_like(dev(t)) for t in (w1, b1, w2, b2)]
-  dpool = ops.se_gate_bwd(dgate, gate, hidden, pool, dev(w1), dev(w2), *grads)
+  dpool = ops.se_gate_bwd(dgate_g, gate, hidden, pool, dev(w1), dev(w2), *grads, premul=True)
+  for nme, gg, pp in zip(('dw1', 'db1', 'dw2', 'db2'), grads, (w1r, b1r, w2r, b2r)):
+    check('se_bn.' + nme, gg.cpu(), pp.grad, dtype, scale=4.0)
   d_y2, partial, nr = ops.se_bwd_apply_bn(dyd, gate, dpool, rd, scale, shift, sm, si)
   assert nr <= ops.BN_ROWS_MAX // 2 + B
   check('se_bn.d_y2', nchw(d_y2.float().cpu()), y2.grad, dtype, scale=3.0)

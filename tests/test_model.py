@@ -752,7 +752,10 @@ BF16_LOSS_TOL = 5e-2  # measured worst: loss_yaw_res 3.4e-2 (a loss of ~1e-2 abs
 #   whole gradient arena: cosine 0.9940, relative L2 0.110;  per-tensor norm error: median 0.0083, p90 0.071, p99 0.226, max 0.745;
 #   sampled elements (16 per tensor, 9068): 9.5 % beyond 0.5 x (rms + |ref|)
 BF16_ARENA_COSINE, BF16_ARENA_REL_L2 = 0.99, 0.15
-BF16_NORM_MEDIAN, BF16_NORM_P90, BF16_NORM_P99, BF16_NORM_MAX = 0.012, 0.10, 0.30, 1.0
+# Round 6 measured the TAIL of that distribution over eight builds that differ only in where one intermediate of the squeeze-excite block is
+# rounded to bf16 (profiles/r06_bf16_tail_statistics.txt): p90 0.062-0.086, p99 0.17-0.33, max 0.48-1.31 -- the p99 / max bars of rounds 3-5
+# (0.30 / 1.0, 1.3x one measurement) sat inside that spread.  Median and the arena statistics do not move.
+BF16_NORM_MEDIAN, BF16_NORM_P90, BF16_NORM_P99, BF16_NORM_MAX = 0.012, 0.11, 0.42, 1.7
 BF16_ELEM_FRACTION_BEYOND_HALF = 0.13
 
 
@@ -832,10 +835,14 @@ def test_bf16_step_is_no_worse_than_the_autocast_reference():
   _report('bf16_vs_autocast_reference', {'hip_bf16_vs_hip_fp32': got, 'reference_autocast_vs_reference_fp32': want,
                                          'losses_rel_dev_hip_and_autocast': {n: [float(a), float(b)] for n, (a, b) in loss_dev.items()},
                                          'hip_bf16_norms_vs_autocast_norms': {'median': direct[len(direct) // 2], 'p90': direct[int(0.9 * len(direct))], 'max': direct[-1]}})
+  # the arena statistics, the median and the element count are stable to the last digit between builds; p90 / p99 / max of the per-tensor norm
+  # error are set by a handful of squeeze-excite fc1 tensors and move by up to 2x between arithmetically equivalent builds (round 6: eight
+  # variants, profiles/r06_bf16_tail_statistics.txt: p99 0.17-0.33 against the reference's single draw of 0.297): those three get that spread
   slack = 1.02
+  tail = {'norm_err_p90': 1.3, 'norm_err_p99': 1.4, 'norm_err_max': 1.5}
   assert got['arena_cosine'] >= 1.0 - (1.0 - want['arena_cosine']) * slack, (got, want)
   for k in STAT_KEYS[1:]:
-    assert got[k] <= want[k] * slack, (k, got, want)
+    assert got[k] <= want[k] * tail.get(k, slack), (k, got, want)
   assert got['tensors'] >= 500
   for n, (a, b) in loss_dev.items():
     assert a <= 2.0 * b + 1e-3, (n, a, b)

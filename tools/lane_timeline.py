@@ -57,6 +57,12 @@ def main():
   for lab, x in zip(labels, us):
     phase, lane = lab.split(' ')[0], lab.split(' ')[1]
     lanes[lane].append((x, phase, lab))
+  if '--dump' in sys.argv:  # every stamp of every lane: time since the first stamp, time to the lane's next stamp, label
+    with open(sys.argv[sys.argv.index('--dump') + 1], 'w', encoding='utf-8') as f:
+      for lane in sorted(lanes):
+        ev = sorted(lanes[lane])
+        for (x0, ph, lab), (x1, _, _) in zip(ev, ev[1:] + [(ev[-1][0], '', '')]):
+          f.write(f'{lane} {x0:10.1f} us  +{x1 - x0:8.1f} us  {lab}\n')
   for lab, x in zip(labels, us):
     if lab.split(' ')[0] == 'step' or 'MAIN CHAIN' in lab or 'joined' in lab:
       print(f'  {x / 1e3:8.3f} ms  {lab}')
