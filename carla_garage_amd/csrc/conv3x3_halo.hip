@@ -327,12 +327,16 @@ template <int FN> int launch_halo_cv(const tfpp_conv_params& p, hipStream_t st) 
 }
 }  // namespace
 
+// narrowest map the 8 x 32 tiles are used on (TFPP_HALO_MIN_W, default 16: the 16 x 16 LiDAR stage-3 maps run with half of every tile's
+// columns masked -- still one staged pass instead of nine gathers; 32 = the rounds 1-5 behaviour)
+static int halo_min_w() { static const int v = [] { const char* e = std::getenv("TFPP_HALO_MIN_W"); return e ? std::atoi(e) : 16; }(); return v; }
+
 // variant code 300 + FN
 bool conv_halo_supported(const tfpp_conv_params& p, int dtype) {
   static const int on = [] { const char* e = std::getenv("TFPP_CONV_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
   if (!on || dtype != TFPP_BF16) return false;
   if (p.R != 3 || p.S != 3 || p.pad != 1) return false;
-  if (p.ks_g % 8 || p.src_ld % 8 || p.n_g > 64 || p.Wd < 32 || p.Hd < 4) return false;
+  if (p.ks_g % 8 || p.src_ld % 8 || p.n_g > 64 || p.Wd < halo_min_w() || p.Hd < 4) return false;
   const int fn = p.n_g <= 16 ? 1 : (p.n_g <= 32 ? 2 : 4);
   if (p.stride == 2) {  // even feature maps only: forward Hs = 2 Hd, data gradient Hd = 2 Hs (TFPP_CONV_HALO_S2=0: implicit GEMM)
     static const int s2 = [] { const char* e = std::getenv("TFPP_CONV_HALO_S2"); return (e && e[0] == '0') ? 0 : 1; }();

@@ -498,7 +498,10 @@ bool wgrad_glds_group_ok(const tfpp_wgrad_params& p, int dtype) {
 }
 
 template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE> static int launch_wgrad_glds_group(const tfpp_wgrad_group& grp, int grid_cap, hipStream_t st) {
-  constexpr size_t lds = (size_t)NSTAGE * BKP * (TM + TN) * 2;
+  constexpr size_t need = (size_t)NSTAGE * BKP * (TM + TN) * 2;
+  // TFPP_WGRAD_GROUP_LDS (bytes): occupancy limiter of the grouped grids, for A/B runs (see launch_wgrad_glds)
+  static const size_t min_lds = [] { const char* e = std::getenv("TFPP_WGRAD_GROUP_LDS"); return e ? (size_t)std::atol(e) : (size_t)0; }();
+  const size_t lds = (TM == 128 && min_lds > need) ? min_lds : need;
   static unsigned long long attr_mask = 0;
   if (tfpp_first_use_on_this_device(&attr_mask))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_glds_group_kernel<TM, TN, WGM, WGN, BKP, NSTAGE>),

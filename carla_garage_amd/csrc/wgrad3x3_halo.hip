@@ -177,12 +177,16 @@ template <int FNN, int CV> int launch(const tfpp_wgrad_params& p, int nblk, hipS
 }
 }  // namespace
 
+// narrowest map the 8 x 32 tiles are used on (TFPP_HALO_MIN_W, default 16: the 16 x 16 LiDAR stage-3 maps run with half of every tile's
+// columns masked -- still one staged pass instead of nine gathers; 32 = the rounds 1-5 behaviour)
+static int halo_min_w() { static const int v = [] { const char* e = std::getenv("TFPP_HALO_MIN_W"); return e ? std::atoi(e) : 16; }(); return v; }
+
 // number of workgroups (= workspace slices) per group; 0 if the kernel does not apply
 int wgrad_halo_slices(const tfpp_wgrad_params& p, int dtype) {
   static const int on = [] { const char* e = std::getenv("TFPP_WGRAD_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
   if (!on || dtype != TFPP_BF16 || !p.ws) return 0;
   if (p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || p.Hs != p.Hd || p.Ws != p.Wd) return 0;
-  if (p.ks_g % 8 || p.n_g % 8 || p.x_ld % 8 || p.dy_ld % 8 || p.n_g > 64 || p.ks_g > 64 || p.Wd < 32 || p.Hd < 4) return 0;
+  if (p.ks_g % 8 || p.n_g % 8 || p.x_ld % 8 || p.dy_ld % 8 || p.n_g > 64 || p.ks_g > 64 || p.Wd < halo_min_w() || p.Hd < 4) return 0;
   if (((uintptr_t)p.dy & 15) || ((uintptr_t)p.x & 15)) return 0;
   const int cv8 = p.ks_g >> 3;
   if (!(cv8 == 1 || cv8 == 2 || cv8 == 3 || cv8 == 4 || cv8 == 8)) return 0;  // instantiated channel counts
@@ -190,7 +194,10 @@ int wgrad_halo_slices(const tfpp_wgrad_params& p, int dtype) {
   if (halo_lds_bytes(p, fnn) > 98304) return 0;
   const long tiles = (long)cdiv(p.Wd, TW) * cdiv(p.Hd, TH) * p.B;
   if (p.ks_g > 32 && tiles < 2048) return 0;  // 64-channel inputs on small maps: the LDS-DMA implicit GEMM measured faster
-  long nblk = 1024 / p.G;  // ~4 workgroups per CU over all groups
+  // workgroups over all groups (each writes one fp32 slice of its group's gradient: fewer workgroups = fewer slice bytes written and
+  // summed, more tiles walked one after the other per workgroup).  TFPP_WGRAD_HALO_WGS, default 512 (1024 / 512 / 288 / 2048: 23.36 / 23.26 / 23.29 / 23.35 ms per step)
+  static const long total_wgs = [] { const char* e = std::getenv("TFPP_WGRAD_HALO_WGS"); const long v = e ? std::atol(e) : 512; return v < 1 ? 1 : v; }();
+  long nblk = total_wgs / p.G;
   if (nblk < 1) nblk = 1;
   if (nblk > tiles) nblk = tiles;
   const long slice = (long)p.G * p.n_g * 9 * p.ks_g;

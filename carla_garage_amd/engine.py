@@ -1418,7 +1418,8 @@ class Engine:
                                   self.g(se.fc2.weight), self.g(se.fc2.bias), premul=True)
           # dx is the complete gradient of relu(BN2(raw2)) (its only consumer is this block): the BatchNorm-backward sums come with it
           dx, partial, nrows = ops.se_bwd_apply_bn(dy, gate, dpool, raw, sL.scale, sL.shift, sL.save_mean, sL.save_invstd)
-          self._bn_pre[_key(x)] = (partial, nrows, dx)
+          if partial is not None:
+            self._bn_pre[_key(x)] = (partial, nrows, dx)
           return dx
 
         self.rec([y], [x], bwd_view)

@@ -895,34 +895,64 @@ def test_bf16_trains_like_fp32_over_200_steps_and_drifts_no_further_than_the_aut
 
 
 @pytest.mark.gpu
-def test_fused_batchnorm_backward_sums_do_not_change_the_bf16_step(monkeypatch):
+@pytest.mark.parametrize('path', ['rows', 'r5'])
+def test_fused_batchnorm_backward_sums_do_not_change_the_bf16_step(monkeypatch, path):
   """The BatchNorm-backward sums emitted by the squeeze-excite backward kernel (the producer of d(y) for conv2 of every bottleneck,
   Engine.squeeze_excite) replace the separate reduction pass: the bf16 step with the fusion must reproduce the step without it (same rounded
-  gradients go into the sums, only the summation order differs), and it must really be taken on the 42 conv2 BatchNorm layers."""
+  gradients go into the sums, only the summation order differs), and it must really be taken on the 42 conv2 BatchNorm layers.
+  'rows': the round-6 path (conv2's output is a BnView, tfpp_se_bwd_apply_bn -> tfpp_bn_bwd_apply_rows2); 'r5': the launch sequence of rounds
+  1-5 (engine.BN_ROWS off: tfpp_se_bwd_apply_bns -> tfpp_bn_bwd_apply_rows), kept for the configurations that still use it (SyncBatchNorm)."""
   from carla_garage_amd import engine as E
   from carla_garage_amd import ops
+  monkeypatch.setattr(E, 'BN_ROWS', path == 'rows')
   out = {}
   calls = {}
-  real_rows = ops.bn_bwd_rows
-  for fused in (False, True):
-    calls[fused] = [0]
+  if path == 'r5':
+    real_rows = ops.bn_bwd_rows
+    for fused in (False, True):
+      calls[fused] = [0]
 
-    def count_rows(*a, _f=fused, **k):
-      calls[_f][0] += 1
-      return real_rows(*a, **k)
+      def count_rows(*a, _f=fused, **k):
+        calls[_f][0] += 1
+        return real_rows(*a, **k)
 
-    monkeypatch.setattr(ops, 'bn_bwd_rows', count_rows)
-    m = _model('bf16').train()
-    with monkeypatch.context() as mp:
-      if not fused:  # the producer only emits the sums when its gradient is the last one the tensor receives: say it never is
-        mp.setattr(E.Tape, 'is_last_contribution', lambda self, t: False)
+      monkeypatch.setattr(ops, 'bn_bwd_rows', count_rows)
+      m = _model('bf16').train()
+      with monkeypatch.context() as mp:
+        if not fused:  # the producer only emits the sums when its gradient is the last one the tensor receives: say it never is
+          mp.setattr(E.Tape, 'is_last_contribution', lambda self, t: False)
+        names, vals, eng = _engine_train_step(m, 4)
+      out[fused] = (vals, eng.flat_grad.detach().double().cpu().numpy().copy())
+    monkeypatch.setattr(ops, 'bn_bwd_rows', real_rows)
+  else:
+    real_reduce, real_se = ops.bn_bwd_reduce_rows, ops.se_bwd_apply_bn
+    for fused in (False, True):
+      calls[fused] = [0]
+      reduces = [0]
+
+      def count_reduce(*a, _r=reduces, **k):
+        _r[0] += 1
+        return real_reduce(*a, **k)
+
+      def se_apply(*a, _f=fused, **k):
+        calls[_f][0] += 1
+        dx, partial, nrows = real_se(*a, **k)
+        return (dx, partial, nrows) if _f else (dx, None, 0)  # without the rows conv2's backward runs its own reduction pass
+
+      monkeypatch.setattr(ops, 'bn_bwd_reduce_rows', count_reduce)
+      monkeypatch.setattr(ops, 'se_bwd_apply_bn', se_apply)
+      m = _model('bf16').train()
       names, vals, eng = _engine_train_step(m, 4)
-    out[fused] = (vals, eng.flat_grad.detach().double().cpu().numpy().copy())
-  monkeypatch.setattr(ops, 'bn_bwd_rows', real_rows)
+      out[fused] = (vals, eng.flat_grad.detach().double().cpu().numpy().copy())
+      calls[('reduce', fused)] = reduces[0]
+    monkeypatch.setattr(ops, 'bn_bwd_reduce_rows', real_reduce)
+    monkeypatch.setattr(ops, 'se_bwd_apply_bn', real_se)
+    assert calls[('reduce', False)] - calls[('reduce', True)] == 42, calls  # the 42 reduction passes the fused sums replace
+    calls[False][0] = 0  # (same bookkeeping as the r5 branch below: "fused launches used")
   assert calls[False][0] == 0 and calls[True][0] == 42, calls   # 21 bottlenecks x 2 encoders
   lerr = float(np.max(np.abs(out[True][0] - out[False][0]) / np.abs(out[False][0])))
   gerr = float(np.linalg.norm(out[True][1] - out[False][1]) / np.linalg.norm(out[False][1]))
-  _report('fused_bn_bwd', {'fused_layers': calls[True][0], 'loss_rel': lerr, 'grad_rel_l2': gerr})
+  _report('fused_bn_bwd_' + path, {'fused_layers': calls[True][0], 'loss_rel': lerr, 'grad_rel_l2': gerr})
   assert lerr <= 1e-5 and gerr <= 2e-2, (lerr, gerr)  # losses: fp32 atomics of the loss sums; gradients: measured 4e-3
 
 

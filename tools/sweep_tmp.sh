@@ -1,11 +1,7 @@
 run() { env $1 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-dropin --no-inference 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1  %.3f ms/step' % d['ms_per_step'])"; }
-run "TFPP_X=1"
-run "TFPP_DEBUG_SKIP_OPS=colsum"
-run "TFPP_DEBUG_SKIP_OPS=wgrad_f32"
-run "TFPP_DEBUG_SKIP_OPS=wgrad_narrow"
-run "TFPP_DEBUG_SKIP_OPS=wgrad_3x3"
-run "TFPP_DEBUG_SKIP_OPS=ln_param"
-run "TFPP_DEBUG_SKIP_OPS=colsum,wgrad_f32,wgrad_narrow,ln_param"
-run "TFPP_DEBUG_SKIP_OPS=colsum,wgrad_f32,wgrad_narrow,ln_param,wgrad_3x3"
-run "TFPP_DEBUG_SKIP_OPS=wgrad_all"
-run "TFPP_X=1"
+for r in 1 2; do
+run "TFPP_WGRAD_HALO_WGS=1024"
+run "TFPP_WGRAD_HALO_WGS=512"
+run "TFPP_WGRAD_HALO_WGS=288"
+run "TFPP_WGRAD_HALO_WGS=2048"
+done
