@@ -323,7 +323,7 @@ def inference_latency(model, cfg, device, log, iters=20):
   return out
 
 
-def video_swin_forward(device, log, bs=4, iters=10, train=True):
+def video_swin_forward(device, log, bs=4, iters=10, train=True, roofline=True):
   """BASELINE config 5 (TransFuser++ with the Video-Swin LiDAR branch, 6 LiDAR frames -> 3 time frames per scale, bs = 4 per GPU):
   inference forward and training step in bf16, random-init weights, synthetic frames, as hipGraph replays.  Reported beside the headline
   metric (BASELINE config 3), never as ``value``."""
@@ -389,6 +389,48 @@ def video_swin_forward(device, log, bs=4, iters=10, train=True):
     out['train_hipgraph_ms_per_step'] = round(ms, 3)
     out['train_samples_per_s'] = round(bs / (ms * 1e-3), 1)
     out['train_final_weighted_loss'] = round(float(tr.total_loss(vals)), 5)
+    try:  # roofline of this configuration's step: algorithmic FLOPs / GEMM-family bytes from two profiled eager steps over the replayed step time
+      if not roofline:
+        raise RuntimeError('skipped (kernel-trace run: the last step of the trace must be a replayed one)')
+      from carla_garage_amd._lib import lib, KernelProfiler
+      prof = KernelProfiler()
+      lib.profiler = prof
+      for _ in range(2):
+        tr.step_count += 1
+        tr.eng.buckets.begin_issue()
+        tr._step_body(tb)
+        tr._optimizer(tr.step_count)
+      lib.profiler = None
+      agg = prof.summary()
+      flop = sum(x['flops'] for x in agg.values()) / 2
+      gb = sum(x['bytes'] for x in agg.values()) / 2
+      peak = PEAK_TFLOPS['bf16']
+      fam, a = max(((f, x) for f, x in agg.items() if x['flops'] > 0), key=lambda fa: fa[1]['ms'])
+      roof5 = {'workload': 'TransFuser++ with the Video-Swin LiDAR branch (BASELINE config 5), training step bs = 4 bf16, 6 LiDAR frames',
+               'algorithmic_tflop_per_step': round(flop / 1e12, 4), 'algorithmic_gb_gemm_families': round(gb / 1e9, 3), 'ms_per_step': round(ms, 3),
+               'achieved_tflops': round(flop / (ms * 1e-3) / 1e12, 2), 'frac_of_mfma_peak': round(flop / (ms * 1e-3) / 1e12 / peak, 4),
+               'at_mfma_peak_ms': round(1e3 * flop / (peak * 1e12), 3), 'at_hbm_peak_ms_gemm_families': round(1e3 * gb / (PEAK_HBM_GBS * 1e9), 3),
+               'launches_per_step_library_calls': sum(x['calls'] for x in agg.values()) // 2,
+               'dominant_family': {'kernel': fam, 'launches_per_step': a['calls'] // 2, 'avg_launch_us': round(1e3 * a['ms'] / a['calls'], 2),
+                                   'achieved_tflops': round(a['flops'] / (a['ms'] * 1e-3) / 1e12, 2), 'frac_of_mfma_peak': round(a['flops'] / (a['ms'] * 1e-3) / 1e12 / peak, 4),
+                                   'share_of_step_kernel_time': round(a['ms'] / sum(x['ms'] for x in agg.values()), 3)},
+               'families_by_time': [{'kernel': f, 'launches_per_step': x['calls'] // 2, 'ms_per_step': round(x['ms'] / 2, 3)}
+                                    for f, x in sorted(agg.items(), key=lambda fa: -fa[1]['ms'])[:8]]}
+      import glob
+      files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_swin_graph_step.json')))
+      if files:
+        with open(files[-1], encoding='utf-8') as f:
+          g5 = json.load(f)
+        roof5['graph_trace'] = {'source': 'profiles/' + os.path.basename(files[-1]), 'launches': g5['launches'], 'span_ms': g5['span_ms'],
+                                'sum_kernel_ms': g5['sum_kernel_ms'], 'busy_union_ms': g5['busy_union_ms']}
+      out['roofline_config5'] = roof5
+    except Exception as e:  # pylint: disable=broad-except
+      try:
+        from carla_garage_amd._lib import lib as _l
+        _l.profiler = None
+      except Exception:  # pylint: disable=broad-except
+        pass
+      log(f'video-swin roofline: {type(e).__name__}: {e}')
     del step, tr
   except Exception as e:  # pylint: disable=broad-except
     out['train_hipgraph_ms_per_step'] = None
@@ -536,8 +578,10 @@ def graph_trace():
 def kernel_pattern(fam):
   """Substring of the demangled kernel name that identifies the kernels of family `fam` in a rocprofv3 table (None: no single kernel)."""
   import re
-  if fam == 'conv_wgrad<bf16,batch>':  # the grouped weight-gradient launch of a lane batch: priced by its dominant kernel (128 x 128 tiles)
+  if fam == 'conv_wgrad<bf16,group128>':  # the grouped weight-gradient grids of a lane batch, one family per member kernel (ops.wgrad_batch_end)
     return 'conv_wgrad_glds_group_kernel<128, 128,'
+  if fam == 'conv_wgrad<bf16,group64>':
+    return 'conv_wgrad_glds_group_kernel<64, 64,'
   m = re.match(r'(conv_gemm|conv_wgrad)<(f32|bf16),(glds|halo|lds)?(\d+)x(\d+)', fam)
   if m is None:
     return None
@@ -648,6 +692,8 @@ def main():
   ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
   ap.add_argument('--autocast-reference-only', default=None, help=argparse.SUPPRESS)
   ap.add_argument('--forward-call-only', default=None, help=argparse.SUPPRESS)
+  ap.add_argument('--config5-only', action='store_true', help='only the Video-Swin configuration (BASELINE config 5): training step bs = 4 bf16 + its roofline; '
+                                                             'what tools/graph_step_profile.sh swin traces')
   ap.add_argument('--seed', type=int, default=1234, help=argparse.SUPPRESS)
   ap.add_argument('--no-bf16-reference', action='store_true', help='skip the CPU autocast-bf16 reference beside the bf16-vs-fp32 gradient statistics')
   ap.add_argument('--cpu-budget', type=float, default=25.0, help=argparse.SUPPRESS)
@@ -702,6 +748,16 @@ def main():
     torch.cuda.synchronize()
     rccl_ranks = int(probe.item())
     assert rccl_ranks == world, f'RCCL all-reduce over {rccl_ranks} ranks, expected {world}'
+
+  if args.config5_only:
+    if world != 1:
+      raise SystemExit('--config5-only is a single-GPU leg')
+    t_c5 = time.perf_counter()
+    res = video_swin_forward(device, lambda m: print(f'[bench +{time.perf_counter() - t_c5:7.1f}s] {m}', file=sys.stderr, flush=True), iters=max(4, args.steps), train=True, roofline=os.environ.get('TFPP_CONFIG5_NO_ROOFLINE', '0') != '1')
+    torch.cuda.synchronize()
+    print(json.dumps({'metric': 'training samples/sec (TransFuser++ Video-Swin, bs=4/GPU: BASELINE config 5; not the headline metric)',
+                      'value': res.get('train_samples_per_s'), 'unit': 'samples/s', 'n_gpus': 1, 'dtype': 'bf16', 'data': 'synthetic', 'video_swin_forward_bs4': res}), flush=True)
+    return
 
   from carla_garage_amd.config import GlobalConfig
   from carla_garage_amd.model import LidarCenterNet
@@ -819,7 +875,9 @@ def main():
       return {'bound': 'mfma' if mfma else 'hbm', 'kernel': fam, 'achieved': round(ach, 2), 'peak': pk, 'unit': unit, 'frac': round(ach / pk, 4),
               'graph_trace': graph_trace_of(gtrace, fam, a['flops'] / a['calls'], (a['bytes'] / a['calls']) if a.get('bytes') else 0.0, mfma, pk),
               'mfma_counters': mfma_counters_of(fam),
-              'traffic': traffic, 'traffic_note': traffic_note, 'algorithmic_flop_per_launch': round(a['flops'] / a['calls']),
+              'traffic': traffic, 'traffic_note': traffic_note,
+              'traffic_over_algorithmic_bytes': round(traffic / (a['bytes'] / a['calls']), 2) if (traffic and a.get('bytes')) else None,
+              'algorithmic_flop_per_launch': round(a['flops'] / a['calls']),
               'algorithmic_bytes_per_launch': round(a['bytes'] / a['calls']) if a.get('bytes') else None,
               'algorithmic_flop_per_byte': round(a['flops'] / a['bytes'], 1) if a.get('bytes') else None,
               'launches_per_step': a['calls'] // nprof, 'avg_launch_us': round(1e3 * a['ms'] / a['calls'], 2),

@@ -753,6 +753,12 @@ static int emit_wgrad_group(const std::vector<tfpp_wgrad_params>& its, int tile,
   return 0;
 }
 
+// 1 if tfpp_conv_wgrad_batch would put this layer into a grouped grid (bench.py's per-kernel bookkeeping; the tile class is the plan's variant)
+extern "C" int tfpp_conv_wgrad_group_ok(const tfpp_wgrad_params* p, int dtype) {
+  if (!p) return TFPP_EINVAL;
+  return (dtype == TFPP_BF16 && wgrad_glds_group_ok(*p, dtype)) ? 1 : 0;
+}
+
 extern "C" int tfpp_conv_wgrad_batch(const tfpp_wgrad_params* items, int n, int dtype, void* stream) {
   if (!items || n < 0 || (dtype != TFPP_F32 && dtype != TFPP_BF16)) return TFPP_EINVAL;
   static const int grid_cap = [] { const char* e = std::getenv("TFPP_WGRAD_GROUP_WGS"); return e ? std::atoi(e) : 0; }();

@@ -228,16 +228,35 @@ def wgrad_batch_end():
   batch, WGRAD_BATCH = WGRAD_BATCH, None
   if not batch:
     return
-  arr = (WgradParams * len(batch))()
-  flops = nbytes = 0.0
-  for i, (p, _) in enumerate(batch):
-    ctypes.memmove(ctypes.byref(arr, i * ctypes.sizeof(WgradParams)), ctypes.byref(p), ctypes.sizeof(WgradParams))
-    kk = p.R * p.S * p.ks_g
-    flops += 2.0 * p.B * p.Hd * p.Wd * p.G * p.n_g * kk
-    nbytes += (p.B * p.Hd * p.Wd * p.G * p.n_g + p.B * p.Hs * p.Ws * p.G * p.ks_g) * 2 + 2 * p.G * p.n_g * kk * 4
-  if lib.profiler is not None:
-    lib.profiler.tag('conv_wgrad<bf16,batch>', flops, nbytes)
-  lib.tfpp_conv_wgrad_batch(arr, len(batch), BF16, stream())
+  def launch(items, family=None):
+    arr = (WgradParams * len(items))()
+    flops = nbytes = 0.0
+    for i, p in enumerate(items):
+      ctypes.memmove(ctypes.byref(arr, i * ctypes.sizeof(WgradParams)), ctypes.byref(p), ctypes.sizeof(WgradParams))
+      kk = p.R * p.S * p.ks_g
+      flops += 2.0 * p.B * p.Hd * p.Wd * p.G * p.n_g * kk
+      # algorithmic bytes: dY and X read once, the gradient read-modify-written once in fp32
+      nbytes += (p.B * p.Hd * p.Wd * p.G * p.n_g + p.B * p.Hs * p.Ws * p.G * p.ks_g) * 2 + 2 * p.G * p.n_g * kk * 4
+    if family is not None:
+      lib.profiler.tag(family, flops, nbytes)
+    lib.tfpp_conv_wgrad_batch(arr, len(items), BF16, stream())
+
+  items = [p for p, _ in batch]
+  if lib.profiler is None:
+    launch(items)
+    return
+  # profiling steps (bench.py roofline): the members of the batch are launched -- and so timed by the events around the library call -- per
+  # kernel: the layers of the grouped 128 x 128 grid, those of the grouped 64 x 64 grid, everything else.  Same kernels, same results (the
+  # groups never mix tile classes); the pixel splits of a group are chosen for the group it is launched with, as always.
+  members = {'group128': [], 'group64': [], 'single': []}
+  plan = (ctypes.c_int * 3)()
+  for p in items:
+    lib.raw('tfpp_conv_wgrad_stage')(ctypes.byref(p), BF16, -1, plan, stream())
+    ok = lib.raw('tfpp_conv_wgrad_group_ok')(ctypes.byref(p), BF16) if plan[0] in (2, 4) else 0
+    members['group128' if (ok and plan[0] == 4) else ('group64' if (ok and plan[0] == 2) else 'single')].append(p)
+  for k, its in members.items():
+    if its:
+      launch(its, f'conv_wgrad<bf16,{k}>')
 
 
 _DBG_SKIP = set(_os.environ.get('TFPP_DEBUG_SKIP_OPS', '').split(','))  # timing experiments only (results are wrong): which side-lane work costs what?

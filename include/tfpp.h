@@ -165,6 +165,8 @@ int tfpp_conv_wgrad_x_bn_ok(const tfpp_wgrad_params* p, int dtype);
  * items[i].ws as the slice workspace (the same buffer for every item of a call).  Results equal n tfpp_conv_wgrad calls up to the order of
  * the fp32 pixel sums.  TFPP_WGRAD_GROUP=0 disables grouping, TFPP_WGRAD_GROUP_WGS=n caps the grid (persistent workgroups). */
 int tfpp_conv_wgrad_batch(const tfpp_wgrad_params* items, int n, int dtype, void* stream);
+/* 1 if tfpp_conv_wgrad_batch runs this layer inside a grouped grid (the tile class -- 64 or 128 -- is the variant tfpp_conv_wgrad_stage plans) */
+int tfpp_conv_wgrad_group_ok(const tfpp_wgrad_params* p, int dtype);
 /* Preferred workspace of one call in bytes (the library never allocates): the size at which the dispatcher's plan is not
  * limited by the workspace.  op 0: split-K slices of tfpp_conv_gemm (params = tfpp_conv_params, field splitk_ws); op 1: pixel slices of
  * tfpp_conv_wgrad (params = tfpp_wgrad_params, field ws); op 2 / 3: BatchNorm / column-sum scratch for C = *(const int*)params channels.

@@ -1,13 +1,20 @@
 #!/bin/bash
 # rocprofv3 kernel trace of hipGraph-replayed training steps; prints span / busy time of the last step and writes the
 # per-kernel table of that step to gpurun_out/graph_step_kernels.txt.  Run on the GPU box from the repo root.
+# `bash tools/graph_step_profile.sh swin`: the same for BASELINE config 5 (Video-Swin LiDAR branch, bs = 4): files gpurun_out/swin_graph_step*.
 set -e
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-inference --no-roofline --no-dropin > $REPO/gpurun_out/prof_bench.log 2>&1
+PREFIX=graph_step
+if [ "$1" = "swin" ]; then
+  PREFIX=swin_graph_step
+  TFPP_CONFIG5_NO_ROOFLINE=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $REPO/bench.py --config5-only --steps 4 > $REPO/gpurun_out/prof_bench.log 2>&1
+else
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-inference --no-roofline --no-dropin > $REPO/gpurun_out/prof_bench.log 2>&1
+fi
 t=$(find /tmp/prof -name "*kernel_trace.csv" | head -1)
-python - "$t" "$REPO/gpurun_out/graph_step_kernels.txt" <<'PY'
+python - "$t" "$REPO/gpurun_out/${PREFIX}_kernels.txt" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -48,7 +55,7 @@ if qkey:
         qb[str(qid)] = {"kernels": n, "busy_ms": round(busy_q / 1e6, 3)}
 with open(sys.argv[2].replace("_kernels.txt", ".json"), "w") as out:
     # machine-readable summary of the same step: bench.py attaches it (graph-accurate launch durations) to its roofline objects
-    json.dump({"what": "rocprofv3 --kernel-trace of one hipGraph-replayed training step (bs=12 bf16), tools/graph_step_profile.sh",
+    json.dump({"what": "rocprofv3 --kernel-trace of one hipGraph-replayed training step (%s), tools/graph_step_profile.sh" % ("Video-Swin configuration, bs=4 bf16" if "swin" in sys.argv[2] else "bs=12 bf16"),
                "launches": len(step), "span_ms": round((t1 - t0) / 1e6, 3), "sum_kernel_ms": round(busy / 1e6, 3), "busy_union_ms": round(cov / 1e6, 3),
                "queues": qb, "kernels": {k: {"calls": v[0], "total_ms": round(v[1] / 1e6, 4), "avg_us": round(v[1] / v[0] / 1e3, 3)} for k, v in agg.items()}},
               out, indent=0)
