@@ -230,8 +230,8 @@ def autocast_reference(state_dict, bs, seed, log, hard_timeout_s=240.0):
 
 
 def forward_call_worker(device_index, iters=20):
-  """Child process (an agent-like one: nothing but the module and its eval forward): model.forward() exactly as sensor_agent.py:456-461 calls it with
-  TFPP_EVAL_GRAPH_AFTER=2 in the environment -- the module captures the eval forward of a signature after two eager calls and replays it (model.py
+  """Child process (an agent-like one: nothing but the module and its eval forward): model.forward() exactly as sensor_agent.py:456-461 calls it, no
+  switch in the environment -- the module captures the eval forward of a signature after two eager calls and replays it (model.py
   _plain_forward).  `_tick` = each call followed by a device synchronisation (the agent reads the predictions on the host before the next tick)."""
   from carla_garage_amd.config import GlobalConfig
   from carla_garage_amd.model import LidarCenterNet
@@ -240,7 +240,6 @@ def forward_call_worker(device_index, iters=20):
   cfg = GlobalConfig(tfpp_dtype='bf16')
   torch.manual_seed(0)
   model = LidarCenterNet(cfg).to(device).eval()
-  model.eval_graph_after = 2  # (what TFPP_EVAL_GRAPH_AFTER=2 in the environment sets for every module; the launcher exports it as well)
   b = synthetic_batch(1, cfg, device, 99)
   inp = [b[k] for k in ('rgb', 'lidar_bev', 'target_point', 'ego_vel', 'command')]
   out = {}
@@ -267,7 +266,8 @@ def forward_call_latency(device, log, hard_timeout_s=150.0):
   import subprocess
   try:
     cmd = [sys.executable, os.path.abspath(__file__), '--forward-call-only', str(device.index or 0)]
-    env = dict(os.environ, TFPP_EVAL_GRAPH_AFTER='2')
+    env = dict(os.environ)  # (no switch: the module's own capture of repeated eval calls is the default since round 6)
+    env.pop('TFPP_EVAL_GRAPH_AFTER', None)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
       env.pop(k, None)
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=hard_timeout_s, env=env, check=False)
@@ -434,7 +434,8 @@ def video_swin_forward(device, log, bs=4, iters=10, train=True, roofline=True):
     del step, tr
   except Exception as e:  # pylint: disable=broad-except
     out['train_hipgraph_ms_per_step'] = None
-    log(f'video-swin training step failed: {type(e).__name__}: {e}')
+    import traceback
+    log(f'video-swin training step failed: {type(e).__name__}: {e}\n' + ''.join(traceback.format_exc().splitlines(True)[-12:]))
   log(f'video-swin bs={bs}: {out}')
   del model
   torch.cuda.empty_cache()
@@ -996,7 +997,7 @@ def main():
   fwd = lidar_hist = swin_fwd = image_aug = None
   if rank == 0 and not args.no_inference:
     fwd = inference_latency(model, cfg, device, log)
-    fwd.update(forward_call_latency(device, log))  # the module's own capture (TFPP_EVAL_GRAPH_AFTER=2), measured in an agent-like child process
+    fwd.update(forward_call_latency(device, log))  # the module's own capture (the default), measured in an agent-like child process
     lidar_hist = lidar_histogram_latency(cfg, device, log)
     try:
       image_aug = image_augmentation_latency(cfg, device, log, bs=args.batch_size)

@@ -131,7 +131,8 @@ class GradBuckets:
     works = []
     cuda = flat_grad.is_cuda and self.sig is not None
     if cuda and self.comm is None:
-      self.comm = torch.cuda.Stream(flat_grad.device)
+      from . import streams
+      self.comm = streams.get(flat_grad.device, 'comm')
     from . import ops
     waited_end = False
     for b, (lo, hi) in enumerate(self.ranges()):

@@ -70,7 +70,8 @@ class DeviceBatchPrefetcher:
     self._hist = None
     if self.device.index is None:
       self.device = torch.device('cuda', torch.cuda.current_device())
-    self.copy_stream = torch.cuda.Stream(self.device)
+    from . import streams
+    self.copy_stream = streams.get(self.device, 'copy')
     self.slots = [dict(pin={}, dev={}, ready=torch.cuda.Event(), used=False) for _ in range(slots)]
     self.keys = [(src, dst, dt) for src, dst, dt, need in KEYMAP if need(config) and not (self.rasterise and dst in TARGET_KEYS) and
                  not (self.lidar_on_device and dst == 'lidar_bev')]

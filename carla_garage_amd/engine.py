@@ -127,7 +127,8 @@ class Lanes:
       return self.main
     st = self.branches.get(k)
     if st is None:
-      st = self.branches[k] = torch.cuda.Stream(self.main.device)
+      from . import streams
+      st = self.branches[k] = streams.get(self.main.device, 'lane', k)  # (process-wide: see streams.py)
     return st
 
   def touch(self, k, ev=None):
@@ -463,8 +464,9 @@ class SideLane:
       fn()
       return
     if self.stream is None:
-      self.stream = torch.cuda.Stream(tensors[0].device)
-      self.streams = [self.stream] + [torch.cuda.Stream(tensors[0].device) for _ in range(_SIDE_STREAMS - 1)]
+      from . import streams
+      self.streams = [streams.get(tensors[0].device, 'side', j) for j in range(_SIDE_STREAMS)]  # (process-wide: see streams.py)
+      self.stream = self.streams[0]
       self.used = set()
     if not self.keep:
       tape.finalizers.append(self.join)
@@ -845,7 +847,8 @@ class Engine:
       # on their own stream beside that millisecond; Engine.forward waits for it at the first fusion point (_join_pack)
       ent['plan'].launch(0)
       if self._pack_stream is None:
-        self._pack_stream = torch.cuda.Stream(self.device)
+        from . import streams
+        self._pack_stream = streams.get(self.device, 'pack')
       cur = torch.cuda.current_stream(self.device)
       self._pack_stream.wait_stream(cur)
       with torch.cuda.stream(self._pack_stream):

@@ -28,8 +28,23 @@ def capture(graph, stream, pool=None):
   gc.disable()
   try:
     kw = {} if pool is None else {'pool': pool}
-    with torch.cuda.graph(graph, stream=stream, capture_error_mode=CAPTURE_MODE, **kw):
+    cm = torch.cuda.graph(graph, stream=stream, capture_error_mode=CAPTURE_MODE, **kw)
+    # capture_begin / capture_end update the CUDA generator's graph-state tensors in place; those are created by the FIRST capture of the
+    # process, and if that one ran under torch.inference_mode() (GraphedForward) they are inference tensors that no later capture outside
+    # inference mode may touch ("Inplace update to inference tensor outside InferenceMode": round 6, bench.py --config5-only).  Enter and
+    # leave the capture with inference mode off; the body keeps the caller's mode.
+    with torch.inference_mode(False):
+      cm.__enter__()
+    try:
       yield
+    except BaseException:
+      import sys
+      with torch.inference_mode(False):
+        if not cm.__exit__(*sys.exc_info()):
+          raise
+    else:
+      with torch.inference_mode(False):
+        cm.__exit__(None, None, None)
   finally:
     if was:
       gc.enable()
@@ -37,17 +52,14 @@ def capture(graph, stream, pool=None):
 
 import os as _os
 
-_CAPTURE_STREAMS = {}
-
 
 def capture_stream(device):
   """One capture stream per device for every graph of this module: the per-stream scratch buffers of ops.py are keyed by stream, so
   all captures share one set, prepared (allocated, statistics rows zeroed) before the capture starts."""
   from . import ops
+  from . import streams
   device = torch.device(device)
-  st = _CAPTURE_STREAMS.get(str(device))
-  if st is None:
-    st = _CAPTURE_STREAMS[str(device)] = torch.cuda.Stream(device)
+  st = streams.get(device, 'capture')
   st.wait_stream(torch.cuda.current_stream(device))
   with torch.cuda.stream(st):
     ops.clone_scratch_for_current_stream(device)

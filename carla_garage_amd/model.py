@@ -19,12 +19,14 @@ from .config import cfg_get
 from .engine import Engine, F32
 
 DTYPES = {'fp32': torch.float32, 'bf16': torch.bfloat16}
-# Eval-mode forwards of one input signature that run eagerly before the forward is captured into a hipGraph and replayed; < 0 (the default): never.
+# Eval-mode forwards of one input signature that run eagerly before the forward is captured into a hipGraph and replayed; < 0: never.
 # The 20 Hz tick of sensor_agent.py:456-461 calls forward() with the same shapes every time: ~740 launches at bs = 1 cost 10 ms issued one by one and
-# 3.6 ms as one replay.  ``TFPP_EVAL_GRAPH_AFTER=2`` in the agent's environment (or ``model.eval_graph_after = 2``) switches it on without touching
-# sensor_agent.py.  Off by default: in ONE test process that had run trainers and other captured modules before, the first replay of a fresh capture crashed
-# inside hipGraphLaunch (ROCm 7.2; history dependent, not reproduced in an agent-like or bench-like process) -- a default must not be able to do that.
-EVAL_GRAPH_AFTER = int(os.environ.get('TFPP_EVAL_GRAPH_AFTER', '-1'))
+# 3.6 ms as one replay -- so the module captures its own eval forward after two calls of a signature, sensor_agent.py untouched.
+# ``TFPP_EVAL_GRAPH_AFTER=-1`` in the environment (or ``model.eval_graph_after = -1``) keeps every call eager.
+# (Round 5 shipped this opt-in: in one test process the first replay of a fresh capture crashed inside hipGraphLaunch.  Round 6 found the cause --
+# per-engine torch.cuda.Stream objects alias each other and the capture stream once the process has used up PyTorch's pool of 32 native streams
+# (carla_garage_amd/streams.py) -- and made it the default; the sequence that crashed is a test: tests/test_model.py::test_captured_eval_signatures_are_bounded.)
+EVAL_GRAPH_AFTER = int(os.environ.get('TFPP_EVAL_GRAPH_AFTER', '2'))
 EVAL_GRAPH_MAX_PLANS = 4  # captured signatures per module (each owns the activations of one forward); further signatures keep running eagerly
 
 
@@ -344,7 +346,7 @@ class LidarCenterNet(nn.Module):
 
   def _plain_forward(self, inputs):
     """The forward without a backward to follow (model.eval() under no_grad / inference_mode: sensor_agent.py:456-461, train.py:923-956 validate()).
-    With EVAL_GRAPH_AFTER >= 0 (opt-in), eval-mode calls of one input signature are captured into a hipGraph after that many eager ones and replayed from then on; the caller gets
+    With EVAL_GRAPH_AFTER >= 0 (default 2), eval-mode calls of one input signature are captured into a hipGraph after that many eager ones and replayed from then on; the caller gets
     copies of the graph's output buffers (so results it keeps are not overwritten by the next call).  A captured plan is only replayed while every
     parameter and buffer has the address and version it had at the capture (Engine.fast_weights_key, ~0.3 ms of host time in front of the replay);
     otherwise it is dropped and the call runs eagerly on freshly packed weight images."""

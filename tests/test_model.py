@@ -1057,6 +1057,51 @@ def test_eval_forward_calls_are_captured_and_replayed_without_changing_results()
 
 
 @pytest.mark.gpu
+def test_the_streams_of_the_lanes_are_process_wide_and_pairwise_distinct():
+  """torch.cuda.Stream() hands out 32 native streams per device round-robin: per-engine stream objects alias each other (and the capture stream)
+  once a process has built a few models -- the cause of the round-5 crash inside hipGraphLaunch (carla_garage_amd/streams.py).  The registry
+  hands every role its stream once, with pairwise distinct native handles, whatever the pool position is."""
+  from carla_garage_amd import streams
+  for _ in range(45):  # wrap the pool
+    torch.cuda.Stream()
+  got = [streams.get('cuda', 'capture'), streams.get('cuda', 'pack'), streams.get('cuda', 'comm'), streams.get('cuda', 'copy')]
+  got += [streams.get('cuda', 'lane', k) for k in (1, 2)] + [streams.get('cuda', 'side', j) for j in range(4)]
+  hs = [s.cuda_stream for s in got]
+  assert len(set(hs)) == len(hs) and 0 not in hs, hs
+  assert streams.get('cuda:0', 'lane', 1) is got[4] and streams.get(torch.device('cuda', 0), 'side', 3) is got[-1]
+  m1, m2 = _model('bf16').eval(), _model('bf16').eval()
+  inp = [x.cuda() for x in P.make_inputs(1)]
+  with torch.inference_mode():
+    a, b = m1(*inp)[2], m2(*inp)[2]
+  assert torch.equal(a, b)
+  assert m1._engine().lanes.branch is m2._engine().lanes.branch is streams.get('cuda', 'lane', 1)
+
+
+@pytest.mark.gpu
+def test_captured_eval_signatures_are_bounded(monkeypatch):
+  """Every captured signature owns the activations of one forward: a module captures at most EVAL_GRAPH_MAX_PLANS of them, further signatures
+  keep running eagerly.  Three batch sizes on one bf16 module, right behind the two tests above in the same process: the sequence that crashed
+  inside hipGraphLaunch in round 5."""
+  import carla_garage_amd.model as MM
+  monkeypatch.setattr(MM, 'EVAL_GRAPH_MAX_PLANS', 2)
+  m = _model('bf16').eval()
+  m.eval_graph_after = 2
+  ref = {}
+  with torch.inference_mode():
+    for bs in (1, 2, 3):
+      inp = [x.cuda() for x in P.make_inputs(bs)]
+      ref[bs] = m(*inp)[2].clone()
+      for _ in range(4):
+        got = m(*inp)[2]
+      assert torch.equal(got, ref[bs])
+    captured = sorted(k[1][0][0] for k, pl in m._eval_plans.items() if pl.get('graph') is not None)  # batch size of the rgb input of the signature
+    assert captured == [1, 2], captured
+    for bs in (3, 1, 2, 1):  # replays of the captured signatures and eager calls of the third one, interleaved
+      inp = [x.cuda() for x in P.make_inputs(bs)]
+      assert torch.equal(m(*inp)[2], ref[bs])
+
+
+@pytest.mark.gpu
 def test_trainer_state_dict_round_trip_and_reference_layout():
   """Trainer.state_dict() has the layout of the reference's optimizer_%04d.pth (torch.optim.AdamW(model.parameters(), amsgrad=True),
   team_code/train.py:529-534,967-976): torch's own AdamW loads it; save -> fresh trainer -> load -> the next step is identical."""
