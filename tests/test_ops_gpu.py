@@ -1062,7 +1062,7 @@ BNS_CASES = [
     ('glds128', 12, 16, 64, 576, 576, 1, 1, 1, 200),     # stage-3 1x1 conv at bs = 12: 8-wave LDS-DMA kernel, M-major order
     ('glds64', 4, 16, 16, 576, 576, 1, 1, 1, 201),       # LiDAR branch: 64x128 LDS-DMA tiles
     ('halo', 2, 16, 64, 72, 72, 3, 1, 3, 302),           # grouped 3x3: halo kernel, one row per 8x32 tile
-    ('strided', 2, 16, 16, 48, 48, 3, 2, 2, 0),          # stride-2 grouped 3x3 (first block of a stage; 16 wide: implicit GEMM, the halo kernel has no statistics variant at stride 2)
+    ('strided', 2, 16, 8, 48, 48, 3, 2, 2, 0),           # stride-2 grouped 3x3 (first block of a stage; 8 wide: implicit GEMM, the halo kernel has no statistics variant at stride 2)
 ]
 
 
