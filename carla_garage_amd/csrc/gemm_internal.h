@@ -32,6 +32,7 @@ struct tfpp_wgrad_item {
   const void* dy; const void* x; float* dw; float* ws; const int* row_map; const int* col_map;
   int P, n_g, KK, c_real, splits, dy_ld, x_ld, dw_ld;
   int wg_start, wgs;  // workgroup range [wg_start, wg_start + wgs) of the launch (wg_start: a multiple of 8 = whole XCD rounds)
+  int pin, pad_;      // >= 0: slices are units pinned to XCDs, unit u on XCD (pin + u) % 8 (gemm_wgrad_glds.hip); -1: the tile orders of the single-layer kernel
 };
 #define TFPP_WGRAD_GROUP_MAX 42
 struct tfpp_wgrad_group {

@@ -699,6 +699,9 @@ static int emit_wgrad_group(const std::vector<tfpp_wgrad_params>& its, int tile,
   static const int target = [] { const char* e = std::getenv("TFPP_WGRAD_GROUP_TARGET"); const int v = e ? std::atoi(e) : 0; return v; }();
   // (swept on the bs = 12 step, profiles/r05_ab_wgrad_group_target.txt: 256: +0.4 ms, 512: +0.05, 2048: -0.03, 6144: +0.1 against the ungrouped lane)
   const long want_wgs = target > 0 ? target : 2048;
+  static const int pin_on = [] { const char* e = std::getenv("TFPP_WGRAD_PIN"); return (e && e[0] == '0') ? 0 : 1; }();
+  static const long pin_max_tiles = [] { const char* e = std::getenv("TFPP_WGRAD_PIN_MAX_TILES"); return e ? std::atol(e) : 48l; }();
+  static const double pin_slab_bytes = [] { const char* e = std::getenv("TFPP_WGRAD_PIN_SLAB_KB"); return (e ? std::atof(e) : 3072.0) * 1024.0; }();
   size_t pos = 0;
   while (pos < its.size()) {
     const size_t n = std::min(its.size() - pos, (size_t)TFPP_WGRAD_GROUP_MAX);
@@ -724,14 +727,32 @@ static int emit_wgrad_group(const std::vector<tfpp_wgrad_params>& its, int tile,
       if (sp < 1) sp = 1;
       if (sp > 64) sp = 64;
       if (sp >= 8) sp = sp / 8 * 8;
+      // Round 6: a layer with a small tile grid (stage-2 / stage-3 convolutions: 16-25 tiles, thousands of pixels) cannot give every XCD a
+      // block of tiles that share operand panels -- dealt round-robin over the XCDs every tile streamed its two panels from the fabric
+      // (157 MB for a 576 x 576 x 12288 layer whose operands are 28 MB).  Its pixel slices become units PINNED to one XCD each, sized so
+      // that the (tiles_m + tiles_n) panels of a slice fit that XCD's L2 (TFPP_WGRAD_PIN=0: the round-5 orders).
+      const long tm = cdiv(q.n_g, tile), tn = cdiv(q.ks_g, tile);
+      int pin = -1;
+      if (pin_on && tm * tn <= pin_max_tiles) {
+        const double slab = (double)(tm + tn) * tile * 2.0 * (double)P;  // bytes of all panels over all pixels
+        long fit = (long)(slab / pin_slab_bytes + 0.999);
+        const long max_sp = stages / 4 > 0 ? stages / 4 : 1;  // >= 4 stages per slice
+        if (fit > max_sp) fit = max_sp;
+        if (sp < fit) sp = fit;
+        if (sp > 64) sp = 64;
+        if (sp >= 8) sp = (sp + 7) / 8 * 8 <= 64 ? (sp + 7) / 8 * 8 : 64;
+        pin = (int)(i & 7);
+      }
       if (sp > 1 && sp * slice > ws_left - ws_off) sp = (ws_left - ws_off) / slice >= 2 ? (ws_left - ws_off) / slice : 1;
+      if ((sp & 7) == 0) pin = -1;  // whole XCD rounds of slices: the kernel's slice-per-XCD order already does this
       tfpp_wgrad_item& it = grp.it[grp.n++];
       it.dy = q.dy; it.x = q.x; it.dw = q.dw; it.row_map = q.row_map; it.col_map = q.col_map;
       it.P = (int)P; it.n_g = q.n_g; it.KK = q.ks_g; it.c_real = q.c_real; it.splits = (int)sp;
       it.dy_ld = (int)q.dy_ld; it.x_ld = (int)q.x_ld; it.dw_ld = (int)q.dw_ld;
       it.ws = sp > 1 ? ws + ws_off : nullptr;
       it.wg_start = grp.total;
-      it.wgs = (int)sp * cdiv(q.n_g, tile) * cdiv(q.ks_g, tile);
+      it.pin = pin; it.pad_ = 0;
+      it.wgs = (int)(pin >= 0 ? (sp + 7) / 8 * 8 : sp) * cdiv(q.n_g, tile) * cdiv(q.ks_g, tile);
       grp.total += (it.wgs + 7) / 8 * 8;
       if (sp > 1) {
         ws_off += sp * slice;

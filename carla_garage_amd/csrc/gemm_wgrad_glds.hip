@@ -47,8 +47,12 @@ template <> __device__ __forceinline__ int swz<128>(int p) { return 2 * (p & 3) 
 // spends ~110 non-MFMA instructions per 16 MFMAs (run-time pointwise / tap branches, 64-bit pointer selects).
 // One workgroup's share of one weight gradient: workgroup `wg_id` of the tfpp_conv_wgrad launch geometry of p (G * splits * tiles
 // workgroups).  Called once per workgroup by conv_wgrad_glds_kernel and in a loop by the grouped kernel below.
+// pin >= 0 (grouped launches, G = 1, layers with a small tile grid): the layer's p.splits pixel slices are UNITS pinned to XCDs -- unit u
+// runs all of its tiles on XCD (pin + u) % 8, back to back, so the (tiles_m + tiles_n) operand panels of a slice enter ONE L2 once and are
+// shared by all tiles of the slice (the host picks the slices so that this slab fits the L2).  The workgroup range of such a layer is
+// 8 * ceil(splits / 8) * ntiles wide; workgroups whose (XCD, position) maps to no unit return at once.
 template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE, bool PW>
-__device__ __forceinline__ void wgrad_glds_tile(const tfpp_wgrad_params& p, const int wg_id) {
+__device__ __forceinline__ void wgrad_glds_tile(const tfpp_wgrad_params& p, const int wg_id, const int pin = -1) {
   typedef bf16_t T;
   constexpr int NT = WGM * WGN * 64, NWAVES = WGM * WGN;
   constexpr int WM = TM / WGM, WN = TN / WGN, FM = WM / 16, FN = WN / 16, KS = BKP / 32;
@@ -73,10 +77,17 @@ __device__ __forceinline__ void wgrad_glds_tile(const tfpp_wgrad_params& p, cons
   int g, split, tile_m, tile_n;
   {
     const int id = wg_id, per_g = p.splits * ntiles;
-    g = id / per_g;
+    g = pin >= 0 ? 0 : id / per_g;  // (pinned layers have one group and a range wider than splits * ntiles)
     const int r = id - g * per_g;
     int tile;
-    if ((p.splits & 7) == 0) {
+    if (pin >= 0) {
+      const int xcd = r & 7, j = r >> 3, rnd = j / ntiles;
+      split = rnd * 8 + ((xcd - pin) & 7);
+      if (split >= p.splits) return;  // (uniform over the workgroup)
+      tile = j - rnd * ntiles;
+      tile_m = tile % tiles_m;
+      tile_n = tile / tiles_m;
+    } else if ((p.splits & 7) == 0) {
       const int xcd = r & 7, j = r >> 3;
       tile = j % ntiles;
       split = (j / ntiles) * 8 + xcd;
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_wgrad_glds_group_kernel(c
     const int local = id - grp.it[k].wg_start;
     if (local < grp.it[k].wgs) {  // (the workgroup ranges are padded to whole XCD rounds)
       const tfpp_wgrad_params p = tfpp_wgrad_item_params(grp.it[k]);
-      wgrad_glds_tile<TM, TN, WGM, WGN, BKP, NSTAGE, true>(p, local);
+      wgrad_glds_tile<TM, TN, WGM, WGN, BKP, NSTAGE, true>(p, local, grp.it[k].pin);
     }
     if (id + (int)gridDim.x < grp.total) {  // another tile follows: every wave is done with the LDS ring before its first DMA, and the
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // epilogue's loads / stores no longer count against the ring's vmcnt arithmetic

@@ -196,7 +196,8 @@ def test_weight_gradients_of_a_batch_with_persistent_workgroups_and_without_grou
   workgroups per layer (no pixel split anywhere) and with many pixel slices walked by a capped grid."""
   import subprocess
   import sys
-  for env in ({'TFPP_WGRAD_GROUP_WGS': '24'}, {'TFPP_WGRAD_GROUP_TARGET': '200'}, {'TFPP_WGRAD_GROUP_TARGET': '20000', 'TFPP_WGRAD_GROUP_WGS': '64'}):
+  for env in ({'TFPP_WGRAD_GROUP_WGS': '24'}, {'TFPP_WGRAD_GROUP_TARGET': '200'}, {'TFPP_WGRAD_GROUP_TARGET': '20000', 'TFPP_WGRAD_GROUP_WGS': '64'},
+              {'TFPP_WGRAD_PIN': '0'}, {'TFPP_WGRAD_PIN_SLAB_KB': '512', 'TFPP_WGRAD_GROUP_WGS': '40'}):
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', 'test_weight_gradients_of_a_batch_as_grouped_launches'],
                        env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, check=False)
     assert r.returncode == 0, (env, r.stdout.decode()[-2000:])
