@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(PKG_DIR, 'libtfpp_hip.so')
 SOURCES = ['gemm_kernels.hip', 'gemm_glds.hip', 'gemm_wgrad_glds.hip', 'attention_kernels.hip', 'conv3x3_halo.hip', 'wgrad3x3_halo.hip', 'pointwise_kernels.hip', 'norm_kernels.hip', 'bn_rows_kernels.hip', 'misc_kernels.hip', 'lidar_kernels.hip', 'swin_kernels.hip', 'bev_kernels.hip', 'head_kernels.hip', 'augment_kernels.hip']
 
 F32, BF16 = 0, 1
-ABI_VERSION = 6  # include/tfpp.h TFPP_ABI_VERSION
+ABI_VERSION = 7  # include/tfpp.h TFPP_ABI_VERSION
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU, ACT_TANH = 0, 1, 2, 3, 4
 EINVAL = -1000
 
@@ -36,7 +36,7 @@ class ConvParams(ctypes.Structure):
               ('pad', i32), ('G', i32), ('ks_g', i32), ('n_g', i32), ('mode', i32), ('act', i32), ('dst_nchw', i32),
               ('alpha', f32), ('src_ld', i64), ('dst_ld', i64), ('res_ld', i64), ('dst_f32', i32), ('stats_partial', vp), ('stats_rows', i32), ('stats_store', i32), ('splitk_ws', vp),
               ('splitk_ws_floats', i64), ('splitk', i32), ('bns_y', vp), ('bns_x', vp), ('bns_mean', vp), ('bns_invstd', vp),
-              ('bns_partial', vp), ('bns_ld', i64), ('bns_relu', i32), ('in_bn', BnRows), ('in_relu', i32)]
+              ('bns_partial', vp), ('bns_ld', i64), ('bns_relu', i32), ('in_bn', BnRows), ('in_relu', i32), ('relu_mask', vp), ('relu_mask_ld', i64)]
 
 
 class WgradParams(ctypes.Structure):

@@ -245,6 +245,12 @@ __device__ __forceinline__ void epi_pass_bf16(const tfpp_conv_params& p, const f
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
       }
+      if (p.relu_mask) {  // ReLU backward of the tensor this gradient belongs to (tfpp.h)
+        float fv[8];
+        load_vec<bf16_t>(reinterpret_cast<const bf16_t*>(p.relu_mask) + (size_t)m * p.relu_mask_ld + ch, fv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fv[e] > 0.f ? v[e] : 0.f;
+      }
       const uint4 packed = pack16<bf16_t>(v);
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.dst) + (size_t)m * p.dst_ld + ch) = packed;
       if constexpr (BNS) {
@@ -292,6 +298,12 @@ __device__ __forceinline__ void epi_finish_bf16(const tfpp_conv_params& p, const
       if (p.act != ACT_NONE) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
+      }
+      if (p.relu_mask) {
+        float fv[8];
+        load_vec<bf16_t>(reinterpret_cast<const bf16_t*>(p.relu_mask) + (size_t)m * p.relu_mask_ld + ch, fv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fv[e] > 0.f ? v[e] : 0.f;
       }
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.dst) + (size_t)m * p.dst_ld + ch) = pack16<bf16_t>(v);
     }

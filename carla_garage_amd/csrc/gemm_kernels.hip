@@ -366,6 +366,22 @@ extern "C" int tfpp_conv_gemm_bns_ok(const tfpp_conv_params* p, int dtype) {
   return conv_bns_ok(q, dtype) ? 1 : 0;
 }
 
+// ReLU backward in the epilogue (tfpp_conv_params.relu_mask): the vector epilogue of a launch without a K split
+static bool conv_relu_mask_ok(const tfpp_conv_params& p, int dtype) {
+  if (dtype != TFPP_BF16 || p.dst_nchw || p.dst_f32 || ((p.n_g | (int)p.dst_ld | (int)p.relu_mask_ld) & 7) || ((uintptr_t)p.dst & 15)) return false;
+  if (((uintptr_t)p.relu_mask & 15) || p.bns_partial) return false;
+  if (p.res && ((((int)p.res_ld) & 7) || ((uintptr_t)p.res & 15))) return false;
+  if (p.R * p.S * p.ks_g <= 32) return false;
+  return conv_splits_for(p, dtype) == 1;
+}
+extern "C" int tfpp_conv_gemm_relu_mask_ok(const tfpp_conv_params* p, int dtype) {
+  if (!p) return TFPP_EINVAL;
+  tfpp_conv_params q = *p;
+  if (!q.relu_mask) q.relu_mask = reinterpret_cast<const void*>(16);
+  if (q.relu_mask_ld == 0) q.relu_mask_ld = q.dst_ld;
+  return conv_relu_mask_ok(q, dtype) ? 1 : 0;
+}
+
 extern "C" int tfpp_conv_gemm_in_bn_ok(const tfpp_conv_params* p, int dtype) {
   if (!p) return TFPP_EINVAL;
   return conv_halo_in_bn_ok(*p, dtype) ? 1 : 0;
@@ -389,6 +405,7 @@ template <typename T> static int dispatch_conv(const tfpp_conv_params& p, hipStr
   if (p.bns_partial && (!conv_bns_ok(p, ElemTraits<T>::DT) || !p.bns_x || !p.bns_mean || !p.bns_invstd || (p.bns_relu && !p.bns_y)))
     return TFPP_EINVAL;  // the caller asks tfpp_conv_gemm_bns_ok first
   if (p.in_bn.scale && !conv_halo_in_bn_ok(p, ElemTraits<T>::DT)) return TFPP_EINVAL;  // the caller asks tfpp_conv_gemm_in_bn_ok first
+  if (p.relu_mask && !conv_relu_mask_ok(p, ElemTraits<T>::DT)) return TFPP_EINVAL;      // the caller asks tfpp_conv_gemm_relu_mask_ok first
   if (p.stats_partial && p.stats_store && p.stats_rows != tfpp_conv_gemm_stats_rows(&p, ElemTraits<T>::DT)) return TFPP_EINVAL;
   if (conv_halo_supported(p, ElemTraits<T>::DT)) return conv_gemm_halo(p, st);
   tfpp_conv_params q = p;

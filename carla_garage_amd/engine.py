@@ -413,6 +413,7 @@ def _early_weights(name):
   """Layers that run before the first fusion point of the default TransFuser backbone (everything else is packed beside them)."""
   return any(name.startswith(p) for p in ('backbone.image_encoder.stem', 'backbone.image_encoder.s1.', 'backbone.lidar_encoder.stem',
                                           'backbone.lidar_encoder.s1.', 'backbone.lidar_channel_to_img.0'))
+RELU_IN_DGRAD = os.environ.get('TFPP_RELU_IN_DGRAD', '1') != '0'  # ReLU backward of conv + bias + ReLU layers in the epilogue of the data gradient that completes their output gradient
 _SKIP_SIDE_WORK = os.environ.get('TFPP_DEBUG_SKIP_SIDE_WORK', '0') == '1'
 _SIDE_CHECK = os.environ.get('TFPP_DEBUG_SIDE_CHECK', '0') == '1'
 _KEEP_ALL = os.environ.get('TFPP_DEBUG_KEEP_ALL', '0') == '1'
@@ -656,6 +657,7 @@ class Engine:
     self._consts = {}
     self._packed_key = None
     self._bn_of, self._bn_pre = {}, {}  # per forward: key(y) -> (spec, raw, relu) of conv+BN layers / key(y) -> fused backward sums
+    self._relu_of, self._relu_done = {}, {}  # per forward: key(y) -> y of conv+bias+ReLU layers / key(y) -> the gradient that arrives already masked
     self._generation = 0
     self._plans, self._plan, self._plan_key = {}, None, None
     self._pack_stream, self._pack_pending = None, False
@@ -1125,6 +1127,8 @@ class Engine:
       y = torch.empty((B, Ho, Wo, s.n_store), device=xt.device, dtype=odt)
       ops.conv_gemm(xt, s.wp, y, act=act, shift=s.bias_pad, res=res, **in_kw, **geo)
       raw = None
+      if RELU_IN_DGRAD and self.tape is not None and act == ACT_RELU and odt == torch.bfloat16:
+        self._relu_of[_key(y)] = y  # the data gradient that completes d(y) may apply this layer's ReLU backward in its epilogue
     elif not bn_train:
       if self.tape is not None:
         raise NotImplementedError('gradients through eval-mode BatchNorm are not implemented on the HIP path (round 1); '
@@ -1174,7 +1178,8 @@ class Engine:
         self.side.label = key
         self.side.in_tail = ('.s1.' in key or key.endswith('.stem'))
         if s.bn is None:
-          dz = ops.act_bwd(dy, y, act) if act != ACT_NONE else dy
+          masked = self._relu_done.pop(_key(y), None) is dy  # the kernel that wrote dy already zeroed it where y <= 0
+          dz = ops.act_bwd(dy, y, act) if (act != ACT_NONE and not masked) else dy
           dres = dz if res is not None else None
           if s.bias is not None and s.bias.requires_grad:
 
@@ -1223,9 +1228,20 @@ class Engine:
         if x_grad:
           dx = torch.empty((B, H, W, Cs), device=xt.device, dtype=xt.dtype)
           # a gradient already pending for x (the other path of a residual / FPN fan-out) is added in the GEMM epilogue
+          last = Tape.current.is_last_contribution(xin)
           pend = Tape.current.take_pending(xin, dx)
           dgeo = dict(B=B, Hs=Ho, Ws=Wo, Cs=s.n_store, Hd=H, Wd=W, Cd=Cs, R=k, S=k, stride=st, pad=pd, G=G, ks_g=s.n_store // G, n_g=Cs // G,
                       mode=1, res=pend)
+          # x = relu(conv + bias) of a layer without BatchNorm and this is the last addend of d(x): that layer's ReLU backward runs here
+          fwd_x = self._relu_of.get(_key(xin)) if xv is None else None
+          if fwd_x is not None and last:  # (masking is idempotent: an addend that still arrived later would only bring the separate pass back)
+            mk = ('relu_mask', tuple(xt.shape), pend is not None)
+            ok = s.plan_cache.get(mk)
+            if ok is None:
+              ok = s.plan_cache[mk] = ops.conv_gemm(gsrc, s.wt, dx, relu_mask_query=True, **dgeo)
+            if ok:
+              dgeo['relu_mask'] = fwd_x
+              self._relu_done[_key(xin)] = dx
           ops.conv_gemm(gsrc, s.wt, dx, **dgeo)
         return dx, dres
 
@@ -1734,6 +1750,7 @@ class Engine:
     bb = m.backbone
     out = {}
     self._bn_of, self._bn_pre = {}, {}
+    self._relu_of, self._relu_done = {}, {}
     if self.sync_bn:
       import torch.distributed as dist
       self.sync_world = dist.get_world_size(self.sync_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -1743,7 +1760,7 @@ class Engine:
     if ops.NODE_HASH['on'] and self.tape is not None:
       ops.node_hash_begin(dev)
     if self.tape is not None:
-      self.tape.on_accumulate = lambda key: self._bn_pre.pop(key, None)  # a "complete" gradient got another addend: sums are stale
+      self.tape.on_accumulate = lambda key: (self._bn_pre.pop(key, None), self._relu_done.pop(key, None))  # a "complete" gradient got another addend: sums / mask are stale
     self.lanes.begin(dev)
     mul = add = None
     if cfg.normalize_imagenet:

@@ -85,7 +85,7 @@ def splitk_workspace(device):
 def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad=0, G=1, ks_g=None, n_g=None, mode=0,
               act=ACT_NONE, scale=None, shift=None, res=None, alpha=1.0, dst_nchw=False, src_ld=None, dst_ld=None,
               res_ld=None, stats_ws=None, stats_acc=None, plan_only=False, bns=None, bns_query=False, stats_rows_query=False, stats_store=None,
-              in_bn=None, in_relu=False, in_bn_query=False):
+              in_bn=None, in_relu=False, in_bn_query=False, relu_mask=None, relu_mask_query=False):
   """stats_ws (double[2*Cd]): also produce per-channel sum / sum of squares of the result (fused BatchNorm statistics).
   stats_acc (True, or zeroed fp32 accumulation rows from stats_rows_buffer()): leave the statistics in the rows for
   bn_finalize_partials and return (number of rows used, rows buffer).
@@ -115,6 +115,11 @@ def conv_gemm(src, w, dst, *, B, Hs, Ws, Cs, Hd, Wd, Cd, R=1, S=1, stride=1, pad
     return lib.raw('tfpp_conv_gemm_stats_rows')(ctypes.byref(p), dt(src))
   if in_bn is not None:
     p.in_bn, p.in_relu = in_bn, int(in_relu)
+  if relu_mask_query:  # can the kernel that runs this data gradient apply a ReLU mask in its epilogue (tfpp_conv_params.relu_mask)?
+    p.relu_mask_ld = Cd
+    return bool(lib.raw('tfpp_conv_gemm_relu_mask_ok')(ctypes.byref(p), dt(src)))
+  if relu_mask is not None:  # forward value of the tensor whose gradient this call completes: zero the result where it is <= 0
+    p.relu_mask, p.relu_mask_ld = ptr(relu_mask), Cd
   if bns_query:  # (can the kernel that runs here emit the fused BatchNorm-backward statistics?, rows of bns_partial it would write)
     p.bns_ld = Cd
     p.bns_partial = 16  # never dereferenced: plan as the launch with the statistics will be planned (tile variant, no split-K)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TFPP_ABI_VERSION 6
+#define TFPP_ABI_VERSION 7
 #define TFPP_EINVAL (-1000)
 #define TFPP_F32 0
 #define TFPP_BF16 1
@@ -111,6 +111,13 @@ typedef struct {
    * finalize prologue described at tfpp_bn_rows.  in_bn.scale == NULL: feature off. */
   tfpp_bn_rows in_bn;
   int in_relu;
+  /* Round 6 (data gradients): the tensor whose gradient this call completes went through a ReLU (conv + bias + ReLU layers without
+   * BatchNorm: transfuser_utils.py:685-704 decoders, center_net.py heads).  relu_mask = that tensor's FORWARD value [M][relu_mask_ld]
+   * (bf16, same row layout as dst): the finished result (residual / pending gradient added) is zeroed where the forward value is <= 0,
+   * i.e. the activation's backward runs in this epilogue instead of as a pass of its own.  tfpp_conv_gemm_relu_mask_ok() says whether
+   * the kernel the dispatcher picks can do it (vector epilogue, no K split). */
+  const void* relu_mask;
+  int64_t relu_mask_ld;
 } tfpp_conv_params;
 /* number of K slices the dispatcher would use for p (1 = no split) */
 int tfpp_conv_gemm_splits(const tfpp_conv_params* p, int dtype);
@@ -126,6 +133,7 @@ int tfpp_conv_gemm_stats_rows(const tfpp_conv_params* p, int dtype);
 /* 1 if the kernel the dispatcher runs for (p, dtype) supports the fused BatchNorm-backward statistics (bns_* fields) */
 int tfpp_conv_gemm_bns_ok(const tfpp_conv_params* p, int dtype);
 /* 1 if the kernel the dispatcher runs for (p, dtype) can normalise its source while loading it (in_bn) */
+int tfpp_conv_gemm_relu_mask_ok(const tfpp_conv_params* p, int dtype);  /* 1: tfpp_conv_params.relu_mask is honoured for this launch */
 int tfpp_conv_gemm_in_bn_ok(const tfpp_conv_params* p, int dtype);
 /* debugging aid (TFPP_GLDS_TRACE=1): per-workgroup phase timestamps of the last LDS-DMA GEMM launch; returns slots per workgroup */
 int tfpp_debug_glds_trace(uint64_t* out, int n_blocks);

@@ -1115,6 +1115,40 @@ def test_dgrad_epilogue_emits_the_batchnorm_backward_sums(ops, case):
   check(name + '.bn_bwd_rows.dbeta', db1, db2, torch.float32, scale=5.0)
 
 
+RELU_MASK_CASES = [
+    # name, B, H, W, Cin (channels of the gradient produced), Cout, k, groups
+    ('halo_fullres_decoder', 2, 64, 96, 32, 8, 3, 1),     # deconv3.2 -> deconv3.0 of the perspective decoders
+    ('halo_64', 2, 32, 64, 64, 32, 3, 1),
+    ('lds_1x1', 3, 16, 20, 72, 72, 1, 1),
+    ('glds_1x1', 12, 16, 64, 576, 576, 1, 1),
+]
+
+
+@pytest.mark.parametrize('case', RELU_MASK_CASES, ids=[c[0] for c in RELU_MASK_CASES])
+def test_dgrad_epilogue_applies_the_relu_backward(ops, case):
+  """tfpp_conv_params.relu_mask: the data gradient that completes d(y), y = relu(conv + bias), zeroes it where y <= 0 -- bit-equal to the plain
+  call followed by tfpp_act_bwd, with and without a pending gradient added in the same epilogue."""
+  name, B, H, W, Cin, Cout, k, G = case
+  dtype = torch.bfloat16
+  pad = k // 2
+  dy = dev(nhwc(rnd(B, Cout, H, W, dtype=dtype, seed=1)), dtype)
+  w = (rnd(Cout, Cin // G, k, k, dtype=dtype, seed=2) * (1.0 / math.sqrt(Cin // G * k * k))).to(dtype).float()
+  wt = ops.pack_conv_weight(dev(w), dtype, G=G, transpose=True)
+  y = torch.relu(rnd(B, H, W, Cin, dtype=dtype, seed=3))  # forward value with zeros
+  yd = dev(y, dtype)
+  pend = dev(rnd(B, H, W, Cin, dtype=dtype, seed=4), dtype)
+  for res in (None, pend):
+    geo = dict(B=B, Hs=H, Ws=W, Cs=Cout, Hd=H, Wd=W, Cd=Cin, R=k, S=k, stride=1, pad=pad, G=G, mode=1, res=res)
+    dx = torch.empty((B, H, W, Cin), device=DEV, dtype=dtype)
+    assert ops.conv_gemm(dy, wt, dx, relu_mask_query=True, **geo), 'this shape is expected on a kernel with the vector epilogue and no K split'
+    ops.conv_gemm(dy, wt, dx, relu_mask=yd, **geo)
+    plain = torch.empty_like(dx)
+    ops.conv_gemm(dy, wt, plain, **geo)
+    want = ops.act_bwd(plain, yd, ops.ACT_RELU)
+    assert torch.equal(dx, want), f'{name}: masked epilogue differs from conv + act_bwd'
+    assert (dx[yd <= 0] == 0).all() and torch.count_nonzero(dx).item() > 0
+
+
 def test_se_bwd_apply_with_fused_batchnorm_backward_sums(ops):
   dtype = torch.bfloat16
   B, H, W, C = 3, 16, 20, 216
