@@ -750,7 +750,7 @@ static int emit_wgrad_group(const std::vector<tfpp_wgrad_params>& its, int tile,
       // that the (tiles_m + tiles_n) panels of a slice fit that XCD's L2 (TFPP_WGRAD_PIN=0: the round-5 orders).
       const long tm = cdiv(q.n_g, tile), tn = cdiv(q.ks_g, tile);
       int pin = -1;
-      if (pin_on && tm * tn <= pin_max_tiles) {
+      if (pin_on && tile <= 128 && tm * tn <= pin_max_tiles) {
         const double slab = (double)(tm + tn) * tile * 2.0 * (double)P;  // bytes of all panels over all pixels
         long fit = (long)(slab / pin_slab_bytes + 0.999);
         const long max_sp = stages / 4 > 0 ? stages / 4 : 1;  // >= 4 stages per slice
@@ -801,7 +801,8 @@ extern "C" int tfpp_conv_wgrad_batch(const tfpp_wgrad_params* items, int n, int 
   if (!items || n < 0 || (dtype != TFPP_F32 && dtype != TFPP_BF16)) return TFPP_EINVAL;
   static const int grid_cap = [] { const char* e = std::getenv("TFPP_WGRAD_GROUP_WGS"); return e ? std::atoi(e) : 0; }();
   hipStream_t st = (hipStream_t)stream;
-  GroupBuild g64{64, 32, {}}, g128{128, 64, {}};
+  GroupBuild g64{64, 32, {}}, g128{128, 64, {}}, g256{256, 32, {}};
+  static const int t256 = [] { const char* e = std::getenv("TFPP_WGRAD_GROUP_256"); return (e && e[0] == '0') ? 0 : 1; }();
   std::vector<const float*> seen;
   for (int i = 0; i < n; ++i) {
     tfpp_wgrad_params q = items[i];
@@ -811,7 +812,8 @@ extern "C" int tfpp_conv_wgrad_batch(const tfpp_wgrad_params* items, int n, int 
       WgradPlan pl;
       tfpp_wgrad_params t = q;
       if (plan_wgrad<bf16_t>(t, pl) == 0 && (pl.variant == 2 || pl.variant == 4)) {
-        (pl.variant == 4 ? g128 : g64).items.push_back(q);
+        const bool wide = t256 && pl.variant == 4 && q.n_g >= 1024 && q.ks_g >= 1024;
+        (wide ? g256 : (pl.variant == 4 ? g128 : g64)).items.push_back(q);
         grouped = true;
       }
     }
@@ -820,7 +822,7 @@ extern "C" int tfpp_conv_wgrad_batch(const tfpp_wgrad_params* items, int n, int 
     const int rc = dtype == TFPP_F32 ? dispatch_wgrad<float>(q, 0, nullptr, st) : dispatch_wgrad<bf16_t>(q, 0, nullptr, st);
     if (rc != 0) return rc;
   }
-  for (GroupBuild* g : {&g128, &g64}) {
+  for (GroupBuild* g : {&g256, &g128, &g64}) {
     if (g->items.empty()) continue;
     // longest pixel reductions first: the workgroups that run longest are dispatched first
     std::stable_sort(g->items.begin(), g->items.end(), [](const tfpp_wgrad_params& a, const tfpp_wgrad_params& b) {

@@ -40,6 +40,7 @@ namespace {
 template <int T> __device__ __forceinline__ int swz(int p);
 template <> __device__ __forceinline__ int swz<64>(int p) { return 2 * ((p >> 1) & 1) + 4 * ((p >> 3) & 1); }
 template <> __device__ __forceinline__ int swz<128>(int p) { return 2 * (p & 3) + 8 * ((p >> 3) & 1); }
+template <> __device__ __forceinline__ int swz<256>(int p) { return 2 * (p & 3) + 8 * ((p >> 3) & 1); }  // 512-byte rows = two bank rows: the same eight 32-byte pairs
 
 // PW: pointwise layers (every linear / 1x1 conv: all but the 3x3 heads) take a lean pixel loop -- scalar loop control, 32-bit running byte
 // offsets against the uniform operand bases, out-of-tile channels clamped into the row instead of redirected to the zero page (they only
@@ -513,6 +514,7 @@ template <int TM, int TN, int WGM, int WGN, int BKP, int NSTAGE> static int laun
   // TFPP_WGRAD_GROUP_LDS (bytes): occupancy limiter of the grouped grids, for A/B runs (see launch_wgrad_glds)
   static const size_t min_lds = [] { const char* e = std::getenv("TFPP_WGRAD_GROUP_LDS"); return e ? (size_t)std::atol(e) : (size_t)0; }();
   const size_t lds = (TM == 128 && min_lds > need) ? min_lds : need;
+  static_assert(need <= 160 * 1024, "ring must fit the LDS of a CU");
   static unsigned long long attr_mask = 0;
   if (tfpp_first_use_on_this_device(&attr_mask))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_glds_group_kernel<TM, TN, WGM, WGN, BKP, NSTAGE>),
@@ -528,5 +530,9 @@ int conv_wgrad_glds_group(const tfpp_wgrad_group& grp, int tile, int grid_cap, h
   if (grp.n < 1 || grp.total < 1) return 0;
   // 128 x 128: the 2 x 32 KB ring (two workgroups per CU, or one beside a forward / data-gradient GEMM of the dY chain)
   if (tile == 128) return launch_wgrad_glds_group<128, 128, 2, 4, 64, 2>(grp, grid_cap, st);
+  // 256 x 256 (round 6; layers with n_g, KK >= 1024: the C = 1512 fusion transformer and stage 4): 8 waves of 128 x 64, 32-pixel stages,
+  // 4 x 32 KB ring, one workgroup per CU.  Half the operand bytes per FLOP of the 128 x 128 tile, and a 3840 x 6048 x 1512 layer is 144
+  // workgroups -- ONE round of the chip, so the tiles that share a panel start together and meet in the L2.
+  if (tile == 256) return launch_wgrad_glds_group<256, 256, 2, 4, 32, 4>(grp, grid_cap, st);
   return launch_wgrad_glds_group<64, 64, 2, 2, 32, 4>(grp, grid_cap, st);
 }
