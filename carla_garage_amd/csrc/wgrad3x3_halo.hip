@@ -26,7 +26,7 @@ __device__ __forceinline__ uint2 lds_tr16(const bf16_t* p) {
 // XBN (round 6): x exists only as (raw output of the 1x1 convolution in front, final BatchNorm scale / shift): every staged chunk of the halo
 // becomes relu(raw * scale[c] + shift[c]) on its way into LDS; out-of-image chunks stay zero (tfpp_wgrad_params.x_scale).
 template <int FNN, int CV, bool XBN = false>
-__global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(tfpp_wgrad_params p, int tiles_w, int tiles_h, int nblk) {
+__global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(tfpp_wgrad_params p, int tiles_w, int tiles_h, int nblk, int xcd_order) {
   typedef bf16_t T;
   constexpr int CB = CV <= 2 ? 1 : (CV <= 4 ? 2 : 4);
   constexpr int NCOL = 9 * CB, NCW = (NCOL + 3) / 4;  // column blocks in total / per wave
@@ -35,7 +35,19 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(tfpp_wgrad_params p,
   constexpr int cin = CV * 8, cv = CV;
   const int ng = p.n_g, nv = ng >> 3;
   const int npitch = FNN * 16 + 8;  // dY row pitch in elements (16-byte skew)
-  const int g = blockIdx.y;
+  // Workgroup id -> (slice, group).  The groups of a layer read 16 * CV-byte pieces of the same NHWC pixel rows (three groups share a 128-byte line
+  // at 24 channels per group).  xcd_order (1-D grid, nblk a multiple of 8): XCD x owns the slices x, x + 8, ... and runs ALL groups of a slice back
+  // to back, so the pixel rows of a tile enter ONE L2 once and serve every group (the 2-D grid dealt the groups of a tile over all eight XCDs:
+  // 57 MB fetched for a stage-3 layer whose operands are 28 MB, profiles/r06_pmc_all_kernels_before_pin.txt).
+  int g, slice;
+  if (xcd_order) {
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    g = j % p.G;
+    slice = (j / p.G) * 8 + xcd;
+  } else {
+    g = blockIdx.y;
+    slice = blockIdx.x;
+  }
   const int H = p.Hd, W = p.Wd;
   T* halo = reinterpret_cast<T*>(smem);                       // [HH*HWID][cin] (+ one chunk row of slack for the last block's overhang)
   T* dyl = halo + (HH * HWID + 4) * cin;                      // [TH*TW][npitch]
@@ -55,7 +67,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(tfpp_wgrad_params p,
     if (tid < cin) { x_sc[tid] = p.x_scale[g * cin + tid]; x_sh[tid] = p.x_shift[g * cin + tid]; }
     __syncthreads();
   }
-  for (int t = blockIdx.x; t < ntiles; t += nblk) {
+  for (int t = slice; t < ntiles; t += nblk) {
     const int tw = t % tiles_w, t2 = t / tiles_w, th = t2 % tiles_h, b = t2 / tiles_h;
     const int h0 = th * TH, w0 = tw * TW;
     // ---- stage X halo and dY tile (zero outside the image)
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(tfpp_wgrad_params p,
 
   // ---- this workgroup's slice -> workspace [blockIdx.x][G*n_g][KK]
   const int KK = 9 * cin;
-  float* __restrict__ wsp = p.ws + ((size_t)blockIdx.x * p.G * ng + (size_t)g * ng) * KK;
+  float* __restrict__ wsp = p.ws + ((size_t)slice * p.G * ng + (size_t)g * ng) * KK;
 #pragma unroll
   for (int c = 0; c < NCW; ++c) {
     const int col = wave + 4 * c;
@@ -170,8 +182,11 @@ template <int FNN, int CV> int launch(const tfpp_wgrad_params& p, int nblk, hipS
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_halo_kernel<FNN, CV>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_halo_kernel<FNN, CV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
   }
-  if (p.x_scale) hipLaunchKernelGGL((wgrad3x3_halo_kernel<FNN, CV, true>), dim3((unsigned)nblk, (unsigned)p.G), dim3(256), lds, st, p, tiles_w, tiles_h, nblk);
-  else hipLaunchKernelGGL((wgrad3x3_halo_kernel<FNN, CV>), dim3((unsigned)nblk, (unsigned)p.G), dim3(256), lds, st, p, tiles_w, tiles_h, nblk);
+  static const int xo_env = [] { const char* e = std::getenv("TFPP_WGRAD_HALO_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+  const int xo = (xo_env && p.G > 1 && nblk % 8 == 0) ? 1 : 0;
+  const dim3 grid = xo ? dim3((unsigned)(nblk * p.G)) : dim3((unsigned)nblk, (unsigned)p.G);
+  if (p.x_scale) hipLaunchKernelGGL((wgrad3x3_halo_kernel<FNN, CV, true>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, nblk, xo);
+  else hipLaunchKernelGGL((wgrad3x3_halo_kernel<FNN, CV>), grid, dim3(256), lds, st, p, tiles_w, tiles_h, nblk, xo);
   TFPP_CHECK_LAUNCH();
   return 0;
 }
@@ -200,6 +215,7 @@ int wgrad_halo_slices(const tfpp_wgrad_params& p, int dtype) {
   long nblk = total_wgs / p.G;
   if (nblk < 1) nblk = 1;
   if (nblk > tiles) nblk = tiles;
+  if (p.G > 1 && nblk >= 8) nblk = (nblk + 4) / 8 * 8 <= tiles ? (nblk + 4) / 8 * 8 : nblk / 8 * 8;  // whole XCD rounds of slices (see the kernel)
   const long slice = (long)p.G * p.n_g * 9 * p.ks_g;
   if (nblk * slice > p.ws_floats) nblk = p.ws_floats / slice;
   return nblk >= 1 ? (int)nblk : 0;
