@@ -579,7 +579,9 @@ def graph_trace():
 def kernel_pattern(fam):
   """Substring of the demangled kernel name that identifies the kernels of family `fam` in a rocprofv3 table (None: no single kernel)."""
   import re
-  if fam == 'conv_wgrad<bf16,group128>':  # the grouped weight-gradient grids of a lane batch, one family per member kernel (ops.wgrad_batch_end)
+  if fam == 'conv_wgrad<bf16,group256>':  # the grouped weight-gradient grids of a lane batch, one family per member kernel (ops.wgrad_batch_end)
+    return 'conv_wgrad_glds_group_kernel<256, 256,'
+  if fam == 'conv_wgrad<bf16,group128>':
     return 'conv_wgrad_glds_group_kernel<128, 128,'
   if fam == 'conv_wgrad<bf16,group64>':
     return 'conv_wgrad_glds_group_kernel<64, 64,'

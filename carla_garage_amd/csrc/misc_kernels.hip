@@ -711,12 +711,11 @@ extern "C" int tfpp_inc_u64(uint64_t* p, void* stream) {
 // Completion signal between a kernel node INSIDE a captured hipGraph and a stream OUTSIDE of it (carla_garage_amd/buckets.py).  ROCm 7.x offers
 // no host-side primitive for that (tools/graph_external_event_test.py: PyTorch refuses external events on ROCm, hipEventRecordWithFlags(...,
 // hipEventRecordExternal) returns hipErrorInvalidValue inside a capture, hipMallocSignalMemory is not available), so the signal is a counter
-// in device memory: tfpp_signal_add is a one-thread kernel node behind the kernels that complete a gradient bucket (device-scope atomic
-// add), tfpp_signal_wait is a one-wave kernel on the collective's stream that polls it with a device-scope atomic (coherent across the XCDs'
+// in device memory: tfpp_signal_set (below) is a one-thread kernel node behind the kernels that complete a gradient bucket -- it raises the
+// word to the serial number of the running pass --, tfpp_signal_wait is a one-wave kernel on the collective's stream that polls it with a device-scope atomic (coherent across the XCDs'
 // L2s, ~1 poll per microsecond, s_sleep in between) until it reaches `value`; the kernel boundary behind it is the acquire for whatever the
 // next kernel on that stream (the RCCL all-reduce) reads.  A wait that sees nothing for `timeout_ms` gives up and counts in *timeouts
 // (a stuck stream must never hang the GPU box); the caller checks that word at its next synchronisation point.
-__global__ void signal_add_kernel(unsigned long long* sig) { atomicAdd(sig, 1ull); }
 __global__ void signal_wait_kernel(unsigned long long* sig, unsigned long long value, unsigned long long timeout_ticks, unsigned int* timeouts) {
   if (threadIdx.x != 0) return;
   const unsigned long long t0 = wall_clock64();  // 100 MHz
@@ -727,12 +726,6 @@ __global__ void signal_wait_kernel(unsigned long long* sig, unsigned long long v
       break;
     }
   }
-}
-extern "C" int tfpp_signal_add(uint64_t* sig, void* stream) {
-  if (!sig) return TFPP_EINVAL;
-  hipLaunchKernelGGL(signal_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)sig);
-  TFPP_CHECK_LAUNCH();
-  return 0;
 }
 // double -> float of a small vector (SyncBatchNorm: the per-channel sums travel between the ranks in double, tfpp_bn_bwd_apply_rows takes float rows)
 __global__ void f64_to_f32_kernel(const double* __restrict__ x, float* __restrict__ y, long n, double scale) {

@@ -94,7 +94,7 @@ class GraphedForward:
 class GraphedTrainStep:
   """Captures the training step body (repack + forward + losses + backward) for a fixed batch layout as ONE hipGraph, for one rank and for
   eight alike; the gradient all-reduces and the optimizer launches stay outside the graph so RCCL is never captured.  The captured pass
-  raises a completion signal (a device counter incremented by a kernel node: buckets.py, include/tfpp.h tfpp_signal_add) behind the kernels
+  raises a completion signal (a device word a kernel node raises to the serial number of the pass: buckets.py, include/tfpp.h tfpp_signal_set) behind the kernels
   that complete each bucket of the gradient arena; after ``graph.replay()`` returns -- the replay is still running --
   Trainer.finish_step() issues the all-reduce of every bucket behind a wait on its signal (tfpp_signal_wait on the collective's stream)."""
 

@@ -253,12 +253,14 @@ def wgrad_batch_end():
   # profiling steps (bench.py roofline): the members of the batch are launched -- and so timed by the events around the library call -- per
   # kernel: the layers of the grouped 128 x 128 grid, those of the grouped 64 x 64 grid, everything else.  Same kernels, same results (the
   # groups never mix tile classes); the pixel splits of a group are chosen for the group it is launched with, as always.
-  members = {'group128': [], 'group64': [], 'single': []}
+  members = {'group256': [], 'group128': [], 'group64': [], 'single': []}
   plan = (ctypes.c_int * 3)()
+  wide_on = _os.environ.get('TFPP_WGRAD_GROUP_256', '1') != '0'
   for p in items:
     lib.raw('tfpp_conv_wgrad_stage')(ctypes.byref(p), BF16, -1, plan, stream())
     ok = lib.raw('tfpp_conv_wgrad_group_ok')(ctypes.byref(p), BF16) if plan[0] in (2, 4) else 0
-    members['group128' if (ok and plan[0] == 4) else ('group64' if (ok and plan[0] == 2) else 'single')].append(p)
+    wide = wide_on and ok and plan[0] == 4 and p.n_g >= 1024 and p.ks_g >= 1024  # (the routing of tfpp_conv_wgrad_batch: 256 x 256 tiles)
+    members['group256' if wide else ('group128' if (ok and plan[0] == 4) else ('group64' if (ok and plan[0] == 2) else 'single'))].append(p)
   for k, its in members.items():
     if its:
       launch(its, f'conv_wgrad<bf16,{k}>')

@@ -553,10 +553,9 @@ int tfpp_add_dropout(const void* a, const void* b, void* y, int64_t n, float p_d
 int tfpp_inc_u64(uint64_t* p, void* stream);
 /* Completion signal from a kernel node inside a captured hipGraph to a stream outside of it (data-parallel gradient exchange,
  * team_code/train.py:516-520: the all-reduce of a gradient bucket starts while backward is still running).  sig: a zero-initialised 64-bit
- * counter in device memory.  tfpp_signal_add: *sig += 1 (device-scope atomic) behind everything issued so far on `stream`.
+ * word in device memory, raised by tfpp_signal_set (below) behind everything issued so far on its stream.
  * tfpp_signal_wait: the work issued on `stream` after this call starts once *sig >= value; gives up after timeout_ms and then adds 1 to
  * *timeouts (nullable). */
-int tfpp_signal_add(uint64_t* sig, void* stream);
 /* y[i] = (float)(x[i] * scale): the per-channel BatchNorm sums of the SyncBatchNorm path (train.py:511-512) are all-reduced in double and handed
  * to tfpp_bn_bwd_apply_rows as one float row (scale = 1 / world: that entry point normalises by the LOCAL row count it also walks). */
 int tfpp_f64_to_f32(const double* x, float* y, int64_t n, double scale, void* stream);

@@ -19,7 +19,8 @@ fp32 step, same statistics -- to these numbers.  The same comparison on the weig
 bench.py with the travelling port (oracle/tfpp_port.py) under the same autocast; tests/test_oracle.py pins port-under-autocast against
 this fixture.
 
-  python -m oracle.make_golden_bf16
+  python -m oracle.make_golden_bf16          # default configuration, bs = 12
+  python -m oracle.make_golden_bf16 swin     # BASELINE config 5 (Video-Swin LiDAR branch), bs = 4 -> tests/golden/tfpp_swin_bf16_autocast_bs4.npz
 """
 import os
 import sys
@@ -51,10 +52,21 @@ def main():
   if not ref_harness.available():
     sys.exit('needs /root/reference (build container)')
   torch.set_num_threads(os.cpu_count())
-  bs = 12
-  model, _ = ref_harness.build_reference_model()
-  cfg = P.PortConfig()
-  sd = P.make_state_dict(cfg)
+  swin = len(sys.argv) > 1 and sys.argv[1] == 'swin'
+  if swin:
+    # BASELINE config 5 at the setting bench.py times (Video-Swin LiDAR branch, 6 LiDAR frames, bs = 4): tests/golden/tfpp_swin_bf16_autocast_bs4.npz,
+    # same contents; tests/test_model.py::test_video_swin_bf16_step_at_the_benchmarked_batch_is_no_worse_than_the_autocast_reference
+    import dataclasses
+    from oracle.make_golden import SWIN_OVERRIDES
+    bs, fname = 4, 'tfpp_swin_bf16_autocast_bs4.npz'
+    model, _ = ref_harness.build_reference_model(**SWIN_OVERRIDES)
+    cfg = dataclasses.replace(P.PortConfig(), lidar_seq_len=6)
+    sd = P.generic_state_dict(model.state_dict(), base=P.make_state_dict(P.PortConfig()))
+  else:
+    bs, fname = 12, 'tfpp_bf16_autocast_bs12.npz'
+    model, _ = ref_harness.build_reference_model()
+    cfg = P.PortConfig()
+    sd = P.make_state_dict(cfg)
   model.load_state_dict(sd, strict=True)
   l32, g32 = reference_step(model, cfg, bs, False)
   model.load_state_dict(sd, strict=True)  # (the first step updated the BN running statistics)
@@ -70,7 +82,7 @@ def main():
        'grad_names': np.array(names), 'autocast_grad_norms': np.array([float(g16[n].double().norm()) for n in names]),
        'fp32_grad_norms': np.array([float(g32[n].double().norm()) for n in names]), 'autocast_grad_samples': samples,
        'torch_version': np.array(torch.__version__), 'batch': np.array(bs)}
-  np.savez_compressed(os.path.join(GOLDEN, 'tfpp_bf16_autocast_bs12.npz'), **d)
+  np.savez_compressed(os.path.join(GOLDEN, fname), **d)
   print('losses fp32    ', l32)
   print('losses autocast', l16)
   print('autocast vs fp32 (reference, CPU):', st)

@@ -12,7 +12,7 @@ tail does (so the wait really is on the point, not on the whole graph, and not o
   C  a counter in signal memory (hipExtMallocWithFlags(hipMallocSignalMemory)) incremented by a kernel node of the graph (tfpp_inc_u64),
      hipStreamWaitValue64(side, counter, replay number, hipStreamWaitValueGte) on the side stream -- the command processor polls, no CU is held
 
-  D  the library's own pair: tfpp_signal_add (one-thread kernel node, device-scope atomic) + tfpp_signal_wait (one-wave polling kernel on the
+  D  the library's own pair: tfpp_inc_u64 (one-thread kernel node, device-scope atomic) + tfpp_signal_wait (one-wave polling kernel on the
      side stream)
 
 Prints one line per replay and a verdict per candidate (carla_garage_amd/buckets.py uses D; C -- plain device memory works, signal memory
@@ -147,7 +147,7 @@ def main():
   elif only == 'C':
     print(f'C: hipExtMallocWithFlags(hipMallocSignalMemory) -> {rc}', flush=True)
     results['C signal counter + hipStreamWaitValue64'] = False
-  # ---- D: the library's own device-side signal (carla_garage_amd/buckets.py): tfpp_signal_add node + tfpp_signal_wait polling kernel
+  # ---- D: the library's own device-side signal (carla_garage_amd/buckets.py): tfpp_inc_u64 node + tfpp_signal_wait polling kernel
   if only != 'D':
     for k, v in results.items():
       print('RESULT', k, 'OK' if v else 'not usable', flush=True)
@@ -156,11 +156,11 @@ def main():
   from carla_garage_amd import ops
   sigD = ops.zeros(1, torch.int64, torch.device('cuda'))
   tmo = ops.zeros(1, torch.int32, torch.device('cuda'))
-  addD, waitD = L2.lib.raw('tfpp_signal_add'), L2.lib.raw('tfpp_signal_wait')
+  addD, waitD = L2.lib.raw('tfpp_inc_u64'), L2.lib.raw('tfpp_signal_wait')
 
   def recD(st):
     if addD(sigD.data_ptr(), st.cuda_stream) != 0:
-      raise RuntimeError('tfpp_signal_add failed')
+      raise RuntimeError('tfpp_inc_u64 failed')
 
   def wD(side, it):
     if waitD(sigD.data_ptr(), it, 2000, tmo.data_ptr(), side.cuda_stream) != 0:
