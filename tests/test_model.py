@@ -849,6 +849,51 @@ def test_bf16_step_is_no_worse_than_the_autocast_reference():
 
 
 @pytest.mark.gpu
+def test_video_swin_bf16_step_at_the_benchmarked_batch_is_no_worse_than_the_autocast_reference():
+  """BASELINE config 5 at the setting bench.py times (Video-Swin LiDAR branch, 6 LiDAR frames, bs = 4, bf16):
+  tests/golden/tfpp_swin_bf16_autocast_bs4.npz holds what bfloat16 autocast does to the unmodified reference's own gradients on this
+  configuration (oracle/make_golden_bf16.py swin).  The HIP bf16 step -- against the HIP fp32 step, same weights, same batch, same statistics
+  (oracle/grad_stats.py) -- must be no worse; the tail statistics get the spread measured on the default configuration
+  (profiles/r06_bf16_tail_statistics.txt), the losses twice the autocast reference's own distance from fp32."""
+  from oracle.grad_stats import STAT_KEYS, gradient_stats
+  g = U.load_golden('tfpp_swin_bf16_autocast_bs4.npz')
+  want = dict(zip([str(k) for k in g['stat_names']], [float(v) for v in g['stats_autocast_vs_fp32']]))
+  bs = int(g['batch'])
+
+  def step(dtype):
+    m, pc = _swin_model(dtype)
+    m.train()
+    m._engine().swin.drop_path_rate = 0.0
+    return _engine_train_step(m, bs, pc)
+
+  _, v32, e32 = step('fp32')
+  ref = {n: e32.grads[n].detach().clone() for n in e32.grads}
+  del e32
+  torch.cuda.empty_cache()
+  names, v16, e16 = step('bf16')
+  got = gradient_stats(ref, {n: e16.grads[n].detach() for n in ref})
+  l_ref = dict(zip([str(x) for x in g['loss_names']], g['losses_fp32']))
+  l_ac = dict(zip([str(x) for x in g['loss_names']], g['losses_autocast']))
+  l32 = dict(zip(names, v32))
+  l16 = dict(zip(names, v16))
+  loss_dev = {n: (abs(float(l16[n]) - l_ref[n]) / abs(l_ref[n]), abs(l_ac[n] - l_ref[n]) / abs(l_ref[n])) for n in names}
+  _report('swin_bf16_bs4_vs_autocast_reference', {'hip_bf16_vs_hip_fp32': got, 'reference_autocast_vs_reference_fp32': want,
+                                                  'losses_rel_dev_hip_and_autocast': {n: [float(a), float(b)] for n, (a, b) in loss_dev.items()}})
+  for n in names:  # the fp32 step itself sits on the reference's fp32 losses
+    assert abs(float(l32[n]) - l_ref[n]) <= 1e-3 * abs(l_ref[n]) + 1e-6, (n, l32[n], l_ref[n])
+  slack = 1.02
+  tail = {'norm_err_p90': 1.3, 'norm_err_p99': 1.4, 'norm_err_max': 1.5}
+  assert got['arena_cosine'] >= 1.0 - (1.0 - want['arena_cosine']) * slack, (got, want)
+  for k in STAT_KEYS[1:]:
+    assert got[k] <= want[k] * tail.get(k, slack), (k, got, want)
+  assert got['tensors'] >= 500
+  # losses: twice the autocast reference's own distance from fp32, plus 1e-3 in LOSS UNITS for the small ones (loss_yaw_res = 0.033 is the mean
+  # L1 residual of the handful of boxes of four samples: HIP bf16 0.0007 away in absolute terms = 2.1 %, the autocast reference 0.5 %)
+  for n, (a, b) in loss_dev.items():
+    assert a * abs(l_ref[n]) <= 2.0 * b * abs(l_ref[n]) + 1e-3 * max(1.0, abs(l_ref[n])), (n, a, b)
+
+
+@pytest.mark.gpu
 def test_bf16_trains_like_fp32_over_200_steps_and_drifts_no_further_than_the_autocast_reference():
   """Does the benchmarked precision TRAIN like fp32?  200 optimizer steps (AdamW-amsgrad, lr 1e-4, four different batches of 4 cycled, dropout
   off), a bf16 Trainer beside an fp32 Trainer from identical weights.  The bar is not an absolute number but the drift of a bf16 REFERENCE:
