@@ -94,7 +94,7 @@ def source_hash():
   compared by load(), so the binary under test is always the one these sources produce."""
   import hashlib
   h = hashlib.sha256()
-  files = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cuh', '.h')))
+  files = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.h')))
   h.update(' '.join(HIPCC_FLAGS).encode() + b'\0')  # a library built with other flags is another library
   for path in [os.path.join(CSRC, f) for f in files] + [HEADER]:
     h.update(os.path.basename(path).encode() + b'\0')

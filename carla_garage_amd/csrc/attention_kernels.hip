@@ -15,7 +15,7 @@
 //      ds_read_b64_tr_b16 addressed with the same labelling (16-byte chunks XOR-swizzled by (key & 7) << 1: conflict-free).
 //      O leaves through a per-wave LDS strip as 16-byte row segments.
 // backward: see attn_bwd_* below (recomputes P from Q, K and the saved log-sum-exp; dQ in one launch, dK / dV in another).
-#include "gemm_core.cuh"
+#include "gemm_core.h"
 #include <cstdlib>
 
 namespace {

@@ -8,7 +8,7 @@
 // pixel, channel): imgaug's numpy stream cannot be matched sample by sample, the distributions are (tests/test_augment_gpu.py; the
 // operator arithmetic itself is restated in oracle/imgaug_port.py from imgaug 0.4.0 / OpenCV 4.6, requirements.txt:48,95).
 // HBM-bound byte work: one thread per pixel (3 channel planes), 9.4 MB per stage at bs = 12.
-#include "common.cuh"
+#include "common.h"
 #include "../../include/tfpp.h"
 
 namespace {

@@ -4,7 +4,7 @@
 // voxels of the column, transposed to image orientation and masked by the visible-BEV-pixel map -- one pass, nothing of the
 // (B, 32, 256, 256, 96) intermediate is materialised.  coords: per voxel (d, w, z) the sample position in FEATURE pixels (host constant);
 // scale: per output pixel (i = w, j = d) valid / normalizer.  One thread per (b, i, j, 16-byte channel chunk).
-#include "common.cuh"
+#include "common.h"
 #include "../../include/tfpp.h"
 
 template <typename T, bool BWD>

@@ -2,7 +2,7 @@
 // convolution (tfpp_bn_rows, include/tfpp.h): bn_rows_kernels.hip (elementwise passes) and conv3x3_halo.hip (normalise-on-load).
 // All of them assume 256-thread workgroups.
 #pragma once
-#include "common.cuh"
+#include "common.h"
 #include "../../include/tfpp.h"
 
 // Column sums of the rows [nrows][2C] (first half | second half) for the NCH = cb * VEC channels of this workgroup's block, in double, fixed

@@ -12,7 +12,7 @@
 //     (forward), dgamma / dbeta (backward).
 // The same layout carries the squeeze-excite passes around a conv2 output that is never normalised in memory (mask and activation are
 // recomputed from the raw tensor: y = relu(raw * scale + shift)).
-#include "bn_rows.cuh"
+#include "bn_rows.h"
 
 namespace {
 
@@ -368,7 +368,7 @@ int launch_bn_bwd_apply_rows(const void* dy, const void* y, const void* x, const
 // ---- squeeze-excite passes around a tensor that exists only as (raw, statistics) -----------------------------------------------------------
 // pool: out[b][c] = mul * sum_hw relu(x * scale + shift)  (the squeeze of a conv2 output that is never normalised in memory).
 // One launch: the (<= 16) row-block workgroups of a sample publish their partial sums and draw a ticket per sample, the last one adds them in
-// row-block order (common.cuh).  grid = (row blocks per sample, channel blocks, B).
+// row-block order (common.h).  grid = (row blocks per sample, channel blocks, B).
 template <typename T>
 __global__ __launch_bounds__(256, 4) void hw_reduce_bn_kernel(const T* __restrict__ x, tfpp_bn_rows bn,
                                                            float* __restrict__ partial, float* __restrict__ out, unsigned* __restrict__ tickets,

@@ -14,9 +14,9 @@
 // and the pixel -> LDS address map is scaled by 2.  Data gradient: dx = stride-1 correlation of the ZERO-STUFFED dy (Z[2a][2b] = dy[a][b])
 // with the same transposed pack, so only the loader changes (3 of 4 halo pixels are zeros; the layers are HBM-bound, the idle MFMA
 // work is free).  The implicit GEMM ran these at 119 / 242 us (stage 1, bs = 12) against a 28 us HBM bound.
-#include "gemm_core.cuh"
+#include "gemm_core.h"
 #include "gemm_internal.h"
-#include "bn_rows.cuh"
+#include "bn_rows.h"
 #include <cstdlib>
 
 namespace {
@@ -27,7 +27,7 @@ template <int GEO> struct HaloGeo { static constexpr int HH = GEO == 1 ? 2 * TH 
 // its ~11 global loads before the first LDS store instead of paying one memory latency per 16-byte chunk.
 // INBN (round 6): the source exists only as (raw output of the 1x1 convolution in front, BatchNorm statistics): every staged chunk becomes
 // relu(raw * scale[c] + shift[c]) on its way into LDS (out-of-image chunks stay zero: the padding is applied AFTER the activation), and when
-// in_bn.partial is set the workgroup first adds the statistics rows of its group's input channels (bn_rows.cuh) -- beside its tile loads, which
+// in_bn.partial is set the workgroup first adds the statistics rows of its group's input channels (bn_rows.h) -- beside its tile loads, which
 // are already in flight.  The normalised tensor is never written (tfpp.h).
 template <int FN, int CV, bool BNS = false, int GEO = 0, bool INBN = false>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(tfpp_conv_params p, int tiles_w, int tiles_h, int ksteps_rt) {

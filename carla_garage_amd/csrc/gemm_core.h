@@ -14,7 +14,7 @@
 // (weight-gradient GEMMs, P@V): those are stored as loaded (8-byte LDS writes) and gathered element-wise into
 // fragments, which transposes them without a global-memory pass.
 #pragma once
-#include "common.cuh"
+#include "common.h"
 #include "../../include/tfpp.h"
 
 template <typename T, int BM_, int BN_, int WM_, int WN_, int BK_ = 32>

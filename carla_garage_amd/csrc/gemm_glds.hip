@@ -9,7 +9,7 @@
 // which makes every ds_read_b128 lane group hit 16 distinct slots.  LDS-DMA cannot zero-fill, so out-of-range rows / taps /
 // K-tails read a 16-byte zero page in global memory.  Fragment reads are inline-asm ds_read_b128 (the compiler would otherwise
 // drain the DMA queue with vmcnt(0) before any LDS read it can see).
-#include "gemm_core.cuh"
+#include "gemm_core.h"
 #include "gemm_internal.h"
 #include <cstdlib>
 

@@ -1,6 +1,6 @@
 // Implicit-GEMM convolution (forward / data-gradient), weight-gradient and strided batched GEMM on MFMA (gfx950).
-// See gemm_core.cuh for the fragment / LDS layouts and include/tfpp.h for the semantics of each entry point.
-#include "gemm_core.cuh"
+// See gemm_core.h for the fragment / LDS layouts and include/tfpp.h for the semantics of each entry point.
+#include "gemm_core.h"
 #include "gemm_internal.h"
 #include <algorithm>
 #include <vector>
@@ -153,7 +153,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
 
   // epilogue
   if constexpr (sizeof(T) == 2) {
-    if (epi_vec_ok(p)) {  // coalesced: 16-row passes through a per-wave LDS strip (see gemm_core.cuh)
+    if (epi_vec_ok(p)) {  // coalesced: 16-row passes through a per-wave LDS strip (see gemm_core.h)
       __syncthreads();
       float* strip = reinterpret_cast<float*>(smem_raw) + wave * EpiStrip<C::FN>::FLOATS;
       if constexpr (BNS) {  // fused BatchNorm-backward statistics of the tensor whose gradient this launch completes (tfpp.h); own instantiation

@@ -21,7 +21,7 @@
 //     moderate split).  Twice the operand reuse per byte brought into LDS and 16 instead of 4 MFMAs per wave between barriers.
 // The single-buffered kernel in gemm_kernels.hip (load -> ds_write -> barrier -> MFMA -> barrier per 64 pixels) measured
 // 25-35 us of main loop on the 576x576 / 216x216 layers; this one keeps NSTAGE-1 stages of loads behind the MFMAs.
-#include "gemm_core.cuh"
+#include "gemm_core.h"
 #include "gemm_internal.h"
 #include <cstdlib>
 

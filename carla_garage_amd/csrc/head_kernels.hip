@@ -1,7 +1,7 @@
 // Kernels of the fp32 planning head (team_code/model.py:137-146,333-358: nn.TransformerDecoder over 11 / 8 queries and 65 memory tokens).
 // The head is 0.1 % of the step's FLOPs and, launch by launch, 10 % of its time: every kernel below replaces a run of dependent launches
 // of the general kernels (batched GEMM -> softmax -> batched GEMM ...) by one.
-#include "common.cuh"
+#include "common.h"
 #include "../../include/tfpp.h"
 
 // ---------------------------------------------------------------------------------------------------------------

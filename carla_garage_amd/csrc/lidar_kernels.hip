@@ -4,7 +4,7 @@
 // bit-exact), then one pass that clips, scales and writes the transposed (C, H, W) float image.
 // Bin semantics are numpy's: index = searchsorted(edges, v, side='right') - 1 on the float64 edges the reference builds with
 // np.linspace (passed in, so any grid configuration bins identically), the last edge belongs to the last bin, NaN / outside dropped.
-#include "common.cuh"
+#include "common.h"
 #include "../../include/tfpp.h"
 
 __device__ __forceinline__ int lidar_bin(const double* __restrict__ edges, int n, double v) {

@@ -1,5 +1,5 @@
 // GRU waypoint decoder, fused loss+gradient kernels and the AdamW(amsgrad) optimizer step.
-#include "common.cuh"
+#include "common.h"
 #include "../../include/tfpp.h"
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -246,7 +246,7 @@ template <typename T, bool VROW> __device__ __forceinline__ void ce_store_row(T*
   }
 }
 
-// pass 1 of cross entropy: ws[0] = sum_i class_weight[label_i] over non-ignored rows (fixed-order grid sum: common.cuh)
+// pass 1 of cross entropy: ws[0] = sum_i class_weight[label_i] over non-ignored rows (fixed-order grid sum: common.h)
 __global__ void ce_norm_kernel(const long long* __restrict__ label, const float* __restrict__ cw, const float* __restrict__ vis, long HW,
                                float* __restrict__ ws, long rows, float* __restrict__ scratch) {
   __shared__ float sm[4];
@@ -639,7 +639,7 @@ static int launch_adamw(float* p, const float* g, float* m, float* v, float* vma
   return 0;
 }
 
-// scratch of the fixed-order grid sums (common.cuh): 64 ticket counters + the partials of the largest user (LayerNorm parameter gradients:
+// scratch of the fixed-order grid sums (common.h): 64 ticket counters + the partials of the largest user (LayerNorm parameter gradients:
 // 64 row blocks x 2 x C <= 3072; the loss kernels publish <= 1024 partials).  Zero before the first use; one buffer per stream.
 extern "C" int tfpp_gridsum_scratch_floats(void) { return TFPP_GRIDSUM_TICKETS + 64 * 2 * 3072; }
 

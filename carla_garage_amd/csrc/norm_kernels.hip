@@ -2,12 +2,12 @@
 // BatchNorm reductions accumulate per-thread partials in fp32 over <=64 rows and combine in double (native fp64
 // atomics on gfx950) so that E[x^2]-E[x]^2 stays accurate; LayerNorm / softmax use one wave64 per row with
 // shuffle reductions.
-#include "common.cuh"
+#include "common.h"
 #include "../../include/tfpp.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // BatchNorm reductions, two stages, no atomics.
-// Stage 1: column-fixed layout (common.cuh): a workgroup is RP row-slots x SW channel-chunks and walks its rows with a
+// Stage 1: column-fixed layout (common.h): a workgroup is RP row-slots x SW channel-chunks and walks its rows with a
 // grid stride (U independent 16-byte loads per operand in flight per lane), then writes one partial per channel to
 // partial[blockIdx.x][2*C].  Stage 2 sums the <=512 partials per value in double.
 // MODE 0: sum x, sum x^2.   MODE 1 (backward): g = dy*(y>0?), sum g, sum g*xhat.
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 
 // parameter gradients of LayerNorm as a column reduction: dgamma[c] += sum_r dy*xhat, dbeta[c] += sum_r dy.
 // grid (ceil(C/64), S); block = 64 channels x 4 row slots.  The S row blocks of a channel block publish their partial sums and the one that
-// draws the last ticket adds them in row-block order (fixed-order grid sum, common.cuh): bit-reproducible, one launch.
+// draws the last ticket adds them in row-block order (fixed-order grid sum, common.h): bit-reproducible, one launch.
 template <typename T>
 __global__ void layernorm_param_grad_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
                                             const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -740,7 +740,7 @@ __global__ void layernorm_param_grad_kernel(const T* __restrict__ dy, const T* _
   }
   if (!grid_last_ticket(reinterpret_cast<unsigned*>(scratch) + blockIdx.x, gridDim.y)) return;
   float tg = 0.f, tb = 0.f;
-  if (c < C && slot < (int)gridDim.y)  // gridDim.y <= 64: at most 16 row blocks per slot, fetched in ONE round trip (common.cuh grid_fetch_pair_sum16)
+  if (c < C && slot < (int)gridDim.y)  // gridDim.y <= 64: at most 16 row blocks per slot, fetched in ONE round trip (common.h grid_fetch_pair_sum16)
     grid_fetch_pair_sum16(part + (size_t)slot * C + c, 4l * C, ((int)gridDim.y - slot + 3) / 4, tg, tb);
   sm[0][slot][cl] = tg;
   sm[1][slot][cl] = tb;

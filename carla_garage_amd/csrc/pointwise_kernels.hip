@@ -1,6 +1,6 @@
 // HBM-bound kernels: weight packing, layout changes, pooling / bilinear resampling, elementwise ops, squeeze-excite.
 // All activations are NHWC; every kernel moves 16-byte vectors per lane along the channel dimension.
-#include "common.cuh"
+#include "common.h"
 #include <cstdlib>
 #include "../../include/tfpp.h"
 

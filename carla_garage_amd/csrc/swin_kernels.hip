@@ -2,7 +2,7 @@
 // embedding gather, the row gather that implements zero padding + cyclic shift + window partition (and their inverse, and the 2x2
 // PatchMerging concatenation) from a precomputed index table, and the window-attention softmax with relative-position bias and
 // shift mask.  All HBM-bound; 16-byte accesses per lane.
-#include "common.cuh"
+#include "common.h"
 #include "../../include/tfpp.h"
 
 // x: fp32 (B, T, H, W) frames (the reference views them as (B, 1, T, H, W), transfuser.py:153) -> rows (b, t/2, h/4, w/4) of 32 values

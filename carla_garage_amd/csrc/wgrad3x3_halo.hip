@@ -7,7 +7,7 @@
 // LDS offset.  MFMA fragments (8 consecutive pixels of one row per lane) come from ds_read_b64_tr_b16.  The whole
 // N x 9*Cin_g gradient of the group stays in registers across the tiles a workgroup visits (4 waves split the (tap, 16-channel)
 // column blocks); at the end each workgroup stores one fp32 slice and wgrad_reduce_kernel sums the slices into dW.
-#include "gemm_core.cuh"
+#include "gemm_core.h"
 #include "gemm_internal.h"
 #include <cstdlib>
 

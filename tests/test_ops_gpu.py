@@ -1396,7 +1396,7 @@ def test_library_loaded_before_torch_touches_the_gpu_still_launches():
 
 def test_grid_sums_are_bit_reproducible_and_streams_do_not_share_tickets(ops):
   """The grid-wide sums of the loss kernels, the cross-entropy normaliser and the LayerNorm parameter gradients are added in a fixed order by
-  the workgroup that draws the last ticket (csrc/common.cuh): the results must be bit-identical launch after launch at the training sizes
+  the workgroup that draws the last ticket (csrc/common.h): the results must be bit-identical launch after launch at the training sizes
   (thousands of workgroups, all 8 XCDs), equal to a float64 sum to fp32 rounding, and two streams running the same kernels at once must not
   disturb each other (each stream owns its scratch)."""
   g = torch.Generator().manual_seed(7)
