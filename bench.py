@@ -585,6 +585,11 @@ def kernel_pattern(fam):
     return 'conv_wgrad_glds_group_kernel<128, 128,'
   if fam == 'conv_wgrad<bf16,group64>':
     return 'conv_wgrad_glds_group_kernel<64, 64,'
+  if fam.startswith('conv_wgrad<bf16,halo3x3>'):
+    return 'wgrad3x3_halo_kernel<'
+  mh = re.match(r'conv_gemm<bf16,halo8x32x(\d+)>', fam)
+  if mh:
+    return f'conv3x3_halo_kernel<{int(mh.group(1)) // 16},'
   m = re.match(r'(conv_gemm|conv_wgrad)<(f32|bf16),(glds|halo|lds)?(\d+)x(\d+)', fam)
   if m is None:
     return None
@@ -663,6 +668,20 @@ def pmc_traffic(family):
   except (OSError, ValueError):
     ent = None
   if not ent:
+    # no per-family pass: the per-kernel table of the whole step (profiles/pmc_all_kernels.json, tools/pmc_all.sh) by kernel name
+    pat = kernel_pattern(family)
+    try:
+      with open(os.path.join(ROOT, 'profiles', 'pmc_all_kernels.json'), encoding='utf-8') as f:
+        allk = json.load(f)
+    except (OSError, ValueError):
+      allk = None
+    if pat and allk:
+      hit = [v for k, v in allk['kernels'].items() if pat in k]
+      n = sum(v['launches'] for v in hit)
+      if n:
+        tot = sum(v['fetch_bytes'] + v['write_bytes'] for v in hit)
+        return int(tot / n), (f"mean over {n} launches of the kernels matching '{pat}' in profiles/pmc_all_kernels.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                              f"whole-step counter passes of {allk.get('measured', '?')}; not tied to a source hash)")
     return None, 'no PMC measurement committed for this kernel family'
   try:
     with open(os.path.join(ROOT, 'carla_garage_amd', 'csrc', ent['source_file']), 'rb') as f:

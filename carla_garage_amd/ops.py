@@ -262,7 +262,10 @@ def wgrad_batch_end():
     wide = wide_on and ok and plan[0] == 4 and p.n_g >= 1024 and p.ks_g >= 1024  # (the routing of tfpp_conv_wgrad_batch: 256 x 256 tiles)
     members['group256' if wide else ('group128' if (ok and plan[0] == 4) else ('group64' if (ok and plan[0] == 2) else 'single'))].append(p)
   for k, its in members.items():
-    if its:
+    if k == 'single':  # everything the grouped grids do not cover (3x3, narrow, strided layers): one profiled call per kernel, as outside a batch
+      for p in its:
+        _profiled_wgrad(p, BF16, 2)
+    elif its:
       launch(its, f'conv_wgrad<bf16,{k}>')
 
 
@@ -276,26 +279,30 @@ def conv_wgrad(dy, x, dw, **kw):
   if WGRAD_BATCH is not None and dy.dtype == torch.bfloat16:
     WGRAD_BATCH.append((p, (dy, x, dw, kw.get('row_map'), kw.get('col_map'), kw.get('x_scale'), kw.get('x_shift'))))
     return dw
-  B, Hd, Wd, Hs, Ws, G, R, S, stride = p.B, p.Hd, p.Wd, p.Hs, p.Ws, p.G, p.R, p.S, p.stride
   if lib.profiler is not None:  # one profiled call per kernel: first stage and slice sum are timed separately
-    plan = (ctypes.c_int * 3)()
-    lib.raw('tfpp_conv_wgrad_stage')(ctypes.byref(p), dt(dy), -1, plan, stream())  # plan only: no launch, not timed
-    kind = ('lds32x32', 'lds64x64', 'glds64x64', 'halo3x3', 'glds128x128')[plan[0]]
-    fam = f'conv_wgrad<{"f32" if dy.dtype == torch.float32 else "bf16"},{kind}>'
-    if PROFILE_SHAPES:
-      fam += f' P={B * Hd * Wd} N={p.n_g} K={R * S * p.ks_g} G={G} k{R}s{stride}'
-    esz = dy.element_size()
-    kk = R * S * p.ks_g
-    # algorithmic bytes: dY and X read once, the fp32 slices (or the gradient itself, read-modify-write) written once
-    nbytes = (B * Hd * Wd * G * p.n_g + B * Hs * Ws * G * p.ks_g) * esz + (plan[1] if plan[2] else 2) * G * p.n_g * kk * 4
-    lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * kk, nbytes)
-    lib.tfpp_conv_wgrad_stage(ctypes.byref(p), dt(dy), 1, None, stream())
-    if plan[2]:
-      lib.profiler.tag('wgrad_slice_sum', 0.0)
-      lib.tfpp_conv_wgrad_stage(ctypes.byref(p), dt(dy), 2, None, stream())
+    _profiled_wgrad(p, dt(dy), dy.element_size())
     return dw
   lib.tfpp_conv_wgrad(ctypes.byref(p), dt(dy), stream())
   return dw
+
+
+def _profiled_wgrad(p, dtc, esz):
+  """One weight gradient under the bench.py profiler: first stage and slice sum as separately timed, separately tagged library calls."""
+  B, Hd, Wd, Hs, Ws, G, R, S, stride = p.B, p.Hd, p.Wd, p.Hs, p.Ws, p.G, p.R, p.S, p.stride
+  plan = (ctypes.c_int * 3)()
+  lib.raw('tfpp_conv_wgrad_stage')(ctypes.byref(p), dtc, -1, plan, stream())  # plan only: no launch, not timed
+  kind = ('lds32x32', 'lds64x64', 'glds64x64', 'halo3x3', 'glds128x128')[plan[0]]
+  fam = f'conv_wgrad<{"f32" if dtc == F32 else "bf16"},{kind}>'
+  if PROFILE_SHAPES:
+    fam += f' P={B * Hd * Wd} N={p.n_g} K={R * S * p.ks_g} G={G} k{R}s{stride}'
+  kk = R * S * p.ks_g
+  # algorithmic bytes: dY and X read once, the fp32 slices (or the gradient itself, read-modify-write) written once
+  nbytes = (B * Hd * Wd * G * p.n_g + B * Hs * Ws * G * p.ks_g) * esz + (plan[1] if plan[2] else 2) * G * p.n_g * kk * 4
+  lib.profiler.tag(fam, 2.0 * B * Hd * Wd * G * p.n_g * kk, nbytes)
+  lib.tfpp_conv_wgrad_stage(ctypes.byref(p), dtc, 1, None, stream())
+  if plan[2]:
+    lib.profiler.tag('wgrad_slice_sum', 0.0)
+    lib.tfpp_conv_wgrad_stage(ctypes.byref(p), dtc, 2, None, stream())
 
 
 def bgemm(A, B, C, *, M, N, K, lda, ldb, ldc, batch0=1, batch1=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), a_km=False,

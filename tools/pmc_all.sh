@@ -33,5 +33,9 @@ with open(repo + '/gpurun_out/pmc_all.txt', 'w') as f:
     f.write('# total fetch %.1f MB, write %.1f MB\n' % (tot_f / 1e6, tot_w / 1e6))
     for k, (n, fb, wb) in rows:
         f.write('%-110s %5d  fetch %9.1f MB  write %9.1f MB  per launch %8.2f / %8.2f MB\n' % (k[:110], n, fb / 1e6, wb / 1e6, fb / 1e6 / max(n, 1), wb / 1e6 / max(n, 1)))
+import json, time
+json.dump({'_comment': 'HBM-side bytes of EVERY kernel over two eager training steps (bs = 12 bf16): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate counter-only passes, FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 B, MI355X_MICROARCH.md); written by tools/pmc_all.sh. bench.py falls back to this table for kernel families without an entry in pmc_traffic.json.',
+           'measured': time.strftime('%Y-%m-%d'), 'kernels': {k[:110].strip(): {'launches': n, 'fetch_bytes': fb, 'write_bytes': wb} for k, (n, fb, wb) in rows}},
+          open(repo + '/gpurun_out/pmc_all_kernels.json', 'w'), indent=1)
 print(open(repo + '/gpurun_out/pmc_all.txt').read()[:6000])
 PY
