@@ -484,7 +484,7 @@ class SideLane:
       # fork points as fractions of the pass (the previous pass of this engine counted its closures): round 3 swept them on the bs = 12 step
       # (334 closures then; 374 in round 4, re-swept: 0.46 / 0.80 / 0.95 = closures 172 / 299 / 355, -0.17 ms against 0.43 / 0.77, profiles/r04_fork_sweep.txt):
       # TWO forks, in the middle of fusion transformer 3's backward (0.43) and when stage 3 of both encoders is done (0.77),
-      # give 26.0 ms/step; any third fork costs ~2 ms, one fork ~2.5 ms, moving the second one 8 closures earlier 1.4 ms (tools/sweep_flush.sh)
+      # give 26.0 ms/step; any third fork costs ~2 ms, one fork ~2.5 ms, moving the second one 8 closures earlier 1.4 ms (tools/sweep_forks.sh)
       if self.count in {max(1, int(round(f * self.total_prev))) for f in self.forks}:
         self.flush()
       return
