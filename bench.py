@@ -564,7 +564,7 @@ def graph_trace():
   durations as they are inside the replayed graph, next to co-running lanes -- the HIP-event times of the eager profiling steps below are ~10 %
   longer and blind to that (VERDICT r3 weak #10).  A committed measurement of the same command, not a live one: `source` names the file."""
   import glob
-  files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_graph_step.json')))
+  files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r[0-9][0-9]_graph_step.json')))
   if not files:
     return None
   try:
