@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(PKG_DIR, 'libtfpp_hip.so')
 SOURCES = ['gemm_kernels.hip', 'gemm_glds.hip', 'gemm_wgrad_glds.hip', 'attention_kernels.hip', 'conv3x3_halo.hip', 'wgrad3x3_halo.hip', 'pointwise_kernels.hip', 'norm_kernels.hip', 'bn_rows_kernels.hip', 'misc_kernels.hip', 'lidar_kernels.hip', 'swin_kernels.hip', 'bev_kernels.hip', 'head_kernels.hip', 'augment_kernels.hip']
 
 F32, BF16 = 0, 1
-ABI_VERSION = 7  # include/tfpp.h TFPP_ABI_VERSION
+ABI_VERSION = 8  # include/tfpp.h TFPP_ABI_VERSION
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU, ACT_TANH = 0, 1, 2, 3, 4
 EINVAL = -1000
 

@@ -170,11 +170,11 @@ extern "C" int tfpp_drop_path(const void* x, void* y, int64_t samples, int64_t e
 
 // Gradient of relative_position_bias_table: dtable[rel_index[i][j]][h] += scale * sum_w ds[w][h][i][j] (ds = gradient of the pre-softmax
 // scores as tfpp_softmax_bwd leaves it, i.e. already multiplied by alpha: scale = 1 / alpha).  One thread per (h, i, j): the sum over
-// windows is a strided walk (consecutive lanes = consecutive j), then one fp32 atomic per thread (<= n^2 heads atomics per launch, spread
-// over (2Wd-1)(2Wh-1)(2Ww-1) heads addresses).
+// windows is a strided walk (consecutive lanes = consecutive j) into a dense (heads, n, n) fp32 image; a second kernel adds, per table entry, the
+// pairs that point at it in the order of an inverse index built once per geometry on the host (round 6: the fp32 atomics of rounds 2-5 are gone,
+// the gradient is bit-reproducible).
 template <typename T>
-__global__ void window_bias_grad_kernel(const T* __restrict__ ds, const int* __restrict__ rel_index, float* __restrict__ dtable, long windows,
-                                        int heads, int n, long ld, float scale) {
+__global__ void window_bias_dense_kernel(const T* __restrict__ ds, float* __restrict__ dense, long windows, int heads, int n, long ld) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)heads * n * n) return;
   const int j = (int)(t % n);
@@ -182,22 +182,41 @@ __global__ void window_bias_grad_kernel(const T* __restrict__ ds, const int* __r
   const int h = (int)(t / ((long)n * n));
   const T* p = ds + ((size_t)h * n + i) * ld + j;
   const size_t wstride = (size_t)heads * n * ld;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four independent chains over the windows (fixed association: bit-reproducible)
+  long w = 0;
+  for (; w + 3 < windows; w += 4) {
+    a0 += ElemTraits<T>::to_f(p[w * wstride]);
+    a1 += ElemTraits<T>::to_f(p[(w + 1) * wstride]);
+    a2 += ElemTraits<T>::to_f(p[(w + 2) * wstride]);
+    a3 += ElemTraits<T>::to_f(p[(w + 3) * wstride]);
+  }
+  for (; w < windows; ++w) a0 += ElemTraits<T>::to_f(p[w * wstride]);
+  dense[t] = (a0 + a1) + (a2 + a3);
+}
+// dtable[t][h] += scale * sum over the (i, j) pairs of table entry t, in the order of the inverse index (single writer per cell: no atomics)
+__global__ void window_bias_gather_kernel(const float* __restrict__ dense, const int* __restrict__ inv_ptr, const int* __restrict__ inv_pairs,
+                                          float* __restrict__ dtable, int ntab, int heads, int n, float scale) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= ntab * heads) return;
+  const int t = q / heads, h = q - t * heads;
+  const float* d = dense + (size_t)h * n * n;
   float acc = 0.f;
-  for (long w = 0; w < windows; ++w) acc += ElemTraits<T>::to_f(p[w * wstride]);
-  atomicAdd(dtable + (size_t)rel_index[(size_t)i * n + j] * heads + h, acc * scale);
+  for (int k = inv_ptr[t]; k < inv_ptr[t + 1]; ++k) acc += d[inv_pairs[k]];
+  dtable[(size_t)t * heads + h] += acc * scale;
 }
 
-extern "C" int tfpp_window_bias_grad(const void* ds, const int32_t* rel_index, float* dtable, int64_t windows, int heads, int n, int64_t ld,
-                                     float scale, int dtype, void* stream) {
-  if (!ds || !rel_index || !dtable || windows < 1 || heads < 1 || n < 1 || ld < n) return TFPP_EINVAL;
+extern "C" int tfpp_window_bias_grad(const void* ds, const int32_t* inv_ptr, const int32_t* inv_pairs, int ntab, float* dense_scratch, float* dtable,
+                                     int64_t windows, int heads, int n, int64_t ld, float scale, int dtype, void* stream) {
+  if (!ds || !inv_ptr || !inv_pairs || !dense_scratch || !dtable || ntab < 1 || windows < 1 || heads < 1 || n < 1 || ld < n) return TFPP_EINVAL;
   const long total = (long)heads * n * n;
   dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
   if (dtype == TFPP_F32)
-    hipLaunchKernelGGL(window_bias_grad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)ds, (const int*)rel_index, dtable,
-                       (long)windows, heads, n, (long)ld, scale);
+    hipLaunchKernelGGL(window_bias_dense_kernel<float>, grid, dim3(256), 0, st, (const float*)ds, dense_scratch, (long)windows, heads, n, (long)ld);
   else
-    hipLaunchKernelGGL(window_bias_grad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ds, (const int*)rel_index, dtable,
-                       (long)windows, heads, n, (long)ld, scale);
+    hipLaunchKernelGGL(window_bias_dense_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)ds, dense_scratch, (long)windows, heads, n, (long)ld);
+  hipLaunchKernelGGL(window_bias_gather_kernel, dim3((unsigned)((ntab * heads + 255) / 256)), dim3(256), 0, st, dense_scratch, (const int*)inv_ptr,
+                     (const int*)inv_pairs, dtable, ntab, heads, n, scale);
   TFPP_CHECK_LAUNCH();
   return 0;
 }

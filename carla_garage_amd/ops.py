@@ -1019,8 +1019,26 @@ def drop_path(x, samples, p, seed):
   return y
 
 
+_WINDOW_BIAS_INV = {}  # (data_ptr of the device index, n) -> (inv_ptr, inv_pairs, table entries) on the device
+
+
 def window_bias_grad(ds, rel_index, dtable, windows, heads, n, ld, scale):
-  lib.tfpp_window_bias_grad(ptr(ds), ptr(rel_index), ptr(dtable), windows, heads, n, ld, scale, dt(ds), stream())
+  """dtable[rel_index[i, j], h] += scale * sum_w ds[w, h, i, j] without atomics: a dense (heads, n, n) window sum, then per table entry the pairs
+  of an inverse index (built once per index tensor on the host, outside any capture) in a fixed order."""
+  key = (rel_index.data_ptr(), n, str(rel_index.device))
+  inv = _WINDOW_BIAS_INV.get(key)
+  ntab = dtable.shape[0]
+  if inv is None:
+    if ds.is_cuda and torch.cuda.is_current_stream_capturing():
+      raise RuntimeError('the inverse relative-position index must be built before hipGraph capture: run one eager warm-up step first')
+    flat = rel_index.reshape(-1).to('cpu', torch.int64)
+    order = torch.argsort(flat, stable=True)
+    counts = torch.bincount(flat, minlength=ntab)
+    inv_ptr = torch.zeros(ntab + 1, dtype=torch.int32)
+    inv_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    inv = _WINDOW_BIAS_INV[key] = (inv_ptr.to(ds.device), order.to(torch.int32).to(ds.device), rel_index)  # (keeps the index tensor alive: the key is its address)
+  dense = torch.empty(heads * n * n, device=ds.device, dtype=torch.float32)
+  lib.tfpp_window_bias_grad(ptr(ds), ptr(inv[0]), ptr(inv[1]), ntab, ptr(dense), ptr(dtable), windows, heads, n, ld, scale, dt(ds), stream())
 
 
 def add_dropout(a, b, p_drop=0.0, seed=0, out=None):

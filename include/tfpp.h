@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TFPP_ABI_VERSION 7
+#define TFPP_ABI_VERSION 8
 #define TFPP_EINVAL (-1000)
 #define TFPP_F32 0
 #define TFPP_BF16 1
@@ -508,13 +508,14 @@ int tfpp_softmax_window_bias(void* s, const float* table, const int32_t* rel_ind
                              int n, int64_t ld, int n_mask, float alpha, int dtype, void* stream);
 /* Training of the same branch.  drop_path: timm DropPath as SwinTransformerBlock3D uses it (:216,276-281): y = x * keep_b / (1 - p) with one
  *   Bernoulli draw per SAMPLE (samples x elems_per_sample elements), from the dropout hash of tfpp_softmax_fwd on (seed, b); the backward is the
- *   same call on the gradient.  window_bias_grad: dtable[rel_index[i][j]][h] += scale * sum_w ds[w][h][i][j], the gradient of
+ *   same call on the gradient.  window_bias_grad: dtable[t][h] += scale * sum over the pairs (i, j) with rel_index[i][j] = t of sum_w ds[w][h][i][j]
+ *   (inv_ptr [ntab + 1] / inv_pairs [n * n]: the pairs i * n + j of every table entry, ascending: a dense window sum + a fixed-order gather, no atomics), the gradient of
  *   relative_position_bias_table from the score gradient tfpp_softmax_bwd produced (scale = 1 / alpha undoes its alpha).  The gathers are their
  *   own adjoints with the inverse index table (gather_rows with rev / fwd swapped). */
 int tfpp_drop_path(const void* x, void* y, int64_t samples, int64_t elems_per_sample, float p, uint64_t seed, const uint64_t* seed_offset,
                    int dtype, void* stream);
-int tfpp_window_bias_grad(const void* ds, const int32_t* rel_index, float* dtable, int64_t windows, int heads, int n, int64_t ld,
-                          float scale, int dtype, void* stream);
+int tfpp_window_bias_grad(const void* ds, const int32_t* inv_ptr, const int32_t* inv_pairs, int ntab, float* dense_scratch /* [heads*n*n] */,
+                          float* dtable, int64_t windows, int heads, int n, int64_t ld, float scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Token ops: LayerNorm (transfuser.py:388-389,288; nn.TransformerDecoderLayer norms), row softmax with the
