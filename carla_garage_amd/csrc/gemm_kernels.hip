@@ -61,7 +61,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
     kt_beg = split * per;
     kt_end = kt_beg + per < nkt ? kt_beg + per : nkt;
   }
-  for (int kt = kt_beg; kt < kt_end; ++kt) {
+  // Register-prefetched K loop (round 6): the global loads of tile kt + 1 are issued before the MFMAs of tile kt and land while they run; the
+  // first version (load -> LDS store -> barrier -> MFMA -> barrier per tile) exposed one memory latency per 32 / 64 channels of K, which is most
+  // of the time of the short-K launches this kernel serves (stage-1 convolutions, the fp32 planning head, every fp32 GEMM of the parity path).
+  uint4 a_val[A_IT], b_val[B_IT];
+  auto load_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int v = tid + i * NT, row = v / KV, kc = v - row * KV, k0 = kt * BK + kc * VEC;
@@ -80,19 +84,36 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_gemm_k
         }
         if (ok) val = *reinterpret_cast<const uint4*>(src + ((size_t)(a_b[i] * p.Hs + hs) * p.Ws + ws) * p.src_ld + g * p.ks_g + c);
       }
-      *reinterpret_cast<uint4*>(&As[row * C::LDK + kc * VEC]) = val;
+      a_val[i] = val;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int v = tid + i * NT;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (v < BN * KV) {
+        const int row = v / KV, kc = v - row * KV, k0 = kt * BK + kc * VEC, n = bn0 + row;
+        if (n < p.n_g && k0 < K) val = *reinterpret_cast<const uint4*>(wk + (size_t)n * K + k0);
+      }
+      b_val[i] = val;
+    }
+  };
+  if (kt_beg < kt_end) load_tile(kt_beg);
+  for (int kt = kt_beg; kt < kt_end; ++kt) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int v = tid + i * NT, row = v / KV, kc = v - row * KV;
+      *reinterpret_cast<uint4*>(&As[row * C::LDK + kc * VEC]) = a_val[i];
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int v = tid + i * NT;
       if (v < BN * KV) {
-        const int row = v / KV, kc = v - row * KV, k0 = kt * BK + kc * VEC, n = bn0 + row;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (n < p.n_g && k0 < K) val = *reinterpret_cast<const uint4*>(wk + (size_t)n * K + k0);
-        *reinterpret_cast<uint4*>(&Bs[row * C::LDK + kc * VEC]) = val;
+        const int row = v / KV, kc = v - row * KV;
+        *reinterpret_cast<uint4*>(&Bs[row * C::LDK + kc * VEC]) = b_val[i];
       }
     }
     __syncthreads();
+    if (kt + 1 < kt_end) load_tile(kt + 1);  // in flight during the MFMAs below
     tile_mma_step<C, T, false, false>(As, Bs, wm, wn, lane, acc);
     __syncthreads();
   }
