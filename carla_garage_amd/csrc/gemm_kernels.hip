@@ -489,25 +489,27 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_
     for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int hw = p.Hd * p.Wd;
-  for (long pt = p_beg; pt < p_end; pt += BK) {
+  // register-prefetched pixel loop (round 6, as conv_gemm_kernel): the loads of stage pt + BK are in flight during the MFMAs of stage pt
+  uint4 a_val[A_IT], b_val[B_IT];
+  auto load_stage = [&](long pt) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int v = tid + i * NT;
+      uint4 val = make_uint4(0, 0, 0, 0);
       if (v < BK * AV) {
         const int pk = v / AV, nc = v - pk * AV, n = bm0 + nc * VEC;
         const long pix = pt + pk;
-        uint4 val = make_uint4(0, 0, 0, 0);
         if (pix < p_end && n < p.n_g) val = *reinterpret_cast<const uint4*>(dy + (size_t)pix * p.dy_ld + g * p.n_g + n);
-        lds_store_km<T>(&As[pk * C::LDRA + nc * VEC], val);
       }
+      a_val[i] = val;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int v = tid + i * NT;
+      uint4 val = make_uint4(0, 0, 0, 0);
       if (v < BK * BV) {
         const int pk = v / BV, kc = v - pk * BV, kk0 = bn0 + kc * VEC;
         const long pix = pt + pk;
-        uint4 val = make_uint4(0, 0, 0, 0);
         if (pix < p_end && kk0 < KK) {
           const int rs = kk0 / p.ks_g, c = kk0 - rs * p.ks_g, r = rs / p.S, s = rs - r * p.S;
           const int b = (int)(pix / hw), rem = (int)(pix - (long)b * hw), hd = rem / p.Wd, wd = rem - hd * p.Wd;
@@ -515,10 +517,30 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void conv_wgrad_
           if (hs >= 0 && hs < p.Hs && ws >= 0 && ws < p.Ws)
             val = *reinterpret_cast<const uint4*>(x + ((size_t)(b * p.Hs + hs) * p.Ws + ws) * p.x_ld + g * p.ks_g + c);
         }
-        lds_store_km<T>(&Bs[pk * C::LDRB + kc * VEC], val);
+      }
+      b_val[i] = val;
+    }
+  };
+  if (p_beg < p_end) load_stage(p_beg);
+  for (long pt = p_beg; pt < p_end; pt += BK) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int v = tid + i * NT;
+      if (v < BK * AV) {
+        const int pk = v / AV, nc = v - pk * AV;
+        lds_store_km<T>(&As[pk * C::LDRA + nc * VEC], a_val[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int v = tid + i * NT;
+      if (v < BK * BV) {
+        const int pk = v / BV, kc = v - pk * BV;
+        lds_store_km<T>(&Bs[pk * C::LDRB + kc * VEC], b_val[i]);
       }
     }
     __syncthreads();
+    if (pt + BK < p_end) load_stage(pt + BK);
     tile_mma_step<C, T, true, true>(As, Bs, wm, wn, lane, acc);
     __syncthreads();
   }
