@@ -945,6 +945,78 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * TFPP_WAVE) void bgemm_kerne
     for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (p.K + BK - 1) / BK;
+  if (vec_ok) {
+    // aligned operands (round 6): register-prefetched K loop -- the 16-byte loads of tile kt + 1 are in flight during the MFMAs of tile kt
+    constexpr int A_RV = BM / VEC, B_RV = BN / VEC;
+    constexpr int AIT = A_KM ? (BK * A_RV + NT - 1) / NT : (BM * KV + NT - 1) / NT;
+    constexpr int BIT = B_KM ? (BK * B_RV + NT - 1) / NT : (BN * KV + NT - 1) / NT;
+    uint4 av[AIT], bv[BIT];
+    auto load_regs = [&](int kt) {
+      const int kb = kt * BK;
+#pragma unroll
+      for (int i = 0; i < AIT; ++i) {
+        const int v = tid + i * NT;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if constexpr (!A_KM) {
+          if (v < BM * KV) {
+            const int row = v / KV, kc = v - row * KV, k0 = kb + kc * VEC, m = bm0 + row;
+            if (m < p.M && k0 < p.K) val = *reinterpret_cast<const uint4*>(A + (size_t)m * p.lda + k0);
+          }
+        } else {
+          if (v < BK * A_RV) {
+            const int kk = v / A_RV, rc = v - kk * A_RV, k = kb + kk, m0 = bm0 + rc * VEC;
+            if (k < p.K && m0 < p.M) val = *reinterpret_cast<const uint4*>(A + (size_t)k * p.lda + m0);
+          }
+        }
+        av[i] = val;
+      }
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) {
+        const int v = tid + i * NT;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if constexpr (!B_KM) {
+          if (v < BN * KV) {
+            const int row = v / KV, kc = v - row * KV, k0 = kb + kc * VEC, n = bn0 + row;
+            if (n < p.N && k0 < p.K) val = *reinterpret_cast<const uint4*>(Bp + (size_t)n * p.ldb + k0);
+          }
+        } else {
+          if (v < BK * B_RV) {
+            const int kk = v / B_RV, rc = v - kk * B_RV, k = kb + kk, n0 = bn0 + rc * VEC;
+            if (k < p.K && n0 < p.N) val = *reinterpret_cast<const uint4*>(Bp + (size_t)k * p.ldb + n0);
+          }
+        }
+        bv[i] = val;
+      }
+    };
+    auto store_regs = [&]() {
+#pragma unroll
+      for (int i = 0; i < AIT; ++i) {
+        const int v = tid + i * NT;
+        if constexpr (!A_KM) {
+          if (v < BM * KV) { const int row = v / KV, kc = v - row * KV; *reinterpret_cast<uint4*>(&As[row * C::LDK + kc * VEC]) = av[i]; }
+        } else {
+          if (v < BK * A_RV) { const int kk = v / A_RV, rc = v - kk * A_RV; lds_store_km<T>(&As[kk * C::LDRA + rc * VEC], av[i]); }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) {
+        const int v = tid + i * NT;
+        if constexpr (!B_KM) {
+          if (v < BN * KV) { const int row = v / KV, kc = v - row * KV; *reinterpret_cast<uint4*>(&Bs[row * C::LDK + kc * VEC]) = bv[i]; }
+        } else {
+          if (v < BK * B_RV) { const int kk = v / B_RV, rc = v - kk * B_RV; lds_store_km<T>(&Bs[kk * C::LDRB + rc * VEC], bv[i]); }
+        }
+      }
+    };
+    if (nkt > 0) load_regs(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+      store_regs();
+      __syncthreads();
+      if (kt + 1 < nkt) load_regs(kt + 1);
+      tile_mma_step<C, T, A_KM, B_KM>(As, Bs, wm, wn, lane, acc);
+      __syncthreads();
+    }
+  } else
   for (int kt = 0; kt < nkt; ++kt) {
     const int kb = kt * BK;
     // ---- A tile
