@@ -1153,6 +1153,80 @@ __global__ __launch_bounds__(256) void bgemm_ks_kernel(tfpp_bgemm_params p, int 
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int nkt = (p.K + BK - 1) / BK, per = (nkt + KW - 1) / KW;
+  if (vec_ok) {
+    // aligned operands (round 6): register-prefetched loop, every wave on its own K range and its own LDS stage
+    constexpr int RVA = 32 / VEC;
+    constexpr int AIT = A_KM ? (BK * RVA + NL - 1) / NL : (32 * KV + NL - 1) / NL;
+    constexpr int BIT = B_KM ? (BK * RVA + NL - 1) / NL : (32 * KV + NL - 1) / NL;
+    uint4 av[AIT], bv[BIT];
+    auto load_regs = [&](int kt) {
+      const int kb = kt * BK;
+      const bool live = kt < nkt;
+#pragma unroll
+      for (int i = 0; i < AIT; ++i) {
+        const int v = lane + i * NL;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if constexpr (!A_KM) {
+          if (live && v < 32 * KV) {
+            const int row = v / KV, kc = v - row * KV, k0 = kb + kc * VEC, m = bm0 + row;
+            if (m < p.M && k0 < p.K) val = *reinterpret_cast<const uint4*>(A + (size_t)m * p.lda + k0);
+          }
+        } else {
+          if (live && v < BK * RVA) {
+            const int kk = v / RVA, rc = v - kk * RVA, k = kb + kk, m0 = bm0 + rc * VEC;
+            if (k < p.K && m0 < p.M) val = *reinterpret_cast<const uint4*>(A + (size_t)k * p.lda + m0);
+          }
+        }
+        av[i] = val;
+      }
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) {
+        const int v = lane + i * NL;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if constexpr (!B_KM) {
+          if (live && v < 32 * KV) {
+            const int row = v / KV, kc = v - row * KV, k0 = kb + kc * VEC, n = bn0 + row;
+            if (n < p.N && k0 < p.K) val = *reinterpret_cast<const uint4*>(Bp + (size_t)n * p.ldb + k0);
+          }
+        } else {
+          if (live && v < BK * RVA) {
+            const int kk = v / RVA, rc = v - kk * RVA, k = kb + kk, n0 = bn0 + rc * VEC;
+            if (k < p.K && n0 < p.N) val = *reinterpret_cast<const uint4*>(Bp + (size_t)k * p.ldb + n0);
+          }
+        }
+        bv[i] = val;
+      }
+    };
+    auto store_regs = [&]() {
+#pragma unroll
+      for (int i = 0; i < AIT; ++i) {
+        const int v = lane + i * NL;
+        if constexpr (!A_KM) {
+          if (v < 32 * KV) { const int row = v / KV, kc = v - row * KV; *reinterpret_cast<uint4*>(&As[row * C::LDK + kc * VEC]) = av[i]; }
+        } else {
+          if (v < BK * RVA) { const int kk = v / RVA, rc = v - kk * RVA; lds_store_km<T>(&As[kk * C::LDRA + rc * VEC], av[i]); }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) {
+        const int v = lane + i * NL;
+        if constexpr (!B_KM) {
+          if (v < 32 * KV) { const int row = v / KV, kc = v - row * KV; *reinterpret_cast<uint4*>(&Bs[row * C::LDK + kc * VEC]) = bv[i]; }
+        } else {
+          if (v < BK * RVA) { const int kk = v / RVA, rc = v - kk * RVA; lds_store_km<T>(&Bs[kk * C::LDRB + rc * VEC], bv[i]); }
+        }
+      }
+    };
+    if (per > 0) load_regs(kw * per);
+    for (int it = 0; it < per; ++it) {
+      const int kt = kw * per + it;
+      store_regs();  // (a tile past the wave's range is stored as zeros and multiplied: exact)
+      __syncthreads();
+      if (it + 1 < per) load_regs(kt + 1);
+      if (kt < nkt) tile_mma_step<C, T, A_KM, B_KM>(As, Bs, 0, 0, lane, acc);
+      __syncthreads();
+    }
+  } else
   for (int it = 0; it < per; ++it) {  // (the same trip count in every wave: the barriers below are workgroup barriers)
     const int kt = kw * per + it;
     const bool live = kt < nkt;
