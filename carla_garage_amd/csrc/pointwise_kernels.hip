@@ -732,13 +732,31 @@ extern "C" int tfpp_bilinear_fwd(const void* x, const void* base, const float* m
 }
 
 // dx[b,hi,wi,:] = sum over output pixels (ho,wo) whose stencil touches (hi,wi) of weight * dy[b,ho,wo,:] * mul[ho,wo]
-template <typename T>
+// acc[e] of the RS consecutive lanes of a group summed in slot order into slot 0 (RS = 1: nothing to do)
+template <int VEC, int RS> __device__ __forceinline__ void slot_sum(float (&acc)[VEC]) {
+  if constexpr (RS > 1) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float tot = acc[e];
+#pragma unroll
+      for (int r = 1; r < RS; ++r) tot += __shfl_down(acc[e], r, 64);
+      acc[e] = tot;
+    }
+  }
+}
+
+// RS (round 6): row slots -- RS consecutive lanes share one output chunk, lane r walks the candidate output rows oh0 + r, oh0 + r + RS, ...
+// and the RS partial sums are added in slot order by slot 0 (fixed order: deterministic).  With upsampling factors 4 / 8 a thread walked 8 / 16
+// rows one after the other, one memory latency each: the full-resolution decoder gradients (201 MB in) ran at 2 TB/s.
+template <typename T, int RS>
 __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ mul, T* __restrict__ dx, int B, int Hi, int Wi,
                                     int Ho, int Wo, int C, long dy_ld, long dx_ld) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const int CV = C / VEC;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)B * Hi * Wi * CV) return;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 >= (long)B * Hi * Wi * CV * RS) return;  // (whole groups of RS lanes: the total is a multiple of RS)
+  const int rslot = (int)(i0 % RS);
+  const long i = i0 / RS;
   const int cv = (int)(i % CV);
   long t = i / CV;
   const int wi = (int)(t % Wi); t /= Wi;
@@ -776,7 +794,7 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, const float* __res
       }
       wwv[j] = ww;
     }
-    for (int oh = oh0; oh <= oh1; ++oh) {
+    for (int oh = oh0 + rslot; oh <= oh1; oh += RS) {
       int h0, h1; float lh;
       bilin_coord(oh, Hi, Ho, h0, h1, lh);
       float wh = 0.f;
@@ -794,10 +812,11 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, const float* __res
         for (int e = 0; e < VEC; ++e) acc[e] += wt * g[e];
       }
     }
-    store_vec<T>(dx + (((size_t)b * Hi + hi) * Wi + wi) * dx_ld + cv * VEC, acc);
+    slot_sum<VEC, RS>(acc);
+    if (rslot == 0) store_vec<T>(dx + (((size_t)b * Hi + hi) * Wi + wi) * dx_ld + cv * VEC, acc);
     return;
   }
-  for (int oh = oh0; oh <= oh1; ++oh) {
+  for (int oh = oh0 + rslot; oh <= oh1; oh += RS) {
     int h0, h1; float lh;
     bilin_coord(oh, Hi, Ho, h0, h1, lh);
     float wh = 0.f;
@@ -818,19 +837,23 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, const float* __res
       for (int e = 0; e < VEC; ++e) acc[e] += wt * g[e];
     }
   }
-  store_vec<T>(dx + (((size_t)b * Hi + hi) * Wi + wi) * dx_ld + cv * VEC, acc);
+  slot_sum<VEC, RS>(acc);
+  if (rslot == 0) store_vec<T>(dx + (((size_t)b * Hi + hi) * Wi + wi) * dx_ld + cv * VEC, acc);
 }
 
 extern "C" int tfpp_bilinear_bwd(const void* dy, const float* mul, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int64_t dy_ld,
                                  int64_t dx_ld, int dtype, void* stream) {
   if (!dy || !dx) return TFPP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const bool rs4 = Ho >= 4 * Hi;  // >= 8 candidate rows per input pixel: four row slots per output chunk
   if (dtype == TFPP_F32) {
     if (C % 4 || dy_ld % 4 || dx_ld % 4) return TFPP_EINVAL;
-    hipLaunchKernelGGL(bilinear_bwd_kernel<float>, grid1d((long)B * Hi * Wi * (C / 4)), dim3(PW_THREADS), 0, st, (const float*)dy, mul, (float*)dx, B, Hi, Wi, Ho, Wo, C, (long)dy_ld, (long)dx_ld);
+    if (rs4) hipLaunchKernelGGL((bilinear_bwd_kernel<float, 4>), grid1d((long)B * Hi * Wi * (C / 4) * 4), dim3(PW_THREADS), 0, st, (const float*)dy, mul, (float*)dx, B, Hi, Wi, Ho, Wo, C, (long)dy_ld, (long)dx_ld);
+    else hipLaunchKernelGGL((bilinear_bwd_kernel<float, 1>), grid1d((long)B * Hi * Wi * (C / 4)), dim3(PW_THREADS), 0, st, (const float*)dy, mul, (float*)dx, B, Hi, Wi, Ho, Wo, C, (long)dy_ld, (long)dx_ld);
   } else {
     if (C % 8 || dy_ld % 8 || dx_ld % 8) return TFPP_EINVAL;
-    hipLaunchKernelGGL(bilinear_bwd_kernel<bf16_t>, grid1d((long)B * Hi * Wi * (C / 8)), dim3(PW_THREADS), 0, st, (const bf16_t*)dy, mul, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, (long)dy_ld, (long)dx_ld);
+    if (rs4) hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, 4>), grid1d((long)B * Hi * Wi * (C / 8) * 4), dim3(PW_THREADS), 0, st, (const bf16_t*)dy, mul, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, (long)dy_ld, (long)dx_ld);
+    else hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, 1>), grid1d((long)B * Hi * Wi * (C / 8)), dim3(PW_THREADS), 0, st, (const bf16_t*)dy, mul, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, (long)dy_ld, (long)dx_ld);
   }
   TFPP_CHECK_LAUNCH();
   return 0;
